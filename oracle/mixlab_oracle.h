@@ -1,0 +1,167 @@
+/*
+ * mixlab_oracle.h -- CPU restatement of haileys/mixlab's per-tick module-graph hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library, and only as the checker / the timed CPU
+ * baseline.  Nothing under mixlab_amd/ links, imports or calls it.
+ *
+ * The reference is Rust and cannot be compiled in this image (no rustc/cargo), so every function
+ * below restates one reference function and cites the file:line it follows (paths relative to the
+ * reference checkout).  Build flags that matter: -O2 -ffp-contract=off, no fast-math -- Rust
+ * evaluates f64 expressions exactly as written with no FMA contraction.
+ *
+ * Parity pinning:
+ *   - orc_eq_three_run is pinned bit-exactly by the reference's own golden pair
+ *     fixtures/module/eq_three/chronos{,-eq}.f32.raw (src/module/eq_three.rs:150-167); a causal
+ *     prefix of that pair is committed under tests/golden/.
+ *   - every other audio module and the VideoMixer cross-fade have NO reference test: the source
+ *     text is the only spec ("parity unpinned by reference tests").
+ *   - the bicubic scaler stands in for libswscale (third-party C, ffmpeg-dev 0.3.8 git rev
+ *     372167ae..., absent from the reference tree): build-specified, parity unpinned.
+ *   - YUV420->RGBA has no reference counterpart at all: build-specified, parity unpinned.
+ */
+#ifndef MIXLAB_ORACLE_H
+#define MIXLAB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- module kinds (same numbering as include/mixlab_gpu.h so tests can share descriptions) ---- */
+enum {
+    ORC_KIND_AMPLIFIER = 0,
+    ORC_KIND_ENVELOPE = 1,
+    ORC_KIND_EQ_THREE = 2,
+    ORC_KIND_FM_SINE = 3,
+    ORC_KIND_MIXER = 4,
+    ORC_KIND_OSCILLATOR = 5,
+    ORC_KIND_PLOTTER = 6,
+    ORC_KIND_STEREO_PANNER = 7,
+    ORC_KIND_STEREO_SPLITTER = 8,
+    ORC_KIND_TRIGGER = 9,
+    ORC_KIND_VIDEO_MIXER = 10,
+    ORC_KIND_SOURCE_MONO = 11,   /* host-fed port: stands in for StreamInput / MediaSource audio */
+    ORC_KIND_SOURCE_STEREO = 12,
+    ORC_KIND_COUNT = 13
+};
+
+/* protocol/src/lib.rs:233-241 (bincode variant order) */
+enum { ORC_WAVE_ON = 0, ORC_WAVE_OFF = 1, ORC_WAVE_SINE = 2, ORC_WAVE_SQUARE = 3, ORC_WAVE_TRIANGLE = 4, ORC_WAVE_SAW = 5 };
+
+/* ---- parameter structs: C mirrors of protocol/src/lib.rs ---- */
+typedef struct { double gain_db; double fader; uint8_t cue; uint8_t _pad[7]; } orc_mixer_channel_params; /* :342-347 */
+typedef struct { double gain_lo_db, gain_mid_db, gain_hi_db; } orc_eq_three_params;                    /* :285-290 */
+typedef struct { double attack_ms, decay_ms, sustain_amplitude, release_ms; } orc_envelope_params;     /* :310-316 */
+typedef struct { double amplitude, mod_depth; } orc_amplifier_params;                                  /* :298-302 */
+typedef struct { double freq; uint32_t waveform; uint32_t _pad; } orc_oscillator_params;               /* :243-247 */
+typedef struct { double freq_lo, freq_hi; } orc_fm_sine_params;                                        /* :292-296 */
+typedef struct { uint32_t gate_open; } orc_trigger_params;                                             /* :304-308 */
+
+/* ---- stateless helpers ---- */
+double orc_decibel_to_linear(double db);                  /* protocol/src/lib.rs:469-471 */
+double orc_lowpass_coeff(double freq, double sample_rate); /* src/module/eq_three.rs:113-115 */
+
+/* ---- audio modules, one call == one ModuleT::run_tick body ---- */
+
+/* src/module/mixer.rs:46-71. inputs[ch] may be NULL (Disconnected => zero buffer, io.rs:45-52). */
+void orc_mixer_run(const orc_mixer_channel_params* ch, size_t n_ch, const float* const* inputs,
+                   float* master, float* cue, size_t len);
+
+/* src/module/eq_three.rs:13-26,58-89,100-125 */
+typedef struct { double lo_f, hi_f; double lo[4], hi[4]; double history[3]; } orc_eq_three;
+void orc_eq_three_init(orc_eq_three* s, double sample_rate);
+void orc_eq_three_run(orc_eq_three* s, const orc_eq_three_params* p, const float* in, float* out, size_t n);
+
+/* src/module/envelope.rs:8-58,91-120 */
+typedef struct { uint32_t tag; /* 0 Initial, 1 TriggerOn, 2 TriggerOff */ uint32_t _pad; uint64_t seq; double off_amplitude; } orc_envelope;
+void orc_envelope_init(orc_envelope* s);
+void orc_envelope_run(orc_envelope* s, const orc_envelope_params* p, double sample_rate, uint64_t t,
+                      const float* gate, float* out, size_t n);
+
+/* src/module/amplifier.rs:38-60,71-73. control == NULL means Disconnected (mod value 1.0). */
+void orc_amplifier_run(const orc_amplifier_params* p, const float* in_stereo, const float* control,
+                       float* out_stereo, size_t stereo_len);
+
+/* src/module/oscillator.rs:15-37,65-92 */
+void orc_oscillator_run(const orc_oscillator_params* p, double sample_rate, uint64_t t,
+                        float* mono, float* stereo, size_t n);
+
+/* src/module/fm_sine.rs:37-56 */
+void orc_fm_sine_run(const orc_fm_sine_params* p, double sample_rate, uint64_t t,
+                     const float* in_mono, float* out_stereo, size_t n);
+
+/* src/module/trigger.rs:35-48 */
+void orc_trigger_run(const orc_trigger_params* p, float* out, size_t n);
+
+/* src/module/stereo_panner.rs:30-41, stereo_splitter.rs:33-47 */
+void orc_stereo_panner_run(const float* l, const float* r, float* out_stereo, size_t n);
+void orc_stereo_splitter_run(const float* in_stereo, float* l, float* r, size_t n);
+
+/* src/module/plotter.rs:37-56. Returns 1 and fills left/right when an indication fires. */
+typedef struct { uint64_t count; } orc_plotter;
+int orc_plotter_run(orc_plotter* s, const float* in_stereo /* NULL = disconnected */, float* left, float* right, size_t n);
+
+/* ---- graph runner: restates Engine::run_tick (src/engine.rs:400-510) ---- */
+typedef struct { uint32_t kind; uint32_t params_len; const void* params; } orc_node;
+typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } orc_edge;
+typedef struct orc_graph orc_graph;
+
+/* sample_rate/ticks_per_second are compile-time 44100/60 in the reference (src/engine.rs:52-55);
+ * they are parameters here only so the 48 kHz performance configuration has a CPU baseline. */
+orc_graph* orc_graph_build(const orc_node* nodes, size_t n_nodes, const orc_edge* edges, size_t n_edges,
+                           uint32_t sample_rate, uint32_t ticks_per_second);
+void orc_graph_destroy(orc_graph* g);
+size_t orc_graph_samples_per_tick(const orc_graph* g);
+/* host-fed source ports: pointer is read during run_tick (SPT mono / 2*SPT stereo floats) */
+int orc_graph_set_source(orc_graph* g, uint32_t node, const float* samples);
+/* one Engine::run_tick: fresh zeroed outputs, topological order, t = tick * SPT */
+int orc_graph_run_tick(orc_graph* g, uint64_t tick);
+/* borrow the output buffer a port produced in the last tick (NULL if bad ids) */
+const float* orc_graph_output(const orc_graph* g, uint32_t node, uint32_t port, size_t* len);
+/* plotter indication of the last tick: returns 1 if it fired, copies SPT floats to each */
+int orc_graph_plotter_indication(const orc_graph* g, uint32_t node, float* left, float* right);
+/* number of nodes in run order; order[i] filled */
+size_t orc_graph_run_order(const orc_graph* g, uint32_t* order, size_t cap);
+
+/* ---- video: planar yuv420p 8-bit ---- */
+typedef struct {
+    uint32_t width, height;     /* luma dimensions (codec/src/ffmpeg/frame.rs:180-186) */
+    uint8_t* data[3];           /* Y, U, V plane bases (frame.rs:188-197) */
+    int32_t stride[3];          /* bytes per row, multiple of 32 (video_mixer.rs:196-201) */
+} orc_frame;
+
+/* codec/src/ffmpeg/frame.rs:76-138: Y=0x00, U=V=0x80 over stride*(h-1)+w bytes of each plane */
+void orc_frame_blank(orc_frame* f);
+/* src/module/video_mixer.rs:168 */
+uint8_t orc_crossfade_factor(double fader);
+/* src/module/video_mixer.rs:151-239: a/b NULL => read the (blank) output plane itself */
+void orc_video_crossfade(orc_frame* out, const orc_frame* a, const orc_frame* b, uint8_t fade);
+/* src/module/video_mixer.rs:276-297 */
+void orc_unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t* w, uint32_t* h);
+/* src/video/encode.rs:354-374 */
+typedef struct { uint32_t scaled_w, scaled_h, letterbox_x, letterbox_y; } orc_scale_geometry;
+void orc_scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, orc_scale_geometry* g);
+/* BUILD-SPECIFIED stand-in for sws_scale(SWS_BICUBIC) (codec/src/ffmpeg/scale.rs:16-39,49-70):
+ * separable Catmull-Rom-family cubic (B=0,C=0.6), 14-bit coefficients, see DESIGN.md.  Scales one
+ * plane. parity unpinned. */
+void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
+                             uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh);
+/* src/video/encode.rs:338-397: identity when sizes match (copies), else blank + scale into letterbox */
+void orc_dynamic_scale(const orc_frame* in, orc_frame* out);
+/* BUILD-SPECIFIED (no reference counterpart): BT.709 limited-range integer YUV420P -> RGBA8,
+ * nearest chroma, then optional 3x4 colour matrix in Q12. parity unpinned. */
+void orc_yuv420_to_rgba(const orc_frame* in, uint8_t* rgba, int32_t rgba_stride, const int32_t* matrix_q12 /* 12 or NULL */);
+
+/* rational time helpers used by VideoMixer frame expiry (util/src/time.rs:9-75) */
+typedef struct { int64_t num, den; } orc_rational;
+orc_rational orc_rational_new(int64_t num, int64_t den);
+orc_rational orc_rational_add(orc_rational a, orc_rational b);
+int orc_rational_cmp(orc_rational a, orc_rational b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,223 @@
+/*
+ * mixlab_oracle_video.c -- CPU restatement of the reference's pixel path.
+ * TEST INFRASTRUCTURE ONLY (see mixlab_oracle.h).
+ *
+ * Reference-following: blank fill, cross-fade, picture-settings unification, scaler geometry,
+ * rational frame-expiry arithmetic.  Build-specified (no reference arithmetic to follow):
+ * the bicubic plane scaler (libswscale is third-party C outside the reference tree) and
+ * YUV420P->RGBA.  Integer work throughout: results are compared bit-exactly.
+ */
+#include "mixlab_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* AvFrame::blank, codec/src/ffmpeg/frame.rs:76-138.
+ * size = stride * (height - 1) + step * width  (frame.rs:126), byte = 0x80 for chroma else 0. */
+void orc_frame_blank(orc_frame* f) {
+    for (int plane = 0; plane < 3; plane++) {
+        int is_chroma = plane > 0;                                  /* frame.rs:103-106 */
+        size_t width = is_chroma ? (f->width >> 1) : f->width;      /* frame.rs:108-112, log2_chroma_w = 1 */
+        size_t height = is_chroma ? (f->height >> 1) : f->height;   /* frame.rs:114-118 */
+        size_t stride = (size_t)f->stride[plane];
+        size_t size = stride * (height ? height - 1 : 0) + width;   /* saturating_sub(1) */
+        memset(f->data[plane], is_chroma ? 0x80 : 0x00, size);
+    }
+}
+
+/* src/module/video_mixer.rs:168  `(self.params.fader * 255.0) as u8` -- Rust float->int casts
+ * saturate and truncate toward zero; NaN -> 0. */
+uint8_t orc_crossfade_factor(double fader) {
+    double v = fader * 255.0;
+    if (!(v == v)) return 0;
+    if (v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+/* fade_line, src/module/video_mixer.rs:211-235: 32-byte blocks, u16 lanes,
+ * out = (a*fade + b*(255-fade)) / 255 (integer division), runs while out < out+len. */
+static void orc_fade_line(uint8_t* out, const uint8_t* a, const uint8_t* b, size_t len, uint8_t fade) {
+    uint16_t a_fade = fade, b_fade = (uint16_t)(255 - fade);
+    uint8_t* end = out + len;
+    while (out < end) {
+        for (int k = 0; k < 32; k++) {
+            uint16_t a_comp = (uint16_t)((uint16_t)a[k] * a_fade);
+            uint16_t b_comp = (uint16_t)((uint16_t)b[k] * b_fade);
+            out[k] = (uint8_t)((uint16_t)(a_comp + b_comp) / 255);
+        }
+        a += 32; b += 32; out += 32;
+    }
+}
+
+/* src/module/video_mixer.rs:151-239 */
+void orc_video_crossfade(orc_frame* out, const orc_frame* a, const orc_frame* b, uint8_t fade) {
+    for (int plane = 0; plane < 3; plane++) {
+        size_t width = plane ? (out->width >> 1) : out->width;     /* video_mixer.rs:176 */
+        size_t height = plane ? (out->height >> 1) : out->height;  /* video_mixer.rs:177 */
+        const uint8_t* a_ptr = a ? a->data[plane] : out->data[plane];           /* :180-183 */
+        size_t a_ls = a ? (size_t)a->stride[plane] : (size_t)out->stride[plane];
+        const uint8_t* b_ptr = b ? b->data[plane] : out->data[plane];           /* :185-188 */
+        size_t b_ls = b ? (size_t)b->stride[plane] : (size_t)out->stride[plane];
+        uint8_t* o_ptr = out->data[plane];
+        size_t o_ls = (size_t)out->stride[plane];
+        for (size_t y = 0; y < height; y++)
+            orc_fade_line(o_ptr + y * o_ls, a_ptr + y * a_ls, b_ptr + y * b_ls, width, fade);
+    }
+}
+
+/* unify_picture_settings, src/module/video_mixer.rs:276-297 (yuv420p: both chroma shifts = 1) */
+void orc_unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t* w, uint32_t* h) {
+    uint32_t width = aw > bw ? aw : bw, height = ah > bh ? ah : bh;
+    *w = (width + 1u) & ~1u;
+    *h = (height + 1u) & ~1u;
+}
+
+/* DynamicScaler::scale geometry, src/video/encode.rs:354-374.
+ * Ratio<usize> comparisons are exact; `(scale_factor * n).to_integer()` truncates. */
+void orc_scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, orc_scale_geometry* g) {
+    /* min(out_w/in_w, out_h/in_h) by cross-multiplication */
+    uint64_t num, den;
+    if ((uint64_t)out_w * in_h <= (uint64_t)out_h * in_w) { num = out_w; den = in_w; }
+    else { num = out_h; den = in_h; }
+    uint32_t sw = (uint32_t)((num * in_w) / den) & ~1u;   /* align_horizontal, pixfmt.rs:104-106 */
+    uint32_t sh = (uint32_t)((num * in_h) / den) & ~1u;   /* align_vertical, pixfmt.rs:108-110 */
+    g->scaled_w = sw; g->scaled_h = sh;
+    g->letterbox_x = ((out_w - sw) / 2) & ~1u;            /* encode.rs:373 */
+    g->letterbox_y = ((out_h - sh) / 2) & ~1u;            /* encode.rs:374 */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* BUILD-SPECIFIED bicubic (stand-in for libswscale SWS_BICUBIC, codec/src/ffmpeg/scale.rs:23-27).
+ * Spec (DESIGN.md "Scaler"):
+ *   pos_q16(o) = floor(((2o+1) * src * 65536) / (2 * dst)) - 32768 ; first tap = (pos>>16) - 1 ;
+ *   d = pos & 0xffff ; taps at distances 1+d, d, 1-d, 2-d of the cubic with B=0, C=0.6:
+ *     |x|<1 : (7x^3 - 12x^2 + 5)/5         1<=|x|<2 : (-3x^3 + 15x^2 - 24x + 12)/5
+ *   coefficients rounded to Q14 (round-half-up, floor division), the larger of taps 1/2 (tie: 1)
+ *   absorbs the residual so each set sums to 16384; source taps clamp to the plane edge.
+ *   H pass: t = (sum_k hc[k]*S[..] + 64) >> 7 (arithmetic shift, int32)
+ *   V pass: D = clip_u8((sum_k vc[k]*t[..] + (1<<20)) >> 21)
+ */
+static int64_t floordiv(int64_t a, int64_t b) { /* b > 0 */
+    int64_t q = a / b, r = a % b;
+    return (r != 0 && r < 0) ? q - 1 : q;
+}
+static int32_t cubic_q14(int64_t X /* |x| in Q16, 0..131072 */) {
+    int64_t num;
+    if (X < 65536) num = 7 * X * X * X - 12 * 65536 * X * X + 5 * ((int64_t)1 << 48);
+    else if (X < 131072) num = -3 * X * X * X + 15 * 65536 * X * X - 24 * ((int64_t)1 << 32) * X + 12 * ((int64_t)1 << 48);
+    else return 0;
+    int64_t den = 5 * ((int64_t)1 << 34);
+    return (int32_t)floordiv(2 * num + den, 2 * den);
+}
+static void bicubic_taps(uint32_t o, uint32_t src, uint32_t dst, int32_t* first, int32_t c[4]) {
+    int64_t pos = floordiv((int64_t)(2 * (int64_t)o + 1) * src * 65536, 2 * (int64_t)dst) - 32768;
+    int64_t ip = pos >> 16; /* arithmetic shift = floor */
+    int64_t d = pos & 0xffff;
+    *first = (int32_t)ip - 1;
+    c[0] = cubic_q14(65536 + d);
+    c[1] = cubic_q14(d);
+    c[2] = cubic_q14(65536 - d);
+    c[3] = cubic_q14(131072 - d);
+    int32_t resid = 16384 - (c[0] + c[1] + c[2] + c[3]);
+    if (c[2] > c[1]) c[2] += resid; else c[1] += resid;
+}
+static inline int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
+                             uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh) {
+    int32_t* hfirst = (int32_t*)malloc(sizeof(int32_t) * dw);
+    int32_t* hc = (int32_t*)malloc(sizeof(int32_t) * 4 * dw);
+    for (uint32_t x = 0; x < dw; x++) bicubic_taps(x, sw, dw, &hfirst[x], &hc[4 * x]);
+    int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * (size_t)dw * sh);
+    for (uint32_t y = 0; y < sh; y++) {
+        const uint8_t* row = src + (size_t)y * src_stride;
+        for (uint32_t x = 0; x < dw; x++) {
+            int32_t acc = 0;
+            for (int k = 0; k < 4; k++) acc += hc[4 * x + k] * (int32_t)row[clampi(hfirst[x] + k, 0, (int32_t)sw - 1)];
+            tmp[(size_t)y * dw + x] = (acc + 64) >> 7;
+        }
+    }
+    for (uint32_t y = 0; y < dh; y++) {
+        int32_t vfirst, vc[4];
+        bicubic_taps(y, sh, dh, &vfirst, vc);
+        uint8_t* drow = dst + (size_t)y * dst_stride;
+        for (uint32_t x = 0; x < dw; x++) {
+            int32_t acc = 0;
+            for (int k = 0; k < 4; k++) acc += vc[k] * tmp[(size_t)clampi(vfirst + k, 0, (int32_t)sh - 1) * dw + x];
+            drow[x] = (uint8_t)clampi((acc + (1 << 20)) >> 21, 0, 255);
+        }
+    }
+    free(hfirst); free(hc); free(tmp);
+}
+
+/* DynamicScaler::scale, src/video/encode.rs:338-397: equal settings => the frame itself (here: a
+ * copy of the visible area); otherwise blank output (encode.rs:382) and scale into the letterboxed
+ * sub-frame (encode.rs:386-392; sub-frame plane offsets, frame.rs:253-278). */
+void orc_dynamic_scale(const orc_frame* in, orc_frame* out) {
+    if (in->width == out->width && in->height == out->height) {
+        for (int p = 0; p < 3; p++) {
+            uint32_t w = p ? in->width >> 1 : in->width, h = p ? in->height >> 1 : in->height;
+            for (uint32_t y = 0; y < h; y++)
+                memcpy(out->data[p] + (size_t)y * out->stride[p], in->data[p] + (size_t)y * in->stride[p], w);
+        }
+        return;
+    }
+    orc_scale_geometry g;
+    orc_scaler_geometry(in->width, in->height, out->width, out->height, &g);
+    orc_frame_blank(out);
+    for (int p = 0; p < 3; p++) {
+        uint32_t sh_ = p ? 1 : 0;
+        uint8_t* dst = out->data[p] + (size_t)(g.letterbox_y >> sh_) * out->stride[p] + (g.letterbox_x >> sh_);
+        orc_scale_plane_bicubic(in->data[p], in->stride[p], in->width >> sh_, in->height >> sh_,
+                                dst, out->stride[p], g.scaled_w >> sh_, g.scaled_h >> sh_);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* BUILD-SPECIFIED: BT.709 limited-range YUV420P -> RGBA8 (nearest chroma), optional Q12 3x4 matrix.
+ *   C=Y-16 D=U-128 E=V-128
+ *   R=clip((298C + 459E + 128)>>8) G=clip((298C - 55D - 136E + 128)>>8) B=clip((298C + 541D + 128)>>8) A=255
+ *   matrix: out_c = clip((m[c][0]R + m[c][1]G + m[c][2]B + m[c][3] + 2048) >> 12) */
+void orc_yuv420_to_rgba(const orc_frame* in, uint8_t* rgba, int32_t rgba_stride, const int32_t* m) {
+    for (uint32_t y = 0; y < in->height; y++) {
+        const uint8_t* yr = in->data[0] + (size_t)y * in->stride[0];
+        const uint8_t* ur = in->data[1] + (size_t)(y >> 1) * in->stride[1];
+        const uint8_t* vr = in->data[2] + (size_t)(y >> 1) * in->stride[2];
+        uint8_t* o = rgba + (size_t)y * rgba_stride;
+        for (uint32_t x = 0; x < in->width; x++) {
+            int32_t C = (int32_t)yr[x] - 16, D = (int32_t)ur[x >> 1] - 128, E = (int32_t)vr[x >> 1] - 128;
+            int32_t R = clampi((298 * C + 459 * E + 128) >> 8, 0, 255);
+            int32_t G = clampi((298 * C - 55 * D - 136 * E + 128) >> 8, 0, 255);
+            int32_t B = clampi((298 * C + 541 * D + 128) >> 8, 0, 255);
+            if (m) {
+                int32_t r2 = clampi((m[0] * R + m[1] * G + m[2] * B + m[3] + 2048) >> 12, 0, 255);
+                int32_t g2 = clampi((m[4] * R + m[5] * G + m[6] * B + m[7] + 2048) >> 12, 0, 255);
+                int32_t b2 = clampi((m[8] * R + m[9] * G + m[10] * B + m[11] + 2048) >> 12, 0, 255);
+                R = r2; G = g2; B = b2;
+            }
+            o[4 * x + 0] = (uint8_t)R; o[4 * x + 1] = (uint8_t)G; o[4 * x + 2] = (uint8_t)B; o[4 * x + 3] = 255;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rational64 arithmetic as used by MediaTime / MediaDuration (util/src/time.rs:9-75): always kept
+ * reduced with a positive denominator, like num_rational::Ratio::new. */
+static int64_t gcd64(int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { int64_t t = a % b; a = b; b = t; } return a ? a : 1; }
+orc_rational orc_rational_new(int64_t num, int64_t den) {
+    if (den < 0) { num = -num; den = -den; }
+    int64_t g = gcd64(num, den);
+    orc_rational r = { num / g, den / g };
+    return r;
+}
+orc_rational orc_rational_add(orc_rational a, orc_rational b) {
+    int64_t g = gcd64(a.den, b.den);
+    int64_t lcm = a.den / g * b.den;
+    return orc_rational_new(a.num * (lcm / a.den) + b.num * (lcm / b.den), lcm);
+}
+int orc_rational_cmp(orc_rational a, orc_rational b) {
+    __int128 l = (__int128)a.num * b.den, r = (__int128)b.num * a.den;
+    return l < r ? -1 : (l > r ? 1 : 0);
+}
