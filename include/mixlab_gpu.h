@@ -1,0 +1,168 @@
+/*
+ * mixlab_gpu.h -- C ABI of the MI355X-native tick engine for haileys/mixlab's per-tick module graph.
+ *
+ * The reference has no C ABI: modules are Rust types behind `trait ModuleT`
+ * (src/module/mod.rs:7-19) dispatched through `DynModuleHostT` (src/engine/module.rs:88-94) by
+ * `Engine::run_tick` (src/engine.rs:400-510).  This header is the thin extern-"C" surface a Rust
+ * `GpuModule: ModuleT` adapter (or a replacement for Engine::run_tick's inner loop) binds with an
+ * `extern "C"` block -- see INTEGRATION.md for the Rust side.  Plain pointers and sizes only.
+ *
+ * Error convention follows the reference's own extern-"C" boundary (FFmpeg I/O callbacks,
+ * codec/src/ffmpeg.rs:25-26, codec/src/ffmpeg/ioctx.rs:51-67,136-152): never unwind across the
+ * boundary, return a negative int sentinel, stash the message, let the caller fetch it
+ * (mx_last_error) and re-raise on its side.
+ *
+ * Threading: like Engine::run_tick (one engine thread, src/engine.rs:78-93) a graph/module handle
+ * is not re-entrant; different handles may be used from different threads.
+ */
+#ifndef MIXLAB_GPU_H
+#define MIXLAB_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MX_ABI_VERSION 1u
+
+/* ---- status codes (0 ok, <0 error; cf. MIXLAB_IOCTX_ERROR / MIXLAB_IOCTX_PANIC) ---- */
+enum {
+    MX_OK = 0,
+    MX_ERR_INVALID = -1,  /* bad argument / id out of range */
+    MX_ERR_TYPE = -2,     /* port line-type mismatch: the reference panics (src/engine/io.rs:40-41,49-50) or refuses the connection (src/engine/workspace.rs:97-114) */
+    MX_ERR_DEVICE = -3,   /* HIP runtime error */
+    MX_ERR_NOMEM = -4,
+    MX_ERR_INTERNAL = -5  /* C++ exception caught at the boundary ("panic") */
+};
+
+/* ---- line types: protocol LineType, src/engine/io.rs:19-24 ---- */
+typedef enum { MX_DISCONNECTED = 0, MX_MONO = 1, MX_STEREO = 2, MX_VIDEO = 3 } mx_line;
+
+/* ---- module kinds: the DSP members of enumerate_modules! (src/module/mod.rs:27-49) ---- */
+enum {
+    MX_KIND_AMPLIFIER = 0,        /* src/module/amplifier.rs       in: Stereo, Mono(control)  out: Stereo */
+    MX_KIND_ENVELOPE = 1,         /* src/module/envelope.rs        in: Mono(gate)             out: Mono */
+    MX_KIND_EQ_THREE = 2,         /* src/module/eq_three.rs        in: Mono                   out: Mono */
+    MX_KIND_FM_SINE = 3,          /* src/module/fm_sine.rs         in: Mono                   out: Stereo */
+    MX_KIND_MIXER = 4,            /* src/module/mixer.rs           in: Stereo x N             out: Stereo Master, Stereo Cue */
+    MX_KIND_OSCILLATOR = 5,       /* src/module/oscillator.rs      in: -                      out: Mono, Stereo */
+    MX_KIND_PLOTTER = 6,          /* src/module/plotter.rs         in: Stereo                 out: - (indication) */
+    MX_KIND_STEREO_PANNER = 7,    /* src/module/stereo_panner.rs   in: Mono L, Mono R         out: Stereo */
+    MX_KIND_STEREO_SPLITTER = 8,  /* src/module/stereo_splitter.rs in: Stereo                 out: Mono L, Mono R */
+    MX_KIND_TRIGGER = 9,          /* src/module/trigger.rs         in: -                      out: Mono */
+    MX_KIND_VIDEO_MIXER = 10,     /* src/module/video_mixer.rs     in: Video x 4              out: Video Output, A, B */
+    MX_KIND_SOURCE_MONO = 11,     /* host/device-fed port; stands in for the audio outputs of the I/O modules */
+    MX_KIND_SOURCE_STEREO = 12,   /*   (StreamInput src/module/stream_input.rs:72-147, MediaSource media_source.rs:93-126) */
+    MX_KIND_COUNT = 13
+};
+
+/* protocol/src/lib.rs:233-241, bincode variant order */
+enum { MX_WAVE_ON = 0, MX_WAVE_OFF = 1, MX_WAVE_SINE = 2, MX_WAVE_SQUARE = 3, MX_WAVE_TRIANGLE = 4, MX_WAVE_SAW = 5 };
+
+/* ---- parameter structs: #[repr(C)] mirrors of protocol/src/lib.rs ---- */
+typedef struct { double gain_db; double fader; uint8_t cue; uint8_t _pad[7]; } mx_mixer_channel_params; /* MixerChannelParams :342-347; MixerParams = array of these (params_len / sizeof) :329-332 */
+typedef struct { double gain_lo_db, gain_mid_db, gain_hi_db; } mx_eq_three_params;                     /* EqThreeParams :285-290 (Decibel = f64 dB :455-456) */
+typedef struct { double attack_ms, decay_ms, sustain_amplitude, release_ms; } mx_envelope_params;      /* EnvelopeParams :310-316 */
+typedef struct { double amplitude, mod_depth; } mx_amplifier_params;                                   /* AmplifierParams :298-302 */
+typedef struct { double freq; uint32_t waveform; uint32_t _pad; } mx_oscillator_params;                /* OscillatorParams :243-247 */
+typedef struct { double freq_lo, freq_hi; } mx_fm_sine_params;                                         /* FmSineParams :292-296 */
+typedef struct { uint32_t gate_open; } mx_trigger_params;                                              /* GateState :304-308 */
+typedef struct { int32_t a, b; /* -1 = None */ double fader; } mx_video_mixer_params;                  /* VideoMixerParams :405-410 */
+
+/* ---- graph description ---- */
+typedef struct { uint32_t kind; uint32_t params_len; const void* params; } mx_node;
+typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /* workspace.connections: InputId -> OutputId */
+
+#define MX_FLAG_EQ_EXACT 1u  /* EqThree: strictly sequential recurrence (bit-exact vs the reference order);
+                                default is the time-parallel chunked scan (<= 1 ULP f32) */
+
+typedef struct {
+    uint32_t sample_rate;        /* 0 => 44100 (src/engine.rs:53) */
+    uint32_t ticks_per_second;   /* 0 => 60    (src/engine.rs:54) */
+    uint32_t max_ticks_per_run;  /* 0 => 1; port buffers hold this many consecutive ticks */
+    uint32_t flags;              /* MX_FLAG_* */
+    int32_t device;              /* HIP device ordinal, -1 => current */
+    int32_t _pad;
+    void* stream;                /* hipStream_t to launch on; NULL => the graph creates its own */
+} mx_graph_opts;
+
+typedef struct mx_graph mx_graph;
+
+/* Thread-local message for the last failing call on this thread (ioctx "stash then report"). */
+const char* mx_last_error(void);
+uint32_t mx_abi_version(void);
+/* Number of visible HIP devices, or <0. */
+int mx_device_count(void);
+
+/* Freeze a topology (the state Engine::run_tick reads from Workspace, src/engine/workspace.rs:13-19)
+ * and allocate every port buffer in one HBM slab.  Connections are type-checked like
+ * Workspace::connect (workspace.rs:97-114): mismatch => MX_ERR_TYPE. */
+int mx_graph_build(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t n_edges,
+                   const mx_graph_opts* opts, mx_graph** out);
+void mx_graph_destroy(mx_graph* g);
+
+int mx_graph_samples_per_tick(const mx_graph* g, size_t* spt);                 /* SAMPLES_PER_TICK, src/engine.rs:55 */
+int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n); /* DFS order of src/engine.rs:421-457 */
+
+/* ModuleT::update (src/module/mod.rs:16): replace one node's params between ticks. */
+int mx_graph_update_params(mx_graph* g, uint32_t node, const void* params, size_t params_len);
+
+/* Feed a SOURCE_* node: n_ticks consecutive tick buffers (SPT mono / 2*SPT interleaved stereo f32). */
+int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks);
+/* Or bind an external device buffer holding max_ticks_per_run tick buffers (read-only, caller-owned). */
+int mx_graph_bind_source_device(mx_graph* g, uint32_t node, const void* device_ptr);
+
+/* n_ticks consecutive Engine::run_tick calls (src/engine.rs:400-510) in one submission:
+ * tick k of the run uses t = (first_tick + k) * SPT (src/engine.rs:490).  Asynchronous on the
+ * graph's stream.  n_ticks <= max_ticks_per_run. */
+int mx_graph_run_ticks(mx_graph* g, uint64_t first_tick, uint32_t n_ticks);
+int mx_graph_sync(mx_graph* g);
+
+/* Copy an output port's buffers of the last run to the host (synchronises the stream). */
+int mx_graph_read_output(mx_graph* g, uint32_t node, uint32_t port, float* host_samples, size_t n_ticks);
+/* Device pointer + per-tick length (floats) of an output port (for zero-copy consumers / RCCL). */
+int mx_graph_output_device_ptr(mx_graph* g, uint32_t node, uint32_t port, void** device_ptr, size_t* floats_per_tick);
+
+/* Plotter indication (src/module/plotter.rs:37-56) for tick `tick_in_run` of the last run:
+ * *fired = 1 and SPT floats in each of left/right when it fired (every 6th call, input connected). */
+int mx_graph_read_plotter(mx_graph* g, uint32_t node, uint32_t tick_in_run, float* left, float* right, int* fired);
+
+/* Per-kind device time of the last profiled run (the PerformanceInfo analogue,
+ * src/engine/timing.rs:86-94): run once with hipEvents around every launch group. */
+int mx_graph_profile_run(mx_graph* g, uint64_t first_tick, uint32_t n_ticks, float* ms_by_kind /* MX_KIND_COUNT */, float* ms_total);
+
+/* ---- per-module compatibility path: one ModuleT instance, host pointers in and out ---- */
+typedef struct {
+    uint32_t width, height;          /* luma size; yuv420p 8-bit planar (always, src/module/video_mixer.rs:282-283) */
+    uint8_t* data[3];                /* AVFrame.data   (codec/src/ffmpeg/frame.rs:188-197) */
+    int32_t stride[3];               /* AVFrame.linesize */
+    int64_t dur_num, dur_den;        /* video::Frame.duration_hint (src/video.rs:8-14) */
+    int64_t off_num, off_den;        /* VideoFrame.tick_offset (src/engine/io.rs:12-17) */
+} mx_frame;
+
+typedef struct { mx_line kind; const float* samples; size_t len; const mx_frame* video; } mx_input;                 /* InputRef, io.rs:19-24 */
+typedef struct { mx_line kind; float* samples; size_t len; mx_frame* video; int video_present; } mx_output;         /* OutputRef, io.rs:96-100 */
+
+typedef struct mx_module mx_module;
+
+/* ModuleT::create (src/module/mod.rs:12) at the reference's compile-time 44100 Hz / 60 ticks. */
+int mx_module_create(uint32_t kind, const void* params, size_t params_len, mx_module** out);
+/* Same with explicit rates/flags (only sample_rate, ticks_per_second, flags, device are read). */
+int mx_module_create_ex(uint32_t kind, const void* params, size_t params_len, const mx_graph_opts* opts, mx_module** out);
+/* ModuleT::update */
+int mx_module_update(mx_module* m, const void* params, size_t params_len);
+/* ModuleT::run_tick (src/module/mod.rs:17): inputs/outputs are host buffers owned by the caller
+ * for the duration of the call; outputs are fully overwritten.  A MX_DISCONNECTED input reads the
+ * zero buffer.  Any input length is accepted (the reference's one test feeds 355 285 samples in
+ * one call, src/module/eq_three.rs:150-167) as long as all ports agree.  Plotter: indication =
+ * left[SPT] then right[SPT] f32, *indication_len set to the byte count (0 = None). */
+int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t n_inputs,
+                       mx_output* outputs, size_t n_outputs, void* indication, size_t* indication_len);
+void mx_module_destroy(mx_module* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXLAB_GPU_H */

@@ -1,0 +1,247 @@
+// mx_abi.cpp -- the extern "C" boundary declared in include/mixlab_gpu.h.
+//
+// Convention (mirrors the reference's own FFI fencing, codec/src/ffmpeg/ioctx.rs:51-67,136-152):
+// nothing unwinds across the boundary; every entry point catches, stashes the message in a
+// thread-local, and returns a negative status.
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "mx_engine.hpp"
+
+using mx::Error;
+using mx::Graph;
+
+struct mx_graph { std::unique_ptr<Graph> g; };
+
+struct mx_module {
+    uint32_t kind = 0;
+    std::unique_ptr<Graph> g;   // node 0 = the module, node 1+i = SOURCE feeding input terminal i
+    std::vector<uint8_t> in_type, out_type;
+};
+
+static thread_local std::string t_last_error;
+
+template <class F>
+static int guard(F&& f) noexcept {
+    try {
+        f();
+        return MX_OK;
+    } catch (const Error& e) {
+        t_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        t_last_error = "host allocation failed";
+        return MX_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        t_last_error = std::string("internal error: ") + e.what();
+        return MX_ERR_INTERNAL;
+    } catch (...) {
+        t_last_error = "internal error: unknown exception";
+        return MX_ERR_INTERNAL;
+    }
+}
+
+#define REQUIRE(cond, msg) do { if (!(cond)) throw Error(MX_ERR_INVALID, msg); } while (0)
+
+extern "C" {
+
+const char* mx_last_error(void) { return t_last_error.c_str(); }
+uint32_t mx_abi_version(void) { return MX_ABI_VERSION; }
+
+int mx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { t_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); (void)hipGetLastError(); return MX_ERR_DEVICE; }
+    return n;
+}
+
+int mx_graph_build(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t n_edges,
+                   const mx_graph_opts* opts, mx_graph** out) {
+    return guard([&] {
+        REQUIRE(out, "out is NULL");
+        *out = nullptr;
+        mx_graph_opts o{};
+        o.device = -1;
+        if (opts) o = *opts;
+        auto h = std::make_unique<mx_graph>();
+        h->g = std::make_unique<Graph>(nodes, n_nodes, edges, n_edges, o);
+        *out = h.release();
+    });
+}
+
+void mx_graph_destroy(mx_graph* g) {
+    (void)guard([&] { delete g; });
+}
+
+int mx_graph_samples_per_tick(const mx_graph* g, size_t* spt) {
+    return guard([&] { REQUIRE(g && spt, "NULL argument"); *spt = g->g->spt(); });
+}
+
+int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n) {
+    return guard([&] {
+        REQUIRE(g && n, "NULL argument");
+        const auto& o = g->g->run_order();
+        *n = o.size();
+        for (size_t i = 0; i < o.size() && i < cap && order; ++i) order[i] = o[i];
+    });
+}
+
+int mx_graph_update_params(mx_graph* g, uint32_t node, const void* params, size_t params_len) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->update_params(node, params, params_len); });
+}
+
+int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->write_source(node, host_samples, n_ticks * g->g->spt()); });
+}
+
+int mx_graph_bind_source_device(mx_graph* g, uint32_t node, const void* device_ptr) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->bind_source(node, device_ptr); });
+}
+
+int mx_graph_run_ticks(mx_graph* g, uint64_t first_tick, uint32_t n_ticks) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        g->g->run(first_tick * (uint64_t)g->g->spt(), g->g->spt(), n_ticks);   // t = tick * SPT, src/engine.rs:490
+    });
+}
+
+int mx_graph_sync(mx_graph* g) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->sync(); });
+}
+
+int mx_graph_read_output(mx_graph* g, uint32_t node, uint32_t port, float* host_samples, size_t n_ticks) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->read_output(node, port, host_samples, n_ticks * g->g->spt()); });
+}
+
+int mx_graph_output_device_ptr(mx_graph* g, uint32_t node, uint32_t port, void** device_ptr, size_t* floats_per_tick) {
+    return guard([&] {
+        REQUIRE(g && device_ptr, "NULL argument");
+        size_t fpf = 0;
+        *device_ptr = g->g->output_ptr(node, port, &fpf);
+        if (floats_per_tick) *floats_per_tick = fpf * g->g->spt();
+    });
+}
+
+int mx_graph_read_plotter(mx_graph* g, uint32_t node, uint32_t tick_in_run, float* left, float* right, int* fired) {
+    return guard([&] {
+        REQUIRE(g && left && right && fired, "NULL argument");
+        *fired = g->g->read_plotter(node, tick_in_run, left, right);
+    });
+}
+
+int mx_graph_profile_run(mx_graph* g, uint64_t first_tick, uint32_t n_ticks, float* ms_by_kind, float* ms_total) {
+    return guard([&] {
+        REQUIRE(g && ms_by_kind, "NULL argument");
+        g->g->run(first_tick * (uint64_t)g->g->spt(), g->g->spt(), n_ticks, ms_by_kind, ms_total);
+    });
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* per-module compatibility path                                                                    */
+/* ---------------------------------------------------------------------------------------------- */
+
+static void module_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+    // one throw-away 1-node graph would also tell us, but keep this host-only: mirror of kind_ports()
+    switch (kind) {
+    case MX_KIND_AMPLIFIER: in = {MX_STEREO, MX_MONO}; out = {MX_STEREO}; break;
+    case MX_KIND_ENVELOPE: case MX_KIND_EQ_THREE: in = {MX_MONO}; out = {MX_MONO}; break;
+    case MX_KIND_FM_SINE: in = {MX_MONO}; out = {MX_STEREO}; break;
+    case MX_KIND_MIXER: in.assign(params_len / sizeof(mx_mixer_channel_params), MX_STEREO); out = {MX_STEREO, MX_STEREO}; break;
+    case MX_KIND_OSCILLATOR: in = {}; out = {MX_MONO, MX_STEREO}; break;
+    case MX_KIND_PLOTTER: in = {MX_STEREO}; out = {}; break;
+    case MX_KIND_STEREO_PANNER: in = {MX_MONO, MX_MONO}; out = {MX_STEREO}; break;
+    case MX_KIND_STEREO_SPLITTER: in = {MX_STEREO}; out = {MX_MONO, MX_MONO}; break;
+    case MX_KIND_TRIGGER: in = {}; out = {MX_MONO}; break;
+    default: throw Error(MX_ERR_INVALID, "kind has no per-module audio path");
+    }
+}
+
+int mx_module_create_ex(uint32_t kind, const void* params, size_t params_len, const mx_graph_opts* opts, mx_module** out) {
+    return guard([&] {
+        REQUIRE(out, "out is NULL");
+        *out = nullptr;
+        auto m = std::make_unique<mx_module>();
+        m->kind = kind;
+        module_ports(kind, params_len, m->in_type, m->out_type);
+        std::vector<mx_node> nodes(1 + m->in_type.size());
+        std::vector<mx_edge> edges(m->in_type.size());
+        nodes[0] = mx_node{kind, (uint32_t)params_len, params};
+        for (size_t i = 0; i < m->in_type.size(); ++i) {
+            nodes[1 + i] = mx_node{m->in_type[i] == MX_MONO ? (uint32_t)MX_KIND_SOURCE_MONO : (uint32_t)MX_KIND_SOURCE_STEREO, 0u, nullptr};
+            edges[i] = mx_edge{(uint32_t)(1 + i), 0u, 0u, (uint32_t)i};
+        }
+        mx_graph_opts o{};
+        o.device = -1;
+        if (opts) { o.sample_rate = opts->sample_rate; o.ticks_per_second = opts->ticks_per_second; o.flags = opts->flags; o.device = opts->device; }
+        o.max_ticks_per_run = 1;
+        m->g = std::make_unique<Graph>(nodes.data(), nodes.size(), edges.data(), edges.size(), o);
+        *out = m.release();
+    });
+}
+
+int mx_module_create(uint32_t kind, const void* params, size_t params_len, mx_module** out) {
+    return mx_module_create_ex(kind, params, params_len, nullptr, out);
+}
+
+int mx_module_update(mx_module* m, const void* params, size_t params_len) {
+    return guard([&] { REQUIRE(m, "module is NULL"); m->g->update_params(0, params, params_len); });
+}
+
+int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t n_inputs,
+                       mx_output* outputs, size_t n_outputs, void* indication, size_t* indication_len) {
+    return guard([&] {
+        REQUIRE(m, "module is NULL");
+        REQUIRE(n_inputs == m->in_type.size(), "wrong number of inputs for this module kind");
+        REQUIRE(n_outputs == m->out_type.size(), "wrong number of outputs for this module kind");
+        REQUIRE(!n_inputs || inputs, "inputs is NULL");
+        REQUIRE(!n_outputs || outputs, "outputs is NULL");
+        if (indication_len) *indication_len = 0;
+
+        // all terminals must agree on the number of frames in this call
+        size_t frames = 0; bool have = false;
+        auto note = [&](size_t len, uint8_t lt) {
+            if (lt == MX_STEREO) { if (len & 1) throw Error(MX_ERR_INVALID, "stereo buffer length is odd"); len >>= 1; }
+            if (have && len != frames) throw Error(MX_ERR_INVALID, "terminals disagree on buffer length");
+            frames = len; have = true;
+        };
+        for (size_t i = 0; i < n_inputs; ++i) {
+            if (inputs[i].kind == MX_DISCONNECTED) continue;
+            // expect_mono()/expect_stereo() panic on the wrong line type (src/engine/io.rs:40-41,49-50)
+            if ((uint8_t)inputs[i].kind != m->in_type[i]) throw Error(MX_ERR_TYPE, "input line type mismatch");
+            REQUIRE(inputs[i].samples || !inputs[i].len, "input samples is NULL");
+            note(inputs[i].len, m->in_type[i]);
+        }
+        for (size_t i = 0; i < n_outputs; ++i) {
+            if ((uint8_t)outputs[i].kind != m->out_type[i]) throw Error(MX_ERR_TYPE, "output line type mismatch");
+            REQUIRE(outputs[i].samples || !outputs[i].len, "output samples is NULL");
+            note(outputs[i].len, m->out_type[i]);
+        }
+        Graph& g = *m->g;
+        if (!have) frames = g.spt();
+        if (frames == 0) return;
+
+        g.ensure_capacity(frames);
+        for (size_t i = 0; i < n_inputs; ++i) {
+            const bool conn = inputs[i].kind != MX_DISCONNECTED;
+            g.set_input_enabled(0, (uint32_t)i, conn);
+            if (conn) g.write_source((uint32_t)(1 + i), inputs[i].samples, frames);
+        }
+        g.run(t, frames, 1);
+        for (size_t i = 0; i < n_outputs; ++i) g.read_output(0, (uint32_t)i, outputs[i].samples, frames);
+        if (m->kind == MX_KIND_PLOTTER) {
+            g.sync();
+            if (indication && indication_len) {
+                float* l = (float*)indication;
+                if (g.read_plotter(0, 0, l, l + frames)) *indication_len = 2 * frames * sizeof(float);
+            }
+        }
+        g.sync();
+    });
+}
+
+void mx_module_destroy(mx_module* m) {
+    (void)guard([&] { delete m; });
+}
+
+}  // extern "C"

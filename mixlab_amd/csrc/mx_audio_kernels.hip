@@ -1,0 +1,378 @@
+// mx_audio_kernels.hip -- hand-written gfx950 kernels for mixlab's audio modules.
+//
+// Build with -ffp-contract=off: the reference (Rust) evaluates every f64 expression as written,
+// never fused; parity with it is bit-exact only if v_fma_f64 is not substituted for mul+add.
+//
+// Layout: every port buffer is a flat f32 stream of `frames` mono samples (or 2*frames interleaved
+// L,R) -- n_ticks consecutive 735/800-sample tick buffers back to back -- 256-byte aligned, so the
+// streaming kernels move 16 B per lane (one float4 quad) and a wave moves 1 KiB per instruction.
+// Instances of one module kind are batched into one launch: blockIdx.y = instance for streaming
+// kernels, one wave per instance for the envelope scan, one lane per instance for the exact EQ.
+#include "mx_kernels.hpp"
+
+namespace mx {
+
+// ---------------------------------------------------------------------------------------------
+// guarded quad access: full quads are one dwordx4, the (single) partial tail quad goes scalar
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* __restrict__ p, size_t q, size_t n) {
+    const size_t b = q * 4;
+    if (b + 4 <= n) return reinterpret_cast<const float4*>(p)[q];
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < n) r.x = p[b];
+    if (b + 1 < n) r.y = p[b + 1];
+    if (b + 2 < n) r.z = p[b + 2];
+    return r;
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, size_t q, size_t n, float4 v) {
+    const size_t b = q * 4;
+    if (b + 4 <= n) { reinterpret_cast<float4*>(p)[q] = v; return; }
+    if (b < n) p[b] = v.x;
+    if (b + 1 < n) p[b + 1] = v.y;
+    if (b + 2 < n) p[b + 2] = v.z;
+}
+__device__ __forceinline__ float2 ld2(const float* __restrict__ p, size_t h, size_t n) {
+    const size_t b = h * 2;
+    if (b + 2 <= n) return reinterpret_cast<const float2*>(p)[h];
+    float2 r = make_float2(0.f, 0.f);
+    if (b < n) r.x = p[b];
+    return r;
+}
+
+static inline unsigned grid_x(size_t items, unsigned block, unsigned cap) {
+    size_t b = (items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Amplifier (src/module/amplifier.rs:38-60,71-73)
+//   out[i] = (in[i] as f64 * (1.0 - d + d * mod[i/2]) * amplitude) as f32
+// algorithmic bytes per frame: 8 (in) + 4 (ctl) + 8 (out) = 20
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_amplifier(const AmpDesc* __restrict__ descs, size_t n /* stereo floats */) {
+    const AmpDesc d = descs[blockIdx.y];
+    const size_t nq = (n + 3) >> 2;
+    const double md = d.mod_depth, amp = d.amplitude;
+    const double one_minus = 1.0 - md;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        const float4 v = ld4(d.in, q, n);
+        double m0 = 1.0, m1 = 1.0;
+        if (d.ctl) {  // block-uniform
+            const float2 c = ld2(d.ctl, q, n >> 1);   // stereo floats 4q..4q+3 <-> mono 2q, 2q+1
+            m0 = (double)c.x; m1 = (double)c.y;
+        }
+        const double dep0 = one_minus + md * m0;      // depth(), amplifier.rs:71-73
+        const double dep1 = one_minus + md * m1;
+        float4 o;
+        o.x = (float)((double)v.x * dep0 * amp);
+        o.y = (float)((double)v.y * dep0 * amp);
+        o.z = (float)((double)v.z * dep1 * amp);
+        o.w = (float)((double)v.w * dep1 * amp);
+        st4(d.out, q, n, o);
+    }
+}
+void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    const size_t ns = frames * 2;
+    dim3 grid(grid_x((ns + 3) / 4, 256, 4096), n);
+    hipLaunchKernelGGL(k_amplifier, grid, dim3(256), 0, s, d, ns);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mixer (src/module/mixer.rs:46-71).  The f32 accumulation order over channels IS the result
+// (order-sensitive far beyond 1 ULP), so each output element owns one strictly sequential add chain;
+// parallelism comes from the sample axis, memory-level parallelism from U independent channel loads
+// in flight per lane ahead of the chain.
+//   master[i] += (in[ch][i] as f64 * gain[ch]) as f32 ;  if cue[ch] { cue[i] += in[ch][i] }
+// algorithmic bytes per mixer per frame: 8 * (n_ch + 2)
+// ---------------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void k_mixer(const MixDesc* __restrict__ descs, size_t n /* stereo floats */) {
+    const MixDesc m = descs[blockIdx.y];
+    const MixChan* __restrict__ ch = m.chans;
+    const size_t nq = (n + 3) >> 2;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // util::zero(master), mixer.rs:54
+        float4 cac = make_float4(0.f, 0.f, 0.f, 0.f);   // util::zero(cue),    mixer.rs:55
+        uint32_t c = 0;
+        for (; c + U <= m.n_ch; c += U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ld4(ch[c + u].in, q, n);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double g = ch[c + u].gain;
+                acc.x += (float)((double)v[u].x * g);
+                acc.y += (float)((double)v[u].y * g);
+                acc.z += (float)((double)v[u].z * g);
+                acc.w += (float)((double)v[u].w * g);
+                if (ch[c + u].cue) { cac.x += v[u].x; cac.y += v[u].y; cac.z += v[u].z; cac.w += v[u].w; }
+            }
+        }
+        for (; c < m.n_ch; ++c) {
+            const float4 v = ld4(ch[c].in, q, n);
+            const double g = ch[c].gain;
+            acc.x += (float)((double)v.x * g);
+            acc.y += (float)((double)v.y * g);
+            acc.z += (float)((double)v.z * g);
+            acc.w += (float)((double)v.w * g);
+            if (ch[c].cue) { cac.x += v.x; cac.y += v.y; cac.z += v.z; cac.w += v.w; }
+        }
+        st4(m.master, q, n, acc);
+        st4(m.cue, q, n, cac);
+    }
+}
+void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    const size_t ns = frames * 2;
+    dim3 grid(grid_x((ns + 3) / 4, 256, 8192), n);
+    hipLaunchKernelGGL(k_mixer<8>, grid, dim3(256), 0, s, d, ns);
+}
+
+// ---------------------------------------------------------------------------------------------
+// EqThree, exact order (src/module/eq_three.rs:58-89,117-124): one lane per instance walks its
+// stream sequentially; bit-exact against the reference's golden pair.  f64-VALU/latency bound.
+// ---------------------------------------------------------------------------------------------
+#define MX_VSA (1.0 / 4294967295.0)   /* eq_three.rs:11 */
+
+__device__ __forceinline__ double pump(const double f, double (&p)[4], const double sample) {
+    p[0] += f * (sample - p[0]) + MX_VSA;
+    p[1] += f * (p[0] - p[1]);
+    p[2] += f * (p[1] - p[2]);
+    p[3] += f * (p[2] - p[3]);
+    return p[3];
+}
+
+__global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
+                                                        uint32_t n_inst, size_t frames, double lo_f, double hi_f) {
+    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= n_inst) return;
+    const EqDesc d = descs[inst];
+    EqState st = states[inst];
+    double lo[4] = {st.lo[0], st.lo[1], st.lo[2], st.lo[3]};
+    double hi[4] = {st.hi[0], st.hi[1], st.hi[2], st.hi[3]};
+    double h0 = st.history[0], h1 = st.history[1], h2 = st.history[2];
+    for (size_t i = 0; i < frames; ++i) {
+        const double sample = d.in ? (double)d.in[i] : 0.0;
+        const double l = pump(lo_f, lo, sample);
+        const double h = h0 - pump(hi_f, hi, sample);
+        const double mid = h0 - (h + l);
+        h0 = h1; h1 = h2; h2 = sample;
+        d.out[i] = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);
+    }
+    for (int k = 0; k < 4; ++k) { st.lo[k] = lo[k]; st.hi[k] = hi[k]; }
+    st.history[0] = h0; st.history[1] = h1; st.history[2] = h2;
+    states[inst] = st;
+}
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f, hipStream_t s) {
+    if (!n || !frames) return;
+    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, frames, lo_f, hi_f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Envelope (src/module/envelope.rs:34-58,91-120).  The reference is a per-sample state machine, but
+// both non-identity inputs are constant maps on {not-on, on}: gate == 1.0 forces "on", gate == 0.0
+// forces "not-on".  So the state bit after sample i is the value of the last marker at or before i,
+// edges are where that bit flips, and (state, since-when) follows from the last rising / falling
+// edge.  One wave per instance: 64 samples per step, edges found with ballots + clz (no shuffles,
+// no LDS), closed-form amplitude per lane, state carried in SGPR-uniform registers across steps.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double seq_ms(uint64_t first, uint64_t last, double sr) {
+    return (double)(last - first) / sr * 1000.0;                       // envelope.rs:16-18
+}
+__device__ __forceinline__ double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }  // envelope.rs:20-28
+__device__ __forceinline__ double amp_on(const EnvDesc& p, uint64_t on, uint64_t t, double sr) {       // envelope.rs:37-49
+    const double ms = seq_ms(on, t, sr);
+    if (ms < p.attack_ms) return p.inv_attack * ms;
+    const double since_decay = ms - p.attack_ms;
+    const double decay_amplitude = 1.0 - clamp01(p.inv_decay * since_decay);
+    return p.sustain + (p.one_minus_sustain * decay_amplitude);
+}
+__device__ __forceinline__ double amp_off(const EnvDesc& p, uint64_t off, double off_amp, uint64_t t, double sr) {  // envelope.rs:51-56
+    const double ms = seq_ms(off, t, sr);
+    const double release_amplitude = 1.0 - clamp01(p.inv_release * ms);
+    return off_amp * release_amplitude;
+}
+__device__ __forceinline__ int top_bit(uint64_t m) { return 63 - __clzll((long long)m); }
+
+__global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ descs, EnvState* __restrict__ states,
+                                                   uint32_t n_inst, size_t frames, uint64_t t0, double sr) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= n_inst) return;  // wave-uniform
+    const EnvDesc p = descs[inst];
+    uint32_t tag = states[inst].tag;
+    uint64_t seq = states[inst].seq;
+    double off_amp = states[inst].off_amplitude;
+
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint64_t le = lt | (1ull << lane);
+
+    for (size_t base = 0; base < frames; base += 64) {
+        const size_t i = base + lane;
+        const bool valid = i < frames;
+        const float x = (valid && p.gate) ? p.gate[i] : 0.0f;   // Disconnected => ZERO_BUFFER_MONO
+        const uint64_t m1 = __ballot(valid && x == 1.0f);        // envelope.rs:102
+        const uint64_t m0 = __ballot(valid && x == 0.0f);        // envelope.rs:107
+        const uint64_t mk = m0 | m1;
+        const uint64_t below = mk & lt;
+        const bool carry_on = (tag == 1u);
+        const bool b_prev = below ? (((m1 >> top_bit(below)) & 1ull) != 0) : carry_on;
+        const bool b_cur = ((mk >> lane) & 1ull) ? (((m1 >> lane) & 1ull) != 0) : b_prev;
+        const uint64_t R = __ballot(valid && !b_prev && b_cur);  // Initial|Off -> On
+        const uint64_t F = __ballot(valid && b_prev && !b_cur);  // On -> Off
+        const uint64_t tb = t0 + base;
+
+        uint32_t my_tag; uint64_t my_seq; double my_off = 0.0;
+        const uint64_t Rle = R & le, Fle = F & le;
+        if (b_cur) {
+            my_tag = 1u;
+            my_seq = Rle ? tb + (uint64_t)top_bit(Rle) : seq;
+        } else if (Fle) {
+            const int fl = top_bit(Fle);
+            const uint64_t off = tb + (uint64_t)fl;
+            const uint64_t Rb = R & ((1ull << fl) - 1ull);
+            const uint64_t on = Rb ? tb + (uint64_t)top_bit(Rb) : seq;
+            my_tag = 2u; my_seq = off;
+            my_off = amp_on(p, on, off, sr);                    // envelope.rs:108-111
+        } else {
+            my_tag = tag; my_seq = seq; my_off = off_amp;       // carried Initial / TriggerOff
+        }
+        const uint64_t t = tb + (uint64_t)lane;
+        double a;
+        if (my_tag == 1u) a = amp_on(p, my_seq, t, sr);
+        else if (my_tag == 2u) a = amp_off(p, my_seq, my_off, t, sr);
+        else a = 0.0;                                           // envelope.rs:36
+        if (valid) p.out[i] = (float)a;
+
+        const size_t rem = frames - base;
+        const int last = rem >= 64 ? 63 : (int)rem - 1;
+        tag = (uint32_t)__shfl((int)my_tag, last);
+        seq = (uint64_t)__shfl((unsigned long long)my_seq, last);
+        off_amp = __shfl(my_off, last);
+    }
+    if (lane == 0) { states[inst].tag = tag; states[inst].seq = seq; states[inst].off_amplitude = off_amp; }
+}
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+    if (!n || !frames) return;
+    hipLaunchKernelGGL(k_envelope, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, t0, sample_rate);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Oscillator (src/module/oscillator.rs:15-37,65-92) and FmSine (src/module/fm_sine.rs:37-56).
+// f64 sin = ocml's; the reference's is the host libm.  Both are sub-ULP f64 routines; after the
+// f32 cast the results differ in at most 1 f32 ULP, rarely (measured in tests).
+// ---------------------------------------------------------------------------------------------
+#define MX_PI 3.14159265358979323846264338327950288
+
+__device__ __forceinline__ double osc_saw(double n) { return 2.0 * (n - floor(0.5 + n)); }
+
+__global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
+    const OscDesc d = descs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256) {
+        const double tt = (double)(t0 + (uint64_t)i) / sr;
+        const double n = tt * d.freq;
+        double v;
+        switch (d.waveform) {
+        case 2: v = sin(n * 2.0 * MX_PI); break;                                      // Sine
+        case 3: { const double sv = sin(n * 2.0 * MX_PI); v = signbit(sv) ? -1.0 : 1.0; break; }  // Square: sign by sign bit (oscillator.rs:15-23)
+        case 5: v = osc_saw(n); break;                                                // Saw
+        case 4: v = 2.0 * fabs(osc_saw(n)) - 1.0; break;                              // Triangle
+        case 0: v = 1.0; break;                                                       // On
+        default: v = 0.0; break;                                                      // Off
+        }
+        const float sm = (float)v;
+        d.mono[i] = sm;
+        reinterpret_cast<float2*>(d.stereo)[i] = make_float2(sm, sm);
+    }
+}
+void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x(frames, 256, 4096), n);
+    hipLaunchKernelGGL(k_oscillator, grid, dim3(256), 0, s, d, frames, t0, sample_rate);
+}
+
+__global__ __launch_bounds__(256) void k_fm_sine(const FmDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
+    const FmDesc d = descs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256) {
+        const double tt = (double)(t0 + (uint64_t)i) / sr;
+        const double xin = d.in ? (double)d.in[i] : 0.0;
+        const double co = (d.freq_mid + d.freq_amp * xin) * 2.0 * MX_PI;
+        const float x = (float)sin(co * tt);
+        reinterpret_cast<float2*>(d.out)[i] = make_float2(x, x);
+    }
+}
+void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x(frames, 256, 4096), n);
+    hipLaunchKernelGGL(k_fm_sine, grid, dim3(256), 0, s, d, frames, t0, sample_rate);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trigger / StereoPanner / StereoSplitter (trigger.rs:35-48, stereo_panner.rs:30-41,
+// stereo_splitter.rs:33-47): fills and layout shuffles, 16 B per lane on the wide side.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trigger(const TrigDesc* __restrict__ descs, size_t frames) {
+    const TrigDesc d = descs[blockIdx.y];
+    const size_t nq = (frames + 3) >> 2;
+    const float4 v = make_float4(d.value, d.value, d.value, d.value);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) st4(d.out, q, frames, v);
+}
+void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x((frames + 3) / 4, 256, 2048), n);
+    hipLaunchKernelGGL(k_trigger, grid, dim3(256), 0, s, d, frames);
+}
+
+__global__ __launch_bounds__(256) void k_panner(const PanDesc* __restrict__ descs, size_t frames) {
+    const PanDesc d = descs[blockIdx.y];
+    const size_t nq = (frames + 3) >> 2;   // quads of frames -> two stereo quads
+    const size_t ns = frames * 2;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        const float4 l = d.l ? ld4(d.l, q, frames) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r = d.r ? ld4(d.r, q, frames) : make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(d.out, 2 * q, ns, make_float4(l.x, r.x, l.y, r.y));
+        if ((2 * q + 1) * 4 < ns) st4(d.out, 2 * q + 1, ns, make_float4(l.z, r.z, l.w, r.w));
+    }
+}
+void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x((frames + 3) / 4, 256, 4096), n);
+    hipLaunchKernelGGL(k_panner, grid, dim3(256), 0, s, d, frames);
+}
+
+__global__ __launch_bounds__(256) void k_splitter(const SplitDesc* __restrict__ descs, size_t frames) {
+    const SplitDesc d = descs[blockIdx.y];
+    const size_t nq = (frames + 3) >> 2;
+    const size_t ns = frames * 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        const float4 a = d.in ? ld4(d.in, 2 * q, ns) : z;
+        const float4 b = (d.in && (2 * q + 1) * 4 < ns) ? ld4(d.in, 2 * q + 1, ns) : z;
+        st4(d.l, q, frames, make_float4(a.x, a.z, b.x, b.z));
+        st4(d.r, q, frames, make_float4(a.y, a.w, b.y, b.w));
+    }
+}
+void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x((frames + 3) / 4, 256, 4096), n);
+    hipLaunchKernelGGL(k_splitter, grid, dim3(256), 0, s, d, frames);
+}
+
+// Plotter (plotter.rs:37-56): de-interleave one tick per job into the indication staging area.
+__global__ __launch_bounds__(256) void k_plotter(const PlotJob* __restrict__ jobs, size_t spt) {
+    const PlotJob j = jobs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < spt; i += (size_t)gridDim.x * 256) {
+        const float2 v = reinterpret_cast<const float2*>(j.in)[i];
+        j.left[i] = v.x; j.right[i] = v.y;
+    }
+}
+void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s) {
+    if (!n || !spt) return;
+    dim3 grid(grid_x(spt, 256, 64), n);
+    hipLaunchKernelGGL(k_plotter, grid, dim3(256), 0, s, d, spt);
+}
+
+}  // namespace mx

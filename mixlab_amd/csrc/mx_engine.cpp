@@ -1,0 +1,470 @@
+// mx_engine.cpp -- device-resident graph executor.  See mx_engine.hpp.
+#include "mx_engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace mx {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(MX_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+void DevBuf::alloc(size_t n) {
+    free_();
+    if (n == 0) n = 256;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipErrorOutOfMemory) { p = nullptr; throw Error(MX_ERR_NOMEM, "hipMalloc: out of device memory"); }
+    hip_check(e, "hipMalloc");
+    bytes = n;
+}
+void DevBuf::free_() {
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+}
+
+// ModuleT::inputs()/outputs() of each kind (reference file:line in include/mixlab_gpu.h)
+static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+    auto need = [&](size_t sz, const char* name) {
+        if (params_len != sz) throw Error(MX_ERR_INVALID, std::string("params_len does not match ") + name);
+    };
+    switch (kind) {
+    case MX_KIND_AMPLIFIER: need(sizeof(mx_amplifier_params), "mx_amplifier_params"); in = {MX_STEREO, MX_MONO}; out = {MX_STEREO}; break;
+    case MX_KIND_ENVELOPE: need(sizeof(mx_envelope_params), "mx_envelope_params"); in = {MX_MONO}; out = {MX_MONO}; break;
+    case MX_KIND_EQ_THREE: need(sizeof(mx_eq_three_params), "mx_eq_three_params"); in = {MX_MONO}; out = {MX_MONO}; break;
+    case MX_KIND_FM_SINE: need(sizeof(mx_fm_sine_params), "mx_fm_sine_params"); in = {MX_MONO}; out = {MX_STEREO}; break;
+    case MX_KIND_MIXER: {
+        if (params_len % sizeof(mx_mixer_channel_params)) throw Error(MX_ERR_INVALID, "mixer params_len is not a multiple of mx_mixer_channel_params");
+        in.assign(params_len / sizeof(mx_mixer_channel_params), MX_STEREO); out = {MX_STEREO, MX_STEREO}; break;
+    }
+    case MX_KIND_OSCILLATOR: need(sizeof(mx_oscillator_params), "mx_oscillator_params"); in = {}; out = {MX_MONO, MX_STEREO}; break;
+    case MX_KIND_PLOTTER: need(0, "() (Plotter has no params)"); in = {MX_STEREO}; out = {}; break;
+    case MX_KIND_STEREO_PANNER: need(0, "()"); in = {MX_MONO, MX_MONO}; out = {MX_STEREO}; break;
+    case MX_KIND_STEREO_SPLITTER: need(0, "()"); in = {MX_STEREO}; out = {MX_MONO, MX_MONO}; break;
+    case MX_KIND_TRIGGER: need(sizeof(mx_trigger_params), "mx_trigger_params"); in = {}; out = {MX_MONO}; break;
+    case MX_KIND_SOURCE_MONO: in = {}; out = {MX_MONO}; break;
+    case MX_KIND_SOURCE_STEREO: in = {}; out = {MX_STEREO}; break;
+    case MX_KIND_VIDEO_MIXER: throw Error(MX_ERR_INVALID, "VideoMixer nodes run through the mx_video_* entry points, not the audio graph");
+    default: throw Error(MX_ERR_INVALID, "unknown module kind");
+    }
+}
+
+static inline size_t floats_per_frame(uint8_t lt) { return lt == MX_MONO ? 1 : (lt == MX_STEREO ? 2 : 0); }
+
+Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t n_edges, const mx_graph_opts& o,
+             size_t cap_frames_override) {
+    if (n_nodes && !nodes) throw Error(MX_ERR_INVALID, "nodes is NULL");
+    if (n_edges && !edges) throw Error(MX_ERR_INVALID, "edges is NULL");
+    const uint32_t sr = o.sample_rate ? o.sample_rate : 44100u;          // src/engine.rs:53
+    const uint32_t tps = o.ticks_per_second ? o.ticks_per_second : 60u;  // src/engine.rs:54
+    if (sr % tps) throw Error(MX_ERR_INVALID, "sample_rate must be a multiple of ticks_per_second");
+    sample_rate_ = (double)sr;
+    spt_ = sr / tps;                                                     // src/engine.rs:55
+    const uint32_t max_ticks = o.max_ticks_per_run ? o.max_ticks_per_run : 1u;
+    cap_frames_ = cap_frames_override ? cap_frames_override : spt_ * (size_t)max_ticks;
+    flags_ = o.flags;
+
+    if (o.device >= 0) { hip_check(hipSetDevice(o.device), "hipSetDevice"); device_ = o.device; }
+    else hip_check(hipGetDevice(&device_), "hipGetDevice");
+    if (o.stream) { stream_ = (hipStream_t)o.stream; own_stream_ = false; }
+    else { hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"); own_stream_ = true; }
+
+    // host-side coefficients: same libm as the reference on this host (eq_three.rs:113-115)
+    lo_f_ = 2.0 * std::sin(3.14159265358979323846264338327950288 * 420.0 / sample_rate_);
+    hi_f_ = 2.0 * std::sin(3.14159265358979323846264338327950288 * 2700.0 / sample_rate_);
+
+    nodes_.resize(n_nodes);
+    for (size_t i = 0; i < n_nodes; ++i) {
+        Node& n = nodes_[i];
+        n.kind = nodes[i].kind;
+        if (nodes[i].params_len && !nodes[i].params) throw Error(MX_ERR_INVALID, "node params is NULL");
+        n.params.assign((const uint8_t*)nodes[i].params, (const uint8_t*)nodes[i].params + nodes[i].params_len);
+        kind_ports(n.kind, n.params.size(), n.in_type, n.out_type);
+        n.in_src.assign(n.in_type.size(), PortRef{});
+        n.out_off.assign(n.out_type.size(), 0);
+    }
+    for (size_t e = 0; e < n_edges; ++e) {
+        const mx_edge& ed = edges[e];
+        if (ed.src_node >= n_nodes || ed.dst_node >= n_nodes) throw Error(MX_ERR_INVALID, "edge references a node out of range");
+        Node& s = nodes_[ed.src_node];
+        Node& d = nodes_[ed.dst_node];
+        if (ed.src_port >= s.out_type.size() || ed.dst_port >= d.in_type.size()) throw Error(MX_ERR_INVALID, "edge references a terminal out of range");
+        if (s.out_type[ed.src_port] != d.in_type[ed.dst_port])   // Workspace::connect, workspace.rs:97-114
+            throw Error(MX_ERR_TYPE, "line type mismatch on connection");
+        d.in_src[ed.dst_port] = PortRef{(int32_t)ed.src_node, ed.src_port};
+    }
+
+    // Run order: DFS through inputs from terminal modules (src/engine.rs:408-457).  The reference
+    // iterates a HashSet (unspecified order); ascending id is one of its valid orders.
+    std::vector<uint8_t> feeds(n_nodes, 0), seen(n_nodes, 0);
+    for (size_t e = 0; e < n_edges; ++e) feeds[edges[e].src_node] = 1;
+    // iterative DFS (graphs with 1e5 nodes must not blow the stack)
+    struct Frame { uint32_t id; uint32_t next; };
+    std::vector<Frame> stack;
+    for (uint32_t root = 0; root < n_nodes; ++root) {
+        if (feeds[root] || seen[root]) continue;
+        seen[root] = 1; stack.push_back({root, 0});
+        while (!stack.empty()) {
+            Frame& f = stack.back();
+            Node& n = nodes_[f.id];
+            if (f.next < n.in_src.size()) {
+                const PortRef pr = n.in_src[f.next++];
+                if (pr.node >= 0 && !seen[pr.node]) { seen[pr.node] = 1; stack.push_back({(uint32_t)pr.node, 0}); }
+            } else {
+                order_.push_back(f.id);
+                stack.pop_back();
+            }
+        }
+    }
+    // A cycle with no terminal module is never reached from a terminal, so the reference never runs
+    // it (engine.rs:428-430); we mirror that: such nodes stay out of order_.
+
+    // dependency levels; an input whose producer runs later this tick is a back-edge and reads
+    // Disconnected (engine.rs:479-482: buffers.get(output_id) is None)
+    std::vector<int64_t> pos(n_nodes, -1);
+    for (size_t i = 0; i < order_.size(); ++i) pos[order_[i]] = (int64_t)i;
+    for (uint32_t id : order_) {
+        Node& n = nodes_[id];
+        int lvl = 0;
+        for (PortRef& pr : n.in_src) {
+            if (pr.node < 0) continue;
+            if (pos[pr.node] < 0 || pos[pr.node] >= pos[id]) { pr.node = -1; continue; }  // back-edge => Disconnected
+            lvl = std::max(lvl, nodes_[pr.node].level + 1);
+        }
+        n.level = lvl;
+        n.in_src_orig = n.in_src;
+    }
+    // groups: (level, kind)
+    std::vector<uint32_t> sorted(order_);
+    std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
+        if (nodes_[a].level != nodes_[b].level) return nodes_[a].level < nodes_[b].level;
+        return nodes_[a].kind < nodes_[b].kind;
+    });
+    for (uint32_t id : sorted) {
+        Node& n = nodes_[id];
+        if (groups_.empty() || groups_.back().level != n.level || groups_.back().kind != n.kind) {
+            Group g; g.level = n.level; g.kind = n.kind; groups_.push_back(std::move(g));
+        }
+        n.group = (int)groups_.size() - 1;
+        n.slot = (uint32_t)groups_.back().nodes.size();
+        groups_.back().nodes.push_back(id);
+    }
+    layout_slab();
+    build_descriptors();
+}
+
+Graph::~Graph() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Graph::layout_slab() {
+    size_t off = 0;
+    auto bump = [&](size_t floats) { size_t o = off; off += (floats + 63) & ~(size_t)63; return o; };  // 256-byte aligned
+    zero_off_ = bump(2 * cap_frames_);
+    for (Node& n : nodes_)
+        for (size_t k = 0; k < n.out_type.size(); ++k) n.out_off[k] = bump(floats_per_frame(n.out_type[k]) * cap_frames_);
+    slab_floats_ = off;
+    slab_.alloc(off * sizeof(float));
+    hip_check(hipMemsetAsync(slab_.p, 0, off * sizeof(float), stream_), "hipMemsetAsync(slab)");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+float* Graph::out_ptr(const Node& n, uint32_t port) const {
+    if (n.bound && port == 0) return const_cast<float*>(n.bound);
+    return (float*)slab_.p + n.out_off[port];
+}
+const float* Graph::in_ptr(const Node& n, uint32_t port, bool null_if_disconnected) const {
+    const PortRef pr = n.in_src[port];
+    if (pr.node < 0) return null_if_disconnected ? nullptr : (const float*)slab_.p + zero_off_;
+    return out_ptr(nodes_[pr.node], pr.port);
+}
+
+static double db_to_linear(double db) { return std::pow(10.0, db / 20.0); }   // protocol/src/lib.rs:469-471
+
+void Graph::upload_group(Group& g) {
+    const size_t n = g.nodes.size();
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) {
+        if (b.bytes < bytes || !b.p) b.alloc(bytes);
+        if (bytes) hip_check(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(desc)");
+    };
+    switch (g.kind) {
+    case MX_KIND_AMPLIFIER: {
+        std::vector<AmpDesc> d(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_amplifier_params p; std::memcpy(&p, nd.params.data(), sizeof p);
+            d[i] = AmpDesc{in_ptr(nd, 0, false), in_ptr(nd, 1, true), out_ptr(nd, 0), p.amplitude, p.mod_depth};
+        }
+        up(g.desc, d.data(), n * sizeof(AmpDesc));
+        break;
+    }
+    case MX_KIND_ENVELOPE: {
+        std::vector<EnvDesc> d(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_envelope_params p; std::memcpy(&p, nd.params.data(), sizeof p);
+            d[i] = EnvDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
+                           p.sustain_amplitude, 1.0 - p.sustain_amplitude, 1.0 / p.release_ms};
+        }
+        up(g.desc, d.data(), n * sizeof(EnvDesc));
+        if (!g.state.p) { g.state.alloc(n * sizeof(EnvState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EnvState)), "hipMemset"); }
+        break;
+    }
+    case MX_KIND_EQ_THREE: {
+        std::vector<EqDesc> d(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_eq_three_params p; std::memcpy(&p, nd.params.data(), sizeof p);
+            d[i] = EqDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), db_to_linear(p.gain_lo_db), db_to_linear(p.gain_mid_db), db_to_linear(p.gain_hi_db)};
+        }
+        up(g.desc, d.data(), n * sizeof(EqDesc));
+        if (!g.state.p) { g.state.alloc(n * sizeof(EqState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EqState)), "hipMemset"); }
+        break;
+    }
+    case MX_KIND_FM_SINE: {
+        std::vector<FmDesc> d(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_fm_sine_params p; std::memcpy(&p, nd.params.data(), sizeof p);
+            const double freq_amp = (p.freq_hi - p.freq_lo) / 2.0;    // fm_sine.rs:42
+            const double freq_mid = p.freq_lo + freq_amp;            // fm_sine.rs:43
+            d[i] = FmDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), freq_mid, freq_amp};
+        }
+        up(g.desc, d.data(), n * sizeof(FmDesc));
+        break;
+    }
+    case MX_KIND_MIXER: {
+        size_t total = 0;
+        for (uint32_t id : g.nodes) total += nodes_[id].in_type.size();
+        std::vector<MixChan> ch(total ? total : 1);
+        if (g.extra.bytes < ch.size() * sizeof(MixChan) || !g.extra.p) g.extra.alloc(ch.size() * sizeof(MixChan));
+        std::vector<MixDesc> d(n);
+        size_t o = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            const size_t nch = nd.in_type.size();
+            const mx_mixer_channel_params* p = (const mx_mixer_channel_params*)nd.params.data();
+            for (size_t c = 0; c < nch; ++c) {
+                mx_mixer_channel_params cp; std::memcpy(&cp, p + c, sizeof cp);
+                ch[o + c] = MixChan{in_ptr(nd, (uint32_t)c, false), cp.fader * db_to_linear(cp.gain_db), cp.cue ? 1u : 0u, 0u};  // mixer.rs:59
+            }
+            d[i] = MixDesc{(const MixChan*)g.extra.p + o, (uint32_t)nch, 0u, out_ptr(nd, 0), out_ptr(nd, 1)};
+            o += nch;
+        }
+        hip_check(hipMemcpy(g.extra.p, ch.data(), ch.size() * sizeof(MixChan), hipMemcpyHostToDevice), "hipMemcpy(mixchan)");
+        up(g.desc, d.data(), n * sizeof(MixDesc));
+        break;
+    }
+    case MX_KIND_OSCILLATOR: {
+        std::vector<OscDesc> d(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_oscillator_params p; std::memcpy(&p, nd.params.data(), sizeof p);
+            d[i] = OscDesc{out_ptr(nd, 0), out_ptr(nd, 1), p.freq, p.waveform, 0u};
+        }
+        up(g.desc, d.data(), n * sizeof(OscDesc));
+        break;
+    }
+    case MX_KIND_STEREO_PANNER: {
+        std::vector<PanDesc> d(n);
+        for (size_t i = 0; i < n; ++i) { const Node& nd = nodes_[g.nodes[i]]; d[i] = PanDesc{in_ptr(nd, 0, false), in_ptr(nd, 1, false), out_ptr(nd, 0)}; }
+        up(g.desc, d.data(), n * sizeof(PanDesc));
+        break;
+    }
+    case MX_KIND_STEREO_SPLITTER: {
+        std::vector<SplitDesc> d(n);
+        for (size_t i = 0; i < n; ++i) { const Node& nd = nodes_[g.nodes[i]]; d[i] = SplitDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), out_ptr(nd, 1)}; }
+        up(g.desc, d.data(), n * sizeof(SplitDesc));
+        break;
+    }
+    case MX_KIND_TRIGGER: {
+        std::vector<TrigDesc> d(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_trigger_params p; std::memcpy(&p, nd.params.data(), sizeof p);
+            d[i] = TrigDesc{out_ptr(nd, 0), p.gate_open ? 1.0f : 0.0f, 0u};   // trigger.rs:38-41
+        }
+        up(g.desc, d.data(), n * sizeof(TrigDesc));
+        break;
+    }
+    default: break;  // PLOTTER (jobs built per run), SOURCE_* (no launch)
+    }
+}
+
+void Graph::build_descriptors() {
+    for (Group& g : groups_) upload_group(g);
+}
+
+void Graph::update_params(uint32_t node, const void* params, size_t len) {
+    if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
+    Node& n = nodes_[node];
+    if (len != n.params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
+    if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
+    sync();
+    if (len) std::memcpy(n.params.data(), params, len);
+    if (n.group >= 0) upload_group(groups_[n.group]);
+}
+
+void Graph::write_source(uint32_t node, const float* host, size_t frames) {
+    if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
+    Node& n = nodes_[node];
+    if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
+    if (n.bound) throw Error(MX_ERR_INVALID, "source is bound to a caller device buffer");
+    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
+    if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
+    const size_t fl = floats_per_frame(n.out_type[0]) * frames;
+    hip_check(hipMemcpyAsync(out_ptr(n, 0), host, fl * sizeof(float), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D source)");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // host buffer is the caller's again on return
+}
+
+void Graph::bind_source(uint32_t node, const void* dev) {
+    if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
+    Node& n = nodes_[node];
+    if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
+    if (dev && ((uintptr_t)dev & 15)) throw Error(MX_ERR_INVALID, "bound device buffer must be 16-byte aligned");
+    sync();
+    n.bound = (const float*)dev;
+    build_descriptors();
+}
+
+void Graph::set_input_enabled(uint32_t node, uint32_t port, bool enabled) {
+    if (node >= nodes_.size() || port >= nodes_[node].in_src.size()) throw Error(MX_ERR_INVALID, "input terminal out of range");
+    Node& n = nodes_[node];
+    if (n.in_src_orig.size() != n.in_src.size()) return;  // node is outside the run order
+    const PortRef want = enabled ? n.in_src_orig[port] : PortRef{};
+    if (want.node == n.in_src[port].node && want.port == n.in_src[port].port) return;
+    sync();
+    n.in_src[port] = want;
+    if (n.group >= 0) upload_group(groups_[n.group]);
+}
+
+void Graph::sync() { hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+
+void Graph::ensure_capacity(size_t frames) {
+    if (frames <= cap_frames_) return;
+    sync();
+    cap_frames_ = frames;
+    layout_slab();
+    build_descriptors();
+}
+
+void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, float* ms_total) {
+    const size_t frames = fpc * (size_t)n_calls;
+    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "n_ticks exceeds max_ticks_per_run");
+    if (n_calls == 0 || fpc == 0) { last_calls_ = n_calls; last_frames_per_call_ = fpc; return; }
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+
+    const bool prof = ms_by_kind != nullptr;
+    std::vector<hipEvent_t> ev;
+    if (prof) {
+        ev.resize(groups_.size() + 1);
+        for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
+        hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
+    }
+
+    // Plotter bookkeeping is host logic (plotter.rs:37-40): count += 1 per call, fire on every 6th
+    std::vector<PlotJob> jobs;
+    size_t total_fired = 0;
+    for (Node& n : nodes_) {
+        if (n.kind != MX_KIND_PLOTTER || n.group < 0) continue;
+        n.plot_fired.assign(n_calls, 0);
+        n.plot_slot.assign(n_calls, -1);
+        const bool connected = n.in_src[0].node >= 0;
+        for (uint32_t c = 0; c < n_calls; ++c) {
+            n.plot_count += 1;
+            if (n.plot_count % 6 == 0 && connected) { n.plot_fired[c] = 1; n.plot_slot[c] = (int32_t)total_fired++; }
+        }
+    }
+    if (total_fired) {
+        const size_t need = total_fired * 2 * fpc * sizeof(float);
+        if (plot_stage_.bytes < need) { sync(); plot_stage_.alloc(need); }
+        if (plot_jobs_.bytes < total_fired * sizeof(PlotJob)) { sync(); plot_jobs_.alloc(total_fired * sizeof(PlotJob)); }
+    }
+
+    size_t gi = 0, job_off = 0;
+    for (Group& g : groups_) {
+        const uint32_t n = (uint32_t)g.nodes.size();
+        switch (g.kind) {
+        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, frames, t0, sample_rate_, stream_); break;
+        case MX_KIND_EQ_THREE: launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, lo_f_, hi_f_, stream_); break;
+        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
+        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
+        case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_PLOTTER: {
+            jobs.clear();
+            for (uint32_t id : g.nodes) {
+                const Node& nd = nodes_[id];
+                for (uint32_t c = 0; c < n_calls; ++c) {
+                    if (!nd.plot_fired[c]) continue;
+                    float* stage = (float*)plot_stage_.p + (size_t)nd.plot_slot[c] * 2 * fpc;
+                    jobs.push_back(PlotJob{in_ptr(nd, 0, false) + (size_t)c * 2 * fpc, stage, stage + fpc});
+                }
+            }
+            if (!jobs.empty()) {
+                // pageable-host upload; synchronise so `jobs` may be reused (fires every 6th tick only)
+                PlotJob* dst = (PlotJob*)plot_jobs_.p + job_off;
+                hip_check(hipMemcpyAsync(dst, jobs.data(), jobs.size() * sizeof(PlotJob), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(plot jobs)");
+                hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                launch_plotter(dst, (uint32_t)jobs.size(), fpc, stream_);
+                job_off += jobs.size();
+            }
+            break;
+        }
+        default: break;
+        }
+        if (prof) hip_check(hipEventRecord(ev[gi + 1], stream_), "hipEventRecord");
+        ++gi;
+    }
+    hip_check(hipGetLastError(), "kernel launch");
+    last_calls_ = n_calls;
+    last_frames_per_call_ = fpc;
+
+    if (prof) {
+        sync();
+        for (int k = 0; k < MX_KIND_COUNT; ++k) ms_by_kind[k] = 0.f;
+        for (size_t i = 0; i < groups_.size(); ++i) {
+            float ms = 0.f;
+            hip_check(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "hipEventElapsedTime");
+            ms_by_kind[groups_[i].kind] += ms;
+        }
+        if (ms_total) hip_check(hipEventElapsedTime(ms_total, ev.front(), ev.back()), "hipEventElapsedTime");
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+}
+
+void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames) {
+    if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
+    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
+    if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
+    const Node& n = nodes_[node];
+    const size_t fl = floats_per_frame(n.out_type[port]) * frames;
+    hip_check(hipMemcpyAsync(host, out_ptr(n, port), fl * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+    sync();
+}
+
+float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
+    if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
+    if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]);
+    return out_ptr(nodes_[node], port);
+}
+
+int Graph::read_plotter(uint32_t node, uint32_t call, float* left, float* right) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_PLOTTER) throw Error(MX_ERR_INVALID, "node is not a Plotter");
+    const Node& n = nodes_[node];
+    if (call >= n.plot_fired.size()) throw Error(MX_ERR_INVALID, "tick_in_run is outside the last run");
+    if (!n.plot_fired[call]) return 0;
+    const size_t fpc = last_frames_per_call_;
+    const float* stage = (const float*)plot_stage_.p + (size_t)n.plot_slot[call] * 2 * fpc;
+    hip_check(hipMemcpyAsync(left, stage, fpc * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+    hip_check(hipMemcpyAsync(right, stage + fpc, fpc * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+    sync();
+    return 1;
+}
+
+}  // namespace mx

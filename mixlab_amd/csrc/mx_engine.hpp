@@ -1,0 +1,123 @@
+// mx_engine.hpp -- device-resident graph executor (internal C++ API behind include/mixlab_gpu.h).
+//
+// Mirrors what Engine::run_tick (reference src/engine.rs:400-510) does per tick -- topological
+// order, fresh outputs, Disconnected => zeros, t = tick * SPT -- but freezes the topology once,
+// keeps every port buffer resident in one HBM slab, batches all instances of a module kind at one
+// dependency level into one launch, and runs n_ticks ticks per submission.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mixlab_gpu.h"
+#include "mx_kernels.hpp"
+
+namespace mx {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char* what);
+
+// simple owning device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t n);
+    void free_();
+    ~DevBuf() { free_(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { free_(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+};
+
+struct PortRef { int32_t node = -1; uint32_t port = 0; };
+
+struct Node {
+    uint32_t kind = 0;
+    std::vector<uint8_t> params;
+    std::vector<uint8_t> in_type, out_type;   // mx_line per terminal (ModuleT::inputs()/outputs())
+    std::vector<PortRef> in_src;              // workspace.connections (back-edges already cut)
+    std::vector<PortRef> in_src_orig;         // in_src before set_input_enabled() toggles
+    std::vector<size_t> out_off;              // float offset of each output port in the slab
+    const float* bound = nullptr;             // SOURCE_*: caller-bound device buffer
+    int level = 0;
+    uint32_t slot = 0;                        // index inside its (level, kind) group
+    int group = -1;
+    // plotter
+    uint64_t plot_count = 0;
+    std::vector<uint8_t> plot_fired;          // per call of the last run
+    std::vector<int32_t> plot_slot;           // staging slot per call (-1 = not fired)
+};
+
+struct Group {
+    int level = 0;
+    uint32_t kind = 0;
+    std::vector<uint32_t> nodes;
+    DevBuf desc;     // kind-specific descriptor array
+    DevBuf state;    // EnvState[] / EqState[]
+    DevBuf extra;    // Mixer: MixChan arrays
+};
+
+class Graph {
+public:
+    Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t n_edges, const mx_graph_opts& opts,
+          size_t cap_frames_override = 0);
+    ~Graph();
+
+    size_t spt() const { return spt_; }
+    double sample_rate() const { return sample_rate_; }
+    size_t cap_frames() const { return cap_frames_; }
+    const std::vector<uint32_t>& run_order() const { return order_; }
+    hipStream_t stream() const { return stream_; }
+    size_t n_nodes() const { return nodes_.size(); }
+    const Node& node(uint32_t i) const { return nodes_.at(i); }
+
+    void update_params(uint32_t node, const void* params, size_t len);
+    void write_source(uint32_t node, const float* host, size_t frames);
+    void bind_source(uint32_t node, const void* dev);
+    // n_calls ModuleT::run_tick calls of frames_per_call mono samples each, back to back
+    void run(uint64_t t0, size_t frames_per_call, uint32_t n_calls, float* ms_by_kind = nullptr, float* ms_total = nullptr);
+    void sync();
+    void read_output(uint32_t node, uint32_t port, float* host, size_t frames);
+    float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_frame);
+    int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
+    void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
+    // module compat path: an InputRef may be Disconnected on one call and connected on the next
+    void set_input_enabled(uint32_t node, uint32_t port, bool enabled);
+
+private:
+    void layout_slab();
+    void build_descriptors();
+    void upload_group(Group& g);
+    const float* in_ptr(const Node& n, uint32_t port, bool null_if_disconnected) const;
+    float* out_ptr(const Node& n, uint32_t port) const;
+
+    std::vector<Node> nodes_;
+    std::vector<uint32_t> order_;
+    std::vector<Group> groups_;   // sorted by (level, kind)
+    uint32_t flags_ = 0;
+    double sample_rate_ = 44100.0;
+    size_t spt_ = 735;
+    size_t cap_frames_ = 735;
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+    DevBuf slab_;
+    size_t zero_off_ = 0;
+    size_t slab_floats_ = 0;
+    double lo_f_ = 0, hi_f_ = 0;
+    // plotter staging
+    DevBuf plot_stage_, plot_jobs_;
+    size_t last_frames_per_call_ = 0;
+    uint32_t last_calls_ = 0;
+};
+
+}  // namespace mx

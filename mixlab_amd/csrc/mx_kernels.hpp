@@ -1,0 +1,60 @@
+// mx_kernels.hpp -- per-kind device descriptors and launcher prototypes (internal).
+//
+// One launch handles every instance of one module kind at one dependency level: instance = blockIdx.y
+// (streaming kernels) or one wave / one lane (recurrences).  Descriptors are plain structs in device
+// memory; all port buffers are raw device pointers into the graph's HBM slab (or caller-bound memory).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mx {
+
+// src/module/amplifier.rs:38-60
+struct AmpDesc { const float* in; const float* ctl; /* nullptr => Disconnected => mod 1.0 */ float* out; double amplitude; double mod_depth; };
+
+// src/module/envelope.rs:34-58,91-120.  Reciprocals are loop-invariant subexpressions of the
+// reference (`1.0 / params.attack_ms * ms`), evaluated once on the host with the same IEEE division.
+struct EnvDesc {
+    const float* gate; float* out;
+    double attack_ms, inv_attack, inv_decay, sustain, one_minus_sustain, inv_release;
+};
+struct EnvState { uint32_t tag; uint32_t pad; uint64_t seq; double off_amplitude; };  // EnvelopeState, envelope.rs:8-13
+
+// src/module/eq_three.rs:58-89
+struct EqDesc { const float* in; float* out; double gain_lo, gain_mid, gain_hi; };
+struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };       // eq_three.rs:13-26,100-103
+
+// src/module/fm_sine.rs:37-56
+struct FmDesc { const float* in; float* out; double freq_mid, freq_amp; };
+
+// src/module/mixer.rs:46-71
+struct MixChan { const float* in; double gain; /* fader * 10^(dB/20), mixer.rs:59 */ uint32_t cue; uint32_t pad; };
+struct MixDesc { const MixChan* chans; uint32_t n_ch; uint32_t pad; float* master; float* cue; };
+
+// src/module/oscillator.rs:65-92
+struct OscDesc { float* mono; float* stereo; double freq; uint32_t waveform; uint32_t pad; };
+
+// src/module/stereo_panner.rs:30-41 / stereo_splitter.rs:33-47
+struct PanDesc { const float* l; const float* r; float* out; };
+struct SplitDesc { const float* in; float* l; float* r; };
+
+// src/module/trigger.rs:35-48
+struct TrigDesc { float* out; float value; uint32_t pad; };
+
+// src/module/plotter.rs:37-56: de-interleave the fired ticks into a staging area
+struct PlotJob { const float* in; float* left; float* right; };
+
+// Launchers.  `frames` = mono samples in this run (= n_ticks * SPT); stereo buffers hold 2*frames.
+void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f, hipStream_t s);
+void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
+void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
+void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s);
+
+}  // namespace mx

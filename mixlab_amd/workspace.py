@@ -1,0 +1,73 @@
+"""Host-side graph description: the frozen part of the reference's Workspace
+(src/engine/workspace.rs:13-19 -- modules + connections), in the form both the C ABI
+(include/mixlab_gpu.h: mx_node / mx_edge) and the test oracle consume.
+
+Defaults follow protocol/src/lib.rs (EnvelopeParams::default :318-327, MixerChannelParams::default
+:342-347 -- gain 0 dB, fader 0.0, cue false).
+"""
+from __future__ import annotations
+
+from . import abi
+
+
+class Workspace:
+    def __init__(self, sample_rate: int = 44100, ticks_per_second: int = 60):
+        self.sample_rate = sample_rate
+        self.ticks_per_second = ticks_per_second
+        self.nodes: list[tuple[int, object]] = []
+        self.edges: list[tuple[int, int, int, int]] = []
+
+    @property
+    def spt(self) -> int:
+        return self.sample_rate // self.ticks_per_second  # src/engine.rs:55
+
+    def add(self, kind: int, params=None) -> int:
+        self.nodes.append((kind, params))
+        return len(self.nodes) - 1
+
+    def connect(self, src: int, src_port: int, dst: int, dst_port: int) -> None:
+        """InputId(dst, dst_port) -> OutputId(src, src_port); a later connect to the same input replaces it
+        (HashMap insert, src/engine/workspace.rs:110)."""
+        self.edges = [e for e in self.edges if not (e[2] == dst and e[3] == dst_port)]
+        self.edges.append((src, src_port, dst, dst_port))
+
+    # ---- module constructors (ModuleT::create) ----
+    def oscillator(self, freq: float, waveform: int) -> int:
+        return self.add(abi.KIND_OSCILLATOR, abi.OscillatorParams(freq, waveform, 0))
+
+    def mixer(self, channels) -> int:
+        """channels: iterable of (gain_db, fader, cue)."""
+        return self.add(abi.KIND_MIXER, [abi.MixerChannelParams(g, f, 1 if c else 0) for (g, f, c) in channels])
+
+    def eq_three(self, lo_db: float, mid_db: float, hi_db: float) -> int:
+        return self.add(abi.KIND_EQ_THREE, abi.EqThreeParams(lo_db, mid_db, hi_db))
+
+    def envelope(self, attack_ms=25.0, decay_ms=500.0, sustain=0.8, release_ms=200.0) -> int:
+        return self.add(abi.KIND_ENVELOPE, abi.EnvelopeParams(attack_ms, decay_ms, sustain, release_ms))
+
+    def amplifier(self, amplitude: float, mod_depth: float) -> int:
+        return self.add(abi.KIND_AMPLIFIER, abi.AmplifierParams(amplitude, mod_depth))
+
+    def fm_sine(self, freq_lo: float, freq_hi: float) -> int:
+        return self.add(abi.KIND_FM_SINE, abi.FmSineParams(freq_lo, freq_hi))
+
+    def trigger(self, gate_open: bool) -> int:
+        return self.add(abi.KIND_TRIGGER, abi.TriggerParams(1 if gate_open else 0))
+
+    def stereo_panner(self) -> int:
+        return self.add(abi.KIND_STEREO_PANNER, None)
+
+    def stereo_splitter(self) -> int:
+        return self.add(abi.KIND_STEREO_SPLITTER, None)
+
+    def plotter(self) -> int:
+        return self.add(abi.KIND_PLOTTER, None)
+
+    def source_mono(self) -> int:
+        return self.add(abi.KIND_SOURCE_MONO, None)
+
+    def source_stereo(self) -> int:
+        return self.add(abi.KIND_SOURCE_STEREO, None)
+
+    def build(self, max_ticks_per_run: int = 1, flags: int = 0, device: int = -1, stream=None) -> "abi.Graph":
+        return abi.Graph(self.nodes, self.edges, self.sample_rate, self.ticks_per_second, max_ticks_per_run, flags, device, stream)

@@ -357,6 +357,12 @@ void orc_graph_destroy(orc_graph* g) {
 
 size_t orc_graph_samples_per_tick(const orc_graph* g) { return g->spt; }
 
+int orc_graph_update_params(orc_graph* g, uint32_t node, const void* params, uint32_t params_len) {
+    if (node >= g->n_nodes || g->nodes[node].params_len != params_len) return -1;
+    if (params_len) memcpy(g->nodes[node].params, params, params_len);
+    return 0;
+}
+
 int orc_graph_set_source(orc_graph* g, uint32_t node, const float* samples) {
     if (node >= g->n_nodes) return -1;
     onode* n = &g->nodes[node];

@@ -115,6 +115,8 @@ orc_graph* orc_graph_build(const orc_node* nodes, size_t n_nodes, const orc_edge
                            uint32_t sample_rate, uint32_t ticks_per_second);
 void orc_graph_destroy(orc_graph* g);
 size_t orc_graph_samples_per_tick(const orc_graph* g);
+/* ModuleT::update (src/module/mod.rs:16): replace a node's params between ticks (same length) */
+int orc_graph_update_params(orc_graph* g, uint32_t node, const void* params, uint32_t params_len);
 /* host-fed source ports: pointer is read during run_tick (SPT mono / 2*SPT stereo floats) */
 int orc_graph_set_source(orc_graph* g, uint32_t node, const float* samples);
 /* one Engine::run_tick: fresh zeroed outputs, topological order, t = tick * SPT */

@@ -1,0 +1,338 @@
+"""GPU parity: hand-written HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for every module whose arithmetic order is preserved (Mixer, EqThree exact mode,
+Envelope, Amplifier, shuffles, Saw/Triangle oscillators); <= 1 f32 ULP where the device's f64 sin
+(ocml) stands in for the host libm (Sine/Square oscillators, FmSine).
+
+Everything except EqThree is unpinned by reference tests: the oracle restates the
+reference source and these tests are only as good as that restatement.
+"""
+import pathlib
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from mixlab_amd.workspace import Workspace
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = pathlib.Path(__file__).resolve().parent / "golden"
+SR = 44100
+SPT = 735
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_exact(got, want, what=""):
+    bad = np.flatnonzero(bits(got) != bits(want))
+    assert bad.size == 0, f"{what}: {bad.size}/{got.size} samples differ, first at {bad[:5]}: got {got[bad[:5]]} want {want[bad[:5]]}"
+
+
+def assert_ulp(got, want, max_ulp, what=""):
+    d = synth.ulp_diff(got, want)
+    assert d.max() <= max_ulp, f"{what}: max {d.max()} ULP (> {max_ulp}); {np.count_nonzero(d)} / {d.size} samples differ"
+    return int(np.count_nonzero(d))
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own golden vectors (src/module/eq_three.rs:150-167), through the device
+# ------------------------------------------------------------------------------------------------
+def _golden():
+    x = np.fromfile(GOLDEN / "eq_three_chronos_prefix131072.f32.raw", dtype="<f4")
+    y = np.fromfile(GOLDEN / "eq_three_chronos-eq_prefix131072.f32.raw", dtype="<f4")
+    return x, y
+
+
+def test_eq_three_reference_golden_one_call_exact_mode():
+    x, y = _golden()
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(4.0, 0.0, 4.0), flags=abi.FLAG_EQ_EXACT)
+    out = np.zeros_like(x)
+    m.run_tick(0, [(abi.MX_MONO, x)], [(abi.MX_MONO, out)])
+    assert_bit_exact(out, y, "EqThree golden, one call")
+
+
+def test_eq_three_reference_golden_ticked_state_carry_exact_mode():
+    x, y = _golden()
+    n_ticks = 64
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(4.0, 0.0, 4.0), flags=abi.FLAG_EQ_EXACT)
+    out = np.zeros(n_ticks * SPT, dtype=np.float32)
+    for k in range(n_ticks):
+        m.run_tick(k * SPT, [(abi.MX_MONO, x[k * SPT:(k + 1) * SPT])], [(abi.MX_MONO, out[k * SPT:(k + 1) * SPT])])
+    assert_bit_exact(out, y[: n_ticks * SPT], "EqThree golden, 735-sample ticks")
+
+
+def test_eq_three_reference_golden_default_mode_within_one_ulp():
+    x, y = _golden()
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(4.0, 0.0, 4.0))
+    out = np.zeros_like(x)
+    m.run_tick(0, [(abi.MX_MONO, x)], [(abi.MX_MONO, out)])
+    assert_ulp(out, y, 1, "EqThree golden, default (time-parallel) mode")
+
+
+# ------------------------------------------------------------------------------------------------
+# per-module parity through mx_module_run_tick (the ModuleT::run_tick surface)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_ch,length", [(1, 2 * SPT), (4, 2 * SPT), (37, 2 * SPT), (256, 2 * 800), (3, 2 * 733)])
+def test_mixer_bit_exact(n_ch, length):
+    gains = synth.uniform(1, n_ch, -24.0, 6.0)
+    faders = synth.uniform(2, n_ch, 0.0, 1.0)
+    chans = [(float(gains[i]), float(faders[i]), i % 3 == 1) for i in range(n_ch)]
+    ins = [synth.noise(100 + i, length) for i in range(n_ch)]
+    if n_ch > 2:
+        ins[2] = None  # Disconnected input reads the zero buffer (src/engine/io.rs:45-52)
+    want_m, want_c = oracle.mixer_run(chans, ins, length)
+    m = abi.Module(abi.KIND_MIXER, [abi.MixerChannelParams(g, f, 1 if c else 0) for g, f, c in chans])
+    got_m = np.empty(length, np.float32)
+    got_c = np.empty(length, np.float32)
+    m.run_tick(0, [(abi.MX_STEREO if a is not None else abi.MX_DISCONNECTED, a) for a in ins],
+               [(abi.MX_STEREO, got_m), (abi.MX_STEREO, got_c)])
+    assert_bit_exact(got_m, want_m, "Mixer master")
+    assert_bit_exact(got_c, want_c, "Mixer cue")
+
+
+def test_mixer_default_channels_are_silent():
+    # MixerChannelParams::default has fader 0.0 (protocol/src/lib.rs:342-347)
+    ins = [synth.noise(7, 2 * SPT), synth.noise(8, 2 * SPT)]
+    m = abi.Module(abi.KIND_MIXER, [abi.MixerChannelParams(0.0, 0.0, 0)] * 2)
+    got_m = np.ones(2 * SPT, np.float32)
+    got_c = np.ones(2 * SPT, np.float32)
+    m.run_tick(0, [(abi.MX_STEREO, a) for a in ins], [(abi.MX_STEREO, got_m), (abi.MX_STEREO, got_c)])
+    assert not got_m.any() and not got_c.any()
+
+
+@pytest.mark.parametrize("gains", [(4.0, 0.0, 4.0), (-24.0, 6.0, -3.5), (0.0, 0.0, 0.0)])
+def test_eq_three_exact_vs_oracle_with_state(gains):
+    x = synth.noise(11, 40 * SPT)
+    st = oracle.eq_three_new(SR)
+    want = oracle.eq_three_run(st, gains, x)
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(*gains), flags=abi.FLAG_EQ_EXACT)
+    got = np.empty_like(x)
+    for k in range(40):
+        m.run_tick(k * SPT, [(abi.MX_MONO, x[k * SPT:(k + 1) * SPT])], [(abi.MX_MONO, got[k * SPT:(k + 1) * SPT])])
+    assert_bit_exact(got, want, "EqThree exact")
+
+
+def test_eq_three_disconnected_input():
+    st = oracle.eq_three_new(SR)
+    want = oracle.eq_three_run(st, (3.0, -2.0, 1.0), np.zeros(SPT, np.float32))
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(3.0, -2.0, 1.0), flags=abi.FLAG_EQ_EXACT)
+    got = np.empty(SPT, np.float32)
+    m.run_tick(0, [(abi.MX_DISCONNECTED, None)], [(abi.MX_MONO, got)])
+    assert_bit_exact(got, want, "EqThree disconnected")
+
+
+def _gate_patterns():
+    n = 12 * SPT
+    pats = {}
+    g = np.zeros(n, np.float32); g[100:3000] = 1.0; g[5000:5010] = 1.0; g[7000:] = 1.0
+    pats["blocks"] = g
+    g = synth.noise(5, n).copy(); g[::97] = 1.0; g[50::131] = 0.0            # markers sprinkled in noise
+    pats["sprinkled"] = g
+    g = np.full(n, 0.5, np.float32); g[63] = 1.0; g[64] = 0.0; g[127] = 1.0; g[128] = 1.0; g[191] = 0.0  # wave-boundary edges
+    pats["boundaries"] = g
+    pats["always_on"] = np.ones(n, np.float32)
+    pats["never"] = np.full(n, 0.25, np.float32)
+    g = np.zeros(n, np.float32); g[1::2] = 1.0
+    pats["alternating"] = g
+    return pats
+
+
+@pytest.mark.parametrize("name", list(_gate_patterns().keys()))
+@pytest.mark.parametrize("params", [(25.0, 500.0, 0.8, 200.0), (1.0, 10.0, 0.3, 5.0)])
+def test_envelope_bit_exact(name, params):
+    gate = _gate_patterns()[name]
+    n_ticks = gate.size // SPT
+    st = oracle.EnvState()
+    want = np.concatenate([oracle.envelope_run(st, params, SR, k * SPT, gate[k * SPT:(k + 1) * SPT], SPT) for k in range(n_ticks)])
+    m = abi.Module(abi.KIND_ENVELOPE, abi.EnvelopeParams(*params))
+    got = np.empty_like(want)
+    for k in range(n_ticks):
+        m.run_tick(k * SPT, [(abi.MX_MONO, gate[k * SPT:(k + 1) * SPT])], [(abi.MX_MONO, got[k * SPT:(k + 1) * SPT])])
+    assert_bit_exact(got, want, f"Envelope {name}")
+
+
+@pytest.mark.parametrize("ctl_connected", [True, False])
+@pytest.mark.parametrize("amp,depth", [(1.0, 0.5), (0.7, 0.1), (2.0, 1.0), (1.0, 0.0)])
+def test_amplifier_bit_exact(ctl_connected, amp, depth):
+    x = synth.noise(21, 2 * SPT)
+    ctl = synth.noise(22, SPT) if ctl_connected else None
+    want = oracle.amplifier_run(amp, depth, x, ctl)
+    m = abi.Module(abi.KIND_AMPLIFIER, abi.AmplifierParams(amp, depth))
+    got = np.empty_like(x)
+    m.run_tick(0, [(abi.MX_STEREO, x), (abi.MX_MONO if ctl_connected else abi.MX_DISCONNECTED, ctl)], [(abi.MX_STEREO, got)])
+    assert_bit_exact(got, want, "Amplifier")
+
+
+@pytest.mark.parametrize("wave,exact", [(abi.WAVE_SAW, True), (abi.WAVE_TRIANGLE, True), (abi.WAVE_ON, True), (abi.WAVE_OFF, True),
+                                        (abi.WAVE_SINE, False), (abi.WAVE_SQUARE, False)])
+@pytest.mark.parametrize("freq,t", [(100.0, 0), (440.0, 735 * 1000), (880.5, 735 * 216000)])
+def test_oscillator(wave, exact, freq, t):
+    want_m, want_s = oracle.oscillator_run(freq, wave, SR, t, SPT)
+    m = abi.Module(abi.KIND_OSCILLATOR, abi.OscillatorParams(freq, wave, 0))
+    got_m = np.empty(SPT, np.float32)
+    got_s = np.empty(2 * SPT, np.float32)
+    m.run_tick(t, [], [(abi.MX_MONO, got_m), (abi.MX_STEREO, got_s)])
+    assert_bit_exact(got_s[0::2], got_m, "stereo L == mono")
+    assert_bit_exact(got_s[1::2], got_m, "stereo R == mono")
+    if exact:
+        assert_bit_exact(got_m, want_m, "Oscillator")
+    elif wave == abi.WAVE_SQUARE:
+        # sign(sin) flips only if the two libms disagree on the sign of a near-zero sine
+        assert np.count_nonzero(got_m != want_m) <= 2
+    else:
+        assert_ulp(got_m, want_m, 1, "Oscillator sine (device sin vs host libm)")
+
+
+@pytest.mark.parametrize("t", [0, 735 * 5000])
+def test_fm_sine_within_one_ulp(t):
+    x = synth.noise(31, SPT)
+    want = oracle.fm_sine_run(220.0, 880.0, SR, t, x, SPT)
+    m = abi.Module(abi.KIND_FM_SINE, abi.FmSineParams(220.0, 880.0))
+    got = np.empty(2 * SPT, np.float32)
+    m.run_tick(t, [(abi.MX_MONO, x)], [(abi.MX_STEREO, got)])
+    assert_ulp(got, want, 1, "FmSine")
+
+
+def test_trigger_panner_splitter_exact():
+    for gate_open in (True, False):
+        m = abi.Module(abi.KIND_TRIGGER, abi.TriggerParams(1 if gate_open else 0))
+        got = np.empty(SPT, np.float32)
+        m.run_tick(0, [], [(abi.MX_MONO, got)])
+        assert (got == (1.0 if gate_open else 0.0)).all()
+    l, r = synth.noise(41, SPT), synth.noise(42, SPT)
+    m = abi.Module(abi.KIND_STEREO_PANNER)
+    st = np.empty(2 * SPT, np.float32)
+    m.run_tick(0, [(abi.MX_MONO, l), (abi.MX_MONO, r)], [(abi.MX_STEREO, st)])
+    assert_bit_exact(st[0::2], l); assert_bit_exact(st[1::2], r)
+    m = abi.Module(abi.KIND_STEREO_SPLITTER)
+    l2, r2 = np.empty(SPT, np.float32), np.empty(SPT, np.float32)
+    m.run_tick(0, [(abi.MX_STEREO, st)], [(abi.MX_MONO, l2), (abi.MX_MONO, r2)])
+    assert_bit_exact(l2, l); assert_bit_exact(r2, r)
+    # panner with R disconnected
+    m = abi.Module(abi.KIND_STEREO_PANNER)
+    m.run_tick(0, [(abi.MX_MONO, l), (abi.MX_DISCONNECTED, None)], [(abi.MX_STEREO, st)])
+    assert_bit_exact(st[0::2], l); assert not st[1::2].any()
+
+
+def test_plotter_fires_every_sixth_call():
+    m = abi.Module(abi.KIND_PLOTTER)
+    x = synth.noise(51, 2 * SPT)
+    ind = np.empty(2 * SPT, np.float32)
+    fired = []
+    for k in range(13):
+        n = m.run_tick(k * SPT, [(abi.MX_STEREO, x)], [], ind)
+        fired.append(n > 0)
+        if n:
+            assert n == 2 * SPT * 4
+            assert_bit_exact(ind[:SPT], x[0::2]); assert_bit_exact(ind[SPT:], x[1::2])
+    assert fired == [(k + 1) % 6 == 0 for k in range(13)]   # first fires on the 6th call (plotter.rs:38-40)
+
+
+def test_type_mismatch_is_reported_not_crashed():
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(0, 0, 0))
+    with pytest.raises(abi.MxError) as e:
+        m.run_tick(0, [(abi.MX_STEREO, np.zeros(2 * SPT, np.float32))], [(abi.MX_MONO, np.zeros(SPT, np.float32))])
+    assert e.value.code == abi.MX_ERR_TYPE   # the reference panics here (src/engine/io.rs:40-41)
+
+
+# ------------------------------------------------------------------------------------------------
+# graphs (Engine::run_tick): SURVEY.md section 8d configs 1 and 2
+# ------------------------------------------------------------------------------------------------
+def config1():
+    ws = Workspace(SR, 60)
+    oscs = [ws.oscillator(100.0, abi.WAVE_SINE), ws.oscillator(220.0, abi.WAVE_SAW),
+            ws.oscillator(440.0, abi.WAVE_SQUARE), ws.oscillator(880.0, abi.WAVE_TRIANGLE)]
+    mix = ws.mixer([(0.0, 1.0, False), (-6.0, 0.8, True), (3.0, 0.5, False), (-12.0, 0.25, True)])
+    plot = ws.plotter()
+    for i, o in enumerate(oscs):
+        ws.connect(o, 1, mix, i)
+    ws.connect(mix, 0, plot, 0)
+    return ws, oscs, mix, plot
+
+
+@pytest.mark.parametrize("batch", [1, 12])
+def test_config1_four_osc_mixer_plotter(batch):
+    ws, oscs, mix, plot = config1()
+    n_ticks = 120
+    og = oracle.OracleGraph(ws)
+    g = ws.build(max_ticks_per_run=batch, flags=abi.FLAG_EQ_EXACT)
+    assert g.run_order() == og.run_order()
+    worst = 0
+    for t0 in range(0, n_ticks, batch):
+        g.run_ticks(t0, batch)
+        got_m = g.read_output(mix, 0, batch, True)
+        got_c = g.read_output(mix, 1, batch, True)
+        for k in range(batch):
+            og.run_tick(t0 + k)
+            sl = slice(k * 2 * SPT, (k + 1) * 2 * SPT)
+            # sine / square inputs come from the device sin: <= 1 ULP each, so the mix is compared
+            # with a tolerance of a few ULP of the largest term instead of bit-exactly
+            wm, wc = og.output(mix, 0), og.output(mix, 1)
+            assert np.max(np.abs(got_m[sl] - wm)) <= 4 * np.spacing(np.float32(2.0))
+            assert np.max(np.abs(got_c[sl] - wc)) <= 4 * np.spacing(np.float32(2.0))
+            worst = max(worst, int(np.count_nonzero(bits(got_m[sl]) != bits(wm))))
+            want_p = og.plotter(plot)
+            got_p = g.read_plotter(plot, k)
+            assert (want_p is None) == (got_p is None)
+            if want_p is not None:
+                assert (t0 + k + 1) % 6 == 0
+                assert_bit_exact(got_p[0], got_m[sl][0::2]); assert_bit_exact(got_p[1], got_m[sl][1::2])
+
+
+def strips(n_strips, sr=SR):
+    """per strip Trigger->Envelope ; Source->EqThree->Panner(L=R)->Amplifier(ctl=Envelope) -> Mixer."""
+    ws = Workspace(sr, 60)
+    gains = synth.uniform(10, 3 * n_strips, -24.0, 6.0)
+    mg = synth.uniform(11, n_strips, -24.0, 6.0)
+    mf = synth.uniform(12, n_strips, 0.0, 1.0)
+    mix = ws.mixer([(float(mg[k]), float(mf[k]), k % 8 == 0) for k in range(n_strips)])
+    srcs, trigs = [], []
+    for k in range(n_strips):
+        trig = ws.trigger(False)
+        env = ws.envelope()
+        src = ws.source_mono()
+        eq = ws.eq_three(float(gains[3 * k]), float(gains[3 * k + 1]), float(gains[3 * k + 2]))
+        pan = ws.stereo_panner()
+        amp = ws.amplifier(1.0, 0.5)
+        ws.connect(trig, 0, env, 0)
+        ws.connect(src, 0, eq, 0)
+        ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1)
+        ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1)
+        ws.connect(amp, 0, mix, k)
+        srcs.append(src); trigs.append(trig)
+    return ws, mix, srcs, trigs
+
+
+@pytest.mark.parametrize("batch", [1, 6])
+def test_config2_strips_exact_mode_bit_exact(batch):
+    n_strips, n_ticks = 48, 60
+    ws, mix, srcs, trigs = strips(n_strips)
+    og = oracle.OracleGraph(ws)
+    g = ws.build(max_ticks_per_run=batch, flags=abi.FLAG_EQ_EXACT)
+    assert g.run_order() == og.run_order()
+    noise = [synth.noise(k, n_ticks * SPT) for k in range(n_strips)]
+    for t0 in range(0, n_ticks, batch):
+        # gate toggles every 30 ticks with per-strip phase k mod 60; params only change between runs,
+        # so batches are aligned to toggle points by construction (30 % batch == 0)
+        for k, tr in enumerate(trigs):
+            open_ = ((t0 + k) // 30) % 2 == 1
+            g.update_params(tr, abi.TriggerParams(1 if open_ else 0))
+            og.update_params(tr, abi.TriggerParams(1 if open_ else 0))
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][t0 * SPT:(t0 + batch) * SPT], batch)
+        g.run_ticks(t0, batch)
+        got_m = g.read_output(mix, 0, batch, True)
+        got_c = g.read_output(mix, 1, batch, True)
+        for kk in range(batch):
+            tick = t0 + kk
+            for k, s in enumerate(srcs):
+                og.set_source(s, noise[k][tick * SPT:(tick + 1) * SPT])
+            sl = slice(kk * 2 * SPT, (kk + 1) * 2 * SPT)
+            og.run_tick(tick)
+            assert_bit_exact(got_m[sl], og.output(mix, 0), f"master tick {tick}")
+            assert_bit_exact(got_c[sl], og.output(mix, 1), f"cue tick {tick}")
