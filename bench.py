@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the per-tick module-graph hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 1024 channel strips
+  Trigger -> Envelope ;  Source(noise) -> EqThree -> StereoPanner(L=R) -> Amplifier(ctl = Envelope) -> Mixer(1024)
+at 48 kHz (SPT = 800), T ticks batched per submission ("step" = one pass of the whole graph over T
+ticks of synthetic input already resident in HBM).  Metric: audio channels mixed per second =
+strip-ticks (one stereo strip processed and mixed for one 1/60 s tick) per second, whole job.
+
+N > 1 (BASELINE.json configs[4]): the 1024 strips are sharded contiguously over the
+ranks (strong scaling), each rank runs Mixer(1024/N) over its strips, the partial Master/Cue buses
+are exchanged with ONE RCCL all-gather per step and summed in rank order by a Mixer(N, unity) --
+i.e. the reference-expressible hierarchical graph N x Mixer(1024/N) -> Mixer(N).
+
+One JSON line on rank 0; see the task contract for the fields.  `roofline` describes the kernel
+that took the most device time in the timed region (hipEvents on the graph's stream);
+`cpu_baseline` is the CPU oracle (a C port of the reference algorithms, one thread like the
+reference's engine thread) timed on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+# algorithmic (module-boundary) bytes per instance per frame: every input port read once + every
+# output port written once; mixer is per input channel, +16/frame for its two outputs
+BYTES_PER_FRAME = {"trigger": 4, "envelope": 8, "eq_three": 8, "stereo_panner": 16, "amplifier": 20, "mixer": 8}
+
+
+def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate):
+    """Config-2 strips [first_strip, first_strip + n_strips) with the global seeded parameters."""
+    total = 1024 if first_strip + n_strips <= 1024 else first_strip + n_strips
+    eq_g = synth.uniform(10, 3 * total, -24.0, 6.0)
+    mg = synth.uniform(11, total, -24.0, 6.0)
+    mf = synth.uniform(12, total, 0.0, 1.0)
+    ws = Workspace(sample_rate, 60)
+    mix = ws.mixer([(float(mg[k]), float(mf[k]), k % 8 == 0) for k in range(first_strip, first_strip + n_strips)])
+    srcs = []
+    for j, k in enumerate(range(first_strip, first_strip + n_strips)):
+        trig = ws.trigger(((k % 60) // 30) == 1)   # gate phase k mod 60, held for the run
+        env = ws.envelope()                         # defaults 25/500/0.8/200 (protocol/src/lib.rs:318-327)
+        src = ws.source_mono()
+        eq = ws.eq_three(float(eq_g[3 * k]), float(eq_g[3 * k + 1]), float(eq_g[3 * k + 2]))
+        pan = ws.stereo_panner()
+        amp = ws.amplifier(1.0, 0.5)
+        ws.connect(trig, 0, env, 0)
+        ws.connect(src, 0, eq, 0)
+        ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1)
+        ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1)
+        ws.connect(amp, 0, mix, j)
+        srcs.append(src)
+    return ws, mix, srcs
+
+
+def cpu_baseline(Workspace, synth, abi, n_strips, sample_rate, target_seconds=12.0):
+    """Time the CPU oracle's graph runner (C, one thread) on a bounded sample of the same workload."""
+    import oracle  # test infrastructure: used here only as the timed CPU baseline
+
+    ws, mix, srcs = build_strips(abi, Workspace, synth, n_strips, 0, sample_rate)
+    og = oracle.OracleGraph(ws)
+    spt = ws.spt
+    noise = [synth.noise(k, spt) for k in range(n_strips)]
+    for s, nz in zip(srcs, noise):
+        og.set_source(s, nz)
+    # calibrate on a few ticks, then run a bounded number
+    t0 = time.perf_counter()
+    for t in range(4):
+        og.run_tick(t)
+    per_tick = (time.perf_counter() - t0) / 4
+    n_ticks = int(max(8, min(4000, target_seconds / max(per_tick, 1e-6))))
+    t0 = time.perf_counter()
+    for t in range(4, 4 + n_ticks):
+        og.run_tick(t)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_strips * n_ticks / dt, "unit": "channel-ticks/s", "cores": 1, "kind": "port",
+        "sample": f"{n_strips} strips x {n_ticks} ticks @ {sample_rate} Hz, single thread (the reference engine is one thread, src/engine.rs:78), {dt:.1f} s",
+        "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
+    }
+
+
+class _DevArray:
+    """zero-copy torch view of a device buffer owned by libmixlab_gpu (plumbing for RCCL)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def dev_view(torch, ptr, n):
+    return torch.as_tensor(_DevArray(ptr, n), device="cuda")
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--strips", type=int, default=1024)
+    ap.add_argument("--ticks-per-step", type=int, default=64)
+    ap.add_argument("--sample-rate", type=int, default=48000)
+    ap.add_argument("--eq-exact", action="store_true", help="strictly sequential EqThree (bit-exact order) instead of the time-parallel scan")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import synth
+    from mixlab_amd import abi
+    from mixlab_amd.workspace import Workspace
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    T, SR = args.ticks_per_step, args.sample_rate
+    spt = SR // 60
+    assert args.strips % world == 0
+    local_strips = args.strips // world
+    first = rank * local_strips
+
+    stream = torch.cuda.Stream()
+    flags = abi.FLAG_EQ_EXACT if args.eq_exact else 0
+    ws, mix, srcs = build_strips(abi, Workspace, synth, local_strips, first, SR)
+    g = ws.build(max_ticks_per_run=T, flags=flags, device=local_rank, stream=stream.cuda_stream)
+
+    # synthetic sources, resident in HBM before the timed region (uploaded once, re-read every step)
+    for j, s in enumerate(srcs):
+        g.write_source(s, synth.noise(first + j, T * spt), T)
+
+    # N > 1: partial buses -> all_gather -> rank-ordered Mixer(N, unity gains) on every rank
+    combine = None
+    if world > 1:
+        m_ptr, fpt = g.output_device_ptr(mix, 0)
+        c_ptr, _ = g.output_device_ptr(mix, 1)
+        n_fl = fpt * T
+        part = torch.empty(2 * n_fl, dtype=torch.float32, device="cuda")
+        gathered = torch.empty(world * 2 * n_fl, dtype=torch.float32, device="cuda")
+        cws = Workspace(SR, 60)
+        fm = cws.mixer([(0.0, 1.0, False)] * world)   # unity gains: the f32 sum of partials in rank order
+        fc = cws.mixer([(0.0, 1.0, False)] * world)
+        c_srcs_m = [cws.source_stereo() for _ in range(world)]
+        c_srcs_c = [cws.source_stereo() for _ in range(world)]
+        for r in range(world):
+            cws.connect(c_srcs_m[r], 0, fm, r)
+            cws.connect(c_srcs_c[r], 0, fc, r)
+        cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
+        for r in range(world):
+            cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + (r * 2 * n_fl) * 4)
+            cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + (r * 2 * n_fl + n_fl) * 4)
+        m_view, c_view = dev_view(torch, m_ptr, n_fl), dev_view(torch, c_ptr, n_fl)
+
+        def combine():
+            # device-to-device pack of (master, cue), then ONE all_gather per step, stream-ordered
+            part[:n_fl].copy_(m_view)
+            part[n_fl:].copy_(c_view)
+            dist.all_gather_into_tensor(gathered, part)
+            cg.run_ticks(0, T)
+
+    def step(i):
+        g.run_ticks(i * T, T)
+        if combine is not None:
+            combine()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        g.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        g.profile_enable(False)
+        by_kind, prof_total_ms, n_prof = g.profile_collect()
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        units = args.strips * T * args.steps
+        value = units / dt
+        # dominant kernel of the timed region
+        dom = max(by_kind, key=by_kind.get) if by_kind else None
+        roof = None
+        if dom is not None and n_prof:
+            avg_ms = by_kind[dom] / n_prof
+            frames = T * spt
+            if dom == "mixer":
+                alg = BYTES_PER_FRAME["mixer"] * (local_strips + 2) * frames
+            else:
+                alg = BYTES_PER_FRAME.get(dom, 0) * local_strips * frames
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": alg,
+                    "kernel_ms_per_step": {k: round(v / n_prof, 5) for k, v in sorted(by_kind.items())}}
+        whole_alg = 51200 * (SR / 48000.0) * local_strips * T   # module-boundary bytes of one step on one rank
+        out = {
+            "metric": "audio_ch_mixed_per_sec", "value": value, "unit": "channel-ticks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (f64 intermediates)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.strips}-channel Mixer + EqThree + Envelope chain (Trigger->Envelope; noise->EqThree->StereoPanner->Amplifier->Mixer), {SR} Hz f32",
+                       "strips": args.strips, "ticks_per_step": T, "samples_per_tick": spt,
+                       "eq_mode": "exact-sequential" if args.eq_exact else "time-parallel",
+                       "parallelism": f"strips sharded x{world}" + (", all-gather + rank-ordered Mixer" if world > 1 else "")},
+            "realtime_channels_equiv": value / 60.0,
+            "graph_hbm_frac": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof,
+        }
+        if args.no_cpu_baseline or world > 1:
+            out["cpu_baseline"] = None
+        else:
+            out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR)
+        print(json.dumps(out))
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

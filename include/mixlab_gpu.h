@@ -132,6 +132,11 @@ int mx_graph_read_plotter(mx_graph* g, uint32_t node, uint32_t tick_in_run, floa
 /* Per-kind device time of the last profiled run (the PerformanceInfo analogue,
  * src/engine/timing.rs:86-94): run once with hipEvents around every launch group. */
 int mx_graph_profile_run(mx_graph* g, uint64_t first_tick, uint32_t n_ticks, float* ms_by_kind /* MX_KIND_COUNT */, float* ms_total);
+/* Same, accumulated over many asynchronous runs: while enabled every mx_graph_run_ticks records a
+ * hipEvent before/after each launch group on the graph's stream (no synchronisation);
+ * collect synchronises and returns the sums (ms) and the number of runs they cover. */
+int mx_graph_profile_enable(mx_graph* g, int on);
+int mx_graph_profile_collect(mx_graph* g, float* ms_by_kind /* MX_KIND_COUNT */, float* ms_total, uint32_t* n_runs);
 
 /* ---- per-module compatibility path: one ModuleT instance, host pointers in and out ---- */
 typedef struct {

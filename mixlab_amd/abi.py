@@ -109,6 +109,8 @@ _proto("mx_graph_read_output", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_
 _proto("mx_graph_output_device_ptr", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 _proto("mx_graph_read_plotter", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int))
 _proto("mx_graph_profile_run", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+_proto("mx_graph_profile_enable", C.c_int, C.c_void_p, C.c_int)
+_proto("mx_graph_profile_collect", C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32))
 _proto("mx_module_create", C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p))
 _proto("mx_module_create_ex", C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(GraphOpts), C.POINTER(C.c_void_p))
 _proto("mx_module_update", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -219,6 +221,18 @@ class Graph:
         total = C.c_float()
         check(lib.mx_graph_profile_run(self._h, first_tick, n_ticks, by_kind, C.byref(total)))
         return {KIND_NAMES[k]: by_kind[k] for k in range(KIND_COUNT) if by_kind[k] > 0}, total.value
+
+
+    def profile_enable(self, on: bool):
+        check(lib.mx_graph_profile_enable(self._h, 1 if on else 0))
+
+    def profile_collect(self):
+        """-> ({kind_name: total ms}, total ms, n_runs) accumulated since profile_enable(True)."""
+        by_kind = (C.c_float * KIND_COUNT)()
+        total = C.c_float()
+        n = C.c_uint32()
+        check(lib.mx_graph_profile_collect(self._h, by_kind, C.byref(total), C.byref(n)))
+        return {KIND_NAMES[k]: by_kind[k] for k in range(KIND_COUNT) if by_kind[k] > 0}, total.value, n.value
 
 
 class Module:

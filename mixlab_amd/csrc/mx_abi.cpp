@@ -137,6 +137,18 @@ int mx_graph_profile_run(mx_graph* g, uint64_t first_tick, uint32_t n_ticks, flo
     });
 }
 
+int mx_graph_profile_enable(mx_graph* g, int on) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->profile_enable(on != 0); });
+}
+
+int mx_graph_profile_collect(mx_graph* g, float* ms_by_kind, float* ms_total, uint32_t* n_runs) {
+    return guard([&] {
+        REQUIRE(g && ms_by_kind, "NULL argument");
+        const uint32_t n = g->g->profile_collect(ms_by_kind, ms_total);
+        if (n_runs) *n_runs = n;
+    });
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 /* per-module compatibility path                                                                    */
 /* ---------------------------------------------------------------------------------------------- */

@@ -156,6 +156,8 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
 
 Graph::~Graph() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
+    for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -356,11 +358,14 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     if (n_calls == 0 || fpc == 0) { last_calls_ = n_calls; last_frames_per_call_ = fpc; return; }
     hip_check(hipSetDevice(device_), "hipSetDevice");
 
-    const bool prof = ms_by_kind != nullptr;
+    const bool prof = ms_by_kind != nullptr || prof_on_;
     std::vector<hipEvent_t> ev;
     if (prof) {
-        ev.resize(groups_.size() + 1);
-        for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
+        if (!prof_pool_.empty()) { ev = std::move(prof_pool_.back()); prof_pool_.pop_back(); }
+        else {
+            ev.resize(groups_.size() + 1);
+            for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
+        }
         hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
     }
 
@@ -425,17 +430,28 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     last_calls_ = n_calls;
     last_frames_per_call_ = fpc;
 
-    if (prof) {
-        sync();
-        for (int k = 0; k < MX_KIND_COUNT; ++k) ms_by_kind[k] = 0.f;
-        for (size_t i = 0; i < groups_.size(); ++i) {
+    if (prof) prof_runs_.push_back(std::move(ev));
+    if (ms_by_kind) (void)profile_collect(ms_by_kind, ms_total);
+}
+
+void Graph::profile_enable(bool on) { prof_on_ = on; }
+
+uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
+    sync();
+    if (ms_by_kind) for (int k = 0; k < MX_KIND_COUNT; ++k) ms_by_kind[k] = 0.f;
+    if (ms_total) *ms_total = 0.f;
+    const uint32_t n = (uint32_t)prof_runs_.size();
+    for (auto& ev : prof_runs_) {
+        for (size_t i = 0; i + 1 < ev.size() && i < groups_.size(); ++i) {
             float ms = 0.f;
             hip_check(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "hipEventElapsedTime");
-            ms_by_kind[groups_[i].kind] += ms;
+            if (ms_by_kind) ms_by_kind[groups_[i].kind] += ms;
         }
-        if (ms_total) hip_check(hipEventElapsedTime(ms_total, ev.front(), ev.back()), "hipEventElapsedTime");
-        for (auto& e : ev) (void)hipEventDestroy(e);
+        if (ms_total) { float ms = 0.f; hip_check(hipEventElapsedTime(&ms, ev.front(), ev.back()), "hipEventElapsedTime"); *ms_total += ms; }
+        prof_pool_.push_back(std::move(ev));
     }
+    prof_runs_.clear();
+    return n;
 }
 
 void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames) {

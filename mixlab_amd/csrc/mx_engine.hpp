@@ -86,6 +86,9 @@ public:
     // n_calls ModuleT::run_tick calls of frames_per_call mono samples each, back to back
     void run(uint64_t t0, size_t frames_per_call, uint32_t n_calls, float* ms_by_kind = nullptr, float* ms_total = nullptr);
     void sync();
+    // accumulate per-group hipEvent timings across runs without synchronising (bench: kernel time over the timed region)
+    void profile_enable(bool on);
+    uint32_t profile_collect(float* ms_by_kind, float* ms_total);   // syncs; returns number of runs collected
     void read_output(uint32_t node, uint32_t port, float* host, size_t frames);
     float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_frame);
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
@@ -117,6 +120,9 @@ private:
     // plotter staging
     DevBuf plot_stage_, plot_jobs_;
     size_t last_frames_per_call_ = 0;
+    bool prof_on_ = false;
+    std::vector<std::vector<hipEvent_t>> prof_runs_;   // one event list (groups+1) per recorded run
+    std::vector<std::vector<hipEvent_t>> prof_pool_;
     uint32_t last_calls_ = 0;
 };
 
