@@ -50,6 +50,24 @@ static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& i
     }
 }
 
+// first column of A^n for the 4-pole cascade's one-sample matrix A (lower-triangular Toeplitz,
+// first column f^k (1-f)): binary exponentiation on polynomials mod x^4, in long double
+static void toeplitz_pow(long double f, uint64_t n, double out[4]) {
+    long double base[4] = {1.0L - f, f * (1.0L - f), f * f * (1.0L - f), f * f * f * (1.0L - f)};
+    long double res[4] = {1.0L, 0.0L, 0.0L, 0.0L};
+    auto mul = [](const long double a[4], const long double b[4], long double c[4]) {
+        long double t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) for (int j = 0; i + j < 4; ++j) t[i + j] += a[i] * b[j];
+        for (int i = 0; i < 4; ++i) c[i] = t[i];
+    };
+    while (n) {
+        if (n & 1) mul(res, base, res);
+        mul(base, base, base);
+        n >>= 1;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = (double)res[i];
+}
+
 static inline size_t floats_per_frame(uint8_t lt) { return lt == MX_MONO ? 1 : (lt == MX_STEREO ? 2 : 0); }
 
 Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t n_edges, const mx_graph_opts& o,
@@ -149,6 +167,20 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         n.group = (int)groups_.size() - 1;
         n.slot = (uint32_t)groups_.back().nodes.size();
         groups_.back().nodes.push_back(id);
+    }
+    // time-parallel EqThree tables (unused in MX_FLAG_EQ_EXACT mode)
+    {
+        std::vector<EqScanTab> tabs(4);
+        const long double fs[2] = {(long double)lo_f_, (long double)hi_f_};
+        for (int v = 0; v < 4; ++v) {
+            const uint64_t L = 4ull << v;
+            for (int f = 0; f < 2; ++f) {
+                for (int j = 0; j <= 64; ++j) toeplitz_pow(fs[f], L * (uint64_t)j, tabs[v].pw[f][j]);
+                for (int k = 0; k < 6; ++k) toeplitz_pow(fs[f], L << k, tabs[v].p2[f][k]);
+            }
+        }
+        eq_tabs_.alloc(tabs.size() * sizeof(EqScanTab));
+        hip_check(hipMemcpy(eq_tabs_.p, tabs.data(), tabs.size() * sizeof(EqScanTab), hipMemcpyHostToDevice), "hipMemcpy(eq tabs)");
     }
     layout_slab();
     build_descriptors();
@@ -394,7 +426,10 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         switch (g.kind) {
         case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, frames, stream_); break;
         case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, frames, t0, sample_rate_, stream_); break;
-        case MX_KIND_EQ_THREE: launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, lo_f_, hi_f_, stream_); break;
+        case MX_KIND_EQ_THREE:
+            if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, lo_f_, hi_f_, stream_);
+            else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
+            break;
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
         case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, frames, stream_); break;
         case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;

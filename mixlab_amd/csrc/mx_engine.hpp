@@ -117,6 +117,7 @@ private:
     size_t zero_off_ = 0;
     size_t slab_floats_ = 0;
     double lo_f_ = 0, hi_f_ = 0;
+    DevBuf eq_tabs_;              // EqScanTab[4] for L = 4, 8, 16, 32
     // plotter staging
     DevBuf plot_stage_, plot_jobs_;
     size_t last_frames_per_call_ = 0;

@@ -25,6 +25,10 @@ struct EnvState { uint32_t tag; uint32_t pad; uint64_t seq; double off_amplitude
 struct EqDesc { const float* in; float* out; double gain_lo, gain_mid, gain_hi; };
 struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };       // eq_three.rs:13-26,100-103
 
+// time-parallel EqThree: Toeplitz powers of the one-sample pole matrix, per chunk length L (host-computed)
+//   pw[f][j] = first column of A_f^(L*j), j = 0..64 ; p2[f][k] = first column of A_f^(L * 2^k), k = 0..5
+struct EqScanTab { double pw[2][65][4]; double p2[2][6][4]; };
+
 // src/module/fm_sine.rs:37-56
 struct FmDesc { const float* in; float* out; double freq_mid, freq_amp; };
 
@@ -49,6 +53,9 @@ struct PlotJob { const float* in; float* left; float* right; };
 void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f, hipStream_t s);
+int eq_scan_log2l(size_t frames);
+void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f,
+                          const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, hipStream_t s);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);

