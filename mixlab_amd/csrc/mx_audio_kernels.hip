@@ -10,6 +10,8 @@
 // kernels, one wave per instance for the envelope scan, one lane per instance for the exact EQ.
 #include "mx_kernels.hpp"
 
+#include <cstdlib>
+
 namespace mx {
 
 // ---------------------------------------------------------------------------------------------
@@ -88,47 +90,104 @@ void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s
 //   master[i] += (in[ch][i] as f64 * gain[ch]) as f32 ;  if cue[ch] { cue[i] += in[ch][i] }
 // algorithmic bytes per mixer per frame: 8 * (n_ch + 2)
 // ---------------------------------------------------------------------------------------------
-template <int U>
-__global__ __launch_bounds__(256) void k_mixer(const MixDesc* __restrict__ descs, size_t n /* stereo floats */) {
+template <int W> struct VecF;
+template <> struct VecF<1> { typedef float T; };
+template <> struct VecF<2> { typedef float2 T; };
+template <> struct VecF<4> { typedef float4 T; };
+
+template <int W>
+__device__ __forceinline__ void ldw(const float* __restrict__ p, size_t idx, size_t n, float (&v)[W]) {
+    const size_t b = idx * W;
+    if (b + W <= n) {
+        const typename VecF<W>::T t = reinterpret_cast<const typename VecF<W>::T*>(p)[idx];
+        const float* tf = reinterpret_cast<const float*>(&t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = tf[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = (b + k < n) ? p[b + k] : 0.f;
+    }
+}
+template <int W>
+__device__ __forceinline__ void stw(float* __restrict__ p, size_t idx, size_t n, const float (&v)[W]) {
+    const size_t b = idx * W;
+    if (b + W <= n) {
+        typename VecF<W>::T t;
+        float* tf = reinterpret_cast<float*>(&t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) tf[k] = v[k];
+        reinterpret_cast<typename VecF<W>::T*>(p)[idx] = t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) if (b + k < n) p[b + k] = v[k];
+    }
+}
+
+// W floats per lane, U channel loads in flight per lane, one wave per block so that small sample
+// counts still spread over all 256 CUs (a CU's HBM pull is capped at ~10 B/clk).
+template <int W, int U>
+__global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs, size_t n /* stereo floats */) {
     const MixDesc m = descs[blockIdx.y];
     const MixChan* __restrict__ ch = m.chans;
-    const size_t nq = (n + 3) >> 2;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // util::zero(master), mixer.rs:54
-        float4 cac = make_float4(0.f, 0.f, 0.f, 0.f);   // util::zero(cue),    mixer.rs:55
+    const size_t items = (n + W - 1) / W;
+    for (size_t q = (size_t)blockIdx.x * 64 + threadIdx.x; q < items; q += (size_t)gridDim.x * 64) {
+        float acc[W], cac[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { acc[k] = 0.f; cac[k] = 0.f; }   // util::zero(master/cue), mixer.rs:54-55
         uint32_t c = 0;
         for (; c + U <= m.n_ch; c += U) {
-            float4 v[U];
+            float v[U][W];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = ld4(ch[c + u].in, q, n);
+            for (int u = 0; u < U; ++u) ldw<W>(ch[c + u].in, q, n, v[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double g = ch[c + u].gain;
-                acc.x += (float)((double)v[u].x * g);
-                acc.y += (float)((double)v[u].y * g);
-                acc.z += (float)((double)v[u].z * g);
-                acc.w += (float)((double)v[u].w * g);
-                if (ch[c + u].cue) { cac.x += v[u].x; cac.y += v[u].y; cac.z += v[u].z; cac.w += v[u].w; }
+                const bool cue = ch[c + u].cue != 0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    acc[k] += (float)((double)v[u][k] * g);   // mixer.rs:62
+                    if (cue) cac[k] += v[u][k];              // mixer.rs:64-66
+                }
             }
         }
         for (; c < m.n_ch; ++c) {
-            const float4 v = ld4(ch[c].in, q, n);
+            float v[W];
+            ldw<W>(ch[c].in, q, n, v);
             const double g = ch[c].gain;
-            acc.x += (float)((double)v.x * g);
-            acc.y += (float)((double)v.y * g);
-            acc.z += (float)((double)v.z * g);
-            acc.w += (float)((double)v.w * g);
-            if (ch[c].cue) { cac.x += v.x; cac.y += v.y; cac.z += v.z; cac.w += v.w; }
+            const bool cue = ch[c].cue != 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                acc[k] += (float)((double)v[k] * g);
+                if (cue) cac[k] += v[k];
+            }
         }
-        st4(m.master, q, n, acc);
-        st4(m.cue, q, n, cac);
+        stw<W>(m.master, q, n, acc);
+        stw<W>(m.cue, q, n, cac);
     }
 }
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s) {
     if (!n || !frames) return;
     const size_t ns = frames * 2;
-    dim3 grid(grid_x((ns + 3) / 4, 256, 8192), n);
-    hipLaunchKernelGGL(k_mixer<8>, grid, dim3(256), 0, s, d, ns);
+    // widest lane vector that still yields >= ~4 waves per CU; tuning override for experiments
+    static const int force_w = env_int("MX_MIXER_W", 0);
+    int w = force_w;
+    if (w != 1 && w != 2 && w != 4) {
+        const size_t want_lanes = (size_t)64 * 1024 / (n ? n : 1);
+        w = (ns / 4 >= want_lanes) ? 4 : (ns / 2 >= want_lanes ? 2 : 1);
+    }
+    const size_t items = (ns + w - 1) / w;
+    dim3 grid(grid_x(items, 64, 16384), n);
+    switch (w) {
+    case 4: hipLaunchKernelGGL((k_mixer<4, 8>), grid, dim3(64), 0, s, d, ns); break;
+    case 2: hipLaunchKernelGGL((k_mixer<2, 16>), grid, dim3(64), 0, s, d, ns); break;
+    default: hipLaunchKernelGGL((k_mixer<1, 16>), grid, dim3(64), 0, s, d, ns); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,85 +430,114 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frame
 // edge.  One wave per instance: 64 samples per step, edges found with ballots + clz (no shuffles,
 // no LDS), closed-form amplitude per lane, state carried in SGPR-uniform registers across steps.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double seq_ms(uint64_t first, uint64_t last, double sr) {
-    return (double)(last - first) / sr * 1000.0;                       // envelope.rs:16-18
+// (last - first) as f64 / SAMPLE_RATE * 1000.0 (envelope.rs:16-18) with the IEEE quotient obtained
+// by Markstein's correction instead of the 20-instruction division expansion: q = a*y, r = fma(-q,b,a),
+// q' = fma(r,y,q) with y = RN(1/b) from the host.  tests/test_fastdiv.py checks q' == a/b bit-for-bit
+// for every a in [0, 2^32) at 44.1 and 48 kHz; larger spans (> 24 h) take the true division.
+__device__ __forceinline__ double seq_ms(uint64_t first, uint64_t last, double sr, double rsr) {
+    const uint64_t dt = last - first;
+    if (dt >> 32) return (double)dt / sr * 1000.0;
+    const double a = (double)(uint32_t)dt;
+    double q = a * rsr;
+    const double r = fma(-q, sr, a);
+    q = fma(r, rsr, q);
+    return q * 1000.0;
 }
 __device__ __forceinline__ double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }  // envelope.rs:20-28
-__device__ __forceinline__ double amp_on(const EnvDesc& p, uint64_t on, uint64_t t, double sr) {       // envelope.rs:37-49
-    const double ms = seq_ms(on, t, sr);
-    if (ms < p.attack_ms) return p.inv_attack * ms;
+__device__ __forceinline__ double amp_on_ms(const EnvDesc& p, double ms) {                            // envelope.rs:37-49
+    const double attack = p.inv_attack * ms;
     const double since_decay = ms - p.attack_ms;
     const double decay_amplitude = 1.0 - clamp01(p.inv_decay * since_decay);
-    return p.sustain + (p.one_minus_sustain * decay_amplitude);
+    const double decay = p.sustain + (p.one_minus_sustain * decay_amplitude);
+    return ms < p.attack_ms ? attack : decay;
 }
-__device__ __forceinline__ double amp_off(const EnvDesc& p, uint64_t off, double off_amp, uint64_t t, double sr) {  // envelope.rs:51-56
-    const double ms = seq_ms(off, t, sr);
+__device__ __forceinline__ double amp_off_ms(const EnvDesc& p, double off_amp, double ms) {           // envelope.rs:51-56
     const double release_amplitude = 1.0 - clamp01(p.inv_release * ms);
     return off_amp * release_amplitude;
 }
 __device__ __forceinline__ int top_bit(uint64_t m) { return 63 - __clzll((long long)m); }
+__device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
 
+template <int K>
 __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ descs, EnvState* __restrict__ states,
-                                                   uint32_t n_inst, size_t frames, uint64_t t0, double sr) {
+                                                   uint32_t n_inst, size_t frames, uint64_t t0, double sr, double rsr) {
     const int lane = threadIdx.x & 63;
     const uint32_t inst = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (inst >= n_inst) return;  // wave-uniform
     const EnvDesc p = descs[inst];
+    // carried EnvelopeState: wave-uniform (kept in SGPRs via readlane)
     uint32_t tag = states[inst].tag;
     uint64_t seq = states[inst].seq;
     double off_amp = states[inst].off_amplitude;
+    tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)tag);
+    seq = read_lane_u64(seq, 0);
+    off_amp = __longlong_as_double((long long)read_lane_u64((uint64_t)__double_as_longlong(off_amp), 0));
 
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint64_t le = lt | (1ull << lane);
 
-    for (size_t base = 0; base < frames; base += 64) {
-        const size_t i = base + lane;
-        const bool valid = i < frames;
-        const float x = (valid && p.gate) ? p.gate[i] : 0.0f;   // Disconnected => ZERO_BUFFER_MONO
-        const uint64_t m1 = __ballot(valid && x == 1.0f);        // envelope.rs:102
-        const uint64_t m0 = __ballot(valid && x == 0.0f);        // envelope.rs:107
-        const uint64_t mk = m0 | m1;
-        const uint64_t below = mk & lt;
-        const bool carry_on = (tag == 1u);
-        const bool b_prev = below ? (((m1 >> top_bit(below)) & 1ull) != 0) : carry_on;
-        const bool b_cur = ((mk >> lane) & 1ull) ? (((m1 >> lane) & 1ull) != 0) : b_prev;
-        const uint64_t R = __ballot(valid && !b_prev && b_cur);  // Initial|Off -> On
-        const uint64_t F = __ballot(valid && b_prev && !b_cur);  // On -> Off
-        const uint64_t tb = t0 + base;
-
-        uint32_t my_tag; uint64_t my_seq; double my_off = 0.0;
-        const uint64_t Rle = R & le, Fle = F & le;
-        if (b_cur) {
-            my_tag = 1u;
-            my_seq = Rle ? tb + (uint64_t)top_bit(Rle) : seq;
-        } else if (Fle) {
-            const int fl = top_bit(Fle);
-            const uint64_t off = tb + (uint64_t)fl;
-            const uint64_t Rb = R & ((1ull << fl) - 1ull);
-            const uint64_t on = Rb ? tb + (uint64_t)top_bit(Rb) : seq;
-            my_tag = 2u; my_seq = off;
-            my_off = amp_on(p, on, off, sr);                    // envelope.rs:108-111
-        } else {
-            my_tag = tag; my_seq = seq; my_off = off_amp;       // carried Initial / TriggerOff
+    for (size_t base = 0; base < frames; base += 64 * K) {
+        float xs[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {                       // K independent loads in flight
+            const size_t i = base + 64 * k + lane;
+            xs[k] = (i < frames && p.gate) ? p.gate[i] : 0.0f;   // Disconnected => ZERO_BUFFER_MONO
         }
-        const uint64_t t = tb + (uint64_t)lane;
-        double a;
-        if (my_tag == 1u) a = amp_on(p, my_seq, t, sr);
-        else if (my_tag == 2u) a = amp_off(p, my_seq, my_off, t, sr);
-        else a = 0.0;                                           // envelope.rs:36
-        if (valid) p.out[i] = (float)a;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const size_t tbase = base + 64 * k;
+            if (tbase >= frames) break;                     // wave-uniform
+            const size_t i = tbase + lane;
+            const bool valid = i < frames;
+            const float x = xs[k];
+            const uint64_t m1 = __ballot(valid && x == 1.0f);        // envelope.rs:102
+            const uint64_t m0 = __ballot(valid && x == 0.0f);        // envelope.rs:107
+            const uint64_t mk = m0 | m1;
+            const uint64_t below = mk & lt;
+            const bool carry_on = (tag == 1u);
+            const bool b_prev = below ? (((m1 >> top_bit(below)) & 1ull) != 0) : carry_on;
+            const bool b_cur = ((mk >> lane) & 1ull) ? (((m1 >> lane) & 1ull) != 0) : b_prev;
+            const uint64_t R = __ballot(valid && !b_prev && b_cur);  // Initial|Off -> On
+            const uint64_t F = __ballot(valid && b_prev && !b_cur);  // On -> Off
+            const uint64_t tb = t0 + tbase;
 
-        const size_t rem = frames - base;
-        const int last = rem >= 64 ? 63 : (int)rem - 1;
-        tag = (uint32_t)__shfl((int)my_tag, last);
-        seq = (uint64_t)__shfl((unsigned long long)my_seq, last);
-        off_amp = __shfl(my_off, last);
+            uint32_t my_tag = tag; uint64_t my_seq = seq; double my_off = off_amp;   // carried Initial / TriggerOff
+            const uint64_t Rle = R & le, Fle = F & le;
+            if (b_cur) {
+                my_tag = 1u;
+                if (Rle) my_seq = tb + (uint64_t)top_bit(Rle);
+            } else if (Fle) {                                         // rare: a falling edge inside this tile
+                const int fl = top_bit(Fle);
+                const uint64_t off = tb + (uint64_t)fl;
+                const uint64_t Rb = R & ((1ull << fl) - 1ull);
+                const uint64_t on = Rb ? tb + (uint64_t)top_bit(Rb) : seq;
+                my_tag = 2u; my_seq = off;
+                my_off = amp_on_ms(p, seq_ms(on, off, sr, rsr));      // envelope.rs:108-111
+            }
+            const double ms = seq_ms(my_seq, tb + (uint64_t)lane, sr, rsr);
+            const double a_on = amp_on_ms(p, ms);
+            const double a_off = amp_off_ms(p, my_off, ms);
+            const double a = my_tag == 1u ? a_on : (my_tag == 2u ? a_off : 0.0);   // envelope.rs:36
+            if (valid) p.out[i] = (float)a;
+
+            const size_t rem = frames - tbase;
+            const int last = rem >= 64 ? 63 : (int)rem - 1;
+            tag = (uint32_t)__builtin_amdgcn_readlane((int)my_tag, last);
+            seq = read_lane_u64(my_seq, last);
+            off_amp = __longlong_as_double((long long)read_lane_u64((uint64_t)__double_as_longlong(my_off), last));
+        }
     }
     if (lane == 0) { states[inst].tag = tag; states[inst].seq = seq; states[inst].off_amplitude = off_amp; }
 }
 void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_envelope, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, t0, sample_rate);
+    const double rsr = 1.0 / sample_rate;
+    if (frames > 64 * 4) hipLaunchKernelGGL(k_envelope<8>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, t0, sample_rate, rsr);
+    else hipLaunchKernelGGL(k_envelope<2>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, t0, sample_rate, rsr);
 }
 
 // ---------------------------------------------------------------------------------------------

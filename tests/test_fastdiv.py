@@ -1,0 +1,22 @@
+"""Host-side proof obligation of the envelope kernel's exact-division shortcut (see
+mixlab_amd/csrc/mx_audio_kernels.hip: seq_ms): checked exhaustively for every sample distance the
+fast path accepts (dt < 2^32, i.e. > 24 h of audio) at both supported rates."""
+import pathlib
+import subprocess
+
+import pytest
+
+HERE = pathlib.Path(__file__).resolve().parent / "helpers"
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("fastdiv") / "fastdiv_check"
+    subprocess.run(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", str(HERE / "fastdiv_check.c"), "-o", str(exe), "-lm"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("rate", [44100, 48000])
+def test_markstein_quotient_is_ieee_quotient_for_all_dt_below_2_32(checker, rate):
+    out = subprocess.run([str(checker), str(rate), "0", str(1 << 32)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
