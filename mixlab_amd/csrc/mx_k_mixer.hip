@@ -1,0 +1,152 @@
+// mx_k_mixer.hip -- Mixer: order-preserving f32 mix bus (reference src/module/mixer.rs:46-71).
+//
+// Build with -ffp-contract=off (see mx_k_stream.hip).
+//
+//   master[i] += (in[ch][i] as f64 * gain[ch]) as f32 ;  if cue[ch] { cue[i] += in[ch][i] }
+//
+// The f32 accumulation order over channels IS the result (reordering a 1024-way sum moves it by
+// tens of ULPs), so every output element owns one strictly sequential add chain and nothing is
+// split across lanes, waves or MFMA.  What is left to engineer is memory-level parallelism:
+//   * one wave per block, W floats per lane: even a single tick (1 600 outputs) spreads over CUs;
+//   * a ring of R channel loads stays in flight per lane ahead of the add chain: the load for
+//     channel c+R is issued in the slot channel c just vacated, so the chain never drains;
+//   * channel descriptors are fetched 64 at a time, one per lane (a coalesced vector load), and
+//     broadcast with v_readlane into SGPRs -- no dependent scalar-memory round trip per channel.
+// algorithmic bytes per mixer per frame: 8 * (n_ch + 2).
+#include "mx_dev.hpp"
+
+namespace mx {
+
+template <int W> struct VecF;
+template <> struct VecF<1> { typedef float T; };
+template <> struct VecF<2> { typedef float2 T; };
+template <> struct VecF<4> { typedef float4 T; };
+
+template <int W>
+__device__ __forceinline__ void ldw(const float* __restrict__ p, size_t idx, size_t n, float (&v)[W]) {
+    const size_t b = idx * W;
+    if (b + W <= n) {
+        const typename VecF<W>::T t = reinterpret_cast<const typename VecF<W>::T*>(p)[idx];
+        const float* tf = reinterpret_cast<const float*>(&t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = tf[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = (b + k < n) ? p[b + k] : 0.f;
+    }
+}
+template <int W>
+__device__ __forceinline__ void stw(float* __restrict__ p, size_t idx, size_t n, const float (&v)[W]) {
+    const size_t b = idx * W;
+    if (b + W <= n) {
+        typename VecF<W>::T t;
+        float* tf = reinterpret_cast<float*>(&t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) tf[k] = v[k];
+        reinterpret_cast<typename VecF<W>::T*>(p)[idx] = t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) if (b + k < n) p[b + k] = v[k];
+    }
+}
+
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int W>
+__device__ __forceinline__ void mix_one(float (&acc)[W], float (&cac)[W], const float (&x)[W], double g, bool cue) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        acc[k] += (float)((double)x[k] * g);   // mixer.rs:62
+        if (cue) cac[k] += x[k];               // mixer.rs:64-66
+    }
+}
+
+// W floats per lane, ring of R loads in flight per lane, one wave per block.
+template <int W, int R>
+__global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs, size_t n /* stereo floats */) {
+    static_assert(64 % R == 0, "ring must divide the descriptor block");
+    const MixDesc m = descs[blockIdx.y];
+    const MixChan* __restrict__ ch = m.chans;
+    const int lane = threadIdx.x;
+    const size_t items = (n + W - 1) / W;
+    const uint32_t n_full = m.n_ch & ~63u;   // channels covered by full 64-channel descriptor blocks
+
+    for (size_t qb = (size_t)blockIdx.x * 64; qb < items; qb += (size_t)gridDim.x * 64) {
+        // the whole wave runs the channel loop together (v_readlane broadcasts need every lane's
+        // descriptor registers): lanes past the end are clamped to the last item and not stored
+        const bool live = qb + lane < items;
+        const size_t q = live ? qb + lane : items - 1;
+        float acc[W], cac[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { acc[k] = 0.f; cac[k] = 0.f; }   // util::zero(master/cue), mixer.rs:54-55
+
+        if (n_full) {
+            // descriptors of the current and the next 64-channel block, one channel per lane
+            uint64_t p_cur = (uint64_t)ch[lane].in, p_nxt = 0;
+            uint64_t g_cur = (uint64_t)__double_as_longlong(ch[lane].gain), g_nxt = 0;
+            uint64_t cue_cur = __ballot(ch[lane].cue != 0), cue_nxt = 0;
+            float v[R][W];
+#pragma unroll
+            for (int u = 0; u < R; ++u) ldw<W>((const float*)bcast_u64(p_cur, u), q, n, v[u]);   // prologue: fill the ring
+
+            for (uint32_t c0 = 0; c0 < n_full; c0 += 64) {
+                const bool have_next = c0 + 64 < n_full;   // uniform
+                if (have_next) {
+                    p_nxt = (uint64_t)ch[c0 + 64 + lane].in;
+                    g_nxt = (uint64_t)__double_as_longlong(ch[c0 + 64 + lane].gain);
+                    cue_nxt = __ballot(ch[c0 + 64 + lane].cue != 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+                    float x[W];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) x[k] = v[u % R][k];
+                    // refill the slot with channel c0 + u + R
+                    if (u + R < 64) {
+                        ldw<W>((const float*)bcast_u64(p_cur, (u + R) & 63), q, n, v[u % R]);
+                    } else if (have_next) {
+                        ldw<W>((const float*)bcast_u64(p_nxt, (u + R) & 63), q, n, v[u % R]);
+                    }
+                    const double g = __longlong_as_double((long long)bcast_u64(g_cur, u));
+                    mix_one<W>(acc, cac, x, g, ((cue_cur >> u) & 1ull) != 0);
+                }
+                p_cur = p_nxt; g_cur = g_nxt; cue_cur = cue_nxt;
+            }
+        }
+        // remaining (< 64) channels: plain scalar-descriptor path
+        for (uint32_t c = n_full; c < m.n_ch; ++c) {
+            float x[W];
+            ldw<W>(ch[c].in, q, n, x);
+            mix_one<W>(acc, cac, x, ch[c].gain, ch[c].cue != 0);
+        }
+        if (live) {
+            stw<W>(m.master, q, n, acc);
+            stw<W>(m.cue, q, n, cac);
+        }
+    }
+}
+
+void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    const size_t ns = frames * 2;
+    // widest lane vector that still yields enough waves to cover the chip; tuning override for experiments
+    static const int force_w = env_int("MX_MIXER_W", 0);
+    int w = force_w;
+    if (w != 1 && w != 2 && w != 4) {
+        const size_t want_lanes = (size_t)64 * 1024 / (n ? n : 1);
+        w = (ns / 4 >= want_lanes) ? 4 : (ns / 2 >= want_lanes ? 2 : 1);
+    }
+    const size_t items = (ns + w - 1) / w;
+    dim3 grid(grid_x(items, 64, 16384), n);
+    switch (w) {
+    case 4: hipLaunchKernelGGL((k_mixer<4, 16>), grid, dim3(64), 0, s, d, ns); break;
+    case 2: hipLaunchKernelGGL((k_mixer<2, 32>), grid, dim3(64), 0, s, d, ns); break;
+    default: hipLaunchKernelGGL((k_mixer<1, 32>), grid, dim3(64), 0, s, d, ns); break;
+    }
+}
+
+}  // namespace mx

@@ -1,0 +1,162 @@
+// mx_k_stream.hip -- streaming kernels: Amplifier, Oscillator, FmSine, Trigger, StereoPanner, StereoSplitter, Plotter.
+//
+// Build with -ffp-contract=off: the reference (Rust) evaluates every f64 expression as written,
+// never fused; parity with it is bit-exact only if v_fma_f64 is not substituted for mul+add.
+//
+// Layout: every port buffer is a flat f32 stream of `frames` mono samples (or 2*frames interleaved
+// L,R) -- n_ticks consecutive 735/800-sample tick buffers back to back -- 256-byte aligned.
+// Instances of one module kind are batched into one launch.
+#include "mx_dev.hpp"
+
+namespace mx {
+
+// ---------------------------------------------------------------------------------------------
+// Amplifier (src/module/amplifier.rs:38-60,71-73)
+//   out[i] = (in[i] as f64 * (1.0 - d + d * mod[i/2]) * amplitude) as f32
+// algorithmic bytes per frame: 8 (in) + 4 (ctl) + 8 (out) = 20
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_amplifier(const AmpDesc* __restrict__ descs, size_t n /* stereo floats */) {
+    const AmpDesc d = descs[blockIdx.y];
+    const size_t nq = (n + 3) >> 2;
+    const double md = d.mod_depth, amp = d.amplitude;
+    const double one_minus = 1.0 - md;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        const float4 v = ld4(d.in, q, n);
+        double m0 = 1.0, m1 = 1.0;
+        if (d.ctl) {  // block-uniform
+            const float2 c = ld2(d.ctl, q, n >> 1);   // stereo floats 4q..4q+3 <-> mono 2q, 2q+1
+            m0 = (double)c.x; m1 = (double)c.y;
+        }
+        const double dep0 = one_minus + md * m0;      // depth(), amplifier.rs:71-73
+        const double dep1 = one_minus + md * m1;
+        float4 o;
+        o.x = (float)((double)v.x * dep0 * amp);
+        o.y = (float)((double)v.y * dep0 * amp);
+        o.z = (float)((double)v.z * dep1 * amp);
+        o.w = (float)((double)v.w * dep1 * amp);
+        st4(d.out, q, n, o);
+    }
+}
+void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    const size_t ns = frames * 2;
+    dim3 grid(grid_x((ns + 3) / 4, 256, 4096), n);
+    hipLaunchKernelGGL(k_amplifier, grid, dim3(256), 0, s, d, ns);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Oscillator (src/module/oscillator.rs:15-37,65-92) and FmSine (src/module/fm_sine.rs:37-56).
+// f64 sin = ocml's; the reference's is the host libm.  Both are sub-ULP f64 routines; after the
+// f32 cast the results differ in at most 1 f32 ULP, rarely (measured in tests).
+// ---------------------------------------------------------------------------------------------
+#define MX_PI 3.14159265358979323846264338327950288
+
+__device__ __forceinline__ double osc_saw(double n) { return 2.0 * (n - floor(0.5 + n)); }
+
+__global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
+    const OscDesc d = descs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256) {
+        const double tt = (double)(t0 + (uint64_t)i) / sr;
+        const double n = tt * d.freq;
+        double v;
+        switch (d.waveform) {
+        case 2: v = sin(n * 2.0 * MX_PI); break;                                      // Sine
+        case 3: { const double sv = sin(n * 2.0 * MX_PI); v = signbit(sv) ? -1.0 : 1.0; break; }  // Square: sign by sign bit (oscillator.rs:15-23)
+        case 5: v = osc_saw(n); break;                                                // Saw
+        case 4: v = 2.0 * fabs(osc_saw(n)) - 1.0; break;                              // Triangle
+        case 0: v = 1.0; break;                                                       // On
+        default: v = 0.0; break;                                                      // Off
+        }
+        const float sm = (float)v;
+        d.mono[i] = sm;
+        reinterpret_cast<float2*>(d.stereo)[i] = make_float2(sm, sm);
+    }
+}
+void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x(frames, 256, 4096), n);
+    hipLaunchKernelGGL(k_oscillator, grid, dim3(256), 0, s, d, frames, t0, sample_rate);
+}
+
+__global__ __launch_bounds__(256) void k_fm_sine(const FmDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
+    const FmDesc d = descs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256) {
+        const double tt = (double)(t0 + (uint64_t)i) / sr;
+        const double xin = d.in ? (double)d.in[i] : 0.0;
+        const double co = (d.freq_mid + d.freq_amp * xin) * 2.0 * MX_PI;
+        const float x = (float)sin(co * tt);
+        reinterpret_cast<float2*>(d.out)[i] = make_float2(x, x);
+    }
+}
+void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x(frames, 256, 4096), n);
+    hipLaunchKernelGGL(k_fm_sine, grid, dim3(256), 0, s, d, frames, t0, sample_rate);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trigger / StereoPanner / StereoSplitter (trigger.rs:35-48, stereo_panner.rs:30-41,
+// stereo_splitter.rs:33-47): fills and layout shuffles, 16 B per lane on the wide side.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trigger(const TrigDesc* __restrict__ descs, size_t frames) {
+    const TrigDesc d = descs[blockIdx.y];
+    const size_t nq = (frames + 3) >> 2;
+    const float4 v = make_float4(d.value, d.value, d.value, d.value);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) st4(d.out, q, frames, v);
+}
+void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x((frames + 3) / 4, 256, 2048), n);
+    hipLaunchKernelGGL(k_trigger, grid, dim3(256), 0, s, d, frames);
+}
+
+__global__ __launch_bounds__(256) void k_panner(const PanDesc* __restrict__ descs, size_t frames) {
+    const PanDesc d = descs[blockIdx.y];
+    const size_t nq = (frames + 3) >> 2;   // quads of frames -> two stereo quads
+    const size_t ns = frames * 2;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        const float4 l = d.l ? ld4(d.l, q, frames) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r = d.r ? ld4(d.r, q, frames) : make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(d.out, 2 * q, ns, make_float4(l.x, r.x, l.y, r.y));
+        if ((2 * q + 1) * 4 < ns) st4(d.out, 2 * q + 1, ns, make_float4(l.z, r.z, l.w, r.w));
+    }
+}
+void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x((frames + 3) / 4, 256, 4096), n);
+    hipLaunchKernelGGL(k_panner, grid, dim3(256), 0, s, d, frames);
+}
+
+__global__ __launch_bounds__(256) void k_splitter(const SplitDesc* __restrict__ descs, size_t frames) {
+    const SplitDesc d = descs[blockIdx.y];
+    const size_t nq = (frames + 3) >> 2;
+    const size_t ns = frames * 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        const float4 a = d.in ? ld4(d.in, 2 * q, ns) : z;
+        const float4 b = (d.in && (2 * q + 1) * 4 < ns) ? ld4(d.in, 2 * q + 1, ns) : z;
+        st4(d.l, q, frames, make_float4(a.x, a.z, b.x, b.z));
+        st4(d.r, q, frames, make_float4(a.y, a.w, b.y, b.w));
+    }
+}
+void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    dim3 grid(grid_x((frames + 3) / 4, 256, 4096), n);
+    hipLaunchKernelGGL(k_splitter, grid, dim3(256), 0, s, d, frames);
+}
+
+// Plotter (plotter.rs:37-56): de-interleave one tick per job into the indication staging area.
+__global__ __launch_bounds__(256) void k_plotter(const PlotJob* __restrict__ jobs, size_t spt) {
+    const PlotJob j = jobs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < spt; i += (size_t)gridDim.x * 256) {
+        const float2 v = reinterpret_cast<const float2*>(j.in)[i];
+        j.left[i] = v.x; j.right[i] = v.y;
+    }
+}
+void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s) {
+    if (!n || !spt) return;
+    dim3 grid(grid_x(spt, 256, 64), n);
+    hipLaunchKernelGGL(k_plotter, grid, dim3(256), 0, s, d, spt);
+}
+
+}  // namespace mx
