@@ -17,37 +17,39 @@
 
 namespace mx {
 
+// Native vector types so the loads can be written against address_space(1) directly.
 template <int W> struct VecF;
 template <> struct VecF<1> { typedef float T; };
-template <> struct VecF<2> { typedef float2 T; };
-template <> struct VecF<4> { typedef float4 T; };
+template <> struct VecF<2> { typedef float __attribute__((ext_vector_type(2))) T; };
+template <> struct VecF<4> { typedef float __attribute__((ext_vector_type(4))) T; };
 
+// Channel pointers travel through SGPRs as integers (v_readlane), so the address space must be
+// restated: a plain float* built from an integer is a FLAT pointer, and flat loads count against
+// both vmcnt and lgkmcnt, which serialises the ring.  address_space(1) + a 32-bit lane offset
+// selects `global_load_* v, v_off, s[base:base+1]`: one VGPR of address per lane for all channels.
+// No tail handling: the launcher only picks W that divides the stream length.
 template <int W>
-__device__ __forceinline__ void ldw(const float* __restrict__ p, size_t idx, size_t n, float (&v)[W]) {
-    const size_t b = idx * W;
-    if (b + W <= n) {
-        const typename VecF<W>::T t = reinterpret_cast<const typename VecF<W>::T*>(p)[idx];
-        const float* tf = reinterpret_cast<const float*>(&t);
+__device__ __forceinline__ void ldw(uint64_t base, uint32_t byte_off, float (&v)[W]) {
+    typedef typename VecF<W>::T VT;
+    const char __attribute__((address_space(1)))* p = (const char __attribute__((address_space(1)))*)base;
+    const VT t = *(const VT __attribute__((address_space(1)))*)(p + byte_off);
+    if constexpr (W == 1) v[0] = t;
+    else {
 #pragma unroll
-        for (int k = 0; k < W; ++k) v[k] = tf[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < W; ++k) v[k] = (b + k < n) ? p[b + k] : 0.f;
+        for (int k = 0; k < W; ++k) v[k] = t[k];
     }
 }
 template <int W>
-__device__ __forceinline__ void stw(float* __restrict__ p, size_t idx, size_t n, const float (&v)[W]) {
-    const size_t b = idx * W;
-    if (b + W <= n) {
-        typename VecF<W>::T t;
-        float* tf = reinterpret_cast<float*>(&t);
+__device__ __forceinline__ void stw(float* __restrict__ pf, uint32_t byte_off, const float (&v)[W]) {
+    typedef typename VecF<W>::T VT;
+    char __attribute__((address_space(1)))* p = (char __attribute__((address_space(1)))*)(uint64_t)pf;
+    VT t;
+    if constexpr (W == 1) t = v[0];
+    else {
 #pragma unroll
-        for (int k = 0; k < W; ++k) tf[k] = v[k];
-        reinterpret_cast<typename VecF<W>::T*>(p)[idx] = t;
-    } else {
-#pragma unroll
-        for (int k = 0; k < W; ++k) if (b + k < n) p[b + k] = v[k];
+        for (int k = 0; k < W; ++k) t[k] = v[k];
     }
+    *(VT __attribute__((address_space(1)))*)(p + byte_off) = t;
 }
 
 __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int l) {
@@ -72,14 +74,14 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
     const MixDesc m = descs[blockIdx.y];
     const MixChan* __restrict__ ch = m.chans;
     const int lane = threadIdx.x;
-    const size_t items = (n + W - 1) / W;
+    const size_t items = n / W;   // W divides n (launcher)
     const uint32_t n_full = m.n_ch & ~63u;   // channels covered by full 64-channel descriptor blocks
 
     for (size_t qb = (size_t)blockIdx.x * 64; qb < items; qb += (size_t)gridDim.x * 64) {
         // the whole wave runs the channel loop together (v_readlane broadcasts need every lane's
         // descriptor registers): lanes past the end are clamped to the last item and not stored
         const bool live = qb + lane < items;
-        const size_t q = live ? qb + lane : items - 1;
+        const uint32_t off = (uint32_t)((live ? qb + lane : items - 1) * (W * sizeof(float)));   // < 4 GiB per buffer (launcher)
         float acc[W], cac[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) { acc[k] = 0.f; cac[k] = 0.f; }   // util::zero(master/cue), mixer.rs:54-55
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
             uint64_t cue_cur = __ballot(ch[lane].cue != 0), cue_nxt = 0;
             float v[R][W];
 #pragma unroll
-            for (int u = 0; u < R; ++u) ldw<W>((const float*)bcast_u64(p_cur, u), q, n, v[u]);   // prologue: fill the ring
+            for (int u = 0; u < R; ++u) ldw<W>(bcast_u64(p_cur, u), off, v[u]);   // prologue: fill the ring
 
             for (uint32_t c0 = 0; c0 < n_full; c0 += 64) {
                 const bool have_next = c0 + 64 < n_full;   // uniform
@@ -107,9 +109,9 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
                     for (int k = 0; k < W; ++k) x[k] = v[u % R][k];
                     // refill the slot with channel c0 + u + R
                     if (u + R < 64) {
-                        ldw<W>((const float*)bcast_u64(p_cur, (u + R) & 63), q, n, v[u % R]);
+                        ldw<W>(bcast_u64(p_cur, (u + R) & 63), off, v[u % R]);
                     } else if (have_next) {
-                        ldw<W>((const float*)bcast_u64(p_nxt, (u + R) & 63), q, n, v[u % R]);
+                        ldw<W>(bcast_u64(p_nxt, (u + R) & 63), off, v[u % R]);
                     }
                     const double g = __longlong_as_double((long long)bcast_u64(g_cur, u));
                     mix_one<W>(acc, cac, x, g, ((cue_cur >> u) & 1ull) != 0);
@@ -120,12 +122,12 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
         // remaining (< 64) channels: plain scalar-descriptor path
         for (uint32_t c = n_full; c < m.n_ch; ++c) {
             float x[W];
-            ldw<W>(ch[c].in, q, n, x);
+            ldw<W>((uint64_t)ch[c].in, off, x);
             mix_one<W>(acc, cac, x, ch[c].gain, ch[c].cue != 0);
         }
         if (live) {
-            stw<W>(m.master, q, n, acc);
-            stw<W>(m.cue, q, n, cac);
+            stw<W>(m.master, off, acc);
+            stw<W>(m.cue, off, cac);
         }
     }
 }
@@ -136,16 +138,17 @@ void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s) {
     // widest lane vector that still yields enough waves to cover the chip; tuning override for experiments
     static const int force_w = env_int("MX_MIXER_W", 0);
     int w = force_w;
-    if (w != 1 && w != 2 && w != 4) {
+    if (w != 2 && w != 4) {
         const size_t want_lanes = (size_t)64 * 1024 / (n ? n : 1);
-        w = (ns / 4 >= want_lanes) ? 4 : (ns / 2 >= want_lanes ? 2 : 1);
+        w = (ns / 4 >= want_lanes) ? 4 : 2;   // one stereo frame per lane is the narrowest form
     }
-    const size_t items = (ns + w - 1) / w;
+    if (w == 4 && (ns & 3)) w = 2;                 // ns = 2 * frames is always even
+    if (ns * sizeof(float) >= (1ull << 32)) return;  // unreachable: the engine caps a port buffer below 4 GiB
+    const size_t items = ns / w;
     dim3 grid(grid_x(items, 64, 16384), n);
     switch (w) {
     case 4: hipLaunchKernelGGL((k_mixer<4, 16>), grid, dim3(64), 0, s, d, ns); break;
-    case 2: hipLaunchKernelGGL((k_mixer<2, 32>), grid, dim3(64), 0, s, d, ns); break;
-    default: hipLaunchKernelGGL((k_mixer<1, 32>), grid, dim3(64), 0, s, d, ns); break;
+    default: hipLaunchKernelGGL((k_mixer<2, 32>), grid, dim3(64), 0, s, d, ns); break;
     }
 }
 
