@@ -1,0 +1,189 @@
+"""CPU suite (`-m "not gpu"`): the oracle against the reference's golden vectors, the oracle's
+restatement of Engine::run_tick semantics, and that the C-ABI library loads and exports every
+symbol include/mixlab_gpu.h declares (no compute calls without a GPU)."""
+import ctypes
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from mixlab_amd.workspace import Workspace
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+REF_FIXTURES = pathlib.Path("/root/reference/fixtures/module/eq_three")
+SPT = 735
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---------------- oracle pinned by the reference's golden pair (src/module/eq_three.rs:150-167) ----------------
+def test_oracle_eq_three_matches_reference_golden_prefix_one_call():
+    x = np.fromfile(GOLDEN / "eq_three_chronos_prefix131072.f32.raw", dtype="<f4")
+    y = np.fromfile(GOLDEN / "eq_three_chronos-eq_prefix131072.f32.raw", dtype="<f4")
+    st = oracle.eq_three_new(44100.0)
+    out = oracle.eq_three_run(st, (4.0, 0.0, 4.0), x)   # Decibel(4.0), Decibel(0.0), Decibel(4.0)
+    assert np.array_equal(bits(out), bits(y))
+
+
+def test_oracle_eq_three_matches_reference_golden_prefix_ticked():
+    x = np.fromfile(GOLDEN / "eq_three_chronos_prefix131072.f32.raw", dtype="<f4")
+    y = np.fromfile(GOLDEN / "eq_three_chronos-eq_prefix131072.f32.raw", dtype="<f4")
+    st = oracle.eq_three_new(44100.0)
+    out = np.concatenate([oracle.eq_three_run(st, (4.0, 0.0, 4.0), x[o:o + SPT]) for o in range(0, x.size, SPT)])
+    assert np.array_equal(bits(out), bits(y))
+
+
+@pytest.mark.skipif(not REF_FIXTURES.exists(), reason="full fixture only exists where /root/reference is mounted")
+def test_oracle_eq_three_matches_full_reference_fixture():
+    x = np.fromfile(REF_FIXTURES / "chronos.f32.raw", dtype="<f4")
+    y = np.fromfile(REF_FIXTURES / "chronos-eq.f32.raw", dtype="<f4")
+    assert x.size == 355285
+    st = oracle.eq_three_new(44100.0)
+    assert np.array_equal(bits(oracle.eq_three_run(st, (4.0, 0.0, 4.0), x)), bits(y))
+    # and the committed prefix really is a prefix of the reference files
+    assert np.array_equal(np.fromfile(GOLDEN / "eq_three_chronos_prefix131072.f32.raw", dtype="<f4"), x[:131072])
+    assert np.array_equal(np.fromfile(GOLDEN / "eq_three_chronos-eq_prefix131072.f32.raw", dtype="<f4"), y[:131072])
+
+
+# ---------------- oracle module semantics (source text is the only spec for these) ----------------
+def test_oracle_decibel_and_coeff():
+    assert oracle.lib.orc_decibel_to_linear(0.0) == 1.0
+    assert abs(oracle.lib.orc_decibel_to_linear(20.0) - 10.0) < 1e-12
+    assert abs(oracle.lib.orc_lowpass_coeff(420.0, 44100.0) - 2.0 * np.sin(np.pi * 420.0 / 44100.0)) < 1e-15
+
+
+def test_oracle_mixer_order_and_cue():
+    a = np.array([1e8, 1.0], np.float32)
+    b = np.array([-1e8, 1.0], np.float32)
+    c = np.array([1.0, 1.0], np.float32)
+    m, cue = oracle.mixer_run([(0.0, 1.0, False), (0.0, 1.0, True), (0.0, 1.0, True)], [a, b, c], 2)
+    assert m[0] == 1.0 and cue[0] == np.float32(-1e8) + np.float32(1.0)   # ((0+1e8)-1e8)+1 in f32, sequentially
+    m2, _ = oracle.mixer_run([(0.0, 1.0, False)] * 3, [a, c, b], 2)
+    assert m2[0] == 0.0                                                    # different order, different f32 result
+    # MixerChannelParams::default: fader 0.0 => silence (protocol/src/lib.rs:342-347)
+    m3, c3 = oracle.mixer_run([(0.0, 0.0, False)], [a], 2)
+    assert not m3.any() and not c3.any()
+
+
+def test_oracle_envelope_shape():
+    p = (25.0, 500.0, 0.8, 200.0)
+    st = oracle.EnvState()
+    gate = np.ones(44100, np.float32)
+    out = oracle.envelope_run(st, p, 44100.0, 0, gate, gate.size)
+    assert out[0] == 0.0 and abs(out[int(0.025 * 44100)] - 1.0) < 2e-3          # end of attack
+    assert abs(out[-1] - 0.8) < 1e-6                                            # sustain after decay
+    off = oracle.envelope_run(st, p, 44100.0, 44100, np.zeros(22050, np.float32), 22050)
+    assert abs(off[0] - 0.8) < 1e-6 and off[int(0.2 * 44100) + 1] == 0.0        # released after 200 ms
+    # exact-compare gate semantics: 0.5 is neither on nor off (envelope.rs:102,107)
+    st2 = oracle.EnvState()
+    assert not oracle.envelope_run(st2, p, 44100.0, 0, np.full(100, 0.5, np.float32), 100).any()
+
+
+def test_oracle_oscillator_waveforms():
+    mono, stereo = oracle.oscillator_run(441.0, abi.WAVE_SAW, 44100.0, 0, 200)
+    assert mono[0] == 0.0 and np.array_equal(stereo[0::2], mono) and np.array_equal(stereo[1::2], mono)
+    assert np.all(np.abs(mono) <= 1.0)
+    sq, _ = oracle.oscillator_run(441.0, abi.WAVE_SQUARE, 44100.0, 0, 200)
+    assert set(np.unique(sq)) <= {-1.0, 1.0} and sq[0] == 1.0     # sign(+0.0) = +1 (oscillator.rs:15-23)
+    on, _ = oracle.oscillator_run(1.0, abi.WAVE_ON, 44100.0, 0, 8)
+    off, _ = oracle.oscillator_run(1.0, abi.WAVE_OFF, 44100.0, 0, 8)
+    assert (on == 1.0).all() and (off == 0.0).all()
+
+
+def test_oracle_amplifier_control_semantics():
+    x = synth.noise(1, 16)
+    assert np.array_equal(oracle.amplifier_run(1.0, 0.0, x, None), x)                      # depth 0: unity
+    ctl = np.zeros(8, np.float32)
+    assert not oracle.amplifier_run(1.0, 1.0, x, ctl).any()                                # depth 1, control 0: silence
+    assert np.array_equal(oracle.amplifier_run(1.0, 1.0, x, None), x)                      # disconnected control = 1.0
+
+
+# ---------------- oracle graph runner == Engine::run_tick semantics ----------------
+def test_graph_run_order_is_dfs_from_terminals():
+    ws = Workspace()
+    o = ws.oscillator(100.0, abi.WAVE_SINE)
+    m = ws.mixer([(0.0, 1.0, False)])
+    p = ws.plotter()
+    ws.connect(o, 1, m, 0)
+    ws.connect(m, 0, p, 0)
+    assert oracle.OracleGraph(ws).run_order() == [o, m, p]
+
+
+def test_graph_plotter_fires_on_sixth_tick_and_disconnected_reads_zero():
+    ws = Workspace()
+    o = ws.oscillator(100.0, abi.WAVE_ON)
+    m = ws.mixer([(0.0, 1.0, True), (0.0, 1.0, True)])   # input 1 left unconnected
+    p = ws.plotter()
+    ws.connect(o, 1, m, 0); ws.connect(m, 1, p, 0)
+    og = oracle.OracleGraph(ws)
+    fired = []
+    for t in range(12):
+        og.run_tick(t)
+        fired.append(og.plotter(p) is not None)
+        assert (og.output(m, 1) == 1.0).all()            # cue = 1.0 + 0.0 (zero buffer)
+    assert fired == [(t + 1) % 6 == 0 for t in range(12)]
+
+
+def test_graph_cycle_back_edge_reads_disconnected():
+    # amp0 -> amp1 -> amp0 (cycle) -> mixer: whichever amp runs first sees its input Disconnected
+    # (engine.rs:479-482), i.e. zeros; nothing hangs and nothing reads last tick's buffer.
+    ws = Workspace()
+    a0 = ws.amplifier(1.0, 0.0); a1 = ws.amplifier(1.0, 0.0); m = ws.mixer([(0.0, 1.0, False)])
+    ws.connect(a1, 0, a0, 0); ws.connect(a0, 0, a1, 0); ws.connect(a1, 0, m, 0)
+    og = oracle.OracleGraph(ws)
+    assert sorted(og.run_order()) == [a0, a1, m]
+    og.run_tick(0); og.run_tick(1)
+    assert not og.output(m, 0).any()
+
+
+def test_graph_type_mismatch_is_refused():
+    ws = Workspace()
+    o = ws.oscillator(100.0, abi.WAVE_SINE); e = ws.eq_three(0, 0, 0)
+    ws.connect(o, 1, e, 0)   # Stereo -> Mono: Workspace::connect refuses (workspace.rs:97-114)
+    with pytest.raises(RuntimeError):
+        oracle.OracleGraph(ws)
+
+
+def test_synth_noise_is_deterministic_and_in_range():
+    a, b = synth.noise(3, 1000), synth.noise(3, 1000)
+    assert np.array_equal(a, b) and a.min() >= -1.0 and a.max() < 1.0 and a.dtype == np.float32
+    assert not np.array_equal(a, synth.noise(4, 1000))
+    assert synth.ulp_diff(np.array([1.0, -0.0], np.float32), np.array([np.nextafter(np.float32(1.0), np.float32(2.0)), 0.0], np.float32)).tolist() == [1, 0]
+
+
+# ---------------- the C-ABI library: loads, and exports every declared symbol ----------------
+def declared_functions():
+    text = (ROOT / "include" / "mixlab_gpu.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(str(abi.LIB_PATH))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/mixlab_gpu.h but not exported: {missing}"
+
+
+def test_abi_version_and_error_channel_without_gpu():
+    assert abi.lib.mx_abi_version() == 1
+    n = abi.lib.mx_device_count()
+    if n <= 0:   # CPU box: the call must fail cleanly and say why, not crash or fall back
+        assert n == abi.MX_ERR_DEVICE and b"hip" in abi.lib.mx_last_error().lower()
+        with pytest.raises(abi.MxError):
+            Workspace().build()   # no silent CPU path
+
+
+def test_param_struct_layouts_match_header():
+    assert ctypes.sizeof(abi.MixerChannelParams) == 24 and ctypes.sizeof(abi.EqThreeParams) == 24
+    assert ctypes.sizeof(abi.EnvelopeParams) == 32 and ctypes.sizeof(abi.AmplifierParams) == 16
+    assert ctypes.sizeof(abi.OscillatorParams) == 16 and ctypes.sizeof(abi.FmSineParams) == 16
+    assert ctypes.sizeof(abi.Node) == 16 and ctypes.sizeof(abi.Edge) == 16 and ctypes.sizeof(abi.GraphOpts) == 32
