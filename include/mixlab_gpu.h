@@ -138,14 +138,66 @@ int mx_graph_profile_run(mx_graph* g, uint64_t first_tick, uint32_t n_ticks, flo
 int mx_graph_profile_enable(mx_graph* g, int on);
 int mx_graph_profile_collect(mx_graph* g, float* ms_by_kind /* MX_KIND_COUNT */, float* ms_total, uint32_t* n_runs);
 
-/* ---- per-module compatibility path: one ModuleT instance, host pointers in and out ---- */
+/* ---------------------------------------------------------------------------------------------- */
+/* pixel path: device-resident yuv420p frames, VideoMixer, scaler, colour                          */
+/* ---------------------------------------------------------------------------------------------- */
+
+/* Host view of a frame: planar yuv420p, 8 bit (always, src/module/video_mixer.rs:282-283). */
 typedef struct {
-    uint32_t width, height;          /* luma size; yuv420p 8-bit planar (always, src/module/video_mixer.rs:282-283) */
+    uint32_t width, height;          /* luma size */
     uint8_t* data[3];                /* AVFrame.data   (codec/src/ffmpeg/frame.rs:188-197) */
     int32_t stride[3];               /* AVFrame.linesize */
     int64_t dur_num, dur_den;        /* video::Frame.duration_hint (src/video.rs:8-14) */
     int64_t off_num, off_den;        /* VideoFrame.tick_offset (src/engine/io.rs:12-17) */
 } mx_frame;
+
+/* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
+ * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer
+ * keeps inputs past the call by retaining them.  Frames are immutable once handed to a mixer.
+ * All stateless pixel calls take a hipStream_t (`stream`, NULL = the library's default video
+ * stream) and are asynchronous on it unless stated. */
+typedef struct mx_dframe mx_dframe;
+int mx_dframe_create(uint32_t width, uint32_t height, void* stream, mx_dframe** out);  /* blank: Y=0 U=V=0x80 (frame.rs:76-138) */
+int mx_dframe_retain(mx_dframe* f);
+void mx_dframe_release(mx_dframe* f);
+int mx_dframe_upload(mx_dframe* f, const mx_frame* host, void* stream);       /* visible area; synchronous */
+int mx_dframe_download(const mx_dframe* f, mx_frame* host, void* stream);     /* visible area; synchronous */
+int mx_dframe_planes(const mx_dframe* f, uint32_t* width, uint32_t* height, void* device_data[3], int32_t stride[3]);
+
+/* AvFrame::blank (frame.rs:76-138) */
+int mx_video_blank(mx_dframe* f, void* stream);
+/* The compose step of VideoMixer::run_tick (src/module/video_mixer.rs:150-239): out = cross-fade of
+ * a and b by `(fader * 255.0) as u8`; a/b NULL reads the blank plane (video_mixer.rs:180-188). */
+int mx_video_crossfade(mx_dframe* out, const mx_dframe* a, const mx_dframe* b, double fader, void* stream);
+/* DynamicScaler::scale (src/video/encode.rs:338-397) of `in` into `out`'s size: identity copy when
+ * equal, else blank + aspect-preserving letterboxed bicubic.  The bicubic arithmetic is
+ * BUILD-SPECIFIED (libswscale is outside the reference tree): see DESIGN.md "Scaler". */
+int mx_video_scale(const mx_dframe* in, mx_dframe* out, void* stream);
+int mx_video_scale_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                            uint32_t* scaled_w, uint32_t* scaled_h, uint32_t* letterbox_x, uint32_t* letterbox_y);   /* encode.rs:354-374 */
+/* BUILD-SPECIFIED (no reference counterpart): BT.709 limited-range YUV420P -> RGBA8 (+ optional Q12 3x4 matrix). */
+int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride, const int32_t* matrix_q12 /* 12 or NULL */, void* stream);
+int mx_video_sync(void* stream);
+
+/* VideoMixer (src/module/video_mixer.rs): 4 video inputs, program + A + B outputs. */
+typedef struct { mx_dframe* frame; /* NULL = no frame this tick */ int64_t dur_num, dur_den, off_num, off_den; } mx_video_input;
+typedef struct mx_video_mixer mx_video_mixer;
+int mx_video_mixer_create(const mx_video_mixer_params* params, uint32_t sample_rate /* 0 => 44100 */, void* stream, mx_video_mixer** out);
+int mx_video_mixer_update(mx_video_mixer* m, const mx_video_mixer_params* params);
+/* One VideoMixer::run_tick (video_mixer.rs:70-250).  Returned frames carry one reference for the
+ * caller (mx_dframe_release when done); NULL = None.  The program frame has duration 1/60 and
+ * tick_offset 0 (video_mixer.rs:241-247). */
+int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input inputs[4],
+                            mx_dframe** out_program, mx_dframe** out_a, mx_dframe** out_b);
+int mx_video_mixer_sync(mx_video_mixer* m);
+void mx_video_mixer_destroy(mx_video_mixer* m);
+
+/* plain device memory for consumers of mx_video_to_rgba (tests, bench) */
+int mx_device_alloc(size_t bytes, void** device_ptr);
+void mx_device_free(void* device_ptr);
+int mx_device_download(void* host, const void* device_ptr, size_t bytes, void* stream);   /* synchronous */
+
+/* ---- per-module compatibility path: one ModuleT instance, host pointers in and out ---- */
 
 typedef struct { mx_line kind; const float* samples; size_t len; const mx_frame* video; } mx_input;                 /* InputRef, io.rs:19-24 */
 typedef struct { mx_line kind; float* samples; size_t len; mx_frame* video; int video_present; } mx_output;         /* OutputRef, io.rs:96-100 */

@@ -21,6 +21,7 @@ struct mx_module {
 };
 
 static thread_local std::string t_last_error;
+void mx_set_last_error(const std::string& s) { t_last_error = s; }   // shared with mx_abi_video.cpp
 
 template <class F>
 static int guard(F&& f) noexcept {

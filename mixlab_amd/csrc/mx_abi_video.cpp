@@ -1,0 +1,252 @@
+// mx_abi_video.cpp -- extern "C" entry points of the pixel path (include/mixlab_gpu.h, second half).
+// Same fencing convention as mx_abi.cpp: catch everything, stash the message, return a status.
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+
+#include "mx_video.hpp"
+
+using mx::DFrame;
+using mx::Error;
+using mx::FrameRef;
+
+// mx_dframe is opaque: an mx_dframe* is a DFrame* in disguise
+static inline DFrame* D(mx_dframe* p) { return reinterpret_cast<DFrame*>(p); }
+static inline const DFrame* D(const mx_dframe* p) { return reinterpret_cast<const DFrame*>(p); }
+static inline mx_dframe* H(DFrame* p) { return reinterpret_cast<mx_dframe*>(p); }
+
+struct mx_video_mixer { std::unique_ptr<mx::VideoMixer> m; };
+
+extern "C" const char* mx_last_error(void);
+void mx_set_last_error(const std::string& s);   // mx_abi.cpp
+
+template <class F>
+static int guard(F&& f) noexcept {
+    try {
+        f();
+        return MX_OK;
+    } catch (const Error& e) {
+        mx_set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        mx_set_last_error("host allocation failed");
+        return MX_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        mx_set_last_error(std::string("internal error: ") + e.what());
+        return MX_ERR_INTERNAL;
+    } catch (...) {
+        mx_set_last_error("internal error: unknown exception");
+        return MX_ERR_INTERNAL;
+    }
+}
+#define REQUIRE(cond, msg) do { if (!(cond)) throw Error(MX_ERR_INVALID, msg); } while (0)
+
+static hipStream_t default_video_stream() {
+    static std::once_flag once;
+    static hipStream_t s = nullptr;
+    std::call_once(once, [] { mx::hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); });
+    return s;
+}
+static hipStream_t S(void* stream) { return stream ? (hipStream_t)stream : default_video_stream(); }
+
+extern "C" {
+
+int mx_dframe_create(uint32_t width, uint32_t height, void* stream, mx_dframe** out) {
+    return guard([&] {
+        REQUIRE(out, "out is NULL");
+        *out = nullptr;
+        *out = H(DFrame::create(width, height, S(stream)));
+    });
+}
+int mx_dframe_retain(mx_dframe* f) {
+    return guard([&] { REQUIRE(f, "frame is NULL"); D(f)->retain(); });
+}
+void mx_dframe_release(mx_dframe* f) {
+    (void)guard([&] { if (f) D(f)->release(); });
+}
+
+static void check_host_frame(const DFrame* d, const mx_frame* h) {
+    REQUIRE(d && h, "NULL argument");
+    if (h->width != d->width || h->height != d->height) throw Error(MX_ERR_INVALID, "host frame size differs from the device frame");
+    for (int p = 0; p < 3; ++p) {
+        REQUIRE(h->data[p], "host plane pointer is NULL");
+        if (h->stride[p] < (int32_t)d->pw(p)) throw Error(MX_ERR_INVALID, "host stride smaller than the plane width");
+    }
+}
+int mx_dframe_upload(mx_dframe* f, const mx_frame* host, void* stream) {
+    return guard([&] {
+        check_host_frame(D(f), host);
+        DFrame* d = D(f);
+        for (int p = 0; p < 3; ++p)
+            mx::hip_check(hipMemcpy2DAsync(d->data[p], d->stride[p], host->data[p], (size_t)host->stride[p], d->pw(p), d->ph(p),
+                                           hipMemcpyHostToDevice, S(stream)), "hipMemcpy2DAsync(H2D frame)");
+        mx::hip_check(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    });
+}
+int mx_dframe_download(const mx_dframe* f, mx_frame* host, void* stream) {
+    return guard([&] {
+        check_host_frame(D(f), host);
+        const DFrame* d = D(f);
+        for (int p = 0; p < 3; ++p)
+            mx::hip_check(hipMemcpy2DAsync(host->data[p], (size_t)host->stride[p], d->data[p], d->stride[p], d->pw(p), d->ph(p),
+                                           hipMemcpyDeviceToHost, S(stream)), "hipMemcpy2DAsync(D2H frame)");
+        mx::hip_check(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    });
+}
+int mx_dframe_planes(const mx_dframe* f, uint32_t* width, uint32_t* height, void* device_data[3], int32_t stride[3]) {
+    return guard([&] {
+        REQUIRE(f, "frame is NULL");
+        const DFrame* d = D(f);
+        if (width) *width = d->width;
+        if (height) *height = d->height;
+        for (int p = 0; p < 3; ++p) { if (device_data) device_data[p] = d->data[p]; if (stride) stride[p] = (int32_t)d->stride[p]; }
+    });
+}
+
+int mx_video_blank(mx_dframe* f, void* stream) {
+    return guard([&] {
+        REQUIRE(f, "frame is NULL");
+        DFrame* d = D(f);
+        mx::launch_blank(d->data[0], d->plane_bytes[0], d->data[1], d->plane_bytes[1], d->data[2], d->plane_bytes[2], S(stream));
+        mx::hip_check(hipGetLastError(), "blank launch");
+    });
+}
+
+int mx_video_crossfade(mx_dframe* out, const mx_dframe* a, const mx_dframe* b, double fader, void* stream) {
+    return guard([&] {
+        REQUIRE(out, "out is NULL");
+        DFrame* o = D(out);
+        const DFrame* fa = a ? D(a) : nullptr;
+        const DFrame* fb = b ? D(b) : nullptr;
+        for (const DFrame* x : {fa, fb})
+            if (x && (x->width != o->width || x->height != o->height)) throw Error(MX_ERR_INVALID, "cross-fade inputs must have the output's size");
+        mx::FadeArgs ar;
+        ar.fade = mx::crossfade_factor(fader);
+        for (int p = 0; p < 3; ++p) {
+            ar.out[p] = o->data[p]; ar.out_stride[p] = o->stride[p];
+            ar.a[p] = fa ? fa->data[p] : nullptr; ar.a_stride[p] = fa ? fa->stride[p] : 0;
+            ar.b[p] = fb ? fb->data[p] : nullptr; ar.b_stride[p] = fb ? fb->stride[p] : 0;
+            ar.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;
+            ar.chunks[p] = ar.chunks_per_row[p] * o->ph(p);
+        }
+        mx::launch_crossfade(ar, S(stream));
+        mx::hip_check(hipGetLastError(), "cross-fade launch");
+    });
+}
+
+int mx_video_scale_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                            uint32_t* scaled_w, uint32_t* scaled_h, uint32_t* letterbox_x, uint32_t* letterbox_y) {
+    return guard([&] {
+        REQUIRE(in_w && in_h && out_w && out_h, "zero dimension");
+        const mx::ScaleGeometry g = mx::scaler_geometry(in_w, in_h, out_w, out_h);
+        if (scaled_w) *scaled_w = g.scaled_w;
+        if (scaled_h) *scaled_h = g.scaled_h;
+        if (letterbox_x) *letterbox_x = g.letterbox_x;
+        if (letterbox_y) *letterbox_y = g.letterbox_y;
+    });
+}
+
+int mx_video_scale(const mx_dframe* in, mx_dframe* out, void* stream) {
+    return guard([&] {
+        REQUIRE(in && out, "NULL argument");
+        DFrame* o = D(out);
+        hipStream_t s = S(stream);
+        mx::Scaler sc(o->width, o->height, s);
+        FrameRef src(const_cast<DFrame*>(D(in)), true);
+        FrameRef res = sc.scale(src);
+        mx::CopyArgs c;
+        for (int p = 0; p < 3; ++p) {
+            c.src[p] = res->data[p]; c.dst[p] = o->data[p];
+            c.src_stride[p] = res->stride[p]; c.dst_stride[p] = o->stride[p];
+            c.rows[p] = o->ph(p); c.row_bytes[p] = o->pw(p);
+        }
+        mx::launch_copy_planes(c, s);
+        mx::hip_check(hipGetLastError(), "scale launch");
+        mx::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");   // the temporary scaler's frame dies here
+    });
+}
+
+int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride, const int32_t* matrix_q12, void* stream) {
+    return guard([&] {
+        REQUIRE(in && device_rgba, "NULL argument");
+        const DFrame* d = D(in);
+        if (rgba_stride < (int32_t)(d->width * 4) || (rgba_stride & 15) || ((uintptr_t)device_rgba & 15))
+            throw Error(MX_ERR_INVALID, "rgba buffer must be 16-byte aligned with stride >= 4 * width, stride % 16 == 0");
+        mx::RgbaArgs a;
+        a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = (uint8_t*)device_rgba;
+        a.y_stride = d->stride[0]; a.u_stride = d->stride[1]; a.v_stride = d->stride[2]; a.rgba_stride = (uint32_t)rgba_stride;
+        a.width = d->width; a.height = d->height;
+        a.use_matrix = matrix_q12 ? 1 : 0;
+        for (int k = 0; k < 12; ++k) a.m[k] = matrix_q12 ? matrix_q12[k] : 0;
+        mx::launch_yuv420_to_rgba(a, S(stream));
+        mx::hip_check(hipGetLastError(), "yuv->rgba launch");
+    });
+}
+
+int mx_video_sync(void* stream) {
+    return guard([&] { mx::hip_check(hipStreamSynchronize(S(stream)), "hipStreamSynchronize"); });
+}
+
+int mx_video_mixer_create(const mx_video_mixer_params* params, uint32_t sample_rate, void* stream, mx_video_mixer** out) {
+    return guard([&] {
+        REQUIRE(params && out, "NULL argument");
+        *out = nullptr;
+        auto h = std::make_unique<mx_video_mixer>();
+        h->m = std::make_unique<mx::VideoMixer>(*params, sample_rate, (hipStream_t)stream);
+        *out = h.release();
+    });
+}
+int mx_video_mixer_update(mx_video_mixer* m, const mx_video_mixer_params* params) {
+    return guard([&] { REQUIRE(m && params, "NULL argument"); m->m->update(*params); });
+}
+int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input inputs[4],
+                            mx_dframe** out_program, mx_dframe** out_a, mx_dframe** out_b) {
+    return guard([&] {
+        REQUIRE(m && inputs, "NULL argument");
+        mx::VideoInput in[4];
+        for (int i = 0; i < 4; ++i) {
+            in[i].frame = inputs[i].frame ? D(inputs[i].frame) : nullptr;
+            if (in[i].frame) {
+                in[i].duration_hint = mx::Rational::make(inputs[i].dur_num, inputs[i].dur_den);
+                in[i].tick_offset = mx::Rational::make(inputs[i].off_num, inputs[i].off_den);
+            }
+        }
+        FrameRef o, a, b;
+        m->m->run_tick(t, in, o, a, b);
+        auto give = [](FrameRef& r, mx_dframe** dst) {
+            if (!dst) return;
+            *dst = nullptr;
+            if (r) { r->retain(); *dst = H(r.f); }
+        };
+        give(o, out_program); give(a, out_a); give(b, out_b);
+    });
+}
+int mx_video_mixer_sync(mx_video_mixer* m) {
+    return guard([&] { REQUIRE(m, "mixer is NULL"); mx::hip_check(hipStreamSynchronize(m->m->stream()), "hipStreamSynchronize"); });
+}
+void mx_video_mixer_destroy(mx_video_mixer* m) {
+    (void)guard([&] { delete m; });
+}
+
+int mx_device_alloc(size_t bytes, void** device_ptr) {
+    return guard([&] {
+        REQUIRE(device_ptr, "device_ptr is NULL");
+        *device_ptr = nullptr;
+        hipError_t e = hipMalloc(device_ptr, bytes ? bytes : 16);
+        if (e == hipErrorOutOfMemory) throw Error(MX_ERR_NOMEM, "hipMalloc: out of device memory");
+        mx::hip_check(e, "hipMalloc");
+    });
+}
+void mx_device_free(void* device_ptr) {
+    if (device_ptr) (void)hipFree(device_ptr);
+}
+int mx_device_download(void* host, const void* device_ptr, size_t bytes, void* stream) {
+    return guard([&] {
+        REQUIRE(host && device_ptr, "NULL argument");
+        mx::hip_check(hipMemcpyAsync(host, device_ptr, bytes, hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync(D2H)");
+        mx::hip_check(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// mx_k_video.hip -- pixel kernels: VideoMixer cross-fade (+ blank), bicubic plane scaler, YUV420P->RGBA.
+//
+// Integer work throughout: results are bit-exact against the CPU oracle.
+// Frames are planar yuv420p, 8 bit, resident in HBM; every plane row starts 64-byte aligned
+// (stride % 64 == 0), so a lane moves 16 pixels (one dwordx4) and a wave 1 KiB per instruction.
+#include "mx_dev.hpp"
+#include "mx_video.hpp"
+
+namespace mx {
+
+// ---------------------------------------------------------------------------------------------
+// Cross-fade (reference src/module/video_mixer.rs:151-239, fade_line :211-235):
+//   out = ((a * fade + b * (255 - fade)) / 255) as u8   in u16 lanes, integer division
+// A missing A or B reads the blank output plane itself (video_mixer.rs:180-188), i.e. the constant
+// the blank fill wrote (Y = 0x00, U = V = 0x80, codec/src/ffmpeg/frame.rs:128-132): the blank pass
+// is folded into this kernel instead of costing a separate frame-sized write.
+// x / 255 == (x + 1 + (x >> 8)) >> 8 for 0 <= x <= 65534; here x <= 255 * 255 (checked exhaustively in tests).
+// Like fade_line, rows are processed in 32-byte blocks up to ceil(width / 32) * 32.
+// algorithmic bytes per output frame: 3 F (2 F read + F written).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fade4(uint32_t a4, uint32_t b4, uint32_t fa, uint32_t fb) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t a = (a4 >> (8 * k)) & 0xffu, b = (b4 >> (8 * k)) & 0xffu;
+        const uint32_t x = a * fa + b * fb;              // <= 255 * 255, fits u16 like the reference's lanes
+        r |= (((x + 1u + (x >> 8)) >> 8) & 0xffu) << (8 * k);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_crossfade(FadeArgs args) {
+    // flat index over (plane, row, 16-byte chunk)
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    uint32_t idx = gid;
+    int plane = 0;
+    if (idx >= args.chunks[0]) { idx -= args.chunks[0]; plane = 1; if (idx >= args.chunks[1]) { idx -= args.chunks[1]; plane = 2; } }
+    if (plane == 2 && idx >= args.chunks[2]) return;
+    const uint32_t cpr = args.chunks_per_row[plane];
+    const uint32_t row = idx / cpr, col = (idx - row * cpr) * 16u;
+    const uint32_t fa = args.fade, fb = 255u - args.fade;
+    const uint32_t blank = plane ? 0x80808080u : 0u;
+    uint4 a = make_uint4(blank, blank, blank, blank), b = a;
+    if (args.a[plane]) a = *reinterpret_cast<const uint4*>(args.a[plane] + (size_t)row * args.a_stride[plane] + col);
+    if (args.b[plane]) b = *reinterpret_cast<const uint4*>(args.b[plane] + (size_t)row * args.b_stride[plane] + col);
+    uint4 o;
+    o.x = fade4(a.x, b.x, fa, fb); o.y = fade4(a.y, b.y, fa, fb); o.z = fade4(a.z, b.z, fa, fb); o.w = fade4(a.w, b.w, fa, fb);
+    *reinterpret_cast<uint4*>(args.out[plane] + (size_t)row * args.out_stride[plane] + col) = o;
+}
+
+void launch_crossfade(const FadeArgs& a, hipStream_t s) {
+    const uint32_t total = a.chunks[0] + a.chunks[1] + a.chunks[2];
+    if (!total) return;
+    hipLaunchKernelGGL(k_crossfade, dim3((total + 255) / 256), dim3(256), 0, s, a);
+}
+
+// Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
+__global__ __launch_bounds__(256) void k_blank(uint8_t* y, size_t y_bytes, uint8_t* u, size_t u_bytes, uint8_t* v, size_t v_bytes) {
+    const size_t yq = y_bytes / 16, uq = u_bytes / 16, vq = v_bytes / 16;
+    const uint4 zy = make_uint4(0, 0, 0, 0), zc = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < yq + uq + vq; i += (size_t)gridDim.x * 256) {
+        if (i < yq) reinterpret_cast<uint4*>(y)[i] = zy;
+        else if (i < yq + uq) reinterpret_cast<uint4*>(u)[i - yq] = zc;
+        else reinterpret_cast<uint4*>(v)[i - yq - uq] = zc;
+    }
+}
+void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s) {
+    const size_t q = (yb + ub + vb) / 16;
+    if (!q) return;
+    hipLaunchKernelGGL(k_blank, dim3(grid_x(q, 256, 2048)), dim3(256), 0, s, y, yb, u, ub, v, vb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bicubic plane scaler -- BUILD-SPECIFIED stand-in for sws_scale(SWS_BICUBIC)
+// (codec/src/ffmpeg/scale.rs:23-27,68; libswscale is third-party C outside the reference tree).
+// Spec in DESIGN.md "Scaler": host-computed Q14 tap tables (first tap index + 4 coefficients per
+// output column / row); H pass t = (sum hc*S + 64) >> 7, V pass D = clip8((sum vc*t + 2^20) >> 21).
+// One lane per output pixel; the 4x4 source neighbourhood is served by L1/L2 (neighbouring lanes
+// share 3 of 4 columns).  All three planes in one launch.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale_bicubic(ScaleArgs a) {
+    const int plane = blockIdx.z;
+    const ScalePlane p = a.p[plane];
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.dw || y >= p.dh) return;
+    const int4 hc = reinterpret_cast<const int4*>(p.hcoef)[x];
+    const int4 vc = reinterpret_cast<const int4*>(p.vcoef)[y];
+    const int hf = p.hfirst[x], vf = p.vfirst[y];
+    const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
+    const int x0 = min(max(hf, 0), sw1), x1 = min(max(hf + 1, 0), sw1), x2 = min(max(hf + 2, 0), sw1), x3 = min(max(hf + 3, 0), sw1);
+    int t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yy = min(max(vf + k, 0), sh1);
+        const uint8_t* row = p.src + (size_t)yy * p.src_stride;
+        const int acc = hc.x * (int)row[x0] + hc.y * (int)row[x1] + hc.z * (int)row[x2] + hc.w * (int)row[x3];
+        t[k] = (acc + 64) >> 7;
+    }
+    const int acc = vc.x * t[0] + vc.y * t[1] + vc.z * t[2] + vc.w * t[3];
+    const int v = (acc + (1 << 20)) >> 21;
+    p.dst[(size_t)y * p.dst_stride + x] = (uint8_t)min(max(v, 0), 255);
+}
+void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s) {
+    uint32_t mw = 0, mh = 0;
+    for (int i = 0; i < 3; ++i) { mw = a.p[i].dw > mw ? a.p[i].dw : mw; mh = a.p[i].dh > mh ? a.p[i].dh : mh; }
+    if (!mw || !mh) return;
+    hipLaunchKernelGGL(k_scale_bicubic, dim3((mw + 63) / 64, (mh + 3) / 4, 3), dim3(256), 0, s, a);
+}
+
+// plane copy (identity "scale" into a differently-strided frame, and frame clones)
+__global__ __launch_bounds__(256) void k_copy_planes(CopyArgs a) {
+    const int plane = blockIdx.z;
+    const uint32_t row = blockIdx.y;
+    if (row >= a.rows[plane]) return;
+    const uint32_t chunks = (a.row_bytes[plane] + 15) / 16;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < chunks; c += gridDim.x * 256)
+        reinterpret_cast<uint4*>(a.dst[plane] + (size_t)row * a.dst_stride[plane])[c] =
+            reinterpret_cast<const uint4*>(a.src[plane] + (size_t)row * a.src_stride[plane])[c];
+}
+void launch_copy_planes(const CopyArgs& a, hipStream_t s) {
+    uint32_t mr = a.rows[0] > a.rows[1] ? a.rows[0] : a.rows[1];
+    uint32_t mb = a.row_bytes[0];
+    if (!mr || !mb) return;
+    hipLaunchKernelGGL(k_copy_planes, dim3(((mb + 15) / 16 + 255) / 256, mr, 3), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// YUV420P -> RGBA8 -- BUILD-SPECIFIED (no reference counterpart): BT.709 limited range, integer,
+// nearest chroma, optional Q12 3x4 colour matrix (DESIGN.md "Colour").  4 pixels per lane: one
+// dword of Y, one ushort of U and V, one dwordx4 of RGBA out.
+// algorithmic bytes per frame: F + 4 * w * h.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clip8(int v) { return min(max(v, 0), 255); }
+
+__global__ __launch_bounds__(256) void k_yuv420_to_rgba(RgbaArgs a) {
+    const uint32_t xq = blockIdx.x * 64 + (threadIdx.x & 63);   // group of 4 pixels
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xq * 4 >= a.width || y >= a.height) return;
+    const uint32_t y4 = *reinterpret_cast<const uint32_t*>(a.y + (size_t)y * a.y_stride + xq * 4);
+    const uint16_t u2 = *reinterpret_cast<const uint16_t*>(a.u + (size_t)(y >> 1) * a.u_stride + xq * 2);
+    const uint16_t v2 = *reinterpret_cast<const uint16_t*>(a.v + (size_t)(y >> 1) * a.v_stride + xq * 2);
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int C = (int)((y4 >> (8 * k)) & 0xff) - 16;
+        const int D = (int)((u2 >> (8 * (k >> 1))) & 0xff) - 128;
+        const int E = (int)((v2 >> (8 * (k >> 1))) & 0xff) - 128;
+        int R = clip8((298 * C + 459 * E + 128) >> 8);
+        int G = clip8((298 * C - 55 * D - 136 * E + 128) >> 8);
+        int B = clip8((298 * C + 541 * D + 128) >> 8);
+        if (a.use_matrix) {
+            const int r2 = clip8((a.m[0] * R + a.m[1] * G + a.m[2] * B + a.m[3] + 2048) >> 12);
+            const int g2 = clip8((a.m[4] * R + a.m[5] * G + a.m[6] * B + a.m[7] + 2048) >> 12);
+            const int b2 = clip8((a.m[8] * R + a.m[9] * G + a.m[10] * B + a.m[11] + 2048) >> 12);
+            R = r2; G = g2; B = b2;
+        }
+        px[k] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xff000000u;
+    }
+    uint8_t* o = a.rgba + (size_t)y * a.rgba_stride + (size_t)xq * 16;
+    if (xq * 4 + 4 <= a.width) *reinterpret_cast<uint4*>(o) = make_uint4(px[0], px[1], px[2], px[3]);
+    else for (uint32_t k = 0; xq * 4 + k < a.width; ++k) reinterpret_cast<uint32_t*>(o)[k] = px[k];
+}
+void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s) {
+    if (!a.width || !a.height) return;
+    hipLaunchKernelGGL(k_yuv420_to_rgba, dim3(((a.width + 3) / 4 + 63) / 64, (a.height + 3) / 4), dim3(256), 0, s, a);
+}
+
+}  // namespace mx

@@ -1,0 +1,236 @@
+// mx_video.cpp -- host logic of the pixel path: frames, DynamicScaler, VideoMixer.  See mx_video.hpp.
+#include "mx_video.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace mx {
+
+// ---------------------------------------------------------------------------------------------
+// Rational64 as used by MediaTime / MediaDuration (util/src/time.rs): reduced, positive denominator
+// ---------------------------------------------------------------------------------------------
+static int64_t gcd_i64(int64_t a, int64_t b) {
+    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    return a ? a : 1;
+}
+Rational Rational::make(int64_t n, int64_t d) {
+    if (d == 0) throw Error(MX_ERR_INVALID, "rational with zero denominator");
+    if (d < 0) { n = -n; d = -d; }
+    const int64_t g = gcd_i64(n, d);
+    Rational r; r.num = n / g; r.den = d / g;
+    return r;
+}
+Rational Rational::operator+(const Rational& o) const {
+    const int64_t g = gcd_i64(den, o.den);
+    const int64_t lcm = den / g * o.den;
+    return make(num * (lcm / den) + o.num * (lcm / o.den), lcm);
+}
+bool Rational::operator>=(const Rational& o) const {
+    return (__int128)num * o.den >= (__int128)o.num * den;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frames
+// ---------------------------------------------------------------------------------------------
+DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s) {
+    if (w == 0 || h == 0 || (w & 1) || (h & 1)) throw Error(MX_ERR_INVALID, "yuv420p frame size must be even and non-zero");
+    if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
+    std::unique_ptr<DFrame> f(new DFrame());
+    f->width = w; f->height = h;
+    size_t off[3], total = 0;
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t pw = p ? w >> 1 : w, ph = p ? h >> 1 : h;
+        f->stride[p] = (pw + 63u) & ~63u;               // rows 64-byte aligned (the reference asserts 32, video_mixer.rs:196-201)
+        f->plane_bytes[p] = (size_t)f->stride[p] * ph;
+        off[p] = total;
+        total += (f->plane_bytes[p] + 255) & ~(size_t)255;
+    }
+    f->mem.alloc(total);
+    for (int p = 0; p < 3; ++p) f->data[p] = (uint8_t*)f->mem.p + off[p];
+    launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s);
+    return f.release();
+}
+
+// video_mixer.rs:276-297: max of each dimension, rounded UP to the chroma grid (yuv420p: even)
+void unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t& w, uint32_t& h) {
+    const uint32_t width = std::max(aw, bw), height = std::max(ah, bh);
+    w = (width + 1u) & ~1u;
+    h = (height + 1u) & ~1u;
+}
+
+// encode.rs:354-374: min of the two exact ratios, scaled size truncated then aligned DOWN to even,
+// letterbox offsets halved then aligned down to even
+ScaleGeometry scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h) {
+    uint64_t num, den;
+    if ((uint64_t)out_w * in_h <= (uint64_t)out_h * in_w) { num = out_w; den = in_w; } else { num = out_h; den = in_h; }
+    ScaleGeometry g;
+    g.scaled_w = (uint32_t)(num * in_w / den) & ~1u;
+    g.scaled_h = (uint32_t)(num * in_h / den) & ~1u;
+    g.letterbox_x = ((out_w - g.scaled_w) / 2) & ~1u;
+    g.letterbox_y = ((out_h - g.scaled_h) / 2) & ~1u;
+    return g;
+}
+
+// video_mixer.rs:168: `(fader * 255.0) as u8` -- saturating, truncating, NaN -> 0
+uint8_t crossfade_factor(double fader) {
+    const double v = fader * 255.0;
+    if (!(v == v) || v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bicubic tap tables (build-specified scaler, DESIGN.md "Scaler")
+// ---------------------------------------------------------------------------------------------
+static int64_t floor_div(int64_t a, int64_t b) {   // b > 0
+    int64_t q = a / b;
+    if ((a % b) < 0) --q;
+    return q;
+}
+static int32_t cubic_weight_q14(int64_t X) {   // |x| in Q16
+    const int64_t one48 = (int64_t)1 << 48;
+    int64_t num;
+    if (X < 65536) num = 7 * X * X * X - 12 * 65536 * X * X + 5 * one48;                                             // (7x^3 - 12x^2 + 5) / 5
+    else if (X < 131072) num = -3 * X * X * X + 15 * 65536 * X * X - 24 * ((int64_t)1 << 32) * X + 12 * one48;    // (-3x^3 + 15x^2 - 24x + 12) / 5
+    else return 0;
+    const int64_t den = 5 * ((int64_t)1 << 34);
+    return (int32_t)floor_div(2 * num + den, 2 * den);
+}
+static void make_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef) {
+    first.resize(dst); coef.resize((size_t)dst * 4);
+    for (uint32_t o = 0; o < dst; ++o) {
+        const int64_t pos = floor_div((2 * (int64_t)o + 1) * (int64_t)src * 65536, 2 * (int64_t)dst) - 32768;
+        const int64_t ip = pos >> 16, d = pos & 0xffff;
+        int32_t c[4] = {cubic_weight_q14(65536 + d), cubic_weight_q14(d), cubic_weight_q14(65536 - d), cubic_weight_q14(131072 - d)};
+        const int32_t resid = 16384 - (c[0] + c[1] + c[2] + c[3]);
+        if (c[2] > c[1]) c[2] += resid; else c[1] += resid;
+        first[o] = (int32_t)ip - 1;
+        std::memcpy(&coef[(size_t)o * 4], c, sizeof c);
+    }
+}
+
+void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
+    in_w_ = in_w; in_h_ = in_h;
+    geo_ = scaler_geometry(in_w, in_h, out_w_, out_h_);
+    frame_ = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
+    // tap tables: [luma h, luma v, chroma h, chroma v]
+    std::vector<int32_t> blob;
+    size_t offs[2][4];
+    for (int c = 0; c < 2; ++c) {
+        std::vector<int32_t> hf, hc, vf, vc;
+        make_taps(in_w >> c, geo_.scaled_w >> c, hf, hc);
+        make_taps(in_h >> c, geo_.scaled_h >> c, vf, vc);
+        auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
+        offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
+    }
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // a previous scale may still read the old tables
+    tabs_.alloc(blob.size() * sizeof(int32_t));
+    hip_check(hipMemcpy(tabs_.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(taps)");
+    for (int c = 0; c < 2; ++c) for (int k = 0; k < 4; ++k) tab_[c][k] = (const int32_t*)tabs_.p + offs[c][k];
+}
+
+FrameRef Scaler::scale(const FrameRef& in) {
+    if (in->width == out_w_ && in->height == out_h_) return in;                 // encode.rs:342-345
+    if (!frame_ || in_w_ != in->width || in_h_ != in->height) retarget(in->width, in->height);   // encode.rs:347-384
+    if (geo_.scaled_w == 0 || geo_.scaled_h == 0) return frame_;
+    ScaleArgs a;
+    for (int p = 0; p < 3; ++p) {
+        const int c = p ? 1 : 0;
+        ScalePlane& sp = a.p[p];
+        sp.src = in->data[p]; sp.src_stride = in->stride[p]; sp.sw = in->pw(p); sp.sh = in->ph(p);
+        // sub-frame view at the letterbox offset (frame.rs:253-278)
+        sp.dst = frame_->data[p] + (size_t)(geo_.letterbox_y >> c) * frame_->stride[p] + (geo_.letterbox_x >> c);
+        sp.dst_stride = frame_->stride[p]; sp.dw = geo_.scaled_w >> c; sp.dh = geo_.scaled_h >> c;
+        sp.hfirst = tab_[c][0]; sp.hcoef = tab_[c][1]; sp.vfirst = tab_[c][2]; sp.vcoef = tab_[c][3];
+    }
+    launch_scale_bicubic(a, stream_);
+    return frame_;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VideoMixer::run_tick (src/module/video_mixer.rs:70-250)
+// ---------------------------------------------------------------------------------------------
+VideoMixer::VideoMixer(const mx_video_mixer_params& p, uint32_t sample_rate, hipStream_t s)
+    : params_(p), sample_rate_(sample_rate ? sample_rate : 44100u), stream_(s) {
+    if (!stream_) { hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"); own_stream_ = true; }
+}
+VideoMixer::~VideoMixer() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& c : ch_) { c.stored.frame = FrameRef(); c.scaler.reset(); }
+    pool_.clear();
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+FrameRef VideoMixer::fresh_output(uint32_t w, uint32_t h) {
+    for (auto& f : pool_)
+        if (f->width == w && f->height == h && f->rc.load(std::memory_order_acquire) == 1) return f;   // only the pool holds it
+    if (pool_.size() >= 8) pool_.erase(pool_.begin());
+    pool_.push_back(FrameRef(DFrame::create(w, h, stream_), false));
+    return pool_.back();
+}
+
+void VideoMixer::rescale(Channel& ch, uint32_t tw, uint32_t th) {   // Channel::rescale, video_mixer.rs:261-274
+    if (!ch.scaler || ch.scaler->out_w() != tw || ch.scaler->out_h() != th) {
+        ch.scaler.reset(new Scaler(tw, th, stream_));
+        if (ch.has_stored) ch.stored.frame = ch.scaler->scale(ch.stored.frame);
+    }
+}
+
+void VideoMixer::run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, FrameRef& out_a, FrameRef& out_b) {
+    out = FrameRef(); out_a = FrameRef(); out_b = FrameRef();
+    // channel-specific pass-through outputs (video_mixer.rs:80-90)
+    if (params_.a >= 0 && params_.a < 4 && in[params_.a].frame) out_a = FrameRef(in[params_.a].frame, true);
+    if (params_.b >= 0 && params_.b < 4 && in[params_.b].frame) out_b = FrameRef(in[params_.b].frame, true);
+
+    const Rational now = Rational::make((int64_t)t, (int64_t)sample_rate_);   // video_mixer.rs:92
+    for (auto& c : ch_)                                                         // expire stored frames, :94-101
+        if (c.has_stored && now >= c.stored.active_until) { c.has_stored = false; c.stored.frame = FrameRef(); }
+
+    // compatible output picture settings (:104-119)
+    bool have = false; uint32_t tw = 0, th = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t w, h;
+        if (in[i].frame) { w = in[i].frame->width; h = in[i].frame->height; }
+        else if (ch_[i].has_stored) { w = ch_[i].stored.frame->width; h = ch_[i].stored.frame->height; }
+        else continue;
+        if (!have) { tw = w; th = h; have = true; }            // fold1: a single item passes through un-unified
+        else unify_picture_settings(tw, th, w, h, tw, th);
+    }
+    if (!have) return;                                         // :113-119, output stays None
+
+    // receive new input frames (:122-148)
+    for (int i = 0; i < 4; ++i) {
+        Channel& c = ch_[i];
+        if (in[i].frame) {
+            c.has_stored = false; c.stored.frame = FrameRef();
+            rescale(c, tw, th);
+            FrameRef f(in[i].frame, true);                     // video.data.decoded.clone()
+            c.stored.frame = c.scaler->scale(f);
+            c.stored.active_until = now + in[i].tick_offset + in[i].duration_hint;
+            c.has_stored = true;
+        } else {
+            rescale(c, tw, th);
+        }
+    }
+
+    // compose (:150-239); the blank fill (:151) is folded into the cross-fade kernel
+    FrameRef o = fresh_output(tw, th);
+    const DFrame* fa = (params_.a >= 0 && params_.a < 4 && ch_[params_.a].has_stored) ? ch_[params_.a].stored.frame.f : nullptr;
+    const DFrame* fb = (params_.b >= 0 && params_.b < 4 && ch_[params_.b].has_stored) ? ch_[params_.b].stored.frame.f : nullptr;
+    FadeArgs a;
+    a.fade = crossfade_factor(params_.fader);
+    for (int p = 0; p < 3; ++p) {
+        a.out[p] = o->data[p]; a.out_stride[p] = o->stride[p];
+        a.a[p] = fa ? fa->data[p] : nullptr; a.a_stride[p] = fa ? fa->stride[p] : 0;
+        a.b[p] = fb ? fb->data[p] : nullptr; a.b_stride[p] = fb ? fb->stride[p] : 0;
+        a.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;
+        a.chunks[p] = a.chunks_per_row[p] * o->ph(p);
+    }
+    launch_crossfade(a, stream_);
+    hip_check(hipGetLastError(), "cross-fade launch");
+    out = o;
+}
+
+}  // namespace mx

@@ -1,0 +1,133 @@
+// mx_video.hpp -- device-resident yuv420p frames, the DynamicScaler and the VideoMixer (internal).
+//
+// Host logic mirrors reference src/module/video_mixer.rs:70-297 and src/video/encode.rs:311-398;
+// pixel work is in mx_k_video.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "mx_engine.hpp"
+
+namespace mx {
+
+// ---- kernel argument blocks (passed by value) ----
+struct FadeArgs {
+    uint8_t* out[3]; const uint8_t* a[3]; const uint8_t* b[3];   // a/b nullptr => blank constant
+    uint32_t out_stride[3], a_stride[3], b_stride[3];
+    uint32_t chunks[3];          // rows * chunks_per_row per plane
+    uint32_t chunks_per_row[3];  // ceil(width / 32) * 2 sixteen-byte chunks (fade_line's 32-byte blocks)
+    uint32_t fade;               // (fader * 255.0) as u8, video_mixer.rs:168
+};
+struct ScalePlane {
+    const uint8_t* src; uint8_t* dst;
+    uint32_t src_stride, dst_stride, sw, sh, dw, dh;
+    const int32_t* hfirst; const int32_t* hcoef;   // [dw], [dw][4]
+    const int32_t* vfirst; const int32_t* vcoef;   // [dh], [dh][4]
+};
+struct ScaleArgs { ScalePlane p[3]; };
+struct CopyArgs { const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], rows[3], row_bytes[3]; };
+struct RgbaArgs {
+    const uint8_t* y; const uint8_t* u; const uint8_t* v; uint8_t* rgba;
+    uint32_t y_stride, u_stride, v_stride, rgba_stride, width, height;
+    int32_t use_matrix; int32_t m[12];
+};
+
+void launch_crossfade(const FadeArgs& a, hipStream_t s);
+void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s);
+void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s);
+void launch_copy_planes(const CopyArgs& a, hipStream_t s);
+void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
+
+// ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----
+struct Rational {
+    int64_t num = 0, den = 1;
+    static Rational make(int64_t n, int64_t d);
+    Rational operator+(const Rational& o) const;
+    bool operator>=(const Rational& o) const;
+};
+
+// ---- device frame: the AvFrame<Video> stand-in (codec/src/ffmpeg/frame.rs) ----
+// Reference-counted like an AVFrame (frame.rs:351-361 clone = av_frame_clone): the VideoMixer keeps
+// inputs past the call by retaining them, never by copying pixels.
+struct DFrame {
+    std::atomic<int> rc{1};
+    uint32_t width = 0, height = 0;      // luma size (even)
+    uint8_t* data[3] = {nullptr, nullptr, nullptr};
+    uint32_t stride[3] = {0, 0, 0};
+    size_t plane_bytes[3] = {0, 0, 0};
+    DevBuf mem;
+    static DFrame* create(uint32_t w, uint32_t h, hipStream_t s);   // blank-filled (frame.rs:76-138)
+    void retain() { rc.fetch_add(1, std::memory_order_relaxed); }
+    void release() { if (rc.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
+    uint32_t pw(int p) const { return p ? width >> 1 : width; }
+    uint32_t ph(int p) const { return p ? height >> 1 : height; }
+};
+struct FrameRef {   // intrusive handle
+    DFrame* f = nullptr;
+    FrameRef() = default;
+    explicit FrameRef(DFrame* p, bool add_ref) : f(p) { if (f && add_ref) f->retain(); }
+    FrameRef(const FrameRef& o) : f(o.f) { if (f) f->retain(); }
+    FrameRef(FrameRef&& o) noexcept : f(o.f) { o.f = nullptr; }
+    FrameRef& operator=(FrameRef o) noexcept { std::swap(f, o.f); return *this; }
+    ~FrameRef() { if (f) f->release(); }
+    explicit operator bool() const { return f != nullptr; }
+    DFrame* operator->() const { return f; }
+};
+
+struct ScaleGeometry { uint32_t scaled_w, scaled_h, letterbox_x, letterbox_y; };
+ScaleGeometry scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h);   // encode.rs:354-374
+void unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t& w, uint32_t& h);   // video_mixer.rs:276-297
+uint8_t crossfade_factor(double fader);   // video_mixer.rs:168
+
+// DynamicScaler (src/video/encode.rs:311-398)
+class Scaler {
+public:
+    Scaler(uint32_t out_w, uint32_t out_h, hipStream_t s) : out_w_(out_w), out_h_(out_h), stream_(s) {}
+    uint32_t out_w() const { return out_w_; }
+    uint32_t out_h() const { return out_h_; }
+    // returns the frame itself when its settings equal the output's (encode.rs:342-345), else the
+    // scaler's own letterboxed output frame (encode.rs:386-396)
+    FrameRef scale(const FrameRef& in);
+private:
+    void retarget(uint32_t in_w, uint32_t in_h);
+    uint32_t out_w_, out_h_;
+    hipStream_t stream_;
+    uint32_t in_w_ = 0, in_h_ = 0;   // settings the cached context was built for (encode.rs:347-352)
+    ScaleGeometry geo_{};
+    FrameRef frame_;                 // cached blank output frame (encode.rs:382)
+    DevBuf tabs_;                    // tap tables for luma and chroma
+    const int32_t* tab_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [luma/chroma][hfirst,hcoef,vfirst,vcoef]
+};
+
+struct VideoInput { DFrame* frame = nullptr; Rational duration_hint; Rational tick_offset; };   // engine::VideoFrame, io.rs:12-17
+
+// VideoMixer (src/module/video_mixer.rs)
+class VideoMixer {
+public:
+    VideoMixer(const mx_video_mixer_params& p, uint32_t sample_rate, hipStream_t s);
+    void update(const mx_video_mixer_params& p) { params_ = p; }   // video_mixer.rs:65-68
+    // returns program / A / B frames (null FrameRef = None)
+    void run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, FrameRef& out_a, FrameRef& out_b);
+    hipStream_t stream() const { return stream_; }
+private:
+    struct Stored { Rational active_until; FrameRef frame; };
+    struct Channel { bool has_stored = false; Stored stored; std::unique_ptr<Scaler> scaler; };
+    void rescale(Channel& ch, uint32_t tw, uint32_t th);   // video_mixer.rs:261-274
+    mx_video_mixer_params params_;
+    uint32_t sample_rate_;
+    hipStream_t stream_;
+    bool own_stream_ = false;
+    Channel ch_[4];
+    // output frames are fresh each tick in the reference; here a small ring recycles them once the
+    // caller has dropped its references
+    std::vector<FrameRef> pool_;
+    FrameRef fresh_output(uint32_t w, uint32_t h);
+public:
+    ~VideoMixer();
+};
+
+}  // namespace mx

@@ -1,0 +1,197 @@
+"""ctypes binding of the pixel half of include/mixlab_gpu.h (plumbing for tests and bench.py)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import check, lib
+
+
+class VideoMixerParams(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("fader", C.c_double)]   # -1 = None (protocol/src/lib.rs:405-410)
+
+
+class VideoInput(C.Structure):
+    _fields_ = [("frame", C.c_void_p), ("dur_num", C.c_int64), ("dur_den", C.c_int64), ("off_num", C.c_int64), ("off_den", C.c_int64)]
+
+
+def _proto(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+
+
+_proto("mx_dframe_create", C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_dframe_retain", C.c_int, C.c_void_p)
+_proto("mx_dframe_release", None, C.c_void_p)
+_proto("mx_dframe_upload", C.c_int, C.c_void_p, C.POINTER(abi.Frame), C.c_void_p)
+_proto("mx_dframe_download", C.c_int, C.c_void_p, C.POINTER(abi.Frame), C.c_void_p)
+_proto("mx_dframe_planes", C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p * 3), C.POINTER(C.c_int32 * 3))
+_proto("mx_video_blank", C.c_int, C.c_void_p, C.c_void_p)
+_proto("mx_video_crossfade", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p)
+_proto("mx_video_scale", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_proto("mx_video_scale_geometry", C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+_proto("mx_video_to_rgba", C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p)
+_proto("mx_video_sync", C.c_int, C.c_void_p)
+_proto("mx_video_mixer_create", C.c_int, C.POINTER(VideoMixerParams), C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_video_mixer_update", C.c_int, C.c_void_p, C.POINTER(VideoMixerParams))
+_proto("mx_video_mixer_run_tick", C.c_int, C.c_void_p, C.c_uint64, C.POINTER(VideoInput),
+       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+_proto("mx_video_mixer_sync", C.c_int, C.c_void_p)
+_proto("mx_video_mixer_destroy", None, C.c_void_p)
+_proto("mx_device_alloc", C.c_int, C.c_size_t, C.POINTER(C.c_void_p))
+_proto("mx_device_free", None, C.c_void_p)
+_proto("mx_device_download", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def _host_frame(planes, w, h):
+    """abi.Frame over three contiguous uint8 plane arrays (rows = plane height, stride = array row length)."""
+    f = abi.Frame()
+    f.width, f.height = w, h
+    for p in range(3):
+        a = planes[p]
+        assert a.dtype == np.uint8 and a.flags.c_contiguous and a.ndim == 2
+        f.data[p] = a.ctypes.data
+        f.stride[p] = a.shape[1]
+    return f
+
+
+class DFrame:
+    """Device-resident yuv420p frame (one reference owned by this object)."""
+
+    def __init__(self, width=None, height=None, stream=None, handle=None):
+        self.stream = stream
+        if handle is not None:
+            self._h = C.c_void_p(handle)
+        else:
+            self._h = C.c_void_p()
+            check(lib.mx_dframe_create(width, height, stream, C.byref(self._h)))
+        w, h = C.c_uint32(), C.c_uint32()
+        self._data = (C.c_void_p * 3)()
+        self._stride = (C.c_int32 * 3)()
+        check(lib.mx_dframe_planes(self._h, C.byref(w), C.byref(h), C.byref(self._data), C.byref(self._stride)))
+        self.width, self.height = w.value, h.value
+
+    @property
+    def handle(self):
+        return self._h.value
+
+    def release(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.mx_dframe_release(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def upload(self, y, u, v):
+        planes = [np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v)]
+        hf = _host_frame(planes, self.width, self.height)
+        check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
+        return self
+
+    def download(self):
+        planes = [np.empty((self.height >> (1 if p else 0), self.width >> (1 if p else 0)), np.uint8) for p in range(3)]
+        hf = _host_frame(planes, self.width, self.height)
+        check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
+        return planes
+
+    def device_planes(self):
+        return [self._data[p] for p in range(3)], [self._stride[p] for p in range(3)]
+
+
+def blank(f: DFrame, stream=None):
+    check(lib.mx_video_blank(f._h, stream))
+
+
+def crossfade(out: DFrame, a: DFrame | None, b: DFrame | None, fader: float, stream=None):
+    check(lib.mx_video_crossfade(out._h, a._h if a else None, b._h if b else None, fader, stream))
+
+
+def scale(src: DFrame, dst: DFrame, stream=None):
+    check(lib.mx_video_scale(src._h, dst._h, stream))
+
+
+def scale_geometry(in_w, in_h, out_w, out_h):
+    v = [C.c_uint32() for _ in range(4)]
+    check(lib.mx_video_scale_geometry(in_w, in_h, out_w, out_h, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def sync(stream=None):
+    check(lib.mx_video_sync(stream))
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = nbytes
+        check(lib.mx_device_alloc(nbytes, C.byref(self.ptr)))
+
+    def download(self, stream=None) -> np.ndarray:
+        out = np.empty(self.nbytes, np.uint8)
+        check(lib.mx_device_download(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes, stream))
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            lib.mx_device_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+
+def to_rgba(f: DFrame, matrix_q12=None, stream=None, out: DeviceBuffer | None = None, download=True):
+    stride = ((f.width * 4 + 15) // 16) * 16
+    buf = out or DeviceBuffer(stride * f.height)
+    m = (C.c_int32 * 12)(*matrix_q12) if matrix_q12 is not None else None
+    check(lib.mx_video_to_rgba(f._h, buf.ptr, stride, m, stream))
+    if not download:
+        return buf
+    return buf.download(stream).reshape(f.height, stride)[:, : f.width * 4].reshape(f.height, f.width, 4)
+
+
+class VideoMixer:
+    """mx_video_mixer_*: VideoMixer::run_tick on device-resident frames (src/module/video_mixer.rs)."""
+
+    def __init__(self, a=None, b=None, fader=1.0, sample_rate=44100, stream=None):
+        self._h = C.c_void_p()
+        p = VideoMixerParams(-1 if a is None else a, -1 if b is None else b, fader)
+        check(lib.mx_video_mixer_create(C.byref(p), sample_rate, stream, C.byref(self._h)))
+
+    def update(self, a=None, b=None, fader=1.0):
+        p = VideoMixerParams(-1 if a is None else a, -1 if b is None else b, fader)
+        check(lib.mx_video_mixer_update(self._h, C.byref(p)))
+
+    def run_tick(self, t, inputs):
+        """inputs: 4 entries, each None or (DFrame, (dur_num, dur_den), (off_num, off_den)).
+        Returns (program, a, b) as DFrame or None (each owns one reference)."""
+        arr = (VideoInput * 4)()
+        for i in range(4):
+            e = inputs[i] if i < len(inputs) else None
+            if e is None:
+                arr[i] = VideoInput(None, 0, 1, 0, 1)
+            else:
+                fr, dur, off = e
+                arr[i] = VideoInput(fr.handle, dur[0], dur[1], off[0], off[1])
+        o, a, b = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.mx_video_mixer_run_tick(self._h, t, arr, C.byref(o), C.byref(a), C.byref(b)))
+        return tuple(DFrame(handle=x.value) if x.value else None for x in (o, a, b))
+
+    def sync(self):
+        check(lib.mx_video_mixer_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.mx_video_mixer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

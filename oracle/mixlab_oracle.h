@@ -128,6 +128,9 @@ int orc_graph_plotter_indication(const orc_graph* g, uint32_t node, float* left,
 /* number of nodes in run order; order[i] filled */
 size_t orc_graph_run_order(const orc_graph* g, uint32_t* order, size_t cap);
 
+/* rational time helpers used by VideoMixer frame expiry (util/src/time.rs:9-75) */
+typedef struct { int64_t num, den; } orc_rational;
+
 /* ---- video: planar yuv420p 8-bit ---- */
 typedef struct {
     uint32_t width, height;     /* luma dimensions (codec/src/ffmpeg/frame.rs:180-186) */
@@ -157,8 +160,18 @@ void orc_dynamic_scale(const orc_frame* in, orc_frame* out);
  * nearest chroma, then optional 3x4 colour matrix in Q12. parity unpinned. */
 void orc_yuv420_to_rgba(const orc_frame* in, uint8_t* rgba, int32_t rgba_stride, const int32_t* matrix_q12 /* 12 or NULL */);
 
-/* rational time helpers used by VideoMixer frame expiry (util/src/time.rs:9-75) */
-typedef struct { int64_t num, den; } orc_rational;
+/* VideoMixer::run_tick (src/module/video_mixer.rs:70-250) as a state machine over owned frame copies */
+typedef struct {
+    int32_t a, b; double fader; uint32_t sample_rate;
+    int has_stored[4]; orc_frame stored[4]; orc_rational active_until[4];
+    int has_scaler[4]; uint32_t scaler_w[4], scaler_h[4];
+} orc_video_mixer;
+typedef struct { const orc_frame* frame; orc_rational duration_hint, tick_offset; } orc_video_input;
+void orc_video_mixer_init(orc_video_mixer* m, int32_t a, int32_t b, double fader, uint32_t sample_rate);
+void orc_video_mixer_free(orc_video_mixer* m);
+/* out: caller-allocated planes large enough for the unified size; width/height are set on return */
+int orc_video_mixer_run_tick(orc_video_mixer* m, uint64_t t, const orc_video_input in[4], orc_frame* out, int* out_present);
+
 orc_rational orc_rational_new(int64_t num, int64_t den);
 orc_rational orc_rational_add(orc_rational a, orc_rational b);
 int orc_rational_cmp(orc_rational a, orc_rational b);

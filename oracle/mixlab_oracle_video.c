@@ -221,3 +221,80 @@ int orc_rational_cmp(orc_rational a, orc_rational b) {
     __int128 l = (__int128)a.num * b.den, r = (__int128)b.num * a.den;
     return l < r ? -1 : (l > r ? 1 : 0);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* VideoMixer::run_tick, src/module/video_mixer.rs:70-250, as a plain state machine over owned
+ * frame copies (an AVFrame refcount clone of an immutable frame is observationally a copy). */
+static void vm_frame_alloc(orc_frame* f, uint32_t w, uint32_t h) {
+    f->width = w; f->height = h;
+    for (int p = 0; p < 3; ++p) {
+        uint32_t pw = p ? w >> 1 : w, ph = p ? h >> 1 : h;
+        f->stride[p] = (int32_t)((pw + 63u) & ~63u);
+        f->data[p] = (uint8_t*)malloc((size_t)f->stride[p] * (ph ? ph : 1));
+    }
+}
+static void vm_frame_free(orc_frame* f) { for (int p = 0; p < 3; ++p) { free(f->data[p]); f->data[p] = NULL; } f->width = f->height = 0; }
+static void vm_frame_copy_from(orc_frame* dst, const orc_frame* src) {   /* dst freshly allocated with src's size */
+    for (int p = 0; p < 3; ++p) {
+        uint32_t pw = p ? src->width >> 1 : src->width, ph = p ? src->height >> 1 : src->height;
+        for (uint32_t y = 0; y < ph; ++y) memcpy(dst->data[p] + (size_t)y * dst->stride[p], src->data[p] + (size_t)y * src->stride[p], pw);
+    }
+}
+
+void orc_video_mixer_init(orc_video_mixer* m, int32_t a, int32_t b, double fader, uint32_t sample_rate) {
+    memset(m, 0, sizeof *m);
+    m->a = a; m->b = b; m->fader = fader; m->sample_rate = sample_rate ? sample_rate : 44100;
+}
+void orc_video_mixer_free(orc_video_mixer* m) {
+    for (int i = 0; i < 4; ++i) if (m->has_stored[i]) { vm_frame_free(&m->stored[i]); m->has_stored[i] = 0; }
+}
+
+/* Channel::rescale, video_mixer.rs:261-274 */
+static void vm_rescale(orc_video_mixer* m, int i, uint32_t tw, uint32_t th) {
+    if (!m->has_scaler[i] || m->scaler_w[i] != tw || m->scaler_h[i] != th) {
+        m->has_scaler[i] = 1; m->scaler_w[i] = tw; m->scaler_h[i] = th;
+        if (m->has_stored[i]) {
+            orc_frame scaled; vm_frame_alloc(&scaled, tw, th);
+            orc_dynamic_scale(&m->stored[i], &scaled);
+            vm_frame_free(&m->stored[i]);
+            m->stored[i] = scaled;
+        }
+    }
+}
+
+int orc_video_mixer_run_tick(orc_video_mixer* m, uint64_t t, const orc_video_input in[4], orc_frame* out, int* out_present) {
+    *out_present = 0;
+    orc_rational now = orc_rational_new((int64_t)t, (int64_t)m->sample_rate);           /* :92 */
+    for (int i = 0; i < 4; ++i)                                                          /* expire, :94-101 */
+        if (m->has_stored[i] && orc_rational_cmp(now, m->active_until[i]) >= 0) { vm_frame_free(&m->stored[i]); m->has_stored[i] = 0; }
+    int have = 0; uint32_t tw = 0, th = 0;                                               /* target, :104-119 */
+    for (int i = 0; i < 4; ++i) {
+        uint32_t w, h;
+        if (in[i].frame) { w = in[i].frame->width; h = in[i].frame->height; }
+        else if (m->has_stored[i]) { w = m->stored[i].width; h = m->stored[i].height; }
+        else continue;
+        if (!have) { tw = w; th = h; have = 1; } else orc_unify_picture_settings(tw, th, w, h, &tw, &th);
+    }
+    if (!have) return 0;
+    for (int i = 0; i < 4; ++i) {                                                        /* new inputs, :122-148 */
+        if (in[i].frame) {
+            if (m->has_stored[i]) { vm_frame_free(&m->stored[i]); m->has_stored[i] = 0; }
+            vm_rescale(m, i, tw, th);
+            vm_frame_alloc(&m->stored[i], tw, th);
+            orc_dynamic_scale(in[i].frame, &m->stored[i]);
+            m->active_until[i] = orc_rational_add(orc_rational_add(now, in[i].tick_offset), in[i].duration_hint);
+            m->has_stored[i] = 1;
+        } else {
+            vm_rescale(m, i, tw, th);
+        }
+    }
+    /* compose, :150-239 (out must have room for tw x th with its own strides) */
+    out->width = tw; out->height = th;
+    orc_frame_blank(out);
+    const orc_frame* fa = (m->a >= 0 && m->a < 4 && m->has_stored[m->a]) ? &m->stored[m->a] : NULL;
+    const orc_frame* fb = (m->b >= 0 && m->b < 4 && m->has_stored[m->b]) ? &m->stored[m->b] : NULL;
+    orc_video_crossfade(out, fa, fb, orc_crossfade_factor(m->fader));
+    *out_present = 1;
+    (void)vm_frame_copy_from;
+    return 0;
+}

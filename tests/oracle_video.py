@@ -1,0 +1,142 @@
+"""ctypes wrapper of the oracle's pixel path -- TEST INFRASTRUCTURE (the checker), never the product."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from oracle import OFrame, Rational, ScaleGeometry, lib
+
+
+class VMixer(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("fader", C.c_double), ("sample_rate", C.c_uint32),
+                ("has_stored", C.c_int * 4), ("stored", OFrame * 4), ("active_until", Rational * 4),
+                ("has_scaler", C.c_int * 4), ("scaler_w", C.c_uint32 * 4), ("scaler_h", C.c_uint32 * 4)]
+
+
+class VInput(C.Structure):
+    _fields_ = [("frame", C.POINTER(OFrame)), ("duration_hint", Rational), ("tick_offset", Rational)]
+
+
+lib.orc_video_mixer_init.argtypes = [C.POINTER(VMixer), C.c_int32, C.c_int32, C.c_double, C.c_uint32]
+lib.orc_video_mixer_free.argtypes = [C.POINTER(VMixer)]
+lib.orc_video_mixer_run_tick.argtypes = [C.POINTER(VMixer), C.c_uint64, C.POINTER(VInput), C.POINTER(OFrame), C.POINTER(C.c_int)]
+lib.orc_video_crossfade.argtypes = [C.POINTER(OFrame), C.POINTER(OFrame), C.POINTER(OFrame), C.c_uint8]
+lib.orc_frame_blank.argtypes = [C.POINTER(OFrame)]
+lib.orc_dynamic_scale.argtypes = [C.POINTER(OFrame), C.POINTER(OFrame)]
+lib.orc_scaler_geometry.argtypes = [C.c_uint32] * 4 + [C.POINTER(ScaleGeometry)]
+lib.orc_unify_picture_settings.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
+lib.orc_yuv420_to_rgba.argtypes = [C.POINTER(OFrame), C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+
+
+def align(v, a):
+    return (v + a - 1) // a * a
+
+
+class HostFrame:
+    """yuv420p frame in host memory with 64-byte-aligned strides (padding zero-initialised)."""
+
+    def __init__(self, w, h):
+        self.w, self.h = w, h
+        self.planes = [np.zeros((h >> (1 if p else 0), align(w >> (1 if p else 0), 64)), np.uint8) for p in range(3)]
+        self.c = OFrame()
+        self.c.width, self.c.height = w, h
+        for p in range(3):
+            self.c.data[p] = self.planes[p].ctypes.data
+            self.c.stride[p] = self.planes[p].shape[1]
+
+    def visible(self):
+        return [self.planes[p][:, : self.w >> (1 if p else 0)] for p in range(3)]
+
+    def fill(self, layer, seed=0):
+        """SURVEY.md section 8d config 4 pattern: Y(x,y) = (x + 2y + 31*layer + LCG noise) mod 256, U/V similar at half res."""
+        for p in range(3):
+            hh, ww = self.h >> (1 if p else 0), self.w >> (1 if p else 0)
+            yy, xx = np.mgrid[0:hh, 0:ww].astype(np.uint32)
+            lcg = ((xx * np.uint32(1664525) + yy * np.uint32(1013904223) + np.uint32(seed * 7919 + layer * 104729 + p * 31337)) >> np.uint32(13)) & np.uint32(15)
+            self.planes[p][:, :ww] = ((xx + 2 * yy + 31 * layer + 57 * p + lcg) & np.uint32(255)).astype(np.uint8)
+        return self
+
+
+def blank(f: HostFrame):
+    lib.orc_frame_blank(C.byref(f.c))
+
+
+def crossfade(out: HostFrame, a: HostFrame | None, b: HostFrame | None, fader: float):
+    fade = lib.orc_crossfade_factor(fader)
+    lib.orc_video_crossfade(C.byref(out.c), C.byref(a.c) if a else None, C.byref(b.c) if b else None, fade)
+
+
+def dynamic_scale(src: HostFrame, dst: HostFrame):
+    lib.orc_dynamic_scale(C.byref(src.c), C.byref(dst.c))
+
+
+def scaler_geometry(iw, ih, ow, oh):
+    g = ScaleGeometry()
+    lib.orc_scaler_geometry(iw, ih, ow, oh, C.byref(g))
+    return g.scaled_w, g.scaled_h, g.letterbox_x, g.letterbox_y
+
+
+def unify(aw, ah, bw, bh):
+    w, h = C.c_uint32(), C.c_uint32()
+    lib.orc_unify_picture_settings(aw, ah, bw, bh, C.byref(w), C.byref(h))
+    return w.value, h.value
+
+
+def to_rgba(f: HostFrame, matrix_q12=None):
+    out = np.zeros((f.h, f.w * 4), np.uint8)
+    m = (C.c_int32 * 12)(*matrix_q12) if matrix_q12 is not None else None
+    lib.orc_yuv420_to_rgba(C.byref(f.c), out.ctypes.data_as(C.c_void_p), f.w * 4, m)
+    return out.reshape(f.h, f.w, 4)
+
+
+class OracleVideoMixer:
+    def __init__(self, a=None, b=None, fader=1.0, sample_rate=44100):
+        self.m = VMixer()
+        lib.orc_video_mixer_init(C.byref(self.m), -1 if a is None else a, -1 if b is None else b, fader, sample_rate)
+
+    def update(self, a=None, b=None, fader=1.0):
+        self.m.a = -1 if a is None else a
+        self.m.b = -1 if b is None else b
+        self.m.fader = fader
+
+    def run_tick(self, t, inputs, max_w=4096, max_h=2304):
+        arr = (VInput * 4)()
+        for i in range(4):
+            e = inputs[i] if i < len(inputs) else None
+            if e is not None:
+                fr, dur, off = e
+                arr[i].frame = C.pointer(fr.c)
+                arr[i].duration_hint = lib.orc_rational_new(dur[0], dur[1])
+                arr[i].tick_offset = lib.orc_rational_new(off[0], off[1])
+        # the unified size is only known after the call: give the oracle room, then re-view at the real size
+        # (strides depend on the width, so run twice: first to learn the size)
+        present = C.c_int()
+        # learn target size without mutating state: replicate the fold here (host logic under test lives in the C code;
+        # this is only buffer sizing)
+        sizes = []
+        for i in range(4):
+            e = inputs[i] if i < len(inputs) else None
+            if e is not None:
+                sizes.append((e[0].w, e[0].h))
+            elif self.m.has_stored[i] and not self._expired(i, t):
+                sizes.append((self.m.stored[i].width, self.m.stored[i].height))
+        if not sizes:
+            out = HostFrame(2, 2)
+            lib.orc_video_mixer_run_tick(C.byref(self.m), t, arr, C.byref(out.c), C.byref(present))
+            assert not present.value
+            return None
+        tw, th = sizes[0]
+        for (w, h) in sizes[1:]:
+            tw, th = unify(tw, th, w, h)
+        out = HostFrame(tw, th)
+        lib.orc_video_mixer_run_tick(C.byref(self.m), t, arr, C.byref(out.c), C.byref(present))
+        assert present.value and out.c.width == tw and out.c.height == th
+        return out
+
+    def _expired(self, i, t):
+        now = lib.orc_rational_new(t, self.m.sample_rate)
+        return lib.orc_rational_cmp(now, self.m.active_until[i]) >= 0
+
+    def __del__(self):
+        lib.orc_video_mixer_free(C.byref(self.m))

@@ -187,3 +187,41 @@ def test_param_struct_layouts_match_header():
     assert ctypes.sizeof(abi.EnvelopeParams) == 32 and ctypes.sizeof(abi.AmplifierParams) == 16
     assert ctypes.sizeof(abi.OscillatorParams) == 16 and ctypes.sizeof(abi.FmSineParams) == 16
     assert ctypes.sizeof(abi.Node) == 16 and ctypes.sizeof(abi.Edge) == 16 and ctypes.sizeof(abi.GraphOpts) == 32
+
+
+# ---------------- pixel path: identities and oracle geometry (CPU) ----------------
+def test_div255_identity_used_by_crossfade_kernel():
+    x = np.arange(255 * 255 + 1, dtype=np.uint32)   # every value a*f + b*(255-f) can take
+    assert np.array_equal(x // 255, (x + 1 + (x >> 8)) >> 8)
+
+
+def test_oracle_scaler_geometry_and_unify():
+    import oracle_video as ov
+    assert ov.scaler_geometry(1280, 720, 1920, 1080) == (1920, 1080, 0, 0)
+    assert ov.scaler_geometry(640, 480, 1920, 1080) == (1440, 1080, 240, 0)      # pillarbox, even offset
+    assert ov.scaler_geometry(1920, 1080, 560, 350) == (560, 314, 0, 18)          # monitor size (monitor.rs:21-22)
+    assert ov.unify(640, 360, 321, 241) == (640, 360)
+    assert ov.unify(321, 241, 100, 100) == (322, 242)                             # rounded UP to even (video_mixer.rs:286-290)
+
+
+def test_oracle_crossfade_factor_and_blank():
+    import oracle_video as ov
+    f = oracle.lib.orc_crossfade_factor
+    assert [f(1.0), f(0.0), f(0.5), f(2.0), f(-1.0), f(float("nan"))] == [255, 0, 127, 255, 0, 0]   # `as u8` saturates/truncates
+    fr = ov.HostFrame(66, 34); fr.planes[0][:] = 7; ov.blank(fr)
+    y, u, v = fr.visible()
+    assert not y.any() and (u == 0x80).all() and (v == 0x80).all()
+    a = ov.HostFrame(66, 34).fill(1)
+    out = ov.HostFrame(66, 34); ov.blank(out); ov.crossfade(out, a, None, 1.0)     # fade 255: exactly A
+    assert all(np.array_equal(o, i) for o, i in zip(out.visible(), a.visible()))
+    out2 = ov.HostFrame(66, 34); ov.blank(out2); ov.crossfade(out2, a, None, 0.0)  # fade 0: exactly the blank B
+    assert not out2.visible()[0].any() and (out2.visible()[1] == 0x80).all()
+
+
+def test_oracle_bicubic_is_identity_preserving_and_bounded():
+    import oracle_video as ov
+    src = ov.HostFrame(64, 48)
+    for p in src.planes:
+        p[:] = 200
+    dst = ov.HostFrame(128, 96); ov.dynamic_scale(src, dst)
+    assert all((v == 200).all() for v in dst.visible())     # taps sum to exactly 1.0 in Q14: flat stays flat

@@ -1,0 +1,151 @@
+"""GPU parity of the pixel path (integer work: bit-exact on the visible area).
+
+Reference-following and unpinned by reference tests: blank, cross-fade, geometry, VideoMixer state
+machine.  Build-specified (no reference arithmetic exists): bicubic scaler, YUV420P->RGBA."""
+import numpy as np
+import pytest
+
+import oracle_video as ov
+from mixlab_amd import video
+
+pytestmark = pytest.mark.gpu
+
+
+def upload(hf: ov.HostFrame) -> video.DFrame:
+    d = video.DFrame(hf.w, hf.h)
+    y, u, v = hf.visible()
+    return d.upload(y, u, v)
+
+
+def assert_frame_equal(dev: video.DFrame, host: ov.HostFrame, what=""):
+    assert (dev.width, dev.height) == (host.w, host.h), what
+    for p, (g, w) in enumerate(zip(dev.download(), host.visible())):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"{what}: plane {p}: {len(bad)} pixels differ, first {bad[:3].tolist()} got {g[tuple(bad[0])]} want {w[tuple(bad[0])]}"
+
+
+def test_blank_frame():
+    d = video.DFrame(130, 70)
+    y, u, v = d.download()
+    assert not y.any() and (u == 0x80).all() and (v == 0x80).all()
+    d.upload(np.full((70, 130), 9, np.uint8), np.full((35, 65), 9, np.uint8), np.full((35, 65), 9, np.uint8))
+    video.blank(d)
+    y, u, v = d.download()
+    assert not y.any() and (u == 0x80).all() and (v == 0x80).all()
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (1280, 720), (66, 34), (640, 480), (2, 2)])
+@pytest.mark.parametrize("fader", [1.0, 0.0, 0.5, 0.75, 0.1, 0.999, 1.5, -0.2])
+def test_crossfade_bit_exact(size, fader):
+    w, h = size
+    ha, hb = ov.HostFrame(w, h).fill(1), ov.HostFrame(w, h).fill(2, seed=5)
+    want = ov.HostFrame(w, h); ov.blank(want); ov.crossfade(want, ha, hb, fader)
+    da, db, out = upload(ha), upload(hb), video.DFrame(w, h)
+    video.crossfade(out, da, db, fader)
+    assert_frame_equal(out, want, f"crossfade {size} fader {fader}")
+
+
+@pytest.mark.parametrize("which", ["a_only", "b_only", "none"])
+def test_crossfade_missing_channel_reads_blank(which):
+    w, h = 322, 182
+    ha = ov.HostFrame(w, h).fill(3)
+    a = ha if which == "a_only" else None
+    b = ha if which == "b_only" else None
+    want = ov.HostFrame(w, h); ov.blank(want); ov.crossfade(want, a, b, 0.6)
+    da = upload(ha)
+    out = video.DFrame(w, h)
+    video.crossfade(out, da if a else None, da if b else None, 0.6)
+    assert_frame_equal(out, want, which)
+
+
+@pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((640, 480), (1920, 1080)), ((1920, 1080), (560, 350)),
+                                  ((1000, 300), (640, 640)), ((64, 64), (64, 64)), ((322, 182), (1120, 700))])
+def test_dynamic_scale_letterbox_bit_exact_vs_build_spec(geom):
+    (iw, ih), (ow, oh) = geom
+    assert video.scale_geometry(iw, ih, ow, oh) == ov.scaler_geometry(iw, ih, ow, oh)
+    src = ov.HostFrame(iw, ih).fill(4, seed=2)
+    want = ov.HostFrame(ow, oh); ov.dynamic_scale(src, want)
+    dsrc, out = upload(src), video.DFrame(ow, oh)
+    video.scale(dsrc, out)
+    assert_frame_equal(out, want, f"scale {geom}")
+
+
+def test_scale_geometry_examples():
+    # 16:9 into 16:9 fills; 4:3 into 16:9 pillarboxes on an even offset (encode.rs:354-374)
+    assert video.scale_geometry(1280, 720, 1920, 1080) == (1920, 1080, 0, 0)
+    assert video.scale_geometry(640, 480, 1920, 1080) == (1440, 1080, 240, 0)
+    assert video.scale_geometry(1000, 300, 640, 640) == (640, 192, 0, 224)
+
+
+@pytest.mark.parametrize("matrix", [None, [4096, 0, 0, 0, 0, 4096, 0, 0, 0, 0, 4096, 0],
+                                     [3000, 800, 296, 40960, -200, 4500, -204, 0, 100, -300, 4296, -8192]])
+@pytest.mark.parametrize("size", [(1920, 1080), (66, 34), (130, 70)])
+def test_yuv_to_rgba_bit_exact_vs_build_spec(size, matrix):
+    w, h = size
+    hf = ov.HostFrame(w, h).fill(6, seed=9)
+    want = ov.to_rgba(hf, matrix)
+    got = video.to_rgba(upload(hf), matrix)
+    assert np.array_equal(got, want)
+
+
+def test_video_mixer_state_machine_matches_oracle():
+    """Frames of different sizes arriving at different rates, expiry by exact rationals, parameter changes."""
+    SPT = 735
+    gm, om = video.VideoMixer(a=0, b=1, fader=0.75), ov.OracleVideoMixer(a=0, b=1, fader=0.75)
+    big = [ov.HostFrame(640, 360).fill(10 + k, seed=k) for k in range(4)]
+    small = [ov.HostFrame(320, 240).fill(20 + k, seed=k) for k in range(4)]
+    odd = ov.HostFrame(322, 182).fill(33)
+    keep = []
+    program_seen = 0
+    for tick in range(40):
+        t = tick * SPT
+        ins_h = [None] * 4
+        if tick >= 2 and tick % 2 == 0:            # channel 0: 30 fps, 640x360
+            ins_h[0] = (big[(tick // 2) % 4], (1, 30), (0, 1))
+        if 5 <= tick < 30 and tick % 3 == 2:       # channel 1: 20 fps, 320x240 (forces scale + pillarbox), offset inside the tick
+            ins_h[1] = (small[(tick // 3) % 4], (1, 20), (1, 240))
+        if tick == 12:                             # channel 2 briefly delivers an odd-ish size: re-target of every scaler
+            ins_h[2] = (odd, (1, 10), (0, 1))
+        if tick == 20:
+            gm.update(a=1, b=0, fader=0.3); om.update(a=1, b=0, fader=0.3)
+        if tick == 33:
+            gm.update(a=2, b=None, fader=1.0); om.update(a=2, b=None, fader=1.0)
+        ins_d = []
+        for e in ins_h:
+            if e is None:
+                ins_d.append(None)
+            else:
+                d = upload(e[0]); keep.append(d)
+                ins_d.append((d, e[1], e[2]))
+        prog, fa, fb = gm.run_tick(t, ins_d)
+        want = om.run_tick(t, ins_h)
+        assert (prog is None) == (want is None), f"tick {tick}: program presence"
+        if want is not None:
+            program_seen += 1
+            assert_frame_equal(prog, want, f"tick {tick}")
+        # A / B pass-through = the raw input frame of that channel this tick (video_mixer.rs:80-90)
+        pa = gm_params_a = (0 if tick < 20 else (1 if tick < 33 else 2))
+        pb = (1 if tick < 20 else (0 if tick < 33 else None))
+        assert (fa is None) == (ins_h[pa] is None)
+        if fa is not None:
+            assert_frame_equal(fa, ins_h[pa][0], f"tick {tick} A pass-through")
+        assert (fb is None) == (pb is None or ins_h[pb] is None)
+    assert program_seen >= 30
+    # first two ticks: nothing to show yet => None (video_mixer.rs:113-119)
+
+
+def test_video_mixer_frame_expiry_is_exact():
+    SPT = 735
+    gm, om = video.VideoMixer(a=0, b=None, fader=1.0), ov.OracleVideoMixer(a=0, b=None, fader=1.0)
+    hf = ov.HostFrame(64, 64).fill(1)
+    d = upload(hf)
+    # duration 1/30 s = exactly 2 ticks: visible on ticks 0 and 1, expired at tick 2 (t/44100 >= 2/60)
+    seen = []
+    for tick in range(4):
+        ins_d = [(d, (1, 30), (0, 1))] if tick == 0 else []
+        ins_h = [(hf, (1, 30), (0, 1))] if tick == 0 else []
+        prog, _, _ = gm.run_tick(tick * SPT, ins_d + [None] * (4 - len(ins_d)))
+        want = om.run_tick(tick * SPT, ins_h + [None] * (4 - len(ins_h)))
+        seen.append(prog is not None)
+        assert (prog is None) == (want is None)
+    assert seen == [True, True, False, False]
