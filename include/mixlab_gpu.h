@@ -55,7 +55,9 @@ enum {
     MX_KIND_VIDEO_MIXER = 10,     /* src/module/video_mixer.rs     in: Video x 4              out: Video Output, A, B */
     MX_KIND_SOURCE_MONO = 11,     /* host/device-fed port; stands in for the audio outputs of the I/O modules */
     MX_KIND_SOURCE_STEREO = 12,   /*   (StreamInput src/module/stream_input.rs:72-147, MediaSource media_source.rs:93-126) */
-    MX_KIND_COUNT = 13
+    MX_KIND_SOURCE_VIDEO = 13,    /* frame-fed port; stands in for MediaSource / StreamInput video (media_source.rs:93-126) */
+    MX_KIND_VIDEO_TO_RGBA = 14,   /* BUILD-SPECIFIED sink (no reference module): YUV420P -> RGBA8 (+ Q12 3x4 matrix)  in: Video */
+    MX_KIND_COUNT = 15
 };
 
 /* protocol/src/lib.rs:233-241, bincode variant order */
@@ -70,6 +72,7 @@ typedef struct { double freq; uint32_t waveform; uint32_t _pad; } mx_oscillator_
 typedef struct { double freq_lo, freq_hi; } mx_fm_sine_params;                                         /* FmSineParams :292-296 */
 typedef struct { uint32_t gate_open; } mx_trigger_params;                                              /* GateState :304-308 */
 typedef struct { int32_t a, b; /* -1 = None */ double fader; } mx_video_mixer_params;                  /* VideoMixerParams :405-410 */
+typedef struct { int32_t use_matrix; int32_t matrix_q12[12]; } mx_video_to_rgba_params;                /* build-specified, DESIGN.md "Colour" */
 
 /* ---- graph description ---- */
 typedef struct { uint32_t kind; uint32_t params_len; const void* params; } mx_node;
@@ -191,6 +194,18 @@ int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input 
                             mx_dframe** out_program, mx_dframe** out_a, mx_dframe** out_b);
 int mx_video_mixer_sync(mx_video_mixer* m);
 void mx_video_mixer_destroy(mx_video_mixer* m);
+
+/* Video nodes inside a graph (MX_KIND_VIDEO_MIXER / SOURCE_VIDEO / VIDEO_TO_RGBA): every tick of
+ * mx_graph_run_ticks runs the video sub-graph in run order, all launches on the graph's stream.
+ * set_video_source: the frame the source emits -- on the next tick only (repeat = 0, like one
+ * decoded frame arriving, media_source.rs:93-126) or as a new frame on every tick (repeat = 1,
+ * synthetic 60 fps input).  frame NULL clears it.  The graph retains the frame. */
+int mx_graph_set_video_source(mx_graph* g, uint32_t node, mx_dframe* frame, int64_t dur_num, int64_t dur_den,
+                              int64_t off_num, int64_t off_den, int repeat);
+/* Output port of a video node after the last tick: one reference for the caller, NULL = None. */
+int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out);
+/* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame). */
+int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t* stride, uint32_t* width, uint32_t* height);
 
 /* plain device memory for consumers of mx_video_to_rgba (tests, bench) */
 int mx_device_alloc(size_t bytes, void** device_ptr);

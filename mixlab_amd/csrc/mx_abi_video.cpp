@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 
+#include "mx_engine.hpp"
 #include "mx_video.hpp"
 
 using mx::DFrame;
@@ -17,6 +18,7 @@ static inline const DFrame* D(const mx_dframe* p) { return reinterpret_cast<cons
 static inline mx_dframe* H(DFrame* p) { return reinterpret_cast<mx_dframe*>(p); }
 
 struct mx_video_mixer { std::unique_ptr<mx::VideoMixer> m; };
+struct mx_graph { std::unique_ptr<mx::Graph> g; };   // same layout as in mx_abi.cpp
 
 extern "C" const char* mx_last_error(void);
 void mx_set_last_error(const std::string& s);   // mx_abi.cpp
@@ -227,6 +229,26 @@ int mx_video_mixer_sync(mx_video_mixer* m) {
 }
 void mx_video_mixer_destroy(mx_video_mixer* m) {
     (void)guard([&] { delete m; });
+}
+
+int mx_graph_set_video_source(mx_graph* g, uint32_t node, mx_dframe* frame, int64_t dur_num, int64_t dur_den,
+                              int64_t off_num, int64_t off_den, int repeat) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        g->g->set_video_source(node, frame ? D(frame) : nullptr, mx::Rational::make(dur_num, dur_den ? dur_den : 1),
+                               mx::Rational::make(off_num, off_den ? off_den : 1), repeat != 0);
+    });
+}
+int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out) {
+    return guard([&] {
+        REQUIRE(g && out, "NULL argument");
+        *out = nullptr;
+        FrameRef r = g->g->video_output(node, port);
+        if (r) { r->retain(); *out = H(r.f); }
+    });
+}
+int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t* stride, uint32_t* width, uint32_t* height) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->rgba_output(node, device_rgba, stride, width, height); });
 }
 
 int mx_device_alloc(size_t bytes, void** device_ptr) {

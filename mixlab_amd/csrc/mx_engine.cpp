@@ -45,7 +45,9 @@ static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& i
     case MX_KIND_TRIGGER: need(sizeof(mx_trigger_params), "mx_trigger_params"); in = {}; out = {MX_MONO}; break;
     case MX_KIND_SOURCE_MONO: in = {}; out = {MX_MONO}; break;
     case MX_KIND_SOURCE_STEREO: in = {}; out = {MX_STEREO}; break;
-    case MX_KIND_VIDEO_MIXER: throw Error(MX_ERR_INVALID, "VideoMixer nodes run through the mx_video_* entry points, not the audio graph");
+    case MX_KIND_VIDEO_MIXER: need(sizeof(mx_video_mixer_params), "mx_video_mixer_params"); in.assign(4, MX_VIDEO); out.assign(3, MX_VIDEO); break;  // video_mixer.rs:42-49
+    case MX_KIND_SOURCE_VIDEO: in = {}; out = {MX_VIDEO}; break;
+    case MX_KIND_VIDEO_TO_RGBA: need(sizeof(mx_video_to_rgba_params), "mx_video_to_rgba_params"); in = {MX_VIDEO}; out = {}; break;
     default: throw Error(MX_ERR_INVALID, "unknown module kind");
     }
 }
@@ -79,6 +81,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     if (sr % tps) throw Error(MX_ERR_INVALID, "sample_rate must be a multiple of ticks_per_second");
     sample_rate_ = (double)sr;
     spt_ = sr / tps;                                                     // src/engine.rs:55
+    tps_ = tps;
     const uint32_t max_ticks = o.max_ticks_per_run ? o.max_ticks_per_run : 1u;
     cap_frames_ = cap_frames_override ? cap_frames_override : spt_ * (size_t)max_ticks;
     flags_ = o.flags;
@@ -168,6 +171,15 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         n.slot = (uint32_t)groups_.back().nodes.size();
         groups_.back().nodes.push_back(id);
     }
+    // video nodes: per-node state lives on the host, pixels on the graph's stream
+    for (Node& n : nodes_) {
+        if (n.kind == MX_KIND_VIDEO_MIXER) {
+            mx_video_mixer_params p; std::memcpy(&p, n.params.data(), sizeof p);
+            n.vmixer.reset(new VideoMixer(p, sr, stream_));
+        }
+        if (n.kind == MX_KIND_VIDEO_MIXER || n.kind == MX_KIND_SOURCE_VIDEO || n.kind == MX_KIND_VIDEO_TO_RGBA) has_video_ = true;
+        n.vout.resize(n.out_type.size());
+    }
     // time-parallel EqThree tables (unused in MX_FLAG_EQ_EXACT mode)
     {
         std::vector<EqScanTab> tabs(4);
@@ -188,6 +200,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
 
 Graph::~Graph() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); }
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -338,6 +351,10 @@ void Graph::update_params(uint32_t node, const void* params, size_t len) {
     if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
     sync();
     if (len) std::memcpy(n.params.data(), params, len);
+    if (n.kind == MX_KIND_VIDEO_MIXER && n.vmixer) {
+        mx_video_mixer_params p; std::memcpy(&p, n.params.data(), sizeof p);
+        n.vmixer->update(p);
+    }
     if (n.group >= 0) upload_group(groups_[n.group]);
 }
 
@@ -395,7 +412,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     if (prof) {
         if (!prof_pool_.empty()) { ev = std::move(prof_pool_.back()); prof_pool_.pop_back(); }
         else {
-            ev.resize(groups_.size() + 1);
+            ev.resize(groups_.size() + 2);   // one slot per launch group + the per-tick video section
             for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
         }
         hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
@@ -461,6 +478,9 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         if (prof) hip_check(hipEventRecord(ev[gi + 1], stream_), "hipEventRecord");
         ++gi;
     }
+    // video sub-graph: tick by tick (frames arrive per tick; nothing to batch over time)
+    if (has_video_) for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc);
+    if (prof) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
     hip_check(hipGetLastError(), "kernel launch");
     last_calls_ = n_calls;
     last_frames_per_call_ = fpc;
@@ -477,10 +497,10 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
     if (ms_total) *ms_total = 0.f;
     const uint32_t n = (uint32_t)prof_runs_.size();
     for (auto& ev : prof_runs_) {
-        for (size_t i = 0; i + 1 < ev.size() && i < groups_.size(); ++i) {
+        for (size_t i = 0; i + 1 < ev.size() && i <= groups_.size(); ++i) {
             float ms = 0.f;
             hip_check(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "hipEventElapsedTime");
-            if (ms_by_kind) ms_by_kind[groups_[i].kind] += ms;
+            if (ms_by_kind) ms_by_kind[i < groups_.size() ? groups_[i].kind : (uint32_t)MX_KIND_VIDEO_MIXER] += ms;
         }
         if (ms_total) { float ms = 0.f; hip_check(hipEventElapsedTime(&ms, ev.front(), ev.back()), "hipEventElapsedTime"); *ms_total += ms; }
         prof_pool_.push_back(std::move(ev));
@@ -516,6 +536,88 @@ int Graph::read_plotter(uint32_t node, uint32_t call, float* left, float* right)
     hip_check(hipMemcpyAsync(right, stage + fpc, fpc * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
     sync();
     return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// video sub-graph: one Engine::run_tick pass over the video nodes in run order
+// ---------------------------------------------------------------------------------------------
+void Graph::run_video_tick(uint64_t t) {
+    for (uint32_t id : order_) {
+        Node& n = nodes_[id];
+        switch (n.kind) {
+        case MX_KIND_SOURCE_VIDEO: {
+            // Output::from_line_type(Video) = None every tick (io.rs:76); the source fills it when a frame is due
+            n.vout[0] = Node::VOut{};
+            if (n.vsrc && (n.vsrc_repeat || n.vsrc_pending)) {
+                n.vout[0].frame = n.vsrc; n.vout[0].dur = n.vsrc_dur; n.vout[0].off = n.vsrc_off;
+                n.vsrc_pending = false;
+            }
+            break;
+        }
+        case MX_KIND_VIDEO_MIXER: {
+            VideoInput in[4];
+            for (int i = 0; i < 4; ++i) {
+                const PortRef pr = n.in_src[i];
+                if (pr.node < 0) continue;                                   // Disconnected => None (io.rs:56-57)
+                const Node::VOut& v = nodes_[pr.node].vout[pr.port];
+                if (!v.frame) continue;
+                in[i].frame = v.frame.f; in[i].duration_hint = v.dur; in[i].tick_offset = v.off;
+            }
+            FrameRef o, a, b;
+            n.vmixer->run_tick(t, in, o, a, b);
+            n.vout[0] = Node::VOut{o, Rational::make(1, (int64_t)tps_), Rational::make(0, 1)};   // video_mixer.rs:241-247
+            // A / B are clones of the input VideoFrames, duration and offset included (video_mixer.rs:80-90)
+            mx_video_mixer_params p; std::memcpy(&p, n.params.data(), sizeof p);
+            n.vout[1] = Node::VOut{}; n.vout[2] = Node::VOut{};
+            if (a && p.a >= 0 && p.a < 4) n.vout[1] = Node::VOut{a, in[p.a].duration_hint, in[p.a].tick_offset};
+            if (b && p.b >= 0 && p.b < 4) n.vout[2] = Node::VOut{b, in[p.b].duration_hint, in[p.b].tick_offset};
+            break;
+        }
+        case MX_KIND_VIDEO_TO_RGBA: {
+            const PortRef pr = n.in_src[0];
+            n.rgba_w = n.rgba_h = 0;
+            if (pr.node < 0) break;
+            const Node::VOut& v = nodes_[pr.node].vout[pr.port];
+            if (!v.frame) break;
+            const DFrame* d = v.frame.f;
+            const int32_t stride = (int32_t)(((size_t)d->width * 4 + 15) & ~(size_t)15);
+            const size_t need = (size_t)stride * d->height;
+            if (n.rgba.bytes < need) { sync(); n.rgba.alloc(need); }
+            mx_video_to_rgba_params p; std::memcpy(&p, n.params.data(), sizeof p);
+            RgbaArgs a;
+            a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = (uint8_t*)n.rgba.p;
+            a.y_stride = d->stride[0]; a.u_stride = d->stride[1]; a.v_stride = d->stride[2]; a.rgba_stride = (uint32_t)stride;
+            a.width = d->width; a.height = d->height; a.use_matrix = p.use_matrix;
+            for (int k = 0; k < 12; ++k) a.m[k] = p.matrix_q12[k];
+            launch_yuv420_to_rgba(a, stream_);
+            n.rgba_w = d->width; n.rgba_h = d->height; n.rgba_stride = stride;
+            break;
+        }
+        default: break;
+        }
+    }
+}
+
+void Graph::set_video_source(uint32_t node, DFrame* frame, Rational dur, Rational off, bool repeat) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_SOURCE_VIDEO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_VIDEO");
+    Node& n = nodes_[node];
+    n.vsrc = frame ? FrameRef(frame, true) : FrameRef();
+    n.vsrc_dur = dur; n.vsrc_off = off; n.vsrc_repeat = repeat; n.vsrc_pending = frame != nullptr;
+}
+
+FrameRef Graph::video_output(uint32_t node, uint32_t port) {
+    if (node >= nodes_.size() || port >= nodes_[node].vout.size() || nodes_[node].out_type[port] != MX_VIDEO)
+        throw Error(MX_ERR_INVALID, "not a video output terminal");
+    return nodes_[node].vout[port].frame;
+}
+
+void Graph::rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_VIDEO_TO_RGBA) throw Error(MX_ERR_INVALID, "node is not a VIDEO_TO_RGBA");
+    const Node& n = nodes_[node];
+    if (dev) *dev = n.rgba_w ? n.rgba.p : nullptr;
+    if (stride) *stride = n.rgba_stride;
+    if (w) *w = n.rgba_w;
+    if (h) *h = n.rgba_h;
 }
 
 }  // namespace mx

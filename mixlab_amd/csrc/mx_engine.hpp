@@ -8,35 +8,15 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
-#include "../../include/mixlab_gpu.h"
+#include "mx_common.hpp"
 #include "mx_kernels.hpp"
+#include "mx_video.hpp"
 
 namespace mx {
-
-struct Error : std::runtime_error {
-    int code;
-    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
-
-void hip_check(hipError_t e, const char* what);
-
-// simple owning device buffer
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    void alloc(size_t n);
-    void free_();
-    ~DevBuf() { free_(); }
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { free_(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
-};
 
 struct PortRef { int32_t node = -1; uint32_t port = 0; };
 
@@ -55,6 +35,12 @@ struct Node {
     uint64_t plot_count = 0;
     std::vector<uint8_t> plot_fired;          // per call of the last run
     std::vector<int32_t> plot_slot;           // staging slot per call (-1 = not fired)
+    // video nodes (run tick by tick inside Graph::run)
+    struct VOut { FrameRef frame; Rational dur, off; };
+    std::unique_ptr<VideoMixer> vmixer;       // VIDEO_MIXER
+    std::vector<VOut> vout;                   // this tick's video outputs (empty FrameRef = None)
+    FrameRef vsrc; Rational vsrc_dur, vsrc_off; bool vsrc_repeat = false, vsrc_pending = false;   // SOURCE_VIDEO
+    DevBuf rgba; uint32_t rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;                       // VIDEO_TO_RGBA
 };
 
 struct Group {
@@ -95,11 +81,16 @@ public:
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
     // module compat path: an InputRef may be Disconnected on one call and connected on the next
     void set_input_enabled(uint32_t node, uint32_t port, bool enabled);
+    // video nodes
+    void set_video_source(uint32_t node, DFrame* frame, Rational dur, Rational off, bool repeat);
+    FrameRef video_output(uint32_t node, uint32_t port);
+    void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 
 private:
     void layout_slab();
     void build_descriptors();
     void upload_group(Group& g);
+    void run_video_tick(uint64_t t);
     const float* in_ptr(const Node& n, uint32_t port, bool null_if_disconnected) const;
     float* out_ptr(const Node& n, uint32_t port) const;
 
@@ -107,6 +98,8 @@ private:
     std::vector<uint32_t> order_;
     std::vector<Group> groups_;   // sorted by (level, kind)
     uint32_t flags_ = 0;
+    bool has_video_ = false;
+    uint32_t tps_ = 60;
     double sample_rate_ = 44100.0;
     size_t spt_ = 735;
     size_t cap_frames_ = 735;

@@ -10,7 +10,7 @@
 #include <memory>
 #include <vector>
 
-#include "mx_engine.hpp"
+#include "mx_common.hpp"
 
 namespace mx {
 

@@ -47,6 +47,46 @@ _proto("mx_device_free", None, C.c_void_p)
 _proto("mx_device_download", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
+_proto("mx_graph_set_video_source", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int)
+_proto("mx_graph_video_output", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p))
+_proto("mx_graph_rgba_output", C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+
+class VideoToRgbaParams(C.Structure):
+    _fields_ = [("use_matrix", C.c_int32), ("matrix_q12", C.c_int32 * 12)]
+
+
+def to_rgba_params(matrix_q12=None) -> VideoToRgbaParams:
+    p = VideoToRgbaParams()
+    p.use_matrix = 1 if matrix_q12 is not None else 0
+    for k in range(12):
+        p.matrix_q12[k] = int(matrix_q12[k]) if matrix_q12 is not None else 0
+    return p
+
+
+# ---- video nodes of an abi.Graph ----
+def graph_set_video_source(g, node, frame, dur=(1, 60), off=(0, 1), repeat=False):
+    check(lib.mx_graph_set_video_source(g._h, node, frame.handle if frame is not None else None, dur[0], dur[1], off[0], off[1], 1 if repeat else 0))
+
+
+def graph_video_output(g, node, port=0):
+    h = C.c_void_p()
+    check(lib.mx_graph_video_output(g._h, node, port, C.byref(h)))
+    return DFrame(handle=h.value) if h.value else None
+
+
+def graph_rgba_output(g, node, stream=None):
+    """-> HxWx4 uint8 array of the last tick's RGBA frame, or None."""
+    p, stride, w, h = C.c_void_p(), C.c_int32(), C.c_uint32(), C.c_uint32()
+    check(lib.mx_graph_rgba_output(g._h, node, C.byref(p), C.byref(stride), C.byref(w), C.byref(h)))
+    if not w.value:
+        return None
+    g.sync()
+    out = np.empty(stride.value * h.value, np.uint8)
+    check(lib.mx_device_download(out.ctypes.data_as(C.c_void_p), p, out.size, stream))
+    return out.reshape(h.value, stride.value)[:, : w.value * 4].reshape(h.value, w.value, 4)
+
+
 def _host_frame(planes, w, h):
     """abi.Frame over three contiguous uint8 plane arrays (rows = plane height, stride = array row length)."""
     f = abi.Frame()

@@ -71,3 +71,16 @@ class Workspace:
 
     def build(self, max_ticks_per_run: int = 1, flags: int = 0, device: int = -1, stream=None) -> "abi.Graph":
         return abi.Graph(self.nodes, self.edges, self.sample_rate, self.ticks_per_second, max_ticks_per_run, flags, device, stream)
+
+    # ---- video nodes ----
+    def video_mixer(self, a=None, b=None, fader=1.0) -> int:
+        """VideoMixerParams (protocol/src/lib.rs:405-420); default fader 1.0 = start at A."""
+        from .video import VideoMixerParams
+        return self.add(abi.KIND_VIDEO_MIXER, VideoMixerParams(-1 if a is None else a, -1 if b is None else b, fader))
+
+    def source_video(self) -> int:
+        return self.add(abi.KIND_SOURCE_VIDEO, None)
+
+    def video_to_rgba(self, matrix_q12=None) -> int:
+        from .video import to_rgba_params
+        return self.add(abi.KIND_VIDEO_TO_RGBA, to_rgba_params(matrix_q12))

@@ -1,0 +1,86 @@
+"""Video nodes inside the graph executor: SURVEY.md section 8d config 4 -- an 8-layer composite expressed in
+reference semantics as a cascade of 7 VideoMixer cross-fades (each truncating to u8), then the
+build-specified YUV420P->RGBA + colour matrix.  Bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle_video as ov
+from mixlab_amd import abi, video
+from mixlab_amd.workspace import Workspace
+
+pytestmark = pytest.mark.gpu
+
+FADERS = [1.0, 0.75, 0.5, 0.5, 0.25, 0.9, 0.1]
+MATRIX = [3900, 150, 46, 4096, 60, 3980, 56, -2048, 20, 120, 3956, 0]   # Q12 3x4, mild cross-talk + offsets
+
+
+def cascade(sizes, matrix):
+    ws = Workspace(44100, 60)
+    srcs = [ws.source_video() for _ in sizes]
+    prev, mixers = srcs[0], []
+    for k in range(1, len(sizes)):
+        m = ws.video_mixer(a=0, b=1, fader=FADERS[k - 1])
+        ws.connect(prev, 0, m, 0)      # A = running composite (or layer 0)
+        ws.connect(srcs[k], 0, m, 1)   # B = next layer
+        mixers.append(m); prev = m
+    rgba = ws.video_to_rgba(matrix)
+    ws.connect(prev, 0, rgba, 0)
+    return ws, srcs, mixers, rgba
+
+
+def upload(hf):
+    y, u, v = hf.visible()
+    return video.DFrame(hf.w, hf.h).upload(y, u, v)
+
+
+@pytest.mark.parametrize("sizes", [[(320, 180)] * 6 + [(212, 120)] * 2, [(1920, 1080)] * 6 + [(1280, 720)] * 2])
+def test_config4_eight_layer_cascade_bit_exact(sizes):
+    ws, srcs, mixers, rgba = cascade(sizes, MATRIX)
+    g = ws.build(max_ticks_per_run=4)
+    layers = [ov.HostFrame(w, h).fill(k, seed=3) for k, (w, h) in enumerate(sizes)]
+    dlayers = [upload(l) for l in layers]
+    for s, d in zip(srcs, dlayers):
+        video.graph_set_video_source(g, s, d, dur=(1, 60), off=(0, 1), repeat=True)
+    g.run_ticks(0, 3)   # every layer delivers a new frame on every tick
+    # oracle: the same cascade of reference VideoMixers, three ticks
+    oms = [ov.OracleVideoMixer(a=0, b=1, fader=FADERS[k]) for k in range(7)]
+    want = None
+    for tick in range(3):
+        prev = (layers[0], (1, 60), (0, 1))
+        for k in range(7):
+            out = oms[k].run_tick(tick * 735, [prev, (layers[k + 1], (1, 60), (0, 1)), None, None])
+            prev = (out, (1, 60), (0, 1))
+        want = prev[0]
+    got = video.graph_video_output(g, mixers[-1], 0)
+    assert (got.width, got.height) == (want.w, want.h)
+    for p, (a, b) in enumerate(zip(got.download(), want.visible())):
+        assert np.array_equal(a, b), f"plane {p} of the final composite differs"
+    assert np.array_equal(video.graph_rgba_output(g, rgba), ov.to_rgba(want, MATRIX))
+
+
+def test_video_source_single_shot_then_none_and_passthrough():
+    ws = Workspace(44100, 60)
+    s = ws.source_video(); m = ws.video_mixer(a=0, b=None, fader=1.0)
+    ws.connect(s, 0, m, 0)
+    g = ws.build()
+    hf = ov.HostFrame(64, 64).fill(2)
+    d = upload(hf)
+    assert video.graph_video_output(g, m, 0) is None
+    video.graph_set_video_source(g, s, d, dur=(1, 30), off=(0, 1), repeat=False)
+    seen = []
+    for tick in range(4):
+        g.run_ticks(tick, 1)
+        prog = video.graph_video_output(g, m, 0)
+        a = video.graph_video_output(g, m, 1)
+        seen.append((prog is not None, a is not None))
+    # the frame arrives on tick 0 only (A pass-through that tick), is shown for its 1/30 s = 2 ticks, then expires
+    assert seen == [(True, True), (True, False), (False, False), (False, False)]
+
+
+def test_video_edge_type_is_checked():
+    ws = Workspace()
+    s = ws.source_video(); e = ws.eq_three(0, 0, 0)
+    ws.connect(s, 0, e, 0)
+    with pytest.raises(abi.MxError) as ei:
+        ws.build()
+    assert ei.value.code == abi.MX_ERR_TYPE
