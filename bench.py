@@ -91,6 +91,76 @@ def cpu_baseline(Workspace, synth, abi, n_strips, sample_rate, target_seconds=12
     }
 
 
+VIDEO_FADERS = [1.0, 0.75, 0.5, 0.5, 0.25, 0.9, 0.1]
+VIDEO_MATRIX = [3900, 150, 46, 4096, 60, 3980, 56, -2048, 20, 120, 3956, 0]
+
+
+def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
+    """BASELINE.json configs[3]: 8 layers (6 x 1080p + 2 x 720p) every tick ->
+    cascade of 7 reference VideoMixer cross-fades (scale + letterbox for the 720p layers) ->
+    build-specified YUV420P->RGBA + colour matrix.  One composited 1080p RGBA frame per tick.
+    N > 1: every rank composites its own independent 8-layer stream (independent VideoMixer
+    instances) -- no exchange step, weak scaling."""
+    import oracle_video as ov   # only its synthetic-pattern generator (numpy); nothing of the oracle is timed or used as a result
+    from mixlab_amd import video
+    from mixlab_amd.workspace import Workspace
+
+    sizes = [(1920, 1080)] * 6 + [(1280, 720)] * 2
+    ws = Workspace(48000, 60)
+    srcs = [ws.source_video() for _ in sizes]
+    prev = srcs[0]
+    for k in range(1, 8):
+        m = ws.video_mixer(a=0, b=1, fader=VIDEO_FADERS[k - 1])
+        ws.connect(prev, 0, m, 0); ws.connect(srcs[k], 0, m, 1)
+        prev = m
+    rgba = ws.video_to_rgba(VIDEO_MATRIX)
+    ws.connect(prev, 0, rgba, 0)
+    T = 64
+    g = ws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
+    keep = []
+    for k, (w, h) in enumerate(sizes):
+        hf = ov.HostFrame(w, h).fill(k, seed=3)
+        y, u, v = hf.visible()
+        d = video.DFrame(w, h).upload(y, u, v)
+        keep.append(d)
+        video.graph_set_video_source(g, srcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)
+    steps = max(1, frames // T)
+    for i in range(max(1, warmup)):
+        g.run_ticks(i * T, T)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    g.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        g.run_ticks((warmup + i) * T, T)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    g.profile_enable(False)
+    by_kind, _tot, n_prof = g.profile_collect()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    F = 1920 * 1080 * 3 // 2
+    F720 = 1280 * 720 * 3 // 2
+    # algorithmic bytes per composited frame, module-boundary accounting (SURVEY.md section 8d):
+    # 7 cross-fades x 3F + 2 scales (F720 in + F out) + RGBA (F in + 4wh out)
+    alg = 7 * 3 * F + 2 * (F720 + F) + (F + 1920 * 1080 * 4)
+    dev_ms = by_kind.get("video_mixer", 0.0) / max(1, n_prof) / T   # device time per composited frame
+    n_frames = steps * T * world
+    return {
+        "metric": "1080p_composited_fps", "value": n_frames / dt, "unit": "frames/s", "scaling": "weak",
+        "workload": "8 layers (6x1080p + 2x720p yuv420p) -> 7 VideoMixer cross-fades (+2 bicubic letterbox scales) -> YUV->RGBA + 3x4 matrix",
+        "frames": n_frames, "realtime_1080p60_streams_equiv": n_frames / dt / 60.0,
+        "device_us_per_frame": round(dev_ms * 1e3, 2), "algorithmic_bytes_per_frame": alg,
+        "hbm_frac_device": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
+        "hbm_frac_wall": round(alg * n_frames / world / dt / 1e9 / HBM_PEAK_GBS, 4),
+    }
+
+
 class _DevArray:
     """zero-copy torch view of a device buffer owned by libmixlab_gpu (plumbing for RCCL)."""
 
@@ -122,6 +192,7 @@ def main():
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-exact", action="store_true", help="strictly sequential EqThree (bit-exact order) instead of the time-parallel scan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -218,6 +289,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    video = None
+    if args.video_frames > 0:
+        with torch.cuda.stream(stream):
+            video = video_leg(torch, dist, world, stream, local_rank, args.video_frames, args.warmup)
+
     if rank == 0:
         units = args.strips * T * args.steps
         value = units / dt
@@ -249,6 +325,7 @@ def main():
             "realtime_channels_equiv": value / 60.0,
             "graph_hbm_frac": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
+            "video": video,
         }
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
