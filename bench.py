@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-exact", action="store_true", help="strictly sequential EqThree (bit-exact order) instead of the time-parallel scan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-combine", action="store_true", help="debug: run the N>1 all-gather + combine path at N=1 (single-rank RCCL group)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
     args = ap.parse_args()
 
@@ -199,7 +200,7 @@ def main():
     import torch.distributed as dist
 
     import synth
-    from mixlab_amd import abi
+    from mixlab_amd import abi, shard
     from mixlab_amd.workspace import Workspace
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,15 +212,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_combine
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     T, SR = args.ticks_per_step, args.sample_rate
     spt = SR // 60
-    assert args.strips % world == 0
-    local_strips = args.strips // world
-    first = rank * local_strips
+    first, local_strips = shard.strip_range(rank, world, args.strips)
 
     stream = torch.cuda.Stream()
     flags = abi.FLAG_EQ_EXACT if args.eq_exact else 0
@@ -232,15 +233,16 @@ def main():
 
     # N > 1: partial buses -> all_gather -> rank-ordered Mixer(N, unity gains) on every rank
     combine = None
-    if world > 1:
+    if use_dist:
         m_ptr, fpt = g.output_device_ptr(mix, 0)
         c_ptr, _ = g.output_device_ptr(mix, 1)
         n_fl = fpt * T
-        part = torch.empty(2 * n_fl, dtype=torch.float32, device="cuda")
-        gathered = torch.empty(world * 2 * n_fl, dtype=torch.float32, device="cuda")
+        part_len, offs = shard.packed_layout(world, n_fl)
+        part = torch.empty(part_len, dtype=torch.float32, device="cuda")
+        gathered = torch.empty(world * part_len, dtype=torch.float32, device="cuda")
         cws = Workspace(SR, 60)
-        fm = cws.mixer([(0.0, 1.0, False)] * world)   # unity gains: the f32 sum of partials in rank order
-        fc = cws.mixer([(0.0, 1.0, False)] * world)
+        fm = cws.mixer(shard.combine_channels(world))   # unity gains: the f32 sum of partials in rank order
+        fc = cws.mixer(shard.combine_channels(world))
         c_srcs_m = [cws.source_stereo() for _ in range(world)]
         c_srcs_c = [cws.source_stereo() for _ in range(world)]
         for r in range(world):
@@ -248,8 +250,8 @@ def main():
             cws.connect(c_srcs_c[r], 0, fc, r)
         cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
         for r in range(world):
-            cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + (r * 2 * n_fl) * 4)
-            cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + (r * 2 * n_fl + n_fl) * 4)
+            cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + offs[r][0] * 4)
+            cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + offs[r][1] * 4)
         m_view, c_view = dev_view(torch, m_ptr, n_fl), dev_view(torch, c_ptr, n_fl)
 
         def combine():
@@ -333,7 +335,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR)
         print(json.dumps(out))
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
