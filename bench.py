@@ -333,7 +333,14 @@ def main():
             out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR)
-        print(json.dumps(out))
+        # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe):
+        # drain it first so the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
     if use_dist:
         dist.destroy_process_group()
