@@ -81,6 +81,11 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
 #define MX_FLAG_EQ_EXACT 1u  /* EqThree: strictly sequential recurrence (bit-exact vs the reference order);
                                 default is the time-parallel chunked scan (<= 1 ULP f32) */
 
+#define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
+                                [-> Amplifier] into the EQ kernel and a single-consumer Trigger into its Envelope; the
+                                folded ports are per-tick temporaries (src/engine.rs:461,504-506) and then cannot be
+                                read back.  Results on every remaining port are bit-identical either way. */
+
 typedef struct {
     uint32_t sample_rate;        /* 0 => 44100 (src/engine.rs:53) */
     uint32_t ticks_per_second;   /* 0 => 60    (src/engine.rs:54) */

@@ -30,6 +30,7 @@ KIND_NAMES = ["amplifier", "envelope", "eq_three", "fm_sine", "mixer", "oscillat
               "stereo_splitter", "trigger", "video_mixer", "source_mono", "source_stereo", "source_video", "video_to_rgba"]
 WAVE_ON, WAVE_OFF, WAVE_SINE, WAVE_SQUARE, WAVE_TRIANGLE, WAVE_SAW = range(6)
 FLAG_EQ_EXACT = 1
+FLAG_NO_FUSE = 2
 
 
 class MixerChannelParams(C.Structure):

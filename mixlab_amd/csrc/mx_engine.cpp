@@ -156,8 +156,11 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         n.level = lvl;
         n.in_src_orig = n.in_src;
     }
-    // groups: (level, kind)
-    std::vector<uint32_t> sorted(order_);
+    for (Node& n : nodes_) n.out_elided.assign(n.out_type.size(), 0);
+    if (!(flags_ & MX_FLAG_NO_FUSE)) plan_fusion();
+    // groups: (level, kind); nodes folded into another node's kernel are never launched
+    std::vector<uint32_t> sorted;
+    for (uint32_t id : order_) if (!nodes_[id].elided) sorted.push_back(id);
     std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
         if (nodes_[a].level != nodes_[b].level) return nodes_[a].level < nodes_[b].level;
         return nodes_[a].kind < nodes_[b].kind;
@@ -206,12 +209,73 @@ Graph::~Graph() {
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
+// Graph-compiler fusion.  A port buffer is a per-tick temporary of Engine::run_tick
+// (src/engine.rs:461,504-506), observable only through connections, so a port whose only consumers
+// are folded into its producer's kernel need not exist.  Two patterns, both bit-identical to the
+// separate modules because the folded arithmetic is applied to the very f32 the producer stores:
+//   F1  EqThree -> StereoPanner(L = R = that EQ) [-> Amplifier input]   => epilogue of the EQ kernel
+//   F2  Trigger (single consumer) -> Envelope gate                       => constant gate, no buffer
+void Graph::plan_fusion() {
+    const size_t N = nodes_.size();
+    std::vector<std::vector<std::vector<std::pair<uint32_t, uint32_t>>>> cons(N);
+    for (size_t i = 0; i < N; ++i) cons[i].resize(nodes_[i].out_type.size());
+    for (uint32_t id : order_)
+        for (uint32_t k = 0; k < nodes_[id].in_src.size(); ++k) {
+            const PortRef pr = nodes_[id].in_src[k];
+            if (pr.node >= 0) cons[pr.node][pr.port].push_back({id, k});
+        }
+    // does `from` (transitively, through its inputs) depend on `target`?  bounded search, conservative
+    auto depends_on = [&](int32_t from, uint32_t target) {
+        std::vector<int32_t> st{from};
+        size_t visited = 0;
+        while (!st.empty()) {
+            const int32_t x = st.back(); st.pop_back();
+            if ((uint32_t)x == target) return true;
+            if (++visited > 256) return true;
+            for (const PortRef& pr : nodes_[x].in_src) if (pr.node >= 0) st.push_back(pr.node);
+        }
+        return false;
+    };
+    for (uint32_t e : order_) {
+        Node& E = nodes_[e];
+        if (E.kind != MX_KIND_EQ_THREE) continue;
+        const auto& c = cons[e][0];
+        if (c.size() != 2 || c[0].first != c[1].first || c[0].second == c[1].second) continue;
+        const uint32_t p = c[0].first;
+        Node& P = nodes_[p];
+        if (P.kind != MX_KIND_STEREO_PANNER || P.elided) continue;
+        E.fuse_pan = (int32_t)p; E.out_elided[0] = 1;
+        P.elided = true; P.owner = (int32_t)e;
+        const auto& pc = cons[p][0];
+        if (pc.size() == 1 && nodes_[pc[0].first].kind == MX_KIND_AMPLIFIER && pc[0].second == 0) {
+            const uint32_t a = pc[0].first;
+            Node& A = nodes_[a];
+            const PortRef ctl = A.in_src[1];
+            if (ctl.node < 0 || !depends_on(ctl.node, e)) {
+                E.fuse_amp = (int32_t)a; P.out_elided[0] = 1;
+                A.elided = true; A.owner = (int32_t)e;
+                if (ctl.node >= 0) E.level = std::max(E.level, nodes_[ctl.node].level + 1);   // the fused kernel reads the control port
+            }
+        }
+    }
+    for (uint32_t v : order_) {
+        Node& V = nodes_[v];
+        if (V.kind != MX_KIND_ENVELOPE) continue;
+        const PortRef g = V.in_src[0];
+        if (g.node < 0 || nodes_[g.node].kind != MX_KIND_TRIGGER || cons[g.node][0].size() != 1) continue;
+        Node& G = nodes_[g.node];
+        V.fuse_trigger = g.node;
+        G.elided = true; G.owner = (int32_t)v; G.out_elided[0] = 1;
+    }
+}
+
 void Graph::layout_slab() {
     size_t off = 0;
     auto bump = [&](size_t floats) { size_t o = off; off += (floats + 63) & ~(size_t)63; return o; };  // 256-byte aligned
     zero_off_ = bump(2 * cap_frames_);
     for (Node& n : nodes_)
-        for (size_t k = 0; k < n.out_type.size(); ++k) n.out_off[k] = bump(floats_per_frame(n.out_type[k]) * cap_frames_);
+        for (size_t k = 0; k < n.out_type.size(); ++k)
+            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump(floats_per_frame(n.out_type[k]) * cap_frames_);
     slab_floats_ = off;
     slab_.alloc(off * sizeof(float));
     hip_check(hipMemsetAsync(slab_.p, 0, off * sizeof(float), stream_), "hipMemsetAsync(slab)");
@@ -252,7 +316,13 @@ void Graph::upload_group(Group& g) {
         for (size_t i = 0; i < n; ++i) {
             const Node& nd = nodes_[g.nodes[i]];
             mx_envelope_params p; std::memcpy(&p, nd.params.data(), sizeof p);
-            d[i] = EnvDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
+            float gate_const = 0.f; uint32_t use_const = 0;
+            if (nd.fuse_trigger >= 0) {   // Trigger folded in: its constant (trigger.rs:38-41) replaces the gate buffer
+                mx_trigger_params tp; std::memcpy(&tp, nodes_[nd.fuse_trigger].params.data(), sizeof tp);
+                gate_const = tp.gate_open ? 1.0f : 0.0f; use_const = 1;
+            }
+            d[i] = EnvDesc{use_const ? nullptr : in_ptr(nd, 0, false), out_ptr(nd, 0), gate_const, use_const,
+                           p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
                            p.sustain_amplitude, 1.0 - p.sustain_amplitude, 1.0 / p.release_ms};
         }
         up(g.desc, d.data(), n * sizeof(EnvDesc));
@@ -264,7 +334,20 @@ void Graph::upload_group(Group& g) {
         for (size_t i = 0; i < n; ++i) {
             const Node& nd = nodes_[g.nodes[i]];
             mx_eq_three_params p; std::memcpy(&p, nd.params.data(), sizeof p);
-            d[i] = EqDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), db_to_linear(p.gain_lo_db), db_to_linear(p.gain_mid_db), db_to_linear(p.gain_hi_db)};
+            EqDesc e{};
+            e.in = in_ptr(nd, 0, false);
+            e.gain_lo = db_to_linear(p.gain_lo_db); e.gain_mid = db_to_linear(p.gain_mid_db); e.gain_hi = db_to_linear(p.gain_hi_db);
+            if (nd.fuse_amp >= 0) {          // EqThree -> StereoPanner(L = R) -> Amplifier in one kernel
+                const Node& amp = nodes_[nd.fuse_amp];
+                mx_amplifier_params ap; std::memcpy(&ap, amp.params.data(), sizeof ap);
+                e.out = out_ptr(amp, 0); e.ctl = in_ptr(amp, 1, true);
+                e.amp_one_minus = 1.0 - ap.mod_depth; e.amp_mod_depth = ap.mod_depth; e.amp_amplitude = ap.amplitude; e.epi = 2;
+            } else if (nd.fuse_pan >= 0) {   // EqThree -> StereoPanner(L = R)
+                e.out = out_ptr(nodes_[nd.fuse_pan], 0); e.epi = 1;
+            } else {
+                e.out = out_ptr(nd, 0); e.epi = 0;
+            }
+            d[i] = e;
         }
         up(g.desc, d.data(), n * sizeof(EqDesc));
         if (!g.state.p) { g.state.alloc(n * sizeof(EqState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EqState)), "hipMemset"); }
@@ -356,6 +439,7 @@ void Graph::update_params(uint32_t node, const void* params, size_t len) {
         n.vmixer->update(p);
     }
     if (n.group >= 0) upload_group(groups_[n.group]);
+    if (n.elided && n.owner >= 0 && nodes_[n.owner].group >= 0) upload_group(groups_[nodes_[n.owner].group]);
 }
 
 void Graph::write_source(uint32_t node, const float* host, size_t frames) {
@@ -514,6 +598,7 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
     if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
     const Node& n = nodes_[node];
+    if (n.out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
     const size_t fl = floats_per_frame(n.out_type[port]) * frames;
     hip_check(hipMemcpyAsync(host, out_ptr(n, port), fl * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
     sync();
@@ -521,6 +606,7 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
 
 float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
+    if (nodes_[node].out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
     if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]);
     return out_ptr(nodes_[node], port);
 }

@@ -35,6 +35,12 @@ struct Node {
     uint64_t plot_count = 0;
     std::vector<uint8_t> plot_fired;          // per call of the last run
     std::vector<int32_t> plot_slot;           // staging slot per call (-1 = not fired)
+    // graph-compiler fusion (Graph::plan_fusion)
+    bool elided = false;                      // never launched: its work is folded into `owner`'s kernel
+    int32_t owner = -1;                       // node whose descriptors carry this node's params
+    int32_t fuse_pan = -1, fuse_amp = -1;     // EQ_THREE: StereoPanner / Amplifier folded into the epilogue
+    int32_t fuse_trigger = -1;                // ENVELOPE: Trigger folded in as a constant gate
+    std::vector<uint8_t> out_elided;          // per output port: buffer not materialised
     // video nodes (run tick by tick inside Graph::run)
     struct VOut { FrameRef frame; Rational dur, off; };
     std::unique_ptr<VideoMixer> vmixer;       // VIDEO_MIXER
@@ -87,6 +93,7 @@ public:
     void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 
 private:
+    void plan_fusion();
     void layout_slab();
     void build_descriptors();
     void upload_group(Group& g);

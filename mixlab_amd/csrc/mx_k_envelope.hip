@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
 #pragma unroll
         for (int k = 0; k < K; ++k) {                       // K independent loads in flight
             const size_t i = base + 64 * k + lane;
-            xs[k] = (i < frames && p.gate) ? p.gate[i] : 0.0f;   // Disconnected => ZERO_BUFFER_MONO
+            xs[k] = p.use_const ? p.gate_const : ((i < frames && p.gate) ? p.gate[i] : 0.0f);   // Disconnected => ZERO_BUFFER_MONO
         }
         // can any marker in these K tiles flip the carried state?  On: only a 0.0; Initial/Off: only a 1.0
         bool quiet = true;

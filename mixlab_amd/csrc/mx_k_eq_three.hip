@@ -16,6 +16,19 @@ namespace mx {
 // ---------------------------------------------------------------------------------------------
 #define MX_VSA (1.0 / 4294967295.0)   /* eq_three.rs:11 */
 
+// Fused epilogue (see EqDesc): what StereoPanner (stereo_panner.rs:35-38) and Amplifier
+// (amplifier.rs:52-57,71-73) would do to the f32 sample y the EQ just produced.
+__device__ __forceinline__ void eq_emit(const EqDesc& d, size_t i, float y) {
+    if (d.epi == 0u) { d.out[i] = y; return; }
+    float v = y;
+    if (d.epi == 2u) {
+        const double m = d.ctl ? (double)d.ctl[i] : 1.0;          // amplifier.rs:54 (mono control, one value per frame)
+        const double depth = d.amp_one_minus + d.amp_mod_depth * m;   // amplifier.rs:71-73
+        v = (float)((double)y * depth * d.amp_amplitude);           // amplifier.rs:56
+    }
+    reinterpret_cast<float2*>(d.out)[i] = make_float2(v, v);
+}
+
 __device__ __forceinline__ double pump(const double f, double (&p)[4], const double sample) {
     p[0] += f * (sample - p[0]) + MX_VSA;
     p[1] += f * (p[0] - p[1]);
@@ -39,7 +52,7 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
         const double h = h0 - pump(hi_f, hi, sample);
         const double mid = h0 - (h + l);
         h0 = h1; h1 = h2; h2 = sample;
-        d.out[i] = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);
+        eq_emit(d, i, (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi));
     }
     for (int k = 0; k < 4; ++k) { st.lo[k] = lo[k]; st.hi[k] = hi[k]; }
     st.history[0] = h0; st.history[1] = h1; st.history[2] = h2;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256) void k_eq_three_scan(const EqDesc* __restrict_
 #pragma unroll 4
         for (int k = 0; k < L; ++k) {
             const int e = tid + 256 * k;
-            if (e < nv) d.out[base + e] = tile[e + (e >> LOG2L)];
+            if (e < nv) eq_emit(d, base + e, tile[e + (e >> LOG2L)]);
         }
         __syncthreads();
     }

@@ -17,12 +17,21 @@ struct AmpDesc { const float* in; const float* ctl; /* nullptr => Disconnected =
 // reference (`1.0 / params.attack_ms * ms`), evaluated once on the host with the same IEEE division.
 struct EnvDesc {
     const float* gate; float* out;
+    float gate_const; uint32_t use_const;   // gate is a Trigger fused in: constant 1.0 / 0.0, no buffer (trigger.rs:38-41)
     double attack_ms, inv_attack, inv_decay, sustain, one_minus_sustain, inv_release;
 };
 struct EnvState { uint32_t tag; uint32_t pad; uint64_t seq; double off_amplitude; };  // EnvelopeState, envelope.rs:8-13
 
 // src/module/eq_three.rs:58-89
-struct EqDesc { const float* in; float* out; double gain_lo, gain_mid, gain_hi; };
+// epi: fused epilogue chosen by the graph compiler (mx_engine.cpp plan_fusion):
+//   0  out[i] = y                                  (plain EqThree)
+//   1  out[2i] = out[2i+1] = y                     (EqThree -> StereoPanner with L = R = this EQ)
+//   2  out[2i] = out[2i+1] = amp(y, ctl[i])        (... -> Amplifier input; ctl nullptr => 1.0)
+// y is the f32 the EQ would have stored, so the fused result is bit-identical to the three modules.
+struct EqDesc {
+    const float* in; float* out; double gain_lo, gain_mid, gain_hi;
+    const float* ctl; double amp_one_minus, amp_mod_depth, amp_amplitude; uint32_t epi; uint32_t pad;
+};
 struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };       // eq_three.rs:13-26,100-103
 
 // time-parallel EqThree: Toeplitz powers of the one-sample pole matrix, per chunk length L (host-computed)

@@ -1,0 +1,80 @@
+"""The graph compiler's fusion (EqThree -> StereoPanner(L=R) [-> Amplifier]; Trigger -> Envelope) must be
+invisible: every port that still exists carries bit-identical samples with and without it."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from mixlab_amd.workspace import Workspace
+from test_gpu_audio_parity import SPT, assert_bit_exact, strips
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("eq_flag", [0, abi.FLAG_EQ_EXACT])
+def test_fused_equals_unfused_on_every_surviving_port(eq_flag):
+    n_strips, T = 24, 5
+    ws, mix, srcs, trigs = strips(n_strips)
+    gf = ws.build(max_ticks_per_run=T, flags=eq_flag)
+    gu = ws.build(max_ticks_per_run=T, flags=eq_flag | abi.FLAG_NO_FUSE)
+    noise = [synth.noise(k, 3 * T * SPT) for k in range(n_strips)]
+    for run in range(3):
+        for g in (gf, gu):
+            for k, tr in enumerate(trigs):
+                g.update_params(tr, abi.TriggerParams(1 if (run + k) % 2 else 0))      # folded Trigger: update must reach the Envelope
+            if run == 2:
+                g.update_params(mix + 6, abi.AmplifierParams(0.7, 0.25))               # folded Amplifier of strip 0
+            for k, s in enumerate(srcs):
+                g.write_source(s, noise[k][run * T * SPT:(run + 1) * T * SPT], T)
+            g.run_ticks(run * T, T)
+        for port in (0, 1):
+            assert_bit_exact(gf.read_output(mix, port, T, True), gu.read_output(mix, port, T, True), f"mixer port {port} run {run}")
+        for k in (0, 7, n_strips - 1):
+            amp, env = mix + 6 * k + 6, mix + 6 * k + 2
+            assert_bit_exact(gf.read_output(amp, 0, T, True), gu.read_output(amp, 0, T, True), f"amp out strip {k}")
+            assert_bit_exact(gf.read_output(env, 0, T, False), gu.read_output(env, 0, T, False), f"envelope out strip {k}")
+
+
+def test_folded_ports_are_not_readable_and_say_why():
+    ws, mix, srcs, trigs = strips(2)
+    g = ws.build()
+    eq, pan, trig = mix + 4, mix + 5, mix + 1
+    for node in (eq, pan, trig):
+        with pytest.raises(abi.MxError) as e:
+            g.read_output(node, 0, 1, node == pan)
+        assert e.value.code == abi.MX_ERR_INVALID and "MX_FLAG_NO_FUSE" in str(e.value)
+    g2 = ws.build(flags=abi.FLAG_NO_FUSE)
+    g2.run_ticks(0, 1)
+    assert g2.read_output(eq, 0, 1, False).shape == (SPT,)
+
+
+def test_fusion_is_not_applied_when_a_port_has_another_consumer():
+    # the EQ output also feeds a second mixer through its own panner input: it must stay materialised
+    ws = Workspace(44100, 60)
+    s = ws.source_mono(); e = ws.eq_three(3.0, 0.0, -3.0); p = ws.stereo_panner(); a = ws.amplifier(1.0, 0.0)
+    e2 = ws.eq_three(0.0, 0.0, 0.0)
+    ws.connect(s, 0, e, 0); ws.connect(e, 0, p, 0); ws.connect(e, 0, p, 1); ws.connect(p, 0, a, 0); ws.connect(e, 0, e2, 0)
+    g = ws.build(flags=abi.FLAG_EQ_EXACT)
+    x = synth.noise(5, SPT)
+    g.write_source(s, x, 1); g.run_ticks(0, 1)
+    st = oracle.eq_three_new(44100.0)
+    want = oracle.eq_three_run(st, (3.0, 0.0, -3.0), x)
+    assert_bit_exact(g.read_output(e, 0, 1, False), want, "EQ port with two consumers")
+    assert_bit_exact(g.read_output(a, 0, 1, True)[0::2], want, "through panner + unity amplifier")
+
+
+def test_eq_panner_only_fusion():
+    ws = Workspace(44100, 60)
+    s = ws.source_mono(); e = ws.eq_three(-6.0, 2.0, 1.0); p = ws.stereo_panner(); m = ws.mixer([(0.0, 1.0, True)])
+    ws.connect(s, 0, e, 0); ws.connect(e, 0, p, 0); ws.connect(e, 0, p, 1); ws.connect(p, 0, m, 0)
+    x = synth.noise(6, 4 * SPT)
+    outs = []
+    for flags in (abi.FLAG_EQ_EXACT, abi.FLAG_EQ_EXACT | abi.FLAG_NO_FUSE):
+        g = ws.build(max_ticks_per_run=4, flags=flags)
+        g.write_source(s, x, 4); g.run_ticks(0, 4)
+        outs.append((g.read_output(p, 0, 4, True), g.read_output(m, 1, 4, True)))
+    assert_bit_exact(outs[0][0], outs[1][0], "panner out"); assert_bit_exact(outs[0][1], outs[1][1], "cue")
+    st = oracle.eq_three_new(44100.0)
+    want = oracle.eq_three_run(st, (-6.0, 2.0, 1.0), x)
+    assert_bit_exact(outs[0][0][0::2], want); assert_bit_exact(outs[0][0][1::2], want)
