@@ -54,9 +54,9 @@ static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& i
 
 // first column of A^n for the 4-pole cascade's one-sample matrix A (lower-triangular Toeplitz,
 // first column f^k (1-f)): binary exponentiation on polynomials mod x^4, in long double
-static void toeplitz_pow(long double f, uint64_t n, double out[4]) {
+static void toeplitz_pow_ld(long double f, uint64_t n, long double res[4]) {
     long double base[4] = {1.0L - f, f * (1.0L - f), f * f * (1.0L - f), f * f * f * (1.0L - f)};
-    long double res[4] = {1.0L, 0.0L, 0.0L, 0.0L};
+    res[0] = 1.0L; res[1] = res[2] = res[3] = 0.0L;
     auto mul = [](const long double a[4], const long double b[4], long double c[4]) {
         long double t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 4; ++i) for (int j = 0; i + j < 4; ++j) t[i + j] += a[i] * b[j];
@@ -67,7 +67,15 @@ static void toeplitz_pow(long double f, uint64_t n, double out[4]) {
         mul(base, base, base);
         n >>= 1;
     }
-    for (int i = 0; i < 4; ++i) out[i] = (double)res[i];
+}
+static void toeplitz_pow(long double f, uint64_t n, double out[4]) {
+    long double r[4];
+    toeplitz_pow_ld(f, n, r);
+    for (int i = 0; i < 4; ++i) out[i] = (double)r[i];
+}
+// y = T(a) v for the lower-triangular Toeplitz matrix with first column a
+static void toeplitz_apply_ld(const long double a[4], const long double v[4], long double y[4]) {
+    for (int i = 0; i < 4; ++i) { y[i] = 0.0L; for (int k = 0; k <= i; ++k) y[i] += a[k] * v[i - k]; }
 }
 
 static inline size_t floats_per_frame(uint8_t lt) { return lt == MX_MONO ? 1 : (lt == MX_STEREO ? 2 : 0); }
@@ -192,6 +200,21 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
             for (int f = 0; f < 2; ++f) {
                 for (int j = 0; j <= 64; ++j) toeplitz_pow(fs[f], L * (uint64_t)j, tabs[v].pw[f][j]);
                 for (int k = 0; k < 6; ++k) toeplitz_pow(fs[f], L << k, tabs[v].p2[f][k]);
+                // phase-A tables: s' = A s + b x + c with b = (f, f^2, f^3, f^4), c = VSA (1, f, f^2, f^3) (eq_three.rs:117-124)
+                const long double ff = fs[f], vsa = 1.0L / 4294967295.0L;
+                const long double b[4] = {ff, ff * ff, ff * ff * ff, ff * ff * ff * ff};
+                const long double c[4] = {vsa, vsa * ff, vsa * ff * ff, vsa * ff * ff * ff};
+                long double sum[4] = {0, 0, 0, 0};
+                for (uint64_t m = 0; m < 32; ++m) {
+                    long double am[4], hb[4];
+                    toeplitz_pow_ld(ff, m, am);
+                    toeplitz_apply_ld(am, b, hb);
+                    for (int q = 0; q < 4; ++q) tabs[v].h[f][m][q] = (double)hb[q];
+                    if (m < L) for (int q = 0; q < 4; ++q) sum[q] += am[q];
+                }
+                long double cz[4];
+                toeplitz_apply_ld(sum, c, cz);
+                for (int q = 0; q < 4; ++q) tabs[v].cz[f][q] = (double)cz[q];
             }
         }
         eq_tabs_.alloc(tabs.size() * sizeof(EqScanTab));

@@ -1,19 +1,13 @@
-// mx_k_eq_three.hip -- EqThree: exact sequential kernel and the time-parallel chunked scan.
+// mx_k_eq_three.hip -- EqThree (reference src/module/eq_three.rs:58-89,100-125): the exact sequential
+// kernel and the time-parallel chunked scan, both with the graph compiler's fused epilogue.
 //
 // Build with -ffp-contract=off: the reference (Rust) evaluates every f64 expression as written,
-// never fused; parity with it is bit-exact only if v_fma_f64 is not substituted for mul+add.
-//
-// Layout: every port buffer is a flat f32 stream of `frames` mono samples (or 2*frames interleaved
-// L,R) -- n_ticks consecutive 735/800-sample tick buffers back to back -- 256-byte aligned.
-// Instances of one module kind are batched into one launch.
+// never fused; the exact recurrence below must not become v_fma_f64.  Explicit fma() calls appear
+// only in the scan's helper arithmetic, whose rounding is free by construction.
 #include "mx_dev.hpp"
 
 namespace mx {
 
-// ---------------------------------------------------------------------------------------------
-// EqThree, exact order (src/module/eq_three.rs:58-89,117-124): one lane per instance walks its
-// stream sequentially; bit-exact against the reference's golden pair.  f64-VALU/latency bound.
-// ---------------------------------------------------------------------------------------------
 #define MX_VSA (1.0 / 4294967295.0)   /* eq_three.rs:11 */
 
 // Fused epilogue (see EqDesc): what StereoPanner (stereo_panner.rs:35-38) and Amplifier
@@ -22,13 +16,14 @@ __device__ __forceinline__ void eq_emit(const EqDesc& d, size_t i, float y) {
     if (d.epi == 0u) { d.out[i] = y; return; }
     float v = y;
     if (d.epi == 2u) {
-        const double m = d.ctl ? (double)d.ctl[i] : 1.0;          // amplifier.rs:54 (mono control, one value per frame)
+        const double m = d.ctl ? (double)d.ctl[i] : 1.0;              // amplifier.rs:54 (mono control, one value per frame)
         const double depth = d.amp_one_minus + d.amp_mod_depth * m;   // amplifier.rs:71-73
-        v = (float)((double)y * depth * d.amp_amplitude);           // amplifier.rs:56
+        v = (float)((double)y * depth * d.amp_amplitude);             // amplifier.rs:56
     }
     reinterpret_cast<float2*>(d.out)[i] = make_float2(v, v);
 }
 
+// LowPass::pump, eq_three.rs:117-124 -- exact order
 __device__ __forceinline__ double pump(const double f, double (&p)[4], const double sample) {
     p[0] += f * (sample - p[0]) + MX_VSA;
     p[1] += f * (p[0] - p[1]);
@@ -37,6 +32,10 @@ __device__ __forceinline__ double pump(const double f, double (&p)[4], const dou
     return p[3];
 }
 
+// ---------------------------------------------------------------------------------------------
+// exact order: one lane per instance walks its stream sequentially; bit-exact against the
+// reference's golden pair.  f64-VALU latency bound; selected by MX_FLAG_EQ_EXACT.
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
                                                         uint32_t n_inst, size_t frames, double lo_f, double hi_f) {
     const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
@@ -64,101 +63,101 @@ void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t fram
 }
 
 // ---------------------------------------------------------------------------------------------
-// EqThree, time-parallel (default).  The two 4-pole cascades are affine recurrences
-//   s[n+1] = A s[n] + b x[n] + c ,  A = lower-triangular Toeplitz with first column f^k (1-f)
+// time-parallel (default).  The two 4-pole cascades are affine recurrences
+//   s[n+1] = A s[n] + b x[n] + c ,  A = lower-triangular Toeplitz with first column f^k (1-f),
+//   b = (f, f^2, f^3, f^4), c = VSA (1, f, f^2, f^3)
 // so a stream can be cut into chunks that are processed concurrently:
 //   one 256-thread workgroup per instance walks its stream in segments of 256 chunks x L samples,
-//   staged through LDS with coalesced loads (lane stride L+1 words => conflict-free ds_read_b32);
-//   phase A: every lane runs the EXACT recurrence over its chunk from a zero state  -> z_j
-//   scan:    S_j = A^(L j) S_seg + sum_{i<j} A^(L (j-1-i)) z_i   (Hillis-Steele over the wave with
-//            f64 shuffles and host-precomputed Toeplitz powers, then a 4-entry hop across waves)
-//   phase C: every lane re-runs the EXACT recurrence from its true initial state and emits samples.
-// Only the chunk-initial states differ from the sequential order, by ~1e-16 relative; the f32
-// outputs stay within 1 ULP of the reference order (measured: tests/test_gpu_audio_parity.py).
-// Work is ~1.7x the sequential op count but spread over 256 lanes per instance.
+//   staged through LDS with coalesced burst loads (lane stride L+1 words => conflict-free ds_read_b32);
+//   phase A: z_j = state a zero-initialised filter reaches after chunk j = sum_m (A^m b) x[L-1-m] + const,
+//            8 independent f64 FMA chains against host tables held in SGPRs (wave-uniform);
+//   scan:    S_j = A^(L j) S_seg + sum_{i<j} A^(L (j-1-i)) z_i  (Hillis-Steele over the wave with f64
+//            shuffles and Toeplitz powers from LDS, then a 4-entry hop across waves);
+//   phase C: every lane runs the EXACT recurrence (pump) from its true initial state and emits.
+// Only chunk-initial states differ from the sequential order, by ~1e-16 relative; f32 outputs stay
+// within 1 ULP of the reference order (tests/test_gpu_audio_parity.py counts the mismatches).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pump_state(const double f, double (&p)[4], const double sample) {
-    p[0] += f * (sample - p[0]) + MX_VSA;
-    p[1] += f * (p[0] - p[1]);
-    p[2] += f * (p[1] - p[2]);
-    p[3] += f * (p[2] - p[3]);
-}
 // y = T(c) v for a lower-triangular Toeplitz matrix with first column c
-__device__ __forceinline__ void toep_apply(const double (&c)[4], const double (&v)[4], double (&y)[4]) {
+__device__ __forceinline__ void toep_apply(const double* c, const double (&v)[4], double (&y)[4]) {
     y[0] = c[0] * v[0];
-    y[1] = c[0] * v[1] + c[1] * v[0];
-    y[2] = c[0] * v[2] + c[1] * v[1] + c[2] * v[0];
-    y[3] = c[0] * v[3] + c[1] * v[2] + c[2] * v[1] + c[3] * v[0];
+    y[1] = fma(c[1], v[0], c[0] * v[1]);
+    y[2] = fma(c[2], v[0], fma(c[1], v[1], c[0] * v[2]));
+    y[3] = fma(c[3], v[0], fma(c[2], v[1], fma(c[1], v[2], c[0] * v[3])));
 }
 
 template <int LOG2L>
-__global__ __launch_bounds__(256) void k_eq_three_scan(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
-                                                        size_t frames, double lo_f, double hi_f,
-                                                        const EqScanTab* __restrict__ tab) {
+__global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
+                                                           size_t frames, double lo_f, double hi_f,
+                                                           const EqScanTab* __restrict__ tab) {
     constexpr int L = 1 << LOG2L;
     constexpr int SEG = 256 * L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);                                  // 256 * (L + 1) floats
-    double* wtot = reinterpret_cast<double*>(smem + 256 * (L + 1) * sizeof(float)); // [4 waves][8]
-    double* carry = wtot + 32;                                                      // [11]
+    float* tile = reinterpret_cast<float*>(smem);                                    // 256 * (L + 1) floats
+    double* wtot = reinterpret_cast<double*>(smem + 256 * (L + 1) * sizeof(float));  // [4 waves][8]
+    double* carry = wtot + 32;                                                       // [11] lo[4] hi[4] hist[3] (+1 pad)
+    double* pw = carry + 12;                                                         // [2][65][4] A^(L j)
+    double* p2 = pw + 2 * 65 * 4;                                                    // [2][6][4]  A^(L 2^k)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const EqDesc d = descs[blockIdx.x];
-    double s_lo[4], s_hi[4], hist[3];
-    {
-        const EqState st = states[blockIdx.x];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s_lo[k] = st.lo[k]; s_hi[k] = st.hi[k]; }
-        hist[0] = st.history[0]; hist[1] = st.history[1]; hist[2] = st.history[2];
+    // tables and the carried state live in LDS, not in registers, across the segment loop
+    for (int i = tid; i < 2 * 65 * 4; i += 256) pw[i] = (&tab->pw[0][0][0])[i];
+    if (tid < 2 * 6 * 4) p2[tid] = (&tab->p2[0][0][0])[tid];
+    if (tid < 11) {
+        const double* st = reinterpret_cast<const double*>(&states[blockIdx.x]);   // lo[4] hi[4] history[3]
+        carry[tid] = st[tid];
     }
-    double pl_lo[4], pl_hi[4], p64_lo[4], p64_hi[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        pl_lo[k] = tab->pw[0][lane][k]; pl_hi[k] = tab->pw[1][lane][k];
-        p64_lo[k] = tab->pw[0][64][k]; p64_hi[k] = tab->pw[1][64][k];
-    }
+    __syncthreads();
 
     for (size_t base = 0; base < frames; base += SEG) {
         const size_t rem = frames - base;
         const int nv = rem < (size_t)SEG ? (int)rem : SEG;
-        // coalesced stage-in: element e of the segment -> tile[e + e / L]
-#pragma unroll 4
-        for (int k = 0; k < L; ++k) {
-            const int e = tid + 256 * k;
-            float v = 0.f;
-            if (e < nv && d.in) v = d.in[base + e];
-            tile[e + (e >> LOG2L)] = v;
+        {   // coalesced stage-in; all L loads of the lane are issued before the first LDS write
+            float r[L];
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + 256 * k;
+                r[k] = (e < nv && d.in) ? d.in[base + e] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + 256 * k;
+                tile[e + (e >> LOG2L)] = r[k];       // element e of the segment -> tile[e + e / L]
+            }
         }
         __syncthreads();
 
         const int start = tid << LOG2L;
         const int my_n = nv - start >= L ? L : (nv - start > 0 ? nv - start : 0);
-        const float* mine = tile + start + tid;   // (start + i) + (start + i) / L == start + tid + i
+        float* mine = tile + start + tid;   // (start + i) + (start + i) / L == start + tid + i
 
-        // phase A: zero-state response of a full chunk
+        // phase A: zero-state response of a full chunk as 8 dot products (tables wave-uniform)
         double zl[4] = {0.0, 0.0, 0.0, 0.0}, zh[4] = {0.0, 0.0, 0.0, 0.0};
         if (my_n == L) {
-#pragma unroll 4
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { zl[q] = tab->cz[0][q]; zh[q] = tab->cz[1][q]; }
+#pragma unroll 8
             for (int i = 0; i < L; ++i) {
                 const double x = (double)mine[i];
-                pump_state(lo_f, zl, x);
-                pump_state(hi_f, zh, x);
+                const int m = L - 1 - i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { zl[q] = fma(tab->h[0][m][q], x, zl[q]); zh[q] = fma(tab->h[1][m][q], x, zh[q]); }
             }
         }
         // the three samples before my chunk (the EQ's 3-sample delay line), read before anyone overwrites the tile
         double h0, h1, h2;
-        if (tid == 0) { h0 = hist[0]; h1 = hist[1]; h2 = hist[2]; }
+        if (tid == 0) { h0 = carry[8]; h1 = carry[9]; h2 = carry[10]; }
         else { const float* prev = tile + (start - L) + (tid - 1); h0 = (double)prev[L - 3]; h1 = (double)prev[L - 2]; h2 = (double)prev[L - 1]; }
 
         // inclusive scan over the wave: E_j = sum_{i<=j} P^(j-i) z_i
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int dd = 1 << k;
-            double ul[4], uh[4], tl[4], th[4], cl[4], ch[4];
+            double ul[4], uh[4], tl[4], th[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { ul[q] = __shfl_up(zl[q], dd); uh[q] = __shfl_up(zh[q], dd); cl[q] = tab->p2[0][k][q]; ch[q] = tab->p2[1][k][q]; }
-            toep_apply(cl, ul, tl);
-            toep_apply(ch, uh, th);
+            for (int q = 0; q < 4; ++q) { ul[q] = __shfl_up(zl[q], dd); uh[q] = __shfl_up(zh[q], dd); }
+            toep_apply(p2 + (0 * 6 + k) * 4, ul, tl);
+            toep_apply(p2 + (1 * 6 + k) * 4, uh, th);
             if (lane >= dd) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { zl[q] += tl[q]; zh[q] += th[q]; }
@@ -170,15 +169,15 @@ __global__ __launch_bounds__(256) void k_eq_three_scan(const EqDesc* __restrict_
         }
         __syncthreads();
         // state entering my wave: C_w = P^64 C_{w-1} + W_{w-1}, C_0 = segment-in state
-        double cl_[4] = {s_lo[0], s_lo[1], s_lo[2], s_lo[3]}, ch_[4] = {s_hi[0], s_hi[1], s_hi[2], s_hi[3]};
+        double cl[4] = {carry[0], carry[1], carry[2], carry[3]}, ch[4] = {carry[4], carry[5], carry[6], carry[7]};
         for (int w = 0; w < wave; ++w) {
             double tl[4], th[4];
-            toep_apply(p64_lo, cl_, tl);
-            toep_apply(p64_hi, ch_, th);
+            toep_apply(pw + (0 * 65 + 64) * 4, cl, tl);
+            toep_apply(pw + (1 * 65 + 64) * 4, ch, th);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { cl_[q] = tl[q] + wtot[w * 8 + q]; ch_[q] = th[q] + wtot[w * 8 + 4 + q]; }
+            for (int q = 0; q < 4; ++q) { cl[q] = tl[q] + wtot[w * 8 + q]; ch[q] = th[q] + wtot[w * 8 + 4 + q]; }
         }
-        // my chunk's true initial state: S = P^lane C_w + E_{lane-1}
+        // my chunk's true initial state: S = P^lane C_w + E_{lane-1}   (lane 0: P^0 = I, E = 0 => S = C_w exactly)
         double lo[4], hi[4];
         {
             double el[4], eh[4], tl[4], th[4];
@@ -188,24 +187,24 @@ __global__ __launch_bounds__(256) void k_eq_three_scan(const EqDesc* __restrict_
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { el[q] = 0.0; eh[q] = 0.0; }
             }
-            toep_apply(pl_lo, cl_, tl);
-            toep_apply(pl_hi, ch_, th);
+            toep_apply(pw + (0 * 65 + lane) * 4, cl, tl);
+            toep_apply(pw + (1 * 65 + lane) * 4, ch, th);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { lo[q] = tl[q] + el[q]; hi[q] = th[q] + eh[q]; }
         }
         // phase C: exact recurrence from the true state, outputs overwrite my chunk of the tile
-        float* mine_w = tile + start + tid;
 #pragma unroll 4
         for (int i = 0; i < L; ++i) {
             if (i < my_n) {
-                const double sample = (double)mine_w[i];
+                const double sample = (double)mine[i];
                 const double l = pump(lo_f, lo, sample);
                 const double h = h0 - pump(hi_f, hi, sample);
                 const double mid = h0 - (h + l);
                 h0 = h1; h1 = h2; h2 = sample;
-                mine_w[i] = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);
+                mine[i] = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);
             }
         }
+        __syncthreads();   // every lane has finished reading wtot / carry of this segment
         // the chunk holding the segment's last valid sample publishes the carried state
         const int jl = (nv - 1) >> LOG2L;
         if (tid == jl) {
@@ -213,25 +212,33 @@ __global__ __launch_bounds__(256) void k_eq_three_scan(const EqDesc* __restrict_
             for (int q = 0; q < 4; ++q) { carry[q] = lo[q]; carry[4 + q] = hi[q]; }
             carry[8] = h0; carry[9] = h1; carry[10] = h2;
         }
-        __syncthreads();
+        // coalesced stage-out through the fused epilogue
+        if (d.epi == 2u && d.ctl) {   // fused Amplifier: fetch the lane's L control samples in one burst first
+            float c[L];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s_lo[q] = carry[q]; s_hi[q] = carry[4 + q]; }
-        hist[0] = carry[8]; hist[1] = carry[9]; hist[2] = carry[10];
-        // coalesced stage-out
-#pragma unroll 4
-        for (int k = 0; k < L; ++k) {
-            const int e = tid + 256 * k;
-            if (e < nv) eq_emit(d, base + e, tile[e + (e >> LOG2L)]);
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + 256 * k;
+                c[k] = (e < nv) ? d.ctl[base + e] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + 256 * k;
+                if (e < nv) {
+                    const double depth = d.amp_one_minus + d.amp_mod_depth * (double)c[k];                 // amplifier.rs:71-73
+                    const float v = (float)((double)tile[e + (e >> LOG2L)] * depth * d.amp_amplitude);   // amplifier.rs:56
+                    reinterpret_cast<float2*>(d.out)[base + e] = make_float2(v, v);                       // stereo_panner.rs:35-38
+                }
+            }
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + 256 * k;
+                if (e < nv) eq_emit(d, base + e, tile[e + (e >> LOG2L)]);
+            }
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        EqState st;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { st.lo[k] = s_lo[k]; st.hi[k] = s_hi[k]; }
-        st.history[0] = hist[0]; st.history[1] = hist[1]; st.history[2] = hist[2]; st.pad = 0.0;
-        states[blockIdx.x] = st;
-    }
+    if (tid < 11) reinterpret_cast<double*>(&states[blockIdx.x])[tid] = carry[tid];
 }
 
 int eq_scan_log2l(size_t frames) {
@@ -245,7 +252,7 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frame
                           const EqScanTab* tabs /* indexed by log2L - 2 */, hipStream_t s) {
     if (!n || !frames) return;
     const int l2 = eq_scan_log2l(frames);
-    const size_t lds = (size_t)256 * ((1u << l2) + 1) * sizeof(float) + (32 + 12) * sizeof(double);
+    const size_t lds = (size_t)256 * ((1u << l2) + 1) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double);
     const EqScanTab* tab = tabs + (l2 - 2);
     switch (l2) {
     case 2: hipLaunchKernelGGL(k_eq_three_scan<2>, dim3(n), dim3(256), lds, s, d, st, frames, lo_f, hi_f, tab); break;

@@ -36,7 +36,9 @@ struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };  
 
 // time-parallel EqThree: Toeplitz powers of the one-sample pole matrix, per chunk length L (host-computed)
 //   pw[f][j] = first column of A_f^(L*j), j = 0..64 ; p2[f][k] = first column of A_f^(L * 2^k), k = 0..5
-struct EqScanTab { double pw[2][65][4]; double p2[2][6][4]; };
+//   h[f][m]  = A_f^m b_f, m = 0..31 (impulse response of the 4 poles: phase A is 8 dot products against it)
+//   cz[f]    = (sum_{m<L} A_f^m) c_f (what the VSA constant alone leaves in a zero-initialised filter after L samples)
+struct EqScanTab { double pw[2][65][4]; double p2[2][6][4]; double h[2][32][4]; double cz[2][4]; };
 
 // src/module/fm_sine.rs:37-56
 struct FmDesc { const float* in; float* out; double freq_mid, freq_amp; };
