@@ -39,8 +39,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 BYTES_PER_FRAME = {"trigger": 4, "envelope": 8, "eq_three": 8, "stereo_panner": 16, "amplifier": 20, "mixer": 8}
 # with the graph compiler's fusion (default): Trigger folded into Envelope (gate never materialised),
 # StereoPanner + Amplifier folded into the EqThree kernel (reads source + control, writes the stereo strip)
-BYTES_PER_FRAME_FUSED = {"envelope": 4, "eq_three": 4 + 4 + 8, "mixer": 8}
-STRIP_BYTES_FUSED_48K = (4 + 16 + 8) * 800   # per strip-tick: envelope out + fused EQ (in, ctl, out) + mixer read
+# Trigger + Envelope + StereoPanner + Amplifier all folded into the EqThree kernel, whose stereo result
+# (L == R) is stored as one float per frame: it reads the source and writes 4 B per frame; the Mixer reads 4 B
+BYTES_PER_FRAME_FUSED = {"envelope": 4, "eq_three": 4 + 4, "mixer": 4}
+STRIP_BYTES_FUSED_48K = (8 + 4) * 800   # per strip-tick: fused EQ (in, out) + mixer read
 
 
 def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate):
@@ -312,7 +314,7 @@ def main():
             frames = T * spt
             bpf = BYTES_PER_FRAME if args.no_fuse else BYTES_PER_FRAME_FUSED
             if dom == "mixer":
-                alg = bpf["mixer"] * (local_strips + 2) * frames
+                alg = (bpf["mixer"] * local_strips + 16) * frames
             else:
                 alg = bpf.get(dom, 0) * local_strips * frames
             ach = alg / (avg_ms * 1e-3) / 1e9
@@ -332,7 +334,7 @@ def main():
             "config": {"workload": f"{args.strips}-channel Mixer + EqThree + Envelope chain (Trigger->Envelope; noise->EqThree->StereoPanner->Amplifier->Mixer), {SR} Hz f32",
                        "strips": args.strips, "ticks_per_step": T, "samples_per_tick": spt,
                        "eq_mode": "exact-sequential" if args.eq_exact else "time-parallel",
-                       "fusion": "off (every port materialised)" if args.no_fuse else "EqThree+StereoPanner+Amplifier, Trigger+Envelope",
+                       "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
                        "parallelism": f"strips sharded x{world}" + (", all-gather + rank-ordered Mixer" if world > 1 else "")},
             "realtime_channels_equiv": value / 60.0,
             "graph_hbm_frac_module_boundary_bytes": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),

@@ -82,8 +82,9 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
                                 default is the time-parallel chunked scan (<= 1 ULP f32) */
 
 #define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
-                                [-> Amplifier] into the EQ kernel and a single-consumer Trigger into its Envelope; the
-                                folded ports are per-tick temporaries (src/engine.rs:461,504-506) and then cannot be
+                                [-> Amplifier [<- Envelope <- Trigger]] into the EQ kernel, a single-consumer Trigger into
+                                its Envelope, and stores an L == R stereo result that only Mixers read as one float per
+                                frame.  Folded ports are per-tick temporaries (src/engine.rs:461,504-506) and cannot be
                                 read back.  Results on every remaining port are bit-identical either way. */
 
 typedef struct {

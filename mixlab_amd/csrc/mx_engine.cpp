@@ -164,7 +164,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         n.level = lvl;
         n.in_src_orig = n.in_src;
     }
-    for (Node& n : nodes_) n.out_elided.assign(n.out_type.size(), 0);
+    for (Node& n : nodes_) { n.out_elided.assign(n.out_type.size(), 0); n.out_dup.assign(n.out_type.size(), 0); }
     if (!(flags_ & MX_FLAG_NO_FUSE)) plan_fusion();
     // groups: (level, kind); nodes folded into another node's kernel are never launched
     std::vector<uint32_t> sorted;
@@ -290,6 +290,28 @@ void Graph::plan_fusion() {
         V.fuse_trigger = g.node;
         G.elided = true; G.owner = (int32_t)v; G.out_elided[0] = 1;
     }
+    for (uint32_t e : order_) {
+        Node& E = nodes_[e];
+        if (E.kind != MX_KIND_EQ_THREE || E.fuse_pan < 0) continue;
+        // F3: the fused Amplifier's control is a constant-gate Envelope that feeds nothing else: its closed form
+        // (envelope.rs:34-58) is evaluated in the epilogue; for a constant gate only the run's first sample can
+        // change the Envelope's state, so no per-sample state machine is needed
+        if (E.fuse_amp >= 0) {
+            const PortRef ctl = nodes_[E.fuse_amp].in_src[1];
+            if (ctl.node >= 0 && nodes_[ctl.node].kind == MX_KIND_ENVELOPE && nodes_[ctl.node].fuse_trigger >= 0 &&
+                cons[ctl.node][0].size() == 1) {
+                Node& V = nodes_[ctl.node];
+                E.fuse_env = ctl.node;
+                V.elided = true; V.owner = (int32_t)e; V.out_elided[0] = 1;
+            }
+        }
+        // F4: the fused result is stereo with L == R by construction; if only Mixers read it, store one float per frame
+        const uint32_t x = (uint32_t)(E.fuse_amp >= 0 ? E.fuse_amp : E.fuse_pan);
+        const auto& xc = cons[x][0];
+        bool only_mixers = !xc.empty();
+        for (const auto& c : xc) only_mixers = only_mixers && nodes_[c.first].kind == MX_KIND_MIXER;
+        if (only_mixers) nodes_[x].out_dup[0] = 1;
+    }
 }
 
 void Graph::layout_slab() {
@@ -298,7 +320,7 @@ void Graph::layout_slab() {
     zero_off_ = bump(2 * cap_frames_);
     for (Node& n : nodes_)
         for (size_t k = 0; k < n.out_type.size(); ++k)
-            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump(floats_per_frame(n.out_type[k]) * cap_frames_);
+            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump((n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * cap_frames_);
     slab_floats_ = off;
     slab_.alloc(off * sizeof(float));
     hip_check(hipMemsetAsync(slab_.p, 0, off * sizeof(float), stream_), "hipMemsetAsync(slab)");
@@ -345,8 +367,8 @@ void Graph::upload_group(Group& g) {
                 gate_const = tp.gate_open ? 1.0f : 0.0f; use_const = 1;
             }
             d[i] = EnvDesc{use_const ? nullptr : in_ptr(nd, 0, false), out_ptr(nd, 0), gate_const, use_const,
-                           p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
-                           p.sustain_amplitude, 1.0 - p.sustain_amplitude, 1.0 / p.release_ms};
+                           EnvParams{p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
+                                     p.sustain_amplitude, 1.0 - p.sustain_amplitude, 1.0 / p.release_ms}};
         }
         up(g.desc, d.data(), n * sizeof(EnvDesc));
         if (!g.state.p) { g.state.alloc(n * sizeof(EnvState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EnvState)), "hipMemset"); }
@@ -362,13 +384,25 @@ void Graph::upload_group(Group& g) {
             e.gain_lo = db_to_linear(p.gain_lo_db); e.gain_mid = db_to_linear(p.gain_mid_db); e.gain_hi = db_to_linear(p.gain_hi_db);
             if (nd.fuse_amp >= 0) {          // EqThree -> StereoPanner(L = R) -> Amplifier in one kernel
                 const Node& amp = nodes_[nd.fuse_amp];
+                if (amp.out_dup[0]) e.flags |= MX_EQF_MONO_DUP;
                 mx_amplifier_params ap; std::memcpy(&ap, amp.params.data(), sizeof ap);
                 e.out = out_ptr(amp, 0); e.ctl = in_ptr(amp, 1, true);
                 e.amp_one_minus = 1.0 - ap.mod_depth; e.amp_mod_depth = ap.mod_depth; e.amp_amplitude = ap.amplitude; e.epi = 2;
             } else if (nd.fuse_pan >= 0) {   // EqThree -> StereoPanner(L = R)
                 e.out = out_ptr(nodes_[nd.fuse_pan], 0); e.epi = 1;
+                if (nodes_[nd.fuse_pan].out_dup[0]) e.flags |= MX_EQF_MONO_DUP;
             } else {
                 e.out = out_ptr(nd, 0); e.epi = 0;
+            }
+            if (nd.fuse_env >= 0) {          // Envelope (constant gate) evaluated inline as the control
+                const Node& env = nodes_[nd.fuse_env];
+                mx_envelope_params ep; std::memcpy(&ep, env.params.data(), sizeof ep);
+                mx_trigger_params tp; std::memcpy(&tp, nodes_[env.fuse_trigger].params.data(), sizeof tp);
+                e.flags |= MX_EQF_ENV; e.ctl = nullptr;
+                e.env = EnvParams{ep.attack_ms, 1.0 / ep.attack_ms, 1.0 / ep.decay_ms, ep.sustain_amplitude, 1.0 - ep.sustain_amplitude, 1.0 / ep.release_ms};
+                e.env_gate = tp.gate_open ? 1.0f : 0.0f;
+                if (!g.state2.p) { g.state2.alloc(n * sizeof(EnvState)); hip_check(hipMemset(g.state2.p, 0, n * sizeof(EnvState)), "hipMemset"); }
+                e.env_state = (EnvState*)g.state2.p + i;
             }
             d[i] = e;
         }
@@ -401,7 +435,9 @@ void Graph::upload_group(Group& g) {
             const mx_mixer_channel_params* p = (const mx_mixer_channel_params*)nd.params.data();
             for (size_t c = 0; c < nch; ++c) {
                 mx_mixer_channel_params cp; std::memcpy(&cp, p + c, sizeof cp);
-                ch[o + c] = MixChan{in_ptr(nd, (uint32_t)c, false), cp.fader * db_to_linear(cp.gain_db), cp.cue ? 1u : 0u, 0u};  // mixer.rs:59
+                const PortRef src = nd.in_src[c];
+                const uint32_t dup = (src.node >= 0 && nodes_[src.node].out_dup[src.port]) ? 1u : 0u;
+                ch[o + c] = MixChan{in_ptr(nd, (uint32_t)c, false), cp.fader * db_to_linear(cp.gain_db), cp.cue ? 1u : 0u, dup};  // mixer.rs:59
             }
             d[i] = MixDesc{(const MixChan*)g.extra.p + o, (uint32_t)nch, 0u, out_ptr(nd, 0), out_ptr(nd, 1)};
             o += nch;
@@ -462,7 +498,9 @@ void Graph::update_params(uint32_t node, const void* params, size_t len) {
         n.vmixer->update(p);
     }
     if (n.group >= 0) upload_group(groups_[n.group]);
-    if (n.elided && n.owner >= 0 && nodes_[n.owner].group >= 0) upload_group(groups_[nodes_[n.owner].group]);
+    int32_t o = (int32_t)node;
+    while (nodes_[o].elided && nodes_[o].owner >= 0) o = nodes_[o].owner;   // Trigger -> Envelope -> EqThree chains
+    if (o != (int32_t)node && nodes_[o].group >= 0) upload_group(groups_[nodes_[o].group]);
 }
 
 void Graph::write_source(uint32_t node, const float* host, size_t frames) {
@@ -551,8 +589,8 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, frames, stream_); break;
         case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, frames, t0, sample_rate_, stream_); break;
         case MX_KIND_EQ_THREE:
-            if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, lo_f_, hi_f_, stream_);
-            else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
+            if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, t0, sample_rate_, lo_f_, hi_f_, stream_);
+            else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
             break;
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
         case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, frames, stream_); break;
@@ -622,6 +660,12 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
     if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
     const Node& n = nodes_[node];
     if (n.out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
+    if (n.out_dup[port]) {   // stored as one float per frame (L == R): expand for the caller
+        hip_check(hipMemcpyAsync(host, out_ptr(n, port), frames * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+        sync();
+        for (size_t i = frames; i-- > 0;) { const float v = host[i]; host[2 * i] = v; host[2 * i + 1] = v; }
+        return;
+    }
     const size_t fl = floats_per_frame(n.out_type[port]) * frames;
     hip_check(hipMemcpyAsync(host, out_ptr(n, port), fl * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
     sync();
@@ -630,6 +674,7 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
 float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (nodes_[node].out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
+    if (nodes_[node].out_dup[port]) throw Error(MX_ERR_INVALID, "port is stored as one float per frame (L == R fused result): use mx_graph_read_output, or build with MX_FLAG_NO_FUSE");
     if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]);
     return out_ptr(nodes_[node], port);
 }

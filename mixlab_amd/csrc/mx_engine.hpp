@@ -40,7 +40,9 @@ struct Node {
     int32_t owner = -1;                       // node whose descriptors carry this node's params
     int32_t fuse_pan = -1, fuse_amp = -1;     // EQ_THREE: StereoPanner / Amplifier folded into the epilogue
     int32_t fuse_trigger = -1;                // ENVELOPE: Trigger folded in as a constant gate
+    int32_t fuse_env = -1;                    // EQ_THREE: constant-gate Envelope evaluated inline as the fused Amplifier's control
     std::vector<uint8_t> out_elided;          // per output port: buffer not materialised
+    std::vector<uint8_t> out_dup;             // per output port: stereo with L == R stored as ONE float per frame
     // video nodes (run tick by tick inside Graph::run)
     struct VOut { FrameRef frame; Rational dur, off; };
     std::unique_ptr<VideoMixer> vmixer;       // VIDEO_MIXER
@@ -56,6 +58,7 @@ struct Group {
     DevBuf desc;     // kind-specific descriptor array
     DevBuf state;    // EnvState[] / EqState[]
     DevBuf extra;    // Mixer: MixChan arrays
+    DevBuf state2;   // EqThree: EnvState[] of Envelopes folded into the epilogue
 };
 
 class Graph {

@@ -15,38 +15,10 @@
 //
 // algorithmic bytes per frame: 4 (gate) + 4 (out).
 #include "mx_dev.hpp"
+#include "mx_env_math.hpp"
 
 namespace mx {
 
-// (last - first) as f64 / SAMPLE_RATE * 1000.0 (envelope.rs:16-18) with the IEEE quotient obtained
-// by Markstein's correction instead of the ~20-instruction division expansion: q = a*y,
-// r = fma(-q,b,a), q' = fma(r,y,q) with y = RN(1/b) from the host.  tests/test_fastdiv.py checks
-// q' == a/b bit-for-bit for every a in [0, 2^32) at 44.1 and 48 kHz; larger spans (> 24 h) take
-// the true division.
-__device__ __forceinline__ double ms_of_u32(uint32_t dt, double sr, double rsr) {
-    const double a = (double)dt;
-    double q = a * rsr;
-    const double r = fma(-q, sr, a);
-    q = fma(r, rsr, q);
-    return q * 1000.0;
-}
-__device__ __forceinline__ double seq_ms(uint64_t first, uint64_t last, double sr, double rsr) {
-    const uint64_t dt = last - first;
-    if (dt >> 32) return (double)dt / sr * 1000.0;
-    return ms_of_u32((uint32_t)dt, sr, rsr);
-}
-__device__ __forceinline__ double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }  // envelope.rs:20-28
-__device__ __forceinline__ double amp_on_ms(const EnvDesc& p, double ms) {                            // envelope.rs:37-49
-    const double attack = p.inv_attack * ms;
-    const double since_decay = ms - p.attack_ms;
-    const double decay_amplitude = 1.0 - clamp01(p.inv_decay * since_decay);
-    const double decay = p.sustain + (p.one_minus_sustain * decay_amplitude);
-    return ms < p.attack_ms ? attack : decay;
-}
-__device__ __forceinline__ double amp_off_ms(const EnvDesc& p, double off_amp, double ms) {           // envelope.rs:51-56
-    const double release_amplitude = 1.0 - clamp01(p.inv_release * ms);
-    return off_amp * release_amplitude;
-}
 __device__ __forceinline__ int top_bit(uint64_t m) { return 63 - __clzll((long long)m); }
 __device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
@@ -97,7 +69,7 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
                 double a = 0.0;                                                   // envelope.rs:36
                 if (tag != 0u) {                                                  // uniform
                     const double ms = ms_of_u32(d0 + (uint32_t)(64 * k + lane), sr, rsr);
-                    a = (tag == 1u) ? amp_on_ms(p, ms) : amp_off_ms(p, off_amp, ms);
+                    a = (tag == 1u) ? amp_on_ms(p.p, ms) : amp_off_ms(p.p, off_amp, ms);
                 }
                 if (i < frames) p.out[i] = (float)a;
             }
@@ -133,11 +105,11 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
                 const uint64_t Rb = R & ((1ull << fl) - 1ull);
                 const uint64_t on = Rb ? tb + (uint64_t)top_bit(Rb) : seq;
                 my_tag = 2u; my_seq = off;
-                my_off = amp_on_ms(p, seq_ms(on, off, sr, rsr));      // envelope.rs:108-111
+                my_off = amp_on_ms(p.p, seq_ms(on, off, sr, rsr));      // envelope.rs:108-111
             }
             const double ms = seq_ms(my_seq, tb + (uint64_t)lane, sr, rsr);
-            const double a_on = amp_on_ms(p, ms);
-            const double a_off = amp_off_ms(p, my_off, ms);
+            const double a_on = amp_on_ms(p.p, ms);
+            const double a_off = amp_off_ms(p.p, my_off, ms);
             const double a = my_tag == 1u ? a_on : (my_tag == 2u ? a_off : 0.0);   // envelope.rs:36
             if (valid) p.out[i] = (float)a;
 

@@ -5,22 +5,44 @@
 // never fused; the exact recurrence below must not become v_fma_f64.  Explicit fma() calls appear
 // only in the scan's helper arithmetic, whose rounding is free by construction.
 #include "mx_dev.hpp"
+#include "mx_env_math.hpp"
 
 namespace mx {
 
 #define MX_VSA (1.0 / 4294967295.0)   /* eq_three.rs:11 */
 
-// Fused epilogue (see EqDesc): what StereoPanner (stereo_panner.rs:35-38) and Amplifier
-// (amplifier.rs:52-57,71-73) would do to the f32 sample y the EQ just produced.
-__device__ __forceinline__ void eq_emit(const EqDesc& d, size_t i, float y) {
-    if (d.epi == 0u) { d.out[i] = y; return; }
+// Fused epilogue (see EqDesc): what StereoPanner (stereo_panner.rs:35-38), Amplifier
+// (amplifier.rs:52-57,71-73) and -- with MX_EQF_ENV -- the Envelope feeding its control
+// (envelope.rs:34-58,117) would do to the f32 sample y the EQ just produced.
+struct EnvCtx { uint32_t tag; uint64_t seq; double off_amp; uint64_t t0; double sr, rsr; };
+
+__device__ __forceinline__ EnvCtx env_ctx_begin(const EqDesc& d, uint64_t t0, double sr, double rsr) {
+    EnvCtx ec{0u, 0ull, 0.0, t0, sr, rsr};
+    if (d.flags & MX_EQF_ENV) {
+        ec.tag = d.env_state->tag; ec.seq = d.env_state->seq; ec.off_amp = d.env_state->off_amplitude;
+        env_const_gate_step(d.env, d.env_gate, t0, sr, rsr, ec.tag, ec.seq, ec.off_amp);   // only the run's first sample can flip it
+    }
+    return ec;
+}
+__device__ __forceinline__ void env_ctx_end(const EqDesc& d, const EnvCtx& ec) {
+    if (d.flags & MX_EQF_ENV) { d.env_state->tag = ec.tag; d.env_state->seq = ec.seq; d.env_state->off_amplitude = ec.off_amp; }
+}
+__device__ __forceinline__ void eq_store(const EqDesc& d, size_t i, float v) {
+    if (d.epi == 0u || (d.flags & MX_EQF_MONO_DUP)) d.out[i] = v;                     // one float per frame
+    else reinterpret_cast<float2*>(d.out)[i] = make_float2(v, v);                    // stereo_panner.rs:35-38
+}
+__device__ __forceinline__ float eq_amp(const EqDesc& d, float y, bool has_ctl, float c) {
+    const double m = has_ctl ? (double)c : 1.0;                                       // amplifier.rs:54
+    const double depth = d.amp_one_minus + d.amp_mod_depth * m;                       // amplifier.rs:71-73
+    return (float)((double)y * depth * d.amp_amplitude);                              // amplifier.rs:56
+}
+__device__ __forceinline__ void eq_emit(const EqDesc& d, const EnvCtx& ec, size_t i, float y) {
     float v = y;
     if (d.epi == 2u) {
-        const double m = d.ctl ? (double)d.ctl[i] : 1.0;              // amplifier.rs:54 (mono control, one value per frame)
-        const double depth = d.amp_one_minus + d.amp_mod_depth * m;   // amplifier.rs:71-73
-        v = (float)((double)y * depth * d.amp_amplitude);             // amplifier.rs:56
+        if (d.flags & MX_EQF_ENV) v = eq_amp(d, y, true, (float)env_amplitude(d.env, ec.tag, ec.seq, ec.off_amp, ec.t0 + i, ec.sr, ec.rsr));   // Envelope stores f32 (envelope.rs:117)
+        else v = eq_amp(d, y, d.ctl != nullptr, d.ctl ? d.ctl[i] : 0.f);
     }
-    reinterpret_cast<float2*>(d.out)[i] = make_float2(v, v);
+    eq_store(d, i, v);
 }
 
 // LowPass::pump, eq_three.rs:117-124 -- exact order
@@ -37,10 +59,12 @@ __device__ __forceinline__ double pump(const double f, double (&p)[4], const dou
 // reference's golden pair.  f64-VALU latency bound; selected by MX_FLAG_EQ_EXACT.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
-                                                        uint32_t n_inst, size_t frames, double lo_f, double hi_f) {
+                                                        uint32_t n_inst, size_t frames, uint64_t t0, double sr, double rsr,
+                                                        double lo_f, double hi_f) {
     const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= n_inst) return;
     const EqDesc d = descs[inst];
+    const EnvCtx ec = env_ctx_begin(d, t0, sr, rsr);
     EqState st = states[inst];
     double lo[4] = {st.lo[0], st.lo[1], st.lo[2], st.lo[3]};
     double hi[4] = {st.hi[0], st.hi[1], st.hi[2], st.hi[3]};
@@ -51,15 +75,16 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
         const double h = h0 - pump(hi_f, hi, sample);
         const double mid = h0 - (h + l);
         h0 = h1; h1 = h2; h2 = sample;
-        eq_emit(d, i, (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi));
+        eq_emit(d, ec, i, (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi));
     }
     for (int k = 0; k < 4; ++k) { st.lo[k] = lo[k]; st.hi[k] = hi[k]; }
     st.history[0] = h0; st.history[1] = h1; st.history[2] = h2;
     states[inst] = st;
+    env_ctx_end(d, ec);
 }
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f, hipStream_t s) {
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, frames, lo_f, hi_f);
+    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -87,7 +112,7 @@ __device__ __forceinline__ void toep_apply(const double* c, const double (&v)[4]
 
 template <int LOG2L>
 __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
-                                                           size_t frames, double lo_f, double hi_f,
+                                                           size_t frames, uint64_t t0, double sr, double rsr, double lo_f, double hi_f,
                                                            const EqScanTab* __restrict__ tab) {
     constexpr int L = 1 << LOG2L;
     constexpr int SEG = 256 * L;
@@ -100,6 +125,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const EqDesc d = descs[blockIdx.x];
+    const EnvCtx ec = env_ctx_begin(d, t0, sr, rsr);   // wave-uniform
     // tables and the carried state live in LDS, not in registers, across the segment loop
     for (int i = tid; i < 2 * 65 * 4; i += 256) pw[i] = (&tab->pw[0][0][0])[i];
     if (tid < 2 * 6 * 4) p2[tid] = (&tab->p2[0][0][0])[tid];
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
             carry[8] = h0; carry[9] = h1; carry[10] = h2;
         }
         // coalesced stage-out through the fused epilogue
-        if (d.epi == 2u && d.ctl) {   // fused Amplifier: fetch the lane's L control samples in one burst first
+        if (d.epi == 2u && d.ctl && !(d.flags & MX_EQF_ENV)) {   // fused Amplifier, control from a buffer: one burst of L loads first
             float c[L];
 #pragma unroll
             for (int k = 0; k < L; ++k) {
@@ -223,22 +249,19 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
 #pragma unroll
             for (int k = 0; k < L; ++k) {
                 const int e = tid + 256 * k;
-                if (e < nv) {
-                    const double depth = d.amp_one_minus + d.amp_mod_depth * (double)c[k];                 // amplifier.rs:71-73
-                    const float v = (float)((double)tile[e + (e >> LOG2L)] * depth * d.amp_amplitude);   // amplifier.rs:56
-                    reinterpret_cast<float2*>(d.out)[base + e] = make_float2(v, v);                       // stereo_panner.rs:35-38
-                }
+                if (e < nv) eq_store(d, base + e, eq_amp(d, tile[e + (e >> LOG2L)], true, c[k]));
             }
         } else {
 #pragma unroll 8
             for (int k = 0; k < L; ++k) {
                 const int e = tid + 256 * k;
-                if (e < nv) eq_emit(d, base + e, tile[e + (e >> LOG2L)]);
+                if (e < nv) eq_emit(d, ec, base + e, tile[e + (e >> LOG2L)]);
             }
         }
         __syncthreads();
     }
     if (tid < 11) reinterpret_cast<double*>(&states[blockIdx.x])[tid] = carry[tid];
+    if (tid == 0) env_ctx_end(d, ec);
 }
 
 int eq_scan_log2l(size_t frames) {
@@ -248,17 +271,17 @@ int eq_scan_log2l(size_t frames) {
     return 5;
 }
 
-void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f,
+void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
                           const EqScanTab* tabs /* indexed by log2L - 2 */, hipStream_t s) {
     if (!n || !frames) return;
     const int l2 = eq_scan_log2l(frames);
     const size_t lds = (size_t)256 * ((1u << l2) + 1) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double);
     const EqScanTab* tab = tabs + (l2 - 2);
     switch (l2) {
-    case 2: hipLaunchKernelGGL(k_eq_three_scan<2>, dim3(n), dim3(256), lds, s, d, st, frames, lo_f, hi_f, tab); break;
-    case 3: hipLaunchKernelGGL(k_eq_three_scan<3>, dim3(n), dim3(256), lds, s, d, st, frames, lo_f, hi_f, tab); break;
-    case 4: hipLaunchKernelGGL(k_eq_three_scan<4>, dim3(n), dim3(256), lds, s, d, st, frames, lo_f, hi_f, tab); break;
-    default: hipLaunchKernelGGL(k_eq_three_scan<5>, dim3(n), dim3(256), lds, s, d, st, frames, lo_f, hi_f, tab); break;
+    case 2: hipLaunchKernelGGL(k_eq_three_scan<2>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
+    case 3: hipLaunchKernelGGL(k_eq_three_scan<3>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
+    case 4: hipLaunchKernelGGL(k_eq_three_scan<4>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
+    default: hipLaunchKernelGGL(k_eq_three_scan<5>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
     }
 }
 

@@ -39,6 +39,19 @@ __device__ __forceinline__ void ldw(uint64_t base, uint32_t byte_off, float (&v)
         for (int k = 0; k < W; ++k) v[k] = t[k];
     }
 }
+// input stored as one float per frame (a stereo port whose L == R by construction, see EqDesc
+// MX_EQF_MONO_DUP): fetch W/2 floats from half the byte offset and duplicate them in registers
+template <int W>
+__device__ __forceinline__ void ldw_dup(uint64_t base, uint32_t byte_off, float (&v)[W]) {
+    float h[W / 2];
+    ldw<W / 2>(base, byte_off >> 1, h);
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = h[k >> 1];
+}
+template <int W>
+__device__ __forceinline__ void ldw_any(uint64_t base, uint32_t byte_off, bool dup, float (&v)[W]) {
+    if (dup) ldw_dup<W>(base, byte_off, v); else ldw<W>(base, byte_off, v);   // wave-uniform
+}
 template <int W>
 __device__ __forceinline__ void stw(float* __restrict__ pf, uint32_t byte_off, const float (&v)[W]) {
     typedef typename VecF<W>::T VT;
@@ -91,9 +104,10 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
             uint64_t p_cur = (uint64_t)ch[lane].in, p_nxt = 0;
             uint64_t g_cur = (uint64_t)__double_as_longlong(ch[lane].gain), g_nxt = 0;
             uint64_t cue_cur = __ballot(ch[lane].cue != 0), cue_nxt = 0;
+            uint64_t dup_cur = __ballot(ch[lane].dup != 0), dup_nxt = 0;
             float v[R][W];
 #pragma unroll
-            for (int u = 0; u < R; ++u) ldw<W>(bcast_u64(p_cur, u), off, v[u]);   // prologue: fill the ring
+            for (int u = 0; u < R; ++u) ldw_any<W>(bcast_u64(p_cur, u), off, ((dup_cur >> u) & 1ull) != 0, v[u]);   // prologue: fill the ring
 
             for (uint32_t c0 = 0; c0 < n_full; c0 += 64) {
                 const bool have_next = c0 + 64 < n_full;   // uniform
@@ -101,6 +115,7 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
                     p_nxt = (uint64_t)ch[c0 + 64 + lane].in;
                     g_nxt = (uint64_t)__double_as_longlong(ch[c0 + 64 + lane].gain);
                     cue_nxt = __ballot(ch[c0 + 64 + lane].cue != 0);
+                    dup_nxt = __ballot(ch[c0 + 64 + lane].dup != 0);
                 }
 #pragma unroll
                 for (int u = 0; u < 64; ++u) {
@@ -109,20 +124,20 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
                     for (int k = 0; k < W; ++k) x[k] = v[u % R][k];
                     // refill the slot with channel c0 + u + R
                     if (u + R < 64) {
-                        ldw<W>(bcast_u64(p_cur, (u + R) & 63), off, v[u % R]);
+                        ldw_any<W>(bcast_u64(p_cur, (u + R) & 63), off, ((dup_cur >> ((u + R) & 63)) & 1ull) != 0, v[u % R]);
                     } else if (have_next) {
-                        ldw<W>(bcast_u64(p_nxt, (u + R) & 63), off, v[u % R]);
+                        ldw_any<W>(bcast_u64(p_nxt, (u + R) & 63), off, ((dup_nxt >> ((u + R) & 63)) & 1ull) != 0, v[u % R]);
                     }
                     const double g = __longlong_as_double((long long)bcast_u64(g_cur, u));
                     mix_one<W>(acc, cac, x, g, ((cue_cur >> u) & 1ull) != 0);
                 }
-                p_cur = p_nxt; g_cur = g_nxt; cue_cur = cue_nxt;
+                p_cur = p_nxt; g_cur = g_nxt; cue_cur = cue_nxt; dup_cur = dup_nxt;
             }
         }
         // remaining (< 64) channels: plain scalar-descriptor path
         for (uint32_t c = n_full; c < m.n_ch; ++c) {
             float x[W];
-            ldw<W>((uint64_t)ch[c].in, off, x);
+            ldw_any<W>((uint64_t)ch[c].in, off, ch[c].dup != 0, x);
             mix_one<W>(acc, cac, x, ch[c].gain, ch[c].cue != 0);
         }
         if (live) {

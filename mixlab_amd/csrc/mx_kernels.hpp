@@ -15,10 +15,11 @@ struct AmpDesc { const float* in; const float* ctl; /* nullptr => Disconnected =
 
 // src/module/envelope.rs:34-58,91-120.  Reciprocals are loop-invariant subexpressions of the
 // reference (`1.0 / params.attack_ms * ms`), evaluated once on the host with the same IEEE division.
+struct EnvParams { double attack_ms, inv_attack, inv_decay, sustain, one_minus_sustain, inv_release; };
 struct EnvDesc {
     const float* gate; float* out;
     float gate_const; uint32_t use_const;   // gate is a Trigger fused in: constant 1.0 / 0.0, no buffer (trigger.rs:38-41)
-    double attack_ms, inv_attack, inv_decay, sustain, one_minus_sustain, inv_release;
+    EnvParams p;
 };
 struct EnvState { uint32_t tag; uint32_t pad; uint64_t seq; double off_amplitude; };  // EnvelopeState, envelope.rs:8-13
 
@@ -28,9 +29,16 @@ struct EnvState { uint32_t tag; uint32_t pad; uint64_t seq; double off_amplitude
 //   1  out[2i] = out[2i+1] = y                     (EqThree -> StereoPanner with L = R = this EQ)
 //   2  out[2i] = out[2i+1] = amp(y, ctl[i])        (... -> Amplifier input; ctl nullptr => 1.0)
 // y is the f32 the EQ would have stored, so the fused result is bit-identical to the three modules.
+// MX_EQF_MONO_DUP: the stereo result has L == R by construction and every consumer is a Mixer input
+//   that understands it, so ONE float per frame is stored (half the write, half the mixer's read).
+// MX_EQF_ENV: the Amplifier's control is an Envelope whose gate is a Trigger constant and that feeds
+//   nothing else: its closed-form amplitude (envelope.rs:34-58) is evaluated in the epilogue and the
+//   control buffer never exists; env_state holds that Envelope's carried state.
+enum { MX_EQF_MONO_DUP = 1u, MX_EQF_ENV = 2u };
 struct EqDesc {
     const float* in; float* out; double gain_lo, gain_mid, gain_hi;
-    const float* ctl; double amp_one_minus, amp_mod_depth, amp_amplitude; uint32_t epi; uint32_t pad;
+    const float* ctl; double amp_one_minus, amp_mod_depth, amp_amplitude; uint32_t epi; uint32_t flags;
+    EnvParams env; EnvState* env_state; float env_gate; uint32_t pad;
 };
 struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };       // eq_three.rs:13-26,100-103
 
@@ -44,7 +52,7 @@ struct EqScanTab { double pw[2][65][4]; double p2[2][6][4]; double h[2][32][4]; 
 struct FmDesc { const float* in; float* out; double freq_mid, freq_amp; };
 
 // src/module/mixer.rs:46-71
-struct MixChan { const float* in; double gain; /* fader * 10^(dB/20), mixer.rs:59 */ uint32_t cue; uint32_t pad; };
+struct MixChan { const float* in; double gain; /* fader * 10^(dB/20), mixer.rs:59 */ uint32_t cue; uint32_t dup; /* input stored as one float per frame (L == R) */ };
 struct MixDesc { const MixChan* chans; uint32_t n_ch; uint32_t pad; float* master; float* cue; };
 
 // src/module/oscillator.rs:65-92
@@ -63,9 +71,9 @@ struct PlotJob { const float* in; float* left; float* right; };
 // Launchers.  `frames` = mono samples in this run (= n_ticks * SPT); stereo buffers hold 2*frames.
 void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f, hipStream_t s);
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f, hipStream_t s);
 int eq_scan_log2l(size_t frames);
-void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, double lo_f, double hi_f,
+void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, hipStream_t s);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s);
