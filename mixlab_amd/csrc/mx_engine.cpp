@@ -428,7 +428,7 @@ void Graph::upload_group(Group& g) {
         std::vector<MixChan> ch(total ? total : 1);
         if (g.extra.bytes < ch.size() * sizeof(MixChan) || !g.extra.p) g.extra.alloc(ch.size() * sizeof(MixChan));
         std::vector<MixDesc> d(n);
-        size_t o = 0;
+        size_t o = 0, n_dup = 0;
         for (size_t i = 0; i < n; ++i) {
             const Node& nd = nodes_[g.nodes[i]];
             const size_t nch = nd.in_type.size();
@@ -437,11 +437,13 @@ void Graph::upload_group(Group& g) {
                 mx_mixer_channel_params cp; std::memcpy(&cp, p + c, sizeof cp);
                 const PortRef src = nd.in_src[c];
                 const uint32_t dup = (src.node >= 0 && nodes_[src.node].out_dup[src.port]) ? 1u : 0u;
+                n_dup += dup;
                 ch[o + c] = MixChan{in_ptr(nd, (uint32_t)c, false), cp.fader * db_to_linear(cp.gain_db), cp.cue ? 1u : 0u, dup};  // mixer.rs:59
             }
             d[i] = MixDesc{(const MixChan*)g.extra.p + o, (uint32_t)nch, 0u, out_ptr(nd, 0), out_ptr(nd, 1)};
             o += nch;
         }
+        g.dup_mode = n_dup == 0 ? 0 : (n_dup == total ? 1 : 2);
         hip_check(hipMemcpy(g.extra.p, ch.data(), ch.size() * sizeof(MixChan), hipMemcpyHostToDevice), "hipMemcpy(mixchan)");
         up(g.desc, d.data(), n * sizeof(MixDesc));
         break;
@@ -593,7 +595,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
             else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
             break;
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
-        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, frames, g.dup_mode, stream_); break;
         case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
         case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, frames, stream_); break;
         case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, frames, stream_); break;

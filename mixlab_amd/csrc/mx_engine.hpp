@@ -59,6 +59,7 @@ struct Group {
     DevBuf state;    // EnvState[] / EqState[]
     DevBuf extra;    // Mixer: MixChan arrays
     DevBuf state2;   // EqThree: EnvState[] of Envelopes folded into the epilogue
+    int dup_mode = 0; // Mixer: 0 no input stored mono-dup, 1 all, 2 mixed
 };
 
 class Graph {

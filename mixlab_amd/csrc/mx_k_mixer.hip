@@ -48,9 +48,13 @@ __device__ __forceinline__ void ldw_dup(uint64_t base, uint32_t byte_off, float 
 #pragma unroll
     for (int k = 0; k < W; ++k) v[k] = h[k >> 1];
 }
-template <int W>
+// DUP: 0 = no input is mono-dup, 1 = every input is, 2 = mixed (per-channel branch; the branch costs the
+// compiler its vmcnt bookkeeping across the ring, so the homogeneous cases get their own instantiation)
+template <int W, int DUP>
 __device__ __forceinline__ void ldw_any(uint64_t base, uint32_t byte_off, bool dup, float (&v)[W]) {
-    if (dup) ldw_dup<W>(base, byte_off, v); else ldw<W>(base, byte_off, v);   // wave-uniform
+    if constexpr (DUP == 0) ldw<W>(base, byte_off, v);
+    else if constexpr (DUP == 1) ldw_dup<W>(base, byte_off, v);
+    else { if (dup) ldw_dup<W>(base, byte_off, v); else ldw<W>(base, byte_off, v); }   // wave-uniform
 }
 template <int W>
 __device__ __forceinline__ void stw(float* __restrict__ pf, uint32_t byte_off, const float (&v)[W]) {
@@ -81,7 +85,7 @@ __device__ __forceinline__ void mix_one(float (&acc)[W], float (&cac)[W], const 
 }
 
 // W floats per lane, ring of R loads in flight per lane, one wave per block.
-template <int W, int R>
+template <int W, int R, int DUP>
 __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs, size_t n /* stereo floats */) {
     static_assert(64 % R == 0, "ring must divide the descriptor block");
     const MixDesc m = descs[blockIdx.y];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
             uint64_t dup_cur = __ballot(ch[lane].dup != 0), dup_nxt = 0;
             float v[R][W];
 #pragma unroll
-            for (int u = 0; u < R; ++u) ldw_any<W>(bcast_u64(p_cur, u), off, ((dup_cur >> u) & 1ull) != 0, v[u]);   // prologue: fill the ring
+            for (int u = 0; u < R; ++u) ldw_any<W, DUP>(bcast_u64(p_cur, u), off, ((dup_cur >> u) & 1ull) != 0, v[u]);   // prologue: fill the ring
 
             for (uint32_t c0 = 0; c0 < n_full; c0 += 64) {
                 const bool have_next = c0 + 64 < n_full;   // uniform
@@ -124,9 +128,9 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
                     for (int k = 0; k < W; ++k) x[k] = v[u % R][k];
                     // refill the slot with channel c0 + u + R
                     if (u + R < 64) {
-                        ldw_any<W>(bcast_u64(p_cur, (u + R) & 63), off, ((dup_cur >> ((u + R) & 63)) & 1ull) != 0, v[u % R]);
+                        ldw_any<W, DUP>(bcast_u64(p_cur, (u + R) & 63), off, ((dup_cur >> ((u + R) & 63)) & 1ull) != 0, v[u % R]);
                     } else if (have_next) {
-                        ldw_any<W>(bcast_u64(p_nxt, (u + R) & 63), off, ((dup_nxt >> ((u + R) & 63)) & 1ull) != 0, v[u % R]);
+                        ldw_any<W, DUP>(bcast_u64(p_nxt, (u + R) & 63), off, ((dup_nxt >> ((u + R) & 63)) & 1ull) != 0, v[u % R]);
                     }
                     const double g = __longlong_as_double((long long)bcast_u64(g_cur, u));
                     mix_one<W>(acc, cac, x, g, ((cue_cur >> u) & 1ull) != 0);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
         // remaining (< 64) channels: plain scalar-descriptor path
         for (uint32_t c = n_full; c < m.n_ch; ++c) {
             float x[W];
-            ldw_any<W>((uint64_t)ch[c].in, off, ch[c].dup != 0, x);
+            ldw_any<W, DUP>((uint64_t)ch[c].in, off, ch[c].dup != 0, x);
             mix_one<W>(acc, cac, x, ch[c].gain, ch[c].cue != 0);
         }
         if (live) {
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
     }
 }
 
-void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, int dup_mode, hipStream_t s) {
     if (!n || !frames) return;
     const size_t ns = frames * 2;
     // widest lane vector that still yields enough waves to cover the chip; tuning override for experiments
@@ -161,10 +165,10 @@ void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s) {
     if (ns * sizeof(float) >= (1ull << 32)) return;  // unreachable: the engine caps a port buffer below 4 GiB
     const size_t items = ns / w;
     dim3 grid(grid_x(items, 64, 16384), n);
-    switch (w) {
-    case 4: hipLaunchKernelGGL((k_mixer<4, 16>), grid, dim3(64), 0, s, d, ns); break;
-    default: hipLaunchKernelGGL((k_mixer<2, 32>), grid, dim3(64), 0, s, d, ns); break;
-    }
+#define MX_MIX_LAUNCH(W, R, D) hipLaunchKernelGGL((k_mixer<W, R, D>), grid, dim3(64), 0, s, d, ns)
+    if (w == 4) { if (dup_mode == 0) MX_MIX_LAUNCH(4, 16, 0); else if (dup_mode == 1) MX_MIX_LAUNCH(4, 16, 1); else MX_MIX_LAUNCH(4, 16, 2); }
+    else        { if (dup_mode == 0) MX_MIX_LAUNCH(2, 32, 0); else if (dup_mode == 1) MX_MIX_LAUNCH(2, 32, 1); else MX_MIX_LAUNCH(2, 32, 2); }
+#undef MX_MIX_LAUNCH
 }
 
 }  // namespace mx

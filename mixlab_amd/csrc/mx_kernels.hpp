@@ -76,7 +76,7 @@ int eq_scan_log2l(size_t frames);
 void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, hipStream_t s);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
-void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, int dup_mode /* 0 none, 1 all, 2 mixed */, hipStream_t s);
 void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s);
