@@ -123,16 +123,18 @@ int mx_video_crossfade(mx_dframe* out, const mx_dframe* a, const mx_dframe* b, d
         const DFrame* fb = b ? D(b) : nullptr;
         for (const DFrame* x : {fa, fb})
             if (x && (x->width != o->width || x->height != o->height)) throw Error(MX_ERR_INVALID, "cross-fade inputs must have the output's size");
-        mx::FadeArgs ar;
-        ar.fade = mx::crossfade_factor(fader);
+        FrameRef ra(const_cast<DFrame*>(fa), fa != nullptr), rb(const_cast<DFrame*>(fb), fb != nullptr);
+        if (ra) ra->ensure_pixels(S(stream));
+        if (rb) rb->ensure_pixels(S(stream));
+        auto chain = mx::make_chain(ra, rb, mx::crossfade_factor(fader), S(stream));
+        mx::ChainArgs ar;
+        mx::fill_chain_sources(*chain, ar.src, ar.n_src, ar.fade, ar.v_is_a);
         for (int p = 0; p < 3; ++p) {
             ar.out[p] = o->data[p]; ar.out_stride[p] = o->stride[p];
-            ar.a[p] = fa ? fa->data[p] : nullptr; ar.a_stride[p] = fa ? fa->stride[p] : 0;
-            ar.b[p] = fb ? fb->data[p] : nullptr; ar.b_stride[p] = fb ? fb->stride[p] : 0;
             ar.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;
             ar.chunks[p] = ar.chunks_per_row[p] * o->ph(p);
         }
-        mx::launch_crossfade(ar, S(stream));
+        mx::launch_fade_chain(ar, S(stream));
         mx::hip_check(hipGetLastError(), "cross-fade launch");
     });
 }

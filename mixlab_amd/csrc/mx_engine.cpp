@@ -191,6 +191,19 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         if (n.kind == MX_KIND_VIDEO_MIXER || n.kind == MX_KIND_SOURCE_VIDEO || n.kind == MX_KIND_VIDEO_TO_RGBA) has_video_ = true;
         n.vout.resize(n.out_type.size());
     }
+    // a VideoMixer whose program output feeds exactly one video node of this graph hands it over as an
+    // unevaluated cross-fade chain: a cascade of mixers becomes one fused pass (mx_k_video.hip k_fade_chain*)
+    if (!(flags_ & MX_FLAG_NO_FUSE)) {
+        std::vector<uint32_t> n_cons(nodes_.size(), 0); std::vector<uint8_t> ok(nodes_.size(), 1);
+        for (const Node& n : nodes_)
+            for (const PortRef& pr : n.in_src)
+                if (pr.node >= 0 && nodes_[pr.node].kind == MX_KIND_VIDEO_MIXER && pr.port == 0) {
+                    n_cons[pr.node]++;
+                    if (n.kind != MX_KIND_VIDEO_MIXER && n.kind != MX_KIND_VIDEO_TO_RGBA) ok[pr.node] = 0;
+                }
+        for (size_t i = 0; i < nodes_.size(); ++i)
+            if (nodes_[i].vmixer) nodes_[i].vmixer->set_lazy_program(n_cons[i] == 1 && ok[i], tps);
+    }
     // time-parallel EqThree tables (unused in MX_FLAG_EQ_EXACT mode)
     {
         std::vector<EqScanTab> tabs(4);
@@ -735,11 +748,21 @@ void Graph::run_video_tick(uint64_t t) {
             if (pr.node < 0) break;
             const Node::VOut& v = nodes_[pr.node].vout[pr.port];
             if (!v.frame) break;
-            const DFrame* d = v.frame.f;
+            DFrame* d = v.frame.f;
             const int32_t stride = (int32_t)(((size_t)d->width * 4 + 15) & ~(size_t)15);
             const size_t need = (size_t)stride * d->height;
             if (n.rgba.bytes < need) { sync(); n.rgba.alloc(need); }
             mx_video_to_rgba_params p; std::memcpy(&p, n.params.data(), sizeof p);
+            if (d->lazy) {   // the composite only exists as a cross-fade chain: evaluate it straight into RGBA
+                ChainRgbaArgs c;
+                fill_chain_sources(*d->lazy, c.src, c.n_src, c.fade, c.v_is_a);
+                c.rgba = (uint8_t*)n.rgba.p; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
+                c.use_matrix = p.use_matrix;
+                for (int k = 0; k < 12; ++k) c.m[k] = p.matrix_q12[k];
+                launch_fade_chain_rgba(c, stream_);
+                n.rgba_w = d->width; n.rgba_h = d->height; n.rgba_stride = stride;
+                break;
+            }
             RgbaArgs a;
             a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = (uint8_t*)n.rgba.p;
             a.y_stride = d->stride[0]; a.u_stride = d->stride[1]; a.v_stride = d->stride[2]; a.rgba_stride = (uint32_t)stride;
@@ -764,7 +787,9 @@ void Graph::set_video_source(uint32_t node, DFrame* frame, Rational dur, Rationa
 FrameRef Graph::video_output(uint32_t node, uint32_t port) {
     if (node >= nodes_.size() || port >= nodes_[node].vout.size() || nodes_[node].out_type[port] != MX_VIDEO)
         throw Error(MX_ERR_INVALID, "not a video output terminal");
-    return nodes_[node].vout[port].frame;
+    FrameRef r = nodes_[node].vout[port].frame;
+    if (r) r->ensure_pixels(stream_);   // a frame crossing the ABI must have pixels
+    return r;
 }
 
 void Graph::rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h) {

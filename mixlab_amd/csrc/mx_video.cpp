@@ -34,14 +34,10 @@ bool Rational::operator>=(const Rational& o) const {
 // ---------------------------------------------------------------------------------------------
 // frames
 // ---------------------------------------------------------------------------------------------
-DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s) {
-    if (w == 0 || h == 0 || (w & 1) || (h & 1)) throw Error(MX_ERR_INVALID, "yuv420p frame size must be even and non-zero");
-    if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
-    std::unique_ptr<DFrame> f(new DFrame());
-    f->width = w; f->height = h;
+static void alloc_planes(DFrame* f) {
     size_t off[3], total = 0;
     for (int p = 0; p < 3; ++p) {
-        const uint32_t pw = p ? w >> 1 : w, ph = p ? h >> 1 : h;
+        const uint32_t pw = p ? f->width >> 1 : f->width, ph = p ? f->height >> 1 : f->height;
         f->stride[p] = (pw + 63u) & ~63u;               // rows 64-byte aligned (the reference asserts 32, video_mixer.rs:196-201)
         f->plane_bytes[p] = (size_t)f->stride[p] * ph;
         off[p] = total;
@@ -49,8 +45,70 @@ DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s) {
     }
     f->mem.alloc(total);
     for (int p = 0; p < 3; ++p) f->data[p] = (uint8_t*)f->mem.p + off[p];
+}
+
+DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s) {
+    if (w == 0 || h == 0 || (w & 1) || (h & 1)) throw Error(MX_ERR_INVALID, "yuv420p frame size must be even and non-zero");
+    if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
+    std::unique_ptr<DFrame> f(new DFrame());
+    f->width = w; f->height = h;
+    alloc_planes(f.get());
     launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s);
     return f.release();
+}
+
+DFrame* DFrame::create_lazy(uint32_t w, uint32_t h, std::shared_ptr<LazyChain> c) {
+    std::unique_ptr<DFrame> f(new DFrame());
+    f->width = w; f->height = h;
+    f->lazy = std::move(c);
+    return f.release();
+}
+
+void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], uint32_t& n_src,
+                        uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1]) {
+    auto put = [&](int k, const FrameRef& f) {
+        for (int p = 0; p < 3; ++p) { src[k].p[p] = f ? f->data[p] : nullptr; src[k].stride[p] = f ? f->stride[p] : 0; }
+    };
+    if (c.steps.size() + 1 > MX_CHAIN_MAX_SRC) throw Error(MX_ERR_INTERNAL, "cross-fade chain too long");
+    for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) put(k, FrameRef());
+    put(0, c.base);
+    n_src = 1 + (uint32_t)c.steps.size();
+    for (size_t k = 0; k < c.steps.size(); ++k) {
+        put((int)k + 1, c.steps[k].other);
+        fade[k] = c.steps[k].fade; v_is_a[k] = c.steps[k].v_is_a ? 1u : 0u;
+    }
+    for (size_t k = c.steps.size(); k < MX_CHAIN_MAX_SRC - 1; ++k) { fade[k] = 0; v_is_a[k] = 1; }
+}
+
+static void launch_chain_into(const LazyChain& c, DFrame* o, hipStream_t s) {
+    ChainArgs a;
+    fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a);
+    for (int p = 0; p < 3; ++p) {
+        a.out[p] = o->data[p]; a.out_stride[p] = o->stride[p];
+        a.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;     // fade_line's 32-byte blocks (video_mixer.rs:219-234)
+        a.chunks[p] = a.chunks_per_row[p] * o->ph(p);
+    }
+    launch_fade_chain(a, s);
+    hip_check(hipGetLastError(), "cross-fade launch");
+}
+
+void DFrame::ensure_pixels(hipStream_t s) {
+    if (!lazy) return;
+    alloc_planes(this);
+    launch_chain_into(*lazy, this, s);
+    lazy.reset();
+}
+
+// (a, b, fade) -> chain; a lazy operand's own chain is extended instead of being evaluated
+std::shared_ptr<LazyChain> make_chain(const FrameRef& a, const FrameRef& b, uint8_t fade, hipStream_t s) {
+    auto c = std::make_shared<LazyChain>();
+    if (a && a->lazy && b && b->lazy) b->ensure_pixels(s);                       // only one side may stay symbolic
+    if (a && a->lazy && a->lazy->steps.size() + 2 > MX_CHAIN_MAX_SRC) a->ensure_pixels(s);
+    if (b && b->lazy && b->lazy->steps.size() + 2 > MX_CHAIN_MAX_SRC) b->ensure_pixels(s);
+    if (a && a->lazy) { *c = *a->lazy; c->steps.push_back({b, fade, true}); }          // v (the running composite) is A
+    else if (b && b->lazy) { *c = *b->lazy; c->steps.push_back({a, fade, false}); }    // v is B
+    else { c->base = a; c->steps.push_back({b, fade, true}); }
+    return c;
 }
 
 // video_mixer.rs:276-297: max of each dimension, rounded UP to the chroma grid (yuv420p: even)
@@ -133,6 +191,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
 
 FrameRef Scaler::scale(const FrameRef& in) {
     if (in->width == out_w_ && in->height == out_h_) return in;                 // encode.rs:342-345
+    in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
     if (!frame_ || in_w_ != in->width || in_h_ != in->height) retarget(in->width, in->height);   // encode.rs:347-384
     if (geo_.scaled_w == 0 || geo_.scaled_h == 0) return frame_;
     ScaleArgs a;
@@ -207,6 +266,10 @@ void VideoMixer::run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, Fra
             c.has_stored = false; c.stored.frame = FrameRef();
             rescale(c, tw, th);
             FrameRef f(in[i].frame, true);                     // video.data.decoded.clone()
+            if (f->lazy) {   // a symbolic frame is only valid inside this tick: keep it symbolic only if it expires by the next one
+                const Rational life = in[i].tick_offset + in[i].duration_hint, one_tick = Rational::make(1, (int64_t)tps_);
+                if (!(one_tick >= life)) f->ensure_pixels(stream_);
+            }
             c.stored.frame = c.scaler->scale(f);
             c.stored.active_until = now + in[i].tick_offset + in[i].duration_hint;
             c.has_stored = true;
@@ -216,20 +279,16 @@ void VideoMixer::run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, Fra
     }
 
     // compose (:150-239); the blank fill (:151) is folded into the cross-fade kernel
-    FrameRef o = fresh_output(tw, th);
-    const DFrame* fa = (params_.a >= 0 && params_.a < 4 && ch_[params_.a].has_stored) ? ch_[params_.a].stored.frame.f : nullptr;
-    const DFrame* fb = (params_.b >= 0 && params_.b < 4 && ch_[params_.b].has_stored) ? ch_[params_.b].stored.frame.f : nullptr;
-    FadeArgs a;
-    a.fade = crossfade_factor(params_.fader);
-    for (int p = 0; p < 3; ++p) {
-        a.out[p] = o->data[p]; a.out_stride[p] = o->stride[p];
-        a.a[p] = fa ? fa->data[p] : nullptr; a.a_stride[p] = fa ? fa->stride[p] : 0;
-        a.b[p] = fb ? fb->data[p] : nullptr; a.b_stride[p] = fb ? fb->stride[p] : 0;
-        a.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;
-        a.chunks[p] = a.chunks_per_row[p] * o->ph(p);
+    FrameRef fa = (params_.a >= 0 && params_.a < 4 && ch_[params_.a].has_stored) ? ch_[params_.a].stored.frame : FrameRef();
+    FrameRef fb = (params_.b >= 0 && params_.b < 4 && ch_[params_.b].has_stored) ? ch_[params_.b].stored.frame : FrameRef();
+    std::shared_ptr<LazyChain> chain = make_chain(fa, fb, crossfade_factor(params_.fader), stream_);
+    FrameRef o;
+    if (lazy_program_) {
+        o = FrameRef(DFrame::create_lazy(tw, th, chain), false);   // pixels are computed by the consumer, fused with its own work
+    } else {
+        o = fresh_output(tw, th);
+        launch_chain_into(*chain, o.f, stream_);
     }
-    launch_crossfade(a, stream_);
-    hip_check(hipGetLastError(), "cross-fade launch");
     out = o;
 }
 

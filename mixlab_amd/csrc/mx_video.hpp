@@ -37,6 +37,28 @@ struct RgbaArgs {
 };
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s);
+
+// A chain of cross-fades evaluated per pixel in registers:  v = src[0];  for k >= 1:
+//   v = v_is_a[k-1] ? fade(v, src[k]) : fade(src[k], v)   with fade(a,b) = (a*f + b*(255-f)) / 255, f = fade[k-1]
+// -- each step truncates to u8 exactly like one VideoMixer (video_mixer.rs:211-235), so a cascade of
+// mixers collapses into ONE pass over the layers without changing a single bit.  src[k] planes may be
+// nullptr (the blank constant, video_mixer.rs:180-188).
+enum { MX_CHAIN_MAX_SRC = 8 };
+struct ChainSrc { const uint8_t* p[3]; uint32_t stride[3]; };
+struct ChainArgs {
+    ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t n_src;
+    uint32_t fade[MX_CHAIN_MAX_SRC - 1]; uint32_t v_is_a[MX_CHAIN_MAX_SRC - 1];
+    uint8_t* out[3]; uint32_t out_stride[3];
+    uint32_t chunks[3], chunks_per_row[3];
+};
+struct ChainRgbaArgs {   // the same chain feeding the build-specified YUV420P -> RGBA (+ matrix) directly: no YUV frame is written
+    ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t n_src;
+    uint32_t fade[MX_CHAIN_MAX_SRC - 1]; uint32_t v_is_a[MX_CHAIN_MAX_SRC - 1];
+    uint8_t* rgba; uint32_t rgba_stride, width, height;
+    int32_t use_matrix; int32_t m[12];
+};
+void launch_fade_chain(const ChainArgs& a, hipStream_t s);
+void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s);
 void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s);
 void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
@@ -53,8 +75,32 @@ struct Rational {
 // ---- device frame: the AvFrame<Video> stand-in (codec/src/ffmpeg/frame.rs) ----
 // Reference-counted like an AVFrame (frame.rs:351-361 clone = av_frame_clone): the VideoMixer keeps
 // inputs past the call by retaining them, never by copying pixels.
+struct DFrame;
+struct FrameRef {   // intrusive handle
+    DFrame* f = nullptr;
+    FrameRef() = default;
+    explicit FrameRef(DFrame* p, bool add_ref);
+    FrameRef(const FrameRef& o);
+    FrameRef(FrameRef&& o) noexcept : f(o.f) { o.f = nullptr; }
+    FrameRef& operator=(FrameRef o) noexcept { DFrame* t = f; f = o.f; o.f = t; return *this; }
+    ~FrameRef();
+    explicit operator bool() const { return f != nullptr; }
+    DFrame* operator->() const { return f; }
+};
+// A frame whose pixels have not been computed yet: the cross-fade chain that defines them.  Created
+// only for VideoMixer program outputs whose single consumer is another video node of the same graph
+// (decided at graph build), and always evaluated inside the tick that created it.
+struct LazyChain {
+    struct Step { FrameRef other; uint8_t fade; bool v_is_a; };
+    FrameRef base;                 // empty = blank
+    std::vector<Step> steps;
+};
+
 struct DFrame {
     std::atomic<int> rc{1};
+    std::shared_ptr<LazyChain> lazy;     // non-null => data[] are nullptr until ensure_pixels()
+    static DFrame* create_lazy(uint32_t w, uint32_t h, std::shared_ptr<LazyChain> c);
+    void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (even)
     uint8_t* data[3] = {nullptr, nullptr, nullptr};
     uint32_t stride[3] = {0, 0, 0};
@@ -66,17 +112,14 @@ struct DFrame {
     uint32_t pw(int p) const { return p ? width >> 1 : width; }
     uint32_t ph(int p) const { return p ? height >> 1 : height; }
 };
-struct FrameRef {   // intrusive handle
-    DFrame* f = nullptr;
-    FrameRef() = default;
-    explicit FrameRef(DFrame* p, bool add_ref) : f(p) { if (f && add_ref) f->retain(); }
-    FrameRef(const FrameRef& o) : f(o.f) { if (f) f->retain(); }
-    FrameRef(FrameRef&& o) noexcept : f(o.f) { o.f = nullptr; }
-    FrameRef& operator=(FrameRef o) noexcept { std::swap(f, o.f); return *this; }
-    ~FrameRef() { if (f) f->release(); }
-    explicit operator bool() const { return f != nullptr; }
-    DFrame* operator->() const { return f; }
-};
+inline FrameRef::FrameRef(DFrame* p, bool add_ref) : f(p) { if (f && add_ref) f->retain(); }
+inline FrameRef::FrameRef(const FrameRef& o) : f(o.f) { if (f) f->retain(); }
+inline FrameRef::~FrameRef() { if (f) f->release(); }
+
+// flatten (a, b, fade) into a chain: extends a's (or b's) chain when that side is lazy
+std::shared_ptr<LazyChain> make_chain(const FrameRef& a, const FrameRef& b, uint8_t fade, hipStream_t s);
+void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], uint32_t& n_src,
+                        uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1]);
 
 struct ScaleGeometry { uint32_t scaled_w, scaled_h, letterbox_x, letterbox_y; };
 ScaleGeometry scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h);   // encode.rs:354-374
@@ -110,6 +153,8 @@ class VideoMixer {
 public:
     VideoMixer(const mx_video_mixer_params& p, uint32_t sample_rate, hipStream_t s);
     void update(const mx_video_mixer_params& p) { params_ = p; }   // video_mixer.rs:65-68
+    // program output as an unevaluated chain (graph compiler: single in-graph video consumer)
+    void set_lazy_program(bool on, uint32_t ticks_per_second) { lazy_program_ = on; tps_ = ticks_per_second ? ticks_per_second : 60; }
     // returns program / A / B frames (null FrameRef = None)
     void run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, FrameRef& out_a, FrameRef& out_b);
     hipStream_t stream() const { return stream_; }
@@ -121,6 +166,8 @@ private:
     uint32_t sample_rate_;
     hipStream_t stream_;
     bool own_stream_ = false;
+    bool lazy_program_ = false;
+    uint32_t tps_ = 60;
     Channel ch_[4];
     // output frames are fresh each tick in the reference; here a small ring recycles them once the
     // caller has dropped its references
