@@ -218,11 +218,76 @@ __global__ __launch_bounds__(256) void k_scale_bicubic(ScaleArgs a) {
     const int v = (acc + (1 << 20)) >> 21;
     p.dst[(size_t)y * p.dst_stride + x] = (uint8_t)min(max(v, 0), 255);
 }
+// Tiled two-pass version of the same arithmetic (bit-identical): a 256-thread block produces a
+// 64 x 16 output tile.  The clamped source window (<= SC_NR x SC_NC bytes) is staged in LDS once,
+// the H pass filters each needed source row exactly once per output column (NR/16 * 4 MACs per
+// output pixel instead of 16), the V pass reads four H-filtered rows per pixel from LDS as
+// ds_read_b128 and stores one dword of 4 pixels.  Used when the window fits (scale ratio <= 2).
+#define SC_NR 40
+#define SC_NC 136
+__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleArgs a) {
+    const int plane = blockIdx.z;
+    const ScalePlane p = a.p[plane];
+    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 16;
+    if (ox0 >= (int)p.dw || oy0 >= (int)p.dh) return;   // block-uniform
+    __shared__ uint8_t S[SC_NR][SC_NC];
+    __shared__ __attribute__((aligned(16))) int T[SC_NR][64];
+    const int tid = threadIdx.x;
+    const int oxl = min(ox0 + 63, (int)p.dw - 1), oyl = min(oy0 + 15, (int)p.dh - 1);
+    const int cx0 = p.hfirst[ox0], nc = p.hfirst[oxl] + 4 - cx0;   // tap tables are monotone
+    const int ry0 = p.vfirst[oy0], nr = p.vfirst[oyl] + 4 - ry0;
+    const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
+    for (int r = tid >> 7; r < nr; r += 2) {
+        const uint8_t* row = p.src + (size_t)min(max(ry0 + r, 0), sh1) * p.src_stride;
+        for (int c = tid & 127; c < nc; c += 128) S[r][c] = row[min(max(cx0 + c, 0), sw1)];   // edge replication happens here
+    }
+    __syncthreads();
+    {   // H pass: t = (sum hc * S + 64) >> 7
+        const int oxi = tid & 63, ox = ox0 + oxi;
+        if (ox < (int)p.dw) {
+            const int4 hc = reinterpret_cast<const int4*>(p.hcoef)[ox];
+            const int hf = p.hfirst[ox] - cx0;
+            for (int r = tid >> 6; r < nr; r += 4) {
+                const int acc = hc.x * (int)S[r][hf] + hc.y * (int)S[r][hf + 1] + hc.z * (int)S[r][hf + 2] + hc.w * (int)S[r][hf + 3];
+                T[r][oxi] = (acc + 64) >> 7;
+            }
+        }
+    }
+    __syncthreads();
+    {   // V pass: D = clip8((sum vc * t + 2^20) >> 21), four pixels per lane
+        const int oy = oy0 + (tid >> 4), oxg = (tid & 15) * 4;
+        if (oy < (int)p.dh && ox0 + oxg < (int)p.dw) {
+            const int4 vc = reinterpret_cast<const int4*>(p.vcoef)[oy];
+            const int vf = p.vfirst[oy] - ry0;
+            const int4 t0 = *reinterpret_cast<const int4*>(&T[vf][oxg]), t1 = *reinterpret_cast<const int4*>(&T[vf + 1][oxg]);
+            const int4 t2 = *reinterpret_cast<const int4*>(&T[vf + 2][oxg]), t3 = *reinterpret_cast<const int4*>(&T[vf + 3][oxg]);
+            const int v0 = min(max((vc.x * t0.x + vc.y * t1.x + vc.z * t2.x + vc.w * t3.x + (1 << 20)) >> 21, 0), 255);
+            const int v1 = min(max((vc.x * t0.y + vc.y * t1.y + vc.z * t2.y + vc.w * t3.y + (1 << 20)) >> 21, 0), 255);
+            const int v2 = min(max((vc.x * t0.z + vc.y * t1.z + vc.z * t2.z + vc.w * t3.z + (1 << 20)) >> 21, 0), 255);
+            const int v3 = min(max((vc.x * t0.w + vc.y * t1.w + vc.z * t2.w + vc.w * t3.w + (1 << 20)) >> 21, 0), 255);
+            uint8_t* o = p.dst + (size_t)oy * p.dst_stride + ox0 + oxg;
+            if (ox0 + oxg + 4 <= (int)p.dw && (((uintptr_t)o) & 3) == 0) {
+                *reinterpret_cast<uint32_t*>(o) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+            } else {
+                const int vv[4] = {v0, v1, v2, v3};
+                for (int k = 0; k < 4 && ox0 + oxg + k < (int)p.dw; ++k) o[k] = (uint8_t)vv[k];
+            }
+        }
+    }
+}
+
 void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s) {
     uint32_t mw = 0, mh = 0;
-    for (int i = 0; i < 3; ++i) { mw = a.p[i].dw > mw ? a.p[i].dw : mw; mh = a.p[i].dh > mh ? a.p[i].dh : mh; }
+    bool tiled = true;
+    for (int i = 0; i < 3; ++i) {
+        mw = a.p[i].dw > mw ? a.p[i].dw : mw; mh = a.p[i].dh > mh ? a.p[i].dh : mh;
+        // window of a 64 x 16 tile: 64 * sw/dw + 5 columns, 16 * sh/dh + 5 rows (the +5 covers tap reach and rounding)
+        if (a.p[i].dw && ((uint64_t)64 * a.p[i].sw / a.p[i].dw + 5 > SC_NC || (uint64_t)16 * a.p[i].sh / a.p[i].dh + 5 > SC_NR)) tiled = false;
+    }
     if (!mw || !mh) return;
-    hipLaunchKernelGGL(k_scale_bicubic, dim3((mw + 63) / 64, (mh + 3) / 4, 3), dim3(256), 0, s, a);
+    static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
+    if (tiled && !force_simple) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3((mw + 63) / 64, (mh + 15) / 16, 3), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_scale_bicubic, dim3((mw + 63) / 64, (mh + 3) / 4, 3), dim3(256), 0, s, a);
 }
 
 // plane copy (identity "scale" into a differently-strided frame, and frame clones)
