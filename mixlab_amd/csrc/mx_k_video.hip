@@ -60,15 +60,50 @@ void launch_crossfade(const FadeArgs& a, hipStream_t s) {
 // registers, one dwordx4 store.  algorithmic bytes per output frame: (n_src + 1) F instead of 3 F per
 // mixer (8 layers: 9 F = 28 MB instead of 65 MB).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 fade16(uint4 a, uint4 b, uint32_t fa) {
-    const uint32_t fb = 255u - fa;
-    uint4 o;
-    o.x = fade4(a.x, b.x, fa, fb); o.y = fade4(a.y, b.y, fa, fb); o.z = fade4(a.z, b.z, fa, fb); o.w = fade4(a.w, b.w, fa, fb);
-    return o;
+// Packed arithmetic: the reference's u16 lanes (packed_simd u16x32, video_mixer.rs:215-227) map onto
+// v_pk_mul_lo_u16 / v_pk_add_u16: two pixels per VALU op.  A dword of 4 pixels is split into its even
+// and odd bytes (two u16x2), and the running composite stays in that form across all steps of a chain.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+struct Px4 { u16x2 e, o; };   // bytes 0,2 and bytes 1,3 of a dword, each widened to u16
+__device__ __forceinline__ Px4 px4_unpack(uint32_t w) {
+    Px4 r;
+    r.e = __builtin_bit_cast(u16x2, w & 0x00ff00ffu);
+    r.o = __builtin_bit_cast(u16x2, (w >> 8) & 0x00ff00ffu);
+    return r;
 }
-__device__ __forceinline__ uint2 fade8(uint2 a, uint2 b, uint32_t fa) {
-    const uint32_t fb = 255u - fa;
-    return make_uint2(fade4(a.x, b.x, fa, fb), fade4(a.y, b.y, fa, fb));
+__device__ __forceinline__ uint32_t px4_pack(Px4 v) {
+    return __builtin_bit_cast(uint32_t, v.e) | (__builtin_bit_cast(uint32_t, v.o) << 8);
+}
+__device__ __forceinline__ u16x2 fade_pk(u16x2 a, u16x2 b, u16x2 fa, u16x2 fb) {
+    const u16x2 x = a * fa + b * fb;                          // <= 255 * 255: no u16 overflow, as in the reference
+    const u16x2 one = {1, 1};
+    return (u16x2)((x + one + (x >> 8)) >> 8);              // x / 255 for x <= 65534; the sum stays below 65536
+}
+__device__ __forceinline__ Px4 fade_px4(Px4 a, Px4 b, u16x2 fa, u16x2 fb) {
+    Px4 r; r.e = fade_pk(a.e, b.e, fa, fb); r.o = fade_pk(a.o, b.o, fa, fb); return r;
+}
+
+template <int NW>   // NW dwords per lane and plane
+__device__ __forceinline__ void chain_eval(uint32_t (&v)[NW], const uint32_t (*L)[NW], uint32_t n_src,
+                                           const uint32_t* fade, const uint32_t* v_is_a) {
+    Px4 acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = px4_unpack(L[0][w]);
+#pragma unroll
+    for (int k = 1; k < MX_CHAIN_MAX_SRC; ++k) {
+        if (k < (int)n_src) {
+            const unsigned short f = (unsigned short)fade[k - 1], g = (unsigned short)(255u - fade[k - 1]);
+            const u16x2 fa = {f, f}, fb = {g, g};
+            const bool va = v_is_a[k - 1] != 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const Px4 o = px4_unpack(L[k][w]);
+                acc[w] = va ? fade_px4(acc[w], o, fa, fb) : fade_px4(o, acc[w], fa, fb);
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = px4_pack(acc[w]);
 }
 
 __global__ __launch_bounds__(256) void k_fade_chain(ChainArgs args) {
@@ -79,18 +114,17 @@ __global__ __launch_bounds__(256) void k_fade_chain(ChainArgs args) {
     const uint32_t cpr = args.chunks_per_row[plane];
     const uint32_t row = idx / cpr, col = (idx - row * cpr) * 16u;
     const uint32_t blank = plane ? 0x80808080u : 0u;
-    uint4 L[MX_CHAIN_MAX_SRC];
+    uint32_t L[MX_CHAIN_MAX_SRC][4];
 #pragma unroll
     for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
-        L[k] = make_uint4(blank, blank, blank, blank);
+        uint4 t = make_uint4(blank, blank, blank, blank);
         if (k < (int)args.n_src && args.src[k].p[plane])
-            L[k] = *reinterpret_cast<const uint4*>(args.src[k].p[plane] + (size_t)row * args.src[k].stride[plane] + col);
+            t = *reinterpret_cast<const uint4*>(args.src[k].p[plane] + (size_t)row * args.src[k].stride[plane] + col);
+        L[k][0] = t.x; L[k][1] = t.y; L[k][2] = t.z; L[k][3] = t.w;
     }
-    uint4 v = L[0];
-#pragma unroll
-    for (int k = 1; k < MX_CHAIN_MAX_SRC; ++k)
-        if (k < (int)args.n_src) v = args.v_is_a[k - 1] ? fade16(v, L[k], args.fade[k - 1]) : fade16(L[k], v, args.fade[k - 1]);
-    *reinterpret_cast<uint4*>(args.out[plane] + (size_t)row * args.out_stride[plane] + col) = v;
+    uint32_t v[4];
+    chain_eval<4>(v, L, args.n_src, args.fade, args.v_is_a);
+    *reinterpret_cast<uint4*>(args.out[plane] + (size_t)row * args.out_stride[plane] + col) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 void launch_fade_chain(const ChainArgs& a, hipStream_t s) {
     const uint32_t total = a.chunks[0] + a.chunks[1] + a.chunks[2];
@@ -117,50 +151,41 @@ __device__ __forceinline__ uint32_t yuv_px(const ChainRgbaArgs& a, int Y, int U,
 }
 
 __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
-    const uint32_t xb = blockIdx.x * 64 + (threadIdx.x & 63);     // 16-pixel column block
+    const uint32_t xb = blockIdx.x * 64 + (threadIdx.x & 63);     // 8-pixel column block
     const uint32_t yb = blockIdx.y * 4 + (threadIdx.x >> 6);       // row pair
-    if (xb * 16 >= a.width || yb * 2 >= a.height) return;
-    const uint4 by = make_uint4(0, 0, 0, 0);
-    const uint2 bc = make_uint2(0x80808080u, 0x80808080u);
-    uint4 Y0[MX_CHAIN_MAX_SRC], Y1[MX_CHAIN_MAX_SRC]; uint2 U[MX_CHAIN_MAX_SRC], V[MX_CHAIN_MAX_SRC];
+    if (xb * 8 >= a.width || yb * 2 >= a.height) return;
+    // per source: 2 dwords of Y for each of the two rows, one dword of U, one of V  (6 dwords)
+    uint32_t L[MX_CHAIN_MAX_SRC][6];
 #pragma unroll
     for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
-        Y0[k] = by; Y1[k] = by; U[k] = bc; V[k] = bc;
+        L[k][0] = L[k][1] = L[k][2] = L[k][3] = 0u; L[k][4] = L[k][5] = 0x80808080u;
         if (k < (int)a.n_src) {
             const ChainSrc& s = a.src[k];
             if (s.p[0]) {
-                Y0[k] = *reinterpret_cast<const uint4*>(s.p[0] + (size_t)(2 * yb) * s.stride[0] + xb * 16);
-                Y1[k] = *reinterpret_cast<const uint4*>(s.p[0] + (size_t)(2 * yb + 1) * s.stride[0] + xb * 16);
+                const uint2 r0 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)(2 * yb) * s.stride[0] + xb * 8);
+                const uint2 r1 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)(2 * yb + 1) * s.stride[0] + xb * 8);
+                L[k][0] = r0.x; L[k][1] = r0.y; L[k][2] = r1.x; L[k][3] = r1.y;
             }
-            if (s.p[1]) U[k] = *reinterpret_cast<const uint2*>(s.p[1] + (size_t)yb * s.stride[1] + xb * 8);
-            if (s.p[2]) V[k] = *reinterpret_cast<const uint2*>(s.p[2] + (size_t)yb * s.stride[2] + xb * 8);
+            if (s.p[1]) L[k][4] = *reinterpret_cast<const uint32_t*>(s.p[1] + (size_t)yb * s.stride[1] + xb * 4);
+            if (s.p[2]) L[k][5] = *reinterpret_cast<const uint32_t*>(s.p[2] + (size_t)yb * s.stride[2] + xb * 4);
         }
     }
-    uint4 y0 = Y0[0], y1 = Y1[0]; uint2 u = U[0], v = V[0];
-#pragma unroll
-    for (int k = 1; k < MX_CHAIN_MAX_SRC; ++k) {
-        if (k < (int)a.n_src) {
-            const uint32_t f = a.fade[k - 1];
-            if (a.v_is_a[k - 1]) { y0 = fade16(y0, Y0[k], f); y1 = fade16(y1, Y1[k], f); u = fade8(u, U[k], f); v = fade8(v, V[k], f); }
-            else { y0 = fade16(Y0[k], y0, f); y1 = fade16(Y1[k], y1, f); u = fade8(U[k], u, f); v = fade8(V[k], v, f); }
-        }
-    }
-    const uint32_t yw0[4] = {y0.x, y0.y, y0.z, y0.w}, yw1[4] = {y1.x, y1.y, y1.z, y1.w};
-    const uint32_t uw[2] = {u.x, u.y}, vw[2] = {v.x, v.y};
+    uint32_t v[6];
+    chain_eval<6>(v, L, a.n_src, a.fade, a.v_is_a);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t yrow = 2 * yb + r;
         if (yrow >= a.height) break;
-        uint8_t* o = a.rgba + (size_t)yrow * a.rgba_stride + (size_t)xb * 64;
+        uint8_t* o = a.rgba + (size_t)yrow * a.rgba_stride + (size_t)xb * 32;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {       // 4 groups of 4 pixels
-            const uint32_t yw = r ? yw1[g4] : yw0[g4];
-            const uint32_t cu = (uw[g4 >> 1] >> (16 * (g4 & 1))) & 0xffffu, cv = (vw[g4 >> 1] >> (16 * (g4 & 1))) & 0xffffu;
+        for (int g4 = 0; g4 < 2; ++g4) {       // 2 groups of 4 pixels
+            const uint32_t yw = v[2 * r + g4];
+            const uint32_t cu = (v[4] >> (16 * g4)) & 0xffffu, cv = (v[5] >> (16 * g4)) & 0xffffu;
             uint32_t px[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 px[k] = yuv_px(a, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
-            const uint32_t x = xb * 16 + g4 * 4;
+            const uint32_t x = xb * 8 + g4 * 4;
             if (x + 4 <= a.width) *reinterpret_cast<uint4*>(o + g4 * 16) = make_uint4(px[0], px[1], px[2], px[3]);
             else for (uint32_t k = 0; x + k < a.width; ++k) reinterpret_cast<uint32_t*>(o + g4 * 16)[k] = px[k];
         }
@@ -168,7 +193,7 @@ __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
 }
 void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s) {
     if (!a.width || !a.height) return;
-    hipLaunchKernelGGL(k_fade_chain_rgba, dim3(((a.width + 15) / 16 + 63) / 64, ((a.height + 1) / 2 + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_fade_chain_rgba, dim3(((a.width + 7) / 8 + 63) / 64, ((a.height + 1) / 2 + 3) / 4), dim3(256), 0, s, a);
 }
 
 // Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
