@@ -50,7 +50,11 @@ static hipStream_t default_video_stream() {
     std::call_once(once, [] { mx::hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); });
     return s;
 }
-static hipStream_t S(void* stream) { return stream ? (hipStream_t)stream : default_video_stream(); }
+static hipStream_t S(void* stream) {
+    hipStream_t s = stream ? (hipStream_t)stream : default_video_stream();
+    mx::flush_scales(s);   // every stateless entry point starts from a stream with no deferred scaler work
+    return s;
+}
 
 extern "C" {
 
@@ -218,6 +222,7 @@ int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input 
         }
         FrameRef o, a, b;
         m->m->run_tick(t, in, o, a, b);
+        mx::flush_scales(m->m->stream());
         auto give = [](FrameRef& r, mx_dframe** dst) {
             if (!dst) return;
             *dst = nullptr;
@@ -227,7 +232,7 @@ int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input 
     });
 }
 int mx_video_mixer_sync(mx_video_mixer* m) {
-    return guard([&] { REQUIRE(m, "mixer is NULL"); mx::hip_check(hipStreamSynchronize(m->m->stream()), "hipStreamSynchronize"); });
+    return guard([&] { REQUIRE(m, "mixer is NULL"); mx::flush_scales(m->m->stream()); mx::hip_check(hipStreamSynchronize(m->m->stream()), "hipStreamSynchronize"); });
 }
 void mx_video_mixer_destroy(mx_video_mixer* m) {
     (void)guard([&] { delete m; });

@@ -238,6 +238,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
 }
 
 Graph::~Graph() {
+    flush_scales(stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); }
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
@@ -551,7 +552,7 @@ void Graph::set_input_enabled(uint32_t node, uint32_t port, bool enabled) {
     if (n.group >= 0) upload_group(groups_[n.group]);
 }
 
-void Graph::sync() { hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+void Graph::sync() { flush_scales(stream_); hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
 
 void Graph::ensure_capacity(size_t frames) {
     if (frames <= cap_frames_) return;
@@ -639,7 +640,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         ++gi;
     }
     // video sub-graph: tick by tick (frames arrive per tick; nothing to batch over time)
-    if (has_video_) for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc);
+    if (has_video_) { for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc); flush_scales(stream_); }
     if (prof) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
     hip_check(hipGetLastError(), "kernel launch");
     last_calls_ = n_calls;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_crossfade(FadeArgs args) {
 }
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s) {
+    flush_scales(s);
     const uint32_t total = a.chunks[0] + a.chunks[1] + a.chunks[2];
     if (!total) return;
     hipLaunchKernelGGL(k_crossfade, dim3((total + 255) / 256), dim3(256), 0, s, a);
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void k_fade_chain(ChainArgs args) {
     *reinterpret_cast<uint4*>(args.out[plane] + (size_t)row * args.out_stride[plane] + col) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 void launch_fade_chain(const ChainArgs& a, hipStream_t s) {
+    flush_scales(s);   // queued scaler output may be among the layers
     const uint32_t total = a.chunks[0] + a.chunks[1] + a.chunks[2];
     if (!total) return;
     hipLaunchKernelGGL(k_fade_chain, dim3((total + 255) / 256), dim3(256), 0, s, a);
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
     }
 }
 void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s) {
+    flush_scales(s);
     if (!a.width || !a.height) return;
     hipLaunchKernelGGL(k_fade_chain_rgba, dim3(((a.width + 7) / 8 + 63) / 64, ((a.height + 1) / 2 + 3) / 4), dim3(256), 0, s, a);
 }
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(256) void k_blank(uint8_t* y, size_t y_bytes, uint8
     }
 }
 void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s) {
+    flush_scales(s);
     const size_t q = (yb + ub + vb) / 16;
     if (!q) return;
     hipLaunchKernelGGL(k_blank, dim3(grid_x(q, 256, 2048)), dim3(256), 0, s, y, yb, u, ub, v, vb);
@@ -220,9 +224,65 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 // One lane per output pixel; the 4x4 source neighbourhood is served by L1/L2 (neighbouring lanes
 // share 3 of 4 columns).  All three planes in one launch.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scale_bicubic(ScaleArgs a) {
+// Tiled two-pass version of the same arithmetic (bit-identical): a 256-thread block produces a
+// 64 x 16 output tile.  The clamped source window (<= SC_NR x SC_NC bytes) is staged in LDS once,
+// the H pass filters each needed source row exactly once per output column (NR/16 * 4 MACs per
+// output pixel instead of 16), the V pass reads four H-filtered rows per pixel from LDS as
+// ds_read_b128 and stores one dword of 4 pixels.  Used when the window fits (scale ratio <= 2).
+#define SC_NR 40
+#define SC_NC 136
+__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     const int plane = blockIdx.z;
     const ScalePlane p = a.p[plane];
+    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 16;
+    if (ox0 >= (int)p.dw || oy0 >= (int)p.dh) return;   // block-uniform
+    __shared__ uint8_t S[SC_NR][SC_NC];
+    __shared__ __attribute__((aligned(16))) int T[SC_NR][64];
+    const int tid = threadIdx.x;
+    const int oxl = min(ox0 + 63, (int)p.dw - 1), oyl = min(oy0 + 15, (int)p.dh - 1);
+    // every table entry this lane will need, fetched in one burst (one memory round trip, not four)
+    const int oxi = tid & 63, ox = min(ox0 + oxi, (int)p.dw - 1);
+    const int oy = min(oy0 + (tid >> 4), (int)p.dh - 1), oxg = (tid & 15) * 4;
+    const int cx0 = p.hfirst[ox0], cxl = p.hfirst[oxl];   // tap tables are monotone
+    const int ry0 = p.vfirst[oy0], ryl = p.vfirst[oyl];
+    const int4 hc = reinterpret_cast<const int4*>(p.hcoef)[ox];
+    const int hf = p.hfirst[ox] - cx0;
+    const int4 vc = reinterpret_cast<const int4*>(p.vcoef)[oy];
+    const int vf = p.vfirst[oy] - ry0;
+    const int nc = cxl + 4 - cx0, nr = ryl + 4 - ry0;
+    const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
+    for (int r = tid >> 7; r < nr; r += 2) {
+        const uint8_t* row = p.src + (size_t)min(max(ry0 + r, 0), sh1) * p.src_stride;
+        for (int c = tid & 127; c < nc; c += 128) S[r][c] = row[min(max(cx0 + c, 0), sw1)];   // edge replication happens here
+    }
+    __syncthreads();
+    if (ox0 + oxi < (int)p.dw) {   // H pass: t = (sum hc * S + 64) >> 7
+        for (int r = tid >> 6; r < nr; r += 4) {
+            const int acc = hc.x * (int)S[r][hf] + hc.y * (int)S[r][hf + 1] + hc.z * (int)S[r][hf + 2] + hc.w * (int)S[r][hf + 3];
+            T[r][oxi] = (acc + 64) >> 7;
+        }
+    }
+    __syncthreads();
+    // V pass: D = clip8((sum vc * t + 2^20) >> 21), four pixels per lane
+    if (oy0 + (tid >> 4) < (int)p.dh && ox0 + oxg < (int)p.dw) {
+        const int4 t0 = *reinterpret_cast<const int4*>(&T[vf][oxg]), t1 = *reinterpret_cast<const int4*>(&T[vf + 1][oxg]);
+        const int4 t2 = *reinterpret_cast<const int4*>(&T[vf + 2][oxg]), t3 = *reinterpret_cast<const int4*>(&T[vf + 3][oxg]);
+        const int v0 = min(max((vc.x * t0.x + vc.y * t1.x + vc.z * t2.x + vc.w * t3.x + (1 << 20)) >> 21, 0), 255);
+        const int v1 = min(max((vc.x * t0.y + vc.y * t1.y + vc.z * t2.y + vc.w * t3.y + (1 << 20)) >> 21, 0), 255);
+        const int v2 = min(max((vc.x * t0.z + vc.y * t1.z + vc.z * t2.z + vc.w * t3.z + (1 << 20)) >> 21, 0), 255);
+        const int v3 = min(max((vc.x * t0.w + vc.y * t1.w + vc.z * t2.w + vc.w * t3.w + (1 << 20)) >> 21, 0), 255);
+        uint8_t* o = p.dst + (size_t)oy * p.dst_stride + ox0 + oxg;
+        if (ox0 + oxg + 4 <= (int)p.dw && (((uintptr_t)o) & 3) == 0) {
+            *reinterpret_cast<uint32_t*>(o) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+        } else {
+            const int vv[4] = {v0, v1, v2, v3};
+            for (int k = 0; k < 4 && ox0 + oxg + k < (int)p.dw; ++k) o[k] = (uint8_t)vv[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {   // simple gather form, any ratio
+    const ScalePlane p = a.p[blockIdx.z];
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= p.dw || y >= p.dh) return;
@@ -234,85 +294,33 @@ __global__ __launch_bounds__(256) void k_scale_bicubic(ScaleArgs a) {
     int t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int yy = min(max(vf + k, 0), sh1);
-        const uint8_t* row = p.src + (size_t)yy * p.src_stride;
-        const int acc = hc.x * (int)row[x0] + hc.y * (int)row[x1] + hc.z * (int)row[x2] + hc.w * (int)row[x3];
-        t[k] = (acc + 64) >> 7;
+        const uint8_t* row = p.src + (size_t)min(max(vf + k, 0), sh1) * p.src_stride;
+        t[k] = (hc.x * (int)row[x0] + hc.y * (int)row[x1] + hc.z * (int)row[x2] + hc.w * (int)row[x3] + 64) >> 7;
     }
-    const int acc = vc.x * t[0] + vc.y * t[1] + vc.z * t[2] + vc.w * t[3];
-    const int v = (acc + (1 << 20)) >> 21;
+    const int v = (vc.x * t[0] + vc.y * t[1] + vc.z * t[2] + vc.w * t[3] + (1 << 20)) >> 21;
     p.dst[(size_t)y * p.dst_stride + x] = (uint8_t)min(max(v, 0), 255);
 }
-// Tiled two-pass version of the same arithmetic (bit-identical): a 256-thread block produces a
-// 64 x 16 output tile.  The clamped source window (<= SC_NR x SC_NC bytes) is staged in LDS once,
-// the H pass filters each needed source row exactly once per output column (NR/16 * 4 MACs per
-// output pixel instead of 16), the V pass reads four H-filtered rows per pixel from LDS as
-// ds_read_b128 and stores one dword of 4 pixels.  Used when the window fits (scale ratio <= 2).
-#define SC_NR 40
-#define SC_NC 136
-__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleArgs a) {
-    const int plane = blockIdx.z;
-    const ScalePlane p = a.p[plane];
-    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 16;
-    if (ox0 >= (int)p.dw || oy0 >= (int)p.dh) return;   // block-uniform
-    __shared__ uint8_t S[SC_NR][SC_NC];
-    __shared__ __attribute__((aligned(16))) int T[SC_NR][64];
-    const int tid = threadIdx.x;
-    const int oxl = min(ox0 + 63, (int)p.dw - 1), oyl = min(oy0 + 15, (int)p.dh - 1);
-    const int cx0 = p.hfirst[ox0], nc = p.hfirst[oxl] + 4 - cx0;   // tap tables are monotone
-    const int ry0 = p.vfirst[oy0], nr = p.vfirst[oyl] + 4 - ry0;
-    const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
-    for (int r = tid >> 7; r < nr; r += 2) {
-        const uint8_t* row = p.src + (size_t)min(max(ry0 + r, 0), sh1) * p.src_stride;
-        for (int c = tid & 127; c < nc; c += 128) S[r][c] = row[min(max(cx0 + c, 0), sw1)];   // edge replication happens here
-    }
-    __syncthreads();
-    {   // H pass: t = (sum hc * S + 64) >> 7
-        const int oxi = tid & 63, ox = ox0 + oxi;
-        if (ox < (int)p.dw) {
-            const int4 hc = reinterpret_cast<const int4*>(p.hcoef)[ox];
-            const int hf = p.hfirst[ox] - cx0;
-            for (int r = tid >> 6; r < nr; r += 4) {
-                const int acc = hc.x * (int)S[r][hf] + hc.y * (int)S[r][hf + 1] + hc.z * (int)S[r][hf + 2] + hc.w * (int)S[r][hf + 3];
-                T[r][oxi] = (acc + 64) >> 7;
-            }
-        }
-    }
-    __syncthreads();
-    {   // V pass: D = clip8((sum vc * t + 2^20) >> 21), four pixels per lane
-        const int oy = oy0 + (tid >> 4), oxg = (tid & 15) * 4;
-        if (oy < (int)p.dh && ox0 + oxg < (int)p.dw) {
-            const int4 vc = reinterpret_cast<const int4*>(p.vcoef)[oy];
-            const int vf = p.vfirst[oy] - ry0;
-            const int4 t0 = *reinterpret_cast<const int4*>(&T[vf][oxg]), t1 = *reinterpret_cast<const int4*>(&T[vf + 1][oxg]);
-            const int4 t2 = *reinterpret_cast<const int4*>(&T[vf + 2][oxg]), t3 = *reinterpret_cast<const int4*>(&T[vf + 3][oxg]);
-            const int v0 = min(max((vc.x * t0.x + vc.y * t1.x + vc.z * t2.x + vc.w * t3.x + (1 << 20)) >> 21, 0), 255);
-            const int v1 = min(max((vc.x * t0.y + vc.y * t1.y + vc.z * t2.y + vc.w * t3.y + (1 << 20)) >> 21, 0), 255);
-            const int v2 = min(max((vc.x * t0.z + vc.y * t1.z + vc.z * t2.z + vc.w * t3.z + (1 << 20)) >> 21, 0), 255);
-            const int v3 = min(max((vc.x * t0.w + vc.y * t1.w + vc.z * t2.w + vc.w * t3.w + (1 << 20)) >> 21, 0), 255);
-            uint8_t* o = p.dst + (size_t)oy * p.dst_stride + ox0 + oxg;
-            if (ox0 + oxg + 4 <= (int)p.dw && (((uintptr_t)o) & 3) == 0) {
-                *reinterpret_cast<uint32_t*>(o) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-            } else {
-                const int vv[4] = {v0, v1, v2, v3};
-                for (int k = 0; k < 4 && ox0 + oxg + k < (int)p.dw; ++k) o[k] = (uint8_t)vv[k];
-            }
-        }
-    }
-}
 
-void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s) {
+// All planes of all queued scale jobs of a stream go out as ONE launch (grid.z = plane): these
+// kernels are latency-bound, so N jobs cost about as much as one.
+void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
     uint32_t mw = 0, mh = 0;
     bool tiled = true;
-    for (int i = 0; i < 3; ++i) {
+    for (uint32_t i = 0; i < a.n; ++i) {
         mw = a.p[i].dw > mw ? a.p[i].dw : mw; mh = a.p[i].dh > mh ? a.p[i].dh : mh;
         // window of a 64 x 16 tile: 64 * sw/dw + 5 columns, 16 * sh/dh + 5 rows (the +5 covers tap reach and rounding)
         if (a.p[i].dw && ((uint64_t)64 * a.p[i].sw / a.p[i].dw + 5 > SC_NC || (uint64_t)16 * a.p[i].sh / a.p[i].dh + 5 > SC_NR)) tiled = false;
     }
-    if (!mw || !mh) return;
+    if (!a.n || !mw || !mh) return;
     static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
-    if (tiled && !force_simple) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3((mw + 63) / 64, (mh + 15) / 16, 3), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_scale_bicubic, dim3((mw + 63) / 64, (mh + 3) / 4, 3), dim3(256), 0, s, a);
+    if (tiled && !force_simple) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3((mw + 63) / 64, (mh + 15) / 16, a.n), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
+}
+void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s) {
+    ScaleBatchArgs b;
+    b.n = 3;
+    for (int i = 0; i < 3; ++i) b.p[i] = a.p[i];
+    launch_scale_batch(b, s);
 }
 
 // plane copy (identity "scale" into a differently-strided frame, and frame clones)
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(256) void k_copy_planes(CopyArgs a) {
             reinterpret_cast<const uint4*>(a.src[plane] + (size_t)row * a.src_stride[plane])[c];
 }
 void launch_copy_planes(const CopyArgs& a, hipStream_t s) {
+    flush_scales(s);
     uint32_t mr = a.rows[0] > a.rows[1] ? a.rows[0] : a.rows[1];
     uint32_t mb = a.row_bytes[0];
     if (!mr || !mb) return;
@@ -369,6 +378,7 @@ __global__ __launch_bounds__(256) void k_yuv420_to_rgba(RgbaArgs a) {
     else for (uint32_t k = 0; xq * 4 + k < a.width; ++k) reinterpret_cast<uint32_t*>(o)[k] = px[k];
 }
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s) {
+    flush_scales(s);
     if (!a.width || !a.height) return;
     hipLaunchKernelGGL(k_yuv420_to_rgba, dim3(((a.width + 3) / 4 + 63) / 64, (a.height + 3) / 4), dim3(256), 0, s, a);
 }

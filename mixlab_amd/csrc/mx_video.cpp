@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 
 namespace mx {
@@ -29,6 +31,33 @@ Rational Rational::operator+(const Rational& o) const {
 }
 bool Rational::operator>=(const Rational& o) const {
     return (__int128)num * o.den >= (__int128)o.num * den;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deferred scaling: jobs queue per stream and leave as one batched launch when pixels are needed
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PendingScales { ScaleBatchArgs args{}; std::vector<FrameRef> keep; };
+std::mutex g_scale_mu;
+std::map<hipStream_t, PendingScales> g_scale_q;
+void flush_locked(hipStream_t s, PendingScales& q) {
+    if (q.args.n) { launch_scale_batch(q.args, s); q.args.n = 0; }
+    q.keep.clear();
+}
+}  // namespace
+void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst) {
+    std::lock_guard<std::mutex> lk(g_scale_mu);
+    PendingScales& q = g_scale_q[s];
+    bool conflict = q.args.n + 3 > MX_SCALE_BATCH_PLANES;
+    for (const FrameRef& k : q.keep) if (k.f == src.f || k.f == dst.f) conflict = true;   // no ordering inside one launch
+    if (conflict) flush_locked(s, q);
+    for (int i = 0; i < 3; ++i) q.args.p[q.args.n++] = a.p[i];
+    q.keep.push_back(src); q.keep.push_back(dst);
+}
+void flush_scales(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_scale_mu);
+    auto it = g_scale_q.find(s);
+    if (it != g_scale_q.end()) flush_locked(s, it->second);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,6 +212,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
     }
+    flush_scales(stream_);
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // a previous scale may still read the old tables
     tabs_.alloc(blob.size() * sizeof(int32_t));
     hip_check(hipMemcpy(tabs_.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(taps)");
@@ -204,7 +234,7 @@ FrameRef Scaler::scale(const FrameRef& in) {
         sp.dst_stride = frame_->stride[p]; sp.dw = geo_.scaled_w >> c; sp.dh = geo_.scaled_h >> c;
         sp.hfirst = tab_[c][0]; sp.hcoef = tab_[c][1]; sp.vfirst = tab_[c][2]; sp.vcoef = tab_[c][3];
     }
-    launch_scale_bicubic(a, stream_);
+    queue_scale(a, stream_, in, frame_);   // leaves with the other scales of this tick as one launch
     return frame_;
 }
 
@@ -216,6 +246,7 @@ VideoMixer::VideoMixer(const mx_video_mixer_params& p, uint32_t sample_rate, hip
     if (!stream_) { hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"); own_stream_ = true; }
 }
 VideoMixer::~VideoMixer() {
+    flush_scales(stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (auto& c : ch_) { c.stored.frame = FrameRef(); c.scaler.reset(); }
     pool_.clear();

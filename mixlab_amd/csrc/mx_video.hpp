@@ -29,6 +29,8 @@ struct ScalePlane {
     const int32_t* vfirst; const int32_t* vcoef;   // [dh], [dh][4]
 };
 struct ScaleArgs { ScalePlane p[3]; };
+enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
+struct ScaleBatchArgs { ScalePlane p[MX_SCALE_BATCH_PLANES]; uint32_t n; };
 struct CopyArgs { const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], rows[3], row_bytes[3]; };
 struct RgbaArgs {
     const uint8_t* y; const uint8_t* u; const uint8_t* v; uint8_t* rgba;
@@ -61,6 +63,11 @@ void launch_fade_chain(const ChainArgs& a, hipStream_t s);
 void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s);
 void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s);
 void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s);
+void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s);
+// deferred scaling: Scaler::scale queues its planes per stream; every reader of frame pixels flushes first
+struct FrameRef;
+void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst);
+void flush_scales(hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
 
@@ -130,6 +137,7 @@ uint8_t crossfade_factor(double fader);   // video_mixer.rs:168
 class Scaler {
 public:
     Scaler(uint32_t out_w, uint32_t out_h, hipStream_t s) : out_w_(out_w), out_h_(out_h), stream_(s) {}
+    ~Scaler() { flush_scales(stream_); }   // queued jobs reference this scaler's tap tables
     uint32_t out_w() const { return out_w_; }
     uint32_t out_h() const { return out_h_; }
     // returns the frame itself when its settings equal the output's (encode.rs:342-345), else the
