@@ -232,10 +232,12 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 #define SC_NR 40
 #define SC_NC 136
 __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
-    const int plane = blockIdx.z;
+    int plane = 0;
+#pragma unroll
+    for (int k = 1; k < MX_SCALE_BATCH_PLANES; ++k) if (k < (int)a.n && blockIdx.x >= a.tile_start[k]) plane = k;   // scalar search
     const ScalePlane p = a.p[plane];
-    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 16;
-    if (ox0 >= (int)p.dw || oy0 >= (int)p.dh) return;   // block-uniform
+    const uint32_t tile = blockIdx.x - a.tile_start[plane];
+    const int ox0 = (int)(tile % a.tiles_x[plane]) * 64, oy0 = (int)(tile / a.tiles_x[plane]) * 16;
     __shared__ uint8_t S[SC_NR][SC_NC];
     __shared__ __attribute__((aligned(16))) int T[SC_NR][64];
     const int tid = threadIdx.x;
@@ -313,8 +315,19 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
     }
     if (!a.n || !mw || !mh) return;
     static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
-    if (tiled && !force_simple) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3((mw + 63) / 64, (mh + 15) / 16, a.n), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
+    if (tiled && !force_simple) {
+        ScaleBatchArgs b = a;
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < a.n; ++i) {
+            b.tile_start[i] = total;
+            b.tiles_x[i] = (a.p[i].dw + 63) / 64;
+            total += b.tiles_x[i] * ((a.p[i].dh + 15) / 16);
+        }
+        for (uint32_t i = a.n; i <= MX_SCALE_BATCH_PLANES; ++i) { b.tile_start[i] = total; if (i < MX_SCALE_BATCH_PLANES) b.tiles_x[i] = 1; }
+        if (total) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3(total), dim3(256), 0, s, b);
+    } else {
+        hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
+    }
 }
 void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s) {
     ScaleBatchArgs b;

@@ -30,7 +30,11 @@ struct ScalePlane {
 };
 struct ScaleArgs { ScalePlane p[3]; };
 enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
-struct ScaleBatchArgs { ScalePlane p[MX_SCALE_BATCH_PLANES]; uint32_t n; };
+struct ScaleBatchArgs {
+    ScalePlane p[MX_SCALE_BATCH_PLANES]; uint32_t n;
+    uint32_t tile_start[MX_SCALE_BATCH_PLANES + 1];   // launcher-filled: flat block index -> (plane, tile), no empty blocks
+    uint32_t tiles_x[MX_SCALE_BATCH_PLANES];
+};
 struct CopyArgs { const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], rows[3], row_bytes[3]; };
 struct RgbaArgs {
     const uint8_t* y; const uint8_t* u; const uint8_t* v; uint8_t* rgba;
