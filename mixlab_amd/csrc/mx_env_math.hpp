@@ -50,4 +50,15 @@ __device__ __forceinline__ double env_amplitude(const EnvParams& p, uint32_t tag
     return tag == 1u ? amp_on_ms(p, ms) : amp_off_ms(p, off_amp, ms);
 }
 
+// Has the amplitude stopped changing at time t (and therefore for every later t of the run)?  ms is
+// non-decreasing in t, so once the decay clamp (envelope.rs:45) or the release clamp (:54) saturates it
+// stays saturated: sustain + (1 - sustain) * 0.0 and off_amp * 0.0 are then the same f64 for all later
+// samples.  Needs positive decay / release times (otherwise the products are not monotone).
+__device__ __forceinline__ bool env_saturated(const EnvParams& p, uint32_t tag, uint64_t seq, uint64_t t, double sr, double rsr) {
+    if (tag == 0u) return true;
+    const double ms = seq_ms(seq, t, sr, rsr);
+    if (tag == 1u) return p.inv_decay > 0.0 && !(ms < p.attack_ms) && p.inv_decay * (ms - p.attack_ms) >= 1.0;
+    return p.inv_release > 0.0 && p.inv_release * ms >= 1.0;
+}
+
 }  // namespace mx

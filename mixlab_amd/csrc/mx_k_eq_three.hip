@@ -251,6 +251,17 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
                 const int e = tid + 256 * k;
                 if (e < nv) eq_store(d, base + e, eq_amp(d, tile[e + (e >> LOG2L)], true, c[k]));
             }
+        } else if (d.epi == 2u && (d.flags & MX_EQF_ENV) && tid < nv &&
+                   env_saturated(d.env, ec.tag, ec.seq, ec.t0 + base + tid, ec.sr, ec.rsr)) {
+            // inline Envelope already flat at this lane's earliest sample (sustain reached, release finished or never
+            // triggered): the control is one constant for all L samples of the lane -- the steady state of a held gate
+            const float c = (float)env_amplitude(d.env, ec.tag, ec.seq, ec.off_amp, ec.t0 + base + tid, ec.sr, ec.rsr);
+            const double depth = d.amp_one_minus + d.amp_mod_depth * (double)c;       // amplifier.rs:71-73
+#pragma unroll 8
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + 256 * k;
+                if (e < nv) eq_store(d, base + e, (float)((double)tile[e + (e >> LOG2L)] * depth * d.amp_amplitude));   // amplifier.rs:56
+            }
         } else {
 #pragma unroll 8
             for (int k = 0; k < L; ++k) {
