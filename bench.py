@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--strips", type=int, default=1024)
-    ap.add_argument("--ticks-per-step", type=int, default=64)
+    ap.add_argument("--ticks-per-step", type=int, default=256, help="ticks batched per submission (SURVEY 8d: throughput mode; 1 = real-time mode)")
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-exact", action="store_true", help="strictly sequential EqThree (bit-exact order) instead of the time-parallel scan")
     ap.add_argument("--no-fuse", action="store_true", help="materialise every port (MX_FLAG_NO_FUSE): module-boundary traffic")
@@ -321,7 +321,9 @@ def main():
             roof = {"kernel": dom + ("" if args.no_fuse or dom == "mixer" else " (fused group)"), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": alg,
-                    "kernel_ms_per_step": {k: round(v / n_prof, 5) for k, v in sorted(by_kind.items())}}
+                    "kernel_ms_per_step": {k: round(v / n_prof, 5) for k, v in sorted(by_kind.items())},
+                    "limiter": ("f64 VALU issue + dependent-chain latency of the 8-pole recurrence (PMC: VALU busy ~55% of the kernel, "
+                                "traffic = 1.2x algorithmic); HBM is the roof only nominally" if dom == "eq_three" else "HBM")}
         # bytes of one step on one rank: module-boundary accounting (every port materialised) and, when the
         # graph compiler fused, the bytes the fused kernels actually have to move
         whole_alg = 51200 * (SR / 48000.0) * local_strips * T

@@ -45,6 +45,12 @@ __device__ __forceinline__ void eq_emit(const EqDesc& d, const EnvCtx& ec, size_
     eq_store(d, i, v);
 }
 
+// what the scan kernel's stage-out needs, parked in LDS by lane 0 (see k_eq_three_scan)
+struct EqEpi {
+    float* out; const float* ctl; double amp_one_minus, amp_mod_depth, amp_amplitude;
+    EnvParams env; double off_amp; uint64_t seq; uint32_t tag, epi, flags, pad;
+};
+
 // LowPass::pump, eq_three.rs:117-124 -- exact order
 __device__ __forceinline__ double pump(const double f, double (&p)[4], const double sample) {
     p[0] += f * (sample - p[0]) + MX_VSA;
@@ -102,6 +108,16 @@ void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t fram
 // Only chunk-initial states differ from the sequential order, by ~1e-16 relative; f32 outputs stay
 // within 1 ULP of the reference order (tests/test_gpu_audio_parity.py counts the mismatches).
 // ---------------------------------------------------------------------------------------------
+// LDS tile layout: element e of a segment lives at float position swz(e) = e with its low 5 bits XORed
+// by bits 5..9 -- a bijection inside every 32-float row.  It makes lane j's walk over its own chunk
+// (elements j*L .. j*L+L-1) conflict-free for ds_read_b32 / ds_write_b32 for every L in {4,8,16,32}
+// AND keeps rows contiguous, which is what the LDS-DMA stage-in needs: `global_load_lds_dword` writes
+// 64 consecutive floats per wave instruction straight from HBM into LDS, no VGPRs, so the swizzle is
+// applied to the SOURCE address (lane at LDS position p fetches element swz(p); swz is an involution).
+__device__ __forceinline__ int swz(int e) { return (e & ~31) | ((e & 31) ^ ((e >> 5) & 31)); }
+typedef const float __attribute__((address_space(1)))* mx_gfp;
+typedef float __attribute__((address_space(3)))* mx_lfp;
+
 // y = T(c) v for a lower-triangular Toeplitz matrix with first column c
 __device__ __forceinline__ void toep_apply(const double* c, const double (&v)[4], double (&y)[4]) {
     y[0] = c[0] * v[0];
@@ -117,15 +133,29 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     constexpr int L = 1 << LOG2L;
     constexpr int SEG = 256 * L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);                                    // 256 * (L + 1) floats
-    double* wtot = reinterpret_cast<double*>(smem + 256 * (L + 1) * sizeof(float));  // [4 waves][8]
+    float* tile = reinterpret_cast<float*>(smem);                                    // 256 * L floats, swizzled (see swz)
+    double* wtot = reinterpret_cast<double*>(smem + 256 * L * sizeof(float));        // [4 waves][8]
     double* carry = wtot + 32;                                                       // [11] lo[4] hi[4] hist[3] (+1 pad)
     double* pw = carry + 12;                                                         // [2][65][4] A^(L j)
     double* p2 = pw + 2 * 65 * 4;                                                    // [2][6][4]  A^(L 2^k)
 
+    EqEpi* epi_lds = reinterpret_cast<EqEpi*>(p2 + 2 * 6 * 4);                       // fused-epilogue parameters
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const EqDesc d = descs[blockIdx.x];
-    const EnvCtx ec = env_ctx_begin(d, t0, sr, rsr);   // wave-uniform
+    // Only what the inner phases need stays in registers; everything the epilogue needs (Amplifier and inline
+    // Envelope parameters, the Envelope's state) is parked in LDS: a 160-byte descriptor held in SGPRs across the
+    // segment loop overflowed the scalar file and its spills cost ~35% extra HBM traffic.
+    const EqDesc* dp = descs + blockIdx.x;
+    const float* __restrict__ din = dp->in;
+    const double g_lo = dp->gain_lo, g_mid = dp->gain_mid, g_hi = dp->gain_hi;
+    if (tid == 0) {
+        const EqDesc d = *dp;
+        const EnvCtx ec = env_ctx_begin(d, t0, sr, rsr);
+        EqEpi e;
+        e.out = d.out; e.ctl = d.ctl; e.amp_one_minus = d.amp_one_minus; e.amp_mod_depth = d.amp_mod_depth; e.amp_amplitude = d.amp_amplitude;
+        e.env = d.env; e.off_amp = ec.off_amp; e.seq = ec.seq; e.tag = ec.tag; e.epi = d.epi; e.flags = d.flags;
+        *epi_lds = e;
+    }
     // tables and the carried state live in LDS, not in registers, across the segment loop
     for (int i = tid; i < 2 * 65 * 4; i += 256) pw[i] = (&tab->pw[0][0][0])[i];
     if (tid < 2 * 6 * 4) p2[tid] = (&tab->p2[0][0][0])[tid];
@@ -138,33 +168,37 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     for (size_t base = 0; base < frames; base += SEG) {
         const size_t rem = frames - base;
         const int nv = rem < (size_t)SEG ? (int)rem : SEG;
-        {   // coalesced stage-in; all L loads of the lane are issued before the first LDS write
-            float r[L];
+        // stage-in by LDS-DMA: each wave issues L `global_load_lds_dword` (256 B each), no VGPRs involved
+        if (din) {
 #pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
-                r[k] = (e < nv && d.in) ? d.in[base + e] : 0.f;
+            for (int kk = 0; kk < L; ++kk) {
+                const int n = wave + 4 * kk;                         // 64-float block of the tile
+                const int p = n * 64 + lane;                         // LDS float position this lane fills
+                const int e = swz(p);                                // ... with this element of the segment
+                const int ec = e < nv ? e : nv - 1;                  // past-the-end positions are never read; keep the address legal
+                __builtin_amdgcn_global_load_lds((mx_gfp)(din + base + ec), (mx_lfp)(tile + n * 64), 4, 0, 0);
             }
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
-                tile[e + (e >> LOG2L)] = r[k];       // element e of the segment -> tile[e + e / L]
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < L; ++k) tile[tid + 256 * k] = 0.f;   // Disconnected input => ZERO_BUFFER_MONO
         }
         __syncthreads();
 
         const int start = tid << LOG2L;
         const int my_n = nv - start >= L ? L : (nv - start > 0 ? nv - start : 0);
-        float* mine = tile + start + tid;   // (start + i) + (start + i) / L == start + tid + i
+        // my chunk: elements start .. start+L-1 sit in one 32-float row; position of element start+i is pbase + (i ^ xl)
+        const int xr = (start >> 5) & 31, xl = xr & (L - 1);
+        float* mine = tile + (start & ~31) + ((start & 31) ^ (xr & ~(L - 1)));
 
         // phase A: zero-state response of a full chunk as 8 dot products (tables wave-uniform)
         double zl[4] = {0.0, 0.0, 0.0, 0.0}, zh[4] = {0.0, 0.0, 0.0, 0.0};
         if (my_n == L) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { zl[q] = tab->cz[0][q]; zh[q] = tab->cz[1][q]; }
-#pragma unroll 8
+#pragma unroll 2   // each step pulls 8 table doubles into SGPRs: a deeper unroll overflows the scalar file and spills
             for (int i = 0; i < L; ++i) {
-                const double x = (double)mine[i];
+                const double x = (double)mine[i ^ xl];
                 const int m = L - 1 - i;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { zl[q] = fma(tab->h[0][m][q], x, zl[q]); zh[q] = fma(tab->h[1][m][q], x, zh[q]); }
@@ -173,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
         // the three samples before my chunk (the EQ's 3-sample delay line), read before anyone overwrites the tile
         double h0, h1, h2;
         if (tid == 0) { h0 = carry[8]; h1 = carry[9]; h2 = carry[10]; }
-        else { const float* prev = tile + (start - L) + (tid - 1); h0 = (double)prev[L - 3]; h1 = (double)prev[L - 2]; h2 = (double)prev[L - 1]; }
+        else { h0 = (double)tile[swz(start - 3)]; h1 = (double)tile[swz(start - 2)]; h2 = (double)tile[swz(start - 1)]; }
 
         // inclusive scan over the wave: E_j = sum_{i<=j} P^(j-i) z_i
 #pragma unroll
@@ -222,12 +256,12 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
 #pragma unroll 4
         for (int i = 0; i < L; ++i) {
             if (i < my_n) {
-                const double sample = (double)mine[i];
+                const double sample = (double)mine[i ^ xl];
                 const double l = pump(lo_f, lo, sample);
                 const double h = h0 - pump(hi_f, hi, sample);
                 const double mid = h0 - (h + l);
                 h0 = h1; h1 = h2; h2 = sample;
-                mine[i] = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);
+                mine[i ^ xl] = (float)(l * g_lo + mid * g_mid + h * g_hi);
             }
         }
         __syncthreads();   // every lane has finished reading wtot / carry of this segment
@@ -239,40 +273,69 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
             carry[8] = h0; carry[9] = h1; carry[10] = h2;
         }
         // coalesced stage-out through the fused epilogue
-        if (d.epi == 2u && d.ctl && !(d.flags & MX_EQF_ENV)) {   // fused Amplifier, control from a buffer: one burst of L loads first
-            float c[L];
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
-                c[k] = (e < nv) ? d.ctl[base + e] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
-                if (e < nv) eq_store(d, base + e, eq_amp(d, tile[e + (e >> LOG2L)], true, c[k]));
-            }
-        } else if (d.epi == 2u && (d.flags & MX_EQF_ENV) && tid < nv &&
-                   env_saturated(d.env, ec.tag, ec.seq, ec.t0 + base + tid, ec.sr, ec.rsr)) {
-            // inline Envelope already flat at this lane's earliest sample (sustain reached, release finished or never
-            // triggered): the control is one constant for all L samples of the lane -- the steady state of a held gate
-            const float c = (float)env_amplitude(d.env, ec.tag, ec.seq, ec.off_amp, ec.t0 + base + tid, ec.sr, ec.rsr);
-            const double depth = d.amp_one_minus + d.amp_mod_depth * (double)c;       // amplifier.rs:71-73
+        {
+            const EqEpi E = *epi_lds;
+            const bool mono = (E.epi == 0u) || (E.flags & MX_EQF_MONO_DUP);
+            auto store = [&](size_t i, float v) {
+                if (mono) E.out[i] = v; else reinterpret_cast<float2*>(E.out)[i] = make_float2(v, v);   // stereo_panner.rs:35-38
+            };
+            auto amp = [&](float y, double depth) { return (float)((double)y * depth * E.amp_amplitude); };   // amplifier.rs:56
+            if (E.epi != 2u) {                                   // plain EqThree, or EqThree -> StereoPanner
 #pragma unroll 8
-            for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
-                if (e < nv) eq_store(d, base + e, (float)((double)tile[e + (e >> LOG2L)] * depth * d.amp_amplitude));   // amplifier.rs:56
-            }
-        } else {
+                for (int k = 0; k < L; ++k) {
+                    const int e = tid + 256 * k;
+                    if (e < nv) store(base + e, tile[swz(e)]);
+                }
+            } else if (E.flags & MX_EQF_ENV) {                   // ... -> Amplifier with the Envelope evaluated inline
+                const uint64_t tl = t0 + base + tid;             // this lane's earliest sample time in the segment
+                if (tid < nv && env_saturated(E.env, E.tag, E.seq, tl, sr, rsr)) {
+                    // already flat (sustain reached, release finished or never triggered): one constant control for all
+                    // L samples of the lane -- the steady state of a held gate
+                    const float c = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, tl, sr, rsr);   // Envelope stores f32 (envelope.rs:117)
+                    const double depth = E.amp_one_minus + E.amp_mod_depth * (double)c;               // amplifier.rs:71-73
 #pragma unroll 8
-            for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
-                if (e < nv) eq_emit(d, ec, base + e, tile[e + (e >> LOG2L)]);
+                    for (int k = 0; k < L; ++k) {
+                        const int e = tid + 256 * k;
+                        if (e < nv) store(base + e, amp(tile[swz(e)], depth));
+                    }
+                } else {
+#pragma unroll 4
+                    for (int k = 0; k < L; ++k) {
+                        const int e = tid + 256 * k;
+                        if (e < nv) {
+                            const float c = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, t0 + base + e, sr, rsr);
+                            store(base + e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)c));
+                        }
+                    }
+                }
+            } else if (E.ctl) {                                  // ... -> Amplifier, control from a buffer: one burst of L loads first
+                float c[L];
+#pragma unroll
+                for (int k = 0; k < L; ++k) {
+                    const int e = tid + 256 * k;
+                    c[k] = (e < nv) ? E.ctl[base + e] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < L; ++k) {
+                    const int e = tid + 256 * k;
+                    if (e < nv) store(base + e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)c[k]));
+                }
+            } else {                                             // ... -> Amplifier with a Disconnected control: mod value 1.0 (amplifier.rs:54)
+                const double depth = E.amp_one_minus + E.amp_mod_depth * 1.0;
+#pragma unroll 8
+                for (int k = 0; k < L; ++k) {
+                    const int e = tid + 256 * k;
+                    if (e < nv) store(base + e, amp(tile[swz(e)], depth));
+                }
             }
         }
         __syncthreads();
     }
     if (tid < 11) reinterpret_cast<double*>(&states[blockIdx.x])[tid] = carry[tid];
-    if (tid == 0) env_ctx_end(d, ec);
+    if (tid == 0 && (epi_lds->flags & MX_EQF_ENV)) {
+        EnvState* es = dp->env_state;
+        es->tag = epi_lds->tag; es->seq = epi_lds->seq; es->off_amplitude = epi_lds->off_amp;
+    }
 }
 
 int eq_scan_log2l(size_t frames) {
@@ -286,7 +349,7 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frame
                           const EqScanTab* tabs /* indexed by log2L - 2 */, hipStream_t s) {
     if (!n || !frames) return;
     const int l2 = eq_scan_log2l(frames);
-    const size_t lds = (size_t)256 * ((1u << l2) + 1) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double);
+    const size_t lds = (size_t)256 * (1u << l2) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + sizeof(EqEpi);
     const EqScanTab* tab = tabs + (l2 - 2);
     switch (l2) {
     case 2: hipLaunchKernelGGL(k_eq_three_scan<2>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
