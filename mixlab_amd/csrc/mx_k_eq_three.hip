@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
         const int nv = rem < (size_t)SEG ? (int)rem : SEG;
         // stage-in by LDS-DMA: each wave issues L `global_load_lds_dword` (256 B each), no VGPRs involved
         if (din) {
-#pragma unroll
+#pragma unroll 4   // DMA needs no data registers, but a full unroll materialises L 64-bit addresses at once
             for (int kk = 0; kk < L; ++kk) {
                 const int n = wave + 4 * kk;                         // 64-float block of the tile
                 const int p = n * 64 + lane;                         // LDS float position this lane fills
@@ -275,16 +275,18 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
         // coalesced stage-out through the fused epilogue
         {
             const EqEpi E = *epi_lds;
+            float* const outb = E.out + (((E.epi == 0u) || (E.flags & MX_EQF_MONO_DUP)) ? base : 2 * base);   // segment base: lane offsets stay 32-bit
+            const float* const ctlb = E.ctl ? E.ctl + base : nullptr;
             const bool mono = (E.epi == 0u) || (E.flags & MX_EQF_MONO_DUP);
-            auto store = [&](size_t i, float v) {
-                if (mono) E.out[i] = v; else reinterpret_cast<float2*>(E.out)[i] = make_float2(v, v);   // stereo_panner.rs:35-38
+            auto store = [&](int i, float v) {
+                if (mono) outb[i] = v; else reinterpret_cast<float2*>(outb)[i] = make_float2(v, v);   // stereo_panner.rs:35-38
             };
             auto amp = [&](float y, double depth) { return (float)((double)y * depth * E.amp_amplitude); };   // amplifier.rs:56
             if (E.epi != 2u) {                                   // plain EqThree, or EqThree -> StereoPanner
-#pragma unroll 8
+#pragma unroll 4
                 for (int k = 0; k < L; ++k) {
                     const int e = tid + 256 * k;
-                    if (e < nv) store(base + e, tile[swz(e)]);
+                    if (e < nv) store(e, tile[swz(e)]);
                 }
             } else if (E.flags & MX_EQF_ENV) {                   // ... -> Amplifier with the Envelope evaluated inline
                 const uint64_t tl = t0 + base + tid;             // this lane's earliest sample time in the segment
@@ -293,10 +295,10 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
                     // L samples of the lane -- the steady state of a held gate
                     const float c = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, tl, sr, rsr);   // Envelope stores f32 (envelope.rs:117)
                     const double depth = E.amp_one_minus + E.amp_mod_depth * (double)c;               // amplifier.rs:71-73
-#pragma unroll 8
+#pragma unroll 4
                     for (int k = 0; k < L; ++k) {
                         const int e = tid + 256 * k;
-                        if (e < nv) store(base + e, amp(tile[swz(e)], depth));
+                        if (e < nv) store(e, amp(tile[swz(e)], depth));
                     }
                 } else {
 #pragma unroll 4
@@ -304,28 +306,32 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
                         const int e = tid + 256 * k;
                         if (e < nv) {
                             const float c = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, t0 + base + e, sr, rsr);
-                            store(base + e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)c));
+                            store(e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)c));
                         }
                     }
                 }
-            } else if (E.ctl) {                                  // ... -> Amplifier, control from a buffer: one burst of L loads first
-                float c[L];
+            } else if (E.ctl) {                                  // ... -> Amplifier, control from a buffer: bursts of <= 16 loads first
+                constexpr int CB = L > 16 ? 16 : L;
+#pragma unroll 1
+                for (int k0 = 0; k0 < L; k0 += CB) {
+                    float c[CB];
 #pragma unroll
-                for (int k = 0; k < L; ++k) {
-                    const int e = tid + 256 * k;
-                    c[k] = (e < nv) ? E.ctl[base + e] : 0.f;
-                }
+                    for (int k = 0; k < CB; ++k) {
+                        const int e = tid + 256 * (k0 + k);
+                        c[k] = (e < nv) ? ctlb[e] : 0.f;
+                    }
 #pragma unroll
-                for (int k = 0; k < L; ++k) {
-                    const int e = tid + 256 * k;
-                    if (e < nv) store(base + e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)c[k]));
+                    for (int k = 0; k < CB; ++k) {
+                        const int e = tid + 256 * (k0 + k);
+                        if (e < nv) store(e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)c[k]));
+                    }
                 }
             } else {                                             // ... -> Amplifier with a Disconnected control: mod value 1.0 (amplifier.rs:54)
                 const double depth = E.amp_one_minus + E.amp_mod_depth * 1.0;
-#pragma unroll 8
+#pragma unroll 4
                 for (int k = 0; k < L; ++k) {
                     const int e = tid + 256 * k;
-                    if (e < nv) store(base + e, amp(tile[swz(e)], depth));
+                    if (e < nv) store(e, amp(tile[swz(e)], depth));
                 }
             }
         }
