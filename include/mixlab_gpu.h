@@ -57,7 +57,10 @@ enum {
     MX_KIND_SOURCE_STEREO = 12,   /*   (StreamInput src/module/stream_input.rs:72-147, MediaSource media_source.rs:93-126) */
     MX_KIND_SOURCE_VIDEO = 13,    /* frame-fed port; stands in for MediaSource / StreamInput video (media_source.rs:93-126) */
     MX_KIND_VIDEO_TO_RGBA = 14,   /* BUILD-SPECIFIED sink (no reference module): YUV420P -> RGBA8 (+ Q12 3x4 matrix)  in: Video */
-    MX_KIND_COUNT = 15
+    MX_KIND_FIR = 15,             /* BUILD-SPECIFIED (BASELINE configs[2]; no reference module): K-tap FIR on a stereo stream  in: Stereo  out: Stereo */
+    MX_KIND_RESAMPLE = 16,        /* BUILD-SPECIFIED rational polyphase resampler (44.1 -> 48 kHz = up 160 / down 147; the reference has only
+                                     `TODO implement resampling`, src/icecast/mod.rs:94-97)  in: Stereo  out: Stereo at rate * up / down */
+    MX_KIND_COUNT = 17
 };
 
 /* protocol/src/lib.rs:233-241, bincode variant order */
@@ -73,6 +76,14 @@ typedef struct { double freq_lo, freq_hi; } mx_fm_sine_params;                  
 typedef struct { uint32_t gate_open; } mx_trigger_params;                                              /* GateState :304-308 */
 typedef struct { int32_t a, b; /* -1 = None */ double fader; } mx_video_mixer_params;                  /* VideoMixerParams :405-410 */
 typedef struct { int32_t use_matrix; int32_t matrix_q12[12]; } mx_video_to_rgba_params;                /* build-specified, DESIGN.md "Colour" */
+/* Build-specified audio extras (DESIGN.md "FIR and resampler").  Both are variable-length blobs: the header below
+ * followed by the f64 coefficients.  Arithmetic: f32 widened to f64, accumulated in f64 in ascending tap index with
+ * separate multiply and add, rounded once to f32 -- the reference's own convention (mixer.rs:62, amplifier.rs:56). */
+typedef struct { uint32_t n_taps; uint32_t _pad; /* double taps[n_taps] */ } mx_fir_params;               /* y[n] = sum_k taps[k] x[n-k] per channel */
+typedef struct { uint32_t up, down, taps_per_phase, _pad; /* double taps[up][taps_per_phase] */ } mx_resample_params;
+/*   output sample M (absolute): n = floor(M * down / up), phase = (M * down) mod up, y[M] = sum_k taps[phase][k] x[n-k].
+ *   A node's output lives in the sample-rate domain (rate * up / down); modules whose arithmetic depends on the sample
+ *   rate or on t (EqThree, Envelope, Oscillator, FmSine) are only accepted in the base domain. */
 
 /* ---- graph description ---- */
 typedef struct { uint32_t kind; uint32_t params_len; const void* params; } mx_node;

@@ -120,7 +120,7 @@ int mx_graph_output_device_ptr(mx_graph* g, uint32_t node, uint32_t port, void**
         REQUIRE(g && device_ptr, "NULL argument");
         size_t fpf = 0;
         *device_ptr = g->g->output_ptr(node, port, &fpf);
-        if (floats_per_tick) *floats_per_tick = fpf * g->g->spt();
+        if (floats_per_tick) *floats_per_tick = fpf;
     });
 }
 
@@ -166,6 +166,7 @@ static void module_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>&
     case MX_KIND_STEREO_PANNER: in = {MX_MONO, MX_MONO}; out = {MX_STEREO}; break;
     case MX_KIND_STEREO_SPLITTER: in = {MX_STEREO}; out = {MX_MONO, MX_MONO}; break;
     case MX_KIND_TRIGGER: in = {}; out = {MX_MONO}; break;
+    case MX_KIND_FIR: in = {MX_STEREO}; out = {MX_STEREO}; break;
     default: throw Error(MX_ERR_INVALID, "kind has no per-module audio path");
     }
 }

@@ -47,6 +47,8 @@ static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& i
     case MX_KIND_SOURCE_STEREO: in = {}; out = {MX_STEREO}; break;
     case MX_KIND_VIDEO_MIXER: need(sizeof(mx_video_mixer_params), "mx_video_mixer_params"); in.assign(4, MX_VIDEO); out.assign(3, MX_VIDEO); break;  // video_mixer.rs:42-49
     case MX_KIND_SOURCE_VIDEO: in = {}; out = {MX_VIDEO}; break;
+    case MX_KIND_FIR: in = {MX_STEREO}; out = {MX_STEREO}; break;        // blob checked in the constructor
+    case MX_KIND_RESAMPLE: in = {MX_STEREO}; out = {MX_STEREO}; break;
     case MX_KIND_VIDEO_TO_RGBA: need(sizeof(mx_video_to_rgba_params), "mx_video_to_rgba_params"); in = {MX_VIDEO}; out = {}; break;
     default: throw Error(MX_ERR_INVALID, "unknown module kind");
     }
@@ -164,6 +166,43 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         n.level = lvl;
         n.in_src_orig = n.in_src;
     }
+    // variable-length blobs of the build-specified modules
+    for (const Node& n : nodes_) {
+        if (n.kind == MX_KIND_FIR) {
+            mx_fir_params h{}; if (n.params.size() >= sizeof h) std::memcpy(&h, n.params.data(), sizeof h);
+            if (n.params.size() < sizeof h || h.n_taps == 0 || h.n_taps > 16384 || n.params.size() != sizeof h + (size_t)h.n_taps * sizeof(double))
+                throw Error(MX_ERR_INVALID, "mx_fir_params: params_len must be 8 + 8 * n_taps (1 <= n_taps <= 16384)");
+        } else if (n.kind == MX_KIND_RESAMPLE) {
+            mx_resample_params h{}; if (n.params.size() >= sizeof h) std::memcpy(&h, n.params.data(), sizeof h);
+            if (n.params.size() < sizeof h || !h.up || !h.down || !h.taps_per_phase || h.taps_per_phase > 4096 ||
+                n.params.size() != sizeof h + (size_t)h.up * h.taps_per_phase * sizeof(double))
+                throw Error(MX_ERR_INVALID, "mx_resample_params: params_len must be 16 + 8 * up * taps_per_phase");
+        }
+    }
+    // sample-rate domains: every input of a node must live in one domain; Resample multiplies it by up / down
+    auto gcd_u = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a ? a : 1; };
+    for (uint32_t id : order_) {
+        Node& n = nodes_[id];
+        bool have = false; uint32_t dn = 1, dd = 1;
+        for (const PortRef& pr : n.in_src) {
+            if (pr.node < 0 || n.in_type[&pr - n.in_src.data()] == MX_VIDEO) continue;
+            const Node& sn = nodes_[pr.node];
+            if (have && (sn.dom_num != dn || sn.dom_den != dd)) throw Error(MX_ERR_TYPE, "inputs of a module live in different sample-rate domains");
+            dn = sn.dom_num; dd = sn.dom_den; have = true;
+        }
+        n.in_dom_num = dn; n.in_dom_den = dd; n.dom_num = dn; n.dom_den = dd;
+        if (n.kind == MX_KIND_RESAMPLE) {
+            mx_resample_params h; std::memcpy(&h, n.params.data(), sizeof h);
+            const uint64_t a = (uint64_t)dn * h.up, b = (uint64_t)dd * h.down, g = gcd_u(a, b);
+            n.dom_num = (uint32_t)(a / g); n.dom_den = (uint32_t)(b / g);
+        }
+        if ((spt_ * n.dom_num) % n.dom_den) throw Error(MX_ERR_INVALID, "resampling ratio does not give a whole number of samples per tick");
+        const bool rate_dependent = n.kind == MX_KIND_EQ_THREE || n.kind == MX_KIND_ENVELOPE || n.kind == MX_KIND_OSCILLATOR || n.kind == MX_KIND_FM_SINE;
+        if (n.kind == MX_KIND_PLOTTER && (n.in_dom_num != 1 || n.in_dom_den != 1))
+            throw Error(MX_ERR_INVALID, "Plotter is only accepted in the base sample-rate domain");
+        if (rate_dependent && (n.dom_num != 1 || n.dom_den != 1))
+            throw Error(MX_ERR_INVALID, "EqThree / Envelope / Oscillator / FmSine depend on the sample rate and are only accepted in the base domain");
+    }
     for (Node& n : nodes_) { n.out_elided.assign(n.out_type.size(), 0); n.out_dup.assign(n.out_type.size(), 0); }
     if (!(flags_ & MX_FLAG_NO_FUSE)) plan_fusion();
     // groups: (level, kind); nodes folded into another node's kernel are never launched
@@ -171,12 +210,18 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     for (uint32_t id : order_) if (!nodes_[id].elided) sorted.push_back(id);
     std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
         if (nodes_[a].level != nodes_[b].level) return nodes_[a].level < nodes_[b].level;
-        return nodes_[a].kind < nodes_[b].kind;
+        if (nodes_[a].kind != nodes_[b].kind) return nodes_[a].kind < nodes_[b].kind;
+        const uint64_t da = ((uint64_t)nodes_[a].dom_num << 32) | nodes_[a].dom_den, db = ((uint64_t)nodes_[b].dom_num << 32) | nodes_[b].dom_den;
+        return da < db;
     });
     for (uint32_t id : sorted) {
         Node& n = nodes_[id];
-        if (groups_.empty() || groups_.back().level != n.level || groups_.back().kind != n.kind) {
-            Group g; g.level = n.level; g.kind = n.kind; groups_.push_back(std::move(g));
+        if (groups_.empty() || groups_.back().level != n.level || groups_.back().kind != n.kind ||
+            groups_.back().dom_num != n.dom_num || groups_.back().dom_den != n.dom_den ||
+            groups_.back().in_dom_num != n.in_dom_num || groups_.back().in_dom_den != n.in_dom_den) {
+            Group g; g.level = n.level; g.kind = n.kind;
+            g.dom_num = n.dom_num; g.dom_den = n.dom_den; g.in_dom_num = n.in_dom_num; g.in_dom_den = n.in_dom_den;
+            groups_.push_back(std::move(g));
         }
         n.group = (int)groups_.size() - 1;
         n.slot = (uint32_t)groups_.back().nodes.size();
@@ -334,7 +379,7 @@ void Graph::layout_slab() {
     zero_off_ = bump(2 * cap_frames_);
     for (Node& n : nodes_)
         for (size_t k = 0; k < n.out_type.size(); ++k)
-            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump((n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * cap_frames_);
+            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump((n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * (cap_frames_ * n.dom_num / n.dom_den + 1));
     slab_floats_ = off;
     slab_.alloc(off * sizeof(float));
     hip_check(hipMemsetAsync(slab_.p, 0, off * sizeof(float), stream_), "hipMemsetAsync(slab)");
@@ -494,6 +539,45 @@ void Graph::upload_group(Group& g) {
         up(g.desc, d.data(), n * sizeof(TrigDesc));
         break;
     }
+    case MX_KIND_FIR: {
+        size_t tt = 0, th = 0; g.max_taps = 0;
+        for (uint32_t id : g.nodes) { mx_fir_params h; std::memcpy(&h, nodes_[id].params.data(), sizeof h); tt += h.n_taps; th += h.n_taps; g.max_taps = std::max(g.max_taps, h.n_taps); }
+        std::vector<double> taps(tt);
+        if (g.extra.bytes < tt * sizeof(double) || !g.extra.p) g.extra.alloc(tt * sizeof(double));
+        if (!g.state.p) { g.state.alloc(th * sizeof(float2)); hip_check(hipMemset(g.state.p, 0, th * sizeof(float2)), "hipMemset"); }
+        std::vector<FirDesc> d(n);
+        size_t o = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_fir_params h; std::memcpy(&h, nd.params.data(), sizeof h);
+            std::memcpy(&taps[o], nd.params.data() + sizeof h, (size_t)h.n_taps * sizeof(double));
+            d[i] = FirDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), (const double*)g.extra.p + o, (float2*)g.state.p + o, h.n_taps, 0u};
+            o += h.n_taps;
+        }
+        hip_check(hipMemcpy(g.extra.p, taps.data(), tt * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(fir taps)");
+        up(g.desc, d.data(), n * sizeof(FirDesc));
+        break;
+    }
+    case MX_KIND_RESAMPLE: {
+        size_t tt = 0, th = 0; g.max_taps = 0;
+        for (uint32_t id : g.nodes) { mx_resample_params h; std::memcpy(&h, nodes_[id].params.data(), sizeof h); tt += (size_t)h.up * h.taps_per_phase; th += h.taps_per_phase; g.max_taps = std::max(g.max_taps, h.taps_per_phase); }
+        std::vector<double> taps(tt);
+        if (g.extra.bytes < tt * sizeof(double) || !g.extra.p) g.extra.alloc(tt * sizeof(double));
+        if (!g.state.p) { g.state.alloc(th * sizeof(float2)); hip_check(hipMemset(g.state.p, 0, th * sizeof(float2)), "hipMemset"); }
+        std::vector<ResampleDesc> d(n);
+        size_t o = 0, oh = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes_[g.nodes[i]];
+            mx_resample_params h; std::memcpy(&h, nd.params.data(), sizeof h);
+            const size_t cnt = (size_t)h.up * h.taps_per_phase;
+            std::memcpy(&taps[o], nd.params.data() + sizeof h, cnt * sizeof(double));
+            d[i] = ResampleDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), (const double*)g.extra.p + o, (float2*)g.state.p + oh, h.up, h.down, h.taps_per_phase, 0u};
+            o += cnt; oh += h.taps_per_phase;
+        }
+        hip_check(hipMemcpy(g.extra.p, taps.data(), tt * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(resample taps)");
+        up(g.desc, d.data(), n * sizeof(ResampleDesc));
+        break;
+    }
     default: break;  // PLOTTER (jobs built per run), SOURCE_* (no launch)
     }
 }
@@ -601,19 +685,25 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     size_t gi = 0, job_off = 0;
     for (Group& g : groups_) {
         const uint32_t n = (uint32_t)g.nodes.size();
+        const size_t gf = frames * g.dom_num / g.dom_den;   // frames of this group's sample-rate domain
         switch (g.kind) {
-        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, frames, stream_); break;
-        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, frames, t0, sample_rate_, stream_); break;
+        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, gf, stream_); break;
+        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_EQ_THREE:
-            if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, t0, sample_rate_, lo_f_, hi_f_, stream_);
-            else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, frames, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
+            if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
+            else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
             break;
-        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
-        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, frames, g.dup_mode, stream_); break;
-        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, frames, t0, sample_rate_, stream_); break;
-        case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, frames, stream_); break;
-        case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, frames, stream_); break;
-        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, frames, stream_); break;
+        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
+        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, gf, g.dup_mode, stream_); break;
+        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
+        case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, gf, stream_); break;
+        case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, gf, stream_); break;
+        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, gf, stream_); break;
+        case MX_KIND_FIR: launch_fir((const FirDesc*)g.desc.p, n, g.max_taps, gf, stream_); break;
+        case MX_KIND_RESAMPLE:
+            launch_resample((const ResampleDesc*)g.desc.p, n, g.max_taps, frames * g.in_dom_num / g.in_dom_den, gf,
+                            t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_);
+            break;
         case MX_KIND_PLOTTER: {
             jobs.clear();
             for (uint32_t id : g.nodes) {
@@ -676,6 +766,7 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
     if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
     const Node& n = nodes_[node];
     if (n.out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
+    frames = frames * n.dom_num / n.dom_den;   // the port's own sample-rate domain
     if (n.out_dup[port]) {   // stored as one float per frame (L == R): expand for the caller
         hip_check(hipMemcpyAsync(host, out_ptr(n, port), frames * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
         sync();
@@ -691,7 +782,7 @@ float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (nodes_[node].out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
     if (nodes_[node].out_dup[port]) throw Error(MX_ERR_INVALID, "port is stored as one float per frame (L == R fused result): use mx_graph_read_output, or build with MX_FLAG_NO_FUSE");
-    if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]);
+    if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]) * (spt_ * nodes_[node].dom_num / nodes_[node].dom_den);   // floats per TICK in the port's own rate domain
     return out_ptr(nodes_[node], port);
 }
 

@@ -29,6 +29,8 @@ struct Node {
     std::vector<size_t> out_off;              // float offset of each output port in the slab
     const float* bound = nullptr;             // SOURCE_*: caller-bound device buffer
     int level = 0;
+    uint32_t dom_num = 1, dom_den = 1;        // sample-rate domain of the OUTPUT ports relative to the graph's rate (Resample changes it)
+    uint32_t in_dom_num = 1, in_dom_den = 1;  // ... of the input ports
     uint32_t slot = 0;                        // index inside its (level, kind) group
     int group = -1;
     // plotter
@@ -54,6 +56,8 @@ struct Node {
 struct Group {
     int level = 0;
     uint32_t kind = 0;
+    uint32_t dom_num = 1, dom_den = 1, in_dom_num = 1, in_dom_den = 1;   // every node of a group shares one rate domain
+    uint32_t max_taps = 0;   // Fir / Resample
     std::vector<uint32_t> nodes;
     DevBuf desc;     // kind-specific descriptor array
     DevBuf state;    // EnvState[] / EqState[]
@@ -86,7 +90,7 @@ public:
     void profile_enable(bool on);
     uint32_t profile_collect(float* ms_by_kind, float* ms_total);   // syncs; returns number of runs collected
     void read_output(uint32_t node, uint32_t port, float* host, size_t frames);
-    float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_frame);
+    float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_tick);
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
     // module compat path: an InputRef may be Disconnected on one call and connected on the next

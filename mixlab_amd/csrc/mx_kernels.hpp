@@ -68,6 +68,11 @@ struct TrigDesc { float* out; float value; uint32_t pad; };
 // src/module/plotter.rs:37-56: de-interleave the fired ticks into a staging area
 struct PlotJob { const float* in; float* left; float* right; };
 
+// build-specified FIR / rational resampler (mx_k_fir.hip); taps live in device memory, hist = carried input frames
+struct FirDesc { const float* in; float* out; const double* taps; float2* hist; uint32_t n_taps; uint32_t pad; };
+struct ResampleDesc { const float* in; float* out; const double* taps /* [up][taps_per_phase] */; float2* hist;
+                      uint32_t up, down, taps_per_phase, pad; };
+
 // Launchers.  `frames` = mono samples in this run (= n_ticks * SPT); stereo buffers hold 2*frames.
 void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
@@ -82,5 +87,8 @@ void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s);
+void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s);
+void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, size_t in_frames, size_t out_frames,
+                     uint64_t in_base, uint64_t out_base, hipStream_t s);
 
 }  // namespace mx

@@ -72,6 +72,20 @@ class Workspace:
     def build(self, max_ticks_per_run: int = 1, flags: int = 0, device: int = -1, stream=None) -> "abi.Graph":
         return abi.Graph(self.nodes, self.edges, self.sample_rate, self.ticks_per_second, max_ticks_per_run, flags, device, stream)
 
+    # ---- build-specified audio extras (no reference module) ----
+    def fir(self, taps) -> int:
+        import struct
+        taps = [float(t) for t in taps]
+        return self.add(abi.KIND_FIR, struct.pack("<II", len(taps), 0) + struct.pack(f"<{len(taps)}d", *taps))
+
+    def resample(self, up: int, down: int, taps) -> int:
+        """taps: up x taps_per_phase polyphase table (row-major)."""
+        import struct
+        import numpy as np
+        t = np.ascontiguousarray(taps, dtype=np.float64)
+        assert t.ndim == 2 and t.shape[0] == up
+        return self.add(abi.KIND_RESAMPLE, struct.pack("<IIII", up, down, t.shape[1], 0) + t.tobytes())
+
     # ---- video nodes ----
     def video_mixer(self, a=None, b=None, fader=1.0) -> int:
         """VideoMixerParams (protocol/src/lib.rs:405-420); default fader 1.0 = start at A."""

@@ -225,6 +225,54 @@ int orc_plotter_run(orc_plotter* s, const float* in, float* left, float* right, 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* BUILD-SPECIFIED: K-tap FIR on an interleaved stereo stream.  x[m < 0] = hist[(K-1) + m]. */
+static inline float fir_x(const float* hist, uint32_t H, const float* in, long long f, int ch) {
+    if (f >= 0) return in ? in[2 * f + ch] : 0.0f;
+    long long h = (long long)H + f;
+    return h >= 0 ? hist[2 * h + ch] : 0.0f;
+}
+static void update_hist(float* hist, uint32_t H, const float* in, size_t frames) {
+    float* tmp = (float*)malloc(sizeof(float) * 2 * (H ? H : 1));
+    for (uint32_t j = 0; j < H; j++) {
+        long long f = (long long)frames - H + j;
+        tmp[2 * j] = fir_x(hist, H, in, f, 0); tmp[2 * j + 1] = fir_x(hist, H, in, f, 1);
+    }
+    memcpy(hist, tmp, sizeof(float) * 2 * H);
+    free(tmp);
+}
+void orc_fir_run(const double* taps, uint32_t n_taps, float* hist, const float* in, float* out, size_t frames) {
+    const uint32_t H = n_taps - 1;
+    for (size_t n = 0; n < frames; n++) {
+        double al = 0.0, ar = 0.0;
+        for (uint32_t k = 0; k < n_taps; k++) {
+            al = al + taps[k] * (double)fir_x(hist, H, in, (long long)n - k, 0);
+            ar = ar + taps[k] * (double)fir_x(hist, H, in, (long long)n - k, 1);
+        }
+        out[2 * n] = (float)al; out[2 * n + 1] = (float)ar;
+    }
+    update_hist(hist, H, in, frames);
+}
+/* BUILD-SPECIFIED: rational polyphase resampler; absolute output index M: n = floor(M*down/up), phase = (M*down) mod up */
+void orc_resample_run(const double* taps, uint32_t up, uint32_t down, uint32_t P, float* hist,
+                      uint64_t in_base, uint64_t out_base, const float* in, size_t in_frames, float* out, size_t out_frames) {
+    const uint32_t H = P - 1;
+    for (size_t m = 0; m < out_frames; m++) {
+        uint64_t num = (out_base + m) * (uint64_t)down;
+        uint64_t n_abs = num / up;
+        uint32_t phase = (uint32_t)(num - n_abs * up);
+        long long n = (long long)(n_abs - in_base);
+        const double* h = taps + (size_t)phase * P;
+        double al = 0.0, ar = 0.0;
+        for (uint32_t k = 0; k < P; k++) {
+            al = al + h[k] * (double)fir_x(hist, H, in, n - k, 0);
+            ar = ar + h[k] * (double)fir_x(hist, H, in, n - k, 1);
+        }
+        out[2 * m] = (float)al; out[2 * m + 1] = (float)ar;
+    }
+    update_hist(hist, H, in, in_frames);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Graph runner: Engine::run_tick, src/engine.rs:400-510 */
 
 enum { LT_MONO = 1, LT_STEREO = 2, LT_VIDEO = 3 };
@@ -246,6 +294,8 @@ typedef struct {
     int plot_fired;
     float* plot_l; float* plot_r;
     const float* source;   /* host-fed */
+    uint32_t dom_num, dom_den, in_dom_num, in_dom_den;   /* sample-rate domain (Resample changes it) */
+    float* hist;           /* Fir / Resample carried input frames */
     int ran;               /* produced output this tick (back-edges read Disconnected) */
 } onode;
 
@@ -255,7 +305,9 @@ struct orc_graph {
     double sample_rate; size_t spt;
 };
 
-static size_t lt_len(const orc_graph* g, uint8_t lt) { return lt == LT_MONO ? g->spt : (lt == LT_STEREO ? 2 * g->spt : 0); }
+
+static size_t node_frames(const orc_graph* g, const onode* n) { return g->spt * n->dom_num / n->dom_den; }
+static size_t node_len(const orc_graph* g, const onode* n, uint8_t lt) { return (lt == LT_MONO ? 1 : (lt == LT_STEREO ? 2 : 0)) * node_frames(g, n); }
 
 static int node_ports(onode* n) {
     static const uint8_t none[1] = {0};
@@ -272,6 +324,7 @@ static int node_ports(onode* n) {
     case ORC_KIND_TRIGGER: ni = 0; no = 1; ot[0] = LT_MONO; break;
     case ORC_KIND_SOURCE_MONO: ni = 0; no = 1; ot[0] = LT_MONO; break;
     case ORC_KIND_SOURCE_STEREO: ni = 0; no = 1; ot[0] = LT_STEREO; break;
+    case ORC_KIND_FIR: case ORC_KIND_RESAMPLE: ni = 1; it[0] = LT_STEREO; no = 1; ot[0] = LT_STEREO; break;
     case ORC_KIND_MIXER: {
         uint32_t nch = n->params_len / (uint32_t)sizeof(orc_mixer_channel_params);              /* mixer.rs:22-28 */
         n->n_in = nch; n->n_out = 2;
@@ -315,7 +368,7 @@ orc_graph* orc_graph_build(const orc_node* nodes, size_t n_nodes, const orc_edge
         n->in_src_port = (uint32_t*)calloc(n->n_in ? n->n_in : 1, sizeof(uint32_t));
         for (uint32_t k = 0; k < n->n_in; k++) n->in_src_node[k] = -1;
         n->out_buf = (float**)calloc(n->n_out ? n->n_out : 1, sizeof(float*));
-        for (uint32_t k = 0; k < n->n_out; k++) n->out_buf[k] = (float*)calloc(lt_len(g, n->out_type[k]), sizeof(float));
+        n->dom_num = n->dom_den = n->in_dom_num = n->in_dom_den = 1;   /* buffers are sized after domain propagation */
         orc_eq_three_init(&n->eq, g->sample_rate);
         orc_envelope_init(&n->env);
         n->plot.count = 0;
@@ -341,6 +394,27 @@ orc_graph* orc_graph_build(const orc_node* nodes, size_t n_nodes, const orc_edge
     for (size_t e = 0; e < n_edges; e++) feeds[edges[e].src_node] = 1;
     for (size_t i = 0; i < n_nodes; i++) if (!feeds[i]) traverse(g, (uint32_t)i, seen);
     free(feeds); free(seen);
+    /* sample-rate domains (build-specified Resample nodes change them), then the port buffers */
+    for (size_t oi = 0; oi < g->n_order; oi++) {
+        onode* n = &g->nodes[g->order[oi]];
+        for (uint32_t k = 0; k < n->n_in; k++) if (n->in_src_node[k] >= 0) {
+            const onode* sn = &g->nodes[n->in_src_node[k]];
+            n->in_dom_num = sn->dom_num; n->in_dom_den = sn->dom_den;
+        }
+        n->dom_num = n->in_dom_num; n->dom_den = n->in_dom_den;
+        if (n->kind == ORC_KIND_RESAMPLE) {
+            const uint32_t* h = (const uint32_t*)n->params;   /* up, down, taps_per_phase, pad */
+            uint64_t a = (uint64_t)n->in_dom_num * h[0], b = (uint64_t)n->in_dom_den * h[1], x = a, y = b;
+            while (y) { uint64_t t = x % y; x = y; y = t; }
+            n->dom_num = (uint32_t)(a / x); n->dom_den = (uint32_t)(b / x);
+            n->hist = (float*)calloc(2 * (size_t)h[2], sizeof(float));
+        }
+        if (n->kind == ORC_KIND_FIR) n->hist = (float*)calloc(2 * (size_t)((const uint32_t*)n->params)[0], sizeof(float));
+    }
+    for (size_t i = 0; i < n_nodes; i++) {
+        onode* n = &g->nodes[i];
+        for (uint32_t k = 0; k < n->n_out; k++) n->out_buf[k] = (float*)calloc(node_len(g, n, n->out_type[k]) + 1, sizeof(float));
+    }
     return g;
 }
 
@@ -350,7 +424,7 @@ void orc_graph_destroy(orc_graph* g) {
         onode* n = &g->nodes[i];
         if (n->out_buf) for (uint32_t k = 0; k < n->n_out; k++) free(n->out_buf[k]);
         free(n->out_buf); free(n->in_type); free(n->out_type); free(n->in_src_node); free(n->in_src_port);
-        free(n->params); free(n->plot_l); free(n->plot_r);
+        free(n->params); free(n->plot_l); free(n->plot_r); free(n->hist);
     }
     free(g->nodes); free(g->order); free(g);
 }
@@ -383,12 +457,12 @@ static const float* in_buf(const orc_graph* g, const onode* n, uint32_t port) {
 
 int orc_graph_run_tick(orc_graph* g, uint64_t tick) {
     uint64_t t = tick * (uint64_t)g->spt; /* engine.rs:490 */
-    size_t spt = g->spt;
     for (size_t i = 0; i < g->n_nodes; i++) { g->nodes[i].ran = 0; g->nodes[i].plot_fired = 0; }
     for (size_t oi = 0; oi < g->n_order; oi++) {
         onode* n = &g->nodes[g->order[oi]];
         /* Output::from_line_type: fresh zero-filled buffers every tick (io.rs:71-77) */
-        for (uint32_t k = 0; k < n->n_out; k++) memset(n->out_buf[k], 0, lt_len(g, n->out_type[k]) * sizeof(float));
+        for (uint32_t k = 0; k < n->n_out; k++) memset(n->out_buf[k], 0, node_len(g, n, n->out_type[k]) * sizeof(float));
+        const size_t spt = node_frames(g, n);   /* this node's frames per tick (its sample-rate domain) */
         switch (n->kind) {
         case ORC_KIND_AMPLIFIER:
             orc_amplifier_run((const orc_amplifier_params*)n->params, in_buf(g, n, 0),
@@ -426,6 +500,18 @@ int orc_graph_run_tick(orc_graph* g, uint64_t tick) {
         case ORC_KIND_TRIGGER:
             orc_trigger_run((const orc_trigger_params*)n->params, n->out_buf[0], spt);
             break;
+        case ORC_KIND_FIR: {
+            const uint32_t* h = (const uint32_t*)n->params;
+            orc_fir_run((const double*)((const char*)n->params + 8), h[0], n->hist, in_buf(g, n, 0), n->out_buf[0], spt);
+            break;
+        }
+        case ORC_KIND_RESAMPLE: {
+            const uint32_t* h = (const uint32_t*)n->params;
+            const size_t in_frames = g->spt * n->in_dom_num / n->in_dom_den;
+            orc_resample_run((const double*)((const char*)n->params + 16), h[0], h[1], h[2], n->hist,
+                             tick * (uint64_t)in_frames, tick * (uint64_t)spt, in_buf(g, n, 0), in_frames, n->out_buf[0], spt);
+            break;
+        }
         case ORC_KIND_SOURCE_MONO:
             if (n->source) memcpy(n->out_buf[0], n->source, spt * sizeof(float));
             break;
@@ -441,7 +527,7 @@ int orc_graph_run_tick(orc_graph* g, uint64_t tick) {
 
 const float* orc_graph_output(const orc_graph* g, uint32_t node, uint32_t port, size_t* len) {
     if (node >= g->n_nodes || port >= g->nodes[node].n_out) return NULL;
-    if (len) *len = lt_len(g, g->nodes[node].out_type[port]);
+    if (len) *len = node_len(g, &g->nodes[node], g->nodes[node].out_type[port]);
     return g->nodes[node].out_buf[port];
 }
 

@@ -45,7 +45,10 @@ enum {
     ORC_KIND_VIDEO_MIXER = 10,
     ORC_KIND_SOURCE_MONO = 11,   /* host-fed port: stands in for StreamInput / MediaSource audio */
     ORC_KIND_SOURCE_STEREO = 12,
-    ORC_KIND_COUNT = 13
+    ORC_KIND_SOURCE_VIDEO = 13, ORC_KIND_VIDEO_TO_RGBA = 14,   /* not handled by the audio graph runner */
+    ORC_KIND_FIR = 15,           /* build-specified (no reference module) */
+    ORC_KIND_RESAMPLE = 16,      /* build-specified (no reference module) */
+    ORC_KIND_COUNT = 17
 };
 
 /* protocol/src/lib.rs:233-241 (bincode variant order) */
@@ -103,6 +106,14 @@ void orc_stereo_splitter_run(const float* in_stereo, float* l, float* r, size_t 
 /* src/module/plotter.rs:37-56. Returns 1 and fills left/right when an indication fires. */
 typedef struct { uint64_t count; } orc_plotter;
 int orc_plotter_run(orc_plotter* s, const float* in_stereo /* NULL = disconnected */, float* left, float* right, size_t n);
+
+/* ---- BUILD-SPECIFIED audio extras (no reference counterpart; DESIGN.md "FIR and resampler") ----
+ * f32 widened to f64, accumulated in f64 in ascending tap index with separate multiply and add, rounded once.
+ * hist: the (n_taps - 1) [resp. (P - 1)] stereo input frames before the call, interleaved; updated on return. */
+void orc_fir_run(const double* taps, uint32_t n_taps, float* hist, const float* in_stereo, float* out_stereo, size_t frames);
+void orc_resample_run(const double* taps /* [up][P] */, uint32_t up, uint32_t down, uint32_t P, float* hist,
+                      uint64_t in_base, uint64_t out_base, const float* in_stereo, size_t in_frames,
+                      float* out_stereo, size_t out_frames);
 
 /* ---- graph runner: restates Engine::run_tick (src/engine.rs:400-510) ---- */
 typedef struct { uint32_t kind; uint32_t params_len; const void* params; } orc_node;

@@ -205,3 +205,22 @@ class OracleGraph:
         arr = (C.c_uint32 * max(1, len(self.ws.nodes)))()
         n = lib.orc_graph_run_order(self._h, arr, len(self.ws.nodes))
         return list(arr[:n])
+
+
+# ---------------- build-specified extras ----------------
+def fir_run(taps, hist: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """hist: (n_taps - 1) * 2 float32, updated in place."""
+    t = np.ascontiguousarray(taps, dtype=np.float64)
+    x = f32(x)
+    out = np.empty_like(x)
+    lib.orc_fir_run(_p(t), C.c_uint32(t.size), _p(hist), _p(x), _p(out), C.c_size_t(x.size // 2))
+    return out
+
+
+def resample_run(taps2d, up, down, hist: np.ndarray, in_base, out_base, x: np.ndarray, out_frames) -> np.ndarray:
+    t = np.ascontiguousarray(taps2d, dtype=np.float64)
+    x = f32(x)
+    out = np.empty(2 * out_frames, dtype=np.float32)
+    lib.orc_resample_run(_p(t), C.c_uint32(up), C.c_uint32(down), C.c_uint32(t.shape[1]), _p(hist), C.c_uint64(in_base), C.c_uint64(out_base),
+                         _p(x), C.c_size_t(x.size // 2), _p(out), C.c_size_t(out_frames))
+    return out
