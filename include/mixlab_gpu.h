@@ -142,6 +142,12 @@ int mx_graph_sync(mx_graph* g);
 
 /* Copy an output port's buffers of the last run to the host (synchronises the stream). */
 int mx_graph_read_output(mx_graph* g, uint32_t node, uint32_t port, float* host_samples, size_t n_ticks);
+/* The data formats either side of the path, converted on the device so PCIe carries 2 bytes per sample:
+ *   sinks (Monitor / StreamOutput, src/video/encode.rs:183-195): clamp to [-1, 1], * 32767.0, `as i16` (saturating, truncating);
+ *   ingest (StreamInput, src/module/stream_input.rs:167-173):    sample as f32 / 32768.0. */
+int mx_graph_read_output_i16(mx_graph* g, uint32_t node, uint32_t port, int16_t* host_samples, size_t n_ticks);
+int mx_graph_write_source_i16(mx_graph* g, uint32_t node, const int16_t* host_samples, size_t n_ticks);
+
 /* Device pointer + per-tick length (floats) of an output port (for zero-copy consumers / RCCL). */
 int mx_graph_output_device_ptr(mx_graph* g, uint32_t node, uint32_t port, void** device_ptr, size_t* floats_per_tick);
 

@@ -107,6 +107,8 @@ _proto("mx_graph_bind_source_device", C.c_int, C.c_void_p, C.c_uint32, C.c_void_
 _proto("mx_graph_run_ticks", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32)
 _proto("mx_graph_sync", C.c_int, C.c_void_p)
 _proto("mx_graph_read_output", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
+_proto("mx_graph_read_output_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
+_proto("mx_graph_write_source_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_output_device_ptr", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 _proto("mx_graph_read_plotter", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int))
 _proto("mx_graph_profile_run", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
@@ -204,6 +206,15 @@ class Graph:
         out = np.empty(n_ticks * (self.spt * rate[0] // rate[1]) * (2 if stereo else 1), dtype=np.float32)
         check(lib.mx_graph_read_output(self._h, node, port, out.ctypes.data_as(C.c_void_p), n_ticks))
         return out
+
+    def read_output_i16(self, node, port, n_ticks: int, stereo: bool, rate=(1, 1)) -> np.ndarray:
+        out = np.empty(n_ticks * (self.spt * rate[0] // rate[1]) * (2 if stereo else 1), dtype=np.int16)
+        check(lib.mx_graph_read_output_i16(self._h, node, port, out.ctypes.data_as(C.c_void_p), n_ticks))
+        return out
+
+    def write_source_i16(self, node, samples: np.ndarray, n_ticks: int):
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        check(lib.mx_graph_write_source_i16(self._h, node, a.ctypes.data_as(C.c_void_p), n_ticks))
 
     def output_device_ptr(self, node, port):
         p = C.c_void_p()

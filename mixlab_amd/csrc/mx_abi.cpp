@@ -115,6 +115,14 @@ int mx_graph_read_output(mx_graph* g, uint32_t node, uint32_t port, float* host_
     return guard([&] { REQUIRE(g, "graph is NULL"); g->g->read_output(node, port, host_samples, n_ticks * g->g->spt()); });
 }
 
+int mx_graph_read_output_i16(mx_graph* g, uint32_t node, uint32_t port, int16_t* host_samples, size_t n_ticks) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->read_output_i16(node, port, host_samples, n_ticks * g->g->spt()); });
+}
+
+int mx_graph_write_source_i16(mx_graph* g, uint32_t node, const int16_t* host_samples, size_t n_ticks) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->write_source_i16(node, host_samples, n_ticks * g->g->spt()); });
+}
+
 int mx_graph_output_device_ptr(mx_graph* g, uint32_t node, uint32_t port, void** device_ptr, size_t* floats_per_tick) {
     return guard([&] {
         REQUIRE(g && device_ptr, "NULL argument");

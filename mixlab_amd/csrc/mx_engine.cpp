@@ -778,6 +778,35 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
     sync();
 }
 
+void Graph::read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t frames) {
+    if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
+    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
+    if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
+    const Node& n = nodes_[node];
+    if (n.out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
+    const size_t cnt = floats_per_frame(n.out_type[port]) * (frames * n.dom_num / n.dom_den);
+    if (!cnt) return;
+    if (conv_stage_.bytes < cnt * sizeof(int16_t)) { sync(); conv_stage_.alloc(cnt * sizeof(int16_t)); }
+    launch_f32_to_i16(out_ptr(n, port), (int16_t*)conv_stage_.p, cnt, n.out_dup[port] ? 1 : 0, stream_);
+    hip_check(hipMemcpyAsync(host, conv_stage_.p, cnt * sizeof(int16_t), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H i16)");
+    sync();
+}
+
+void Graph::write_source_i16(uint32_t node, const int16_t* host, size_t frames) {
+    if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
+    Node& n = nodes_[node];
+    if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
+    if (n.bound) throw Error(MX_ERR_INVALID, "source is bound to a caller device buffer");
+    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
+    if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
+    const size_t cnt = floats_per_frame(n.out_type[0]) * frames;
+    if (!cnt) return;
+    if (conv_stage_.bytes < cnt * sizeof(int16_t)) { sync(); conv_stage_.alloc(cnt * sizeof(int16_t)); }
+    hip_check(hipMemcpyAsync(conv_stage_.p, host, cnt * sizeof(int16_t), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D i16)");
+    launch_i16_to_f32((const int16_t*)conv_stage_.p, out_ptr(n, 0), cnt, stream_);
+    sync();   // host buffer is the caller's again on return
+}
+
 float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (nodes_[node].out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");

@@ -90,6 +90,8 @@ public:
     void profile_enable(bool on);
     uint32_t profile_collect(float* ms_by_kind, float* ms_total);   // syncs; returns number of runs collected
     void read_output(uint32_t node, uint32_t port, float* host, size_t frames);
+    void read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t frames);   // sink hand-off format
+    void write_source_i16(uint32_t node, const int16_t* host, size_t frames);            // ingest format
     float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_tick);
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
@@ -128,6 +130,7 @@ private:
     DevBuf eq_tabs_;              // EqScanTab[4] for L = 4, 8, 16, 32
     // plotter staging
     DevBuf plot_stage_, plot_jobs_;
+    DevBuf conv_stage_;           // i16 staging for sink / ingest conversions
     size_t last_frames_per_call_ = 0;
     bool prof_on_ = false;
     std::vector<std::vector<hipEvent_t>> prof_runs_;   // one event list (groups+1) per recorded run

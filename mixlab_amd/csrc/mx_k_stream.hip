@@ -159,4 +159,36 @@ void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s) {
     hipLaunchKernelGGL(k_plotter, grid, dim3(256), 0, s, d, spt);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sink / ingest sample formats (the data formats either side of the path):
+//   f32 -> i16: clamp to [-1, 1], * i16::MAX as f32, `as i16` (saturating, truncating, NaN -> 0)
+//               (src/video/encode.rs:183-195) -- done on the device so a sink reads back half the bytes
+//   i16 -> f32: sample as f32 / 32768.0 (src/module/stream_input.rs:167-173)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_f32_to_i16(const float* __restrict__ in, int16_t* __restrict__ out, size_t n, int dup) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = in[dup ? (i >> 1) : i];                    // dup: port stored as one float per frame (L == R)
+        s = s > 1.0f ? 1.0f : (s < -1.0f ? -1.0f : s);       // NaN stays NaN, as in the reference's comparisons
+        const float v = s * 32767.0f;
+        int r;
+        if (!(v == v)) r = 0;                                // Rust `as i16`: NaN -> 0
+        else if (v >= 32767.0f) r = 32767;
+        else if (v <= -32768.0f) r = -32768;
+        else r = (int)v;                                     // truncation toward zero
+        out[i] = (int16_t)r;
+    }
+}
+void launch_f32_to_i16(const float* in, int16_t* out, size_t n, int dup, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_f32_to_i16, dim3(grid_x(n, 256, 4096)), dim3(256), 0, s, in, out, n, dup);
+}
+__global__ __launch_bounds__(256) void k_i16_to_f32(const int16_t* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (float)in[i] / 32768.0f;
+}
+void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_i16_to_f32, dim3(grid_x(n, 256, 4096)), dim3(256), 0, s, in, out, n);
+}
+
 }  // namespace mx

@@ -224,6 +224,24 @@ int orc_plotter_run(orc_plotter* s, const float* in, float* left, float* right, 
     return 0;
 }
 
+/* AudioCtx::send_audio, src/video/encode.rs:183-195: clamp, * i16::max_value() as f32, `as i16`
+ * (Rust float->int casts saturate, truncate toward zero, and map NaN to 0) */
+void orc_f32_to_i16(const float* in, int16_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        float sample = in[i];
+        if (sample > 1.0f) sample = 1.0f; else if (sample < -1.0f) sample = -1.0f;
+        float v = sample * 32767.0f;
+        int r;
+        if (!(v == v)) r = 0; else if (v >= 32767.0f) r = 32767; else if (v <= -32768.0f) r = -32768; else r = (int)v;
+        out[i] = (int16_t)r;
+    }
+}
+/* convert_sample, src/module/stream_input.rs:167-173 */
+void orc_i16_to_f32(const int16_t* in, float* out, size_t n) {
+    float divisor = -(float)INT16_MIN;
+    for (size_t i = 0; i < n; i++) out[i] = (float)in[i] / divisor;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* BUILD-SPECIFIED: K-tap FIR on an interleaved stereo stream.  x[m < 0] = hist[(K-1) + m]. */
 static inline float fir_x(const float* hist, uint32_t H, const float* in, long long f, int ch) {

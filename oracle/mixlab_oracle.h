@@ -107,6 +107,10 @@ void orc_stereo_splitter_run(const float* in_stereo, float* l, float* r, size_t 
 typedef struct { uint64_t count; } orc_plotter;
 int orc_plotter_run(orc_plotter* s, const float* in_stereo /* NULL = disconnected */, float* left, float* right, size_t n);
 
+/* ---- sink / ingest sample formats ---- */
+void orc_f32_to_i16(const float* in, int16_t* out, size_t n);   /* src/video/encode.rs:183-195 */
+void orc_i16_to_f32(const int16_t* in, float* out, size_t n);   /* src/module/stream_input.rs:167-173 */
+
 /* ---- BUILD-SPECIFIED audio extras (no reference counterpart; DESIGN.md "FIR and resampler") ----
  * f32 widened to f64, accumulated in f64 in ascending tap index with separate multiply and add, rounded once.
  * hist: the (n_taps - 1) [resp. (P - 1)] stereo input frames before the call, interleaved; updated on return. */
