@@ -17,6 +17,7 @@ struct mx_graph { std::unique_ptr<Graph> g; };
 struct mx_module {
     uint32_t kind = 0;
     std::unique_ptr<Graph> g;   // node 0 = the module, node 1+i = SOURCE feeding input terminal i
+    std::unique_ptr<mx::VideoMixer> vm;   // MX_KIND_VIDEO_MIXER: host frames in, host frames out
     std::vector<uint8_t> in_type, out_type;
 };
 
@@ -185,6 +186,15 @@ int mx_module_create_ex(uint32_t kind, const void* params, size_t params_len, co
         *out = nullptr;
         auto m = std::make_unique<mx_module>();
         m->kind = kind;
+        if (kind == MX_KIND_VIDEO_MIXER) {   // src/module/video_mixer.rs: 4 video inputs, program + A + B outputs
+            REQUIRE(params && params_len == sizeof(mx_video_mixer_params), "params_len does not match mx_video_mixer_params");
+            mx_video_mixer_params p; std::memcpy(&p, params, sizeof p);
+            if (opts && opts->device >= 0) mx::hip_check(hipSetDevice(opts->device), "hipSetDevice");
+            m->in_type.assign(4, MX_VIDEO); m->out_type.assign(3, MX_VIDEO);
+            m->vm = std::make_unique<mx::VideoMixer>(p, opts ? opts->sample_rate : 0u, nullptr);
+            *out = m.release();
+            return;
+        }
         module_ports(kind, params_len, m->in_type, m->out_type);
         std::vector<mx_node> nodes(1 + m->in_type.size());
         std::vector<mx_edge> edges(m->in_type.size());
@@ -207,7 +217,16 @@ int mx_module_create(uint32_t kind, const void* params, size_t params_len, mx_mo
 }
 
 int mx_module_update(mx_module* m, const void* params, size_t params_len) {
-    return guard([&] { REQUIRE(m, "module is NULL"); m->g->update_params(0, params, params_len); });
+    return guard([&] {
+        REQUIRE(m, "module is NULL");
+        if (m->vm) {
+            REQUIRE(params && params_len == sizeof(mx_video_mixer_params), "params_len does not match mx_video_mixer_params");
+            mx_video_mixer_params p; std::memcpy(&p, params, sizeof p);
+            m->vm->update(p);
+            return;
+        }
+        m->g->update_params(0, params, params_len);
+    });
 }
 
 int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t n_inputs,
@@ -219,6 +238,49 @@ int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t 
         REQUIRE(!n_inputs || inputs, "inputs is NULL");
         REQUIRE(!n_outputs || outputs, "outputs is NULL");
         if (indication_len) *indication_len = 0;
+        if (m->vm) {   // VideoMixer::run_tick on host frames: upload, run on the device, download what the caller has room for
+            hipStream_t st = m->vm->stream();
+            mx::VideoInput vin[4];
+            mx::FrameRef keep[4];
+            for (size_t i = 0; i < 4; ++i) {
+                if (inputs[i].kind == MX_DISCONNECTED || !inputs[i].video) continue;          // Disconnected / Video(None), io.rs:54-61
+                if (inputs[i].kind != MX_VIDEO) throw Error(MX_ERR_TYPE, "input line type mismatch");
+                const mx_frame* hf = inputs[i].video;
+                keep[i] = mx::FrameRef(mx::DFrame::create(hf->width, hf->height, st), false);
+                for (int p = 0; p < 3; ++p) {
+                    REQUIRE(hf->data[p] && hf->stride[p] >= (int32_t)keep[i]->pw(p), "host frame plane is NULL or its stride is smaller than the width");
+                    mx::hip_check(hipMemcpy2DAsync(keep[i]->data[p], keep[i]->stride[p], hf->data[p], (size_t)hf->stride[p], keep[i]->pw(p), keep[i]->ph(p),
+                                                   hipMemcpyHostToDevice, st), "hipMemcpy2DAsync(H2D frame)");
+                }
+                vin[i].frame = keep[i].f;
+                vin[i].duration_hint = mx::Rational::make(hf->dur_num, hf->dur_den ? hf->dur_den : 1);
+                vin[i].tick_offset = mx::Rational::make(hf->off_num, hf->off_den ? hf->off_den : 1);
+            }
+            mx::FrameRef res[3];
+            m->vm->run_tick(t, vin, res[0], res[1], res[2]);
+            mx::flush_scales(st);
+            for (size_t i = 0; i < 3; ++i) {
+                if ((uint8_t)outputs[i].kind != MX_VIDEO) throw Error(MX_ERR_TYPE, "output line type mismatch");
+                outputs[i].video_present = 0;
+                if (!res[i] || !outputs[i].video) continue;
+                mx_frame* hf = outputs[i].video;      // on entry width/height = capacity of the caller's planes
+                if (hf->width < res[i]->width || hf->height < res[i]->height) throw Error(MX_ERR_INVALID, "output frame buffer is smaller than the composed picture");
+                res[i]->ensure_pixels(st);
+                for (int p = 0; p < 3; ++p) {
+                    REQUIRE(hf->data[p] && hf->stride[p] >= (int32_t)res[i]->pw(p), "host frame plane is NULL or its stride is smaller than the width");
+                    mx::hip_check(hipMemcpy2DAsync(hf->data[p], (size_t)hf->stride[p], res[i]->data[p], res[i]->stride[p], res[i]->pw(p), res[i]->ph(p),
+                                                   hipMemcpyDeviceToHost, st), "hipMemcpy2DAsync(D2H frame)");
+                }
+                hf->width = res[i]->width; hf->height = res[i]->height;
+                if (i == 0) { hf->dur_num = 1; hf->dur_den = 60; hf->off_num = 0; hf->off_den = 1; }     // video_mixer.rs:241-247
+                else { const int src = (i == 1) ? m->vm->param_a() : m->vm->param_b();                      // clone of the input VideoFrame (:80-90)
+                       if (src >= 0 && src < 4 && inputs[src].video) { hf->dur_num = inputs[src].video->dur_num; hf->dur_den = inputs[src].video->dur_den;
+                                                                       hf->off_num = inputs[src].video->off_num; hf->off_den = inputs[src].video->off_den; } }
+                outputs[i].video_present = 1;
+            }
+            mx::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+            return;
+        }
 
         // all terminals must agree on the number of frames in this call
         size_t frames = 0; bool have = false;

@@ -170,6 +170,8 @@ public:
     // returns program / A / B frames (null FrameRef = None)
     void run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, FrameRef& out_a, FrameRef& out_b);
     hipStream_t stream() const { return stream_; }
+    int param_a() const { return params_.a; }
+    int param_b() const { return params_.b; }
 private:
     struct Stored { Rational active_until; FrameRef frame; };
     struct Channel { bool has_stored = false; Stored stored; std::unique_ptr<Scaler> scaler; };
