@@ -691,7 +691,21 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_EQ_THREE:
             if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
-            else launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, stream_);
+            else {
+                EqSplit sp{1u, 0u, gf, nullptr, nullptr, nullptr};
+                EqSpanPow pp{};
+                eq_plan_split(n, gf, sp.n_split, sp.span);
+                if (sp.n_split > 1) {   // few instances, long streams: cut each stream into spans for different workgroups
+                    const size_t need = (size_t)n * sp.n_split * (8 + 12) * sizeof(double) + (size_t)n * sizeof(EnvState);
+                    if (g.extra.bytes < need || !g.extra.p) { sync(); g.extra.alloc(need); }
+                    sp.zbuf = (double*)g.extra.p;
+                    sp.bound = sp.zbuf + (size_t)n * sp.n_split * 8;
+                    sp.env_snap = (EnvState*)(sp.bound + (size_t)n * sp.n_split * 12);
+                    toeplitz_pow((long double)lo_f_, sp.span, pp.lo);
+                    toeplitz_pow((long double)hi_f_, sp.span, pp.hi);
+                }
+                launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, sp, pp, stream_);
+            }
             break;
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, gf, g.dup_mode, stream_); break;

@@ -16,10 +16,10 @@ namespace mx {
 // (envelope.rs:34-58,117) would do to the f32 sample y the EQ just produced.
 struct EnvCtx { uint32_t tag; uint64_t seq; double off_amp; uint64_t t0; double sr, rsr; };
 
-__device__ __forceinline__ EnvCtx env_ctx_begin(const EqDesc& d, uint64_t t0, double sr, double rsr) {
+__device__ __forceinline__ EnvCtx env_ctx_begin(const EqDesc& d, const EnvState* es, uint64_t t0, double sr, double rsr) {
     EnvCtx ec{0u, 0ull, 0.0, t0, sr, rsr};
     if (d.flags & MX_EQF_ENV) {
-        ec.tag = d.env_state->tag; ec.seq = d.env_state->seq; ec.off_amp = d.env_state->off_amplitude;
+        ec.tag = es->tag; ec.seq = es->seq; ec.off_amp = es->off_amplitude;
         env_const_gate_step(d.env, d.env_gate, t0, sr, rsr, ec.tag, ec.seq, ec.off_amp);   // only the run's first sample can flip it
     }
     return ec;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
     const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= n_inst) return;
     const EqDesc d = descs[inst];
-    const EnvCtx ec = env_ctx_begin(d, t0, sr, rsr);
+    const EnvCtx ec = env_ctx_begin(d, d.env_state, t0, sr, rsr);
     EqState st = states[inst];
     double lo[4] = {st.lo[0], st.lo[1], st.lo[2], st.lo[3]};
     double hi[4] = {st.hi[0], st.hi[1], st.hi[2], st.hi[3]};
@@ -126,10 +126,17 @@ __device__ __forceinline__ void toep_apply(const double* c, const double (&v)[4]
     y[3] = fma(c[3], v[0], fma(c[2], v[1], fma(c[1], v[2], c[0] * v[3])));
 }
 
-template <int LOG2L>
+// MODE 0: one workgroup walks the whole stream of its instance (enough instances to fill the chip).
+// Few instances, long streams (a sharded rank, a small graph): the stream is cut into n_split spans handled by
+// different workgroups --
+//   MODE 1 (pre-pass, spans 0 .. n_split-2): stage-in + phase A + scan only; leaves the state a zero-initialised
+//          filter reaches at the end of the span (zbuf);
+//   k_eq_boundaries: folds them into the true state at every span start (bound), snapshots the Envelope state;
+//   MODE 2 (main): like MODE 0 on one span, starting from bound.
+template <int LOG2L, int MODE>
 __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
                                                            size_t frames, uint64_t t0, double sr, double rsr, double lo_f, double hi_f,
-                                                           const EqScanTab* __restrict__ tab) {
+                                                           const EqScanTab* __restrict__ tab, EqSplit sp) {
     constexpr int L = 1 << LOG2L;
     constexpr int SEG = 256 * L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,9 +155,9 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     const EqDesc* dp = descs + blockIdx.x;
     const float* __restrict__ din = dp->in;
     const double g_lo = dp->gain_lo, g_mid = dp->gain_mid, g_hi = dp->gain_hi;
-    if (tid == 0) {
+    if (MODE != 1 && tid == 0) {
         const EqDesc d = *dp;
-        const EnvCtx ec = env_ctx_begin(d, t0, sr, rsr);
+        const EnvCtx ec = env_ctx_begin(d, MODE == 2 ? sp.env_snap + blockIdx.x : d.env_state, t0, sr, rsr);
         EqEpi e;
         e.out = d.out; e.ctl = d.ctl; e.amp_one_minus = d.amp_one_minus; e.amp_mod_depth = d.amp_mod_depth; e.amp_amplitude = d.amp_amplitude;
         e.env = d.env; e.off_amp = ec.off_amp; e.seq = ec.seq; e.tag = ec.tag; e.epi = d.epi; e.flags = d.flags;
@@ -159,14 +166,18 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     // tables and the carried state live in LDS, not in registers, across the segment loop
     for (int i = tid; i < 2 * 65 * 4; i += 256) pw[i] = (&tab->pw[0][0][0])[i];
     if (tid < 2 * 6 * 4) p2[tid] = (&tab->p2[0][0][0])[tid];
+    const uint32_t span_idx = MODE == 0 ? 0u : blockIdx.y;
     if (tid < 11) {
-        const double* st = reinterpret_cast<const double*>(&states[blockIdx.x]);   // lo[4] hi[4] history[3]
-        carry[tid] = st[tid];
+        if (MODE == 0) carry[tid] = reinterpret_cast<const double*>(&states[blockIdx.x])[tid];   // lo[4] hi[4] history[3]
+        else if (MODE == 1) carry[tid] = 0.0;
+        else carry[tid] = sp.bound[((size_t)blockIdx.x * sp.n_split + span_idx) * 12 + tid];
     }
     __syncthreads();
+    const size_t s_begin = MODE == 0 ? 0 : (size_t)span_idx * sp.span;
+    const size_t s_end = MODE == 0 ? frames : (s_begin + sp.span < frames ? s_begin + sp.span : frames);
 
-    for (size_t base = 0; base < frames; base += SEG) {
-        const size_t rem = frames - base;
+    for (size_t base = s_begin; base < s_end; base += SEG) {
+        const size_t rem = s_end - base;
         const int nv = rem < (size_t)SEG ? (int)rem : SEG;
         // stage-in by LDS-DMA: each wave issues L `global_load_lds_dword` (256 B each), no VGPRs involved
         if (din) {
@@ -251,6 +262,20 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
             toep_apply(pw + (1 * 65 + lane) * 4, ch, th);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { lo[q] = tl[q] + el[q]; hi[q] = th[q] + eh[q]; }
+        }
+        if (MODE == 1) {
+            // pre-pass: the span consists of full segments; the state at the segment's end is the end state of chunk 255
+            //   = P^(64) C_3 + E_63 (lane 63 of wave 3).  No phase C, nothing is emitted.
+            __syncthreads();
+            if (tid == 255) {
+                double tl[4], th[4];
+                toep_apply(pw + (0 * 65 + 64) * 4, cl, tl);
+                toep_apply(pw + (1 * 65 + 64) * 4, ch, th);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { carry[q] = tl[q] + zl[q]; carry[4 + q] = th[q] + zh[q]; }
+            }
+            __syncthreads();
+            continue;
         }
         // phase C: exact recurrence from the true state, outputs overwrite my chunk of the tile
 #pragma unroll 4
@@ -337,11 +362,42 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
         }
         __syncthreads();
     }
+    if (MODE == 1) {
+        if (tid < 8) sp.zbuf[((size_t)blockIdx.x * sp.n_split + span_idx) * 8 + tid] = carry[tid];
+        return;
+    }
+    if (MODE == 2 && span_idx + 1 != sp.n_split) return;   // only the last span owns the carried state
     if (tid < 11) reinterpret_cast<double*>(&states[blockIdx.x])[tid] = carry[tid];
     if (tid == 0 && (epi_lds->flags & MX_EQF_ENV)) {
         EnvState* es = dp->env_state;
         es->tag = epi_lds->tag; es->seq = epi_lds->seq; es->off_amplitude = epi_lds->off_amp;
     }
+}
+
+// true state at the start of every span: S_0 = carried state, S_{s+1} = A^span S_s + Z_s; the 3-sample delay
+// line at a span start is simply the three input samples before it
+__global__ __launch_bounds__(64) void k_eq_boundaries(const EqDesc* __restrict__ descs, const EqState* __restrict__ states,
+                                                       uint32_t n_inst, EqSplit sp, EqSpanPow pp) {
+    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= n_inst) return;
+    const EqDesc d = descs[inst];
+    const EqState st = states[inst];
+    double lo[4] = {st.lo[0], st.lo[1], st.lo[2], st.lo[3]}, hi[4] = {st.hi[0], st.hi[1], st.hi[2], st.hi[3]};
+    double h[3] = {st.history[0], st.history[1], st.history[2]};
+    for (uint32_t s = 0; s < sp.n_split; ++s) {
+        double* b = sp.bound + ((size_t)inst * sp.n_split + s) * 12;
+        for (int q = 0; q < 4; ++q) { b[q] = lo[q]; b[4 + q] = hi[q]; }
+        b[8] = h[0]; b[9] = h[1]; b[10] = h[2]; b[11] = 0.0;
+        if (s + 1 == sp.n_split) break;
+        const double* z = sp.zbuf + ((size_t)inst * sp.n_split + s) * 8;
+        double tl[4], th[4];
+        toep_apply(pp.lo, lo, tl);
+        toep_apply(pp.hi, hi, th);
+        for (int q = 0; q < 4; ++q) { lo[q] = tl[q] + z[q]; hi[q] = th[q] + z[4 + q]; }
+        const size_t nb = (size_t)(s + 1) * sp.span;       // first sample of the next span (span >= 1024 > 3)
+        for (int q = 0; q < 3; ++q) h[q] = d.in ? (double)d.in[nb - 3 + q] : 0.0;
+    }
+    if (d.flags & MX_EQF_ENV) sp.env_snap[inst] = *d.env_state;
 }
 
 int eq_scan_log2l(size_t frames) {
@@ -352,17 +408,38 @@ int eq_scan_log2l(size_t frames) {
 }
 
 void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
-                          const EqScanTab* tabs /* indexed by log2L - 2 */, hipStream_t s) {
+                          const EqScanTab* tabs /* indexed by log2L - 2 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s) {
     if (!n || !frames) return;
-    const int l2 = eq_scan_log2l(frames);
+    const int l2 = eq_scan_log2l(split.n_split > 1 ? split.span : frames);
     const size_t lds = (size_t)256 * (1u << l2) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + sizeof(EqEpi);
     const EqScanTab* tab = tabs + (l2 - 2);
-    switch (l2) {
-    case 2: hipLaunchKernelGGL(k_eq_three_scan<2>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
-    case 3: hipLaunchKernelGGL(k_eq_three_scan<3>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
-    case 4: hipLaunchKernelGGL(k_eq_three_scan<4>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
-    default: hipLaunchKernelGGL(k_eq_three_scan<5>, dim3(n), dim3(256), lds, s, d, st, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f, tab); break;
+    const double rsr = 1.0 / sample_rate;
+#define MX_EQ_GO(L2, MODE, GRID) hipLaunchKernelGGL((k_eq_three_scan<L2, MODE>), GRID, dim3(256), lds, s, d, st, frames, t0, sample_rate, rsr, lo_f, hi_f, tab, split)
+#define MX_EQ_MODE(MODE, GRID) switch (l2) { case 2: MX_EQ_GO(2, MODE, GRID); break; case 3: MX_EQ_GO(3, MODE, GRID); break; case 4: MX_EQ_GO(4, MODE, GRID); break; default: MX_EQ_GO(5, MODE, GRID); break; }
+    if (split.n_split <= 1) {
+        MX_EQ_MODE(0, dim3(n));
+    } else {
+        MX_EQ_MODE(1, dim3(n, split.n_split - 1));
+        hipLaunchKernelGGL(k_eq_boundaries, dim3((n + 63) / 64), dim3(64), 0, s, d, (const EqState*)st, n, split, pp);
+        MX_EQ_MODE(2, dim3(n, split.n_split));
     }
+#undef MX_EQ_MODE
+#undef MX_EQ_GO
+}
+
+// span plan for n instances of `frames` samples: enough workgroups to cover the chip, spans are whole segments
+void eq_plan_split(uint32_t n, size_t frames, uint32_t& n_split, size_t& span) {
+    n_split = 1; span = frames;
+    const int force = env_int("MX_EQ_SPLIT", 0);          // tuning / test override (read per call: tests flip it)
+    uint32_t want = force > 0 ? (uint32_t)force : (n >= 512 ? 1u : 1024u / (n ? n : 1));
+    if (want > 16) want = 16;
+    if (want < 2) return;
+    const size_t seg = (size_t)256 << 5;                  // spans are planned on the largest segment size
+    size_t sp = (frames + want - 1) / want;
+    sp = (sp + seg - 1) / seg * seg;
+    if (sp >= frames) return;                             // stream too short to cut
+    span = sp;
+    n_split = (uint32_t)((frames + sp - 1) / sp);
 }
 
 }  // namespace mx
