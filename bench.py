@@ -241,37 +241,51 @@ def main():
     # N > 1: partial buses -> all_gather -> rank-ordered Mixer(N, unity gains) on every rank
     combine = None
     if use_dist:
+        # The exchange is pipelined against the next step's compute: partial buses are packed into one of two
+        # buffers on the compute stream, and a second stream all-gathers them and runs the rank-ordered Mixer(N)
+        # while the compute stream is already on step i+1.  Steady-state step time = max(compute, exchange).
         m_ptr, fpt = g.output_device_ptr(mix, 0)
         c_ptr, _ = g.output_device_ptr(mix, 1)
         n_fl = fpt * T
         part_len, offs = shard.packed_layout(world, n_fl)
-        part = torch.empty(part_len, dtype=torch.float32, device="cuda")
-        gathered = torch.empty(world * part_len, dtype=torch.float32, device="cuda")
-        cws = Workspace(SR, 60)
-        fm = cws.mixer(shard.combine_channels(world))   # unity gains: the f32 sum of partials in rank order
-        fc = cws.mixer(shard.combine_channels(world))
-        c_srcs_m = [cws.source_stereo() for _ in range(world)]
-        c_srcs_c = [cws.source_stereo() for _ in range(world)]
-        for r in range(world):
-            cws.connect(c_srcs_m[r], 0, fm, r)
-            cws.connect(c_srcs_c[r], 0, fc, r)
-        cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
-        for r in range(world):
-            cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + offs[r][0] * 4)
-            cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + offs[r][1] * 4)
         m_view, c_view = dev_view(torch, m_ptr, n_fl), dev_view(torch, c_ptr, n_fl)
+        comm = torch.cuda.Stream()
+        slots = []
+        for _slot in range(2):
+            part = torch.empty(part_len, dtype=torch.float32, device="cuda")
+            gathered = torch.empty(world * part_len, dtype=torch.float32, device="cuda")
+            cws = Workspace(SR, 60)
+            fm = cws.mixer(shard.combine_channels(world))   # unity gains: the f32 sum of partials in rank order
+            fc = cws.mixer(shard.combine_channels(world))
+            c_srcs_m = [cws.source_stereo() for _ in range(world)]
+            c_srcs_c = [cws.source_stereo() for _ in range(world)]
+            for r in range(world):
+                cws.connect(c_srcs_m[r], 0, fm, r)
+                cws.connect(c_srcs_c[r], 0, fc, r)
+            cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=comm.cuda_stream)
+            for r in range(world):
+                cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + offs[r][0] * 4)
+                cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + offs[r][1] * 4)
+            slots.append({"part": part, "gathered": gathered, "cg": cg, "packed": torch.cuda.Event(), "done": torch.cuda.Event(), "used": False})
 
-        def combine():
-            # device-to-device pack of (master, cue), then ONE all_gather per step, stream-ordered
-            part[:n_fl].copy_(m_view)
-            part[n_fl:].copy_(c_view)
-            dist.all_gather_into_tensor(gathered, part)
-            cg.run_ticks(0, T)
+        def combine(i):
+            sl = slots[i % 2]
+            if sl["used"]:
+                stream.wait_event(sl["done"])          # the exchange that last used this slot has finished
+            sl["part"][:n_fl].copy_(m_view)            # device-to-device pack of (master, cue) on the compute stream
+            sl["part"][n_fl:].copy_(c_view)
+            sl["packed"].record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(sl["packed"])
+                dist.all_gather_into_tensor(sl["gathered"], sl["part"])   # ONE all-gather per step (RCCL over xGMI)
+                sl["cg"].run_ticks(0, T)                                   # rank-ordered f32 sum: Mixer(N, unity)
+                sl["done"].record(comm)
+            sl["used"] = True
 
     def step(i):
         g.run_ticks(i * T, T)
         if combine is not None:
-            combine()
+            combine(i)
 
     def barrier():
         if world > 1:
