@@ -178,6 +178,22 @@ def dev_view(torch, ptr, n):
     return torch.as_tensor(_DevArray(ptr, n), device="cuda")
 
 
+def pmc_traffic(dom, args, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json,
+    collected with this same command under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`); None when the run's configuration
+    differs from the profiled one -- counters cannot be read from inside the process."""
+    try:
+        rec = json.load(open(ROOT / "profiles" / "r01" / "pmc_traffic.json"))
+    except (OSError, ValueError):
+        return None, None
+    c = rec.get("config", {})
+    same = (c.get("strips") == args.strips and c.get("ticks_per_step") == args.ticks_per_step and c.get("sample_rate") == args.sample_rate
+            and c.get("fused") == (not args.no_fuse) and c.get("eq_exact") == bool(args.eq_exact) and c.get("n_gpus") == world)
+    if not same or dom not in rec.get("bytes_per_launch", {}):
+        return None, None
+    return rec["bytes_per_launch"][dom], "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -332,12 +348,21 @@ def main():
             else:
                 alg = bpf.get(dom, 0) * local_strips * frames
             ach = alg / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(dom, args, world)
             roof = {"kernel": dom + ("" if args.no_fuse or dom == "mixer" else " (fused group)"), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": alg,
                     "kernel_ms_per_step": {k: round(v / n_prof, 5) for k, v in sorted(by_kind.items())},
                     "limiter": ("f64 VALU issue + dependent-chain latency of the 8-pole recurrence (PMC: VALU busy ~55% of the kernel, "
-                                "traffic = 1.2x algorithmic); HBM is the roof only nominally" if dom == "eq_three" else "HBM")}
+                                "traffic = 1.02x algorithmic); HBM is the roof only nominally" if dom == "eq_three" else "HBM")}
+            if dom == "eq_three" and not args.eq_exact:
+                # the bound that actually applies: f64 VALU.  ~52 f64 instructions per sample: exact recurrence 8 poles x
+                # (sub, mul, add) = 24, band split + gains + conversions ~12, chunk-state dot products 8 (FMA), scan hops ~4,
+                # fused epilogue ~4.  Peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T f64 instructions/s
+                f64_ops = 52.0 * local_strips * frames
+                roof["f64_valu"] = {"ops_per_launch": f64_ops, "achieved_tops": round(f64_ops / (avg_ms * 1e-3) / 1e12, 2),
+                                    "peak_tops": 39.3, "frac": round(f64_ops / (avg_ms * 1e-3) / 1e12 / 39.3, 3),
+                                    "note": "f64 VALU instruction rate (an FMA counts once); per-sample count is analytic, see DESIGN.md 5.2"}
         # bytes of one step on one rank: module-boundary accounting (every port materialised) and, when the
         # graph compiler fused, the bytes the fused kernels actually have to move
         whole_alg = 51200 * (SR / 48000.0) * local_strips * T
