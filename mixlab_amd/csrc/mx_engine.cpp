@@ -646,6 +646,8 @@ void Graph::ensure_capacity(size_t frames) {
     build_descriptors();
 }
 
+static bool group_launches(const Group& g);
+
 void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, float* ms_total) {
     const size_t frames = fpc * (size_t)n_calls;
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "n_ticks exceeds max_ticks_per_run");
@@ -692,15 +694,15 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         case MX_KIND_EQ_THREE:
             if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
             else {
-                EqSplit sp{1u, 0u, gf, nullptr, nullptr, nullptr};
+                EqSplit sp{1u, 5u, gf, gf, nullptr, nullptr, nullptr};
                 EqSpanPow pp{};
-                eq_plan_split(n, gf, sp.n_split, sp.span);
+                eq_plan_split(n, gf, lo_f_, hi_f_, sp);
                 if (sp.n_split > 1) {   // few instances, long streams: cut each stream into spans for different workgroups
-                    const size_t need = (size_t)n * sp.n_split * (8 + 12) * sizeof(double) + (size_t)n * sizeof(EnvState);
+                    const size_t need = (size_t)n * sp.n_split * 8 * sizeof(double) + (size_t)n * 12 * sizeof(double) + (size_t)n * sizeof(EnvState);
                     if (g.extra.bytes < need || !g.extra.p) { sync(); g.extra.alloc(need); }
-                    sp.zbuf = (double*)g.extra.p;
-                    sp.bound = sp.zbuf + (size_t)n * sp.n_split * 8;
-                    sp.env_snap = (EnvState*)(sp.bound + (size_t)n * sp.n_split * 12);
+                    sp.zbuf = (double*)g.extra.p;                         // [n][n_split][8] zero-state span end states
+                    sp.bound = sp.zbuf + (size_t)n * sp.n_split * 8;      // [n][12] snapshot of the carried EqState
+                    sp.env_snap = (EnvState*)(sp.bound + (size_t)n * 12); // [n] snapshot of the carried EnvelopeState
                     toeplitz_pow((long double)lo_f_, sp.span, pp.lo);
                     toeplitz_pow((long double)hi_f_, sp.span, pp.hi);
                 }
@@ -740,18 +742,27 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         }
         default: break;
         }
-        if (prof) hip_check(hipEventRecord(ev[gi + 1], stream_), "hipEventRecord");
+        // an event costs ~5 us of stream time: none for groups that launch nothing (sources, video kinds)
+        if (prof && group_launches(g)) hip_check(hipEventRecord(ev[gi + 1], stream_), "hipEventRecord");
         ++gi;
     }
     // video sub-graph: tick by tick (frames arrive per tick; nothing to batch over time)
     if (has_video_) { for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc); flush_scales(stream_); }
-    if (prof) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
+    if (prof && has_video_) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
     hip_check(hipGetLastError(), "kernel launch");
     last_calls_ = n_calls;
     last_frames_per_call_ = fpc;
 
     if (prof) prof_runs_.push_back(std::move(ev));
     if (ms_by_kind) (void)profile_collect(ms_by_kind, ms_total);
+}
+
+static bool group_launches(const Group& g) {
+    switch (g.kind) {
+    case MX_KIND_SOURCE_MONO: case MX_KIND_SOURCE_STEREO: case MX_KIND_SOURCE_VIDEO:
+    case MX_KIND_VIDEO_MIXER: case MX_KIND_VIDEO_TO_RGBA: return false;   // bound buffers / the per-tick video section
+    default: return true;
+    }
 }
 
 void Graph::profile_enable(bool on) { prof_on_ = on; }
@@ -762,12 +773,16 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
     if (ms_total) *ms_total = 0.f;
     const uint32_t n = (uint32_t)prof_runs_.size();
     for (auto& ev : prof_runs_) {
+        size_t last = 0;   // index of the latest event that was recorded in this run
         for (size_t i = 0; i + 1 < ev.size() && i <= groups_.size(); ++i) {
+            const bool recorded = i < groups_.size() ? group_launches(groups_[i]) : has_video_;
+            if (!recorded) continue;
             float ms = 0.f;
-            hip_check(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "hipEventElapsedTime");
+            hip_check(hipEventElapsedTime(&ms, ev[last], ev[i + 1]), "hipEventElapsedTime");
             if (ms_by_kind) ms_by_kind[i < groups_.size() ? groups_[i].kind : (uint32_t)MX_KIND_VIDEO_MIXER] += ms;
+            last = i + 1;
         }
-        if (ms_total) { float ms = 0.f; hip_check(hipEventElapsedTime(&ms, ev.front(), ev.back()), "hipEventElapsedTime"); *ms_total += ms; }
+        if (ms_total) { float ms = 0.f; hip_check(hipEventElapsedTime(&ms, ev.front(), ev[last]), "hipEventElapsedTime"); *ms_total += ms; }
         prof_pool_.push_back(std::move(ev));
     }
     prof_runs_.clear();

@@ -49,7 +49,8 @@ struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };  
 struct EqScanTab { double pw[2][65][4]; double p2[2][6][4]; double h[2][32][4]; double cz[2][4]; };
 
 // time-split plan of the scan kernel (see k_eq_three_scan MODE 1/2): wave-uniform kernel arguments
-struct EqSplit { uint32_t n_split; uint32_t pad; size_t span; double* zbuf /* [n][n_split][8] */; double* bound /* [n][n_split][12] */; EnvState* env_snap /* [n] */; };
+// warm / l2_pre: the pre-pass runs over the last `warm` samples of a span only (whole segments of 256 << l2_pre); see eq_plan_split
+struct EqSplit { uint32_t n_split; uint32_t l2_pre; size_t span; size_t warm; double* zbuf /* [n][n_split][8] */; double* bound /* [n][12] */; EnvState* env_snap /* [n] */; };
 struct EqSpanPow { double lo[4], hi[4]; };   // first column of A^span per filter (host, long double)
 
 // src/module/fm_sine.rs:37-56
@@ -84,7 +85,7 @@ void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t fram
 int eq_scan_log2l(size_t frames);
 void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s);
-void eq_plan_split(uint32_t n, size_t frames, uint32_t& n_split, size_t& span);
+void eq_plan_split(uint32_t n, size_t frames, double lo_f, double hi_f, EqSplit& sp);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, int dup_mode /* 0 none, 1 all, 2 mixed */, hipStream_t s);
 void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);

@@ -434,6 +434,34 @@ def test_eq_three_time_split_within_one_ulp_and_state_carries(n_inst, T, force, 
     assert diffs <= max(3, 3 * n_inst * T * SPT // 20000)
 
 
+def test_eq_three_prepass_window_equals_full_prepass(monkeypatch):
+    # the pre-pass reads only the tail of each span (what the poles have not forgotten, < 2^-280 left out):
+    # the result must be the very bits the full-span pre-pass gives, bursts of 1e30 followed by 1e-30 included
+    n_inst, T = 4, 80
+    ws = Workspace(SR, 60)
+    gains = synth.uniform(81, 3 * n_inst, -24.0, 6.0)
+    srcs, eqs = [], []
+    for k in range(n_inst):
+        s = ws.source_mono(); e = ws.eq_three(*[float(v) for v in gains[3 * k:3 * k + 3]])
+        ws.connect(s, 0, e, 0); srcs.append(s); eqs.append(e)
+    noise = [synth.noise(500 + k, 2 * T * SPT) for k in range(n_inst)]
+    noise[1] = noise[1].copy(); noise[1][10000:10050] *= np.float32(1e30); noise[1][10050:30000] *= np.float32(1e-30)
+    noise[2] = (noise[2] * np.float32(1e-20)).astype(np.float32)
+    monkeypatch.setenv("MX_EQ_SPLIT", "4")
+    outs = []
+    for full in ("1", "0"):
+        monkeypatch.setenv("MX_EQ_FULL_PREPASS", full)
+        g = ws.build(max_ticks_per_run=T)
+        res = []
+        for run in range(2):
+            for k, s in enumerate(srcs):
+                g.write_source(s, noise[k][run * T * SPT:(run + 1) * T * SPT], T)
+            g.run_ticks(run * T, T)
+            res.append(np.concatenate([g.read_output(e, 0, T, False) for e in eqs]))
+        outs.append(np.concatenate(res))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
 def test_fused_strips_with_time_split_equal_unsplit(monkeypatch):
     # the whole fused strip (inline Envelope, Amplifier, mono-stored result) through the split path
     ws, mix, srcs, trigs = strips(6)
