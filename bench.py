@@ -97,6 +97,48 @@ def cpu_baseline(Workspace, synth, abi, n_strips, sample_rate, target_seconds=12
     }
 
 
+def cpu_baseline_all_cores(Workspace, synth, abi, shard, n_strips, sample_rate, per_strip_tick_s, target_seconds=6.0):
+    """The same CPU oracle, one graph shard per host core (SURVEY.md section 8d "(ii)"): the strips are partitioned like
+    the multi-GPU job (contiguous shards, each with its own sub-Mixer); ctypes releases the GIL, so plain threads run
+    the C runners concurrently.  The final Mixer(shards) over the partial buses is not included (negligible)."""
+    import threading
+
+    import oracle  # test infrastructure: used here only as the timed CPU baseline
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    n_thr = max(1, min(cores, n_strips))
+    shards = []
+    for r in range(n_thr):
+        first, cnt = shard.strip_range(r, n_thr, n_strips)
+        ws, _mix, srcs = build_strips(abi, Workspace, synth, cnt, first, sample_rate)
+        og = oracle.OracleGraph(ws)
+        for j, sn in enumerate(srcs):
+            og.set_source(sn, synth.noise(first + j, ws.spt))
+        shards.append(og)
+    worst = max(1, (n_strips + n_thr - 1) // n_thr)
+    n_ticks = int(max(4, min(4000, target_seconds / max(per_strip_tick_s * worst, 1e-7))))
+    go = threading.Barrier(n_thr + 1)
+
+    def work(og):
+        go.wait()
+        for t in range(n_ticks):
+            og.run_tick(t)
+
+    th = [threading.Thread(target=work, args=(og,)) for og in shards]
+    for t in th:
+        t.start()
+    go.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": n_strips * n_ticks / dt, "unit": "channel-ticks/s", "cores": n_thr, "kind": "port",
+            "sample": f"{n_strips} strips in {n_thr} contiguous shards (one thread each) x {n_ticks} ticks @ {sample_rate} Hz, {dt:.1f} s"}
+
+
 VIDEO_FADERS = [1.0, 0.75, 0.5, 0.5, 0.25, 0.9, 0.1]
 VIDEO_MATRIX = [3900, 150, 46, 4096, 60, 3980, 56, -2048, 20, 120, 3956, 0]
 
@@ -345,6 +387,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # real-time regime: one 60 Hz tick per submission, synchronised every tick like a live engine
+    realtime = None
+    if not use_dist:
+        with torch.cuda.stream(stream):
+            base_t = (args.warmup + args.steps + 4) * T
+            for i in range(20):
+                g.run_ticks(base_t + i, 1)
+            g.sync()
+            n_rt = 300
+            t0 = time.perf_counter()
+            for i in range(n_rt):
+                g.run_ticks(base_t + 20 + i, 1)
+                g.sync()
+            tick_us = (time.perf_counter() - t0) / n_rt * 1e6
+        realtime = {"ticks_per_submission": 1, "tick_us": round(tick_us, 1), "tick_budget_us": round(1e6 / 60.0, 1),
+                    "headroom": round(1e6 / 60.0 / tick_us, 1), "note": "submit + wait per tick (host-paired), same 1024-strip graph"}
+
     video = None
     if args.video_frames > 0:
         with torch.cuda.stream(stream):
@@ -399,12 +458,15 @@ def main():
             "graph_hbm_frac_module_boundary_bytes": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "graph_hbm_frac_moved_bytes": round((whole_alg if args.no_fuse else fused_alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
+            "realtime": realtime,
             "video": video,
         }
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(Workspace, synth, abi, shard, args.strips, SR,
+                                                                   1.0 / max(out["cpu_baseline"]["value"], 1.0))
         # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe):
         # drain it first so the JSON line is the LAST line of stdout
         import ctypes
