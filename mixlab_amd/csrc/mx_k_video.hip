@@ -93,14 +93,12 @@ __device__ __forceinline__ void chain_eval(uint32_t (&v)[NW], const uint32_t (*L
 #pragma unroll
     for (int k = 1; k < MX_CHAIN_MAX_SRC; ++k) {
         if (k < (int)n_src) {
-            const unsigned short f = (unsigned short)fade[k - 1], g = (unsigned short)(255u - fade[k - 1]);
+            // fade(a, b; f, 255 - f) with the running value as B is fade(running, other; 255 - f, f): which side the
+            // running value sits on only swaps the two (wave-uniform) factors, never the per-pixel code
+            const unsigned short f = (unsigned short)(v_is_a[k - 1] ? fade[k - 1] : 255u - fade[k - 1]), g = (unsigned short)(255u - f);
             const u16x2 fa = {f, f}, fb = {g, g};
-            const bool va = v_is_a[k - 1] != 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const Px4 o = px4_unpack(L[k][w]);
-                acc[w] = va ? fade_px4(acc[w], o, fa, fb) : fade_px4(o, acc[w], fa, fb);
-            }
+            for (int w = 0; w < NW; ++w) acc[w] = fade_px4(acc[w], px4_unpack(L[k][w]), fa, fb);
         }
     }
 #pragma unroll
@@ -138,20 +136,33 @@ void launch_fade_chain(const ChainArgs& a, hipStream_t s) {
 // 8 + 8 chroma samples, so the composite never exists as a YUV frame.  algorithmic bytes per frame:
 // n_src F + 4 w h.
 __device__ __forceinline__ int clip8c(int v) { return min(max(v, 0), 255); }
-__device__ __forceinline__ uint32_t yuv_px(const ChainRgbaArgs& a, int Y, int U, int V) {
+// 24-bit multiplies (v_mad_i32_i24, full rate; a 32-bit v_mul_lo_u32 is quarter rate): R, G, B are 8-bit and the
+// launcher takes this path only when every matrix entry fits 24 bits signed, so the products are the int32 ones
+__device__ __forceinline__ int mx_row24(const int* m, int R, int G, int B) {
+    return __mul24(m[0], R) + __mul24(m[1], G) + __mul24(m[2], B) + m[3] + 2048;
+}
+// pixel assembly: {clip8(r >> sh), clip8(g >> sh), clip8(b >> sh), 255} with gfx950's v_ashr_pk_u8_i32 (two
+// shift + saturate + pack per instruction).  The builtin is used on purpose: the instruction writes only the low 16
+// bits of its destination, the builtin's u16 result makes the compiler select that half -- while the compiler's own
+// pattern match of clip8(x >> s) | clip8(y >> s) << 8 (ROCm 7.2) ORs the whole register into the pixel and
+// leaves stale bits in the B byte (caught by tests/test_gpu_video_graph.py).
+__device__ __forceinline__ uint32_t pack_rgba(int r, int g, int b, int sh) {
+    const uint32_t rg = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(r, g, sh);
+    const uint32_t ba = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(b, 255 << sh, sh);
+    return rg | (ba << 16);
+}
+template <int MM>   // matrix mode: 0 none, 1 full 32-bit products, 2 24-bit products
+__device__ __forceinline__ uint32_t yuv_px(const int* m, int Y, int U, int V) {
     const int C = Y - 16, D = U - 128, E = V - 128;
-    int R = clip8c((298 * C + 459 * E + 128) >> 8);
-    int G = clip8c((298 * C - 55 * D - 136 * E + 128) >> 8);
-    int B = clip8c((298 * C + 541 * D + 128) >> 8);
-    if (a.use_matrix) {
-        const int r2 = clip8c((a.m[0] * R + a.m[1] * G + a.m[2] * B + a.m[3] + 2048) >> 12);
-        const int g2 = clip8c((a.m[4] * R + a.m[5] * G + a.m[6] * B + a.m[7] + 2048) >> 12);
-        const int b2 = clip8c((a.m[8] * R + a.m[9] * G + a.m[10] * B + a.m[11] + 2048) >> 12);
-        R = r2; G = g2; B = b2;
-    }
-    return (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xff000000u;
+    const int rs = 298 * C + 459 * E + 128, gs = 298 * C - 55 * D - 136 * E + 128, bs = 298 * C + 541 * D + 128;
+    if (MM == 0) return pack_rgba(rs, gs, bs, 8);
+    const int R = clip8c(rs >> 8), G = clip8c(gs >> 8), B = clip8c(bs >> 8);
+    if (MM == 2) return pack_rgba(mx_row24(m, R, G, B), mx_row24(m + 4, R, G, B), mx_row24(m + 8, R, G, B), 12);
+    return pack_rgba(m[0] * R + m[1] * G + m[2] * B + m[3] + 2048, m[4] * R + m[5] * G + m[6] * B + m[7] + 2048,
+                     m[8] * R + m[9] * G + m[10] * B + m[11] + 2048, 12);
 }
 
+template <int MM>
 __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
     const uint32_t xb = blockIdx.x * 64 + (threadIdx.x & 63);     // 8-pixel column block
     const uint32_t yb = blockIdx.y * 4 + (threadIdx.x >> 6);       // row pair
@@ -186,17 +197,26 @@ __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
             uint32_t px[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                px[k] = yuv_px(a, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
+                px[k] = yuv_px<MM>(a.m, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
             const uint32_t x = xb * 8 + g4 * 4;
             if (x + 4 <= a.width) *reinterpret_cast<uint4*>(o + g4 * 16) = make_uint4(px[0], px[1], px[2], px[3]);
             else for (uint32_t k = 0; x + k < a.width; ++k) reinterpret_cast<uint32_t*>(o + g4 * 16)[k] = px[k];
         }
     }
 }
-void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s) {
+void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
     flush_scales(s);
-    if (!a.width || !a.height) return;
-    hipLaunchKernelGGL(k_fade_chain_rgba, dim3(((a.width + 7) / 8 + 63) / 64, ((a.height + 1) / 2 + 3) / 4), dim3(256), 0, s, a);
+    if (!a0.width || !a0.height) return;
+    ChainRgbaArgs a = a0;
+    if (a.use_matrix) {
+        bool fits = true;
+        for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
+        a.use_matrix = fits ? 2 : 1;
+    }
+    const dim3 grid(((a.width + 7) / 8 + 63) / 64, ((a.height + 1) / 2 + 3) / 4);
+    if (a.use_matrix == 2) hipLaunchKernelGGL(k_fade_chain_rgba<2>, grid, dim3(256), 0, s, a);
+    else if (a.use_matrix) hipLaunchKernelGGL(k_fade_chain_rgba<1>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_fade_chain_rgba<0>, grid, dim3(256), 0, s, a);
 }
 
 // Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
@@ -225,60 +245,94 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 // share 3 of 4 columns).  All three planes in one launch.
 // ---------------------------------------------------------------------------------------------
 // Tiled two-pass version of the same arithmetic (bit-identical): a 256-thread block produces a
-// 64 x 16 output tile.  The clamped source window (<= SC_NR x SC_NC bytes) is staged in LDS once,
-// the H pass filters each needed source row exactly once per output column (NR/16 * 4 MACs per
-// output pixel instead of 16), the V pass reads four H-filtered rows per pixel from LDS as
-// ds_read_b128 and stores one dword of 4 pixels.  Used when the window fits (scale ratio <= 2).
-#define SC_NR 40
-#define SC_NC 136
+// 128 x 32 output tile.  The source window is staged in LDS once (aligned dwords; edge replication
+// happens there), the H pass filters each needed source row exactly once per output column, the V
+// pass reads four H-filtered rows per pixel group from LDS as ds_read_b128 and stores one dword of 4
+// pixels.  The kernel is latency-bound (a 1080p target is ~800 tiles per plane set), so the window
+// origin is COMPUTED from the tap spec instead of fetched -- the source loads do not wait for a table
+// round trip -- and every coefficient a lane will need is requested in the same burst.
+// Used when the window fits 64 KB of LDS (scale ratio <= 2); LDS is sized per launch.
+#define SC_TW 128
+#define SC_TH 32
+__host__ __device__ __forceinline__ int sc_first_tap(uint32_t o, uint32_t src, uint32_t dst) {   // DESIGN.md "Scaler": first tap of output o
+    const uint64_t n = (uint64_t)(2u * o + 1u) * src * 65536ull;                                 // < 2^49 for planes up to 65535
+    const int64_t pos = (int64_t)(n / (2ull * dst)) - 32768;
+    return (int)(pos >> 16) - 1;
+}
 __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     int plane = 0;
 #pragma unroll
     for (int k = 1; k < MX_SCALE_BATCH_PLANES; ++k) if (k < (int)a.n && blockIdx.x >= a.tile_start[k]) plane = k;   // scalar search
     const ScalePlane p = a.p[plane];
     const uint32_t tile = blockIdx.x - a.tile_start[plane];
-    const int ox0 = (int)(tile % a.tiles_x[plane]) * 64, oy0 = (int)(tile / a.tiles_x[plane]) * 16;
-    __shared__ uint8_t S[SC_NR][SC_NC];
-    __shared__ __attribute__((aligned(16))) int T[SC_NR][64];
+    const int ox0 = (int)(tile % a.tiles_x[plane]) * SC_TW, oy0 = (int)(tile / a.tiles_x[plane]) * SC_TH;
+    extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
+    uint8_t* const S = sc_smem;                                                       // [s_rows][s_stride] source window
+    int* const T = reinterpret_cast<int*>(sc_smem + (size_t)a.s_rows * a.s_stride);   // [s_rows][SC_TW] H-filtered rows
     const int tid = threadIdx.x;
-    const int oxl = min(ox0 + 63, (int)p.dw - 1), oyl = min(oy0 + 15, (int)p.dh - 1);
-    // every table entry this lane will need, fetched in one burst (one memory round trip, not four)
-    const int oxi = tid & 63, ox = min(ox0 + oxi, (int)p.dw - 1);
-    const int oy = min(oy0 + (tid >> 4), (int)p.dh - 1), oxg = (tid & 15) * 4;
-    const int cx0 = p.hfirst[ox0], cxl = p.hfirst[oxl];   // tap tables are monotone
-    const int ry0 = p.vfirst[oy0], ryl = p.vfirst[oyl];
+    const int oxl = min(ox0 + SC_TW - 1, (int)p.dw - 1), oyl = min(oy0 + SC_TH - 1, (int)p.dh - 1);
+    // window origin / extent from the tap spec (tap tables are monotone); columns start on a dword of the source row
+    const int cx0 = sc_first_tap((uint32_t)ox0, p.sw, p.dw), cxl = sc_first_tap((uint32_t)oxl, p.sw, p.dw);
+    const int ry0 = sc_first_tap((uint32_t)oy0, p.sh, p.dh), ryl = sc_first_tap((uint32_t)oyl, p.sh, p.dh);
+    const int cxa = cx0 & ~3;
+    const int nc4 = min((cxl + 4 - cxa + 3) >> 2, (int)a.s_stride >> 2), nr = min(ryl + 4 - ry0, (int)a.s_rows);
+    // every table entry this lane will need, in one burst
+    const int oxi = tid & (SC_TW - 1), ox = min(ox0 + oxi, (int)p.dw - 1);
     const int4 hc = reinterpret_cast<const int4*>(p.hcoef)[ox];
-    const int hf = p.hfirst[ox] - cx0;
-    const int4 vc = reinterpret_cast<const int4*>(p.vcoef)[oy];
-    const int vf = p.vfirst[oy] - ry0;
-    const int nc = cxl + 4 - cx0, nr = ryl + 4 - ry0;
+    const int hf = p.hfirst[ox] - cxa;
+    const int cg = tid & 31, oyr = tid >> 5;                  // V pass: pixel group (4 columns) and first row; rows oyr + 8k
+    int4 vc[4]; int vf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oy = min(oy0 + oyr + 8 * k, (int)p.dh - 1);
+        vc[k] = reinterpret_cast<const int4*>(p.vcoef)[oy];
+        vf[k] = p.vfirst[oy] - ry0;
+    }
     const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
-    for (int r = tid >> 7; r < nr; r += 2) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.src) | p.src_stride) & 3u) == 0;
+    for (int idx = tid; idx < nr * nc4; idx += 256) {
+        const int r = idx / nc4, c4 = idx - r * nc4;
         const uint8_t* row = p.src + (size_t)min(max(ry0 + r, 0), sh1) * p.src_stride;
-        for (int c = tid & 127; c < nc; c += 128) S[r][c] = row[min(max(cx0 + c, 0), sw1)];   // edge replication happens here
+        const int x = cxa + 4 * c4;
+        uint32_t w;
+        if (aligned && x >= 0 && x + 3 <= sw1) w = *reinterpret_cast<const uint32_t*>(row + x);
+        else w = (uint32_t)row[min(max(x, 0), sw1)] | ((uint32_t)row[min(max(x + 1, 0), sw1)] << 8) |
+                 ((uint32_t)row[min(max(x + 2, 0), sw1)] << 16) | ((uint32_t)row[min(max(x + 3, 0), sw1)] << 24);   // edge replication
+        *reinterpret_cast<uint32_t*>(S + (size_t)r * a.s_stride + 4 * c4) = w;
     }
     __syncthreads();
-    if (ox0 + oxi < (int)p.dw) {   // H pass: t = (sum hc * S + 64) >> 7
-        for (int r = tid >> 6; r < nr; r += 4) {
-            const int acc = hc.x * (int)S[r][hf] + hc.y * (int)S[r][hf + 1] + hc.z * (int)S[r][hf + 2] + hc.w * (int)S[r][hf + 3];
-            T[r][oxi] = (acc + 64) >> 7;
+    if (ox0 + oxi < (int)p.dw) {   // H pass: t = (sum hc * S + 64) >> 7; the 4 taps come out of two aligned dwords
+        const int hb = hf & ~3, sh8 = (hf & 3) * 8;
+        for (int r = tid >> 7; r < nr; r += 2) {
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(S + (size_t)r * a.s_stride + hb);
+            const uint64_t two = ((uint64_t)sp[1] << 32) | sp[0];
+            const uint32_t w = (uint32_t)(two >> sh8);
+            const int acc = hc.x * (int)(w & 0xffu) + hc.y * (int)((w >> 8) & 0xffu) + hc.z * (int)((w >> 16) & 0xffu) + hc.w * (int)(w >> 24);
+            T[r * SC_TW + oxi] = (acc + 64) >> 7;
         }
     }
     __syncthreads();
-    // V pass: D = clip8((sum vc * t + 2^20) >> 21), four pixels per lane
-    if (oy0 + (tid >> 4) < (int)p.dh && ox0 + oxg < (int)p.dw) {
-        const int4 t0 = *reinterpret_cast<const int4*>(&T[vf][oxg]), t1 = *reinterpret_cast<const int4*>(&T[vf + 1][oxg]);
-        const int4 t2 = *reinterpret_cast<const int4*>(&T[vf + 2][oxg]), t3 = *reinterpret_cast<const int4*>(&T[vf + 3][oxg]);
-        const int v0 = min(max((vc.x * t0.x + vc.y * t1.x + vc.z * t2.x + vc.w * t3.x + (1 << 20)) >> 21, 0), 255);
-        const int v1 = min(max((vc.x * t0.y + vc.y * t1.y + vc.z * t2.y + vc.w * t3.y + (1 << 20)) >> 21, 0), 255);
-        const int v2 = min(max((vc.x * t0.z + vc.y * t1.z + vc.z * t2.z + vc.w * t3.z + (1 << 20)) >> 21, 0), 255);
-        const int v3 = min(max((vc.x * t0.w + vc.y * t1.w + vc.z * t2.w + vc.w * t3.w + (1 << 20)) >> 21, 0), 255);
-        uint8_t* o = p.dst + (size_t)oy * p.dst_stride + ox0 + oxg;
-        if (ox0 + oxg + 4 <= (int)p.dw && (((uintptr_t)o) & 3) == 0) {
-            *reinterpret_cast<uint32_t*>(o) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-        } else {
-            const int vv[4] = {v0, v1, v2, v3};
-            for (int k = 0; k < 4 && ox0 + oxg + k < (int)p.dw; ++k) o[k] = (uint8_t)vv[k];
+    // V pass: D = clip8((sum vc * t + 2^20) >> 21), four pixels per lane and row
+    const int oxg = cg * 4;
+    if (ox0 + oxg < (int)p.dw) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oyk = oy0 + oyr + 8 * k;
+            if (oyk >= (int)p.dh) break;
+            const int4 t0 = *reinterpret_cast<const int4*>(&T[(vf[k] + 0) * SC_TW + oxg]), t1 = *reinterpret_cast<const int4*>(&T[(vf[k] + 1) * SC_TW + oxg]);
+            const int4 t2 = *reinterpret_cast<const int4*>(&T[(vf[k] + 2) * SC_TW + oxg]), t3 = *reinterpret_cast<const int4*>(&T[(vf[k] + 3) * SC_TW + oxg]);
+            const int4 c = vc[k];
+            const int v0 = min(max((c.x * t0.x + c.y * t1.x + c.z * t2.x + c.w * t3.x + (1 << 20)) >> 21, 0), 255);
+            const int v1 = min(max((c.x * t0.y + c.y * t1.y + c.z * t2.y + c.w * t3.y + (1 << 20)) >> 21, 0), 255);
+            const int v2 = min(max((c.x * t0.z + c.y * t1.z + c.z * t2.z + c.w * t3.z + (1 << 20)) >> 21, 0), 255);
+            const int v3 = min(max((c.x * t0.w + c.y * t1.w + c.z * t2.w + c.w * t3.w + (1 << 20)) >> 21, 0), 255);
+            uint8_t* o = p.dst + (size_t)oyk * p.dst_stride + ox0 + oxg;
+            if (ox0 + oxg + 4 <= (int)p.dw && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+                *reinterpret_cast<uint32_t*>(o) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+            } else {
+                const int vv[4] = {v0, v1, v2, v3};
+                for (int j = 0; j < 4 && ox0 + oxg + j < (int)p.dw; ++j) o[j] = (uint8_t)vv[j];
+            }
         }
     }
 }
@@ -306,25 +360,31 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {
 // All planes of all queued scale jobs of a stream go out as ONE launch (grid.z = plane): these
 // kernels are latency-bound, so N jobs cost about as much as one.
 void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
-    uint32_t mw = 0, mh = 0;
-    bool tiled = true;
+    uint32_t mw = 0, mh = 0, s_rows = 0, s_stride = 0;
     for (uint32_t i = 0; i < a.n; ++i) {
-        mw = a.p[i].dw > mw ? a.p[i].dw : mw; mh = a.p[i].dh > mh ? a.p[i].dh : mh;
-        // window of a 64 x 16 tile: 64 * sw/dw + 5 columns, 16 * sh/dh + 5 rows (the +5 covers tap reach and rounding)
-        if (a.p[i].dw && ((uint64_t)64 * a.p[i].sw / a.p[i].dw + 5 > SC_NC || (uint64_t)16 * a.p[i].sh / a.p[i].dh + 5 > SC_NR)) tiled = false;
+        const ScalePlane& p = a.p[i];
+        mw = p.dw > mw ? p.dw : mw; mh = p.dh > mh ? p.dh : mh;
+        if (!p.dw || !p.dh) continue;
+        // window of a 128 x 32 tile: taps of its first and last output + 4, columns widened to whole dwords
+        const uint32_t rows = (uint32_t)(((uint64_t)SC_TH * p.sh + p.dh - 1) / p.dh) + 6;
+        const uint32_t cols = (uint32_t)(((uint64_t)SC_TW * p.sw + p.dw - 1) / p.dw) + 6 + 3 + 4;   // + the H pass's second dword
+        s_rows = rows > s_rows ? rows : s_rows; s_stride = cols > s_stride ? cols : s_stride;
     }
     if (!a.n || !mw || !mh) return;
+    s_stride = (s_stride + 15u) & ~15u;               // rows * stride stays a multiple of 16: T is read as int4
+    const size_t lds = (size_t)s_rows * s_stride + (size_t)s_rows * SC_TW * sizeof(int);
     static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
-    if (tiled && !force_simple) {
+    if (lds <= 64 * 1024 && !force_simple) {
         ScaleBatchArgs b = a;
         uint32_t total = 0;
         for (uint32_t i = 0; i < a.n; ++i) {
             b.tile_start[i] = total;
-            b.tiles_x[i] = (a.p[i].dw + 63) / 64;
-            total += b.tiles_x[i] * ((a.p[i].dh + 15) / 16);
+            b.tiles_x[i] = (a.p[i].dw + SC_TW - 1) / SC_TW;
+            total += b.tiles_x[i] * ((a.p[i].dh + SC_TH - 1) / SC_TH);
         }
         for (uint32_t i = a.n; i <= MX_SCALE_BATCH_PLANES; ++i) { b.tile_start[i] = total; if (i < MX_SCALE_BATCH_PLANES) b.tiles_x[i] = 1; }
-        if (total) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3(total), dim3(256), 0, s, b);
+        b.s_rows = s_rows; b.s_stride = s_stride;
+        if (total) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3(total), dim3(256), lds, s, b);
     } else {
         hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
     }
@@ -372,19 +432,8 @@ __global__ __launch_bounds__(256) void k_yuv420_to_rgba(RgbaArgs a) {
     uint32_t px[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int C = (int)((y4 >> (8 * k)) & 0xff) - 16;
-        const int D = (int)((u2 >> (8 * (k >> 1))) & 0xff) - 128;
-        const int E = (int)((v2 >> (8 * (k >> 1))) & 0xff) - 128;
-        int R = clip8((298 * C + 459 * E + 128) >> 8);
-        int G = clip8((298 * C - 55 * D - 136 * E + 128) >> 8);
-        int B = clip8((298 * C + 541 * D + 128) >> 8);
-        if (a.use_matrix) {
-            const int r2 = clip8((a.m[0] * R + a.m[1] * G + a.m[2] * B + a.m[3] + 2048) >> 12);
-            const int g2 = clip8((a.m[4] * R + a.m[5] * G + a.m[6] * B + a.m[7] + 2048) >> 12);
-            const int b2 = clip8((a.m[8] * R + a.m[9] * G + a.m[10] * B + a.m[11] + 2048) >> 12);
-            R = r2; G = g2; B = b2;
-        }
-        px[k] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xff000000u;
+        const int Y = (int)((y4 >> (8 * k)) & 0xff), U = (int)((u2 >> (8 * (k >> 1))) & 0xff), V = (int)((v2 >> (8 * (k >> 1))) & 0xff);
+        px[k] = a.use_matrix ? yuv_px<1>(a.m, Y, U, V) : yuv_px<0>(a.m, Y, U, V);
     }
     uint8_t* o = a.rgba + (size_t)y * a.rgba_stride + (size_t)xq * 16;
     if (xq * 4 + 4 <= a.width) *reinterpret_cast<uint4*>(o) = make_uint4(px[0], px[1], px[2], px[3]);

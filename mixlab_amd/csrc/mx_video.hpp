@@ -34,6 +34,7 @@ struct ScaleBatchArgs {
     ScalePlane p[MX_SCALE_BATCH_PLANES]; uint32_t n;
     uint32_t tile_start[MX_SCALE_BATCH_PLANES + 1];   // launcher-filled: flat block index -> (plane, tile), no empty blocks
     uint32_t tiles_x[MX_SCALE_BATCH_PLANES];
+    uint32_t s_rows, s_stride;                        // launcher-filled: LDS window geometry of the tiled kernel
 };
 struct CopyArgs { const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], rows[3], row_bytes[3]; };
 struct RgbaArgs {
