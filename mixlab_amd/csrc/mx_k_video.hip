@@ -254,10 +254,21 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 // Used when the window fits 64 KB of LDS (scale ratio <= 2); LDS is sized per launch.
 #define SC_TW 128
 #define SC_TH 32
-__host__ __device__ __forceinline__ int sc_first_tap(uint32_t o, uint32_t src, uint32_t dst) {   // DESIGN.md "Scaler": first tap of output o
-    const uint64_t n = (uint64_t)(2u * o + 1u) * src * 65536ull;                                 // < 2^49 for planes up to 65535
-    const int64_t pos = (int64_t)(n / (2ull * dst)) - 32768;
-    return (int)(pos >> 16) - 1;
+// first tap of output o (DESIGN.md "Scaler"): ((floor((2o+1) * src * 65536 / (2 dst)) - 32768) >> 16) - 1, evaluated in f64:
+// numerator and denominator are exact (< 2^49), the quotient is corrected with an exact fma remainder, and the rest
+// are exact operations on integers below 2^53 -- a 64-bit integer division costs several hundred VALU cycles here.
+// Scaler::retarget checks it against the integer tap tables for every tile origin it can be asked for.
+__host__ __device__ __forceinline__ int sc_first_tap(uint32_t o, uint32_t src, uint32_t dst) {
+    const double n = (double)(2u * o + 1u) * ((double)src * 65536.0), d = 2.0 * (double)dst;
+    double q = floor(n / d);
+    const double r = fma(-q, d, n);          // exact: |r| < 2 d
+    q += (r >= d) ? 1.0 : ((r < 0.0) ? -1.0 : 0.0);
+    return (int)floor((q - 32768.0) * (1.0 / 65536.0)) - 1;
+}
+bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first /* host copy of the tap table */) {
+    for (uint32_t o = 0; o < dst; ++o)
+        if ((o % SC_TW == 0 || o % SC_TH == 0 || o + 1 == dst || (o + 1) % SC_TW == 0 || (o + 1) % SC_TH == 0) && sc_first_tap(o, src, dst) != first[o]) return false;
+    return true;
 }
 __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     int plane = 0;
@@ -302,12 +313,12 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     }
     __syncthreads();
     if (ox0 + oxi < (int)p.dw) {   // H pass: t = (sum hc * S + 64) >> 7; the 4 taps come out of two aligned dwords
-        const int hb = hf & ~3, sh8 = (hf & 3) * 8;
+        const int hb = hf & ~3;
         for (int r = tid >> 7; r < nr; r += 2) {
             const uint32_t* sp = reinterpret_cast<const uint32_t*>(S + (size_t)r * a.s_stride + hb);
-            const uint64_t two = ((uint64_t)sp[1] << 32) | sp[0];
-            const uint32_t w = (uint32_t)(two >> sh8);
-            const int acc = hc.x * (int)(w & 0xffu) + hc.y * (int)((w >> 8) & 0xffu) + hc.z * (int)((w >> 16) & 0xffu) + hc.w * (int)(w >> 24);
+            const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], (uint32_t)(hf & 3));   // bytes hf .. hf+3
+            // 24-bit products (full rate; v_mul_lo_u32 is quarter rate): Q14 coefficients x bytes
+            const int acc = __mul24(hc.x, (int)(w & 0xffu)) + __mul24(hc.y, (int)((w >> 8) & 0xffu)) + __mul24(hc.z, (int)((w >> 16) & 0xffu)) + __mul24(hc.w, (int)(w >> 24));
             T[r * SC_TW + oxi] = (acc + 64) >> 7;
         }
     }
@@ -322,17 +333,15 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
             const int4 t0 = *reinterpret_cast<const int4*>(&T[(vf[k] + 0) * SC_TW + oxg]), t1 = *reinterpret_cast<const int4*>(&T[(vf[k] + 1) * SC_TW + oxg]);
             const int4 t2 = *reinterpret_cast<const int4*>(&T[(vf[k] + 2) * SC_TW + oxg]), t3 = *reinterpret_cast<const int4*>(&T[(vf[k] + 3) * SC_TW + oxg]);
             const int4 c = vc[k];
-            const int v0 = min(max((c.x * t0.x + c.y * t1.x + c.z * t2.x + c.w * t3.x + (1 << 20)) >> 21, 0), 255);
-            const int v1 = min(max((c.x * t0.y + c.y * t1.y + c.z * t2.y + c.w * t3.y + (1 << 20)) >> 21, 0), 255);
-            const int v2 = min(max((c.x * t0.z + c.y * t1.z + c.z * t2.z + c.w * t3.z + (1 << 20)) >> 21, 0), 255);
-            const int v3 = min(max((c.x * t0.w + c.y * t1.w + c.z * t2.w + c.w * t3.w + (1 << 20)) >> 21, 0), 255);
+            // Q14 coefficients x H-filtered values (|t| < 2^16): 24-bit products are the int32 ones
+            auto col = [&](int a0, int a1, int a2, int a3) { return __mul24(c.x, a0) + __mul24(c.y, a1) + __mul24(c.z, a2) + __mul24(c.w, a3) + (1 << 20); };
+            // clip8(sum >> 21) x 4 -> one dword: two v_ashr_pk_u8_i32 (explicit builtin, see pack_rgba)
+            const uint32_t lo = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(col(t0.x, t1.x, t2.x, t3.x), col(t0.y, t1.y, t2.y, t3.y), 21);
+            const uint32_t hi = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(col(t0.z, t1.z, t2.z, t3.z), col(t0.w, t1.w, t2.w, t3.w), 21);
+            const uint32_t quad = lo | (hi << 16);
             uint8_t* o = p.dst + (size_t)oyk * p.dst_stride + ox0 + oxg;
-            if (ox0 + oxg + 4 <= (int)p.dw && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
-                *reinterpret_cast<uint32_t*>(o) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-            } else {
-                const int vv[4] = {v0, v1, v2, v3};
-                for (int j = 0; j < 4 && ox0 + oxg + j < (int)p.dw; ++j) o[j] = (uint8_t)vv[j];
-            }
+            if (ox0 + oxg + 4 <= (int)p.dw && (reinterpret_cast<uintptr_t>(o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = quad;
+            else for (int j = 0; j < 4 && ox0 + oxg + j < (int)p.dw; ++j) o[j] = (uint8_t)(quad >> (8 * j));
         }
     }
 }

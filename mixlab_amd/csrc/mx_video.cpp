@@ -209,6 +209,8 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
         std::vector<int32_t> hf, hc, vf, vc;
         make_taps(in_w >> c, geo_.scaled_w >> c, hf, hc);
         make_taps(in_h >> c, geo_.scaled_h >> c, vf, vc);
+        if (!scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_h >> c, geo_.scaled_h >> c, vf.data()))
+            throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
     }

@@ -44,6 +44,7 @@ struct RgbaArgs {
 };
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s);
+bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first);   // f64 window-origin formula of the tiled scaler == tap table
 
 // A chain of cross-fades evaluated per pixel in registers:  v = src[0];  for k >= 1:
 //   v = v_is_a[k-1] ? fade(v, src[k]) : fade(src[k], v)   with fade(a,b) = (a*f + b*(255-f)) / 255, f = fade[k-1]

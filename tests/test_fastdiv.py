@@ -20,3 +20,10 @@ def checker(tmp_path_factory):
 def test_markstein_quotient_is_ieee_quotient_for_all_dt_below_2_32(checker, rate):
     out = subprocess.run([str(checker), str(rate), "0", str(1 << 32)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
+
+
+def test_scaler_window_origin_f64_formula_equals_integer_tap_spec(tmp_path):
+    exe = tmp_path / "tap_origin_check"
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-std=c11", str(HERE / "tap_origin_check.c"), "-o", str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
