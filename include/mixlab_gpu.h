@@ -164,6 +164,39 @@ int mx_graph_profile_run(mx_graph* g, uint64_t first_tick, uint32_t n_ticks, flo
 int mx_graph_profile_enable(mx_graph* g, int on);
 int mx_graph_profile_collect(mx_graph* g, float* ms_by_kind /* MX_KIND_COUNT */, float* ms_total, uint32_t* n_runs);
 
+/* The reference's performance panel (PerformanceInfo, protocol/src/lib.rs:32-59, filled by EngineStat::report,
+ * src/engine/timing.rs:46-60) from the most recent profiled run (mx_graph_profile_run, or profile_enable + collect):
+ *   realtime       the tick finished inside its budget (timing.rs:33)
+ *   lag            0 none, 1 Recent (< 5 s ago), 2 Active (< 100 ms ago): a tick ran over its budget (util.rs:47-60)
+ *   tick_budget_us 1e6 / ticks_per_second (timing.rs:9)
+ *   module_us[i]   PerformanceAccount::Module(i), "last" metric, per tick: the time of the launch that served the module,
+ *                  split evenly over the modules (and folded modules) that launch served
+ *   engine_us      PerformanceAccount::Engine = tick time - sum of module accounts (timing.rs:43) */
+typedef struct mx_performance_info {
+    int32_t realtime; int32_t lag; uint32_t tick_rate; uint32_t n_modules;
+    uint64_t tick_budget_us; uint64_t engine_us;
+} mx_performance_info;
+int mx_graph_performance_info(mx_graph* g, mx_performance_info* info, uint64_t* module_us /* [cap >= n nodes] or NULL */, size_t cap);
+
+/* Topology edit (Engine::client_update, src/engine.rs:277-398): modules persist while connections are added and removed.
+ * Build the edited graph with mx_graph_build, then let it take over the state of every module that survives:
+ * old_node_of_new[i] = index in `old_graph` of the module that is node i of `new_graph`, or -1 for a new module
+ * (EqThree poles and delay line, Envelope state, FIR / resampler history, Plotter count, VideoMixer stored frames and
+ * scalers, pending video sources).  Kinds must match (MX_ERR_TYPE).  VideoMixers are MOVED: destroy `old_graph`
+ * afterwards, do not run it. */
+int mx_graph_adopt_state(mx_graph* new_graph, mx_graph* old_graph, const int32_t* old_node_of_new, size_t n);
+
+/* Ingest re-blocking (StreamInput::run_tick, src/module/stream_input.rs:92-124): decoded audio arrives as i16 frames of
+ * any length; every tick takes exactly 2 * SPT interleaved samples from the queue, a partly consumed frame stays queued,
+ * and what the queue cannot fill is zeroed.  mx_pcm_ring_feed re-blocks n_ticks ticks into a SOURCE_STEREO node
+ * (H2D as i16, sample / 32768 on the device, stream_input.rs:167-173); *zero_filled = samples it had to zero. */
+typedef struct mx_pcm_ring mx_pcm_ring;
+int mx_pcm_ring_create(mx_pcm_ring** out);
+void mx_pcm_ring_destroy(mx_pcm_ring* r);
+int mx_pcm_ring_push_i16(mx_pcm_ring* r, const int16_t* samples, size_t n_samples);
+int mx_pcm_ring_queued(const mx_pcm_ring* r, size_t* n_samples);
+int mx_pcm_ring_feed(mx_pcm_ring* r, mx_graph* g, uint32_t node, uint32_t n_ticks, size_t* zero_filled);
+
 /* ---------------------------------------------------------------------------------------------- */
 /* pixel path: device-resident yuv420p frames, VideoMixer, scaler, colour                          */
 /* ---------------------------------------------------------------------------------------------- */

@@ -114,6 +114,21 @@ _proto("mx_graph_read_plotter", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c
 _proto("mx_graph_profile_run", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
 _proto("mx_graph_profile_enable", C.c_int, C.c_void_p, C.c_int)
 _proto("mx_graph_profile_collect", C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32))
+
+
+class PerformanceInfo(C.Structure):
+    """mx_performance_info (PerformanceInfo, protocol/src/lib.rs:32-59)."""
+    _fields_ = [("realtime", C.c_int32), ("lag", C.c_int32), ("tick_rate", C.c_uint32), ("n_modules", C.c_uint32),
+                ("tick_budget_us", C.c_uint64), ("engine_us", C.c_uint64)]
+
+
+_proto("mx_graph_performance_info", C.c_int, C.c_void_p, C.POINTER(PerformanceInfo), C.POINTER(C.c_uint64), C.c_size_t)
+_proto("mx_graph_adopt_state", C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_size_t)
+_proto("mx_pcm_ring_create", C.c_int, C.POINTER(C.c_void_p))
+_proto("mx_pcm_ring_destroy", None, C.c_void_p)
+_proto("mx_pcm_ring_push_i16", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_proto("mx_pcm_ring_queued", C.c_int, C.c_void_p, C.POINTER(C.c_size_t))
+_proto("mx_pcm_ring_feed", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t))
 _proto("mx_module_create", C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p))
 _proto("mx_module_create_ex", C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(GraphOpts), C.POINTER(C.c_void_p))
 _proto("mx_module_update", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -246,6 +261,48 @@ class Graph:
         n = C.c_uint32()
         check(lib.mx_graph_profile_collect(self._h, by_kind, C.byref(total), C.byref(n)))
         return {KIND_NAMES[k]: by_kind[k] for k in range(KIND_COUNT) if by_kind[k] > 0}, total.value, n.value
+
+
+    def performance_info(self, n_nodes: int):
+        """-> (PerformanceInfo, [module us per tick]) for the most recent profiled run (src/engine/timing.rs:46-60)."""
+        info = PerformanceInfo()
+        us = (C.c_uint64 * max(1, n_nodes))()
+        check(lib.mx_graph_performance_info(self._h, C.byref(info), us, n_nodes))
+        return info, list(us[:n_nodes])
+
+    def adopt_state(self, old: "Graph", old_node_of_new):
+        """Topology edit (src/engine.rs:277-398): take over the state of surviving modules; `old` must not run again."""
+        arr = (C.c_int32 * max(1, len(old_node_of_new)))(*old_node_of_new)
+        check(lib.mx_graph_adopt_state(self._h, old._h, arr, len(old_node_of_new)))
+
+
+class PcmRing:
+    """mx_pcm_ring_*: decoded i16 frames of any length re-blocked to ticks (src/module/stream_input.rs:92-124)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(lib.mx_pcm_ring_create(C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.mx_pcm_ring_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def push(self, samples: np.ndarray):
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        check(lib.mx_pcm_ring_push_i16(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def queued(self) -> int:
+        n = C.c_size_t()
+        check(lib.mx_pcm_ring_queued(self._h, C.byref(n)))
+        return n.value
+
+    def feed(self, graph: "Graph", node: int, n_ticks: int) -> int:
+        z = C.c_size_t()
+        check(lib.mx_pcm_ring_feed(self._h, graph._h, node, n_ticks, C.byref(z)))
+        return z.value
 
 
 class Module:

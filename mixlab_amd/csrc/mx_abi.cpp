@@ -159,6 +159,68 @@ int mx_graph_profile_collect(mx_graph* g, float* ms_by_kind, float* ms_total, ui
     });
 }
 
+int mx_graph_adopt_state(mx_graph* new_graph, mx_graph* old_graph, const int32_t* old_node_of_new, size_t n) {
+    return guard([&] {
+        REQUIRE(new_graph && old_graph, "graph is NULL");
+        REQUIRE(new_graph != old_graph, "a graph cannot adopt its own state");
+        new_graph->g->adopt_state(*old_graph->g, old_node_of_new, n);
+    });
+}
+
+int mx_graph_performance_info(mx_graph* g, mx_performance_info* info, uint64_t* module_us, size_t cap) {
+    return guard([&] {
+        REQUIRE(g && info, "NULL argument");
+        const Graph::Perf p = g->g->performance_info(module_us, cap);
+        info->realtime = p.realtime ? 1 : 0; info->lag = p.lag; info->tick_rate = p.tick_rate;
+        info->tick_budget_us = p.tick_budget_us; info->engine_us = p.engine_us; info->n_modules = (uint32_t)g->g->n_nodes();
+    });
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* PCM ingest ring: variable-length decoded frames re-blocked to ticks (stream_input.rs:92-124)     */
+/* ---------------------------------------------------------------------------------------------- */
+struct mx_pcm_ring {
+    std::vector<int16_t> q;     // interleaved samples not yet consumed, oldest first
+    size_t head = 0;
+    std::vector<int16_t> stage;
+};
+
+int mx_pcm_ring_create(mx_pcm_ring** out) {
+    return guard([&] { REQUIRE(out, "out is NULL"); *out = new mx_pcm_ring(); });
+}
+void mx_pcm_ring_destroy(mx_pcm_ring* r) { (void)guard([&] { delete r; }); }
+
+int mx_pcm_ring_push_i16(mx_pcm_ring* r, const int16_t* samples, size_t n) {
+    return guard([&] {
+        REQUIRE(r && (samples || !n), "NULL argument");
+        if (r->head && r->head * 2 >= r->q.size()) { r->q.erase(r->q.begin(), r->q.begin() + (ptrdiff_t)r->head); r->head = 0; }   // compact
+        r->q.insert(r->q.end(), samples, samples + n);
+    });
+}
+
+int mx_pcm_ring_queued(const mx_pcm_ring* r, size_t* n) {
+    return guard([&] { REQUIRE(r && n, "NULL argument"); *n = r->q.size() - r->head; });
+}
+
+int mx_pcm_ring_feed(mx_pcm_ring* r, mx_graph* g, uint32_t node, uint32_t n_ticks, size_t* zero_filled) {
+    return guard([&] {
+        REQUIRE(r && g, "NULL argument");
+        REQUIRE(node < g->g->n_nodes() && g->g->node(node).kind == MX_KIND_SOURCE_STEREO, "node is not a SOURCE_STEREO");
+        const size_t per_tick = 2 * g->g->spt();            // audio_out.len(), stream_input.rs:80
+        r->stage.assign(per_tick * n_ticks, 0);              // util::zero for whatever the queue cannot fill (stream_input.rs:120-122)
+        size_t missing = 0;
+        for (uint32_t t = 0; t < n_ticks; ++t) {
+            const size_t have = r->q.size() - r->head, take = have < per_tick ? have : per_tick;
+            std::memcpy(r->stage.data() + (size_t)t * per_tick, r->q.data() + r->head, take * sizeof(int16_t));   // partial frames stay queued (:113-116)
+            r->head += take;
+            missing += per_tick - take;
+        }
+        if (r->head == r->q.size()) { r->q.clear(); r->head = 0; }
+        g->g->write_source_i16(node, r->stage.data(), (size_t)n_ticks * g->g->spt());   // H2D as i16, /32768 on the device (:167-173)
+        if (zero_filled) *zero_filled = missing;
+    });
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 /* per-module compatibility path                                                                    */
 /* ---------------------------------------------------------------------------------------------- */

@@ -1,4 +1,6 @@
 // mx_engine.cpp -- device-resident graph executor.  See mx_engine.hpp.
+#include <chrono>
+
 #include "mx_engine.hpp"
 
 #include <algorithm>
@@ -773,6 +775,7 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
     if (ms_total) *ms_total = 0.f;
     const uint32_t n = (uint32_t)prof_runs_.size();
     for (auto& ev : prof_runs_) {
+        perf_group_ms_.assign(groups_.size() + 1, 0.f);
         size_t last = 0;   // index of the latest event that was recorded in this run
         for (size_t i = 0; i + 1 < ev.size() && i <= groups_.size(); ++i) {
             const bool recorded = i < groups_.size() ? group_launches(groups_[i]) : has_video_;
@@ -780,13 +783,123 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
             float ms = 0.f;
             hip_check(hipEventElapsedTime(&ms, ev[last], ev[i + 1]), "hipEventElapsedTime");
             if (ms_by_kind) ms_by_kind[i < groups_.size() ? groups_[i].kind : (uint32_t)MX_KIND_VIDEO_MIXER] += ms;
+            perf_group_ms_[i] = ms;
             last = i + 1;
         }
-        if (ms_total) { float ms = 0.f; hip_check(hipEventElapsedTime(&ms, ev.front(), ev[last]), "hipEventElapsedTime"); *ms_total += ms; }
+        { float ms = 0.f; hip_check(hipEventElapsedTime(&ms, ev.front(), ev[last]), "hipEventElapsedTime"); if (ms_total) *ms_total += ms; perf_total_ms_ = ms; }
+        perf_calls_ = last_calls_;
+        if (perf_calls_ && perf_total_ms_ * 1000.0 / perf_calls_ > 1e6 / (double)tps_)   // timing.rs:37-40: the tick ran over its budget
+            perf_last_lag_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         prof_pool_.push_back(std::move(ev));
     }
     prof_runs_.clear();
     return n;
+}
+
+// -------------------------------------------------------------------------------------------------
+// state that a module carries from tick to tick, as device regions in a canonical order per kind
+// -------------------------------------------------------------------------------------------------
+std::vector<Graph::StateLoc> Graph::state_locs(uint32_t id) const {
+    std::vector<StateLoc> out;
+    const Node& n = nodes_[id];
+    switch (n.kind) {
+    case MX_KIND_EQ_THREE:
+        if (n.group >= 0 && groups_[n.group].state.p) out.push_back({(EqState*)groups_[n.group].state.p + n.slot, sizeof(EqState)});
+        break;
+    case MX_KIND_ENVELOPE:
+        if (n.elided && n.owner >= 0 && nodes_[n.owner].kind == MX_KIND_EQ_THREE) {   // evaluated inline by the EqThree kernel
+            const Node& e = nodes_[n.owner];
+            if (e.group >= 0 && groups_[e.group].state2.p) out.push_back({(EnvState*)groups_[e.group].state2.p + e.slot, sizeof(EnvState)});
+        } else if (n.group >= 0 && groups_[n.group].state.p) {
+            out.push_back({(EnvState*)groups_[n.group].state.p + n.slot, sizeof(EnvState)});
+        }
+        break;
+    case MX_KIND_FIR: case MX_KIND_RESAMPLE:
+        if (n.group >= 0 && groups_[n.group].state.p) {
+            size_t off = 0, mine = 0;
+            for (uint32_t other : groups_[n.group].nodes) {
+                size_t h;
+                if (n.kind == MX_KIND_FIR) { mx_fir_params q; std::memcpy(&q, nodes_[other].params.data(), sizeof q); h = q.n_taps; }
+                else { mx_resample_params q; std::memcpy(&q, nodes_[other].params.data(), sizeof q); h = q.taps_per_phase; }
+                if (other == id) { mine = h; break; }
+                off += h;
+            }
+            out.push_back({(float2*)groups_[n.group].state.p + off, mine * sizeof(float2)});
+        }
+        break;
+    default: break;
+    }
+    return out;
+}
+
+void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
+    if (n != nodes_.size()) throw Error(MX_ERR_INVALID, "old_node_of_new must have one entry per node of the new graph");
+    if (n && !old_of_new) throw Error(MX_ERR_INVALID, "old_node_of_new is NULL");
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t j = old_of_new[i];
+        if (j < 0) continue;
+        if ((size_t)j >= old.nodes_.size()) throw Error(MX_ERR_INVALID, "old node out of range");
+        if (old.nodes_[j].kind != nodes_[i].kind) throw Error(MX_ERR_TYPE, "a module cannot change kind across a topology edit");
+    }
+    old.sync(); sync();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t j = old_of_new[i];
+        if (j < 0) continue;
+        Node& nn = nodes_[i]; Node& on = old.nodes_[j];
+        const auto a = state_locs((uint32_t)i), b = old.state_locs((uint32_t)j);
+        for (size_t k = 0; k < a.size() && k < b.size(); ++k)
+            if (a[k].bytes == b[k].bytes && a[k].bytes)   // a filter whose length changed starts from silence
+                hip_check(hipMemcpyAsync(a[k].p, b[k].p, a[k].bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(adopt state)");
+        if (nn.kind == MX_KIND_PLOTTER) nn.plot_count = on.plot_count;          // plotter.rs:37-40
+        if (nn.kind == MX_KIND_VIDEO_MIXER && on.vmixer) {                       // stored frames, scalers, expiry times
+            mx_video_mixer_params p; std::memcpy(&p, nn.params.data(), sizeof p);
+            nn.vmixer = std::move(on.vmixer);
+            nn.vmixer->update(p);
+        }
+        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
+    }
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+Graph::Perf Graph::performance_info(uint64_t* module_us, size_t cap) {
+    if (cap < nodes_.size() && module_us) throw Error(MX_ERR_INVALID, "module_us is shorter than the node count");
+    Perf pf{};
+    pf.tick_rate = tps_;
+    pf.tick_budget_us = 1000000ull / tps_;                                          // timing.rs:9
+    const double calls = perf_calls_ ? (double)perf_calls_ : 1.0;
+    const double tick_us = perf_total_ms_ * 1000.0 / calls;
+    pf.realtime = perf_calls_ != 0 && tick_us < (double)pf.tick_budget_us;         // timing.rs:33
+    if (perf_last_lag_s_ >= 0.0) {                                                  // util.rs:47-60
+        const double since = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - perf_last_lag_s_;
+        pf.lag = since < 0.1 ? 2 : (since < 5.0 ? 1 : 0);
+    }
+    if (module_us) for (size_t i = 0; i < nodes_.size(); ++i) module_us[i] = 0;
+    double accounted = 0.0;
+    for (size_t gi = 0; gi < groups_.size() && gi < perf_group_ms_.size(); ++gi) {
+        // one launch serves every module of the group and the modules folded into them: the launch's time per tick is
+        // split evenly over all of those (PerformanceAccount::Module, timing.rs:86-94)
+        std::vector<uint32_t> members;
+        for (uint32_t id : groups_[gi].nodes) {
+            members.push_back(id);
+            const Node& nd = nodes_[id];
+            for (int32_t f : {nd.fuse_pan, nd.fuse_amp, nd.fuse_env, nd.fuse_trigger}) if (f >= 0) members.push_back((uint32_t)f);
+            if (nd.fuse_env >= 0 && nodes_[nd.fuse_env].fuse_trigger >= 0) members.push_back((uint32_t)nodes_[nd.fuse_env].fuse_trigger);
+        }
+        if (members.empty()) continue;
+        const double us = perf_group_ms_[gi] * 1000.0 / calls;
+        accounted += us;
+        if (module_us) for (uint32_t id : members) module_us[id] += (uint64_t)(us / (double)members.size() + 0.5);
+    }
+    if (has_video_ && perf_group_ms_.size() > groups_.size()) {   // the per-tick video section
+        std::vector<uint32_t> members;
+        for (size_t i = 0; i < nodes_.size(); ++i) if (nodes_[i].kind == MX_KIND_VIDEO_MIXER || nodes_[i].kind == MX_KIND_VIDEO_TO_RGBA) members.push_back((uint32_t)i);
+        const double us = perf_group_ms_[groups_.size()] * 1000.0 / calls;
+        accounted += us;
+        if (module_us) for (uint32_t id : members) module_us[id] += (uint64_t)(us / (double)members.size() + 0.5);
+    }
+    pf.engine_us = (uint64_t)std::max(0.0, tick_us - accounted + 0.5);             // PerformanceAccount::Engine = tick - modules (timing.rs:43)
+    return pf;
 }
 
 void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames) {

@@ -95,6 +95,12 @@ public:
     float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_tick);
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
+    // topology edit (client_update, src/engine.rs:277-398): modules persist while the connection set changes.
+    // Takes over the carried state of every surviving module: old_of_new[i] = node of `old` that is node i here, or -1.
+    void adopt_state(Graph& old, const int32_t* old_of_new, size_t n);
+    // per-module time of the last profiled run in the reference's PerformanceInfo shape (src/engine/timing.rs:46-60)
+    struct Perf { bool realtime; int lag; uint32_t tick_rate; uint64_t tick_budget_us, engine_us; };
+    Perf performance_info(uint64_t* module_us, size_t cap);
     // module compat path: an InputRef may be Disconnected on one call and connected on the next
     void set_input_enabled(uint32_t node, uint32_t port, bool enabled);
     // video nodes
@@ -103,6 +109,8 @@ public:
     void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 
 private:
+    struct StateLoc { void* p; size_t bytes; };
+    std::vector<StateLoc> state_locs(uint32_t node) const;
     void plan_fusion();
     void layout_slab();
     void build_descriptors();
@@ -136,6 +144,10 @@ private:
     std::vector<std::vector<hipEvent_t>> prof_runs_;   // one event list (groups+1) per recorded run
     std::vector<std::vector<hipEvent_t>> prof_pool_;
     uint32_t last_calls_ = 0;
+    // PerformanceInfo bookkeeping (last profiled run)
+    std::vector<float> perf_group_ms_;   // per group (+1: video section) of the last collected run
+    float perf_total_ms_ = 0.f; uint32_t perf_calls_ = 0;
+    double perf_last_lag_s_ = -1.0;      // steady-clock seconds of the last over-budget tick; < 0: never
 };
 
 }  // namespace mx

@@ -301,15 +301,16 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     }
     const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.src) | p.src_stride) & 3u) == 0;
-    for (int idx = tid; idx < nr * nc4; idx += 256) {
-        const int r = idx / nc4, c4 = idx - r * nc4;
+    for (int r = tid >> 5; r < nr; r += 8) {                 // 32 lanes per window row, one dword each (no index division)
         const uint8_t* row = p.src + (size_t)min(max(ry0 + r, 0), sh1) * p.src_stride;
-        const int x = cxa + 4 * c4;
-        uint32_t w;
-        if (aligned && x >= 0 && x + 3 <= sw1) w = *reinterpret_cast<const uint32_t*>(row + x);
-        else w = (uint32_t)row[min(max(x, 0), sw1)] | ((uint32_t)row[min(max(x + 1, 0), sw1)] << 8) |
-                 ((uint32_t)row[min(max(x + 2, 0), sw1)] << 16) | ((uint32_t)row[min(max(x + 3, 0), sw1)] << 24);   // edge replication
-        *reinterpret_cast<uint32_t*>(S + (size_t)r * a.s_stride + 4 * c4) = w;
+        for (int c4 = tid & 31; c4 < nc4; c4 += 32) {
+            const int x = cxa + 4 * c4;
+            uint32_t w;
+            if (aligned && x >= 0 && x + 3 <= sw1) w = *reinterpret_cast<const uint32_t*>(row + x);
+            else w = (uint32_t)row[min(max(x, 0), sw1)] | ((uint32_t)row[min(max(x + 1, 0), sw1)] << 8) |
+                     ((uint32_t)row[min(max(x + 2, 0), sw1)] << 16) | ((uint32_t)row[min(max(x + 3, 0), sw1)] << 24);   // edge replication
+            *reinterpret_cast<uint32_t*>(S + (size_t)r * a.s_stride + 4 * c4) = w;
+        }
     }
     __syncthreads();
     if (ox0 + oxi < (int)p.dw) {   // H pass: t = (sum hc * S + 64) >> 7; the 4 taps come out of two aligned dwords

@@ -1,0 +1,182 @@
+"""ingest re-blocking (stream_input.rs:92-124), topology edits that keep module
+state (engine.rs:277-398) and the PerformanceInfo shape (timing.rs:46-60), through the C ABI on the device.
+
+Oracles: the re-blocking rule is restated here in a dozen lines of numpy (partly consumed frames stay queued,
+underruns are zero-filled, sample / 32768); module state across an edit is checked against the per-module CPU
+oracle run continuously -- a module must not notice that the connection set around it changed.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from mixlab_amd.workspace import Workspace
+
+pytestmark = pytest.mark.gpu
+
+SR = 44100
+SPT = 735
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------
+# ingest re-blocking
+# ------------------------------------------------------------------------------------------------
+def reblock_reference(frames, per_tick, n_ticks_per_feed):
+    """stream_input.rs:92-124 restated: returns the f32 ticks each feed produces and the zero-filled counts."""
+    q = np.zeros(0, np.int16)
+    fed, zeros = [], []
+    for pushes, n_ticks in zip(frames, n_ticks_per_feed):
+        for f in pushes:
+            q = np.concatenate([q, f])
+        out = np.zeros(per_tick * n_ticks, np.int16)
+        missing = 0
+        for t in range(n_ticks):
+            take = min(q.size, per_tick)
+            out[t * per_tick:t * per_tick + take] = q[:take]
+            q = q[take:]
+            missing += per_tick - take
+        fed.append(out.astype(np.float32) / np.float32(32768.0))   # convert_sample, stream_input.rs:167-173
+        zeros.append(missing)
+    return fed, zeros
+
+
+def test_pcm_ring_reblocks_ragged_frames_and_zero_fills_underruns():
+    rng = np.random.default_rng(7)
+    ws = Workspace(SR, 60)
+    src = ws.source_stereo()
+    amp = ws.amplifier(1.0, 0.0)
+    ws.connect(src, 0, amp, 0)
+    g = ws.build(max_ticks_per_run=4)
+    ring = abi.PcmRing()
+    per_tick = 2 * SPT
+    # feeds: ragged frame sizes (AAC-like 2048, odd sizes, one huge frame spanning ticks), then an underrun, then recovery
+    sizes = [[2048, 2048, 37], [1], [9000], [], [2 * per_tick + 11], [5, 7, 2048]]
+    frames = [[rng.integers(-32768, 32768, n, dtype=np.int16) for n in row] for row in sizes]
+    n_ticks = [2, 1, 4, 2, 1, 3]
+    want, want_zero = reblock_reference(frames, per_tick, n_ticks)
+    tick0 = 0
+    for row, nt, w, wz in zip(frames, n_ticks, want, want_zero):
+        for f in row:
+            ring.push(f)
+        z = ring.feed(g, src, nt)
+        assert z == wz
+        g.run_ticks(tick0, nt)
+        got = g.read_output(src, 0, nt, True)
+        assert np.array_equal(bits(got), bits(w))
+        # and it really is what the graph consumed: Amplifier(1.0, depth 0) is the identity in f64 -> f32
+        assert np.array_equal(bits(g.read_output(amp, 0, nt, True)), bits(w))
+        tick0 += nt
+    assert ring.queued() == 0 or ring.queued() < per_tick
+
+
+def test_pcm_ring_refuses_non_stereo_source():
+    ws = Workspace(SR, 60)
+    src = ws.source_mono()
+    g = ws.build()
+    ring = abi.PcmRing()
+    ring.push(np.zeros(10, np.int16))
+    with pytest.raises(abi.MxError) as e:
+        ring.feed(g, src, 1)
+    assert e.value.code == abi.MX_ERR_INVALID
+
+
+# ------------------------------------------------------------------------------------------------
+# topology edit: modules keep their state
+# ------------------------------------------------------------------------------------------------
+def test_topology_edit_keeps_eq_envelope_and_fir_state():
+    T = 6
+    gains = (3.0, -6.0, 4.5)
+    env_p = (25.0, 500.0, 0.8, 200.0)
+    taps = np.asarray(synth.uniform(5, 16, -0.3, 0.3), dtype=np.float64)
+    x = synth.noise(41, 3 * T * SPT)
+    xs = synth.noise(42, 3 * T * 2 * SPT)
+    gate = np.zeros(3 * T * SPT, np.float32); gate[100:5000] = 1.0; gate[9000:] = 1.0
+
+    def build(with_amp):
+        ws = Workspace(SR, 60)
+        s = ws.source_mono(); eq = ws.eq_three(*gains)
+        gs = ws.source_mono(); env = ws.envelope(*env_p)
+        ss = ws.source_stereo(); fir = ws.fir(taps)
+        ws.connect(s, 0, eq, 0); ws.connect(gs, 0, env, 0); ws.connect(ss, 0, fir, 0)
+        ids = {"s": s, "eq": eq, "gs": gs, "env": env, "ss": ss, "fir": fir}
+        if with_amp:   # the edit: a panner + amplifier appear behind the EQ, the envelope becomes their control
+            pan = ws.stereo_panner(); amp = ws.amplifier(1.0, 0.5)
+            ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1); ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1)
+            ids.update(pan=pan, amp=amp)
+        return ws, ids
+
+    def feed(g, ids, run):
+        g.write_source(ids["s"], x[run * T * SPT:(run + 1) * T * SPT], T)
+        g.write_source(ids["gs"], gate[run * T * SPT:(run + 1) * T * SPT], T)
+        g.write_source(ids["ss"], xs[run * T * 2 * SPT:(run + 1) * T * 2 * SPT], T)
+
+    # continuous oracle
+    est = oracle.eq_three_new(SR); want_eq = oracle.eq_three_run(est, gains, x)
+    vst = oracle.EnvState()
+    want_env = np.concatenate([oracle.envelope_run(vst, env_p, SR, k * SPT, gate[k * SPT:(k + 1) * SPT], SPT) for k in range(3 * T)])
+    hist = np.zeros((len(taps) - 1) * 2, np.float32); want_fir = oracle.fir_run(taps, hist, xs)
+
+    ws0, id0 = build(False)
+    g0 = ws0.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_EXACT)
+    feed(g0, id0, 0); g0.run_ticks(0, T)
+    assert np.array_equal(bits(g0.read_output(id0["eq"], 0, T, False)), bits(want_eq[:T * SPT]))
+
+    ws1, id1 = build(True)
+    g1 = ws1.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_EXACT)
+    mapping = [-1] * len(ws1.nodes)
+    for k in ("s", "eq", "gs", "env", "ss", "fir"):
+        mapping[id1[k]] = id0[k]
+    g1.adopt_state(g0, mapping)
+    del g0
+    for run in (1, 2):
+        feed(g1, id1, run); g1.run_ticks(run * T, T)
+        sl = slice(run * T * SPT, (run + 1) * T * SPT)
+        assert np.array_equal(bits(g1.read_output(id1["fir"], 0, T, True)), bits(want_fir[run * T * 2 * SPT:(run + 1) * T * 2 * SPT])), "FIR history lost"
+        got_amp = g1.read_output(id1["amp"], 0, T, True)
+        want_amp = oracle.amplifier_run(1.0, 0.5, np.repeat(want_eq[sl], 2), want_env[sl])
+        assert np.array_equal(bits(got_amp), bits(want_amp)), f"EqThree / Envelope state lost across the edit (run {run})"
+
+
+def test_topology_edit_refuses_kind_change_and_bad_maps():
+    ws = Workspace(SR, 60)
+    s = ws.source_mono(); e = ws.eq_three(0.0, 0.0, 0.0); ws.connect(s, 0, e, 0)
+    g0 = ws.build(); g1 = ws.build()
+    with pytest.raises(abi.MxError) as err:
+        g1.adopt_state(g0, [e, s])      # source <- eq
+    assert err.value.code == abi.MX_ERR_TYPE
+    with pytest.raises(abi.MxError):
+        g1.adopt_state(g0, [0])          # wrong length
+    with pytest.raises(abi.MxError):
+        g1.adopt_state(g0, [0, 99])      # out of range
+    g1.adopt_state(g0, [-1, -1])         # nothing survives: fine
+
+
+# ------------------------------------------------------------------------------------------------
+# PerformanceInfo
+# ------------------------------------------------------------------------------------------------
+def test_performance_info_shape_and_accounting():
+    ws = Workspace(48000, 60)
+    mix = ws.mixer([(0.0, 1.0, False)] * 8)
+    ids = []
+    for k in range(8):
+        trig = ws.trigger(True); env = ws.envelope(); src = ws.source_mono(); eq = ws.eq_three(1.0, 2.0, 3.0)
+        pan = ws.stereo_panner(); amp = ws.amplifier(1.0, 0.5)
+        ws.connect(trig, 0, env, 0); ws.connect(src, 0, eq, 0); ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1)
+        ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1); ws.connect(amp, 0, mix, k)
+        ids.append((trig, env, src, eq, pan, amp))
+    g = ws.build(max_ticks_per_run=4)
+    by_kind, total = g.profile_run(0, 4)
+    info, us = g.performance_info(len(ws.nodes))
+    assert info.tick_rate == 60 and info.tick_budget_us == 16666 and info.n_modules == len(ws.nodes)
+    assert info.realtime == 1 and info.lag == 0          # a few dozen microseconds per tick against 16.7 ms
+    tick_us = total * 1000.0 / 4
+    assert abs(sum(us) + info.engine_us - tick_us) <= len(ws.nodes) + 2      # accounts add up to the tick (rounding per account)
+    for trig, env, src, eq, pan, amp in ids:
+        assert us[src] == 0                                # a bound buffer costs nothing
+        assert us[eq] == us[pan] == us[amp] == us[env] == us[trig]   # folded into one launch: equal shares
+    assert us[mix] > 0
