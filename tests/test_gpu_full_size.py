@@ -1,0 +1,133 @@
+"""BASELINE.json configurations at their FULL sizes (1024 strips @48 kHz; 256 stereo FIR + resampler channels), checked
+through properties that do not need the CPU oracle to replay the whole job:
+
+* the Mixer is an ordered f32 sum: the oracle mixer fed with the DEVICE's own 1024 strip outputs must give the
+  device's Master / Cue bit for bit (checksum of parts);
+* batching is invisible: T ticks in one submission == T submissions of one tick, bit for bit (exact mode);
+* fusion is invisible: every surviving port has the same bits with and without it;
+* the time-parallel EqThree stays within 1 ULP of the exact-order kernel (itself bit-exact against the
+  reference's golden pair at small sizes), with rare mismatches, on every one of the 1024 strips;
+* time-splitting a stream across workgroups leaves the mix within a few ULP (span-initial states differ by ~1e-16).
+
+The small-size tests next door compare the same kernels against the oracle sample by sample.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from test_gpu_audio_parity import strips, bits
+from test_gpu_fir_resample import polyphase_table, reverb_taps
+
+pytestmark = pytest.mark.gpu
+
+SR48, SPT48 = 48000, 800
+N = 1024
+
+
+def _feed(g, srcs, noise, run, T, spt):
+    for k, s in enumerate(srcs):
+        g.write_source(s, noise[k][run * T * spt:(run + 1) * T * spt], T)
+
+
+@pytest.fixture(scope="module")
+def noise48():
+    return [synth.noise(k, 16 * SPT48) for k in range(N)]
+
+
+def test_config2_full_size_mixer_is_the_ordered_sum_of_the_device_strips(noise48):
+    T = 4
+    ws, mix, srcs, trigs = strips(N, SR48)
+    g = ws.build(max_ticks_per_run=T)
+    for k, tr in enumerate(trigs):
+        g.update_params(tr, abi.TriggerParams(((k % 60) // 30) == 1))
+    _feed(g, srcs, noise48, 0, T, SPT48)
+    g.run_ticks(0, T)
+    chans = [(float(synth.uniform(11, N, -24.0, 6.0)[k]), float(synth.uniform(12, N, 0.0, 1.0)[k]), k % 8 == 0) for k in range(N)]
+    dev_amp = [g.read_output(mix + 6 * k + 6, 0, T, True) for k in range(N)]
+    want_m, want_c = oracle.mixer_run(chans, dev_amp, 2 * T * SPT48)
+    assert np.array_equal(bits(g.read_output(mix, 0, T, True)), bits(want_m))
+    assert np.array_equal(bits(g.read_output(mix, 1, T, True)), bits(want_c))
+
+
+def test_config2_full_size_batching_and_fusion_are_invisible_in_exact_mode(noise48):
+    T = 6
+    outs = {}
+    for name, flags, batch in (("batched", abi.FLAG_EQ_EXACT, T), ("ticked", abi.FLAG_EQ_EXACT, 1), ("unfused", abi.FLAG_EQ_EXACT | abi.FLAG_NO_FUSE, T)):
+        ws, mix, srcs, trigs = strips(N, SR48)
+        g = ws.build(max_ticks_per_run=batch, flags=flags)
+        res_m, res_c = [], []
+        for t0 in range(0, T, batch):
+            for k, s in enumerate(srcs):
+                g.write_source(s, noise48[k][t0 * SPT48:(t0 + batch) * SPT48], batch)
+            g.run_ticks(t0, batch)
+            res_m.append(g.read_output(mix, 0, batch, True)); res_c.append(g.read_output(mix, 1, batch, True))
+        outs[name] = (np.concatenate(res_m), np.concatenate(res_c))
+    for other in ("ticked", "unfused"):
+        assert np.array_equal(bits(outs["batched"][0]), bits(outs[other][0])), f"Master differs: batched vs {other}"
+        assert np.array_equal(bits(outs["batched"][1]), bits(outs[other][1])), f"Cue differs: batched vs {other}"
+
+
+def test_config2_full_size_time_parallel_eq_within_one_ulp_of_exact_order_on_every_strip(noise48):
+    T = 16
+    res = {}
+    for name, flags in (("exact", abi.FLAG_EQ_EXACT), ("scan", 0)):
+        ws, mix, srcs, trigs = strips(N, SR48)
+        g = ws.build(max_ticks_per_run=T, flags=flags)
+        for k, tr in enumerate(trigs):
+            g.update_params(tr, abi.TriggerParams(((k % 60) // 30) == 1))
+        _feed(g, srcs, noise48, 0, T, SPT48)
+        g.run_ticks(0, T)
+        res[name] = np.stack([g.read_output(mix + 6 * k + 6, 0, T, True)[0::2] for k in range(N)])
+    d = synth.ulp_diff(res["scan"].ravel(), res["exact"].ravel())
+    assert d.max() <= 1
+    assert np.count_nonzero(d) <= d.size // 20000, f"{np.count_nonzero(d)} of {d.size} samples differ by 1 ULP"
+
+
+def test_rank_sized_shard_time_split_mix_close_to_unsplit(noise48, monkeypatch):
+    # what one rank of an 8-GPU job runs: 128 strips, streams cut into 8 spans
+    T = 16
+    outs = []
+    for force in ("1", "0"):
+        monkeypatch.setenv("MX_EQ_SPLIT", force)
+        ws, mix, srcs, trigs = strips(128, SR48)
+        g = ws.build(max_ticks_per_run=T)
+        res = []
+        for run in range(1):
+            _feed(g, srcs, noise48, run, T, SPT48)
+            g.run_ticks(run * T, T)
+            res.append(g.read_output(mix, 0, T, True))
+        outs.append(np.concatenate(res))
+    assert np.max(np.abs(outs[0] - outs[1])) <= 16 * np.spacing(np.float32(np.max(np.abs(outs[0]))))
+    assert np.count_nonzero(outs[0] != outs[1]) <= outs[0].size // 500
+
+
+def test_config3_full_size_256_channels_fir_then_resampler_spot_checked_against_oracle():
+    n_ch, T, SPT = 256, 4, 735
+    from mixlab_amd.workspace import Workspace
+    table = polyphase_table()
+    ws = Workspace(44100, 60)
+    srcs, outs = [], []
+    for k in range(n_ch):
+        s = ws.source_stereo(); f = ws.fir(reverb_taps(128, seed=20 + k)); r = ws.resample(160, 147, table)
+        ws.connect(s, 0, f, 0); ws.connect(f, 0, r, 0)
+        srcs.append(s); outs.append((f, r))
+    mix = ws.mixer([(0.0, 1.0, k % 2 == 0) for k in range(n_ch)])
+    for k, (_f, r) in enumerate(outs):
+        ws.connect(r, 0, mix, k)
+    g = ws.build(max_ticks_per_run=T)
+    noise = [synth.noise(60 + k, 2 * SPT * T) for k in range(n_ch)]
+    for k, s in enumerate(srcs):
+        g.write_source(s, noise[k], T)
+    g.run_ticks(0, T)
+    # every 17th channel against the per-module oracle; the mix against the oracle mixer over the device's own channels
+    for k in range(0, n_ch, 17):
+        taps = reverb_taps(128, seed=20 + k)
+        hist = np.zeros((len(taps) - 1) * 2, np.float32)
+        want_f = oracle.fir_run(taps, hist, noise[k])
+        assert np.array_equal(bits(g.read_output(outs[k][0], 0, T, True)), bits(want_f)), f"FIR channel {k}"
+    dev_r = [g.read_output(r, 0, T, True, rate=(160, 147)) for (_f, r) in outs]
+    want_m, want_c = oracle.mixer_run([(0.0, 1.0, k % 2 == 0) for k in range(n_ch)], dev_r, 2 * T * 800)
+    assert np.array_equal(bits(g.read_output(mix, 0, T, True, rate=(160, 147))), bits(want_m))
+    assert np.array_equal(bits(g.read_output(mix, 1, T, True, rate=(160, 147))), bits(want_c))
