@@ -543,6 +543,14 @@ int orc_graph_run_tick(orc_graph* g, uint64_t tick) {
     return 0;
 }
 
+int orc_graph_run_ticks(orc_graph* g, uint64_t first_tick, uint32_t n) {
+    for (uint32_t k = 0; k < n; ++k) {
+        const int rc = orc_graph_run_tick(g, first_tick + k);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 const float* orc_graph_output(const orc_graph* g, uint32_t node, uint32_t port, size_t* len) {
     if (node >= g->n_nodes || port >= g->nodes[node].n_out) return NULL;
     if (len) *len = node_len(g, &g->nodes[node], g->nodes[node].out_type[port]);

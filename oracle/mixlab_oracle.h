@@ -136,6 +136,8 @@ int orc_graph_update_params(orc_graph* g, uint32_t node, const void* params, uin
 int orc_graph_set_source(orc_graph* g, uint32_t node, const float* samples);
 /* one Engine::run_tick: fresh zeroed outputs, topological order, t = tick * SPT */
 int orc_graph_run_tick(orc_graph* g, uint64_t tick);
+/* n consecutive ticks with the sources left as they are (one foreign call: lets a threaded timing harness run free of the caller's interpreter lock) */
+int orc_graph_run_ticks(orc_graph* g, uint64_t first_tick, uint32_t n);
 /* borrow the output buffer a port produced in the last tick (NULL if bad ids) */
 const float* orc_graph_output(const orc_graph* g, uint32_t node, uint32_t port, size_t* len);
 /* plotter indication of the last tick: returns 1 if it fired, copies SPT floats to each */

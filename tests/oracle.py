@@ -65,6 +65,7 @@ lib.orc_graph_samples_per_tick.argtypes = [C.c_void_p]
 lib.orc_graph_set_source.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
 lib.orc_graph_update_params.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
 lib.orc_graph_run_tick.argtypes = [C.c_void_p, C.c_uint64]
+lib.orc_graph_run_ticks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
 lib.orc_graph_output.restype = C.POINTER(C.c_float)
 lib.orc_graph_output.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
 lib.orc_graph_plotter_indication.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -187,6 +188,9 @@ class OracleGraph:
 
     def run_tick(self, tick: int):
         assert lib.orc_graph_run_tick(self._h, tick) == 0
+
+    def run_ticks(self, first_tick: int, n: int):
+        assert lib.orc_graph_run_ticks(self._h, first_tick, n) == 0
 
     def output(self, node, port) -> np.ndarray:
         n = C.c_size_t()
