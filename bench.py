@@ -207,6 +207,61 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
     }
 
 
+def fir_leg(torch, stream, local_rank, T, steps, warmup):
+    """BASELINE.json configs[2] (build-specified): 256 stereo channels @44.1 kHz ->
+    128-tap FIR reverb -> 160/147 polyphase resampler (16 taps per phase) -> 48 kHz-domain Mixer(256).
+    f64 accumulation in ascending tap order with separate multiply and add, one rounding to f32."""
+    import synth
+    from mixlab_amd.workspace import Workspace
+
+    n_ch, SPT = 256, 735
+    up, down, tpp = 160, 147, 16
+    n = up * tpp
+    m = np.arange(n) - (n - 1) / 2.0
+    fc = 0.5 / max(up, down) * 0.92
+    table = np.ascontiguousarray((2 * fc * np.sinc(2 * fc * m) * np.kaiser(n, 8.6) * up).reshape(tpp, up).T)
+    ws = Workspace(44100, 60)
+    srcs, rs = [], []
+    for k in range(n_ch):
+        taps = (synth.uniform(20 + k, 128, -1.0, 1.0) * np.exp(-np.arange(128) / 24.0) * 0.35).astype(np.float64)
+        s = ws.source_stereo(); f = ws.fir(taps); r = ws.resample(up, down, table)
+        ws.connect(s, 0, f, 0); ws.connect(f, 0, r, 0)
+        srcs.append(s); rs.append(r)
+    mix = ws.mixer([(0.0, 1.0, k % 2 == 0) for k in range(n_ch)])
+    for k, r in enumerate(rs):
+        ws.connect(r, 0, mix, k)
+    g = ws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
+    for k, s in enumerate(srcs):
+        blk = synth.noise(60 + k, 2 * SPT * min(T, 64))
+        g.write_source(s, np.tile(blk, (T + 63) // 64)[: 2 * SPT * T], T)
+    for i in range(max(1, warmup)):
+        g.run_ticks(i * T, T)
+    torch.cuda.synchronize()
+    g.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        g.run_ticks((warmup + i) * T, T)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g.profile_enable(False)
+    by_kind, _tot, n_prof = g.profile_collect()
+    frames_in = T * SPT
+    # f64 operations the spec prescribes: per output frame 2 channels x taps x (mul + add)
+    fir_ops = n_ch * frames_in * 2 * 128 * 2
+    rs_ops = n_ch * (T * 800) * 2 * tpp * 2
+    k_ms = {k: v / max(1, n_prof) for k, v in by_kind.items() if v > 0}
+    out = {"metric": "fir_resample_stereo_ch_ticks_per_sec", "value": n_ch * T * steps / dt, "unit": "channel-ticks/s",
+           "workload": "256 stereo channels @44.1 kHz: 128-tap FIR -> 160/147 polyphase resampler (16 taps/phase) -> Mixer(256) @48 kHz",
+           "ticks_per_step": T, "ms_per_step": dt / steps * 1e3, "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
+           "realtime_stereo_channels_equiv": n_ch * T * steps / dt / 60.0}
+    if "fir" in k_ms:
+        out["fir_f64_valu"] = {"ops_per_launch": fir_ops, "achieved_tops": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12, 2), "peak_tops": 39.3,
+                               "frac": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12 / 39.3, 3), "note": "prescribed f64 mul + add only (no FMA by spec)"}
+    if "resample" in k_ms:
+        out["resample_f64_tops"] = round(rs_ops / (k_ms["resample"] * 1e-3) / 1e12, 2)
+    return out
+
+
 class _DevArray:
     """zero-copy torch view of a device buffer owned by libmixlab_gpu (plumbing for RCCL)."""
 
@@ -257,6 +312,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-combine", action="store_true", help="debug: run the N>1 all-gather + combine path at N=1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
+    ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
     args = ap.parse_args()
 
@@ -407,6 +463,11 @@ def main():
         with torch.cuda.stream(stream):
             video = video_leg(torch, dist, world, stream, local_rank, args.video_frames, args.warmup)
 
+    fir = None
+    if args.fir_ticks > 0 and not use_dist:
+        with torch.cuda.stream(stream):
+            fir = fir_leg(torch, stream, local_rank, args.fir_ticks, 10, 2)
+
     if rank == 0:
         units = args.strips * T * args.steps
         value = units / dt
@@ -458,6 +519,7 @@ def main():
             "roofline": roof,
             "realtime": realtime,
             "video": video,
+            "fir_resample": fir,
         }
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None

@@ -562,7 +562,13 @@ void Graph::upload_group(Group& g) {
     }
     case MX_KIND_RESAMPLE: {
         size_t tt = 0, th = 0; g.max_taps = 0;
-        for (uint32_t id : g.nodes) { mx_resample_params h; std::memcpy(&h, nodes_[id].params.data(), sizeof h); tt += (size_t)h.up * h.taps_per_phase; th += h.taps_per_phase; g.max_taps = std::max(g.max_taps, h.taps_per_phase); }
+        g.rs_tab_doubles = 0; g.rs_win_frames = 0;
+        for (uint32_t id : g.nodes) {
+            mx_resample_params h; std::memcpy(&h, nodes_[id].params.data(), sizeof h);
+            tt += (size_t)h.up * h.taps_per_phase; th += h.taps_per_phase; g.max_taps = std::max(g.max_taps, h.taps_per_phase);
+            g.rs_tab_doubles = (uint32_t)std::min<uint64_t>(0xffffffffu, std::max<uint64_t>(g.rs_tab_doubles, (uint64_t)h.up * h.taps_per_phase));
+            g.rs_win_frames = (uint32_t)std::min<uint64_t>(0xffffffffu, std::max<uint64_t>(g.rs_win_frames, (uint64_t)255 * h.down / h.up + 2 + h.taps_per_phase));
+        }
         std::vector<double> taps(tt);
         if (g.extra.bytes < tt * sizeof(double) || !g.extra.p) g.extra.alloc(tt * sizeof(double));
         if (!g.state.p) { g.state.alloc(th * sizeof(float2)); hip_check(hipMemset(g.state.p, 0, th * sizeof(float2)), "hipMemset"); }
@@ -719,7 +725,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, gf, stream_); break;
         case MX_KIND_FIR: launch_fir((const FirDesc*)g.desc.p, n, g.max_taps, gf, stream_); break;
         case MX_KIND_RESAMPLE:
-            launch_resample((const ResampleDesc*)g.desc.p, n, g.max_taps, frames * g.in_dom_num / g.in_dom_den, gf,
+            launch_resample((const ResampleDesc*)g.desc.p, n, g.max_taps, g.rs_tab_doubles, g.rs_win_frames, frames * g.in_dom_num / g.in_dom_den, gf,
                             t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_);
             break;
         case MX_KIND_PLOTTER: {

@@ -8,38 +8,82 @@
 //
 // Every output sample is independent given the input history, so both kernels are plain
 // data-parallel: a 256-lane block stages its input window in LDS (coalesced), taps are wave-uniform.
+#include <algorithm>
+
 #include "mx_dev.hpp"
 
 namespace mx {
 
 #define FIR_BLOCK 256
-// out[n] = (f32) sum_k h[k] * (f64) x[n-k] per channel; x[m<0] comes from the carried history
+#define FIR_PER 4                          // consecutive outputs per lane
+#define FIR_TILE (FIR_BLOCK * FIR_PER)     // outputs per block step
+// out[n] = (f32) sum_k h[k] * (f64) x[n-k] per channel; x[m<0] comes from the carried history.
+//
+// The prescribed work is 4 f64 operations per tap and stereo frame (2 mul + 2 add, no FMA by spec).  With one output
+// per lane every tap step also needs 16 B of LDS per lane, and LDS (128 B/clk/CU) feeds only half of what the four
+// SIMDs can multiply -- measured 0.475 of the f64 rate, exactly that roof.  So a lane owns FOUR consecutive outputs:
+// their inputs are a sliding window in registers, one new frame per tap step serves all four, LDS traffic drops 4x.
+// Lanes then read frames 4 apart; the window is stored with one pad frame after every 4 (p = f + f/4): a stride of
+// 5 frames = 20 banks, and the 16 lanes a ds_read_b128 serves per pass cover all 64 banks exactly once.
+// Frames are widened to f64 once while staging (exact); taps sit in LDS (uniform reads broadcast).
+__device__ __forceinline__ int fir_pad(int f) { return f + (f >> 2); }
 __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const FirDesc* __restrict__ descs, size_t frames) {
     const FirDesc d = descs[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* win = reinterpret_cast<float2*>(smem);           // [FIR_BLOCK + n_taps - 1] stereo frames
     const int K = (int)d.n_taps;
-    for (size_t blk = (size_t)blockIdx.x * FIR_BLOCK; blk < frames; blk += (size_t)gridDim.x * FIR_BLOCK) {
-        // window frames blk-(K-1) .. blk+FIR_BLOCK-1
-        for (int w = threadIdx.x; w < FIR_BLOCK + K - 1; w += FIR_BLOCK) {
+    double* tapl = reinterpret_cast<double*>(smem);                       // [K rounded up to even]
+    double2* win = reinterpret_cast<double2*>(tapl + ((K + 1) & ~1));     // padded window of FIR_TILE + K - 1 frames
+    for (int k = threadIdx.x; k < K; k += FIR_BLOCK) tapl[k] = d.taps[k];
+    // FIR_PER zero frames in front of the window: the frame that "enters" after the last tap of the first output is
+    // never used, and with the pad its read needs no guard -- the tap loop is branch-free
+    if (threadIdx.x < FIR_PER) win[fir_pad((int)threadIdx.x)] = make_double2(0.0, 0.0);
+    const int WN = FIR_TILE + K - 1;
+    for (size_t blk = (size_t)blockIdx.x * FIR_TILE; blk < frames; blk += (size_t)gridDim.x * FIR_TILE) {
+        // window frame w <-> stream frame blk - (K-1) + w
+        for (int w = threadIdx.x; w < WN; w += FIR_BLOCK) {
             const long long f = (long long)blk + w - (K - 1);
             float2 v = make_float2(0.f, 0.f);
             if (f >= 0) { if ((size_t)f < frames && d.in) v = reinterpret_cast<const float2*>(d.in)[f]; }
             else { const long long h = (long long)(K - 1) + f; if (h >= 0) v = d.hist[h]; }   // hist[j] = x[j - (K-1)]
-            win[w] = v;
+            win[fir_pad(w + FIR_PER)] = make_double2((double)v.x, (double)v.y);
         }
         __syncthreads();
-        const size_t n = blk + threadIdx.x;
-        if (n < frames) {
-            double al = 0.0, ar = 0.0;
-            const float2* x = win + threadIdx.x + (K - 1);     // x[0] = current frame
-            for (int k = 0; k < K; ++k) {
-                const double h = d.taps[k];
-                const float2 v = x[-k];
-                al = al + h * (double)v.x;
-                ar = ar + h * (double)v.y;
+        const int o = FIR_PER * (int)threadIdx.x;                         // my first output inside the tile
+        if (blk + o < frames) {
+            double al[FIR_PER], ar[FIR_PER];
+            double2 w[FIR_PER];                                           // w[j] = x[o + j - k] for the current tap k
+            // o is a multiple of 4, so fir_pad(o + m) = fir_pad(o) + fir_pad(m): one per-lane base, wave-uniform (scalar) offsets
+            const char* lane_base = reinterpret_cast<const char*>(win) + (size_t)fir_pad(o) * sizeof(double2);
+            auto rd = [&](int m) { return *reinterpret_cast<const double2*>(lane_base + (size_t)fir_pad(m) * sizeof(double2)); };
+#pragma unroll
+            for (int j = 0; j < FIR_PER; ++j) { al[j] = 0.0; ar[j] = 0.0; w[j] = rd(j + (K - 1) + FIR_PER); }
+            int k = 0;
+#pragma unroll 2
+            for (; k + FIR_PER <= K; k += FIR_PER) {
+#pragma unroll
+                for (int u = 0; u < FIR_PER; ++u) {                       // tap k + u: the window has slid u frames; slot names rotate, nothing moves
+                    const double h = tapl[k + u];
+#pragma unroll
+                    for (int j = 0; j < FIR_PER; ++j) {
+                        const double2 x = w[(j - u + FIR_PER) % FIR_PER];
+                        al[j] = al[j] + h * x.x;
+                        ar[j] = ar[j] + h * x.y;
+                    }
+                    // frame x[o - 1 - (k + u)] enters; it replaces the slot of x[o + 3 - (k + u)], which no later tap needs
+                    w[(FIR_PER - 1 - u + FIR_PER) % FIR_PER] = rd((K - 1) - 1 - (k + u) + FIR_PER);
+                }
             }
-            reinterpret_cast<float2*>(d.out)[n] = make_float2((float)al, (float)ar);
+            for (; k < K; ++k) {                                          // K not a multiple of 4: rotate by moving
+                const double h = tapl[k];
+#pragma unroll
+                for (int j = 0; j < FIR_PER; ++j) { al[j] = al[j] + h * w[j].x; ar[j] = ar[j] + h * w[j].y; }
+#pragma unroll
+                for (int j = FIR_PER - 1; j > 0; --j) w[j] = w[j - 1];
+                w[0] = rd((K - 1) - 1 - k + FIR_PER);
+            }
+            float2* out = reinterpret_cast<float2*>(d.out) + blk + o;
+#pragma unroll
+            for (int j = 0; j < FIR_PER; ++j) if (blk + o + j < frames) out[j] = make_float2((float)al[j], (float)ar[j]);
         }
         __syncthreads();
     }
@@ -62,8 +106,9 @@ __global__ __launch_bounds__(256) void k_fir_history(const FirDesc* __restrict__
 }
 void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    const size_t lds = (FIR_BLOCK + max_taps) * sizeof(float2);
-    dim3 grid(grid_x(frames, FIR_BLOCK, 1024), n);
+    const size_t wn = (size_t)FIR_TILE + max_taps + FIR_PER;
+    const size_t lds = (size_t)((max_taps + 1) & ~1u) * sizeof(double) + (wn + wn / 4 + 2) * sizeof(double2);
+    dim3 grid(grid_x(frames, FIR_TILE, 1024), n);
     hipLaunchKernelGGL(k_fir, grid, dim3(FIR_BLOCK), lds, s, d, frames);
     hipLaunchKernelGGL(k_fir_history, dim3(n), dim3(256), max_taps * sizeof(float2), s, d, frames);
 }
@@ -71,8 +116,63 @@ void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, 
 // Rational resampler.  Output sample m (absolute index M = out_base + m):
 //   n = floor(M * down / up), phase = (M * down) mod up
 //   y[m] = (f32) sum_{k < P} h[phase][k] * (f64) x[n - k]      (x indexed absolutely; x before the run from history)
+//
+// k_resample: a block owns 256 consecutive outputs.  Their inputs are one contiguous window (256 * down / up + P
+// frames), staged in LDS with coalesced loads; the polyphase table sits in LDS TRANSPOSED ([k][phase]: consecutive
+// outputs walk distinct phases, so a tap step reads 64 different doubles, at most 2 per bank pair, instead of 64
+// rows of one 128-byte-strided column); the 64-bit division M * down / up is done once per block, each lane only
+// divides a 32-bit offset.  A block walks many 256-output groups so the table is loaded once per ~50 groups.
+// k_resample_gather is the plain form for tables that do not fit LDS.
 __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict__ descs, size_t out_frames,
-                                                  uint64_t out_base, uint64_t in_base) {
+                                                  uint64_t out_base, uint64_t in_base, uint32_t win_cap) {
+    const ResampleDesc d = descs[blockIdx.y];
+    const int P = (int)d.taps_per_phase, H = P - 1;
+    const uint32_t up = d.up, down = d.down;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);                       // [P][up]
+    double2* win = reinterpret_cast<double2*>(tab + (size_t)P * up);     // [win_cap] widened once while staging
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)P * up; i += 256) {
+        const uint32_t ph = i / (uint32_t)P, k = i - ph * (uint32_t)P;
+        tab[(size_t)k * up + ph] = d.taps[i];
+    }
+    const bool small = (uint64_t)255 * down + up < (1ull << 32);          // lane offsets fit 32 bits (always, for audio ratios)
+    for (size_t blk = (size_t)blockIdx.x * 256; blk < out_frames; blk += (size_t)gridDim.x * 256) {
+        const uint64_t num0 = (out_base + blk) * down;
+        const uint64_t n0_abs = num0 / up;                                // block-uniform
+        const uint32_t r0 = (uint32_t)(num0 - n0_abs * up);
+        const uint32_t last = (uint32_t)min((size_t)255, out_frames - 1 - blk);
+        const uint32_t span = (uint32_t)((r0 + (uint64_t)last * down) / up);   // n of the last output relative to n0
+        const long long f0 = (long long)(n0_abs - in_base) - H;           // input index of win[0]
+        const uint32_t cnt = min(span + 1u + (uint32_t)H, win_cap);
+        for (uint32_t w = tid; w < cnt; w += 256) {
+            const long long f = f0 + w;
+            float2 v = make_float2(0.f, 0.f);
+            if (f >= 0) { if (d.in) v = reinterpret_cast<const float2*>(d.in)[f]; }
+            else { const long long hh = (long long)H + f; if (hh >= 0) v = d.hist[hh]; }
+            win[w] = make_double2((double)v.x, (double)v.y);
+        }
+        __syncthreads();
+        if (blk + tid < out_frames) {
+            uint32_t dn, phase;
+            if (small) { const uint32_t q = r0 + (uint32_t)tid * down; dn = q / up; phase = q - dn * up; }
+            else { const uint64_t q = r0 + (uint64_t)tid * down; dn = (uint32_t)(q / up); phase = (uint32_t)(q - (uint64_t)dn * up); }
+            const double2* x = win + H + dn;                              // x[0] = frame n of this output
+            const double* h = tab + phase;
+            double al = 0.0, ar = 0.0;
+            for (int k = 0; k < P; ++k) {
+                const double c = h[(size_t)k * up];
+                const double2 v = x[-k];
+                al = al + c * v.x;
+                ar = ar + c * v.y;
+            }
+            reinterpret_cast<float2*>(d.out)[blk + tid] = make_float2((float)al, (float)ar);
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_resample_gather(const ResampleDesc* __restrict__ descs, size_t out_frames,
+                                                         uint64_t out_base, uint64_t in_base) {
     const ResampleDesc d = descs[blockIdx.y];
     const int P = (int)d.taps_per_phase, H = P - 1;
     for (size_t m = (size_t)blockIdx.x * 256 + threadIdx.x; m < out_frames; m += (size_t)gridDim.x * 256) {
@@ -109,11 +209,17 @@ __global__ __launch_bounds__(256) void k_resample_history(const ResampleDesc* __
     __syncthreads();
     for (int j = threadIdx.x; j < H; j += 256) d.hist[j] = tmp[j];
 }
-void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, size_t in_frames, size_t out_frames,
-                     uint64_t in_base, uint64_t out_base, hipStream_t s) {
+void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles, uint32_t win_frames,
+                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s) {
     if (!n || !out_frames) return;
-    dim3 grid(grid_x(out_frames, 256, 1024), n);
-    hipLaunchKernelGGL(k_resample, grid, dim3(256), 0, s, d, out_frames, out_base, in_base);
+    const size_t lds = (size_t)tab_doubles * sizeof(double) + (size_t)win_frames * sizeof(double2);
+    if (lds <= 60 * 1024) {
+        // few blocks per channel, each walking many 256-output groups: the table is loaded once per block
+        const uint32_t per_ch = (uint32_t)std::max<size_t>(1, std::min<size_t>((out_frames + 255) / 256, std::max<uint32_t>(1u, 4096u / n)));
+        hipLaunchKernelGGL(k_resample, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
+    } else {
+        hipLaunchKernelGGL(k_resample_gather, dim3(grid_x(out_frames, 256, 1024), n), dim3(256), 0, s, d, out_frames, out_base, in_base);
+    }
     hipLaunchKernelGGL(k_resample_history, dim3(n), dim3(256), (max_taps + 1) * sizeof(float2), s, d, in_frames);
 }
 
