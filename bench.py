@@ -108,6 +108,20 @@ def cpu_baseline_all_cores(Workspace, synth, abi, shard, n_strips, sample_rate, 
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    quota = None
+    try:   # a container may see every host CPU and still be throttled to a few cores' worth of time
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
     n_thr = max(1, min(cores, n_strips))
     shards = []
     for r in range(n_thr):
@@ -117,23 +131,29 @@ def cpu_baseline_all_cores(Workspace, synth, abi, shard, n_strips, sample_rate, 
         for j, sn in enumerate(srcs):
             og.set_source(sn, synth.noise(first + j, ws.spt))
         shards.append(og)
-    worst = max(1, (n_strips + n_thr - 1) // n_thr)
-    n_ticks = int(max(4, min(400000, target_seconds / max(per_strip_tick_s * worst, 1e-7))))
-    go = threading.Barrier(n_thr + 1)
 
-    def work(og):
+    def timed(n_ticks):
+        go = threading.Barrier(n_thr + 1)
+
+        def work(og):
+            go.wait()
+            og.run_ticks(0, n_ticks)     # one foreign call per thread: the GIL is released for its whole duration
+
+        th = [threading.Thread(target=work, args=(og,)) for og in shards]
+        for t in th:
+            t.start()
         go.wait()
-        og.run_ticks(0, n_ticks)     # one foreign call per thread: the GIL is released for its whole duration
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
 
-    th = [threading.Thread(target=work, args=(og,)) for og in shards]
-    for t in th:
-        t.start()
-    go.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    probe = 16
+    dt_probe = timed(probe)                                   # calibrate under the real contention, then run the bounded sample
+    n_ticks = int(max(probe, min(400000, target_seconds / max(dt_probe / probe, 1e-7))))
+    dt = timed(n_ticks)
     return {"value": n_strips * n_ticks / dt, "unit": "channel-ticks/s", "cores": n_thr, "kind": "port",
+            "cpu_quota_cores": quota, "host_logical_cpus": os.cpu_count(),
             "sample": f"{n_strips} strips in {n_thr} contiguous shards (one thread each) x {n_ticks} ticks @ {sample_rate} Hz, {dt:.1f} s"}
 
 
