@@ -232,6 +232,15 @@ int mx_video_crossfade(mx_dframe* out, const mx_dframe* a, const mx_dframe* b, d
  * equal, else blank + aspect-preserving letterboxed bicubic.  The bicubic arithmetic is
  * BUILD-SPECIFIED (libswscale is outside the reference tree): see DESIGN.md "Scaler". */
 int mx_video_scale(const mx_dframe* in, mx_dframe* out, void* stream);
+/* DynamicScaler (src/video/encode.rs:338-397): keeps its context (tap tables, blank letterboxed output frame) while the
+ * input settings stay the same -- what Monitor / StreamOutput call once per tick to shrink the program frame before it
+ * leaves the device (monitor.rs:21-22, stream_output.rs:23-24, encode.rs:287-295).  *out holds one reference
+ * (mx_dframe_release); it is the input itself when the sizes are equal (encode.rs:342-345), else the scaler's own frame,
+ * overwritten by the next call.  Asynchronous on the scaler's stream. */
+typedef struct mx_video_scaler mx_video_scaler;
+int mx_video_scaler_create(uint32_t out_width, uint32_t out_height, void* stream, mx_video_scaler** out);
+int mx_video_scaler_scale(mx_video_scaler* sc, const mx_dframe* in, mx_dframe** out);
+void mx_video_scaler_destroy(mx_video_scaler* sc);
 int mx_video_scale_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                             uint32_t* scaled_w, uint32_t* scaled_h, uint32_t* letterbox_x, uint32_t* letterbox_y);   /* encode.rs:354-374 */
 /* BUILD-SPECIFIED (no reference counterpart): BT.709 limited-range YUV420P -> RGBA8 (+ optional Q12 3x4 matrix). */

@@ -175,6 +175,35 @@ int mx_video_scale(const mx_dframe* in, mx_dframe* out, void* stream) {
     });
 }
 
+/* DynamicScaler (src/video/encode.rs:338-397): a scaler that keeps its context (tap tables, blank letterboxed output
+ * frame) while the input settings stay the same -- the per-tick rescale of Monitor / StreamOutput (encode.rs:287-295). */
+struct mx_video_scaler { std::unique_ptr<mx::Scaler> s; hipStream_t stream; };
+
+int mx_video_scaler_create(uint32_t out_width, uint32_t out_height, void* stream, mx_video_scaler** out) {
+    return guard([&] {
+        REQUIRE(out, "out is NULL");
+        REQUIRE(out_width && out_height && !(out_width & 1) && !(out_height & 1), "output size must be even and non-zero (yuv420p)");
+        auto* h = new mx_video_scaler();
+        h->stream = S(stream);
+        h->s.reset(new mx::Scaler(out_width, out_height, h->stream));
+        *out = h;
+    });
+}
+int mx_video_scaler_scale(mx_video_scaler* sc, const mx_dframe* in, mx_dframe** out) {
+    return guard([&] {
+        REQUIRE(sc && in && out, "NULL argument");
+        FrameRef src(const_cast<DFrame*>(D(in)), true);
+        FrameRef res = sc->s->scale(src);           // the input itself when the settings are equal (encode.rs:342-345)
+        mx::flush_scales(sc->stream);
+        mx::hip_check(hipGetLastError(), "scale launch");
+        res->retain();
+        *out = H(res.f);
+    });
+}
+void mx_video_scaler_destroy(mx_video_scaler* sc) {
+    (void)guard([&] { if (sc) { (void)hipStreamSynchronize(sc->stream); delete sc; } });
+}
+
 int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride, const int32_t* matrix_q12, void* stream) {
     return guard([&] {
         REQUIRE(in && device_rgba, "NULL argument");

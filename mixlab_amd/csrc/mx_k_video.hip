@@ -3,6 +3,8 @@
 // Integer work throughout: results are bit-exact against the CPU oracle.
 // Frames are planar yuv420p, 8 bit, resident in HBM; every plane row starts 64-byte aligned
 // (stride % 64 == 0), so a lane moves 16 pixels (one dwordx4) and a wave 1 KiB per instruction.
+#include <algorithm>
+
 #include "mx_dev.hpp"
 #include "mx_video.hpp"
 
@@ -399,6 +401,38 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
     }
 }
+// Downscaling: the kernel widens with the scale factor (hn / vn taps, DESIGN.md "Scaler").  Two plain passes through
+// ScalePlane::tmp -- the H pass filters every source row once, the V pass reads vn of those rows per pixel -- instead of
+// hn * vn source reads per pixel.  Same arithmetic as the 4-tap kernels; outputs are monitor-sized, this is not a hot path.
+__global__ __launch_bounds__(256) void k_scale_wide_h(ScaleArgs a) {
+    const ScalePlane p = a.p[blockIdx.z];
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.dw || y >= p.sh) return;
+    const uint8_t* row = p.src + (size_t)y * p.src_stride;
+    const int32_t* c = p.hcoef + (size_t)x * p.hn;
+    const int f = p.hfirst[x], sw1 = (int)p.sw - 1;
+    int acc = 0;
+    for (uint32_t k = 0; k < p.hn; ++k) acc += c[k] * (int)row[min(max(f + (int)k, 0), sw1)];
+    p.tmp[(size_t)y * p.dw + x] = (acc + 64) >> 7;
+}
+__global__ __launch_bounds__(256) void k_scale_wide_v(ScaleArgs a) {
+    const ScalePlane p = a.p[blockIdx.z];
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.dw || y >= p.dh) return;
+    const int32_t* c = p.vcoef + (size_t)y * p.vn;
+    const int f = p.vfirst[y], sh1 = (int)p.sh - 1;
+    int acc = 0;
+    for (uint32_t k = 0; k < p.vn; ++k) acc += c[k] * p.tmp[(size_t)min(max(f + (int)k, 0), sh1) * p.dw + x];
+    p.dst[(size_t)y * p.dst_stride + x] = (uint8_t)min(max((acc + (1 << 20)) >> 21, 0), 255);
+}
+void launch_scale_wide(const ScaleArgs& a, hipStream_t s) {
+    uint32_t mw = 0, msh = 0, mdh = 0;
+    for (int i = 0; i < 3; ++i) { mw = std::max(mw, a.p[i].dw); msh = std::max(msh, a.p[i].sh); mdh = std::max(mdh, a.p[i].dh); }
+    if (!mw || !msh || !mdh) return;
+    hipLaunchKernelGGL(k_scale_wide_h, dim3((mw + 63) / 64, (msh + 3) / 4, 3), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_scale_wide_v, dim3((mw + 63) / 64, (mdh + 3) / 4, 3), dim3(256), 0, s, a);
+}
+
 void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s) {
     ScaleBatchArgs b;
     b.n = 3;

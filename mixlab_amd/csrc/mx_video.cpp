@@ -185,16 +185,39 @@ static int32_t cubic_weight_q14(int64_t X) {   // |x| in Q16
     const int64_t den = 5 * ((int64_t)1 << 34);
     return (int32_t)floor_div(2 * num + den, 2 * den);
 }
+static uint32_t tap_count(uint32_t src, uint32_t dst) {   // DESIGN.md "Scaler": the kernel widens with the scale factor when downscaling
+    if (src <= dst) return 4;
+    return 2 * (uint32_t)((2 * (uint64_t)src + dst - 1) / dst) + 2;
+}
 static void make_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef) {
-    first.resize(dst); coef.resize((size_t)dst * 4);
+    const uint32_t n = tap_count(src, dst);
+    first.resize(dst); coef.resize((size_t)dst * n);
     for (uint32_t o = 0; o < dst; ++o) {
         const int64_t pos = floor_div((2 * (int64_t)o + 1) * (int64_t)src * 65536, 2 * (int64_t)dst) - 32768;
         const int64_t ip = pos >> 16, d = pos & 0xffff;
-        int32_t c[4] = {cubic_weight_q14(65536 + d), cubic_weight_q14(d), cubic_weight_q14(65536 - d), cubic_weight_q14(131072 - d)};
-        const int32_t resid = 16384 - (c[0] + c[1] + c[2] + c[3]);
-        if (c[2] > c[1]) c[2] += resid; else c[1] += resid;
-        first[o] = (int32_t)ip - 1;
-        std::memcpy(&coef[(size_t)o * 4], c, sizeof c);
+        int32_t* c = &coef[(size_t)o * n];
+        if (n == 4) {
+            c[0] = cubic_weight_q14(65536 + d); c[1] = cubic_weight_q14(d); c[2] = cubic_weight_q14(65536 - d); c[3] = cubic_weight_q14(131072 - d);
+            const int32_t resid = 16384 - (c[0] + c[1] + c[2] + c[3]);
+            if (c[2] > c[1]) c[2] += resid; else c[1] += resid;
+            first[o] = (int32_t)ip - 1;
+            continue;
+        }
+        first[o] = (int32_t)ip - (int32_t)(n / 2) + 1;
+        int64_t sum = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            int64_t dist = ((int64_t)first[o] + k) * 65536 - pos;
+            if (dist < 0) dist = -dist;
+            c[k] = cubic_weight_q14(floor_div(dist * (int64_t)dst, (int64_t)src));
+            sum += c[k];
+        }
+        int64_t tot = 0; uint32_t best = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            c[k] = (int32_t)floor_div(2 * (int64_t)c[k] * 16384 + sum, 2 * sum);
+            tot += c[k];
+            if (c[k] > c[best]) best = k;
+        }
+        c[best] += (int32_t)(16384 - tot);
     }
 }
 
@@ -209,7 +232,9 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
         std::vector<int32_t> hf, hc, vf, vc;
         make_taps(in_w >> c, geo_.scaled_w >> c, hf, hc);
         make_taps(in_h >> c, geo_.scaled_h >> c, vf, vc);
-        if (!scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_h >> c, geo_.scaled_h >> c, vf.data()))
+        taps_[c][0] = tap_count(in_w >> c, geo_.scaled_w >> c); taps_[c][1] = tap_count(in_h >> c, geo_.scaled_h >> c);
+        if (taps_[c][0] == 4 && taps_[c][1] == 4 &&
+            (!scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_h >> c, geo_.scaled_h >> c, vf.data())))
             throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
@@ -219,6 +244,15 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
     tabs_.alloc(blob.size() * sizeof(int32_t));
     hip_check(hipMemcpy(tabs_.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(taps)");
     for (int c = 0; c < 2; ++c) for (int k = 0; k < 4; ++k) tab_[c][k] = (const int32_t*)tabs_.p + offs[c][k];
+    // downscaling on any axis: the two-pass path keeps the H-filtered rows of each plane in device memory
+    const bool wide = taps_[0][0] > 4 || taps_[0][1] > 4 || taps_[1][0] > 4 || taps_[1][1] > 4;
+    tmp_plane_[0] = tmp_plane_[1] = tmp_plane_[2] = nullptr;
+    if (wide) {
+        size_t off[3], total = 0;
+        for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; off[p] = total; total += (size_t)(geo_.scaled_w >> c) * (in_h >> c); }
+        tmp_.alloc(total * sizeof(int32_t));
+        for (int p = 0; p < 3; ++p) tmp_plane_[p] = (int32_t*)tmp_.p + off[p];
+    }
 }
 
 FrameRef Scaler::scale(const FrameRef& in) {
@@ -235,6 +269,12 @@ FrameRef Scaler::scale(const FrameRef& in) {
         sp.dst = frame_->data[p] + (size_t)(geo_.letterbox_y >> c) * frame_->stride[p] + (geo_.letterbox_x >> c);
         sp.dst_stride = frame_->stride[p]; sp.dw = geo_.scaled_w >> c; sp.dh = geo_.scaled_h >> c;
         sp.hfirst = tab_[c][0]; sp.hcoef = tab_[c][1]; sp.vfirst = tab_[c][2]; sp.vcoef = tab_[c][3];
+        sp.hn = taps_[c][0]; sp.vn = taps_[c][1]; sp.tmp = tmp_plane_[p];
+    }
+    if (tmp_plane_[0]) {                    // widened kernel (downscale): two passes, launched in stream order
+        flush_scales(stream_);
+        launch_scale_wide(a, stream_);
+        return frame_;
     }
     queue_scale(a, stream_, in, frame_);   // leaves with the other scales of this tick as one launch
     return frame_;

@@ -25,8 +25,10 @@ struct FadeArgs {
 struct ScalePlane {
     const uint8_t* src; uint8_t* dst;
     uint32_t src_stride, dst_stride, sw, sh, dw, dh;
-    const int32_t* hfirst; const int32_t* hcoef;   // [dw], [dw][4]
-    const int32_t* vfirst; const int32_t* vcoef;   // [dh], [dh][4]
+    const int32_t* hfirst; const int32_t* hcoef;   // [dw], [dw][hn]
+    const int32_t* vfirst; const int32_t* vcoef;   // [dh], [dh][vn]
+    uint32_t hn, vn;                               // taps per output sample: 4, or 2*ceil(2*src/dst)+2 on a downscaled axis
+    int32_t* tmp;                                  // wide path only: [sh][dw] H-filtered rows
 };
 struct ScaleArgs { ScalePlane p[3]; };
 enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
@@ -44,6 +46,7 @@ struct RgbaArgs {
 };
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s);
+void launch_scale_wide(const ScaleArgs& a, hipStream_t s);   // two passes through ScalePlane::tmp, any tap counts
 bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first);   // f64 window-origin formula of the tiled scaler == tap table
 
 // A chain of cross-fades evaluated per pixel in registers:  v = src[0];  for k >= 1:
@@ -157,6 +160,9 @@ private:
     ScaleGeometry geo_{};
     FrameRef frame_;                 // cached blank output frame (encode.rs:382)
     DevBuf tabs_;                    // tap tables for luma and chroma
+    DevBuf tmp_;                     // downscaling: H-filtered rows of the three planes
+    int32_t* tmp_plane_[3] = {nullptr, nullptr, nullptr};
+    uint32_t taps_[2][2] = {{4, 4}, {4, 4}};   // [luma/chroma][h, v]
     const int32_t* tab_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [luma/chroma][hfirst,hcoef,vfirst,vcoef]
 };
 

@@ -32,6 +32,9 @@ _proto("mx_dframe_planes", C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER
 _proto("mx_video_blank", C.c_int, C.c_void_p, C.c_void_p)
 _proto("mx_video_crossfade", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p)
 _proto("mx_video_scale", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_proto("mx_video_scaler_create", C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_video_scaler_scale", C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_video_scaler_destroy", None, C.c_void_p)
 _proto("mx_video_scale_geometry", C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _proto("mx_video_to_rgba", C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p)
@@ -156,6 +159,26 @@ def crossfade(out: DFrame, a: DFrame | None, b: DFrame | None, fader: float, str
 
 def scale(src: DFrame, dst: DFrame, stream=None):
     check(lib.mx_video_scale(src._h, dst._h, stream))
+
+
+class Scaler:
+    """mx_video_scaler_*: DynamicScaler (src/video/encode.rs:338-397) -- context kept across calls."""
+
+    def __init__(self, out_w, out_h, stream=None):
+        self._h = C.c_void_p()
+        check(lib.mx_video_scaler_create(out_w, out_h, stream, C.byref(self._h)))
+
+    def scale(self, src: "DFrame") -> "DFrame":
+        h = C.c_void_p()
+        check(lib.mx_video_scaler_scale(self._h, src._h, C.byref(h)))
+        return DFrame(handle=h.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.mx_video_scaler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
 
 
 def scale_geometry(in_w, in_h, out_w, out_h):

@@ -169,6 +169,9 @@ void orc_scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t 
 /* BUILD-SPECIFIED stand-in for sws_scale(SWS_BICUBIC) (codec/src/ffmpeg/scale.rs:16-39,49-70):
  * separable Catmull-Rom-family cubic (B=0,C=0.6), 14-bit coefficients, see DESIGN.md.  Scales one
  * plane. parity unpinned. */
+/* taps per output sample on one axis: 4, or 2*ceil(2*src/dst)+2 when downscaling (widened kernel) */
+uint32_t orc_bicubic_tap_count(uint32_t src, uint32_t dst);
+void orc_bicubic_taps_n(uint32_t o, uint32_t src, uint32_t dst, int32_t* first, int32_t* coef);
 void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
                              uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh);
 /* src/video/encode.rs:338-397: identity when sizes match (copies), else blank + scale into letterbox */

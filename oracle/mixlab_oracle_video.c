@@ -125,31 +125,65 @@ static void bicubic_taps(uint32_t o, uint32_t src, uint32_t dst, int32_t* first,
 }
 static inline int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* Downscaling (src > dst on an axis) widens the kernel with the scale factor, as libswscale does for SWS_BICUBIC: the
+ * same cubic stretched by s = src/dst, so every source sample between two output centres is weighted instead of skipped.
+ *   N = 2*ceil(2*src/dst) + 2 taps ; first = (pos>>16) - N/2 + 1 ; tap k sits at i = first + k ;
+ *   raw_k = cubic_q14( floor(|i*65536 - pos| * dst / src) ) ; coefficients = round-half-up(raw_k * 16384 / sum raw),
+ *   the first largest coefficient absorbs the residual so each set sums to 16384.  Upscaling and 1:1 keep the 4-tap
+ *   form above bit for bit.  Passes as before. */
+uint32_t orc_bicubic_tap_count(uint32_t src, uint32_t dst) {
+    if (src <= dst) return 4;
+    return 2 * (uint32_t)((2 * (uint64_t)src + dst - 1) / dst) + 2;
+}
+void orc_bicubic_taps_n(uint32_t o, uint32_t src, uint32_t dst, int32_t* first, int32_t* c /* [orc_bicubic_tap_count] */) {
+    const uint32_t n = orc_bicubic_tap_count(src, dst);
+    if (n == 4) { bicubic_taps(o, src, dst, first, c); return; }
+    int64_t pos = floordiv((int64_t)(2 * (int64_t)o + 1) * src * 65536, 2 * (int64_t)dst) - 32768;
+    int64_t ip = pos >> 16;
+    *first = (int32_t)ip - (int32_t)(n / 2) + 1;
+    int64_t sum = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        int64_t dist = ((int64_t)*first + k) * 65536 - pos;
+        if (dist < 0) dist = -dist;
+        c[k] = cubic_q14(floordiv(dist * dst, src));
+        sum += c[k];
+    }
+    int64_t tot = 0; uint32_t best = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        c[k] = (int32_t)floordiv(2 * (int64_t)c[k] * 16384 + sum, 2 * sum);
+        tot += c[k];
+        if (c[k] > c[best]) best = k;
+    }
+    c[best] += (int32_t)(16384 - tot);
+}
+
 void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
                              uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh) {
+    const uint32_t hn = orc_bicubic_tap_count(sw, dw), vn = orc_bicubic_tap_count(sh, dh);
     int32_t* hfirst = (int32_t*)malloc(sizeof(int32_t) * dw);
-    int32_t* hc = (int32_t*)malloc(sizeof(int32_t) * 4 * dw);
-    for (uint32_t x = 0; x < dw; x++) bicubic_taps(x, sw, dw, &hfirst[x], &hc[4 * x]);
+    int32_t* hc = (int32_t*)malloc(sizeof(int32_t) * hn * dw);
+    for (uint32_t x = 0; x < dw; x++) orc_bicubic_taps_n(x, sw, dw, &hfirst[x], &hc[(size_t)hn * x]);
     int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * (size_t)dw * sh);
     for (uint32_t y = 0; y < sh; y++) {
         const uint8_t* row = src + (size_t)y * src_stride;
         for (uint32_t x = 0; x < dw; x++) {
             int32_t acc = 0;
-            for (int k = 0; k < 4; k++) acc += hc[4 * x + k] * (int32_t)row[clampi(hfirst[x] + k, 0, (int32_t)sw - 1)];
+            for (uint32_t k = 0; k < hn; k++) acc += hc[(size_t)hn * x + k] * (int32_t)row[clampi(hfirst[x] + (int32_t)k, 0, (int32_t)sw - 1)];
             tmp[(size_t)y * dw + x] = (acc + 64) >> 7;
         }
     }
+    int32_t* vc = (int32_t*)malloc(sizeof(int32_t) * vn);
     for (uint32_t y = 0; y < dh; y++) {
-        int32_t vfirst, vc[4];
-        bicubic_taps(y, sh, dh, &vfirst, vc);
+        int32_t vfirst;
+        orc_bicubic_taps_n(y, sh, dh, &vfirst, vc);
         uint8_t* drow = dst + (size_t)y * dst_stride;
         for (uint32_t x = 0; x < dw; x++) {
             int32_t acc = 0;
-            for (int k = 0; k < 4; k++) acc += vc[k] * tmp[(size_t)clampi(vfirst + k, 0, (int32_t)sh - 1) * dw + x];
+            for (uint32_t k = 0; k < vn; k++) acc += vc[k] * tmp[(size_t)clampi(vfirst + (int32_t)k, 0, (int32_t)sh - 1) * dw + x];
             drow[x] = (uint8_t)clampi((acc + (1 << 20)) >> 21, 0, 255);
         }
     }
-    free(hfirst); free(hc); free(tmp);
+    free(hfirst); free(hc); free(tmp); free(vc);
 }
 
 /* DynamicScaler::scale, src/video/encode.rs:338-397: equal settings => the frame itself (here: a

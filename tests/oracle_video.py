@@ -27,6 +27,8 @@ lib.orc_dynamic_scale.argtypes = [C.POINTER(OFrame), C.POINTER(OFrame)]
 lib.orc_scaler_geometry.argtypes = [C.c_uint32] * 4 + [C.POINTER(ScaleGeometry)]
 lib.orc_unify_picture_settings.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
 lib.orc_yuv420_to_rgba.argtypes = [C.POINTER(OFrame), C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+lib.orc_bicubic_tap_count.argtypes = [C.c_uint32, C.c_uint32]
+lib.orc_bicubic_tap_count.restype = C.c_uint32
 
 
 def align(v, a):

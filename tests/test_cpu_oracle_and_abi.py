@@ -225,3 +225,16 @@ def test_oracle_bicubic_is_identity_preserving_and_bounded():
         p[:] = 200
     dst = ov.HostFrame(128, 96); ov.dynamic_scale(src, dst)
     assert all((v == 200).all() for v in dst.visible())     # taps sum to exactly 1.0 in Q14: flat stays flat
+    # downscaling widens the kernel (2 * ceil(2 * src / dst) + 2 taps, normalised to 1.0 in Q14): flat stays flat, and a
+    # one-pixel checkerboard -- which a 4-tap kernel would alias into stripes -- averages out to mid grey
+    small = ov.HostFrame(16, 12); ov.dynamic_scale(src, small)
+    assert all((v == 200).all() for v in small.visible())
+    assert ov.lib.orc_bicubic_tap_count(1920, 560) == 16 and ov.lib.orc_bicubic_tap_count(560, 1920) == 4 and ov.lib.orc_bicubic_tap_count(100, 100) == 4
+    chk = ov.HostFrame(256, 256)
+    yy, xx = np.mgrid[0:256, 0:256]
+    chk.planes[0][:256, :256] = np.where((xx + yy) % 2 == 0, 16, 235)
+    for p in chk.planes[1:]:
+        p[:] = 128
+    out = ov.HostFrame(64, 64); ov.dynamic_scale(chk, out)
+    y = out.visible()[0][4:-4, 4:-4].astype(int)
+    assert abs(int(y.mean()) - 125) <= 2 and y.max() - y.min() <= 6

@@ -59,7 +59,9 @@ def test_crossfade_missing_channel_reads_blank(which):
 
 
 @pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((640, 480), (1920, 1080)), ((1920, 1080), (560, 350)),
-                                  ((1000, 300), (640, 640)), ((64, 64), (64, 64)), ((322, 182), (1120, 700))])
+                                  ((1000, 300), (640, 640)), ((64, 64), (64, 64)), ((322, 182), (1120, 700)),
+                                  # downscales (widened kernel): monitor sizes, a 12.8x shrink, a ratio just above 1, awkward sizes
+                                  ((1920, 1080), (1120, 700)), ((4096, 2160), (320, 180)), ((1922, 1082), (1920, 1080)), ((1002, 564), (400, 226))])
 def test_dynamic_scale_letterbox_bit_exact_vs_build_spec(geom):
     (iw, ih), (ow, oh) = geom
     assert video.scale_geometry(iw, ih, ow, oh) == ov.scaler_geometry(iw, ih, ow, oh)
@@ -68,6 +70,19 @@ def test_dynamic_scale_letterbox_bit_exact_vs_build_spec(geom):
     dsrc, out = upload(src), video.DFrame(ow, oh)
     video.scale(dsrc, out)
     assert_frame_equal(out, want, f"scale {geom}")
+
+
+def test_persistent_scaler_is_the_monitor_rescale_and_follows_input_changes():
+    # Monitor / StreamOutput shrink the program frame every tick with one DynamicScaler (encode.rs:287-295,338-397)
+    sc = video.Scaler(560, 350)
+    for k, (iw, ih) in enumerate([(1920, 1080), (1920, 1080), (1280, 720), (560, 350)]):
+        src = ov.HostFrame(iw, ih).fill(k, seed=9)
+        want = ov.HostFrame(560, 350); ov.dynamic_scale(src, want)
+        d = upload(src)
+        out = sc.scale(d)
+        assert_frame_equal(out, want, f"scaler call {k} {iw}x{ih}")
+        if (iw, ih) == (560, 350):
+            assert out.device_planes()[0] == d.device_planes()[0]      # equal settings: the frame itself (encode.rs:342-345)
 
 
 def test_scale_geometry_examples():
