@@ -505,6 +505,8 @@ void Graph::upload_group(Group& g) {
             o += nch;
         }
         g.dup_mode = n_dup == 0 ? 0 : (n_dup == total ? 1 : 2);
+        g.max_taps = 0;
+        for (uint32_t id : g.nodes) g.max_taps = std::max<uint32_t>(g.max_taps, (uint32_t)nodes_[id].in_type.size());   // Mixer: most channels
         hip_check(hipMemcpy(g.extra.p, ch.data(), ch.size() * sizeof(MixChan), hipMemcpyHostToDevice), "hipMemcpy(mixchan)");
         up(g.desc, d.data(), n * sizeof(MixDesc));
         break;
@@ -718,7 +720,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
             }
             break;
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
-        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, gf, g.dup_mode, stream_); break;
+        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, g.max_taps /* = most channels */, gf, g.dup_mode, stream_); break;
         case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, gf, stream_); break;
         case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, gf, stream_); break;

@@ -151,7 +151,113 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
     }
 }
 
-void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, int dup_mode, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// Short streams (the real-time mode: one tick = 800 frames): k_mixer is then a handful of waves, each walking all
+// channels with at most 32 loads in flight -- pure load latency (61 us for 1024 channels, whatever the chip).
+// k_mixer_coop keeps the single ordered add chain per output but lets SIXTEEN waves work for it: a block owns 64
+// frames; per batch of channels every wave loads its share, forms the products (in as f64 * gain) as f32 and the cue
+// term (x or +0.0) and lands {product, cue term} in LDS; wave 0 then only walks the batch in channel order with one
+// packed f32 add per channel -- the ordered sums -- while the next batch is already in flight.
+// The cue term as a select is exact: the cue bus never holds -0.0 (it starts +0.0 and +0.0 + -0.0 = +0.0), so adding
+// +0.0 for a non-cue channel changes nothing, NaN and infinity included.
+// ---------------------------------------------------------------------------------------------
+#define MC_WAVES 16
+template <int DUP> struct McCfg { static constexpr int FW = DUP ? 1 : 2; static constexpr int BATCH = DUP ? 128 : 64; static constexpr int PER = BATCH / MC_WAVES; };
+
+template <int DUP>   // 1: every input stored mono (L == R), 0: every input interleaved stereo
+__global__ __launch_bounds__(64 * MC_WAVES) void k_mixer_coop(const MixDesc* __restrict__ descs, size_t frames) {
+    constexpr int FW = McCfg<DUP>::FW, BATCH = McCfg<DUP>::BATCH, PER = McCfg<DUP>::PER;
+    typedef float __attribute__((ext_vector_type(2 * FW))) Slot;      // {products[FW], cue terms[FW]} of one frame and channel
+    const MixDesc m = descs[blockIdx.y];
+    const MixChan* __restrict__ ch = m.chans;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) char mc_smem[];
+    Slot* lds = reinterpret_cast<Slot*>(mc_smem);                     // [2][BATCH][64]
+    const size_t f0 = (size_t)blockIdx.x * 64;
+    const bool live = f0 + lane < frames;
+    const uint32_t foff = (uint32_t)((live ? f0 + lane : frames - 1) * (FW * sizeof(float)));   // lanes past the end re-read the last frame, never stored
+    const uint32_t n_ch = m.n_ch, n_batch = (n_ch + BATCH - 1) / BATCH;
+
+    // descriptors of my share of a batch: one channel per lane (lanes < PER), broadcast with v_readlane at use; channels past
+    // the end repeat the last one with gain 0 and no cue (+0.0 terms).  Disconnected inputs point at the graph's zero buffer.
+    uint64_t p_nxt, g_nxt; uint32_t cue_nxt;
+    auto fetch_desc = [&](uint32_t b) {
+        const uint32_t c = b * BATCH + wave * PER + (lane < PER ? lane : 0);
+        const MixChan* mc = ch + (c < n_ch ? c : n_ch - 1);
+        p_nxt = (uint64_t)mc->in;
+        g_nxt = (uint64_t)__double_as_longlong(c < n_ch ? mc->gain : 0.0);
+        cue_nxt = (uint32_t)__ballot(c < n_ch && mc->cue != 0);
+    };
+    float v[PER][FW];
+    auto issue = [&](uint64_t pl) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) ldw<FW>(bcast_u64(pl, u), foff, v[u]);
+    };
+    auto land = [&](uint32_t b, uint64_t gl, uint32_t cuel, uint32_t valid /* channels of mine that exist */) {
+        Slot* dst = lds + ((size_t)(b & 1) * BATCH + (size_t)wave * PER) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const double g = __longlong_as_double((long long)bcast_u64(gl, u));
+            const bool cue = ((cuel >> u) & 1u) != 0;
+            Slot sl;
+#pragma unroll
+            for (int k = 0; k < FW; ++k) {
+                const float x = (uint32_t)u < valid ? v[u][k] : 0.0f;                // a channel past the end contributes +0.0 + +0.0
+                sl[k] = (float)((double)x * g);                                      // mixer.rs:62 (the product)
+                sl[FW + k] = cue ? x : 0.0f;                                         // mixer.rs:64-66 (what the cue bus gets)
+            }
+            dst[(size_t)u * 64] = sl;
+        }
+    };
+    auto my_valid = [&](uint32_t b) -> uint32_t {
+        const uint32_t c0 = b * BATCH + wave * PER;
+        return c0 >= n_ch ? 0u : (n_ch - c0 < (uint32_t)PER ? n_ch - c0 : (uint32_t)PER);
+    };
+
+    fetch_desc(0);
+    uint64_t p_cur = p_nxt, g_cur = g_nxt; uint32_t cue_cur = cue_nxt;
+    issue(p_cur);
+    if (n_batch > 1) fetch_desc(1);
+    land(0, g_cur, cue_cur, my_valid(0));
+    __syncthreads();
+
+    Slot acc;                                                         // {master[FW], cue[FW]}: both ordered sums in one packed add per channel
+#pragma unroll
+    for (int k = 0; k < 2 * FW; ++k) acc[k] = 0.f;                    // util::zero(master/cue), mixer.rs:54-55
+    for (uint32_t b = 0; b < n_batch; ++b) {
+        const bool more = b + 1 < n_batch;                            // uniform
+        if (more) {
+            p_cur = p_nxt; g_cur = g_nxt; cue_cur = cue_nxt;
+            issue(p_cur);
+            if (b + 2 < n_batch) fetch_desc(b + 2);
+        }
+        if (wave == 0) {
+            const Slot* src = lds + (size_t)(b & 1) * BATCH * 64 + lane;
+            const uint32_t c0 = b * BATCH, cnt = n_ch - c0 < (uint32_t)BATCH ? n_ch - c0 : (uint32_t)BATCH;
+            uint32_t u = 0;
+            for (; u + 16 <= cnt; u += 16) {
+                Slot t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t[j] = src[(size_t)(u + j) * 64];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += t[j];             // channel order
+            }
+            for (; u < cnt; ++u) acc += src[(size_t)u * 64];
+        }
+        if (more) {
+            land(b + 1, g_cur, cue_cur, my_valid(b + 1));             // the other buffer: wave 0 finished with it one barrier ago
+            __syncthreads();
+        }
+    }
+    if (wave == 0 && live) {
+        float2* om = reinterpret_cast<float2*>(m.master) + f0 + lane;
+        float2* oc = reinterpret_cast<float2*>(m.cue) + f0 + lane;
+        if constexpr (DUP) { *om = make_float2(acc[0], acc[0]); *oc = make_float2(acc[1], acc[1]); }   // L == R inputs: one chain is both
+        else { *om = make_float2(acc[0], acc[1]); *oc = make_float2(acc[2], acc[3]); }
+    }
+}
+
+void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch, size_t frames, int dup_mode, hipStream_t s) {
     if (!n || !frames) return;
     const size_t ns = frames * 2;
     // widest lane vector that still yields enough waves to cover the chip; tuning override for experiments
@@ -163,6 +269,16 @@ void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, int dup_mode, hip
     }
     if (w == 4 && (ns & 3)) w = 2;                 // ns = 2 * frames is always even
     if (ns * sizeof(float) >= (1ull << 32)) return;  // unreachable: the engine caps a port buffer below 4 GiB
+    // short streams with many channels: the cooperative form (see k_mixer_coop)
+    static const int coop_max_blocks = env_int("MX_MIXER_COOP_BLOCKS", 512);
+    const size_t coop_blocks = (frames + 63) / 64 * n;
+    if (dup_mode != 2 && max_ch >= 128 && coop_blocks <= (size_t)coop_max_blocks) {
+        const size_t lds = (size_t)2 * (dup_mode ? McCfg<1>::BATCH * McCfg<1>::FW : McCfg<0>::BATCH * McCfg<0>::FW) * 64 * 2 * sizeof(float);
+        const dim3 g((unsigned)((frames + 63) / 64), n);
+        if (dup_mode) hipLaunchKernelGGL(k_mixer_coop<1>, g, dim3(64 * MC_WAVES), lds, s, d, frames);
+        else hipLaunchKernelGGL(k_mixer_coop<0>, g, dim3(64 * MC_WAVES), lds, s, d, frames);
+        return;
+    }
     const size_t items = ns / w;
     dim3 grid(grid_x(items, 64, 16384), n);
 #define MX_MIX_LAUNCH(W, R, D) hipLaunchKernelGGL((k_mixer<W, R, D>), grid, dim3(64), 0, s, d, ns)

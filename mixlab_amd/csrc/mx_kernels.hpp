@@ -87,7 +87,8 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frame
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s);
 void eq_plan_split(uint32_t n, size_t frames, double lo_f, double hi_f, EqSplit& sp);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
-void launch_mixer(const MixDesc* d, uint32_t n, size_t frames, int dup_mode /* 0 none, 1 all, 2 mixed */, hipStream_t s);
+void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch /* most channels of any mixer in the group */, size_t frames,
+                  int dup_mode /* 0 none, 1 all, 2 mixed */, hipStream_t s);
 void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s);
