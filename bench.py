@@ -167,7 +167,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
     build-specified YUV420P->RGBA + colour matrix.  One composited 1080p RGBA frame per tick.
     N > 1: every rank composites its own independent 8-layer stream (independent VideoMixer
     instances) -- no exchange step, weak scaling."""
-    import oracle_video as ov   # only its synthetic-pattern generator (numpy); nothing of the oracle is timed or used as a result
+    import synth   # seeded synthetic patterns (numpy only)
     from mixlab_amd import video
     from mixlab_amd.workspace import Workspace
 
@@ -185,8 +185,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
     g = ws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
     keep = []
     for k, (w, h) in enumerate(sizes):
-        hf = ov.HostFrame(w, h).fill(k, seed=3)
-        y, u, v = hf.visible()
+        y, u, v = synth.yuv_pattern(w, h, k, seed=3)
         d = video.DFrame(w, h).upload(y, u, v)
         keep.append(d)
         video.graph_set_video_source(g, srcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)

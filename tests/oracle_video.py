@@ -52,11 +52,9 @@ class HostFrame:
 
     def fill(self, layer, seed=0):
         """SURVEY.md section 8d config 4 pattern: Y(x,y) = (x + 2y + 31*layer + LCG noise) mod 256, U/V similar at half res."""
-        for p in range(3):
-            hh, ww = self.h >> (1 if p else 0), self.w >> (1 if p else 0)
-            yy, xx = np.mgrid[0:hh, 0:ww].astype(np.uint32)
-            lcg = ((xx * np.uint32(1664525) + yy * np.uint32(1013904223) + np.uint32(seed * 7919 + layer * 104729 + p * 31337)) >> np.uint32(13)) & np.uint32(15)
-            self.planes[p][:, :ww] = ((xx + 2 * yy + 31 * layer + 57 * p + lcg) & np.uint32(255)).astype(np.uint8)
+        import synth
+        for p, a in enumerate(synth.yuv_pattern(self.w, self.h, layer, seed)):
+            self.planes[p][:, : a.shape[1]] = a
         return self
 
 
