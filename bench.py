@@ -281,6 +281,68 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup):
     return out
 
 
+def video_cpu_baseline(target_seconds=4.0):
+    """CPU oracle (C, one thread) on the config-4 cascade: 7 reference VideoMixer cross-fades (+2 bicubic letterbox scales)
+    + YUV->RGBA + matrix per composited 1080p frame; a bounded number of frames."""
+    import oracle_video as ov   # test infrastructure: used here only as the timed CPU baseline
+    import synth
+
+    sizes = [(1920, 1080)] * 6 + [(1280, 720)] * 2
+    layers = []
+    for k, (w, h) in enumerate(sizes):
+        hf = ov.HostFrame(w, h)
+        for pl, a in zip(hf.visible(), synth.yuv_pattern(w, h, k, seed=3)):
+            pl[:] = a
+        layers.append(hf)
+    oms = [ov.OracleVideoMixer(a=0, b=1, fader=VIDEO_FADERS[k]) for k in range(7)]
+
+    def one(tick):
+        prev = (layers[0], (1, 60), (0, 1))
+        for k in range(7):
+            out = oms[k].run_tick(tick * 800, [prev, (layers[k + 1], (1, 60), (0, 1)), None, None])
+            prev = (out, (1, 60), (0, 1))
+        return ov.to_rgba(prev[0], VIDEO_MATRIX)
+
+    t0 = time.perf_counter(); one(0); per = time.perf_counter() - t0
+    n = int(max(2, min(200, target_seconds / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(1, n + 1):
+        one(i)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"{n} composited 1080p frames, single thread, {dt:.1f} s"}
+
+
+def fir_cpu_baseline(T_ref_ticks=8, n_ch=8):
+    """CPU oracle (C, one thread) on config 3, a bounded slice: n_ch of the 256 stereo channels for a few ticks."""
+    import oracle  # test infrastructure: used here only as the timed CPU baseline
+    import synth
+    from mixlab_amd.workspace import Workspace
+
+    up, down, tpp = 160, 147, 16
+    n = up * tpp
+    m = np.arange(n) - (n - 1) / 2.0
+    fc = 0.5 / max(up, down) * 0.92
+    table = np.ascontiguousarray((2 * fc * np.sinc(2 * fc * m) * np.kaiser(n, 8.6) * up).reshape(tpp, up).T)
+    ws = Workspace(44100, 60)
+    srcs, rs = [], []
+    for k in range(n_ch):
+        taps = (synth.uniform(20 + k, 128, -1.0, 1.0) * np.exp(-np.arange(128) / 24.0) * 0.35).astype(np.float64)
+        s = ws.source_stereo(); f = ws.fir(taps); r = ws.resample(up, down, table)
+        ws.connect(s, 0, f, 0); ws.connect(f, 0, r, 0)
+        srcs.append(s); rs.append(r)
+    mix = ws.mixer([(0.0, 1.0, k % 2 == 0) for k in range(n_ch)])
+    for k, r in enumerate(rs):
+        ws.connect(r, 0, mix, k)
+    og = oracle.OracleGraph(ws)
+    for k, s in enumerate(srcs):
+        og.set_source(s, synth.noise(60 + k, 2 * 735))
+    t0 = time.perf_counter(); og.run_ticks(0, 4); per = (time.perf_counter() - t0) / 4
+    n_ticks = int(max(T_ref_ticks, min(20000, 3.0 / max(per, 1e-6))))
+    t0 = time.perf_counter(); og.run_ticks(4, n_ticks); dt = time.perf_counter() - t0
+    return {"value": n_ch * n_ticks / dt, "unit": "channel-ticks/s", "cores": 1, "kind": "port",
+            "sample": f"{n_ch} of the 256 stereo channels x {n_ticks} ticks, single thread, {dt:.1f} s"}
+
+
 class _DevArray:
     """zero-copy torch view of a device buffer owned by libmixlab_gpu (plumbing for RCCL)."""
 
@@ -543,6 +605,10 @@ def main():
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
         else:
+            if video is not None:
+                video["cpu_baseline"] = video_cpu_baseline()
+            if fir is not None:
+                fir["cpu_baseline"] = fir_cpu_baseline()
             out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(Workspace, synth, abi, shard, args.strips, SR,
                                                                    1.0 / max(out["cpu_baseline"]["value"], 1.0))
