@@ -32,7 +32,7 @@ template <int W>
 __device__ __forceinline__ void ldw(uint64_t base, uint32_t byte_off, float (&v)[W]) {
     typedef typename VecF<W>::T VT;
     const char __attribute__((address_space(1)))* p = (const char __attribute__((address_space(1)))*)base;
-    const VT t = *(const VT __attribute__((address_space(1)))*)(p + byte_off);
+    const VT t = __builtin_nontemporal_load((const VT __attribute__((address_space(1)))*)(p + byte_off));   // streamed once
     if constexpr (W == 1) v[0] = t;
     else {
 #pragma unroll
