@@ -704,7 +704,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         case MX_KIND_EQ_THREE:
             if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
             else {
-                EqSplit sp{1u, 5u, gf, gf, nullptr, nullptr, nullptr};
+                EqSplit sp{1u, 5u, 0u, 0u, gf, gf, nullptr, nullptr, nullptr};
                 EqSpanPow pp{};
                 eq_plan_split(n, gf, lo_f_, hi_f_, sp);
                 if (sp.n_split > 1) {   // few instances, long streams: cut each stream into spans for different workgroups

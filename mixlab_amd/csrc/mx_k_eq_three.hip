@@ -142,7 +142,7 @@ __device__ __forceinline__ void toep_apply(const double* c, const double (&v)[4]
 //          before it into the true state at the span start: S_0 = carried, S_{s+1} = A^span S_s + Z_s.
 struct EqSegCtx {
     float* tile; double* wtot; double* carry; double* pw; double* p2; const EqEpi* epi;
-    const float* din; double g_lo, g_mid, g_hi, lo_f, hi_f, sr, rsr; uint64_t t0;
+    const float* din; double g_lo, g_mid, g_hi, lo_f, hi_f, sr, rsr; uint64_t t0; bool stream_out;
 };
 
 template <int LOG2L>
@@ -171,7 +171,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
             const int p = n * 64 + lane;                         // LDS float position this lane fills
             const int e = swz(p);                                // ... with this element of the segment
             const int ec = e < nv ? e : nv - 1;                  // past-the-end positions are never read; keep the address legal
-            __builtin_amdgcn_global_load_lds((mx_gfp)(din + base + ec), (mx_lfp)(tile + n * 64), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((mx_gfp)(din + base + ec), (mx_lfp)(tile + n * 64), 4, 0, 2);   // aux = nt: the source is streamed once
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -300,7 +300,13 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
         const float* const ctlb = E.ctl ? E.ctl + base : nullptr;
         const bool mono = (E.epi == 0u) || (E.flags & MX_EQF_MONO_DUP);
         auto store = [&](int i, float v) {
-            if (mono) outb[i] = v; else reinterpret_cast<float2*>(outb)[i] = make_float2(v, v);   // stereo_panner.rs:35-38
+            typedef float __attribute__((ext_vector_type(2))) f2;
+            if (c.stream_out) {                                  // long runs: the strips cannot stay cached until their consumer runs -- do not displace what can
+                if (mono) __builtin_nontemporal_store(v, outb + i);
+                else { f2 t = {v, v}; __builtin_nontemporal_store(t, reinterpret_cast<f2*>(outb) + i); }
+            } else {
+                if (mono) outb[i] = v; else reinterpret_cast<float2*>(outb)[i] = make_float2(v, v);   // stereo_panner.rs:35-38
+            }
         };
         auto amp = [&](float y, double depth) { return (float)((double)y * depth * E.amp_amplitude); };   // amplifier.rs:56
         if (E.epi != 2u) {                                   // plain EqThree, or EqThree -> StereoPanner
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     c.p2 = c.pw + 2 * 65 * 4;                                                       // [2][6][4]  A^(L 2^k)
     EqEpi* epi_lds = reinterpret_cast<EqEpi*>(c.p2 + 2 * 6 * 4);                    // fused-epilogue parameters
     c.epi = epi_lds;
-    c.lo_f = lo_f; c.hi_f = hi_f; c.sr = sr; c.rsr = rsr; c.t0 = t0;
+    c.lo_f = lo_f; c.hi_f = hi_f; c.sr = sr; c.rsr = rsr; c.t0 = t0; c.stream_out = sp.stream_out != 0;
 
     const int tid = threadIdx.x;
     // Only what the inner phases need stays in registers; everything the epilogue needs (Amplifier and inline
@@ -468,8 +474,10 @@ int eq_scan_log2l(size_t frames) {
 }
 
 void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
-                          const EqScanTab* tabs /* indexed by log2L - 2 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s) {
+                          const EqScanTab* tabs /* indexed by log2L - 2 */, const EqSplit& split_in, const EqSpanPow& pp, hipStream_t s) {
     if (!n || !frames) return;
+    EqSplit split = split_in;
+    split.stream_out = (uint64_t)n * frames * sizeof(float) > (64ull << 20) ? 1u : 0u;   // beyond what L2 + Infinity Cache keep for the consumer
     int l2 = eq_scan_log2l(split.n_split > 1 ? split.span : frames);
     const double rsr = 1.0 / sample_rate;
 #define MX_EQ_GO(L2, MODE, GRID) hipLaunchKernelGGL((k_eq_three_scan<L2, MODE>), GRID, dim3(256), lds, s, d, st, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs, split, pp)

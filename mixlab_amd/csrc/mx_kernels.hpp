@@ -50,7 +50,7 @@ struct EqScanTab { double pw[2][65][4]; double p2[2][6][4]; double h[2][32][4]; 
 
 // time-split plan of the scan kernel (see k_eq_three_scan MODE 1/2): wave-uniform kernel arguments
 // warm / l2_pre: the pre-pass runs over the last `warm` samples of a span only (whole segments of 256 << l2_pre); see eq_plan_split
-struct EqSplit { uint32_t n_split; uint32_t l2_pre; size_t span; size_t warm; double* zbuf /* [n][n_split][8] */; double* bound /* [n][12] */; EnvState* env_snap /* [n] */; };
+struct EqSplit { uint32_t n_split; uint32_t l2_pre; uint32_t stream_out /* outputs too large to stay cached: non-temporal stores */; uint32_t pad; size_t span; size_t warm; double* zbuf /* [n][n_split][8] */; double* bound /* [n][12] */; EnvState* env_snap /* [n] */; };
 struct EqSpanPow { double lo[4], hi[4]; };   // first column of A^span per filter (host, long double)
 
 // src/module/fm_sine.rs:37-56
