@@ -485,3 +485,43 @@ def test_fused_strips_with_time_split_equal_unsplit(monkeypatch):
     # is compared with a few-ULP bound
     assert np.max(np.abs(outs[0] - outs[1])) <= 8 * np.spacing(np.float32(4.0))
     assert np.count_nonzero(outs[0] != outs[1]) <= outs[0].size // 2000
+
+
+def test_mixer_and_amplifier_keep_f32_subnormals_nan_and_infinity_like_the_cpu():
+    # Rust's f32 arithmetic is IEEE with subnormals; the kernels must not flush them (and NaN / infinity must travel)
+    n_ch, length = 6, 2 * SPT
+    base = synth.noise(900, length)
+    ins = [(base * np.float32(s)).astype(np.float32) for s in (1e-40, 3e-39, 1e-38, 1.0, 1e-44, 1e-41)]
+    ins[3] = ins[3].copy(); ins[3][5] = np.float32("nan"); ins[3][9] = np.float32("inf"); ins[3][11] = np.float32("-inf"); ins[3][13] = np.float32(-0.0)
+    chans = [(0.0, 1.0, True), (-6.0, 0.5, False), (3.0, 1.0, True), (0.0, 1e-3, False), (6.0, 1.0, True), (0.0, 1.0, False)]
+    want_m, want_c = oracle.mixer_run(chans, ins, length)
+    m = abi.Module(abi.KIND_MIXER, [abi.MixerChannelParams(g, f, 1 if c else 0) for g, f, c in chans])
+    got_m = np.empty(length, np.float32); got_c = np.empty(length, np.float32)
+    m.run_tick(0, [(abi.MX_STEREO, a) for a in ins], [(abi.MX_STEREO, got_m), (abi.MX_STEREO, got_c)])
+    assert_bit_exact(got_m, want_m, "Mixer master with subnormals / NaN / inf")
+    assert_bit_exact(got_c, want_c, "Mixer cue with subnormals / NaN / inf")
+    x = ins[0]
+    want = oracle.amplifier_run(0.5, 0.25, x, None)
+    a = abi.Module(abi.KIND_AMPLIFIER, abi.AmplifierParams(0.5, 0.25))
+    got = np.empty_like(x)
+    a.run_tick(0, [(abi.MX_STEREO, x), (abi.MX_DISCONNECTED, None)], [(abi.MX_STEREO, got)])
+    assert_bit_exact(got, want, "Amplifier on subnormal input")
+
+
+def test_cooperative_mixer_special_values_bit_exact():
+    # >= 128 channels on a short stream takes k_mixer_coop, whose cue bus adds +0.0 for non-cue channels: must stay exact for
+    # -0.0 (every cue channel -0.0 at one frame), NaN, infinities and subnormals
+    n_ch, length = 131, 2 * 70
+    ins = [synth.noise(1000 + i, length).copy() for i in range(n_ch)]
+    for i in range(n_ch):
+        ins[i][8:10] = np.float32(-0.0)                     # all channels -0.0 on frame 4: master and cue end at +0.0 like the CPU
+    ins[7][20] = np.float32("nan"); ins[40][30] = np.float32("inf"); ins[41][30] = np.float32("-inf"); ins[90][40:44] = np.float32(1e-42)
+    ins[129] = (ins[129] * np.float32(1e-40)).astype(np.float32)
+    gains = synth.uniform(3, n_ch, -24.0, 6.0); faders = synth.uniform(4, n_ch, 0.0, 1.0)
+    chans = [(float(gains[i]), float(faders[i]), i % 5 == 2) for i in range(n_ch)]
+    want_m, want_c = oracle.mixer_run(chans, ins, length)
+    m = abi.Module(abi.KIND_MIXER, [abi.MixerChannelParams(g, f, 1 if c else 0) for g, f, c in chans])
+    got_m = np.empty(length, np.float32); got_c = np.empty(length, np.float32)
+    m.run_tick(0, [(abi.MX_STEREO, a) for a in ins], [(abi.MX_STEREO, got_m), (abi.MX_STEREO, got_c)])
+    assert_bit_exact(got_m, want_m, "coop Mixer master, special values")
+    assert_bit_exact(got_c, want_c, "coop Mixer cue, special values")
