@@ -525,3 +525,23 @@ def test_cooperative_mixer_special_values_bit_exact():
     m.run_tick(0, [(abi.MX_STEREO, a) for a in ins], [(abi.MX_STEREO, got_m), (abi.MX_STEREO, got_c)])
     assert_bit_exact(got_m, want_m, "coop Mixer master, special values")
     assert_bit_exact(got_c, want_c, "coop Mixer cue, special values")
+
+
+def test_empty_cases_zero_ticks_zero_channels_empty_graph():
+    # a Mixer with no channels still zeroes its buses (mixer.rs:54-55); zero ticks is a no-op; an empty graph builds and runs
+    ws = Workspace(SR, 60)
+    mix = ws.mixer([])
+    osc = ws.oscillator(440.0, abi.WAVE_SAW)
+    g = ws.build(max_ticks_per_run=2)
+    g.run_ticks(0, 0)
+    g.run_ticks(0, 2)
+    assert not g.read_output(mix, 0, 2, True).any() and not g.read_output(mix, 1, 2, True).any()
+    assert g.read_output(osc, 0, 2, False).any()
+    g.run_ticks(2, 0)
+    assert g.read_output(mix, 0, 0, True).size == 0
+    empty = Workspace(SR, 60).build()
+    empty.run_ticks(0, 1)
+    with pytest.raises(abi.MxError):
+        g.run_ticks(0, 3)           # more ticks than max_ticks_per_run
+    with pytest.raises(abi.MxError):
+        g.read_output(mix, 2, 1, True)   # no such port
