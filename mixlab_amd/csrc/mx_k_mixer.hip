@@ -270,7 +270,7 @@ void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch, size_t frames, 
     if (w == 4 && (ns & 3)) w = 2;                 // ns = 2 * frames is always even
     if (ns * sizeof(float) >= (1ull << 32)) return;  // unreachable: the engine caps a port buffer below 4 GiB
     // short streams with many channels: the cooperative form (see k_mixer_coop)
-    static const int coop_max_blocks = env_int("MX_MIXER_COOP_BLOCKS", 512);
+    const int coop_max_blocks = env_int("MX_MIXER_COOP_BLOCKS", 512);   // read per call: tests force either kernel
     const size_t coop_blocks = (frames + 63) / 64 * n;
     if (dup_mode != 2 && max_ch >= 128 && coop_blocks <= (size_t)coop_max_blocks) {
         const size_t lds = (size_t)2 * (dup_mode ? McCfg<1>::BATCH * McCfg<1>::FW : McCfg<0>::BATCH * McCfg<0>::FW) * 64 * 2 * sizeof(float);

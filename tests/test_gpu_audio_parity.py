@@ -79,7 +79,9 @@ def test_eq_three_reference_golden_default_mode_within_one_ulp():
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_ch,length", [(1, 2 * SPT), (4, 2 * SPT), (37, 2 * SPT), (256, 2 * 800), (3, 2 * 733),
                                          (200, 2 * SPT), (129, 2 * 733), (1031, 2 * 70)])   # >= 128 channels on short streams: k_mixer_coop, ragged batches
-def test_mixer_bit_exact(n_ch, length):
+@pytest.mark.parametrize("coop_blocks", ["512", "0"])   # default kernel choice / streaming kernel forced
+def test_mixer_bit_exact(n_ch, length, coop_blocks, monkeypatch):
+    monkeypatch.setenv("MX_MIXER_COOP_BLOCKS", coop_blocks)
     gains = synth.uniform(1, n_ch, -24.0, 6.0)
     faders = synth.uniform(2, n_ch, 0.0, 1.0)
     chans = [(float(gains[i]), float(faders[i]), i % 3 == 1) for i in range(n_ch)]

@@ -36,7 +36,9 @@ def noise48():
     return [synth.noise(k, 16 * SPT48) for k in range(N)]
 
 
-def test_config2_full_size_mixer_is_the_ordered_sum_of_the_device_strips(noise48):
+@pytest.mark.parametrize("coop_blocks", ["0", "100000"])   # the streaming kernel (what long runs use) and the cooperative one
+def test_config2_full_size_mixer_is_the_ordered_sum_of_the_device_strips(noise48, coop_blocks, monkeypatch):
+    monkeypatch.setenv("MX_MIXER_COOP_BLOCKS", coop_blocks)
     T = 4
     ws, mix, srcs, trigs = strips(N, SR48)
     g = ws.build(max_ticks_per_run=T)
