@@ -28,7 +28,7 @@ def polyphase_table(up=160, down=147, taps_per_phase=16, beta=8.6):
     return np.ascontiguousarray(h.reshape(taps_per_phase, up).T)
 
 
-@pytest.mark.parametrize("n_taps", [1, 2, 128, 300])
+@pytest.mark.parametrize("n_taps", [1, 2, 3, 5, 128, 131, 300])
 def test_fir_module_path_bit_exact_with_history(n_taps):
     taps = reverb_taps(n_taps)
     import struct
