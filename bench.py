@@ -8,9 +8,11 @@ ticks of synthetic input already resident in HBM).  Metric: audio channels mixed
 strip-ticks (one stereo strip processed and mixed for one 1/60 s tick) per second, whole job.
 
 N > 1 (BASELINE.json configs[4]): the 1024 strips are sharded contiguously over the
-ranks (strong scaling), each rank runs Mixer(1024/N) over its strips, the partial Master/Cue buses
-are exchanged with ONE RCCL all-gather per step and summed in rank order by a Mixer(N, unity) --
-i.e. the reference-expressible hierarchical graph N x Mixer(1024/N) -> Mixer(N).
+ranks (strong scaling), each rank runs Mixer(1024/N) over its strips, and the partial Master/Cue buses
+are summed in rank order by a Mixer(N, unity) -- i.e. the reference-expressible hierarchical graph
+N x Mixer(1024/N) -> Mixer(N) -- with every rank ending up with the whole bus.  Exchange over RCCL: an
+all-to-all of time slices, the ordered sum of the own slice, an all-gather of the finished slices
+(the ordered form of reduce-scatter + all-gather; --exchange allgather gathers whole partials instead).
 
 One JSON line on rank 0; see the task contract for the fields.  `roofline` describes the kernel
 that took the most device time in the timed region (hipEvents on the graph's stream);
@@ -391,6 +393,9 @@ def main():
     ap.add_argument("--eq-exact", action="store_true", help="strictly sequential EqThree (bit-exact order) instead of the time-parallel scan")
     ap.add_argument("--no-fuse", action="store_true", help="materialise every port (MX_FLAG_NO_FUSE): module-boundary traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["auto", "slices", "allgather"], default="auto",
+                    help="N > 1 bus exchange: ordered reduce-scatter + all-gather over time slices (2(N-1)/N bus lengths received per rank; auto: N >= 4) "
+                         "or one all-gather of the whole partial buses (N-1 bus lengths; auto: N < 4)")
     ap.add_argument("--force-combine", action="store_true", help="debug: run the N>1 all-gather + combine path at N=1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
@@ -435,24 +440,27 @@ def main():
         blk = synth.noise(first + j, base_ticks * spt)
         g.write_source(s, np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt], T)
 
-    # N > 1: partial buses -> all_gather -> rank-ordered Mixer(N, unity gains) on every rank
+    # N > 1: the partial buses of all ranks are summed in rank order -- Mixer(N, unity gains) -- and every rank ends with the
+    # whole bus.  Exchange (mixlab_amd/shard.py): the ordered form of reduce-scatter + all-gather when the step divides into
+    # N time slices (an all-to-all hands rank j slice j of every partial, rank j sums them, an all-gather distributes the
+    # finished slices: 2 (N-1)/N bus lengths received per rank), else one all-gather of the whole partials ((N-1) bus lengths).
     combine = None
+    exchange = None
     if use_dist:
         # The exchange is pipelined against the next step's compute: partial buses are packed into one of two
-        # buffers on the compute stream, and a second stream all-gathers them and runs the rank-ordered Mixer(N)
+        # buffers on the compute stream, and a second stream runs the collectives and the rank-ordered Mixer(N)
         # while the compute stream is already on step i+1.  Steady-state step time = max(compute, exchange).
         m_ptr, fpt = g.output_device_ptr(mix, 0)
         c_ptr, _ = g.output_device_ptr(mix, 1)
         n_fl = fpt * T
-        part_len, offs = shard.packed_layout(world, n_fl)
         m_view, c_view = dev_view(torch, m_ptr, n_fl), dev_view(torch, c_ptr, n_fl)
         # Master and Cue are neighbours in the graph's slab: one device-to-device copy packs both
         mc_view = dev_view(torch, m_ptr, 2 * n_fl) if c_ptr == m_ptr + 4 * n_fl else None
         comm = torch.cuda.Stream()
+        sliced = (args.exchange == "slices" or (args.exchange == "auto" and world >= 4)) and T % world == 0
+        exchange = "alltoall + ordered sum + allgather (slices)" if sliced else "allgather + ordered sum"
         slots = []
         for _slot in range(2):
-            part = torch.empty(part_len, dtype=torch.float32, device="cuda")
-            gathered = torch.empty(world * part_len, dtype=torch.float32, device="cuda")
             cws = Workspace(SR, 60)
             fm = cws.mixer(shard.combine_channels(world))   # unity gains: the f32 sum of partials in rank order
             fc = cws.mixer(shard.combine_channels(world))
@@ -461,17 +469,41 @@ def main():
             for r in range(world):
                 cws.connect(c_srcs_m[r], 0, fm, r)
                 cws.connect(c_srcs_c[r], 0, fc, r)
-            cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=comm.cuda_stream)
-            for r in range(world):
-                cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + offs[r][0] * 4)
-                cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + offs[r][1] * 4)
-            slots.append({"part": part, "gathered": gathered, "cg": cg, "packed": torch.cuda.Event(), "done": torch.cuda.Event(), "used": False})
+            if sliced:
+                L, offs = shard.slice_layout(world, n_fl)
+                t_slice = T // world
+                send = torch.empty(world * 2 * L, dtype=torch.float32, device="cuda")
+                recv = torch.empty(world * 2 * L, dtype=torch.float32, device="cuda")
+                fin = torch.empty(2 * L, dtype=torch.float32, device="cuda")
+                final_all = torch.empty(world * 2 * L, dtype=torch.float32, device="cuda")
+                cg = cws.build(max_ticks_per_run=t_slice, device=local_rank, stream=comm.cuda_stream)
+                for r in range(world):
+                    cg.bind_source_device(c_srcs_m[r], recv.data_ptr() + offs[r][0] * 4)
+                    cg.bind_source_device(c_srcs_c[r], recv.data_ptr() + offs[r][1] * 4)
+                fm_ptr, _ = cg.output_device_ptr(fm, 0)
+                fc_ptr, _ = cg.output_device_ptr(fc, 0)
+                slots.append({"send": send, "recv": recv, "fin": fin, "final_all": final_all, "cg": cg, "t_slice": t_slice, "L": L,
+                              "fm_view": dev_view(torch, fm_ptr, L), "fc_view": dev_view(torch, fc_ptr, L),
+                              "packed": torch.cuda.Event(), "done": torch.cuda.Event(), "used": False})
+            else:
+                part_len, offs = shard.packed_layout(world, n_fl)
+                part = torch.empty(part_len, dtype=torch.float32, device="cuda")
+                gathered = torch.empty(world * part_len, dtype=torch.float32, device="cuda")
+                cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=comm.cuda_stream)
+                for r in range(world):
+                    cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + offs[r][0] * 4)
+                    cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + offs[r][1] * 4)
+                slots.append({"part": part, "gathered": gathered, "cg": cg, "packed": torch.cuda.Event(), "done": torch.cuda.Event(), "used": False})
 
         def combine(i):
             sl = slots[i % 2]
             if sl["used"]:
                 stream.wait_event(sl["done"])          # the exchange that last used this slot has finished
-            if mc_view is not None:
+            if sliced:                                 # device-to-device pack on the compute stream: [dest][master slice | cue slice]
+                sv = sl["send"].view(world, 2, sl["L"])
+                sv[:, 0, :].copy_(m_view.view(world, sl["L"]))
+                sv[:, 1, :].copy_(c_view.view(world, sl["L"]))
+            elif mc_view is not None:
                 sl["part"].copy_(mc_view)              # device-to-device pack of (master, cue) on the compute stream
             else:
                 sl["part"][:n_fl].copy_(m_view)
@@ -479,8 +511,14 @@ def main():
             sl["packed"].record(stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(sl["packed"])
-                dist.all_gather_into_tensor(sl["gathered"], sl["part"])   # ONE all-gather per step (RCCL over xGMI)
-                sl["cg"].run_ticks(0, T)                                   # rank-ordered f32 sum: Mixer(N, unity)
+                if sliced:
+                    dist.all_to_all_single(sl["recv"], sl["send"])            # slice j of every rank's partial buses -> rank j
+                    sl["cg"].run_ticks(0, sl["t_slice"])                      # rank-ordered f32 sum of my slice: Mixer(N, unity)
+                    sl["fin"][: sl["L"]].copy_(sl["fm_view"]); sl["fin"][sl["L"]:].copy_(sl["fc_view"])
+                    dist.all_gather_into_tensor(sl["final_all"], sl["fin"])   # every rank ends with the whole Master and Cue
+                else:
+                    dist.all_gather_into_tensor(sl["gathered"], sl["part"])   # ONE all-gather per step (RCCL over xGMI)
+                    sl["cg"].run_ticks(0, T)                                   # rank-ordered f32 sum: Mixer(N, unity)
                 sl["done"].record(comm)
             sl["used"] = True
 
@@ -593,7 +631,7 @@ def main():
                        "strips": args.strips, "ticks_per_step": T, "samples_per_tick": spt,
                        "eq_mode": "exact-sequential" if args.eq_exact else "time-parallel",
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
-                       "parallelism": f"strips sharded x{world}" + (", all-gather + rank-ordered Mixer" if world > 1 else "")},
+                       "parallelism": f"strips sharded x{world}" + (f", {exchange}" if exchange else "")},
             "realtime_channels_equiv": value / 60.0,
             "graph_hbm_frac_module_boundary_bytes": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "graph_hbm_frac_moved_bytes": round((whole_alg if args.no_fuse else fused_alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),

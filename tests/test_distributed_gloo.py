@@ -52,12 +52,28 @@ for t in range(T):
     og.run_tick(t)
     part[t * 2 * SPT:(t + 1) * 2 * SPT] = torch.from_numpy(og.output(mix, 0))
     part[n_fl + t * 2 * SPT: n_fl + (t + 1) * 2 * SPT] = torch.from_numpy(og.output(mix, 1))
-gathered = torch.zeros(world * part_len, dtype=torch.float32)
-dist.all_gather_into_tensor(gathered, part)
-g = gathered.numpy()
 chans = shard.combine_channels(world)
-master, _ = oracle.mixer_run(chans, [g[offs[r][0]:offs[r][0] + n_fl] for r in range(world)], n_fl)
-cue, _ = oracle.mixer_run(chans, [g[offs[r][1]:offs[r][1] + n_fl] for r in range(world)], n_fl)
+if os.environ.get("EXCHANGE") == "slices":
+    # ordered reduce-scatter + all-gather: all-to-all of time slices, rank-ordered sum of the own slice, all-gather of the results
+    L, soffs = shard.slice_layout(world, n_fl)
+    send = torch.empty(world * 2 * L, dtype=torch.float32)
+    send.view(world, 2, L).copy_(shard.pack_slices(part, world))
+    recv = torch.zeros(world * 2 * L, dtype=torch.float32)
+    dist.all_to_all_single(recv, send)
+    rv = recv.numpy()
+    m_mine, _ = oracle.mixer_run(chans, [rv[soffs[r][0]:soffs[r][0] + L] for r in range(world)], L)
+    c_mine, _ = oracle.mixer_run(chans, [rv[soffs[r][1]:soffs[r][1] + L] for r in range(world)], L)
+    fin = torch.from_numpy(np.concatenate([m_mine, c_mine]))
+    final_all = torch.zeros(world * 2 * L, dtype=torch.float32)
+    dist.all_gather_into_tensor(final_all, fin)
+    m_t, c_t = shard.unpack_slices(final_all, world)
+    master, cue = m_t.numpy().copy(), c_t.numpy().copy()
+else:
+    gathered = torch.zeros(world * part_len, dtype=torch.float32)
+    dist.all_gather_into_tensor(gathered, part)
+    g = gathered.numpy()
+    master, _ = oracle.mixer_run(chans, [g[offs[r][0]:offs[r][0] + n_fl] for r in range(world)], n_fl)
+    cue, _ = oracle.mixer_run(chans, [g[offs[r][1]:offs[r][1] + n_fl] for r in range(world)], n_fl)
 np.save(os.environ["OUT_DIR"] + f"/rank{{rank}}.npy", np.stack([master, cue]))
 dist.barrier(); dist.destroy_process_group()
 """
@@ -93,13 +109,14 @@ def reference_hierarchy(N=12, T=3, SPT=735, world=2):
     return np.concatenate(m), np.concatenate(c)
 
 
-def test_two_rank_gloo_allgather_combine_equals_hierarchical_graph():
+@pytest.mark.parametrize("exchange,port", [("allgather", "29611"), ("slices", "29612")])
+def test_two_rank_gloo_exchange_and_ordered_combine_equal_hierarchical_graph(exchange, port):
     with tempfile.TemporaryDirectory() as td:
         script = pathlib.Path(td) / "worker.py"
         script.write_text(WORKER.format(root=str(ROOT)))
-        env = dict(os.environ, OUT_DIR=td, MASTER_ADDR="127.0.0.1")
+        env = dict(os.environ, OUT_DIR=td, MASTER_ADDR="127.0.0.1", EXCHANGE=exchange)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-               "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)]
+               "--master-addr", "127.0.0.1", "--master-port", port, str(script)]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         want_m, want_c = reference_hierarchy()
@@ -116,3 +133,13 @@ def test_shard_plan():
         shard.strip_range(0, 3, 1024)
     part, offs = shard.packed_layout(2, 100)
     assert part == 200 and offs == [(0, 100), (200, 300)]
+    L, soffs = shard.slice_layout(4, 100)
+    assert L == 25 and soffs[1] == (50, 75)
+    with pytest.raises(ValueError):
+        shard.slice_layout(3, 100)
+    import torch
+    mc = torch.arange(16, dtype=torch.float32)                 # master 0..7 | cue 8..15, 2 ranks -> slices of 4
+    send = torch.empty(16); send.view(2, 2, 4).copy_(shard.pack_slices(mc, 2))
+    assert send.tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+    m, c = shard.unpack_slices(send, 2)                        # the same layout comes back from the all-gather
+    assert m.tolist() == list(range(8)) and c.tolist() == list(range(8, 16))
