@@ -228,6 +228,55 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
     }
 
 
+def north_star_realtime_leg(torch, stream, local_rank, abi, Workspace, synth, n_strips=10240, sample_rate=48000):
+    """The north-star's real-time statement as ONE graph, one tick per submission: 10 240 stereo channel strips (config-2 strips)
+    into a flat Mixer(10 240) plus the config-4 video cascade (8 layers -> 7 VideoMixers -> RGBA), every tick synchronised
+    like a live engine.  Reports the tick time against the 16 667 us budget."""
+    from mixlab_amd import video
+
+    t_build = time.perf_counter()
+    ws, mix, srcs = build_strips(abi, Workspace, synth, n_strips, 0, sample_rate)
+    sizes = [(1920, 1080)] * 6 + [(1280, 720)] * 2
+    vsrcs = [ws.source_video() for _ in sizes]
+    prev = vsrcs[0]
+    for k in range(1, 8):
+        m = ws.video_mixer(a=0, b=1, fader=VIDEO_FADERS[k - 1])
+        ws.connect(prev, 0, m, 0); ws.connect(vsrcs[k], 0, m, 1)
+        prev = m
+    rgba = ws.video_to_rgba(VIDEO_MATRIX)
+    ws.connect(prev, 0, rgba, 0)
+    g = ws.build(max_ticks_per_run=1, device=local_rank, stream=stream.cuda_stream)
+    spt = ws.spt
+    blk = [synth.noise(k, spt) for k in range(64)]
+    for j, s in enumerate(srcs):
+        g.write_source(s, blk[j % 64], 1)
+    keep = []
+    for k, (w, h) in enumerate(sizes):
+        y, u, v = synth.yuv_pattern(w, h, k, seed=3)
+        d = video.DFrame(w, h).upload(y, u, v)
+        keep.append(d)
+        video.graph_set_video_source(g, vsrcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)
+    t_build = time.perf_counter() - t_build
+    for i in range(20):
+        g.run_ticks(i, 1)
+    g.sync()
+    n = 200
+    t0 = time.perf_counter()
+    for i in range(n):
+        g.run_ticks(20 + i, 1)
+        g.sync()
+    tick_us = (time.perf_counter() - t0) / n * 1e6
+    by_kind, _tot = g.profile_run(20 + n, 1)
+    # module-boundary bytes of one tick (SURVEY.md section 8d): strips 51 200 B each, the mixer's two buses, the video cascade
+    F, F720 = 1920 * 1080 * 3 // 2, 1280 * 720 * 3 // 2
+    tick_bytes = 51200 * (sample_rate / 48000.0) * n_strips + 7 * 3 * F + 2 * (F720 + F) + (F + 1920 * 1080 * 4)
+    return {"workload": f"{n_strips} channel strips -> Mixer({n_strips}) + 8-layer 1080p cascade -> RGBA, one 1/60 s tick per submission, synchronised every tick",
+            "tick_us": round(tick_us, 1), "tick_budget_us": round(1e6 / 60.0, 1), "headroom": round(1e6 / 60.0 / tick_us, 1),
+            "device_ms_by_kind": {k: round(v, 4) for k, v in sorted(by_kind.items()) if v > 0},
+            "hbm_frac_module_boundary_bytes": round(tick_bytes / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "graph_nodes": len(ws.nodes), "graph_build_s": round(t_build, 2)}
+
+
 def fir_leg(torch, stream, local_rank, T, steps, warmup):
     """BASELINE.json configs[2] (build-specified): 256 stereo channels @44.1 kHz ->
     128-tap FIR reverb -> 160/147 polyphase resampler (16 taps per phase) -> 48 kHz-domain Mixer(256).
@@ -398,6 +447,7 @@ def main():
                          "or one all-gather of the whole partial buses (N-1 bus lengths; auto: N < 4)")
     ap.add_argument("--force-combine", action="store_true", help="debug: run the N>1 all-gather + combine path at N=1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 10 240-strip + 8-layer real-time leg")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
     args = ap.parse_args()
@@ -582,6 +632,11 @@ def main():
         with torch.cuda.stream(stream):
             video = video_leg(torch, dist, world, stream, local_rank, args.video_frames, args.warmup)
 
+    north = None
+    if not args.no_north_star and not use_dist:
+        with torch.cuda.stream(stream):
+            north = north_star_realtime_leg(torch, stream, local_rank, abi, Workspace, synth)
+
     fir = None
     if args.fir_ticks > 0 and not use_dist:
         with torch.cuda.stream(stream):
@@ -637,6 +692,7 @@ def main():
             "graph_hbm_frac_moved_bytes": round((whole_alg if args.no_fuse else fused_alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
             "realtime": realtime,
+            "north_star_realtime": north,
             "video": video,
             "fir_resample": fir,
         }

@@ -15,7 +15,7 @@ class Workspace:
         self.sample_rate = sample_rate
         self.ticks_per_second = ticks_per_second
         self.nodes: list[tuple[int, object]] = []
-        self.edges: list[tuple[int, int, int, int]] = []
+        self._conn: dict[tuple[int, int], tuple[int, int]] = {}   # InputId -> OutputId (HashMap, src/engine/workspace.rs:17)
 
     @property
     def spt(self) -> int:
@@ -28,8 +28,12 @@ class Workspace:
     def connect(self, src: int, src_port: int, dst: int, dst_port: int) -> None:
         """InputId(dst, dst_port) -> OutputId(src, src_port); a later connect to the same input replaces it
         (HashMap insert, src/engine/workspace.rs:110)."""
-        self.edges = [e for e in self.edges if not (e[2] == dst and e[3] == dst_port)]
-        self.edges.append((src, src_port, dst, dst_port))
+        self._conn[(dst, dst_port)] = (src, src_port)
+
+    @property
+    def edges(self) -> list[tuple[int, int, int, int]]:
+        """(src, src_port, dst, dst_port) per connection."""
+        return [(s, sp, d, dp) for (d, dp), (s, sp) in self._conn.items()]
 
     # ---- module constructors (ModuleT::create) ----
     def oscillator(self, freq: float, waveform: int) -> int:
