@@ -447,6 +447,7 @@ def main():
                          "or one all-gather of the whole partial buses (N-1 bus lengths; auto: N < 4)")
     ap.add_argument("--force-combine", action="store_true", help="debug: run the N>1 all-gather + combine path at N=1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
+    ap.add_argument("--no-realtime", action="store_true", help="skip the one-tick-per-submission leg (hundreds of tiny dispatches: slow under a counter-collecting profiler)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 240-strip + 8-layer real-time leg")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
@@ -612,7 +613,7 @@ def main():
 
     # real-time regime: one 60 Hz tick per submission, synchronised every tick like a live engine
     realtime = None
-    if not use_dist:
+    if not use_dist and not args.no_realtime:
         with torch.cuda.stream(stream):
             base_t = (args.warmup + args.steps + 4) * T
             for i in range(20):
