@@ -664,7 +664,7 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": alg,
                     "kernel_ms_per_step": {k: round(v / n_prof, 5) for k, v in sorted(by_kind.items()) if v > 0},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
-                    "limiter": ("f64 VALU issue + dependent-chain latency of the 8-pole recurrence (PMC: VALU busy ~55% of the kernel, "
+                    "limiter": ("f64 VALU issue + dependent-chain latency of the 8-pole recurrence (PMC: the VALU issues 69% of the kernel's cycles, "
                                 "traffic = 1.02x algorithmic); HBM is the roof only nominally" if dom == "eq_three" else "HBM")}
             if dom == "eq_three" and not args.eq_exact:
                 # the bound that actually applies: f64 VALU.  ~52 f64 instructions per sample: exact recurrence 8 poles x
