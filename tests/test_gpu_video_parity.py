@@ -204,3 +204,47 @@ def test_video_mixer_module_compat_path_host_frames():
         assert np.array_equal(outs_h[1].planes[p][: a.h >> (1 if p else 0), : a.w >> (1 if p else 0)], a.visible()[p])   # A pass-through
     assert (outs_f[2].width, outs_f[2].height) == (160, 120) and (outs_f[0].dur_num, outs_f[0].dur_den) == (1, 60)
     abi.lib.mx_module_destroy(h)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_video_mixer_random_scenarios_match_oracle(seed):
+    """Seeded random arrivals on all four channels (sizes, durations, tick offsets), random A / B / fader changes, gaps long
+    enough for stored frames to expire: program frame presence and pixels, tick by tick, against the oracle state machine."""
+    rng = np.random.default_rng(seed)
+    SPT = 735
+    sizes = [(64, 64), (96, 54), (128, 72), (66, 34), (160, 120), (130, 70)]
+    pool = [ov.HostFrame(w, h).fill(int(rng.integers(0, 50)), seed=int(rng.integers(0, 99))) for (w, h) in sizes for _ in range(2)]
+    a, b, fader = 0, 1, float(rng.uniform(0, 1))
+    gm, om = video.VideoMixer(a=a, b=b, fader=fader), ov.OracleVideoMixer(a=a, b=b, fader=fader)
+    keep, shown = [], 0
+    quiet_until = -1
+    for tick in range(36):
+        if rng.random() < 0.06:
+            quiet_until = tick + int(rng.integers(3, 9))      # nobody delivers for a while: stored frames run out
+        ins_h = [None] * 4
+        for ch in range(4):
+            if tick > quiet_until and rng.random() < (0.5, 0.3, 0.15, 0.05)[ch]:
+                dur = [(1, 60), (1, 30), (1, 20), (1, 10), (2, 25), (1, 7)][int(rng.integers(0, 6))]
+                off = [(0, 1), (1, 240), (1, 120), (1, 61)][int(rng.integers(0, 4))]
+                ins_h[ch] = (pool[int(rng.integers(0, len(pool)))], dur, off)
+        if rng.random() < 0.15:
+            a = [None, 0, 1, 2, 3][int(rng.integers(0, 5))]; b = [None, 0, 1, 2, 3][int(rng.integers(0, 5))]
+            fader = float([0.0, 1.0, rng.uniform(0, 1), 1.5, -0.1][int(rng.integers(0, 5))])
+            gm.update(a=a, b=b, fader=fader); om.update(a=a, b=b, fader=fader)
+        ins_d = []
+        for e in ins_h:
+            if e is None:
+                ins_d.append(None)
+            else:
+                d = upload(e[0]); keep.append(d)
+                ins_d.append((d, e[1], e[2]))
+        prog, fa, fb = gm.run_tick(tick * SPT, ins_d)
+        want = om.run_tick(tick * SPT, ins_h)
+        assert (prog is None) == (want is None), f"seed {seed} tick {tick}: program presence"
+        if want is not None:
+            shown += 1
+            assert (prog.width, prog.height) == (want.w, want.h), f"seed {seed} tick {tick}: target size"
+            assert_frame_equal(prog, want, f"seed {seed} tick {tick}")
+        assert (fa is None) == (a is None or ins_h[a] is None)
+        assert (fb is None) == (b is None or ins_h[b] is None)
+    assert shown > 5
