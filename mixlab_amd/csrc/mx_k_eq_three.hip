@@ -152,14 +152,19 @@ __device__ __forceinline__ void eq_load_tables(const EqSegCtx& c, const EqScanTa
     if (tid < 2 * 6 * 4) c.p2[tid] = (&tab->p2[0][0][0])[tid];
 }
 
-// one segment of up to 256 chunks x L samples starting at sample `base` (nv valid samples); ends on a barrier
-template <int LOG2L, int MODE>
+// one segment of up to 64 * NW chunks x L samples starting at sample `base` (nv valid samples); ends on a barrier.
+// NW = waves per instance: 4 (a 256-thread workgroup walks one stream) or 1 (short streams: one wave per instance, four
+// instances per workgroup, no cross-wave step)
+template <int LOG2L, int MODE, int NW = 4>
 __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* __restrict__ tabs, const size_t base, const int nv) {
     constexpr int L = 1 << LOG2L;
     const EqScanTab* __restrict__ tab = tabs + (LOG2L - 2);
     float* const tile = c.tile;
     double* const wtot = c.wtot; double* const carry = c.carry; double* const pw = c.pw; double* const p2 = c.p2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    const int tid = NW == 4 ? (int)threadIdx.x : lane;        // thread index inside the instance
+    const int wave = NW == 4 ? (int)(threadIdx.x >> 6) : 0;   // wave index inside the instance
+    constexpr int NT = 64 * NW;                               // threads (= chunks per segment) of an instance
     const float* __restrict__ din = c.din;
     const double lo_f = c.lo_f, hi_f = c.hi_f;
 
@@ -167,7 +172,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
     if (din) {
 #pragma unroll 4   // DMA needs no data registers, but a full unroll materialises L 64-bit addresses at once
         for (int kk = 0; kk < L; ++kk) {
-            const int n = wave + 4 * kk;                         // 64-float block of the tile
+            const int n = wave + NW * kk;                        // 64-float block of the tile
             const int p = n * 64 + lane;                         // LDS float position this lane fills
             const int e = swz(p);                                // ... with this element of the segment
             const int ec = e < nv ? e : nv - 1;                  // past-the-end positions are never read; keep the address legal
@@ -176,7 +181,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
 #pragma unroll 8
-        for (int k = 0; k < L; ++k) tile[tid + 256 * k] = 0.f;   // Disconnected input => ZERO_BUFFER_MONO
+        for (int k = 0; k < L; ++k) tile[tid + NT * k] = 0.f;   // Disconnected input => ZERO_BUFFER_MONO
     }
     __syncthreads();
 
@@ -218,7 +223,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
             for (int q = 0; q < 4; ++q) { zl[q] += tl[q]; zh[q] += th[q]; }
         }
     }
-    if (lane == 63) {
+    if (NW > 1 && lane == 63) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { wtot[wave * 8 + q] = zl[q]; wtot[wave * 8 + 4 + q] = zh[q]; }
     }
@@ -251,7 +256,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
         // pre-pass: whole segments only; the state at the segment's end is the end state of chunk 255
         //   = P^(64) C_3 + E_63 (lane 63 of wave 3).  No phase C, nothing is emitted.
         __syncthreads();
-        if (tid == 255) {
+        if (tid == NT - 1) {
             double tl[4], th[4];
             toep_apply(pw + (0 * 65 + 64) * 4, cl, tl);
             toep_apply(pw + (1 * 65 + 64) * 4, ch, th);
@@ -312,7 +317,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
         if (E.epi != 2u) {                                   // plain EqThree, or EqThree -> StereoPanner
 #pragma unroll 4
             for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
+                const int e = tid + NT * k;
                 if (e < nv) store(e, tile[swz(e)]);
             }
         } else if (E.flags & MX_EQF_ENV) {                   // ... -> Amplifier with the Envelope evaluated inline
@@ -324,13 +329,13 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
                 const double depth = E.amp_one_minus + E.amp_mod_depth * (double)cc;               // amplifier.rs:71-73
 #pragma unroll 4
                 for (int k = 0; k < L; ++k) {
-                    const int e = tid + 256 * k;
+                    const int e = tid + NT * k;
                     if (e < nv) store(e, amp(tile[swz(e)], depth));
                 }
             } else {
 #pragma unroll 4
                 for (int k = 0; k < L; ++k) {
-                    const int e = tid + 256 * k;
+                    const int e = tid + NT * k;
                     if (e < nv) {
                         const float cc = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, t0 + base + e, sr, rsr);
                         store(e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)cc));
@@ -344,12 +349,12 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
                 float cv[CB];
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
-                    const int e = tid + 256 * (k0 + k);
+                    const int e = tid + NT * (k0 + k);
                     cv[k] = (e < nv) ? ctlb[e] : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
-                    const int e = tid + 256 * (k0 + k);
+                    const int e = tid + NT * (k0 + k);
                     if (e < nv) store(e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)cv[k]));
                 }
             }
@@ -357,7 +362,7 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
             const double depth = E.amp_one_minus + E.amp_mod_depth * 1.0;
 #pragma unroll 4
             for (int k = 0; k < L; ++k) {
-                const int e = tid + 256 * k;
+                const int e = tid + NT * k;
                 if (e < nv) store(e, amp(tile[swz(e)], depth));
             }
         }
@@ -466,6 +471,57 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     }
 }
 
+// Short streams (the real-time mode: one tick of 800 samples per instance): a 256-thread workgroup per instance is mostly
+// start-up -- tables, descriptor, four barriers for a few hundred samples -- and 10 240 instances queue up ten deep.
+// Here one WAVE owns an instance (64 chunks of L samples per segment, the wave scan is the whole scan) and a workgroup
+// carries four instances that share the tables.  Same arithmetic, same eq_segment.
+template <int LOG2L>
+__global__ __launch_bounds__(256, 4) void k_eq_three_wave(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst,
+                                                           size_t frames, uint64_t t0, double sr, double rsr, double lo_f, double hi_f,
+                                                           const EqScanTab* __restrict__ tabs) {
+    constexpr int L = 1 << LOG2L;
+    constexpr int SEG = 64 * L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // shared: tables; per wave: tile, carry, epilogue parameters
+    double* pw = reinterpret_cast<double*>(smem);
+    double* p2 = pw + 2 * 65 * 4;
+    constexpr size_t PER = (size_t)SEG * sizeof(float) + 12 * sizeof(double) + sizeof(EqEpi);
+    char* mine = smem + (2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + (size_t)wv * ((PER + 15) & ~(size_t)15);
+    EqSegCtx c;
+    c.tile = reinterpret_cast<float*>(mine);
+    c.carry = reinterpret_cast<double*>(mine + (size_t)SEG * sizeof(float));
+    c.wtot = nullptr; c.pw = pw; c.p2 = p2;
+    EqEpi* epi_lds = reinterpret_cast<EqEpi*>(c.carry + 12);
+    c.epi = epi_lds;
+    c.lo_f = lo_f; c.hi_f = hi_f; c.sr = sr; c.rsr = rsr; c.t0 = t0; c.stream_out = false;
+    // a workgroup past the end re-does the last instance (identical values written twice) so that every wave reaches every barrier
+    const uint32_t inst = min(blockIdx.x * 4u + (uint32_t)wv, n_inst - 1);
+    const EqDesc* dp = descs + inst;
+    c.din = dp->in;
+    c.g_lo = dp->gain_lo; c.g_mid = dp->gain_mid; c.g_hi = dp->gain_hi;
+    if (lane == 0) {
+        const EqDesc d = *dp;
+        const EnvCtx ec = env_ctx_begin(d, d.env_state, t0, sr, rsr);
+        EqEpi e;
+        e.out = d.out; e.ctl = d.ctl; e.amp_one_minus = d.amp_one_minus; e.amp_mod_depth = d.amp_mod_depth; e.amp_amplitude = d.amp_amplitude;
+        e.env = d.env; e.off_amp = ec.off_amp; e.seq = ec.seq; e.tag = ec.tag; e.epi = d.epi; e.flags = d.flags;
+        *epi_lds = e;
+    }
+    eq_load_tables<LOG2L>(c, tabs, (int)threadIdx.x);
+    if (lane < 11) c.carry[lane] = reinterpret_cast<const double*>(&states[inst])[lane];   // lo[4] hi[4] history[3]
+    __syncthreads();
+    for (size_t base = 0; base < frames; base += SEG) {
+        const size_t rem = frames - base;
+        eq_segment<LOG2L, 0, 1>(c, tabs, base, rem < (size_t)SEG ? (int)rem : SEG);
+    }
+    if (lane < 11) reinterpret_cast<double*>(&states[inst])[lane] = c.carry[lane];
+    if (lane == 0 && (epi_lds->flags & MX_EQF_ENV)) {
+        EnvState* es = dp->env_state;
+        es->tag = epi_lds->tag; es->seq = epi_lds->seq; es->off_amplitude = epi_lds->off_amp;
+    }
+}
+
 int eq_scan_log2l(size_t frames) {
     if (frames <= 256 * 4) return 2;
     if (frames <= 256 * 8) return 3;
@@ -484,7 +540,20 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frame
 #define MX_EQ_MODE(MODE, GRID) { \
         const size_t lds = (size_t)256 * (1u << l2) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + sizeof(EqEpi); \
         switch (l2) { case 2: MX_EQ_GO(2, MODE, GRID); break; case 3: MX_EQ_GO(3, MODE, GRID); break; case 4: MX_EQ_GO(4, MODE, GRID); break; default: MX_EQ_GO(5, MODE, GRID); break; } }
-    if (split.n_split <= 1) {
+    static const int no_wave = env_int("MX_EQ_NO_WAVE", 0);
+    if (split.n_split <= 1 && frames <= 2048 && n >= 256 && !no_wave) {
+        // short streams, many instances: one wave per instance (k_eq_three_wave)
+        const int lw = frames <= 256 ? 2 : (frames <= 512 ? 3 : (frames <= 1024 ? 4 : 5));
+        const size_t per = (((size_t)64 << lw) * sizeof(float) + 12 * sizeof(double) + sizeof(EqEpi) + 15) & ~(size_t)15;
+        const size_t lds = (2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + 4 * per;
+        const dim3 g((n + 3) / 4);
+        switch (lw) {
+        case 2: hipLaunchKernelGGL(k_eq_three_wave<2>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
+        case 3: hipLaunchKernelGGL(k_eq_three_wave<3>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
+        case 4: hipLaunchKernelGGL(k_eq_three_wave<4>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
+        default: hipLaunchKernelGGL(k_eq_three_wave<5>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
+        }
+    } else if (split.n_split <= 1) {
         MX_EQ_MODE(0, dim3(n));
     } else {
         const int l2_main = l2;
