@@ -161,8 +161,9 @@ __global__ __launch_bounds__(64) void k_mixer(const MixDesc* __restrict__ descs,
 // The cue term as a select is exact: the cue bus never holds -0.0 (it starts +0.0 and +0.0 + -0.0 = +0.0), so adding
 // +0.0 for a non-cue channel changes nothing, NaN and infinity included.
 // ---------------------------------------------------------------------------------------------
-#define MC_WAVES 16
-template <int DUP> struct McCfg { static constexpr int FW = DUP ? 1 : 2; static constexpr int BATCH = DUP ? 128 : 64; static constexpr int PER = BATCH / MC_WAVES; };
+#define MC_WAVES 16                     // wave 0 only adds; waves 1..15 load, multiply and land
+#define MC_PROD (MC_WAVES - 1)
+template <int DUP> struct McCfg { static constexpr int FW = DUP ? 1 : 2; static constexpr int PER = DUP ? 8 : 4; static constexpr int BATCH = PER * MC_PROD; };
 
 template <int DUP>   // 1: every input stored mono (L == R), 0: every input interleaved stereo
 __global__ __launch_bounds__(64 * MC_WAVES) void k_mixer_coop(const MixDesc* __restrict__ descs, size_t frames) {
@@ -181,73 +182,86 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_mixer_coop(const MixDesc* __r
     // descriptors of my share of a batch: one channel per lane (lanes < PER), broadcast with v_readlane at use; channels past
     // the end repeat the last one with gain 0 and no cue (+0.0 terms).  Disconnected inputs point at the graph's zero buffer.
     uint64_t p_nxt, g_nxt; uint32_t cue_nxt;
+    const int prod = wave - 1;                                        // producer index of waves 1..15 (wave 0: -1, loads nothing)
     auto fetch_desc = [&](uint32_t b) {
-        const uint32_t c = b * BATCH + wave * PER + (lane < PER ? lane : 0);
+        const uint32_t c = b * BATCH + (prod < 0 ? 0 : prod) * PER + (lane < PER ? lane : 0);
         const MixChan* mc = ch + (c < n_ch ? c : n_ch - 1);
         p_nxt = (uint64_t)mc->in;
         g_nxt = (uint64_t)__double_as_longlong(c < n_ch ? mc->gain : 0.0);
         cue_nxt = (uint32_t)__ballot(c < n_ch && mc->cue != 0);
     };
-    float v[PER][FW];
-    auto issue = [&](uint64_t pl) {
+    // loads of one batch in flight + what landing them needs; two sets: a batch has two iterations to arrive
+    struct Inflight { float v[PER][FW]; uint64_t g; uint32_t cue; };
+    Inflight A, B;
+    auto issue = [&](Inflight& st) {                                  // the batch whose descriptors fetch_desc() brought last
+        st.g = g_nxt; st.cue = cue_nxt;
+        const uint64_t pl = p_nxt;
 #pragma unroll
-        for (int u = 0; u < PER; ++u) ldw<FW>(bcast_u64(pl, u), foff, v[u]);
+        for (int u = 0; u < PER; ++u) ldw<FW>(bcast_u64(pl, u), foff, st.v[u]);
     };
-    auto land = [&](uint32_t b, uint64_t gl, uint32_t cuel, uint32_t valid /* channels of mine that exist */) {
-        Slot* dst = lds + ((size_t)(b & 1) * BATCH + (size_t)wave * PER) * 64 + lane;
+    auto land = [&](const Inflight& st, uint32_t b) {
+        const uint32_t c0 = b * BATCH + (uint32_t)prod * PER;
+        const uint32_t valid = c0 >= n_ch ? 0u : (n_ch - c0 < (uint32_t)PER ? n_ch - c0 : (uint32_t)PER);   // channels of mine that exist
+        Slot* dst = lds + ((size_t)(b & 1) * BATCH + (size_t)prod * PER) * 64 + lane;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const double g = __longlong_as_double((long long)bcast_u64(gl, u));
-            const bool cue = ((cuel >> u) & 1u) != 0;
+            const double g = __longlong_as_double((long long)bcast_u64(st.g, u));
+            const bool cue = ((st.cue >> u) & 1u) != 0;
             Slot sl;
 #pragma unroll
             for (int k = 0; k < FW; ++k) {
-                const float x = (uint32_t)u < valid ? v[u][k] : 0.0f;                // a channel past the end contributes +0.0 + +0.0
+                const float x = (uint32_t)u < valid ? st.v[u][k] : 0.0f;             // a channel past the end contributes +0.0 + +0.0
                 sl[k] = (float)((double)x * g);                                      // mixer.rs:62 (the product)
                 sl[FW + k] = cue ? x : 0.0f;                                         // mixer.rs:64-66 (what the cue bus gets)
             }
             dst[(size_t)u * 64] = sl;
         }
     };
-    auto my_valid = [&](uint32_t b) -> uint32_t {
-        const uint32_t c0 = b * BATCH + wave * PER;
-        return c0 >= n_ch ? 0u : (n_ch - c0 < (uint32_t)PER ? n_ch - c0 : (uint32_t)PER);
-    };
 
-    fetch_desc(0);
-    uint64_t p_cur = p_nxt, g_cur = g_nxt; uint32_t cue_cur = cue_nxt;
-    issue(p_cur);
-    if (n_batch > 1) fetch_desc(1);
-    land(0, g_cur, cue_cur, my_valid(0));
+    if (prod >= 0) {
+        fetch_desc(0); issue(A);
+        if (n_batch > 1) { fetch_desc(1); issue(B); }
+        if (n_batch > 2) fetch_desc(2);
+        land(A, 0);
+    }
     __syncthreads();
 
     Slot acc;                                                         // {master[FW], cue[FW]}: both ordered sums in one packed add per channel
 #pragma unroll
     for (int k = 0; k < 2 * FW; ++k) acc[k] = 0.f;                    // util::zero(master/cue), mixer.rs:54-55
-    for (uint32_t b = 0; b < n_batch; ++b) {
-        const bool more = b + 1 < n_batch;                            // uniform
-        if (more) {
-            p_cur = p_nxt; g_cur = g_nxt; cue_cur = cue_nxt;
-            issue(p_cur);
-            if (b + 2 < n_batch) fetch_desc(b + 2);
-        }
+    // one step: batch b sits in LDS, `nx` holds batch b+1 in flight, `fr` is free; the descriptors of batch b+2 are fetched
+    auto step = [&](Inflight& fr, const Inflight& nx, uint32_t b) {
+        if (prod >= 0 && b + 2 < n_batch) { issue(fr); if (b + 3 < n_batch) fetch_desc(b + 3); }
         if (wave == 0) {
             const Slot* src = lds + (size_t)(b & 1) * BATCH * 64 + lane;
             const uint32_t c0 = b * BATCH, cnt = n_ch - c0 < (uint32_t)BATCH ? n_ch - c0 : (uint32_t)BATCH;
             uint32_t u = 0;
-            for (; u + 16 <= cnt; u += 16) {
-                Slot t[16];
+            if (cnt >= 8) {                                           // groups of 8, the next group's LDS reads in flight under this group's adds
+                Slot t[8], nxt8[8];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) t[j] = src[(size_t)(u + j) * 64];
+                for (int j = 0; j < 8; ++j) t[j] = src[(size_t)j * 64];
+                for (; u + 16 <= cnt; u += 8) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc += t[j];             // channel order
+                    for (int j = 0; j < 8; ++j) nxt8[j] = src[(size_t)(u + 8 + j) * 64];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += t[j];          // channel order
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = nxt8[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += t[j];
+                u += 8;
             }
             for (; u < cnt; ++u) acc += src[(size_t)u * 64];
         }
-        if (more) {
-            land(b + 1, g_cur, cue_cur, my_valid(b + 1));             // the other buffer: wave 0 finished with it one barrier ago
+        if (b + 1 < n_batch) {
+            if (prod >= 0) land(nx, b + 1);                           // the other buffer: wave 0 finished with it one barrier ago
             __syncthreads();
         }
+    };
+    for (uint32_t b = 0; b < n_batch; b += 2) {
+        step(A, B, b);
+        if (b + 1 < n_batch) step(B, A, b + 1);
     }
     if (wave == 0 && live) {
         float2* om = reinterpret_cast<float2*>(m.master) + f0 + lane;
