@@ -47,13 +47,16 @@ BYTES_PER_FRAME_FUSED = {"envelope": 4, "eq_three": 4 + 4, "mixer": 4}
 STRIP_BYTES_FUSED_48K = (8 + 4) * 800   # per strip-tick: fused EQ (in, out) + mixer read
 
 
-def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate):
-    """Config-2 strips [first_strip, first_strip + n_strips) with the global seeded parameters."""
-    total = 1024 if first_strip + n_strips <= 1024 else first_strip + n_strips
+def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=None, total=None):
+    """Config-2 strips [first_strip, first_strip + n_strips) with the global seeded parameters, into a Mixer(n_strips);
+    `ws`: add them to an existing workspace (group buses), `total`: size of the whole job the parameters are drawn for."""
+    if total is None:
+        total = 1024 if first_strip + n_strips <= 1024 else first_strip + n_strips
     eq_g = synth.uniform(10, 3 * total, -24.0, 6.0)
     mg = synth.uniform(11, total, -24.0, 6.0)
     mf = synth.uniform(12, total, 0.0, 1.0)
-    ws = Workspace(sample_rate, 60)
+    if ws is None:
+        ws = Workspace(sample_rate, 60)
     mix = ws.mixer([(float(mg[k]), float(mf[k]), k % 8 == 0) for k in range(first_strip, first_strip + n_strips)])
     srcs = []
     for j, k in enumerate(range(first_strip, first_strip + n_strips)):
@@ -230,51 +233,81 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
 
 def north_star_realtime_leg(torch, stream, local_rank, abi, Workspace, synth, n_strips=10240, sample_rate=48000):
     """The north-star's real-time statement as ONE graph, one tick per submission: 10 240 stereo channel strips (config-2 strips)
-    into a flat Mixer(10 240) plus the config-4 video cascade (8 layers -> 7 VideoMixers -> RGBA), every tick synchronised
-    like a live engine.  Reports the tick time against the 16 667 us budget."""
+    mixed, plus the config-4 video cascade (8 layers -> 7 VideoMixers -> RGBA), every tick synchronised like a live engine.
+    Two mix topologies the reference can express: one flat Mixer(10 240) -- a single ordered chain per output sample, the
+    strictest reading -- and ten group buses Mixer(1024) into a Mixer(10) master, how a desk of that size is wired.
+    Reports the tick time against the 16 667 us budget."""
     from mixlab_amd import video
 
-    t_build = time.perf_counter()
-    ws, mix, srcs = build_strips(abi, Workspace, synth, n_strips, 0, sample_rate)
     sizes = [(1920, 1080)] * 6 + [(1280, 720)] * 2
-    vsrcs = [ws.source_video() for _ in sizes]
-    prev = vsrcs[0]
-    for k in range(1, 8):
-        m = ws.video_mixer(a=0, b=1, fader=VIDEO_FADERS[k - 1])
-        ws.connect(prev, 0, m, 0); ws.connect(vsrcs[k], 0, m, 1)
-        prev = m
-    rgba = ws.video_to_rgba(VIDEO_MATRIX)
-    ws.connect(prev, 0, rgba, 0)
-    g = ws.build(max_ticks_per_run=1, device=local_rank, stream=stream.cuda_stream)
-    spt = ws.spt
-    blk = [synth.noise(k, spt) for k in range(64)]
-    for j, s in enumerate(srcs):
-        g.write_source(s, blk[j % 64], 1)
-    keep = []
-    for k, (w, h) in enumerate(sizes):
-        y, u, v = synth.yuv_pattern(w, h, k, seed=3)
-        d = video.DFrame(w, h).upload(y, u, v)
-        keep.append(d)
-        video.graph_set_video_source(g, vsrcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)
-    t_build = time.perf_counter() - t_build
-    for i in range(20):
-        g.run_ticks(i, 1)
-    g.sync()
-    n = 200
-    t0 = time.perf_counter()
-    for i in range(n):
-        g.run_ticks(20 + i, 1)
-        g.sync()
-    tick_us = (time.perf_counter() - t0) / n * 1e6
-    by_kind, _tot = g.profile_run(20 + n, 1)
-    # module-boundary bytes of one tick (SURVEY.md section 8d): strips 51 200 B each, the mixer's two buses, the video cascade
+    frames_host = [synth.yuv_pattern(w, h, k, seed=3) for k, (w, h) in enumerate(sizes)]
+    blk = None
     F, F720 = 1920 * 1080 * 3 // 2, 1280 * 720 * 3 // 2
-    tick_bytes = 51200 * (sample_rate / 48000.0) * n_strips + 7 * 3 * F + 2 * (F720 + F) + (F + 1920 * 1080 * 4)
-    return {"workload": f"{n_strips} channel strips -> Mixer({n_strips}) + 8-layer 1080p cascade -> RGBA, one 1/60 s tick per submission, synchronised every tick",
-            "tick_us": round(tick_us, 1), "tick_budget_us": round(1e6 / 60.0, 1), "headroom": round(1e6 / 60.0 / tick_us, 1),
-            "device_ms_by_kind": {k: round(v, 4) for k, v in sorted(by_kind.items()) if v > 0},
-            "hbm_frac_module_boundary_bytes": round(tick_bytes / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-            "graph_nodes": len(ws.nodes), "graph_build_s": round(t_build, 2)}
+
+    def one(topology):
+        nonlocal blk
+        t_build = time.perf_counter()
+        extra_bytes = 0
+        if topology == "flat":
+            ws, mix, srcs = build_strips(abi, Workspace, synth, n_strips, 0, sample_rate)
+        else:
+            # strips k*1024 .. k*1024+1023 into group bus k (same gains / faders / cue flags as the flat job), buses into a unity master
+            n_bus = n_strips // 1024
+            ws, srcs, buses = Workspace(sample_rate, 60), [], []
+            for b in range(n_bus):
+                _ws, bus, s_b = build_strips(abi, Workspace, synth, 1024, b * 1024, sample_rate, ws=ws, total=n_strips)
+                buses.append(bus); srcs += s_b
+            master = ws.mixer([(0.0, 1.0, False)] * n_bus)
+            for b, bus in enumerate(buses):
+                ws.connect(bus, 0, master, b)
+            spt_ = sample_rate // 60
+            extra_bytes = n_bus * 2 * 8 * spt_ + (n_bus + 2) * 8 * spt_     # the buses' outputs + the master Mixer(n_bus)
+        vsrcs = [ws.source_video() for _ in sizes]
+        prev = vsrcs[0]
+        for k in range(1, 8):
+            m = ws.video_mixer(a=0, b=1, fader=VIDEO_FADERS[k - 1])
+            ws.connect(prev, 0, m, 0); ws.connect(vsrcs[k], 0, m, 1)
+            prev = m
+        rgba = ws.video_to_rgba(VIDEO_MATRIX)
+        ws.connect(prev, 0, rgba, 0)
+        g = ws.build(max_ticks_per_run=1, device=local_rank, stream=stream.cuda_stream)
+        spt = ws.spt
+        if blk is None:
+            blk = [synth.noise(k, spt) for k in range(64)]
+        for j, s in enumerate(srcs):
+            g.write_source(s, blk[j % 64], 1)
+        keep = []
+        for k, (w, h) in enumerate(sizes):
+            y, u, v = frames_host[k]
+            d = video.DFrame(w, h).upload(y, u, v)
+            keep.append(d)
+            video.graph_set_video_source(g, vsrcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)
+        t_build = time.perf_counter() - t_build
+        for i in range(20):
+            g.run_ticks(i, 1)
+        g.sync()
+        n = 200
+        t0 = time.perf_counter()
+        for i in range(n):
+            g.run_ticks(20 + i, 1)
+            g.sync()
+        tick_us = (time.perf_counter() - t0) / n * 1e6
+        by_kind, _tot = g.profile_run(20 + n, 1)
+        # module-boundary bytes of one tick (SURVEY.md section 8d): strips 51 200 B each (incl. their mixer input), the video cascade
+        tick_bytes = 51200 * (sample_rate / 48000.0) * n_strips + extra_bytes + 7 * 3 * F + 2 * (F720 + F) + (F + 1920 * 1080 * 4)
+        return {"tick_us": round(tick_us, 1), "headroom": round(1e6 / 60.0 / tick_us, 1),
+                "device_ms_by_kind": {k: round(v, 4) for k, v in sorted(by_kind.items()) if v > 0},
+                "hbm_frac_module_boundary_bytes": round(tick_bytes / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "graph_nodes": len(ws.nodes), "graph_build_s": round(t_build, 2)}
+
+    flat = one("flat")
+    buses = one("buses")
+    out = {"workload": f"{n_strips} channel strips mixed + 8-layer 1080p cascade -> RGBA, one 1/60 s tick per submission, synchronised every tick",
+           "tick_budget_us": round(1e6 / 60.0, 1)}
+    out.update(flat)                         # headline fields: the flat Mixer(10 240)
+    out["mix_topology"] = f"flat Mixer({n_strips})"
+    out["group_buses"] = dict(buses, mix_topology=f"{n_strips // 1024} x Mixer(1024) -> Mixer({n_strips // 1024}, unity)")
+    return out
 
 
 def fir_leg(torch, stream, local_rank, T, steps, warmup):
