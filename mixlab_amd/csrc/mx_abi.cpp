@@ -182,7 +182,9 @@ int mx_graph_performance_info(mx_graph* g, mx_performance_info* info, uint64_t* 
 struct mx_pcm_ring {
     std::vector<int16_t> q;     // interleaved samples not yet consumed, oldest first
     size_t head = 0;
-    std::vector<int16_t> stage;
+    int16_t* stage = nullptr;   // page-locked staging for the H2D copy (the reference stages through ring buffers too, src/source.rs:97-98)
+    size_t stage_cap = 0;
+    ~mx_pcm_ring() { if (stage) (void)hipHostFree(stage); }
 };
 
 int mx_pcm_ring_create(mx_pcm_ring** out) {
@@ -207,16 +209,22 @@ int mx_pcm_ring_feed(mx_pcm_ring* r, mx_graph* g, uint32_t node, uint32_t n_tick
         REQUIRE(r && g, "NULL argument");
         REQUIRE(node < g->g->n_nodes() && g->g->node(node).kind == MX_KIND_SOURCE_STEREO, "node is not a SOURCE_STEREO");
         const size_t per_tick = 2 * g->g->spt();            // audio_out.len(), stream_input.rs:80
-        r->stage.assign(per_tick * n_ticks, 0);              // util::zero for whatever the queue cannot fill (stream_input.rs:120-122)
+        const size_t need = per_tick * (size_t)n_ticks;
+        if (need > r->stage_cap) {
+            if (r->stage) { (void)hipHostFree(r->stage); r->stage = nullptr; r->stage_cap = 0; }
+            mx::hip_check(hipHostMalloc((void**)&r->stage, need * sizeof(int16_t), hipHostMallocDefault), "hipHostMalloc(pcm staging)");
+            r->stage_cap = need;
+        }
+        std::memset(r->stage, 0, need * sizeof(int16_t));   // util::zero for whatever the queue cannot fill (stream_input.rs:120-122)
         size_t missing = 0;
         for (uint32_t t = 0; t < n_ticks; ++t) {
             const size_t have = r->q.size() - r->head, take = have < per_tick ? have : per_tick;
-            std::memcpy(r->stage.data() + (size_t)t * per_tick, r->q.data() + r->head, take * sizeof(int16_t));   // partial frames stay queued (:113-116)
+            std::memcpy(r->stage + (size_t)t * per_tick, r->q.data() + r->head, take * sizeof(int16_t));   // partial frames stay queued (:113-116)
             r->head += take;
             missing += per_tick - take;
         }
         if (r->head == r->q.size()) { r->q.clear(); r->head = 0; }
-        g->g->write_source_i16(node, r->stage.data(), (size_t)n_ticks * g->g->spt());   // H2D as i16, /32768 on the device (:167-173)
+        g->g->write_source_i16(node, r->stage, (size_t)n_ticks * g->g->spt());   // H2D as i16 from pinned memory, /32768 on the device (:167-173)
         if (zero_filled) *zero_filled = missing;
     });
 }
