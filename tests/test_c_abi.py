@@ -31,3 +31,29 @@ def test_plain_c_client_runs_on_gpu(tmp_path):
     res = subprocess.run([str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "abi_smoke ok" in res.stdout
+
+
+def build_cpp(tmp_path):
+    exe = tmp_path / "host_mirror"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "tests" / "cpp" / "host_mirror.cpp"),
+           "-L", str(ROOT / "mixlab_amd"), "-lmixlab_gpu", f"-Wl,-rpath,{ROOT / 'mixlab_amd'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_cpp_host_mirror_compiles_links_and_reports_missing_gpu_cleanly(tmp_path):
+    # include/mixlab_gpu.hpp: ModuleT / InputRef / OutputRef / Workspace / Engine with the reference's names over the C ABI
+    exe = build_cpp(tmp_path)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode in (0, 2), res.stdout + res.stderr
+    if res.returncode == 2:
+        assert "no GPU" in res.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_runs_on_gpu(tmp_path):
+    exe = build_cpp(tmp_path)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "host_mirror ok" in res.stdout
