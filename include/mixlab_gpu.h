@@ -89,8 +89,13 @@ typedef struct { uint32_t up, down, taps_per_phase, _pad; /* double taps[up][tap
 typedef struct { uint32_t kind; uint32_t params_len; const void* params; } mx_node;
 typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /* workspace.connections: InputId -> OutputId */
 
-#define MX_FLAG_EQ_EXACT 1u  /* EqThree: strictly sequential recurrence (bit-exact vs the reference order);
-                                default is the time-parallel chunked scan (<= 1 ULP f32) */
+/* EqThree arithmetic.  DEFAULT: bit-exact with the reference's sequential order (src/module/eq_three.rs:58-89) -- the
+ * reference's own module test asserts exact equality with its golden file (eq_three.rs:150-167) and the default passes it.
+ * MX_FLAG_EQ_FAST opts into the time-parallel chunked scan: NOT bit-exact -- every f32 output is within 1 ULP of the
+ * reference order and about 1 sample in 20 000 differs (DESIGN.md "EqThree").  MX_FLAG_EQ_EXACT is the default's old
+ * name, kept as a no-op; it wins if both are given. */
+#define MX_FLAG_EQ_EXACT 1u
+#define MX_FLAG_EQ_FAST 4u
 
 #define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
                                 [-> Amplifier [<- Envelope <- Trigger]] into the EQ kernel, a single-consumer Trigger into
@@ -293,8 +298,10 @@ int mx_module_update(mx_module* m, const void* params, size_t params_len);
 /* ModuleT::run_tick (src/module/mod.rs:17): inputs/outputs are host buffers owned by the caller
  * for the duration of the call; outputs are fully overwritten.  A MX_DISCONNECTED input reads the
  * zero buffer.  Any input length is accepted (the reference's one test feeds 355 285 samples in
- * one call, src/module/eq_three.rs:150-167) as long as all ports agree.  Plotter: indication =
- * left[SPT] then right[SPT] f32, *indication_len set to the byte count (0 = None). */
+ * one call, src/module/eq_three.rs:150-167) as long as all ports agree.  Plotter: *indication_len is IN/OUT --
+ * on entry the capacity of `indication` in bytes, on return the bytes written (0 = None): left[frames] then
+ * right[frames] f32 for the call's buffer length; a capacity below 2 * frames floats is MX_ERR_INVALID.
+ * EqThree always runs in the reference's exact order on this path unless MX_FLAG_EQ_FAST was given at creation. */
 int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t n_inputs,
                        mx_output* outputs, size_t n_outputs, void* indication, size_t* indication_len);
 void mx_module_destroy(mx_module* m);

@@ -29,8 +29,9 @@ MX_DISCONNECTED, MX_MONO, MX_STEREO, MX_VIDEO = 0, 1, 2, 3
 KIND_NAMES = ["amplifier", "envelope", "eq_three", "fm_sine", "mixer", "oscillator", "plotter", "stereo_panner",
               "stereo_splitter", "trigger", "video_mixer", "source_mono", "source_stereo", "source_video", "video_to_rgba", "fir", "resample"]
 WAVE_ON, WAVE_OFF, WAVE_SINE, WAVE_SQUARE, WAVE_TRIANGLE, WAVE_SAW = range(6)
-FLAG_EQ_EXACT = 1
+FLAG_EQ_EXACT = 1   # the default (kept as a no-op name)
 FLAG_NO_FUSE = 2
+FLAG_EQ_FAST = 4    # time-parallel EqThree: <= 1 ULP, not bit-exact
 
 
 class MixerChannelParams(C.Structure):
@@ -345,7 +346,7 @@ class Module:
         for i, (lk, arr) in enumerate(outputs):
             assert arr.dtype == np.float32 and arr.flags.c_contiguous
             outs[i] = Output(lk, arr.ctypes.data_as(C.c_void_p), arr.size, None, 0)
-        ind_len = C.c_size_t(0)
+        ind_len = C.c_size_t(indication.nbytes if indication is not None else 0)   # in: capacity, out: bytes written
         ind_ptr = indication.ctypes.data_as(C.c_void_p) if indication is not None else None
         check(lib.mx_module_run_tick(self._h, t, ins, len(inputs), outs, len(outputs), ind_ptr, C.byref(ind_len)))
         return ind_len.value

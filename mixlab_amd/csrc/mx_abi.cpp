@@ -18,6 +18,7 @@ struct mx_module {
     uint32_t kind = 0;
     std::unique_ptr<Graph> g;   // node 0 = the module, node 1+i = SOURCE feeding input terminal i
     std::unique_ptr<mx::VideoMixer> vm;   // MX_KIND_VIDEO_MIXER: host frames in, host frames out
+    uint32_t tps = 60;                    // TICKS_PER_SECOND (src/engine.rs:54) the module was created for
     std::vector<uint8_t> in_type, out_type;
 };
 
@@ -262,6 +263,8 @@ int mx_module_create_ex(uint32_t kind, const void* params, size_t params_len, co
             if (opts && opts->device >= 0) mx::hip_check(hipSetDevice(opts->device), "hipSetDevice");
             m->in_type.assign(4, MX_VIDEO); m->out_type.assign(3, MX_VIDEO);
             m->vm = std::make_unique<mx::VideoMixer>(p, opts ? opts->sample_rate : 0u, nullptr);
+            m->tps = (opts && opts->ticks_per_second) ? opts->ticks_per_second : 60u;
+            m->vm->set_lazy_program(false, m->tps);   // frame expiry and the program frame's duration follow the configured tick rate
             *out = m.release();
             return;
         }
@@ -307,6 +310,7 @@ int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t 
         REQUIRE(n_outputs == m->out_type.size(), "wrong number of outputs for this module kind");
         REQUIRE(!n_inputs || inputs, "inputs is NULL");
         REQUIRE(!n_outputs || outputs, "outputs is NULL");
+        const size_t indication_cap = indication_len ? *indication_len : 0;   // in: capacity of `indication` in bytes
         if (indication_len) *indication_len = 0;
         if (m->vm) {   // VideoMixer::run_tick on host frames: upload, run on the device, download what the caller has room for
             hipStream_t st = m->vm->stream();
@@ -342,7 +346,7 @@ int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t 
                                                    hipMemcpyDeviceToHost, st), "hipMemcpy2DAsync(D2H frame)");
                 }
                 hf->width = res[i]->width; hf->height = res[i]->height;
-                if (i == 0) { hf->dur_num = 1; hf->dur_den = 60; hf->off_num = 0; hf->off_den = 1; }     // video_mixer.rs:241-247
+                if (i == 0) { hf->dur_num = 1; hf->dur_den = (int64_t)m->tps; hf->off_num = 0; hf->off_den = 1; }     // video_mixer.rs:241-247 (1 / TICKS_PER_SECOND)
                 else { const int src = (i == 1) ? m->vm->param_a() : m->vm->param_b();                      // clone of the input VideoFrame (:80-90)
                        if (src >= 0 && src < 4 && inputs[src].video) { hf->dur_num = inputs[src].video->dur_num; hf->dur_den = inputs[src].video->dur_den;
                                                                        hf->off_num = inputs[src].video->off_num; hf->off_den = inputs[src].video->off_den; } }
@@ -386,6 +390,8 @@ int mx_module_run_tick(mx_module* m, uint64_t t, const mx_input* inputs, size_t 
         if (m->kind == MX_KIND_PLOTTER) {
             g.sync();
             if (indication && indication_len) {
+                // PlotterIndication { inputs: [left, right] } (plotter.rs:44-52): `frames` floats each, never more than the caller has room for
+                if (indication_cap < 2 * frames * sizeof(float)) throw Error(MX_ERR_INVALID, "indication buffer is smaller than 2 * frames floats");
                 float* l = (float*)indication;
                 if (g.read_plotter(0, 0, l, l + frames)) *indication_len = 2 * frames * sizeof(float);
             }

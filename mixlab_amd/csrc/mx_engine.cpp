@@ -249,7 +249,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
                     if (n.kind != MX_KIND_VIDEO_MIXER && n.kind != MX_KIND_VIDEO_TO_RGBA) ok[pr.node] = 0;
                 }
         for (size_t i = 0; i < nodes_.size(); ++i)
-            if (nodes_[i].vmixer) nodes_[i].vmixer->set_lazy_program(n_cons[i] == 1 && ok[i], tps);
+            if (nodes_[i].vmixer) { nodes_[i].vlazy = n_cons[i] == 1 && ok[i]; nodes_[i].vmixer->set_lazy_program(nodes_[i].vlazy, tps); }
     }
     // time-parallel EqThree tables (unused in MX_FLAG_EQ_EXACT mode)
     {
@@ -378,7 +378,14 @@ void Graph::plan_fusion() {
 void Graph::layout_slab() {
     size_t off = 0;
     auto bump = [&](size_t floats) { size_t o = off; off += (floats + 63) & ~(size_t)63; return o; };  // 256-byte aligned
-    zero_off_ = bump(2 * cap_frames_);
+    // Disconnected inputs read this region (io.rs:8-9); a node behind a Resample runs cap_frames * up / down frames per
+    // launch, so the region is sized for the largest sample-rate domain of the graph
+    size_t zero_frames = cap_frames_;
+    for (const Node& n : nodes_) {
+        zero_frames = std::max(zero_frames, cap_frames_ * n.dom_num / n.dom_den + 1);
+        zero_frames = std::max(zero_frames, cap_frames_ * n.in_dom_num / n.in_dom_den + 1);
+    }
+    zero_off_ = bump(2 * zero_frames);
     for (Node& n : nodes_)
         for (size_t k = 0; k < n.out_type.size(); ++k)
             n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump((n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * (cap_frames_ * n.dom_num / n.dom_den + 1));
@@ -702,7 +709,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, gf, stream_); break;
         case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_EQ_THREE:
-            if (flags_ & MX_FLAG_EQ_EXACT) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
+            if (eq_exact()) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
             else {
                 EqSplit sp{1u, 5u, 0u, 0u, gf, gf, nullptr, nullptr, nullptr};
                 EqSpanPow pp{};
@@ -863,6 +870,7 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
         if (nn.kind == MX_KIND_VIDEO_MIXER && on.vmixer) {                       // stored frames, scalers, expiry times
             mx_video_mixer_params p; std::memcpy(&p, nn.params.data(), sizeof p);
             nn.vmixer = std::move(on.vmixer);
+            nn.vmixer->rebind(stream_, nn.vlazy, tps_);   // the old graph's stream may be gone after this call; this graph's fusion plan and tick rate apply
             nn.vmixer->update(p);
         }
         if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }

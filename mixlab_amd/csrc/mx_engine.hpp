@@ -48,6 +48,7 @@ struct Node {
     // video nodes (run tick by tick inside Graph::run)
     struct VOut { FrameRef frame; Rational dur, off; };
     std::unique_ptr<VideoMixer> vmixer;       // VIDEO_MIXER
+    bool vlazy = false;                       // VIDEO_MIXER: program output handed over as an unevaluated cross-fade chain (graph compiler)
     std::vector<VOut> vout;                   // this tick's video outputs (empty FrameRef = None)
     FrameRef vsrc; Rational vsrc_dur, vsrc_off; bool vsrc_repeat = false, vsrc_pending = false;   // SOURCE_VIDEO
     DevBuf rgba; uint32_t rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;                       // VIDEO_TO_RGBA
@@ -79,6 +80,7 @@ public:
     const std::vector<uint32_t>& run_order() const { return order_; }
     hipStream_t stream() const { return stream_; }
     size_t n_nodes() const { return nodes_.size(); }
+    bool eq_exact() const { return (flags_ & MX_FLAG_EQ_EXACT) || !(flags_ & MX_FLAG_EQ_FAST); }   // the default is the reference's order
     const Node& node(uint32_t i) const { return nodes_.at(i); }
 
     void update_params(uint32_t node, const void* params, size_t len);

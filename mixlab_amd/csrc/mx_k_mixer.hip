@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_mixer_coop(const MixDesc* __r
         }
     };
 
-    if (prod >= 0) {
+    if (prod >= 0 && n_ch) {   // a Mixer with no channels (params_len 0) sharing the launch: nothing to fetch, its buses stay +0.0 (mixer.rs:54-55)
         fetch_desc(0); issue(A);
         if (n_batch > 1) { fetch_desc(1); issue(B); }
         if (n_batch > 2) fetch_desc(2);

@@ -47,11 +47,34 @@ void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 // Oscillator (src/module/oscillator.rs:15-37,65-92) and FmSine (src/module/fm_sine.rs:37-56).
 // f64 sin = ocml's; the reference's is the host libm.  Both are sub-ULP f64 routines; after the
-// f32 cast the results differ in at most 1 f32 ULP, rarely (measured in tests).
+// f32 cast the Sine / FmSine results differ in at most 1 f32 ULP, rarely (measured in tests).  Square is bit-exact.
 // ---------------------------------------------------------------------------------------------
 #define MX_PI 3.14159265358979323846264338327950288
 
 __device__ __forceinline__ double osc_saw(double n) { return 2.0 * (n - floor(0.5 + n)); }
+
+// Square = sign(sin(x)) by the sign BIT (oscillator.rs:15-23,80).  libm's sin never gets the sign of a non-zero result
+// wrong, so the reference's value is the sign of the real number sin(x) for the f64 x it formed -- computed here EXACTLY,
+// not through the device's sin (whose last-bit differences flip the sign next to a zero crossing):
+//   m = rint(x / pi);  r = x - m pi  with pi = PI_HI + PI_MID + PI_LO (161 bits);  sign(sin x) = sign(r) * (-1)^m.
+// fma(-m, PI_HI, x) is exact (the difference is a multiple of ulp(PI_HI) below 2 in magnitude), the PI_MID product is
+// split exactly (two-product) and added with a two-sum; what is left out is below m * 1e-49.  No f64 below 2^40 comes
+// closer than ~1e-20 to a multiple of pi, so the sign is that of the real number.  |x| >= 2^40 (days of audio at ultrasonic
+// frequencies), infinities and NaN keep the sign bit of the device's sin.  An m that is off by one (x / pi next to a
+// half-integer) leaves |r| < pi, where the identity still holds.
+__device__ __forceinline__ bool sin_is_negative(double x) {
+    if (x == 0.0) return signbit(x);                               // sin(+-0) = +-0: the sign bit decides (oscillator.rs:16-22)
+    if (!(fabs(x) < 1099511627776.0)) return signbit(sin(x));      // 2^40 and beyond, inf, NaN
+    const double PI_HI = 0x1.921fb54442d18p+1, PI_MID = 0x1.1a62633145c07p-53, PI_LO = -0x1.f1976b7ed8fbcp-109;
+    const double m = rint(x * 0x1.45f306dc9c883p-2);
+    const double r1 = fma(-m, PI_HI, x);                           // exact
+    const double p2 = m * PI_MID, e2 = fma(m, PI_MID, -p2);        // m * PI_MID = p2 + e2 exactly
+    const double sd = r1 - p2, bb = sd - r1;
+    const double t = (r1 - (sd - bb)) + (-p2 - bb);                // r1 - p2 = sd + t exactly (two-sum)
+    const double r = sd + ((t - e2) - m * PI_LO);
+    const bool m_odd = ((long long)m & 1LL) != 0;
+    return (r < 0.0) != m_odd;
+}
 
 __global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
     const OscDesc d = descs[blockIdx.y];
@@ -61,7 +84,7 @@ __global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ 
         double v;
         switch (d.waveform) {
         case 2: v = sin(n * 2.0 * MX_PI); break;                                      // Sine
-        case 3: { const double sv = sin(n * 2.0 * MX_PI); v = signbit(sv) ? -1.0 : 1.0; break; }  // Square: sign by sign bit (oscillator.rs:15-23)
+        case 3: v = sin_is_negative(n * 2.0 * MX_PI) ? -1.0 : 1.0; break;                // Square: exact sign of sin (see sin_is_negative)
         case 5: v = osc_saw(n); break;                                                // Saw
         case 4: v = 2.0 * fabs(osc_saw(n)) - 1.0; break;                              // Triangle
         case 0: v = 1.0; break;                                                       // On

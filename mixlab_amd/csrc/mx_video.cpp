@@ -295,6 +295,18 @@ VideoMixer::~VideoMixer() {
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
+void VideoMixer::rebind(hipStream_t s, bool lazy_program, uint32_t ticks_per_second) {
+    if (!s) throw Error(MX_ERR_INVALID, "VideoMixer::rebind needs a stream");
+    for (auto& c : ch_) if (c.has_stored && c.stored.frame && c.stored.frame->lazy) c.stored.frame->ensure_pixels(stream_);   // a symbolic frame of the old graph must exist before that graph goes
+    flush_scales(stream_);
+    if (stream_) hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // everything queued on the old stream has run
+    for (auto& c : ch_) if (c.scaler) c.scaler->rebind(s);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    own_stream_ = false;
+    stream_ = s;
+    set_lazy_program(lazy_program, ticks_per_second);
+}
+
 FrameRef VideoMixer::fresh_output(uint32_t w, uint32_t h) {
     for (auto& f : pool_)
         if (f->width == w && f->height == h && f->rc.load(std::memory_order_acquire) == 1) return f;   // only the pool holds it

@@ -152,6 +152,8 @@ public:
     // returns the frame itself when its settings equal the output's (encode.rs:342-345), else the
     // scaler's own letterboxed output frame (encode.rs:386-396)
     FrameRef scale(const FrameRef& in);
+    // a topology edit moved the owning VideoMixer to another graph: queued work leaves on the old stream first
+    void rebind(hipStream_t s) { flush_scales(stream_); stream_ = s; }
 private:
     void retarget(uint32_t in_w, uint32_t in_h);
     uint32_t out_w_, out_h_;
@@ -178,6 +180,10 @@ public:
     // returns program / A / B frames (null FrameRef = None)
     void run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, FrameRef& out_a, FrameRef& out_b);
     hipStream_t stream() const { return stream_; }
+    // topology edit (Engine::client_update, src/engine.rs:277-398: the module persists, its connections change): the
+    // mixer -- stored frames, expiry times, per-channel scalers -- moves to the edited graph and from now on launches on
+    // THAT graph's stream, with that graph's fusion decision and tick rate
+    void rebind(hipStream_t s, bool lazy_program, uint32_t ticks_per_second);
     int param_a() const { return params_.a; }
     int param_b() const { return params_.b; }
 private:

@@ -27,3 +27,10 @@ def test_scaler_window_origin_f64_formula_equals_integer_tap_spec(tmp_path):
     subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-std=c11", str(HERE / "tap_origin_check.c"), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_square_oscillator_exact_sign_of_sine_agrees_with_libm_on_52_million_arguments(tmp_path):
+    exe = tmp_path / "sin_sign_check"
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-std=gnu11", str(HERE / "sin_sign_check.c"), "-o", str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("0 /"), out.stdout + out.stderr

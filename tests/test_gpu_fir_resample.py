@@ -8,7 +8,7 @@ import oracle
 import synth
 from mixlab_amd import abi
 from mixlab_amd.workspace import Workspace
-from test_gpu_audio_parity import SPT, assert_bit_exact
+from test_gpu_audio_parity import SPT, assert_bit_exact, bits
 
 pytestmark = pytest.mark.gpu
 
@@ -161,3 +161,29 @@ def test_random_resampler_and_fir_chains_match_oracle_graph(seed):
                 w = np.concatenate(want[n])
                 got = g.read_output(n, 0, T, True, rate=(w.size, 2 * 735 * T))
                 assert_bit_exact(got, w, f"seed {seed} run {run} node {n}")
+
+
+def test_disconnected_input_of_a_mixer_behind_the_resampler_reads_silence_at_full_capacity():
+    """A Mixer in the 48 kHz domain (behind a 160/147 Resample) with one Disconnected channel, run at n_ticks ==
+    max_ticks_per_run: the zero buffer (src/engine/io.rs:8-9) must cover the UPSAMPLED length -- the disconnected channel
+    has fader 1.0 and cue on, so anything but silence would show on both buses."""
+    from mixlab_amd.workspace import Workspace
+    T = 8
+    table = polyphase_table()
+    ws = Workspace(44100, 60)
+    s = ws.source_stereo(); r = ws.resample(160, 147, table)
+    ws.connect(s, 0, r, 0)
+    # many ports after the zero region so that an overrun would read live signal
+    fill = [ws.oscillator(100.0 + k, abi.WAVE_SAW) for k in range(4)]
+    mix = ws.mixer([(0.0, 1.0, True), (0.0, 1.0, True)])
+    ws.connect(r, 0, mix, 0)                      # channel 1 stays Disconnected
+    g = ws.build(max_ticks_per_run=T)
+    x = synth.noise(77, 2 * 735 * T)
+    g.write_source(s, x, T)
+    g.run_ticks(0, T)                             # full capacity
+    hist = np.zeros((table.shape[1] - 1) * 2, np.float32)
+    want_r = oracle.resample_run(table, 160, 147, hist, 0, 0, x, 800 * T)
+    want_m, want_c = oracle.mixer_run([(0.0, 1.0, True), (0.0, 1.0, True)], [want_r, None], 2 * 800 * T)
+    assert np.array_equal(bits(g.read_output(mix, 0, T, True, rate=(160, 147))), bits(want_m))
+    assert np.array_equal(bits(g.read_output(mix, 1, T, True, rate=(160, 147))), bits(want_c))
+    assert fill

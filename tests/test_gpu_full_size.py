@@ -53,6 +53,47 @@ def test_config2_full_size_mixer_is_the_ordered_sum_of_the_device_strips(noise48
     assert np.array_equal(bits(g.read_output(mix, 1, T, True)), bits(want_c))
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_config2_full_size_48khz_every_strip_and_the_mix_against_the_oracle(noise48, mode):
+    """BASELINE configs[1] at its own size and rate -- 1024 strips, 48 kHz -- against the ORACLE (not against another device
+    kernel): every strip's Amplifier output and the Master / Cue buses, sample by sample, over two runs of 6 ticks with
+    the gates set per strip between the runs.  Exact mode: bit-exact.  Fast (time-parallel) mode: every strip within
+    1 ULP, and the Mixer bit-exact given the device's own strips."""
+    T, runs = 6, 2
+    ws, mix, srcs, trigs = strips(N, SR48)
+    og = oracle.OracleGraph(ws)
+    g = ws.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_EXACT if mode == "exact" else abi.FLAG_EQ_FAST | abi.FLAG_NO_FUSE)
+    fused = mode == "exact"
+    n_diff = 0
+    for run in range(runs):
+        for k, tr in enumerate(trigs):
+            p = abi.TriggerParams(1 if ((run * T + k) // 3) % 2 else 0)
+            g.update_params(tr, p); og.update_params(tr, p)
+        _feed(g, srcs, noise48, run, T, SPT48)
+        g.run_ticks(run * T, T)
+        got_m, got_c = g.read_output(mix, 0, T, True), g.read_output(mix, 1, T, True)
+        dev_amp = None if fused else [g.read_output(mix + 6 * k + 6, 0, T, True) for k in range(N)]
+        for kk in range(T):
+            tick = run * T + kk
+            for k, s in enumerate(srcs):
+                og.set_source(s, noise48[k][tick * SPT48:(tick + 1) * SPT48])
+            og.run_tick(tick)
+            sl = slice(kk * 2 * SPT48, (kk + 1) * 2 * SPT48)
+            if fused:
+                assert np.array_equal(bits(got_m[sl]), bits(og.output(mix, 0))), f"Master tick {tick}"
+                assert np.array_equal(bits(got_c[sl]), bits(og.output(mix, 1))), f"Cue tick {tick}"
+            else:
+                for k in range(N):
+                    d = synth.ulp_diff(dev_amp[k][sl], og.output(mix + 6 * k + 6, 0))
+                    assert d.max() <= 1, f"strip {k} tick {tick}: {d.max()} ULP"
+                    n_diff += int(np.count_nonzero(d))
+        if not fused:
+            chans = [(float(synth.uniform(11, N, -24.0, 6.0)[k]), float(synth.uniform(12, N, 0.0, 1.0)[k]), k % 8 == 0) for k in range(N)]
+            want_m, want_c = oracle.mixer_run(chans, dev_amp, 2 * T * SPT48)
+            assert np.array_equal(bits(got_m), bits(want_m)) and np.array_equal(bits(got_c), bits(want_c))
+    assert n_diff <= runs * T * N * 2 * SPT48 // 20000
+
+
 def test_config2_full_size_batching_and_fusion_are_invisible_in_exact_mode(noise48):
     T = 6
     outs = {}
@@ -74,7 +115,7 @@ def test_config2_full_size_batching_and_fusion_are_invisible_in_exact_mode(noise
 def test_config2_full_size_time_parallel_eq_within_one_ulp_of_exact_order_on_every_strip(noise48):
     T = 16
     res = {}
-    for name, flags in (("exact", abi.FLAG_EQ_EXACT), ("scan", 0)):
+    for name, flags in (("exact", abi.FLAG_EQ_EXACT), ("scan", abi.FLAG_EQ_FAST)):
         ws, mix, srcs, trigs = strips(N, SR48)
         g = ws.build(max_ticks_per_run=T, flags=flags)
         for k, tr in enumerate(trigs):
@@ -94,7 +135,7 @@ def test_rank_sized_shard_time_split_mix_close_to_unsplit(noise48, monkeypatch):
     for force in ("1", "0"):
         monkeypatch.setenv("MX_EQ_SPLIT", force)
         ws, mix, srcs, trigs = strips(128, SR48)
-        g = ws.build(max_ticks_per_run=T)
+        g = ws.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_FAST)
         res = []
         for run in range(1):
             _feed(g, srcs, noise48, run, T, SPT48)

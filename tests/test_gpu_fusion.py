@@ -12,7 +12,7 @@ from test_gpu_audio_parity import SPT, assert_bit_exact, strips
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("eq_flag", [0, abi.FLAG_EQ_EXACT])
+@pytest.mark.parametrize("eq_flag", [abi.FLAG_EQ_FAST, 0])
 def test_fused_equals_unfused_on_every_surviving_port(eq_flag):
     n_strips, T = 24, 5
     ws, mix, srcs, trigs = strips(n_strips)

@@ -180,3 +180,62 @@ def test_performance_info_shape_and_accounting():
         assert us[src] == 0                                # a bound buffer costs nothing
         assert us[eq] == us[pan] == us[amp] == us[env] == us[trig]   # folded into one launch: equal shares
     assert us[mix] > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# a VideoMixer across a topology edit: stored frames, expiry times and scalers move to the edited graph, which then
+# launches them on ITS stream (the old graph is destroyed straight after the edit, as the header tells callers to do)
+# ------------------------------------------------------------------------------------------------
+def test_topology_edit_moves_a_video_mixer_to_the_new_graphs_stream():
+    import oracle_video as ov
+    from mixlab_amd import video
+
+    def upload(hf):
+        y, u, v = hf.visible()
+        return video.DFrame(hf.w, hf.h).upload(y, u, v)
+
+    def build(with_sink):
+        ws = Workspace(SR, 60)
+        s0 = ws.source_video(); s1 = ws.source_video()
+        m = ws.video_mixer(a=0, b=1, fader=0.25)
+        ws.connect(s0, 0, m, 0); ws.connect(s1, 0, m, 1)
+        ids = {"s0": s0, "s1": s1, "m": m}
+        if with_sink:   # the edit: an RGBA sink appears behind the mixer (its program output becomes a fused chain)
+            r = ws.video_to_rgba(None); ws.connect(m, 0, r, 0); ids["rgba"] = r
+        return ws, ids
+
+    big, small = ov.HostFrame(320, 180).fill(1, seed=5), ov.HostFrame(212, 120).fill(2, seed=5)   # the small one goes through the channel's scaler
+    om = ov.OracleVideoMixer(a=0, b=1, fader=0.25)
+    ws0, id0 = build(False)
+    g0 = ws0.build()
+    # both frames arrive on tick 0 and stay on screen for 10 ticks
+    video.graph_set_video_source(g0, id0["s0"], upload(big), dur=(10, 60), off=(0, 1), repeat=False)
+    video.graph_set_video_source(g0, id0["s1"], upload(small), dur=(10, 60), off=(0, 1), repeat=False)
+    g0.run_ticks(0, 1)
+    want0 = om.run_tick(0, [(big, (10, 60), (0, 1)), (small, (10, 60), (0, 1)), None, None])
+    got0 = video.graph_video_output(g0, id0["m"], 0)
+    for a, b in zip(got0.download(), want0.visible()):
+        assert np.array_equal(a, b)
+
+    ws1, id1 = build(True)
+    g1 = ws1.build()
+    mapping = [-1] * len(ws1.nodes)
+    for k in ("s0", "s1", "m"):
+        mapping[id1[k]] = id0[k]
+    g1.adopt_state(g0, mapping)
+    g0.close(); del g0            # the old graph and its stream are gone
+    for tick in (1, 2, 3):
+        g1.run_ticks(tick, 1)     # no new frames: the STORED frames (one of them the moved scaler's output) are composed
+        want = om.run_tick(tick * SPT, [None, None, None, None])
+        got = video.graph_video_output(g1, id1["m"], 0)
+        assert got is not None and (got.width, got.height) == (want.w, want.h)
+        for p, (a, b) in enumerate(zip(got.download(), want.visible())):
+            assert np.array_equal(a, b), f"tick {tick}: plane {p} differs after the edit"
+        assert np.array_equal(video.graph_rgba_output(g1, id1["rgba"]), ov.to_rgba(want, None))
+    # a frame of a new size after the edit: the moved mixer re-targets its scalers on the new stream
+    small2 = ov.HostFrame(160, 90).fill(3, seed=5)
+    video.graph_set_video_source(g1, id1["s1"], upload(small2), dur=(10, 60), off=(0, 1), repeat=False)
+    g1.run_ticks(4, 1)
+    want = om.run_tick(4 * SPT, [None, (small2, (10, 60), (0, 1)), None, None])
+    for p, (a, b) in enumerate(zip(video.graph_video_output(g1, id1["m"], 0).download(), want.visible())):
+        assert np.array_equal(a, b), f"plane {p} differs for a new frame size after the edit"
