@@ -134,6 +134,22 @@ int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n
 /* ModuleT::update (src/module/mod.rs:16): replace one node's params between ticks. */
 int mx_graph_update_params(mx_graph* g, uint32_t node, const void* params, size_t params_len);
 
+/* Engine::client_update BETWEEN two ticks of one submission (src/engine.rs:192-214 drains the command queue after every tick;
+ * :277-398 applies ModuleT::update): `params` replace `node`'s at the boundary before tick `tick_in_run` (0-based) of the NEXT
+ * mx_graph_run_ticks, which must cover that tick (else that run fails with MX_ERR_INVALID and drops its schedule).  Updates for
+ * the same node and tick apply in submission order; after the run the node holds the last one.  A Trigger's updates cost nothing
+ * (one gate bit per tick read by the kernels that folded it in); an update of any other kind cuts the run into separately
+ * launched spans at its tick.  The _batch form queues many at once (one foreign call per run). */
+typedef struct { uint32_t node; uint32_t tick_in_run; const void* params; size_t params_len; } mx_param_event;
+int mx_graph_schedule_params(mx_graph* g, uint32_t node, uint32_t tick_in_run, const void* params, size_t params_len);
+int mx_graph_schedule_params_batch(mx_graph* g, const mx_param_event* events, size_t n_events);
+
+/* Counters of the default EqThree path on long streams (speculative time-parallel form proven bit-exact chunk by chunk,
+ * DESIGN.md "EqThree"), accumulated since the graph was built: stream chunks run, and chunks whose start state the
+ * verification pass found different from the sequential order's and re-ran (exactly-constant input after a signal).
+ * Synchronises the graph's stream. */
+int mx_graph_eq_spec_stats(mx_graph* g, uint64_t* chunks_run, uint64_t* chunks_repaired);
+
 /* Feed a SOURCE_* node: n_ticks consecutive tick buffers (SPT mono / 2*SPT interleaved stereo f32). */
 int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks);
 /* Or bind an external device buffer holding max_ticks_per_run tick buffers (read-only, caller-owned). */

@@ -103,6 +103,14 @@ _proto("mx_graph_destroy", None, C.c_void_p)
 _proto("mx_graph_samples_per_tick", C.c_int, C.c_void_p, C.POINTER(C.c_size_t))
 _proto("mx_graph_run_order", C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t))
 _proto("mx_graph_update_params", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
+class ParamEvent(C.Structure):
+    """mx_param_event: ModuleT::update of `node` at the boundary before tick `tick_in_run` of the next run."""
+    _fields_ = [("node", C.c_uint32), ("tick_in_run", C.c_uint32), ("params", C.c_void_p), ("params_len", C.c_size_t)]
+
+
+_proto("mx_graph_schedule_params", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
+_proto("mx_graph_schedule_params_batch", C.c_int, C.c_void_p, C.POINTER(ParamEvent), C.c_size_t)
+_proto("mx_graph_eq_spec_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _proto("mx_graph_write_source", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_bind_source_device", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p)
 _proto("mx_graph_run_ticks", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32)
@@ -203,6 +211,21 @@ class Graph:
     def update_params(self, node, params):
         blob = params_bytes(params)
         check(lib.mx_graph_update_params(self._h, node, blob, len(blob)))
+
+    def schedule_params(self, node, tick_in_run: int, params):
+        """ModuleT::update at the boundary before tick `tick_in_run` of the next run (client_update between ticks)."""
+        blob = params_bytes(params)
+        check(lib.mx_graph_schedule_params(self._h, node, tick_in_run, blob, len(blob)))
+
+    def schedule_params_batch(self, events: "C.Array", n: int | None = None):
+        """events: a ctypes array of ParamEvent whose `params` pointers the caller keeps alive for the call."""
+        check(lib.mx_graph_schedule_params_batch(self._h, events, len(events) if n is None else n))
+
+    def eq_spec_stats(self):
+        """-> (chunks run, chunks repaired) of the speculative exact EqThree path since the graph was built."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib.mx_graph_eq_spec_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def write_source(self, node, samples: np.ndarray, n_ticks: int):
         a = np.ascontiguousarray(samples, dtype=np.float32)

@@ -94,6 +94,28 @@ int mx_graph_update_params(mx_graph* g, uint32_t node, const void* params, size_
     return guard([&] { REQUIRE(g, "graph is NULL"); g->g->update_params(node, params, params_len); });
 }
 
+int mx_graph_schedule_params(mx_graph* g, uint32_t node, uint32_t tick_in_run, const void* params, size_t params_len) {
+    return guard([&] { REQUIRE(g, "graph is NULL"); g->g->schedule_params(node, tick_in_run, params, params_len); });
+}
+
+int mx_graph_schedule_params_batch(mx_graph* g, const mx_param_event* events, size_t n_events) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        REQUIRE(events || !n_events, "events is NULL");
+        for (size_t i = 0; i < n_events; ++i) g->g->schedule_params(events[i].node, events[i].tick_in_run, events[i].params, events[i].params_len);
+    });
+}
+
+int mx_graph_eq_spec_stats(mx_graph* g, uint64_t* chunks_run, uint64_t* chunks_repaired) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        uint64_t v[2];
+        g->g->eq_spec_stats(v);
+        if (chunks_run) *chunks_run = v[0];
+        if (chunks_repaired) *chunks_repaired = v[1];
+    });
+}
+
 int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks) {
     return guard([&] { REQUIRE(g, "graph is NULL"); g->g->write_source(node, host_samples, n_ticks * g->g->spt()); });
 }

@@ -290,6 +290,7 @@ Graph::~Graph() {
     for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); }
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
+    for (Stage& st : stage_) { if (st.done) (void)hipEventDestroy(st.done); if (st.host) (void)hipHostFree(st.host); }
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -396,8 +397,12 @@ void Graph::layout_slab() {
 }
 
 float* Graph::out_ptr(const Node& n, uint32_t port) const {
-    if (n.bound && port == 0) return const_cast<float*>(n.bound);
-    return (float*)slab_.p + n.out_off[port];
+    // run_off_frames_: a run that is cut at scheduled parameter updates launches span by span; a span's buffers start that many
+    // (base-rate) frames into the port
+    const size_t fpf = n.out_dup[port] ? 1 : floats_per_frame(n.out_type[port]);
+    const size_t off = fpf * (run_off_frames_ * n.dom_num / n.dom_den);
+    if (n.bound && port == 0) return const_cast<float*>(n.bound) + off;
+    return (float*)slab_.p + n.out_off[port] + off;
 }
 const float* Graph::in_ptr(const Node& n, uint32_t port, bool null_if_disconnected) const {
     const PortRef pr = n.in_src[port];
@@ -430,9 +435,9 @@ void Graph::upload_group(Group& g) {
             const Node& nd = nodes_[g.nodes[i]];
             mx_envelope_params p; std::memcpy(&p, nd.params.data(), sizeof p);
             float gate_const = 0.f; uint32_t use_const = 0;
-            if (nd.fuse_trigger >= 0) {   // Trigger folded in: its constant (trigger.rs:38-41) replaces the gate buffer
+            if (nd.fuse_trigger >= 0) {   // Trigger folded in: its per-tick constant (trigger.rs:38-41) replaces the gate buffer (GateBits row i)
                 mx_trigger_params tp; std::memcpy(&tp, nodes_[nd.fuse_trigger].params.data(), sizeof tp);
-                gate_const = tp.gate_open ? 1.0f : 0.0f; use_const = 1;
+                gate_const = tp.gate_open ? 1.0f : 0.0f; use_const = 2; g.has_gates = true;
             }
             d[i] = EnvDesc{use_const ? nullptr : in_ptr(nd, 0, false), out_ptr(nd, 0), gate_const, use_const,
                            EnvParams{p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
@@ -444,6 +449,8 @@ void Graph::upload_group(Group& g) {
     }
     case MX_KIND_EQ_THREE: {
         std::vector<EqDesc> d(n);
+        std::vector<EnvTickDesc> td(n);
+        bool any_env = false;
         for (size_t i = 0; i < n; ++i) {
             const Node& nd = nodes_[g.nodes[i]];
             mx_eq_three_params p; std::memcpy(&p, nd.params.data(), sizeof p);
@@ -465,16 +472,17 @@ void Graph::upload_group(Group& g) {
             if (nd.fuse_env >= 0) {          // Envelope (constant gate) evaluated inline as the control
                 const Node& env = nodes_[nd.fuse_env];
                 mx_envelope_params ep; std::memcpy(&ep, env.params.data(), sizeof ep);
-                mx_trigger_params tp; std::memcpy(&tp, nodes_[env.fuse_trigger].params.data(), sizeof tp);
                 e.flags |= MX_EQF_ENV; e.ctl = nullptr;
                 e.env = EnvParams{ep.attack_ms, 1.0 / ep.attack_ms, 1.0 / ep.decay_ms, ep.sustain_amplitude, 1.0 - ep.sustain_amplitude, 1.0 / ep.release_ms};
-                e.env_gate = tp.gate_open ? 1.0f : 0.0f;
                 if (!g.state2.p) { g.state2.alloc(n * sizeof(EnvState)); hip_check(hipMemset(g.state2.p, 0, n * sizeof(EnvState)), "hipMemset"); }
-                e.env_state = (EnvState*)g.state2.p + i;
+                // its per-tick states are laid out by k_env_ticks before the EQ kernel runs (gate = the folded Trigger, GateBits row i)
+                td[i] = EnvTickDesc{e.env, e.amp_one_minus, e.amp_mod_depth, (EnvState*)g.state2.p + i};
+                any_env = true; g.has_gates = true;
             }
             d[i] = e;
         }
         up(g.desc, d.data(), n * sizeof(EqDesc));
+        if (any_env) up(g.tick_desc, td.data(), n * sizeof(EnvTickDesc));
         if (!g.state.p) { g.state.alloc(n * sizeof(EqState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EqState)), "hipMemset"); }
         break;
     }
@@ -547,6 +555,7 @@ void Graph::upload_group(Group& g) {
             mx_trigger_params p; std::memcpy(&p, nd.params.data(), sizeof p);
             d[i] = TrigDesc{out_ptr(nd, 0), p.gate_open ? 1.0f : 0.0f, 0u};   // trigger.rs:38-41
         }
+        g.has_gates = true;
         up(g.desc, d.data(), n * sizeof(TrigDesc));
         break;
     }
@@ -605,19 +614,101 @@ void Graph::build_descriptors() {
 
 void Graph::update_params(uint32_t node, const void* params, size_t len) {
     if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
-    Node& n = nodes_[node];
-    if (len != n.params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
+    if (len != nodes_[node].params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
     if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
     sync();
+    apply_params(node, params, len);
+}
+
+// ModuleT::update (src/module/mod.rs:16) on a quiescent stream: new params into the node, descriptors of every launch that
+// reads them re-uploaded.  A Trigger only lives in the GateBits rows, which the next run refreshes.
+void Graph::apply_params(uint32_t node, const void* params, size_t len) {
+    Node& n = nodes_[node];
     if (len) std::memcpy(n.params.data(), params, len);
+    if (n.kind == MX_KIND_TRIGGER) { ++gates_version_; return; }
     if (n.kind == MX_KIND_VIDEO_MIXER && n.vmixer) {
         mx_video_mixer_params p; std::memcpy(&p, n.params.data(), sizeof p);
         n.vmixer->update(p);
     }
     if (n.group >= 0) upload_group(groups_[n.group]);
     int32_t o = (int32_t)node;
-    while (nodes_[o].elided && nodes_[o].owner >= 0) o = nodes_[o].owner;   // Trigger -> Envelope -> EqThree chains
+    while (nodes_[o].elided && nodes_[o].owner >= 0) o = nodes_[o].owner;   // Envelope -> EqThree chains
     if (o != (int32_t)node && nodes_[o].group >= 0) upload_group(groups_[nodes_[o].group]);
+}
+
+void Graph::schedule_params(uint32_t node, uint32_t tick, const void* params, size_t len) {
+    if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
+    Node& n = nodes_[node];
+    if (len != n.params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
+    if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
+    Node::SchedEv ev; ev.tick = tick;
+    ev.params.assign((const uint8_t*)params, (const uint8_t*)params + len);
+    n.sched.push_back(std::move(ev));
+    if (n.kind == MX_KIND_TRIGGER) ++gates_version_;
+}
+
+// H2D copy on the graph's stream out of page-locked staging: the caller's buffer is free on return, nothing waits for the device
+void Graph::stage_upload(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    Stage& st = stage_[stage_next_];
+    stage_next_ = (stage_next_ + 1) % 4;
+    if (st.pending) { hip_check(hipEventSynchronize(st.done), "hipEventSynchronize"); st.pending = false; }
+    if (st.cap < bytes) {
+        if (st.host) (void)hipHostFree(st.host);
+        st.host = nullptr; st.cap = 0;
+        hip_check(hipHostMalloc(&st.host, bytes, hipHostMallocDefault), "hipHostMalloc(staging)");
+        st.cap = bytes;
+    }
+    if (!st.done) hip_check(hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "hipEventCreate");
+    std::memcpy(st.host, src, bytes);
+    hip_check(hipMemcpyAsync(dst, st.host, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D staged)");
+    hip_check(hipEventRecord(st.done, stream_), "hipEventRecord");
+    st.pending = true;
+}
+
+uint32_t Graph::trigger_of_row(const Group& g, uint32_t row) const {
+    const Node& nd = nodes_[g.nodes[row]];
+    if (g.kind == MX_KIND_TRIGGER) return g.nodes[row];
+    if (g.kind == MX_KIND_ENVELOPE) return nd.fuse_trigger >= 0 ? (uint32_t)nd.fuse_trigger : ~0u;
+    if (g.kind == MX_KIND_EQ_THREE) return nd.fuse_env >= 0 && nodes_[nd.fuse_env].fuse_trigger >= 0 ? (uint32_t)nodes_[nd.fuse_env].fuse_trigger : ~0u;
+    return ~0u;
+}
+
+// GateBits rows of a group for the coming run: bit c of row i = gate_open of row i's Trigger during tick c -- its current params,
+// then every scheduled update from its tick on (the reference applies client_update between two ticks, src/engine.rs:192-214)
+void Graph::refresh_gates(Group& g, uint32_t run_calls) {
+    if (!g.has_gates) return;
+    if (g.gates.p && g.gates_version == gates_version_ && g.gates_calls == run_calls) return;
+    const uint32_t words = (run_calls + 31) / 32;
+    const size_t n = g.nodes.size();
+    std::vector<uint32_t> bits(n * words, 0u);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t tr = trigger_of_row(g, (uint32_t)i);
+        if (tr == ~0u) continue;
+        const Node& T = nodes_[tr];
+        mx_trigger_params tp; std::memcpy(&tp, T.params.data(), sizeof tp);
+        bool open = tp.gate_open != 0;
+        uint32_t c = 0;
+        uint32_t* row = bits.data() + i * words;
+        auto fill_to = [&](uint32_t end) { if (open) for (; c < end; ++c) row[c >> 5] |= 1u << (c & 31); else c = end; };
+        for (const Node::SchedEv& ev : T.sched) {           // stable by tick: submission order decides among updates for one tick
+            const uint32_t at = ev.tick < run_calls ? ev.tick : run_calls;
+            if (at > c) fill_to(at);
+            mx_trigger_params np; std::memcpy(&np, ev.params.data(), sizeof np);
+            open = np.gate_open != 0;
+        }
+        fill_to(run_calls);
+    }
+    if (g.gates.bytes < bits.size() * sizeof(uint32_t) || !g.gates.p) { sync(); g.gates.alloc(std::max<size_t>(bits.size() * sizeof(uint32_t), 256)); }
+    stage_upload(g.gates.p, bits.data(), bits.size() * sizeof(uint32_t));
+    g.gate_words = words; g.gates_version = gates_version_; g.gates_calls = run_calls;
+}
+
+void Graph::eq_spec_stats(uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    if (!eq_stats_.p) return;
+    sync();
+    hip_check(hipMemcpy(out, eq_stats_.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(eq stats)");
 }
 
 void Graph::write_source(uint32_t node, const float* host, size_t frames) {
@@ -667,23 +758,36 @@ static bool group_launches(const Group& g);
 
 void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, float* ms_total) {
     const size_t frames = fpc * (size_t)n_calls;
-    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "n_ticks exceeds max_ticks_per_run");
-    if (n_calls == 0 || fpc == 0) { last_calls_ = n_calls; last_frames_per_call_ = fpc; return; }
+    auto drop_schedules = [&] { for (Node& n : nodes_) n.sched.clear(); };
+    if (frames > cap_frames_) { drop_schedules(); throw Error(MX_ERR_INVALID, "n_ticks exceeds max_ticks_per_run"); }
+    if (n_calls == 0 || fpc == 0) { drop_schedules(); last_calls_ = n_calls; last_frames_per_call_ = fpc; return; }
     hip_check(hipSetDevice(device_), "hipSetDevice");
 
-    const bool prof = ms_by_kind != nullptr || prof_on_;
-    std::vector<hipEvent_t> ev;
-    if (prof) {
-        if (!prof_pool_.empty()) { ev = std::move(prof_pool_.back()); prof_pool_.pop_back(); }
-        else {
-            ev.resize(groups_.size() + 2);   // one slot per launch group + the per-tick video section
-            for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
-        }
-        hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
+    // ---- scheduled parameter updates (Engine::client_update between two ticks, src/engine.rs:192-214,277-398) ----
+    // Trigger updates travel as one gate bit per tick and cost nothing.  Any other module's update cuts the run into spans:
+    // the update is applied (ModuleT::update) between the span that ends before its tick and the span that starts with it.
+    std::vector<uint32_t> cuts;   // span starts > 0
+    bool any_sched = false;
+    for (Node& n : nodes_) {
+        if (n.sched.empty()) continue;
+        any_sched = true;
+        std::stable_sort(n.sched.begin(), n.sched.end(), [](const Node::SchedEv& x, const Node::SchedEv& y) { return x.tick < y.tick; });
+        if (n.sched.back().tick >= n_calls) { drop_schedules(); throw Error(MX_ERR_INVALID, "a scheduled parameter update lies beyond the run (tick_in_run >= n_ticks)"); }
+        if (n.kind != MX_KIND_TRIGGER) for (const Node::SchedEv& ev : n.sched) if (ev.tick) cuts.push_back(ev.tick);
     }
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    auto apply_at = [&](uint32_t tick) {   // every non-Trigger update scheduled for `tick`, in submission order
+        bool any = false;
+        for (uint32_t id = 0; id < nodes_.size(); ++id) {
+            Node& n = nodes_[id];
+            if (n.kind == MX_KIND_TRIGGER) continue;
+            for (const Node::SchedEv& ev : n.sched) if (ev.tick == tick) { if (!any) { sync(); any = true; } apply_params(id, ev.params.data(), ev.params.size()); }
+        }
+    };
+    if (any_sched) apply_at(0);
 
     // Plotter bookkeeping is host logic (plotter.rs:37-40): count += 1 per call, fire on every 6th
-    std::vector<PlotJob> jobs;
     size_t total_fired = 0;
     for (Node& n : nodes_) {
         if (n.kind != MX_KIND_PLOTTER || n.group < 0) continue;
@@ -700,38 +804,108 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         if (plot_stage_.bytes < need) { sync(); plot_stage_.alloc(need); }
         if (plot_jobs_.bytes < total_fired * sizeof(PlotJob)) { sync(); plot_jobs_.alloc(total_fired * sizeof(PlotJob)); }
     }
+    plot_job_off_ = 0;
+    for (Group& g : groups_) refresh_gates(g, n_calls);
 
-    size_t gi = 0, job_off = 0;
+    const bool prof = ms_by_kind != nullptr || prof_on_;
+    prof_this_run_ = prof;
+    if (cuts.empty()) {
+        run_span(t0, fpc, 0, n_calls, n_calls);
+    } else {
+        cuts.push_back(n_calls);
+        uint32_t from = 0;
+        for (uint32_t to : cuts) {
+            if (from) {
+                apply_at(from);
+                sync();
+                run_off_frames_ = (size_t)from * fpc;
+                build_descriptors();                       // every port pointer moves to the span's first tick
+            }
+            run_span(t0 + (uint64_t)from * fpc, fpc, from, to - from, n_calls);
+            from = to;
+        }
+        sync();
+        run_off_frames_ = 0;
+        build_descriptors();
+    }
+    // the modules keep the last scheduled params (a Trigger's are read by the next run's GateBits)
+    if (any_sched) {
+        for (Node& n : nodes_) {
+            if (n.sched.empty()) continue;
+            if (n.kind == MX_KIND_TRIGGER) { std::memcpy(n.params.data(), n.sched.back().params.data(), n.params.size()); ++gates_version_; }
+            n.sched.clear();
+        }
+    }
+    hip_check(hipGetLastError(), "kernel launch");
+    last_calls_ = n_calls;
+    last_frames_per_call_ = fpc;
+    if (prof) ++prof_runs_count_;
+    if (ms_by_kind) (void)profile_collect(ms_by_kind, ms_total);
+}
+
+// ticks [call_off, call_off + n_calls) of the current run: one launch per (level, kind, domain) group, then the video section
+void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_calls, uint32_t run_calls) {
+    const size_t frames = fpc * (size_t)n_calls;
+    const bool prof = prof_this_run_;
+    std::vector<hipEvent_t> ev;
+    if (prof) {
+        if (!prof_pool_.empty()) { ev = std::move(prof_pool_.back()); prof_pool_.pop_back(); }
+        else {
+            ev.resize(groups_.size() + 2);   // one slot per launch group + the per-tick video section
+            for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
+        }
+        hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
+    }
+    std::vector<PlotJob> jobs;
+    size_t gi = 0;
     for (Group& g : groups_) {
         const uint32_t n = (uint32_t)g.nodes.size();
         const size_t gf = frames * g.dom_num / g.dom_den;   // frames of this group's sample-rate domain
+        const size_t gfpc = fpc * g.dom_num / g.dom_den;    // ... per tick
+        const GateBits gates{(const uint32_t*)g.gates.p, g.gate_words, call_off};
         switch (g.kind) {
         case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, gf, stream_); break;
-        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, gf, t0, sample_rate_, stream_); break;
-        case MX_KIND_EQ_THREE:
-            if (eq_exact()) launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, stream_);
-            else {
+        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_); break;
+        case MX_KIND_EQ_THREE: {
+            EqRun r{gf, gfpc, n_calls, 0u, t0, sample_rate_, 1.0 / sample_rate_, lo_f_, hi_f_, nullptr};
+            if (g.state2.p) {   // Envelopes folded into the epilogue: their state entering every tick of this span
+                const size_t need = (size_t)n * n_calls * sizeof(EnvTick);
+                if (g.env_ticks.bytes < need || !g.env_ticks.p) { sync(); g.env_ticks.alloc(need); }
+                launch_env_ticks((const EnvTickDesc*)g.tick_desc.p, n, gates, n_calls, gfpc, t0, sample_rate_, (EnvTick*)g.env_ticks.p, stream_);
+                r.ticks = (const EnvTick*)g.env_ticks.p;
+            }
+            if (eq_exact()) {
+                EqSpecPlan plan;
+                if (eq_plan_spec(n, gf, lo_f_, hi_f_, plan)) {   // long streams: speculative time-parallel form, verified bit-exact
+                    const size_t need = eq_spec_scratch_bytes(n, plan);
+                    if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
+                    if (!eq_stats_.p) { eq_stats_.alloc(2 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 2 * sizeof(uint64_t)), "hipMemset"); }
+                    launch_eq_three_spec((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, plan, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
+                } else {
+                    launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, stream_);
+                }
+            } else {
                 EqSplit sp{1u, 5u, 0u, 0u, gf, gf, nullptr, nullptr, nullptr};
                 EqSpanPow pp{};
                 eq_plan_split(n, gf, lo_f_, hi_f_, sp);
                 if (sp.n_split > 1) {   // few instances, long streams: cut each stream into spans for different workgroups
-                    const size_t need = (size_t)n * sp.n_split * 8 * sizeof(double) + (size_t)n * 12 * sizeof(double) + (size_t)n * sizeof(EnvState);
+                    const size_t need = (size_t)n * sp.n_split * 8 * sizeof(double) + (size_t)n * 12 * sizeof(double);
                     if (g.extra.bytes < need || !g.extra.p) { sync(); g.extra.alloc(need); }
                     sp.zbuf = (double*)g.extra.p;                         // [n][n_split][8] zero-state span end states
                     sp.bound = sp.zbuf + (size_t)n * sp.n_split * 8;      // [n][12] snapshot of the carried EqState
-                    sp.env_snap = (EnvState*)(sp.bound + (size_t)n * 12); // [n] snapshot of the carried EnvelopeState
                     toeplitz_pow((long double)lo_f_, sp.span, pp.lo);
                     toeplitz_pow((long double)hi_f_, sp.span, pp.hi);
                 }
-                launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, gf, t0, sample_rate_, lo_f_, hi_f_, (const EqScanTab*)eq_tabs_.p, sp, pp, stream_);
+                launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, (const EqScanTab*)eq_tabs_.p, sp, pp, stream_);
             }
             break;
+        }
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, g.max_taps /* = most channels */, gf, g.dup_mode, stream_); break;
         case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, gf, stream_); break;
         case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, gf, stream_); break;
-        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, gf, stream_); break;
+        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, gf, gfpc, &gates, stream_); break;
         case MX_KIND_FIR: launch_fir((const FirDesc*)g.desc.p, n, g.max_taps, gf, stream_); break;
         case MX_KIND_RESAMPLE:
             launch_resample((const ResampleDesc*)g.desc.p, n, g.max_taps, g.rs_tab_doubles, g.rs_win_frames, frames * g.in_dom_num / g.in_dom_den, gf,
@@ -742,18 +916,16 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
             for (uint32_t id : g.nodes) {
                 const Node& nd = nodes_[id];
                 for (uint32_t c = 0; c < n_calls; ++c) {
-                    if (!nd.plot_fired[c]) continue;
-                    float* stage = (float*)plot_stage_.p + (size_t)nd.plot_slot[c] * 2 * fpc;
+                    if (!nd.plot_fired[call_off + c]) continue;
+                    float* stage = (float*)plot_stage_.p + (size_t)nd.plot_slot[call_off + c] * 2 * fpc;
                     jobs.push_back(PlotJob{in_ptr(nd, 0, false) + (size_t)c * 2 * fpc, stage, stage + fpc});
                 }
             }
             if (!jobs.empty()) {
-                // pageable-host upload; synchronise so `jobs` may be reused (fires every 6th tick only)
-                PlotJob* dst = (PlotJob*)plot_jobs_.p + job_off;
-                hip_check(hipMemcpyAsync(dst, jobs.data(), jobs.size() * sizeof(PlotJob), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(plot jobs)");
-                hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                PlotJob* dst = (PlotJob*)plot_jobs_.p + plot_job_off_;
+                stage_upload(dst, jobs.data(), jobs.size() * sizeof(PlotJob));
                 launch_plotter(dst, (uint32_t)jobs.size(), fpc, stream_);
-                job_off += jobs.size();
+                plot_job_off_ += jobs.size();
             }
             break;
         }
@@ -763,15 +935,11 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         if (prof && group_launches(g)) hip_check(hipEventRecord(ev[gi + 1], stream_), "hipEventRecord");
         ++gi;
     }
+    (void)run_calls;
     // video sub-graph: tick by tick (frames arrive per tick; nothing to batch over time)
     if (has_video_) { for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc); flush_scales(stream_); }
     if (prof && has_video_) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
-    hip_check(hipGetLastError(), "kernel launch");
-    last_calls_ = n_calls;
-    last_frames_per_call_ = fpc;
-
     if (prof) prof_runs_.push_back(std::move(ev));
-    if (ms_by_kind) (void)profile_collect(ms_by_kind, ms_total);
 }
 
 static bool group_launches(const Group& g) {
@@ -788,7 +956,8 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
     sync();
     if (ms_by_kind) for (int k = 0; k < MX_KIND_COUNT; ++k) ms_by_kind[k] = 0.f;
     if (ms_total) *ms_total = 0.f;
-    const uint32_t n = (uint32_t)prof_runs_.size();
+    const uint32_t n = prof_runs_count_;   // run() calls; a run cut into spans recorded one event list per span
+    prof_runs_count_ = 0;
     for (auto& ev : prof_runs_) {
         perf_group_ms_.assign(groups_.size() + 1, 0.f);
         size_t last = 0;   // index of the latest event that was recorded in this run

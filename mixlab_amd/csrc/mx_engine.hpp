@@ -33,6 +33,9 @@ struct Node {
     uint32_t in_dom_num = 1, in_dom_den = 1;  // ... of the input ports
     uint32_t slot = 0;                        // index inside its (level, kind) group
     int group = -1;
+    // parameter updates queued for ticks inside the next run (Engine::client_update between two ticks, src/engine.rs:192-214)
+    struct SchedEv { uint32_t tick; std::vector<uint8_t> params; };
+    std::vector<SchedEv> sched;
     // plotter
     uint64_t plot_count = 0;
     std::vector<uint8_t> plot_fired;          // per call of the last run
@@ -66,6 +69,13 @@ struct Group {
     DevBuf extra;    // Mixer: MixChan arrays
     DevBuf state2;   // EqThree: EnvState[] of Envelopes folded into the epilogue
     int dup_mode = 0; // Mixer: 0 no input stored mono-dup, 1 all, 2 mixed
+    // Trigger gates per tick of the run (GateBits rows, one per node of the group): Trigger groups, Envelope groups with a folded
+    // Trigger, EqThree groups with a folded Envelope.  Re-uploaded only when a gate, a schedule or the run length changed.
+    bool has_gates = false;
+    DevBuf gates; uint32_t gate_words = 0; uint64_t gates_version = ~0ull; uint32_t gates_calls = 0;
+    DevBuf tick_desc;   // EqThree: EnvTickDesc[] of the folded Envelopes
+    DevBuf env_ticks;   // EqThree: EnvTick[n][n_calls] of the current launch
+    DevBuf spec;        // EqThree: chunk records of the speculative exact kernel
 };
 
 class Graph {
@@ -84,6 +94,10 @@ public:
     const Node& node(uint32_t i) const { return nodes_.at(i); }
 
     void update_params(uint32_t node, const void* params, size_t len);
+    // ModuleT::update at the boundary before tick `tick_in_run` of the NEXT run (client_update between ticks, src/engine.rs:192-214)
+    void schedule_params(uint32_t node, uint32_t tick_in_run, const void* params, size_t len);
+    // counters of the speculative exact EqThree kernel since the graph was built: [0] chunks run, [1] chunks the repair pass had to re-run
+    void eq_spec_stats(uint64_t out[2]);
     void write_source(uint32_t node, const float* host, size_t frames);
     void bind_source(uint32_t node, const void* dev);
     // n_calls ModuleT::run_tick calls of frames_per_call mono samples each, back to back
@@ -119,6 +133,12 @@ private:
     void build_descriptors();
     void upload_group(Group& g);
     void run_video_tick(uint64_t t);
+    // one launch sequence over ticks [call_off, call_off + n_calls) of the current run
+    void run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_calls, uint32_t run_calls);
+    void apply_params(uint32_t node, const void* params, size_t len);   // update_params without the synchronisation
+    void refresh_gates(Group& g, uint32_t run_calls);
+    uint32_t trigger_of_row(const Group& g, uint32_t row) const;        // node id of the Trigger behind row `row` of a gated group, or ~0u
+    void stage_upload(void* dst, const void* src, size_t bytes);         // H2D on the graph's stream through page-locked staging
     const float* in_ptr(const Node& n, uint32_t port, bool null_if_disconnected) const;
     float* out_ptr(const Node& n, uint32_t port) const;
 
@@ -135,6 +155,14 @@ private:
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
     DevBuf slab_;
+    size_t run_off_frames_ = 0;   // base-rate frames before the span being launched (a run cut at scheduled parameter updates)
+    uint64_t gates_version_ = 0;  // bumped whenever a Trigger's params or schedule change
+    DevBuf eq_stats_;             // [2] u64 counters of the speculative EqThree kernel
+    struct Stage { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
+    Stage stage_[4]; uint32_t stage_next_ = 0;
+    uint32_t prof_runs_count_ = 0;
+    bool prof_this_run_ = false;
+    size_t plot_job_off_ = 0;
     size_t zero_off_ = 0;
     size_t slab_floats_ = 0;
     double lo_f_ = 0, hi_f_ = 0;

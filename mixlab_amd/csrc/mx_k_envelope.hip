@@ -31,7 +31,7 @@ __device__ __forceinline__ double read_lane_f64(double v, int l) {
 
 template <int K>
 __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ descs, EnvState* __restrict__ states,
-                                                   uint32_t n_inst, size_t frames, uint64_t t0, double sr, double rsr) {
+                                                   uint32_t n_inst, size_t frames, size_t fpc, GateBits gates, uint64_t t0, double sr, double rsr) {
     const int lane = threadIdx.x & 63;
     const uint32_t inst = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (inst >= n_inst) return;  // wave-uniform
@@ -43,12 +43,20 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
 
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint64_t le = lt | (1ull << lane);
+    // a Trigger whose params change at tick boundaries inside the run (use_const == 2): the gate of sample i is the bit of tick
+    // i / fpc; the lane's tick index advances with its sample index (64 per tile)
+    uint32_t g_call = (uint32_t)((size_t)lane / fpc); size_t g_rem = (size_t)lane % fpc;
 
     for (size_t base = 0; base < frames; base += 64 * K) {
         float xs[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {                       // K independent loads in flight
             const size_t i = base + 64 * k + lane;
+            if (p.use_const == 2u) {
+                xs[k] = (i < frames && gate_bit(gates, inst, g_call)) ? 1.0f : 0.0f;   // trigger.rs:38-41 with this tick's params
+                g_rem += 64;
+                while (g_rem >= fpc) { g_rem -= fpc; ++g_call; }
+            } else
             xs[k] = p.use_const ? p.gate_const : ((i < frames && p.gate) ? p.gate[i] : 0.0f);   // Disconnected => ZERO_BUFFER_MONO
         }
         // can any marker in these K tiles flip the carried state?  On: only a 0.0; Initial/Off: only a 1.0
@@ -123,11 +131,12 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
     if (lane == 0) { states[inst].tag = tag; states[inst].seq = seq; states[inst].off_amplitude = off_amp; }
 }
 
-void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s) {
     if (!n || !frames) return;
     const double rsr = 1.0 / sample_rate;
-    if (frames > 64 * 4) hipLaunchKernelGGL(k_envelope<8>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, t0, sample_rate, rsr);
-    else hipLaunchKernelGGL(k_envelope<2>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, t0, sample_rate, rsr);
+    if (!fpc) fpc = frames;
+    if (frames > 64 * 4) hipLaunchKernelGGL(k_envelope<8>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, fpc, gates, t0, sample_rate, rsr);
+    else hipLaunchKernelGGL(k_envelope<2>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, fpc, gates, t0, sample_rate, rsr);
 }
 
 }  // namespace mx

@@ -1,0 +1,461 @@
+// mx_k_eq_exact.hip -- EqThree in the reference's exact order (reference src/module/eq_three.rs:58-89,100-125), the default:
+//
+//   k_env_ticks        per-tick states of the Envelopes folded into the EQ epilogue (one wave per instance, ballots + clz)
+//   k_eq_three_exact   one lane per instance walks its stream (short streams: a tick at a time)
+//   k_eq_three_spec    SPECULATIVE time-parallel form for long streams, bit-exact by verification:
+//   k_eq_three_repair  ... the pass that proves (or restores) exactness
+//
+// Why speculation can be exact.  The two 4-pole cascades are contractions: two trajectories driven by the same input from
+// different states approach each other by (1 - f) per sample and, because every step rounds to the same f64 grid, they
+// COALESCE bit for bit once their distance is below half an ulp -- after a warm-up of W samples (eq_warm_len: the
+// cascade's k^3 p^k envelope below 2^-72) a filter started from zeros is in the very state the sequential filter is in,
+// for every live signal (noise, tones, music, DC; measured, DESIGN.md "EqThree").  So the stream of an instance is cut into
+// chunks of C samples, one LANE per chunk: the lane runs the exact recurrence over the W samples before its chunk from a
+// zero state, records the state it reaches (start), runs its chunk in the exact order -- outputs through the fused epilogue
+// -- and records its end state.  Chunk 0 starts from the carried state.  k_eq_three_repair then walks the chunks of an
+// instance in order: chunk j is PROVEN exact when its recorded start state equals, bit for bit, the proven end state of
+// chunk j-1 (induction from chunk 0).  Where the bits differ (it happens when the input was exactly constant for a long
+// time -- digital silence after a signal: the poles stall a few ulps from the fixed point, on the side they came from) the
+// pass re-runs the chunk from the proven state beside the speculative trajectory, rewrites the output samples whose f32
+// differs, and stops as soon as the two trajectories coalesce.  The result is the sequential order's, always; only the time
+// it takes depends on the input.
+#include <algorithm>
+#include <cmath>
+
+#include "mx_k_eq_common.hpp"
+
+namespace mx {
+
+// ---------------------------------------------------------------------------------------------
+// per-tick Envelope states (EnvTick) for Envelopes whose gate is a Trigger constant per tick
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int top_bit64(uint64_t m) { return 63 - __clzll((long long)m); }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), l));
+}
+
+// One wave per instance, 64 ticks per step: the gate of tick c is bit c, so "state after the first sample of tick c" follows
+// from the last rising / falling edge at or before c exactly as in k_envelope (envelope.rs:99-115 with one marker per tick).
+__global__ __launch_bounds__(256) void k_env_ticks(const EnvTickDesc* __restrict__ descs, uint32_t n_inst, GateBits gates, uint32_t n_calls,
+                                                    size_t fpc, uint64_t t0, double sr, double rsr, EnvTick* __restrict__ ticks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= n_inst) return;   // wave-uniform
+    const EnvTickDesc d = descs[inst];
+    if (!d.state) return;   // this instance folds no Envelope (wave-uniform)
+    uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.state->tag);
+    uint64_t seq = readlane_u64(d.state->seq, 0);
+    double off_amp = readlane_f64(d.state->off_amplitude, 0);
+    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    for (uint32_t c0 = 0; c0 < n_calls; c0 += 64) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        const bool valid = c < n_calls;
+        const bool b_cur = valid && gate_bit(gates, inst, c);
+        const uint64_t m1 = __ballot(b_cur);
+        const bool carry_on = tag == 1u;
+        const bool b_prev = lane ? ((m1 >> (lane - 1)) & 1ull) != 0 : carry_on;
+        const uint64_t R = __ballot(valid && !b_prev && b_cur);   // Initial | Off -> On  (envelope.rs:101-105)
+        const uint64_t F = __ballot(valid && b_prev && !b_cur);   // On -> Off             (envelope.rs:106-113)
+        auto t_of = [&](int l) { return t0 + (uint64_t)(c0 + (uint32_t)l) * (uint64_t)fpc; };
+        uint32_t my_tag = tag; uint64_t my_seq = seq; double my_off = off_amp;
+        const uint64_t Rle = R & le, Fle = F & le;
+        if (b_cur) {
+            my_tag = 1u;
+            if (Rle) my_seq = t_of(top_bit64(Rle));
+        } else if (Fle) {
+            const int fl = top_bit64(Fle);
+            const uint64_t off = t_of(fl);
+            const uint64_t Rb = R & ((1ull << fl) - 1ull);
+            const uint64_t on = Rb ? t_of(top_bit64(Rb)) : seq;
+            my_tag = 2u; my_seq = off;
+            my_off = amp_on_ms(d.p, seq_ms(on, off, sr, rsr));       // envelope.rs:108-111
+        }
+        if (valid) {
+            const uint64_t t = t_of(lane);
+            EnvTick k;
+            k.seq = my_seq; k.off_amp = my_off; k.tag = my_tag;
+            k.flat = env_saturated(d.p, my_tag, my_seq, t, sr, rsr) ? 1u : 0u;
+            const float cc = (float)env_amplitude(d.p, my_tag, my_seq, my_off, t, sr, rsr);
+            k.depth = d.amp_one_minus + d.amp_mod_depth * (double)cc;
+            ticks[(size_t)inst * n_calls + c] = k;
+        }
+        const int last = n_calls - c0 >= 64u ? 63 : (int)(n_calls - c0) - 1;
+        tag = (uint32_t)__builtin_amdgcn_readlane((int)my_tag, last);
+        seq = readlane_u64(my_seq, last);
+        off_amp = readlane_f64(my_off, last);
+    }
+    if (lane == 0) { d.state->tag = tag; d.state->seq = seq; d.state->off_amplitude = off_amp; }
+}
+void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s) {
+    if (!n || !n_calls) return;
+    hipLaunchKernelGGL(k_env_ticks, dim3((n + 3) / 4), dim3(256), 0, s, d, n, gates, n_calls, fpc, t0, sample_rate, 1.0 / sample_rate, ticks);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one lane per instance, strictly sequential (short streams; what the speculative form degenerates to at one chunk)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r) {
+    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= n_inst) return;
+    const EqDesc d = descs[inst];
+    EqSeqEmit em;
+    em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
+    em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
+    em.seek(0);
+    EqState st = states[inst];
+    EqPoles s;
+    for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
+    s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
+    for (size_t i = 0; i < r.frames; ++i) {
+        const float x = d.in ? d.in[i] : 0.f;
+        em.emit(i, eq_step(s, r.lo_f, r.hi_f, d.gain_lo, d.gain_mid, d.gain_hi, x));
+    }
+    for (int k = 0; k < 4; ++k) { st.lo[k] = s.lo[k]; st.hi[k] = s.hi[k]; }
+    st.history[0] = s.h0; st.history[1] = s.h1; st.history[2] = s.h2;
+    states[inst] = st;
+}
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s) {
+    if (!n || !r.frames) return;
+    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// speculative time-parallel exact form
+// ---------------------------------------------------------------------------------------------
+// what a chunk's lane leaves for the repair pass
+struct EqChunkRec {
+    double start[8];        // state the warm-up reached at the chunk's first sample (chunk 0: the carried state)
+    double end[8];          // state after the chunk's last sample
+    uint32_t xmin, xmax;    // min / max of the chunk's input bit patterns: equal => the input was constant
+    uint32_t pad[2];
+};
+
+typedef float __attribute__((ext_vector_type(4))) f4v;
+typedef float __attribute__((ext_vector_type(2))) f2v;
+__device__ __forceinline__ f4v ld_stream4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); }   // the source is streamed once
+
+// epilogue modes of the chunk loop (wave-uniform: one instance per wave)
+enum { EQM_PLAIN = 0, EQM_AMP_CONST = 1, EQM_AMP_CTL = 2, EQM_AMP_ENV = 3 };
+
+constexpr int EQ_BLK = 16;   // samples per block: four 16-byte loads in flight per lane while the previous block is computed
+
+template <int MODE, bool STEREO>
+__device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, const EnvTick* __restrict__ ticks, const size_t begin, const size_t len,
+                                              EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
+    const float* __restrict__ in = d.in + begin;
+    float* __restrict__ outm = d.out + (STEREO ? 2 * begin : begin);
+    const float* __restrict__ ctl = MODE == EQM_AMP_CTL ? d.ctl + begin : nullptr;
+    const double g_lo = d.gain_lo, g_mid = d.gain_mid, g_hi = d.gain_hi, lo_f = r.lo_f, hi_f = r.hi_f;
+    const double one_minus = d.amp_one_minus, mod_depth = d.amp_mod_depth, amplitude = d.amp_amplitude;
+    const double depth_const = one_minus + mod_depth * 1.0;                    // Disconnected control: mod value 1.0 (amplifier.rs:54)
+    const double rsr = r.rsr;
+    // tick cursor of the inline Envelope: `left` samples remain in tick `call`
+    uint32_t call = 0; uint32_t left = 0; EnvTick cur{}; uint64_t t = r.t0 + begin;
+    if (MODE == EQM_AMP_ENV) { call = (uint32_t)(begin / r.fpc); left = (uint32_t)(r.fpc - begin % r.fpc); cur = ticks[call]; }
+    auto fold = [&](float y, float c) -> float {
+        if (MODE == EQM_PLAIN) return y;
+        double depth;
+        if (MODE == EQM_AMP_CONST) depth = depth_const;
+        else if (MODE == EQM_AMP_CTL) depth = one_minus + mod_depth * (double)c;   // amplifier.rs:71-73
+        else {
+            if (left == 0) { ++call; cur = ticks[call]; left = (uint32_t)r.fpc; }
+            --left;
+            depth = env_depth(d.env, cur, one_minus, mod_depth, t, r.sr, rsr);
+            ++t;
+        }
+        return amp_apply(y, depth, amplitude);
+    };
+    auto put4 = [&](size_t i, const float (&v)[4]) {   // i multiple of 4
+        if (STEREO) {
+            f4v a = {v[0], v[0], v[1], v[1]}, b = {v[2], v[2], v[3], v[3]};       // stereo_panner.rs:35-38
+            __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(outm + 2 * i));
+            __builtin_nontemporal_store(b, reinterpret_cast<f4v*>(outm + 2 * i + 4));
+        } else {
+            f4v a = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(outm + i));
+        }
+    };
+    const size_t n_blk = len / EQ_BLK;
+    f4v xa[EQ_BLK / 4], ca[EQ_BLK / 4];
+    if (n_blk) {
+#pragma unroll
+        for (int q = 0; q < EQ_BLK / 4; ++q) { xa[q] = ld_stream4(in + 4 * q); if (MODE == EQM_AMP_CTL) ca[q] = ld_stream4(ctl + 4 * q); }
+    }
+    for (size_t b = 0; b < n_blk; ++b) {
+        f4v xb[EQ_BLK / 4], cb[EQ_BLK / 4];
+        const size_t nb = (b + 1 < n_blk ? b + 1 : b) * EQ_BLK;                 // the last block re-reads itself (in bounds, unused)
+#pragma unroll
+        for (int q = 0; q < EQ_BLK / 4; ++q) { xb[q] = ld_stream4(in + nb + 4 * q); if (MODE == EQM_AMP_CTL) cb[q] = ld_stream4(ctl + nb + 4 * q); }
+#pragma unroll
+        for (int q = 0; q < EQ_BLK / 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = xa[q][e];
+                const uint32_t xb32 = __float_as_uint(x);
+                xmin = xb32 < xmin ? xb32 : xmin; xmax = xb32 > xmax ? xb32 : xmax;
+                v[e] = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ca[q][e] : 0.f);
+            }
+            put4(b * EQ_BLK + 4 * q, v);
+        }
+#pragma unroll
+        for (int q = 0; q < EQ_BLK / 4; ++q) { xa[q] = xb[q]; if (MODE == EQM_AMP_CTL) ca[q] = cb[q]; }
+    }
+    for (size_t i = n_blk * EQ_BLK; i < len; ++i) {   // ragged tail of the stream's last chunk
+        const float x = in[i];
+        const uint32_t xb32 = __float_as_uint(x);
+        xmin = xb32 < xmin ? xb32 : xmin; xmax = xb32 > xmax ? xb32 : xmax;
+        const float v = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ctl[i] : 0.f);
+        if (STEREO) reinterpret_cast<float2*>(outm)[i] = make_float2(v, v); else outm[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_eq_three_spec(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+                                                       uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
+    const uint32_t inst = blockIdx.x / waves_per_inst;                         // wave-uniform: one instance per wave, descriptor in SGPRs
+    const uint32_t j = (blockIdx.x % waves_per_inst) * 64u + threadIdx.x;      // my chunk
+    if (j >= plan.n_chunks) return;
+    const EqDesc& d = descs[inst];
+    const size_t C = plan.chunk, W = plan.warm;
+    const size_t begin = (size_t)j * C;
+    const size_t len = r.frames - begin < C ? r.frames - begin : C;
+    EqPoles s;
+    if (j == 0) {
+        const EqState& st = states[inst];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
+        s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
+    } else {
+        // warm-up: the exact recurrence over the W samples before my chunk, from a zero state (C >= W: they exist)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s.lo[k] = 0.0; s.hi[k] = 0.0; }
+        const float* __restrict__ in = d.in + (begin - W);
+        f4v xa[EQ_BLK / 4];
+#pragma unroll
+        for (int q = 0; q < EQ_BLK / 4; ++q) xa[q] = ld_stream4(in + 4 * q);
+        const size_t n_blk = W / EQ_BLK;
+        for (size_t b = 0; b < n_blk; ++b) {
+            f4v xb[EQ_BLK / 4];
+            const size_t nb = (b + 1 < n_blk ? b + 1 : b) * EQ_BLK;
+#pragma unroll
+            for (int q = 0; q < EQ_BLK / 4; ++q) xb[q] = ld_stream4(in + nb + 4 * q);
+#pragma unroll
+            for (int q = 0; q < EQ_BLK / 4; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double x = (double)xa[q][e]; pump(r.lo_f, s.lo, x); pump(r.hi_f, s.hi, x); }
+            }
+#pragma unroll
+            for (int q = 0; q < EQ_BLK / 4; ++q) xa[q] = xb[q];
+        }
+        // the EQ's 3-sample delay line is the input itself: exact
+        s.h0 = (double)d.in[begin - 3]; s.h1 = (double)d.in[begin - 2]; s.h2 = (double)d.in[begin - 1];
+    }
+    EqChunkRec* rec = recs + (size_t)inst * plan.n_chunks + j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
+    uint32_t xmin = 0xffffffffu, xmax = 0u;
+    const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
+    const bool stereo = !(d.epi == 0u || (d.flags & MX_EQF_MONO_DUP));
+    const int mode = d.epi != 2u ? EQM_PLAIN : ((d.flags & MX_EQF_ENV) ? EQM_AMP_ENV : (d.ctl ? EQM_AMP_CTL : EQM_AMP_CONST));
+#define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true>(d, r, ticks, begin, len, s, xmin, xmax); else eq_spec_chunk<M, false>(d, r, ticks, begin, len, s, xmin, xmax); break
+    switch (mode) { MX_EQ_CASE(EQM_PLAIN); MX_EQ_CASE(EQM_AMP_CONST); MX_EQ_CASE(EQM_AMP_CTL); default: MX_EQ_CASE(EQM_AMP_ENV); }
+#undef MX_EQ_CASE
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rec->end[k] = s.lo[k]; rec->end[4 + k] = s.hi[k]; }
+    rec->xmin = xmin; rec->xmax = xmax;
+}
+
+// ---- repair ----
+__device__ __forceinline__ bool same8(const double (&a)[8], const double* b) {
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) eq = eq && (__double_as_longlong(a[k]) == __double_as_longlong(b[k]));
+    return eq;
+}
+struct Dual { double lo[4], hi[4]; };
+__device__ __forceinline__ void dual_load(Dual& s, const double* p) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.lo[k] = p[k]; s.hi[k] = p[4 + k]; }
+}
+__device__ __forceinline__ bool dual_same(const Dual& a, const Dual& b) {
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) eq = eq && __double_as_longlong(a.lo[k]) == __double_as_longlong(b.lo[k]) && __double_as_longlong(a.hi[k]) == __double_as_longlong(b.hi[k]);
+    return eq;
+}
+// does one sample of input x leave the state where it is?  (then every further sample of the same x does, too)
+__device__ __forceinline__ bool dual_stuck(const Dual& s, double lo_f, double hi_f, double x) {
+    Dual n = s;
+    pump(lo_f, n.lo, x); pump(hi_f, n.hi, x);
+    return dual_same(n, s);
+}
+// the EQ's f32 for a state that one more sample of the input has ALREADY been pumped into (eq_three.rs:70-85)
+__device__ __forceinline__ float eq_out_of(const Dual& s, double h0, double g_lo, double g_mid, double g_hi) {
+    const double l = s.lo[3];
+    const double h = h0 - s.hi[3];
+    const double mid = h0 - (h + l);
+    return (float)(l * g_lo + mid * g_mid + h * g_hi);
+}
+
+// One wave per instance.  First every boundary is checked in parallel against the SPECULATIVE end state of the chunk before
+// it: if all of them match, induction from chunk 0 (which started from the carried state) proves the whole stream.  Otherwise
+// lane 0 walks on from the first mismatch with the proven state in hand.
+__global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+                                                         const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats) {
+    const uint32_t inst = blockIdx.x;
+    const int lane = threadIdx.x;
+    const EqDesc& d = descs[inst];
+    const EqChunkRec* rc = recs + (size_t)inst * plan.n_chunks;
+    const size_t C = plan.chunk;
+    uint32_t first_fail = plan.n_chunks;
+    for (uint32_t j0 = 1; j0 < plan.n_chunks; j0 += 64) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        bool ok = true;
+        if (j < plan.n_chunks) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ok = ok && __double_as_longlong(rc[j].start[k]) == __double_as_longlong(rc[j - 1].end[k]);
+        }
+        const uint64_t bad = __ballot(!ok);
+        if (bad) { first_fail = j0 + (uint32_t)__builtin_ctzll(bad); break; }
+    }
+    if (lane != 0) return;
+    double E[8];                                   // proven state at the end of the chunks walked so far
+    unsigned long long repaired = 0;
+    if (first_fail == plan.n_chunks) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) E[k] = rc[plan.n_chunks - 1].end[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) E[k] = rc[first_fail - 1].end[k];
+    }
+    for (uint32_t j = first_fail; j < plan.n_chunks; ++j) {
+        const EqChunkRec& R = rc[j];
+        if (same8(E, R.start)) {                   // the speculative chunk started from the true state: everything it wrote is exact
+#pragma unroll
+            for (int k = 0; k < 8; ++k) E[k] = R.end[k];
+            continue;
+        }
+        ++repaired;
+        const size_t begin = (size_t)j * C;
+        const size_t len = r.frames - begin < C ? r.frames - begin : C;
+        Dual A, B;                                 // A: from the proven state (the sequential order); B: the trajectory the chunk's lane ran
+        dual_load(A, E); dual_load(B, R.start);
+        double h0 = (double)d.in[begin - 3], h1 = (double)d.in[begin - 2], h2 = (double)d.in[begin - 1];
+        if (R.xmin == R.xmax) {
+            // constant input over the whole chunk (digital silence, DC): if both trajectories already stand still under it, the
+            // chunk's f32 outputs are a function of (state, delay-line value) only -- compare them for the four delay-line values
+            // the chunk sees; equal => what the lane wrote is the sequential order's, and the proven state stays where it is
+            const double xc = (double)__uint_as_float(R.xmin);
+            if (dual_stuck(A, r.lo_f, r.hi_f, xc) && dual_stuck(B, r.lo_f, r.hi_f, xc)) {
+                bool same = true;
+                const double hv[4] = {h0, h1, h2, xc};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    same = same && __float_as_uint(eq_out_of(A, hv[q], d.gain_lo, d.gain_mid, d.gain_hi)) == __float_as_uint(eq_out_of(B, hv[q], d.gain_lo, d.gain_mid, d.gain_hi));
+                if (same) continue;                // E unchanged: the state stands still through the chunk
+            }
+        }
+        // general case: both trajectories sample by sample; rewrite the outputs whose f32 differs; stop when they coalesce
+        EqSeqEmit em;
+        em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
+        em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
+        bool coalesced = false, stuckA = false, stuckB = false;
+        uint32_t prev_bits = 0; bool have_prev = false;
+        for (size_t i = 0; i < len; ++i) {
+            const float xf = d.in[begin + i];
+            const double x = (double)xf;
+            const bool rep = have_prev && __float_as_uint(xf) == prev_bits;     // same input as the previous sample
+            prev_bits = __float_as_uint(xf); have_prev = true;
+            if (!(rep && stuckA)) { const Dual o = A; pump(r.lo_f, A.lo, x); pump(r.hi_f, A.hi, x); stuckA = rep && dual_same(o, A); }
+            if (!(rep && stuckB)) { const Dual o = B; pump(r.lo_f, B.lo, x); pump(r.hi_f, B.hi, x); stuckB = rep && dual_same(o, B); }
+            const float ya = eq_out_of(A, h0, d.gain_lo, d.gain_mid, d.gain_hi), yb = eq_out_of(B, h0, d.gain_lo, d.gain_mid, d.gain_hi);
+            h0 = h1; h1 = h2; h2 = x;
+            if (__float_as_uint(ya) != __float_as_uint(yb)) { em.seek(begin + i); em.emit(begin + i, ya); }
+            if (dual_same(A, B)) { coalesced = true; break; }                   // from here on the lane's run IS the sequential order
+        }
+        if (coalesced) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) E[k] = R.end[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { E[k] = A.lo[k]; E[4 + k] = A.hi[k]; }
+        }
+    }
+    // the carried state (eq_three.rs:17-22): poles after the last sample, delay line = the last three inputs
+    EqState st = states[inst];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { st.lo[k] = E[k]; st.hi[k] = E[4 + k]; }
+    const size_t F = r.frames;
+    st.history[0] = (double)d.in[F - 3]; st.history[1] = (double)d.in[F - 2]; st.history[2] = (double)d.in[F - 1];   // F >= 2 warm-ups >= 3 samples
+    states[inst] = st;
+    if (stats) { atomicAdd(&stats[0], (unsigned long long)plan.n_chunks); if (repaired) atomicAdd(&stats[1], repaired); }
+}
+
+// warm-up length: the 4-pole cascade's response to a unit difference k samples back is at most C(k+3,3) p^k (p = 1 - f); W is
+// the first multiple of 128 where that is below 2^-72 -- twenty bits under the f64 ulp of a full-scale state, so that two
+// trajectories are within rounding of each other and coalesce (measured: 0 mismatching boundaries from W = 1024 at 48 kHz
+// on every live signal tried, all of them at W = 768).  A longer W only costs time; a shorter one only costs repairs.
+static size_t eq_warm_len(double f) {
+    const long double p = 1.0L - (long double)f;
+    if (!(p > 0.0L) || !(p < 1.0L)) return 128;
+    const long double lim = ldexpl(1.0L, -72);
+    for (size_t K = 128; K <= ((size_t)1 << 22); K += 128) {
+        const long double c = (long double)(K + 3) * (long double)(K + 2) * (long double)(K + 1) / 6.0L;
+        if (c * expl((long double)K * logl(p)) < lim) return K;
+    }
+    return (size_t)-1;
+}
+
+bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPlan& plan) {
+    plan = EqSpecPlan{1u, 0u, 0u, 0u};
+    if (!n || !frames) return false;
+    size_t W = std::max(eq_warm_len(lo_f), eq_warm_len(hi_f));
+    const int force_w = env_int("MX_EQ_SPEC_WARM", 0);       // tests: a short warm-up makes every boundary fail and the repair pass do all the work
+    if (force_w > 0) W = ((size_t)force_w + 15) / 16 * 16;
+    if (W == (size_t)-1) return false;
+    const int force_c = env_int("MX_EQ_SPEC_CHUNKS", 0);     // tuning / tests: chunks per instance (1 = never speculate)
+    if (force_c == 1) return false;
+    if (frames < 2 * W || frames < 64) return false;          // a stream shorter than two warm-ups: one lane per instance
+    // Cost model (cycles, per SIMD): a wave issues one f64 instruction per 4 cycles and a chunk lane needs ~45 of them per
+    // sample, so a wave takes (C + W) * 180 cycles whether 1 or 64 of its lanes are active; waves queue on 1024 SIMDs.
+    // One lane per instance (no speculation) is a dependent chain of ~110 cycles per sample, 64 instances per wave.
+    const double c_issue = 180.0, c_lat = 110.0, simds = 1024.0;
+    auto cost = [&](size_t nc) {
+        const size_t C = ((frames + nc - 1) / nc + 31) / 32 * 32;
+        const double waves = (double)n * (double)((nc + 63) / 64);
+        const double per_simd = std::ceil(waves / simds);
+        return (double)(C + W) * std::max(c_lat, c_issue * per_simd);
+    };
+    size_t best = 1; double best_cost = (double)frames * c_lat * std::ceil((double)((n + 63) / 64) / simds);
+    const size_t nc_max = frames / W;                          // C >= W: a warm-up never reaches before the stream
+    if (force_c > 1) best = std::min<size_t>((size_t)force_c, nc_max);
+    else {
+        for (size_t nc = 2; nc <= nc_max && nc <= 4096; nc = nc < 64 ? nc + 1 : nc + 64) {
+            const double c = cost(nc);
+            if (c < best_cost * 0.999) { best_cost = c; best = nc; }
+        }
+    }
+    if (best < 2) return false;
+    size_t C = ((frames + best - 1) / best + 31) / 32 * 32;
+    if (C < W) C = (W + 31) / 32 * 32;
+    plan.chunk = (uint32_t)C; plan.warm = (uint32_t)W;
+    plan.n_chunks = (uint32_t)((frames + C - 1) / C);
+    return plan.n_chunks >= 2;
+}
+
+size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan) { return (size_t)n * plan.n_chunks * sizeof(EqChunkRec); }
+
+void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, void* scratch, uint64_t* stats, hipStream_t s) {
+    if (!n || !r.frames) return;
+    const uint32_t wpi = (plan.n_chunks + 63) / 64;
+    EqChunkRec* recs = (EqChunkRec*)scratch;
+    hipLaunchKernelGGL(k_eq_three_spec, dim3(n * wpi), dim3(64), 0, s, d, (const EqState*)st, r, plan, wpi, recs);
+    hipLaunchKernelGGL(k_eq_three_repair, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
+}
+
+}  // namespace mx

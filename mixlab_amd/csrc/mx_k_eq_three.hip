@@ -1,103 +1,19 @@
-// mx_k_eq_three.hip -- EqThree (reference src/module/eq_three.rs:58-89,100-125): the exact sequential
-// kernel and the time-parallel chunked scan, both with the graph compiler's fused epilogue.
+// mx_k_eq_three.hip -- EqThree, the opt-in FAST mode (MX_FLAG_EQ_FAST): time-parallel chunked scan with the graph compiler's
+// fused epilogue.  NOT bit-exact: f32 outputs within 1 ULP of the reference order (src/module/eq_three.rs:58-89), about one
+// sample in 20 000 differs.  The default, exact-order kernels are in mx_k_eq_exact.hip.
 //
 // Build with -ffp-contract=off: the reference (Rust) evaluates every f64 expression as written,
-// never fused; the exact recurrence below must not become v_fma_f64.  Explicit fma() calls appear
+// never fused; the recurrence in phase C must not become v_fma_f64.  Explicit fma() calls appear
 // only in the scan's helper arithmetic, whose rounding is free by construction.
 #include <algorithm>
 #include <cmath>
 
-#include "mx_dev.hpp"
-#include "mx_env_math.hpp"
+#include "mx_k_eq_common.hpp"
 
 namespace mx {
 
-#define MX_VSA (1.0 / 4294967295.0)   /* eq_three.rs:11 */
-
-// Fused epilogue (see EqDesc): what StereoPanner (stereo_panner.rs:35-38), Amplifier
-// (amplifier.rs:52-57,71-73) and -- with MX_EQF_ENV -- the Envelope feeding its control
-// (envelope.rs:34-58,117) would do to the f32 sample y the EQ just produced.
-struct EnvCtx { uint32_t tag; uint64_t seq; double off_amp; uint64_t t0; double sr, rsr; };
-
-__device__ __forceinline__ EnvCtx env_ctx_begin(const EqDesc& d, const EnvState* es, uint64_t t0, double sr, double rsr) {
-    EnvCtx ec{0u, 0ull, 0.0, t0, sr, rsr};
-    if (d.flags & MX_EQF_ENV) {
-        ec.tag = es->tag; ec.seq = es->seq; ec.off_amp = es->off_amplitude;
-        env_const_gate_step(d.env, d.env_gate, t0, sr, rsr, ec.tag, ec.seq, ec.off_amp);   // only the run's first sample can flip it
-    }
-    return ec;
-}
-__device__ __forceinline__ void env_ctx_end(const EqDesc& d, const EnvCtx& ec) {
-    if (d.flags & MX_EQF_ENV) { d.env_state->tag = ec.tag; d.env_state->seq = ec.seq; d.env_state->off_amplitude = ec.off_amp; }
-}
-__device__ __forceinline__ void eq_store(const EqDesc& d, size_t i, float v) {
-    if (d.epi == 0u || (d.flags & MX_EQF_MONO_DUP)) d.out[i] = v;                     // one float per frame
-    else reinterpret_cast<float2*>(d.out)[i] = make_float2(v, v);                    // stereo_panner.rs:35-38
-}
-__device__ __forceinline__ float eq_amp(const EqDesc& d, float y, bool has_ctl, float c) {
-    const double m = has_ctl ? (double)c : 1.0;                                       // amplifier.rs:54
-    const double depth = d.amp_one_minus + d.amp_mod_depth * m;                       // amplifier.rs:71-73
-    return (float)((double)y * depth * d.amp_amplitude);                              // amplifier.rs:56
-}
-__device__ __forceinline__ void eq_emit(const EqDesc& d, const EnvCtx& ec, size_t i, float y) {
-    float v = y;
-    if (d.epi == 2u) {
-        if (d.flags & MX_EQF_ENV) v = eq_amp(d, y, true, (float)env_amplitude(d.env, ec.tag, ec.seq, ec.off_amp, ec.t0 + i, ec.sr, ec.rsr));   // Envelope stores f32 (envelope.rs:117)
-        else v = eq_amp(d, y, d.ctl != nullptr, d.ctl ? d.ctl[i] : 0.f);
-    }
-    eq_store(d, i, v);
-}
-
-// what the scan kernel's stage-out needs, parked in LDS by lane 0 (see k_eq_three_scan)
-struct EqEpi {
-    float* out; const float* ctl; double amp_one_minus, amp_mod_depth, amp_amplitude;
-    EnvParams env; double off_amp; uint64_t seq; uint32_t tag, epi, flags, pad;
-};
-
-// LowPass::pump, eq_three.rs:117-124 -- exact order
-__device__ __forceinline__ double pump(const double f, double (&p)[4], const double sample) {
-    p[0] += f * (sample - p[0]) + MX_VSA;
-    p[1] += f * (p[0] - p[1]);
-    p[2] += f * (p[1] - p[2]);
-    p[3] += f * (p[2] - p[3]);
-    return p[3];
-}
-
 // ---------------------------------------------------------------------------------------------
-// exact order: one lane per instance walks its stream sequentially; bit-exact against the
-// reference's golden pair.  f64-VALU latency bound; selected by MX_FLAG_EQ_EXACT.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
-                                                        uint32_t n_inst, size_t frames, uint64_t t0, double sr, double rsr,
-                                                        double lo_f, double hi_f) {
-    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
-    if (inst >= n_inst) return;
-    const EqDesc d = descs[inst];
-    const EnvCtx ec = env_ctx_begin(d, d.env_state, t0, sr, rsr);
-    EqState st = states[inst];
-    double lo[4] = {st.lo[0], st.lo[1], st.lo[2], st.lo[3]};
-    double hi[4] = {st.hi[0], st.hi[1], st.hi[2], st.hi[3]};
-    double h0 = st.history[0], h1 = st.history[1], h2 = st.history[2];
-    for (size_t i = 0; i < frames; ++i) {
-        const double sample = d.in ? (double)d.in[i] : 0.0;
-        const double l = pump(lo_f, lo, sample);
-        const double h = h0 - pump(hi_f, hi, sample);
-        const double mid = h0 - (h + l);
-        h0 = h1; h1 = h2; h2 = sample;
-        eq_emit(d, ec, i, (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi));
-    }
-    for (int k = 0; k < 4; ++k) { st.lo[k] = lo[k]; st.hi[k] = hi[k]; }
-    st.history[0] = h0; st.history[1] = h1; st.history[2] = h2;
-    states[inst] = st;
-    env_ctx_end(d, ec);
-}
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f, hipStream_t s) {
-    if (!n || !frames) return;
-    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, frames, t0, sample_rate, 1.0 / sample_rate, lo_f, hi_f);
-}
-
-// ---------------------------------------------------------------------------------------------
-// time-parallel (default).  The two 4-pole cascades are affine recurrences
+// time-parallel.  The two 4-pole cascades are affine recurrences
 //   s[n+1] = A s[n] + b x[n] + c ,  A = lower-triangular Toeplitz with first column f^k (1-f),
 //   b = (f, f^2, f^3, f^4), c = VSA (1, f, f^2, f^3)
 // so a stream can be cut into chunks that are processed concurrently:
@@ -142,7 +58,7 @@ __device__ __forceinline__ void toep_apply(const double* c, const double (&v)[4]
 //          before it into the true state at the span start: S_0 = carried, S_{s+1} = A^span S_s + Z_s.
 struct EqSegCtx {
     float* tile; double* wtot; double* carry; double* pw; double* p2; const EqEpi* epi;
-    const float* din; double g_lo, g_mid, g_hi, lo_f, hi_f, sr, rsr; uint64_t t0; bool stream_out;
+    const float* din; double g_lo, g_mid, g_hi, lo_f, hi_f, sr, rsr; uint64_t t0; size_t fpc; bool stream_out;
 };
 
 template <int LOG2L>
@@ -320,27 +236,20 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
                 const int e = tid + NT * k;
                 if (e < nv) store(e, tile[swz(e)]);
             }
-        } else if (E.flags & MX_EQF_ENV) {                   // ... -> Amplifier with the Envelope evaluated inline
-            const uint64_t tl = t0 + base + tid;             // this lane's earliest sample time in the segment
-            if (tid < nv && env_saturated(E.env, E.tag, E.seq, tl, sr, rsr)) {
-                // already flat (sustain reached, release finished or never triggered): one constant control for all
-                // L samples of the lane -- the steady state of a held gate
-                const float cc = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, tl, sr, rsr);   // Envelope stores f32 (envelope.rs:117)
-                const double depth = E.amp_one_minus + E.amp_mod_depth * (double)cc;               // amplifier.rs:71-73
-#pragma unroll 4
-                for (int k = 0; k < L; ++k) {
-                    const int e = tid + NT * k;
-                    if (e < nv) store(e, amp(tile[swz(e)], depth));
+        } else if (E.flags & MX_EQF_ENV) {                   // ... -> Amplifier with the Envelope evaluated inline from its per-tick states
+            const size_t fpc = c.fpc;
+            const size_t i0 = base + (size_t)tid;            // my first sample of the segment (run-relative)
+            uint32_t call = (uint32_t)(i0 / fpc); size_t rem = i0 % fpc;
+            uint32_t have = 0xffffffffu; EnvTick cur{};
+#pragma unroll 2
+            for (int k = 0; k < L; ++k) {
+                const int e = tid + NT * k;
+                if (e < nv) {
+                    if (call != have) { cur = E.ticks[call]; have = call; }
+                    store(e, amp(tile[swz(e)], env_depth(E.env, cur, E.amp_one_minus, E.amp_mod_depth, t0 + base + e, sr, rsr)));
                 }
-            } else {
-#pragma unroll 4
-                for (int k = 0; k < L; ++k) {
-                    const int e = tid + NT * k;
-                    if (e < nv) {
-                        const float cc = (float)env_amplitude(E.env, E.tag, E.seq, E.off_amp, t0 + base + e, sr, rsr);
-                        store(e, amp(tile[swz(e)], E.amp_one_minus + E.amp_mod_depth * (double)cc));
-                    }
-                }
+                rem += NT;
+                while (rem >= fpc) { rem -= fpc; ++call; }
             }
         } else if (E.ctl) {                                  // ... -> Amplifier, control from a buffer: bursts of <= 16 loads first
             constexpr int CB = L > 16 ? 16 : L;
@@ -371,9 +280,9 @@ __device__ __forceinline__ void eq_segment(const EqSegCtx& c, const EqScanTab* _
 }
 
 template <int LOG2L, int MODE>
-__global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restrict__ descs, EqState* __restrict__ states,
-                                                           size_t frames, uint64_t t0, double sr, double rsr, double lo_f, double hi_f,
+__global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r,
                                                            const EqScanTab* __restrict__ tabs /* L = 4, 8, 16, 32 */, EqSplit sp, EqSpanPow pp) {
+    const size_t frames = r.frames;
     constexpr int L = 1 << LOG2L;
     constexpr int SEG = 256 * L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -385,7 +294,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     c.p2 = c.pw + 2 * 65 * 4;                                                       // [2][6][4]  A^(L 2^k)
     EqEpi* epi_lds = reinterpret_cast<EqEpi*>(c.p2 + 2 * 6 * 4);                    // fused-epilogue parameters
     c.epi = epi_lds;
-    c.lo_f = lo_f; c.hi_f = hi_f; c.sr = sr; c.rsr = rsr; c.t0 = t0; c.stream_out = sp.stream_out != 0;
+    c.lo_f = r.lo_f; c.hi_f = r.hi_f; c.sr = r.sr; c.rsr = r.rsr; c.t0 = r.t0; c.fpc = r.fpc; c.stream_out = sp.stream_out != 0;
 
     const int tid = threadIdx.x;
     // Only what the inner phases need stays in registers; everything the epilogue needs (Amplifier and inline
@@ -395,17 +304,9 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     c.din = dp->in;
     c.g_lo = dp->gain_lo; c.g_mid = dp->gain_mid; c.g_hi = dp->gain_hi;
     const uint32_t span_idx = MODE == 0 ? 0u : blockIdx.y;
-    if (MODE != 1 && tid == 0) {
-        const EqDesc d = *dp;
-        const EnvCtx ec = env_ctx_begin(d, MODE == 2 ? sp.env_snap + blockIdx.x : d.env_state, t0, sr, rsr);
-        EqEpi e;
-        e.out = d.out; e.ctl = d.ctl; e.amp_one_minus = d.amp_one_minus; e.amp_mod_depth = d.amp_mod_depth; e.amp_amplitude = d.amp_amplitude;
-        e.env = d.env; e.off_amp = ec.off_amp; e.seq = ec.seq; e.tag = ec.tag; e.epi = d.epi; e.flags = d.flags;
-        *epi_lds = e;
-    }
+    if (MODE != 1 && tid == 0) *epi_lds = eq_epi_of(*dp, r.ticks ? r.ticks + (size_t)blockIdx.x * r.n_calls : nullptr);
     if (MODE == 1 && span_idx == 0) {   // snapshot of the carried state for the main pass (which overwrites it)
         if (tid < 11) sp.bound[(size_t)blockIdx.x * 12 + tid] = reinterpret_cast<const double*>(&states[blockIdx.x])[tid];
-        if (tid == 11 && (dp->flags & MX_EQF_ENV)) sp.env_snap[blockIdx.x] = *dp->env_state;
     }
     // tables and the carried state live in LDS, not in registers, across the segment loop
     eq_load_tables<LOG2L>(c, tabs, tid);
@@ -465,10 +366,6 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
     }
     if (MODE == 2 && span_idx + 1 != sp.n_split) return;   // only the last span owns the carried state
     if (tid < 11) reinterpret_cast<double*>(&states[blockIdx.x])[tid] = c.carry[tid];
-    if (tid == 0 && (epi_lds->flags & MX_EQF_ENV)) {
-        EnvState* es = dp->env_state;
-        es->tag = epi_lds->tag; es->seq = epi_lds->seq; es->off_amplitude = epi_lds->off_amp;
-    }
 }
 
 // Short streams (the real-time mode: one tick of 800 samples per instance): a 256-thread workgroup per instance is mostly
@@ -476,9 +373,9 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_scan(const EqDesc* __restri
 // Here one WAVE owns an instance (64 chunks of L samples per segment, the wave scan is the whole scan) and a workgroup
 // carries four instances that share the tables.  Same arithmetic, same eq_segment.
 template <int LOG2L>
-__global__ __launch_bounds__(256, 4) void k_eq_three_wave(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst,
-                                                           size_t frames, uint64_t t0, double sr, double rsr, double lo_f, double hi_f,
+__global__ __launch_bounds__(256, 4) void k_eq_three_wave(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r,
                                                            const EqScanTab* __restrict__ tabs) {
+    const size_t frames = r.frames;
     constexpr int L = 1 << LOG2L;
     constexpr int SEG = 64 * L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -494,20 +391,13 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_wave(const EqDesc* __restri
     c.wtot = nullptr; c.pw = pw; c.p2 = p2;
     EqEpi* epi_lds = reinterpret_cast<EqEpi*>(c.carry + 12);
     c.epi = epi_lds;
-    c.lo_f = lo_f; c.hi_f = hi_f; c.sr = sr; c.rsr = rsr; c.t0 = t0; c.stream_out = false;
+    c.lo_f = r.lo_f; c.hi_f = r.hi_f; c.sr = r.sr; c.rsr = r.rsr; c.t0 = r.t0; c.fpc = r.fpc; c.stream_out = false;
     // a workgroup past the end re-does the last instance (identical values written twice) so that every wave reaches every barrier
     const uint32_t inst = min(blockIdx.x * 4u + (uint32_t)wv, n_inst - 1);
     const EqDesc* dp = descs + inst;
     c.din = dp->in;
     c.g_lo = dp->gain_lo; c.g_mid = dp->gain_mid; c.g_hi = dp->gain_hi;
-    if (lane == 0) {
-        const EqDesc d = *dp;
-        const EnvCtx ec = env_ctx_begin(d, d.env_state, t0, sr, rsr);
-        EqEpi e;
-        e.out = d.out; e.ctl = d.ctl; e.amp_one_minus = d.amp_one_minus; e.amp_mod_depth = d.amp_mod_depth; e.amp_amplitude = d.amp_amplitude;
-        e.env = d.env; e.off_amp = ec.off_amp; e.seq = ec.seq; e.tag = ec.tag; e.epi = d.epi; e.flags = d.flags;
-        *epi_lds = e;
-    }
+    if (lane == 0) *epi_lds = eq_epi_of(*dp, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
     eq_load_tables<LOG2L>(c, tabs, (int)threadIdx.x);
     if (lane < 11) c.carry[lane] = reinterpret_cast<const double*>(&states[inst])[lane];   // lo[4] hi[4] history[3]
     __syncthreads();
@@ -516,10 +406,6 @@ __global__ __launch_bounds__(256, 4) void k_eq_three_wave(const EqDesc* __restri
         eq_segment<LOG2L, 0, 1>(c, tabs, base, rem < (size_t)SEG ? (int)rem : SEG);
     }
     if (lane < 11) reinterpret_cast<double*>(&states[inst])[lane] = c.carry[lane];
-    if (lane == 0 && (epi_lds->flags & MX_EQF_ENV)) {
-        EnvState* es = dp->env_state;
-        es->tag = epi_lds->tag; es->seq = epi_lds->seq; es->off_amplitude = epi_lds->off_amp;
-    }
 }
 
 int eq_scan_log2l(size_t frames) {
@@ -529,14 +415,14 @@ int eq_scan_log2l(size_t frames) {
     return 5;
 }
 
-void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
+void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r,
                           const EqScanTab* tabs /* indexed by log2L - 2 */, const EqSplit& split_in, const EqSpanPow& pp, hipStream_t s) {
+    const size_t frames = r.frames;
     if (!n || !frames) return;
     EqSplit split = split_in;
     split.stream_out = (uint64_t)n * frames * sizeof(float) > (64ull << 20) ? 1u : 0u;   // beyond what L2 + Infinity Cache keep for the consumer
     int l2 = eq_scan_log2l(split.n_split > 1 ? split.span : frames);
-    const double rsr = 1.0 / sample_rate;
-#define MX_EQ_GO(L2, MODE, GRID) hipLaunchKernelGGL((k_eq_three_scan<L2, MODE>), GRID, dim3(256), lds, s, d, st, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs, split, pp)
+#define MX_EQ_GO(L2, MODE, GRID) hipLaunchKernelGGL((k_eq_three_scan<L2, MODE>), GRID, dim3(256), lds, s, d, st, r, tabs, split, pp)
 #define MX_EQ_MODE(MODE, GRID) { \
         const size_t lds = (size_t)256 * (1u << l2) * sizeof(float) + (32 + 12 + 2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + sizeof(EqEpi); \
         switch (l2) { case 2: MX_EQ_GO(2, MODE, GRID); break; case 3: MX_EQ_GO(3, MODE, GRID); break; case 4: MX_EQ_GO(4, MODE, GRID); break; default: MX_EQ_GO(5, MODE, GRID); break; } }
@@ -548,10 +434,10 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frame
         const size_t lds = (2 * 65 * 4 + 2 * 6 * 4) * sizeof(double) + 4 * per;
         const dim3 g((n + 3) / 4);
         switch (lw) {
-        case 2: hipLaunchKernelGGL(k_eq_three_wave<2>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
-        case 3: hipLaunchKernelGGL(k_eq_three_wave<3>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
-        case 4: hipLaunchKernelGGL(k_eq_three_wave<4>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
-        default: hipLaunchKernelGGL(k_eq_three_wave<5>, g, dim3(256), lds, s, d, st, n, frames, t0, sample_rate, rsr, lo_f, hi_f, tabs); break;
+        case 2: hipLaunchKernelGGL(k_eq_three_wave<2>, g, dim3(256), lds, s, d, st, n, r, tabs); break;
+        case 3: hipLaunchKernelGGL(k_eq_three_wave<3>, g, dim3(256), lds, s, d, st, n, r, tabs); break;
+        case 4: hipLaunchKernelGGL(k_eq_three_wave<4>, g, dim3(256), lds, s, d, st, n, r, tabs); break;
+        default: hipLaunchKernelGGL(k_eq_three_wave<5>, g, dim3(256), lds, s, d, st, n, r, tabs); break;
         }
     } else if (split.n_split <= 1) {
         MX_EQ_MODE(0, dim3(n));

@@ -127,8 +127,19 @@ __global__ __launch_bounds__(256) void k_trigger(const TrigDesc* __restrict__ de
     const float4 v = make_float4(d.value, d.value, d.value, d.value);
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) st4(d.out, q, frames, v);
 }
-void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+// a Trigger whose params change at tick boundaries inside the run (Engine::client_update between two ticks, src/engine.rs:192-214):
+// sample i carries the gate of tick i / fpc
+__global__ __launch_bounds__(256) void k_trigger_sched(const TrigDesc* __restrict__ descs, size_t frames, size_t fpc, GateBits gates) {
+    const TrigDesc d = descs[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256)
+        d.out[i] = gate_bit(gates, blockIdx.y, (uint32_t)(i / fpc)) ? 1.0f : 0.0f;   // trigger.rs:38-41
+}
+void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, size_t fpc, const GateBits* gates, hipStream_t s) {
     if (!n || !frames) return;
+    if (gates) {
+        hipLaunchKernelGGL(k_trigger_sched, dim3(grid_x(frames, 256, 2048), n), dim3(256), 0, s, d, frames, fpc ? fpc : frames, *gates);
+        return;
+    }
     dim3 grid(grid_x((frames + 3) / 4, 256, 2048), n);
     hipLaunchKernelGGL(k_trigger, grid, dim3(256), 0, s, d, frames);
 }

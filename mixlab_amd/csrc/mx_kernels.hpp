@@ -18,10 +18,28 @@ struct AmpDesc { const float* in; const float* ctl; /* nullptr => Disconnected =
 struct EnvParams { double attack_ms, inv_attack, inv_decay, sustain, one_minus_sustain, inv_release; };
 struct EnvDesc {
     const float* gate; float* out;
-    float gate_const; uint32_t use_const;   // gate is a Trigger fused in: constant 1.0 / 0.0, no buffer (trigger.rs:38-41)
+    float gate_const; uint32_t use_const;   // 1: gate is a Trigger fused in: constant 1.0 / 0.0, no buffer (trigger.rs:38-41)
+                                            // 2: ... whose params change at tick boundaries inside this run: one bit per tick (GateBits)
     EnvParams p;
 };
 struct EnvState { uint32_t tag; uint32_t pad; uint64_t seq; double off_amplitude; };  // EnvelopeState, envelope.rs:8-13
+
+// Per-tick parameter schedule of a Trigger (Engine::client_update between two ticks, src/engine.rs:192-214,277-398, applied
+// inside one submission): bit c of an instance's row = gate_open during tick c of the run.  Rows are `words` u32 long,
+// instance i of a launch group reads row i; `call_off` = first tick of this launch inside the run.
+struct GateBits { const uint32_t* bits; uint32_t words; uint32_t call_off; };
+__host__ __device__ inline bool gate_bit(const GateBits& g, uint32_t inst, uint32_t call) {
+    const uint32_t c = g.call_off + call;
+    return (g.bits[(size_t)inst * g.words + (c >> 5)] >> (c & 31)) & 1u;
+}
+
+// State of an Envelope whose gate is such a Trigger, as it ENTERS each tick of the run (k_env_ticks): with a gate that is
+// constant over a tick only the tick's first sample can change the state (envelope.rs:99-115), so the EqThree kernels'
+// fused epilogue reads one entry per tick and evaluates the closed form (envelope.rs:34-58) per sample from it.
+//   flat: the amplitude no longer changes from this tick's first sample on (Initial, sustain reached, release finished):
+//   `depth` = the Amplifier's depth() for that constant control (amplifier.rs:71-73), hoisted.
+struct EnvTick { uint64_t seq; double off_amp; double depth; uint32_t tag; uint32_t flat; };
+struct EnvTickDesc { EnvParams p; double amp_one_minus, amp_mod_depth; EnvState* state; };
 
 // src/module/eq_three.rs:58-89
 // epi: fused epilogue chosen by the graph compiler (mx_engine.cpp plan_fusion):
@@ -38,7 +56,7 @@ enum { MX_EQF_MONO_DUP = 1u, MX_EQF_ENV = 2u };
 struct EqDesc {
     const float* in; float* out; double gain_lo, gain_mid, gain_hi;
     const float* ctl; double amp_one_minus, amp_mod_depth, amp_amplitude; uint32_t epi; uint32_t flags;
-    EnvParams env; EnvState* env_state; float env_gate; uint32_t pad;
+    EnvParams env;   // MX_EQF_ENV: the folded Envelope's parameters; its per-tick states come from k_env_ticks (EnvTick table)
 };
 struct EqState { double lo[4]; double hi[4]; double history[3]; double pad; };       // eq_three.rs:13-26,100-103
 
@@ -68,7 +86,7 @@ struct PanDesc { const float* l; const float* r; float* out; };
 struct SplitDesc { const float* in; float* l; float* r; };
 
 // src/module/trigger.rs:35-48
-struct TrigDesc { float* out; float value; uint32_t pad; };
+struct TrigDesc { float* out; float value; uint32_t pad; };   // a scheduled run reads GateBits instead of `value`
 
 // src/module/plotter.rs:37-56: de-interleave the fired ticks into a staging area
 struct PlotJob { const float* in; float* left; float* right; };
@@ -80,11 +98,21 @@ struct ResampleDesc { const float* in; float* out; const double* taps /* [up][ta
 
 // Launchers.  `frames` = mono samples in this run (= n_ticks * SPT); stereo buffers hold 2*frames.
 void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s);
-void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f, hipStream_t s);
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s);
+// per-tick Envelope states of the folded Envelopes of an EqThree group: ticks[inst][call], `n_calls` ticks of `fpc` samples from t0
+void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s);
+// what every EqThree launch needs beyond the descriptors: the per-tick Envelope table (null when no instance folds one)
+struct EqRun { size_t frames; size_t fpc /* samples per tick (call) */; uint32_t n_calls; uint32_t pad; uint64_t t0; double sr, rsr /* RN(1 / sr), host */, lo_f, hi_f; const EnvTick* ticks /* [n][n_calls] */; };
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s);
 int eq_scan_log2l(size_t frames);
-void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, size_t frames, uint64_t t0, double sample_rate, double lo_f, double hi_f,
+void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r,
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s);
+// speculative time-parallel EXACT mode (k_eq_three_spec + k_eq_three_repair): see mx_k_eq_three.hip
+struct EqSpecPlan { uint32_t n_chunks; uint32_t chunk; uint32_t warm; uint32_t pad; };
+bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPlan& plan);   // false: one lane per instance (launch_eq_three_exact)
+size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan);
+void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, void* scratch,
+                          uint64_t* stats /* [2]: chunks run, chunks repaired */, hipStream_t s);
 void eq_plan_split(uint32_t n, size_t frames, double lo_f, double hi_f, EqSplit& sp);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch /* most channels of any mixer in the group */, size_t frames,
@@ -92,7 +120,7 @@ void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch /* most channels
 void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s);
-void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, hipStream_t s);
+void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, size_t fpc, const GateBits* gates /* null: constant per instance */, hipStream_t s);
 void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s);
 void launch_f32_to_i16(const float* in, int16_t* out, size_t n, int dup, hipStream_t s);
 void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s);

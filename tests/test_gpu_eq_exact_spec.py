@@ -1,0 +1,188 @@
+"""The default EqThree path on long streams: the SPECULATIVE time-parallel form (k_eq_three_spec) and the pass that proves it
+bit-exact chunk by chunk (k_eq_three_repair) -- mixlab_amd/csrc/mx_k_eq_exact.hip.
+
+Every case is compared bit for bit with the oracle's sequential order (src/module/eq_three.rs:58-89), which is pinned on the
+reference's golden pair.  Besides plain noise the cases aim at the verification pass itself:
+
+* a warm-up forced far too short (MX_EQ_SPEC_WARM) makes EVERY chunk boundary fail -- the repair pass then re-derives the
+  whole stream and the result must still be the sequential order's;
+* digital silence / DC after a signal (the poles stall a few ulps from the fixed point, on the side they came from) is the
+  input class on which speculation really fails: repairs are counted and the output is still exact;
+* NaN / infinity bursts poison the poles of the sequential filter for ever: the speculative lanes after the burst never see
+  it, the repair pass must.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from mixlab_amd.workspace import Workspace
+from test_gpu_audio_parity import RATES, assert_bit_exact, bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_graph(sr, gains_list, T, flags=0):
+    ws = Workspace(sr, 60)
+    srcs, eqs = [], []
+    for g3 in gains_list:
+        s = ws.source_mono(); e = ws.eq_three(*g3)
+        ws.connect(s, 0, e, 0); srcs.append(s); eqs.append(e)
+    return ws, srcs, eqs, ws.build(max_ticks_per_run=T, flags=flags)
+
+
+def _gains(n, seed=90):
+    g = synth.uniform(seed, 3 * n, -24.0, 6.0)
+    return [tuple(float(v) for v in g[3 * k:3 * k + 3]) for k in range(n)]
+
+
+def _signals(n, length):
+    """Inputs that exercise both outcomes of the speculation."""
+    out = []
+    for k in range(n):
+        x = synth.noise(700 + k, length).copy()
+        kind = k % 6
+        if kind == 1:                                  # bursts of signal and digital silence
+            for a in range(0, length, 30000):
+                x[a + 9000:a + 30000] = 0.0
+        elif kind == 2:                                # a tone that stops dead, then DC, then noise again
+            t = np.arange(length)
+            x = (0.8 * np.sin(2 * np.pi * 220.0 * t / 48000.0)).astype(np.float32)
+            x[length // 3: length // 2] = 0.0
+            x[length // 2: length // 2 + 40000] = np.float32(0.25)
+        elif kind == 3:                                # sparse impulses on silence
+            x[:] = 0.0; x[::50000] = 1.0
+        elif kind == 4:                                # very quiet noise
+            x = (x * np.float32(1e-6)).astype(np.float32)
+        elif kind == 5:                                # silence from the first sample on (also what a Disconnected input reads)
+            x[:] = 0.0
+        out.append(np.ascontiguousarray(x, dtype=np.float32))
+    return out
+
+
+@pytest.mark.parametrize("rate", RATES)
+@pytest.mark.parametrize("chunks", [0, 2, 7, 64, 130])   # 0 = the planner's own choice
+def test_spec_eq_bit_exact_on_live_and_stalling_inputs_state_carried(rate, chunks, monkeypatch):
+    SR, SPT = rate
+    if chunks:
+        monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", str(chunks))
+    n, T, runs = 12, 300, 2
+    gl = _gains(n)
+    ws, srcs, eqs, g = _eq_graph(SR, gl, T)
+    sig = _signals(n, runs * T * SPT)
+    states = [oracle.eq_three_new(SR) for _ in range(n)]
+    for run in range(runs):
+        sl = slice(run * T * SPT, (run + 1) * T * SPT)
+        for k, s in enumerate(srcs):
+            g.write_source(s, sig[k][sl], T)
+        g.run_ticks(run * T, T)
+        for k, e in enumerate(eqs):
+            want = oracle.eq_three_run(states[k], gl[k], sig[k][sl])
+            assert_bit_exact(g.read_output(e, 0, T, False), want, f"speculative EQ, instance {k} (signal kind {k % 6}), run {run}")
+    ran, repaired = g.eq_spec_stats()
+    assert ran > 0, "the speculative kernel did not run"
+    # live inputs (kinds 0 and 4) never need a repair; stalling inputs may
+    assert repaired < ran
+
+
+def test_spec_eq_noise_needs_no_repairs():
+    SR, SPT = 48000, 800
+    n, T = 16, 256
+    gl = _gains(n, 91)
+    ws, srcs, eqs, g = _eq_graph(SR, gl, T)
+    x = [synth.noise(800 + k, T * SPT) for k in range(n)]
+    for k, s in enumerate(srcs):
+        g.write_source(s, x[k], T)
+    g.run_ticks(0, T)
+    for k, e in enumerate(eqs):
+        assert_bit_exact(g.read_output(e, 0, T, False), oracle.eq_three_run(oracle.eq_three_new(SR), gl[k], x[k]), f"instance {k}")
+    ran, repaired = g.eq_spec_stats()
+    assert ran >= 2 * n and repaired == 0, f"{repaired} of {ran} chunks needed a repair on plain noise"
+
+
+@pytest.mark.parametrize("warm", [16, 64, 256])
+def test_spec_eq_with_a_useless_warm_up_is_repaired_to_the_sequential_order(warm, monkeypatch):
+    monkeypatch.setenv("MX_EQ_SPEC_WARM", str(warm))
+    monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", "24")
+    SR, SPT = 44100, 735
+    n, T = 6, 120
+    gl = _gains(n, 92)
+    ws, srcs, eqs, g = _eq_graph(SR, gl, T)
+    x = [synth.noise(810 + k, 2 * T * SPT) for k in range(n)]
+    states = [oracle.eq_three_new(SR) for _ in range(n)]
+    for run in range(2):
+        sl = slice(run * T * SPT, (run + 1) * T * SPT)
+        for k, s in enumerate(srcs):
+            g.write_source(s, x[k][sl], T)
+        g.run_ticks(run * T, T)
+        for k, e in enumerate(eqs):
+            assert_bit_exact(g.read_output(e, 0, T, False), oracle.eq_three_run(states[k], gl[k], x[k][sl]), f"instance {k} run {run}")
+    ran, repaired = g.eq_spec_stats()
+    assert repaired >= ran // 2, f"only {repaired} of {ran} chunks were repaired: the short warm-up was expected to fail nearly everywhere"
+
+
+def test_spec_eq_nan_and_infinity_poison_the_poles_exactly_like_the_sequential_filter():
+    SR, SPT = 48000, 800
+    T = 200
+    gl = [(3.0, -2.0, 1.0), (0.0, 0.0, 0.0)]
+    ws, srcs, eqs, g = _eq_graph(SR, gl, T)
+    x0 = synth.noise(820, T * SPT).copy(); x0[40000] = np.float32("nan")
+    x1 = synth.noise(821, T * SPT).copy(); x1[70000] = np.float32("inf"); x1[70001] = np.float32("-inf")
+    for s, x in zip(srcs, (x0, x1)):
+        g.write_source(s, x, T)
+    g.run_ticks(0, T)
+    for k, (e, x) in enumerate(zip(eqs, (x0, x1))):
+        want = oracle.eq_three_run(oracle.eq_three_new(SR), gl[k], x)
+        got = g.read_output(e, 0, T, False)
+        # NaN payloads / signs are compared too: the same operations in the same order give the same bits
+        assert_bit_exact(got, want, f"poisoned instance {k}")
+        assert np.isnan(got[-1])
+
+
+@pytest.mark.parametrize("rate", RATES)
+def test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate):
+    """The chunk loop's four epilogue modes on long streams: plain EQ; EQ -> Panner (stereo store); -> Amplifier with a control
+    BUFFER; -> Amplifier with a Disconnected control; -> Amplifier whose control is an inline Envelope (per-tick states), the last
+    one stored as one float per frame for the Mixer."""
+    SR, SPT = rate
+    T = 240
+    ws = Workspace(SR, 60)
+    src = [ws.source_mono() for _ in range(5)]
+    ctl_src = ws.source_mono()
+    eq = [ws.eq_three(4.0 - k, -1.0 + 0.5 * k, 2.0 - k) for k in range(5)]
+    for s, e in zip(src, eq):
+        ws.connect(s, 0, e, 0)
+    pan = [ws.stereo_panner() for _ in range(4)]
+    for k in range(4):
+        ws.connect(eq[k + 1], 0, pan[k], 0); ws.connect(eq[k + 1], 0, pan[k], 1)
+    amp_buf = ws.amplifier(0.9, 0.6); ws.connect(pan[1], 0, amp_buf, 0); ws.connect(ctl_src, 0, amp_buf, 1)
+    amp_dis = ws.amplifier(1.2, 0.3); ws.connect(pan[2], 0, amp_dis, 0)
+    trig = ws.trigger(True); env = ws.envelope(5.0, 80.0, 0.6, 40.0)
+    amp_env = ws.amplifier(1.0, 0.5); ws.connect(pan[3], 0, amp_env, 0); ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp_env, 1)
+    mix = ws.mixer([(0.0, 1.0, True)]); ws.connect(amp_env, 0, mix, 0)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    x = [synth.noise(830 + k, T * SPT) for k in range(5)]
+    ctl = np.abs(synth.noise(840, T * SPT))
+    for s, v in zip(src, x):
+        g.write_source(s, v, T)
+    g.write_source(ctl_src, ctl, T)
+    # the Trigger closes at tick 100 and re-opens at tick 180 inside the run
+    g.schedule_params(trig, 100, abi.TriggerParams(0)); g.schedule_params(trig, 180, abi.TriggerParams(1))
+    g.run_ticks(0, T)
+    outs = {"eq": (eq[0], 0, False), "pan": (pan[0], 0, True), "amp_buf": (amp_buf, 0, True), "amp_dis": (amp_dis, 0, True), "master": (mix, 0, True)}
+    got = {k: g.read_output(nd, port, T, st) for k, (nd, port, st) in outs.items()}
+    for t in range(T):
+        if t == 100: og.update_params(trig, abi.TriggerParams(0))
+        if t == 180: og.update_params(trig, abi.TriggerParams(1))
+        for s, v in zip(src, x):
+            og.set_source(s, v[t * SPT:(t + 1) * SPT])
+        og.set_source(ctl_src, ctl[t * SPT:(t + 1) * SPT])
+        og.run_tick(t)
+        for k, (nd, port, st) in outs.items():
+            w = og.output(nd, port)
+            sl = slice(t * w.size, (t + 1) * w.size)
+            assert_bit_exact(got[k][sl], w, f"{k} tick {t}")
+    ran, _ = g.eq_spec_stats()
+    assert ran > 0
