@@ -135,8 +135,11 @@ def test_spec_eq_nan_and_infinity_poison_the_poles_exactly_like_the_sequential_f
     for k, (e, x) in enumerate(zip(eqs, (x0, x1))):
         want = oracle.eq_three_run(oracle.eq_three_new(SR), gl[k], x)
         got = g.read_output(e, 0, T, False)
-        # NaN payloads / signs are compared too: the same operations in the same order give the same bits
-        assert_bit_exact(got, want, f"poisoned instance {k}")
+        # NaN sign / payload bits are the ISA's business (x86 makes its default NaN negative, gfx950 positive): NaNs must sit
+        # at the same samples, everything else is compared bit for bit
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"poisoned instance {k}: NaNs at different samples"
+        ok = ~np.isnan(want)
+        assert_bit_exact(got[ok], want[ok], f"poisoned instance {k}")
         assert np.isnan(got[-1])
 
 
