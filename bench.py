@@ -47,7 +47,34 @@ BYTES_PER_FRAME_FUSED = {"envelope": 4, "eq_three": 4 + 4, "mixer": 4}
 STRIP_BYTES_FUSED_48K = (8 + 4) * 800   # per strip-tick: fused EQ (in, out) + mixer read
 
 
-def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=None, total=None):
+def gate_open(tick, k):
+    """the Trigger of strip k toggles every 30 ticks with phase k mod 60."""
+    return ((tick + k) // 30) % 2 == 1
+
+
+def gate_events(abi, trigs, first_strip, t0, n_ticks):
+    """The toggles of every strip's Trigger that fall INSIDE ticks (t0, t0 + n_ticks) as one mx_param_event array for
+    mx_graph_schedule_params_batch (the state at t0 itself is what the previous step left, or the initial params).
+    Returns (ctypes array, keep-alive list) or None."""
+    import ctypes as C
+    p_open, p_closed = abi.TriggerParams(1), abi.TriggerParams(0)
+    po, pc = C.cast(C.pointer(p_open), C.c_void_p), C.cast(C.pointer(p_closed), C.c_void_p)
+    ev = []
+    for j, tr in enumerate(trigs):
+        k = first_strip + j
+        c = 30 - (t0 + k) % 30                      # first toggle after t0
+        while c < n_ticks:
+            ev.append((tr, c, po if gate_open(t0 + c, k) else pc))
+            c += 30
+    if not ev:
+        return None
+    arr = (abi.ParamEvent * len(ev))()
+    for i, (tr, c, pp) in enumerate(ev):
+        arr[i].node = tr; arr[i].tick_in_run = c; arr[i].params = pp; arr[i].params_len = C.sizeof(abi.TriggerParams)
+    return arr, (p_open, p_closed)
+
+
+def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=None, total=None, want_trigs=False):
     """Config-2 strips [first_strip, first_strip + n_strips) with the global seeded parameters, into a Mixer(n_strips);
     `ws`: add them to an existing workspace (group buses), `total`: size of the whole job the parameters are drawn for."""
     if total is None:
@@ -58,9 +85,10 @@ def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=N
     if ws is None:
         ws = Workspace(sample_rate, 60)
     mix = ws.mixer([(float(mg[k]), float(mf[k]), k % 8 == 0) for k in range(first_strip, first_strip + n_strips)])
-    srcs = []
+    srcs, trigs = [], []
     for j, k in enumerate(range(first_strip, first_strip + n_strips)):
-        trig = ws.trigger(((k % 60) // 30) == 1)   # gate phase k mod 60, held for the run
+        trig = ws.trigger(gate_open(0, k))          # gate at tick 0; toggles every 30 ticks with phase k mod 60 (gate_events)
+        trigs.append(trig)
         env = ws.envelope()                         # defaults 25/500/0.8/200 (protocol/src/lib.rs:318-327)
         src = ws.source_mono()
         eq = ws.eq_three(float(eq_g[3 * k]), float(eq_g[3 * k + 1]), float(eq_g[3 * k + 2]))
@@ -72,6 +100,8 @@ def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=N
         ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1)
         ws.connect(amp, 0, mix, j)
         srcs.append(src)
+    if want_trigs:
+        return ws, mix, srcs, trigs
     return ws, mix, srcs
 
 

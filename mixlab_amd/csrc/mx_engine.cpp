@@ -480,6 +480,8 @@ void Graph::upload_group(Group& g) {
                 any_env = true; g.has_gates = true;
             }
             d[i] = e;
+            const int em = eq_epilogue_mode(e.epi, e.flags, e.ctl != nullptr);
+            g.eq_mode = i == 0 ? em : (g.eq_mode == em ? em : -1);
         }
         up(g.desc, d.data(), n * sizeof(EqDesc));
         if (any_env) up(g.tick_desc, td.data(), n * sizeof(EnvTickDesc));
@@ -876,11 +878,11 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
             }
             if (eq_exact()) {
                 EqSpecPlan plan;
-                if (eq_plan_spec(n, gf, lo_f_, hi_f_, plan)) {   // long streams: speculative time-parallel form, verified bit-exact
+                if (eq_plan_spec(n, gf, gfpc, lo_f_, hi_f_, plan)) {   // long streams: speculative time-parallel form, verified bit-exact
                     const size_t need = eq_spec_scratch_bytes(n, plan);
                     if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
                     if (!eq_stats_.p) { eq_stats_.alloc(2 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 2 * sizeof(uint64_t)), "hipMemset"); }
-                    launch_eq_three_spec((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, plan, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
+                    launch_eq_three_spec((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
                 } else {
                     launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, stream_);
                 }

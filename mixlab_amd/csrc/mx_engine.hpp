@@ -76,6 +76,7 @@ struct Group {
     DevBuf tick_desc;   // EqThree: EnvTickDesc[] of the folded Envelopes
     DevBuf env_ticks;   // EqThree: EnvTick[n][n_calls] of the current launch
     DevBuf spec;        // EqThree: chunk records of the speculative exact kernel
+    int eq_mode = -1;   // EqThree: the one epilogue every instance has (eq_epilogue_mode), or -1 when they differ
 };
 
 class Graph {

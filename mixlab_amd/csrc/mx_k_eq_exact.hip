@@ -144,33 +144,69 @@ enum { EQM_PLAIN = 0, EQM_AMP_CONST = 1, EQM_AMP_CTL = 2, EQM_AMP_ENV = 3 };
 
 constexpr int EQ_BLK = 16;   // samples per block: four 16-byte loads in flight per lane while the previous block is computed
 
-template <int MODE, bool STEREO>
-__device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, const EnvTick* __restrict__ ticks, const size_t begin, const size_t len,
-                                              EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
-    const float* __restrict__ in = d.in + begin;
-    float* __restrict__ outm = d.out + (STEREO ? 2 * begin : begin);
-    const float* __restrict__ ctl = MODE == EQM_AMP_CTL ? d.ctl + begin : nullptr;
+// The inline Envelope of one tick for one lane, reduced to per-lane coefficients so that the per-sample code has NO branch
+// (lanes of a wave sit in different ticks and Envelope phases; branches would also fence the recurrence's instruction stream):
+//   On  (envelope.rs:37-49):  ms < attack_ms ? inv_attack * ms : sustain + (1 - sustain) * (1 - clamp(inv_decay * (ms - attack_ms)))
+//   Off (envelope.rs:51-56):  off_amplitude * (1 - clamp(inv_release * ms))
+// Both are  A + B * (1 - clamp(k * (ms - m0)))  with (A, B, k, m0) = (sustain, 1 - sustain, inv_decay, attack_ms) resp.
+// (0, off_amplitude, inv_release, 0): for Off the two extra operations are exact identities (ms - 0.0 == ms; 0.0 + p == p for
+// every p but -0.0, which off_amplitude * [0, 1] cannot be when off_amplitude >= +0.0 -- env_lane_coeffs() falls back to the
+// general form otherwise).  ms = (dt as f64) / SR * 1000 with dt = dt0 + sample index (u32; spans whose dt leaves 32 bits also
+// take the general form).
+struct EnvLane { double A, B, k, m0, depth; uint32_t dt0; uint32_t on; uint32_t flat; uint32_t general;
+                 uint32_t k0 = 0; uint64_t t_chunk = 0; /* tiled kernel: chunk-relative index of the tick's first sample; absolute time of the chunk's */ };
+__device__ __forceinline__ EnvLane env_lane_coeffs(const EnvParams& p, const EnvTick& c, uint64_t t_begin, size_t n) {
+    EnvLane e;
+    e.depth = c.depth; e.flat = c.flat; e.on = c.tag == 1u ? 1u : 0u;
+    e.A = e.on ? p.sustain : 0.0; e.B = e.on ? p.one_minus_sustain : c.off_amp;
+    e.k = e.on ? p.inv_decay : p.inv_release; e.m0 = e.on ? p.attack_ms : 0.0;
+    const uint64_t d0 = t_begin - c.seq;
+    e.dt0 = (uint32_t)d0;
+    const bool off_ok = !(c.off_amp < 0.0) && (c.off_amp == c.off_amp) && !signbit(c.off_amp);
+    e.general = (c.tag != 0u && !c.flat && ((((d0 + n) >> 32) != 0) || (c.tag == 2u && !off_ok))) ? 1u : 0u;
+    return e;
+}
+// amplifier depth() for sample k of the span (branch-free form; `e.general` lanes are handled by the caller)
+__device__ __forceinline__ double env_lane_depth(const EnvParams& p, const EnvLane& e, uint32_t k, double one_minus, double mod_depth, double sr, double rsr) {
+    const double ms = ms_of_u32(e.dt0 + k, sr, rsr);
+    const double tt = e.k * (ms - e.m0);
+    double c = tt;
+    c = tt > 1.0 ? 1.0 : c;                                    // clamp(), envelope.rs:20-28 (a NaN passes through like there)
+    c = tt < 0.0 ? 0.0 : c;
+    const double val = e.A + e.B * (1.0 - c);
+    const double att = p.inv_attack * ms;
+    const double a = (e.on && ms < p.attack_ms) ? att : val;
+    const float cc = (float)a;                                 // Envelope stores f32 (envelope.rs:117)
+    const double d = one_minus + mod_depth * (double)cc;       // amplifier.rs:71-73
+    return e.flat ? e.depth : d;
+}
+
+// A run of `n` consecutive samples of one chunk through the recurrence and the epilogue: blocks of EQ_BLK samples with the next
+// block's loads in flight, then the ragged tail.  Everything the epilogue needs is in registers before the loop starts -- no
+// load sits inside a per-sample condition (its join would cost an s_waitcnt vmcnt(0), i.e. the prefetch).
+// ENVK: 0 no inline Envelope; 1 every lane of the wave is flat this tick (constant depth); 2 branch-free closed form;
+//       3 general form (env_depth: 64-bit distances, negative off_amplitude).
+template <int MODE, bool STEREO, int ENVK>
+__device__ __forceinline__ void eq_spec_span(const EqDesc& d, const EqRun& r, const float* __restrict__ in, float* __restrict__ outm,
+                                             const float* __restrict__ ctl, const size_t n, const EnvTick& cur, const EnvLane& el, uint64_t t,
+                                             EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     const double g_lo = d.gain_lo, g_mid = d.gain_mid, g_hi = d.gain_hi, lo_f = r.lo_f, hi_f = r.hi_f;
     const double one_minus = d.amp_one_minus, mod_depth = d.amp_mod_depth, amplitude = d.amp_amplitude;
     const double depth_const = one_minus + mod_depth * 1.0;                    // Disconnected control: mod value 1.0 (amplifier.rs:54)
     const double rsr = r.rsr;
-    // tick cursor of the inline Envelope: `left` samples remain in tick `call`
-    uint32_t call = 0; uint32_t left = 0; EnvTick cur{}; uint64_t t = r.t0 + begin;
-    if (MODE == EQM_AMP_ENV) { call = (uint32_t)(begin / r.fpc); left = (uint32_t)(r.fpc - begin % r.fpc); cur = ticks[call]; }
+    uint32_t kk = 0;
     auto fold = [&](float y, float c) -> float {
         if (MODE == EQM_PLAIN) return y;
         double depth;
         if (MODE == EQM_AMP_CONST) depth = depth_const;
         else if (MODE == EQM_AMP_CTL) depth = one_minus + mod_depth * (double)c;   // amplifier.rs:71-73
-        else {
-            if (left == 0) { ++call; cur = ticks[call]; left = (uint32_t)r.fpc; }
-            --left;
-            depth = env_depth(d.env, cur, one_minus, mod_depth, t, r.sr, rsr);
-            ++t;
-        }
+        else if (ENVK == 1) depth = el.depth;
+        else if (ENVK == 2) { depth = env_lane_depth(d.env, el, kk, one_minus, mod_depth, r.sr, rsr); ++kk; }
+        else { depth = env_depth(d.env, cur, one_minus, mod_depth, t, r.sr, rsr); ++t; }
         return amp_apply(y, depth, amplitude);
     };
-    auto put4 = [&](size_t i, const float (&v)[4]) {   // i multiple of 4
+    auto track = [&](float x) { const uint32_t b = __float_as_uint(x); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax; };
+    auto put4 = [&](size_t i, const float (&v)[4]) {
         if (STEREO) {
             f4v a = {v[0], v[0], v[1], v[1]}, b = {v[2], v[2], v[3], v[3]};       // stereo_panner.rs:35-38
             __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(outm + 2 * i));
@@ -180,7 +216,7 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
             __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(outm + i));
         }
     };
-    const size_t n_blk = len / EQ_BLK;
+    const size_t n_blk = n / EQ_BLK;
     f4v xa[EQ_BLK / 4], ca[EQ_BLK / 4];
     if (n_blk) {
 #pragma unroll
@@ -197,25 +233,70 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x = xa[q][e];
-                const uint32_t xb32 = __float_as_uint(x);
-                xmin = xb32 < xmin ? xb32 : xmin; xmax = xb32 > xmax ? xb32 : xmax;
+                track(x);
                 v[e] = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ca[q][e] : 0.f);
             }
             put4(b * EQ_BLK + 4 * q, v);
+            __builtin_amdgcn_sched_barrier(0);   // four samples at a time: interleaving all sixteen epilogues costs more registers than it hides latency
         }
 #pragma unroll
         for (int q = 0; q < EQ_BLK / 4; ++q) { xa[q] = xb[q]; if (MODE == EQM_AMP_CTL) ca[q] = cb[q]; }
     }
-    for (size_t i = n_blk * EQ_BLK; i < len; ++i) {   // ragged tail of the stream's last chunk
+    // ragged tail (a tick of 735 samples, the stream's last chunk): at most EQ_BLK - 1 samples, four at a time, then one at a time
+    size_t i = n_blk * EQ_BLK;
+#pragma unroll 1
+    for (; i + 4 <= n; i += 4) {
+        const f4v x4 = ld_stream4(in + i);
+        f4v c4 = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == EQM_AMP_CTL) c4 = ld_stream4(ctl + i);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { track(x4[e]); v[e] = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x4[e]), c4[e]); }
+        put4(i, v);
+    }
+#pragma unroll 1
+    for (; i < n; ++i) {
         const float x = in[i];
-        const uint32_t xb32 = __float_as_uint(x);
-        xmin = xb32 < xmin ? xb32 : xmin; xmax = xb32 > xmax ? xb32 : xmax;
+        track(x);
         const float v = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ctl[i] : 0.f);
         if (STEREO) reinterpret_cast<float2*>(outm)[i] = make_float2(v, v); else outm[i] = v;
     }
 }
 
-__global__ __launch_bounds__(64) void k_eq_three_spec(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+// my chunk: [begin, begin + len) of the instance's stream.  With an inline Envelope the chunk is a whole number of ticks
+// (eq_plan_spec) and is walked tick by tick: the tick's Envelope state is loaded once per tick and turned into per-lane coefficients.
+template <int MODE, bool STEREO>
+__device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, const EnvTick* __restrict__ ticks, const size_t begin, const size_t len,
+                                              EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
+    const float* __restrict__ in = d.in + begin;
+    float* __restrict__ outm = d.out + (STEREO ? 2 * begin : begin);
+    const float* __restrict__ ctl = MODE == EQM_AMP_CTL ? d.ctl + begin : nullptr;
+    if (MODE != EQM_AMP_ENV) {
+        const EnvTick none{}; const EnvLane nl{};
+        eq_spec_span<MODE, STEREO, 0>(d, r, in, outm, ctl, len, none, nl, 0, s, xmin, xmax);
+        return;
+    }
+    const size_t fpc = r.fpc;
+    uint32_t call = (uint32_t)(begin / fpc);
+    size_t off = begin % fpc;                                                  // 0 when chunks are whole ticks; the walk is general
+    for (size_t i = 0; i < len;) {
+        const size_t n = (fpc - off) < (len - i) ? (fpc - off) : (len - i);
+        const EnvTick cur = ticks[call];                                       // one 32-byte load per tick of 800 samples
+        const uint64_t t = r.t0 + begin + i;
+        const EnvLane el = env_lane_coeffs(d.env, cur, t, n);
+        float* const o = outm + (STEREO ? 2 * i : i);
+        // wave-level choice of the span's form (lanes that left the loop already do not vote)
+        if (__ballot(el.general != 0u) != 0ull) eq_spec_span<MODE, STEREO, 3>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
+        else if (__ballot(el.flat == 0u) == 0ull) eq_spec_span<MODE, STEREO, 1>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
+        else eq_spec_span<MODE, STEREO, 2>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
+        i += n; off = 0; ++call;
+    }
+}
+
+// KMODE / KSTEREO >= 0: every instance of the launch has that epilogue (the usual case: a bank of equal strips) and the kernel is
+// compiled for it alone -- its own register budget, no dead variants; -1: decided per wave.
+template <int KMODE, int KSTEREO>
+__global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) void k_eq_three_spec(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                        uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
     const uint32_t inst = blockIdx.x / waves_per_inst;                         // wave-uniform: one instance per wave, descriptor in SGPRs
     const uint32_t j = (blockIdx.x % waves_per_inst) * 64u + threadIdx.x;      // my chunk
@@ -262,12 +343,201 @@ __global__ __launch_bounds__(64) void k_eq_three_spec(const EqDesc* __restrict__
     const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
     const bool stereo = !(d.epi == 0u || (d.flags & MX_EQF_MONO_DUP));
     const int mode = d.epi != 2u ? EQM_PLAIN : ((d.flags & MX_EQF_ENV) ? EQM_AMP_ENV : (d.ctl ? EQM_AMP_CTL : EQM_AMP_CONST));
+    if constexpr (KMODE >= 0) {
+        eq_spec_chunk<KMODE, KSTEREO != 0>(d, r, ticks, begin, len, s, xmin, xmax);
+    } else {
 #define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true>(d, r, ticks, begin, len, s, xmin, xmax); else eq_spec_chunk<M, false>(d, r, ticks, begin, len, s, xmin, xmax); break
-    switch (mode) { MX_EQ_CASE(EQM_PLAIN); MX_EQ_CASE(EQM_AMP_CONST); MX_EQ_CASE(EQM_AMP_CTL); default: MX_EQ_CASE(EQM_AMP_ENV); }
+        switch (mode) { MX_EQ_CASE(EQM_PLAIN); MX_EQ_CASE(EQM_AMP_CONST); MX_EQ_CASE(EQM_AMP_CTL); default: MX_EQ_CASE(EQM_AMP_ENV); }
 #undef MX_EQ_CASE
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { rec->end[k] = s.lo[k]; rec->end[4 + k] = s.hi[k]; }
     rec->xmin = xmin; rec->xmax = xmax;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TILED form of the speculative kernel: the same arithmetic, but the wave moves its 64 chunk streams through LDS.
+//
+// Why: with one lane per chunk the lanes of a wave are C samples apart in memory.  Loading / storing 16 bytes per lane directly
+// (the form above) makes every wave instruction touch 64 different cache lines, 16 bytes each: PMC on MI355X showed one memory
+// write request per lane per store (2.3x the algorithmic write bytes), 4 L2 read requests per line, the L1 miss queue full for
+// 97 % of the kernel's cycles and the VALU active for 9 % -- 25.7 ms for 1024 strips x 2048 ticks.  Here a SUPER-BLOCK of 32
+// samples per lane (one 128-byte line per chunk) is moved per step:
+//   stage-in   8 x global_load_lds_dwordx4: instruction k brings the lines of chunks 8k .. 8k+7, eight lanes per line (whole
+//              lines, no VGPRs), straight into the tile buffer of the NEXT super-block while this one is computed;
+//   tile       [64 chunks][8 slots of 16 B]; chunk row c keeps piece p in slot p ^ ((c >> 1) & 7): the walk of lane j over its own
+//              row (ds_read_b128 / ds_write_b128 of slot p ^ ((j >> 1) & 7)) is conflict-free, and rows stay contiguous for the
+//              DMA, whose destination is lane-linear -- so the swizzle is applied to the SOURCE address (inverse) and to the READ;
+//   compute    lane j walks its row: recurrence + epilogue, results written back in place;
+//   stage-out  the tile is read back linearly (lane l of step k holds slot l & 7 of chunk 8k + (l >> 3)) and stored with eight
+//              lanes per line: whole lines again.
+// The wave needs no barrier (a wave per workgroup; its own vmcnt orders the DMA before its ds_reads).  16 KiB of LDS per wave.
+// Conditions (launch_eq_three_spec): frames % 4 == 0, chunk % 32 == 0, frames < 2^31, no control BUFFER (EQM_AMP_CTL keeps the
+// direct form), and with an inline Envelope samples-per-tick % 32 == 0 (48 kHz: 800).
+// ---------------------------------------------------------------------------------------------
+typedef const float __attribute__((address_space(1)))* mx_gfp1;
+typedef float __attribute__((address_space(3)))* mx_lfp3;
+constexpr int EQ_SB = 32;                 // samples per lane per super-block
+constexpr int EQ_TILE = 64 * EQ_SB;       // floats per tile buffer
+
+struct EqTileCtx {
+    const float* in; float* out;          // stream bases of the instance
+    uint32_t chunk0, n_chunks, C, F;      // first chunk of the wave, chunks per instance, chunk length, stream length (samples)
+    int lane;
+};
+
+// stage-in of the super-block whose first sample sits `so` samples from each chunk's begin (negative during the warm-up)
+__device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, int so) {
+    const int s = c.lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cj = 8 * k + (c.lane >> 3);
+        const int pce = s ^ ((4 * k + (c.lane >> 4)) & 7);            // = s ^ ((cj >> 1) & 7): the piece that belongs in slot s of row cj
+        long long idx = (long long)(c.chunk0 + (uint32_t)cj) * (long long)c.C + (long long)so + 4 * pce;
+        idx = idx < 0 ? 0 : idx;                                      // before the stream (chunk 0's warm-up) / past it (lanes beyond the last
+        idx = idx > (long long)c.F - 4 ? (long long)c.F - 4 : idx;    // chunk): never used, keep the address legal
+        __builtin_amdgcn_global_load_lds((mx_gfp1)(c.in + idx), (mx_lfp3)(buf + k * 256), 16, 0, 0);
+    }
+}
+
+// compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
+template <int MODE, int ENVK, bool WARM>
+__device__ __forceinline__ void eq_tile_compute(const EqDesc& d, const EqRun& r, float* buf, const int lane, const int so, const int len,
+                                                const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
+    const double g_lo = d.gain_lo, g_mid = d.gain_mid, g_hi = d.gain_hi, lo_f = r.lo_f, hi_f = r.hi_f;
+    const double one_minus = d.amp_one_minus, mod_depth = d.amp_mod_depth, amplitude = d.amp_amplitude;
+    const double depth_const = one_minus + mod_depth * 1.0;           // Disconnected control: mod value 1.0 (amplifier.rs:54)
+    const int sw = (lane >> 1) & 7;
+    f4v* row = reinterpret_cast<f4v*>(buf + lane * EQ_SB);
+    f4v x4 = row[0 ^ sw];
+#pragma unroll 1
+    for (int pce = 0; pce < 8; ++pce) {
+        const f4v xn = row[((pce + 1) & 7) ^ sw];                     // next piece travels while this one is computed
+        if (WARM || so + 4 * pce < len) {
+            f4v v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = x4[e];
+                if (WARM) {
+                    const double xd = (double)x;
+                    pump(lo_f, s.lo, xd); pump(hi_f, s.hi, xd);
+                    s.h0 = s.h1; s.h1 = s.h2; s.h2 = xd;
+                } else {
+                    const uint32_t b = __float_as_uint(x); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
+                    const float y = eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x);
+                    if (MODE == EQM_PLAIN) v[e] = y;
+                    else {
+                        double depth;
+                        const uint32_t kk = (uint32_t)(so + 4 * pce + e);      // sample index inside the chunk; el.dt0 counts from the tick's first sample
+                        if (MODE == EQM_AMP_CONST) depth = depth_const;
+                        else if (ENVK == 1) depth = el.depth;
+                        else if (ENVK == 2) depth = env_lane_depth(d.env, el, kk - el.k0, one_minus, mod_depth, r.sr, r.rsr);
+                        else depth = env_depth(d.env, cur, one_minus, mod_depth, el.t_chunk + kk, r.sr, r.rsr);
+                        v[e] = amp_apply(y, depth, amplitude);
+                    }
+                }
+            }
+            if (!WARM) row[pce ^ sw] = v;
+        }
+        x4 = xn;
+    }
+}
+
+// stage-out of a computed tile: whole lines, eight lanes per chunk line
+template <bool STEREO>
+__device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* buf, int so) {
+    const int s = c.lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f4v o = *reinterpret_cast<const f4v*>(buf + k * 256 + c.lane * 4);
+        const uint32_t chunk = c.chunk0 + (uint32_t)(8 * k + (c.lane >> 3));
+        const int pce = s ^ ((4 * k + (c.lane >> 4)) & 7);
+        const long long idx = (long long)chunk * (long long)c.C + (long long)so + 4 * pce;
+        if (chunk < c.n_chunks && idx + 4 <= (long long)c.F) {
+            if (STEREO) {
+                f4v a = {o[0], o[0], o[1], o[1]}, b = {o[2], o[2], o[3], o[3]};   // stereo_panner.rs:35-38
+                __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(c.out + 2 * idx));
+                __builtin_nontemporal_store(b, reinterpret_cast<f4v*>(c.out + 2 * idx + 4));
+            } else {
+                __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(c.out + idx));
+            }
+        }
+    }
+}
+
+template <int KMODE, int KSTEREO>
+__global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+                                                                uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][EQ_TILE]
+    const uint32_t inst = blockIdx.x / waves_per_inst;
+    const EqDesc& d = descs[inst];
+    EqTileCtx c;
+    c.in = d.in; c.out = d.out;
+    c.chunk0 = (blockIdx.x % waves_per_inst) * 64u; c.n_chunks = plan.n_chunks; c.C = plan.chunk; c.F = (uint32_t)r.frames;
+    c.lane = threadIdx.x;
+    const uint32_t j = c.chunk0 + threadIdx.x;
+    const bool active = j < plan.n_chunks;
+    const long long begin = (long long)j * c.C;
+    const int len = active ? (int)((long long)c.F - begin < (long long)c.C ? (long long)c.F - begin : (long long)c.C) : 0;
+    const int len0 = (int)((long long)c.F - (long long)c.chunk0 * c.C < (long long)c.C ? (long long)c.F - (long long)c.chunk0 * c.C : (long long)c.C);   // the wave's longest chunk (wave-uniform)
+    const int n_warm = (int)(plan.warm / EQ_SB), n_main = (len0 + EQ_SB - 1) / EQ_SB;
+    const int total = n_warm + n_main;
+
+    EqPoles s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.lo[k] = 0.0; s.hi[k] = 0.0; }
+    s.h0 = s.h1 = s.h2 = 0.0;
+    uint32_t xmin = 0xffffffffu, xmax = 0u;
+    const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
+    EnvTick cur{}; EnvLane el{};
+    int envk = 0;
+    EqChunkRec* rec = recs + (size_t)inst * plan.n_chunks + (active ? j : 0);
+
+    eq_tile_issue(c, eq_tiles, -(int)plan.warm);
+    for (int g = 0; g < total; ++g) {
+        float* buf = eq_tiles + (g & 1) * EQ_TILE;
+        const int so = (g - n_warm) * EQ_SB;
+        if (g + 1 < total) eq_tile_issue(c, eq_tiles + ((g + 1) & 1) * EQ_TILE, so + EQ_SB);   // its previous tenant was stored one step ago
+        // everything but the 8 DMA just issued has landed: this super-block's tile, and the stores of the one before
+        if (g + 1 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g < n_warm) {
+            if (j != 0) eq_tile_compute<EQM_PLAIN, 0, true>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            continue;
+        }
+        if (g == n_warm) {   // first sample of my chunk: chunk 0 takes the carried state, the others record where the warm-up took them
+            if (j == 0) {
+                const EqState& st = states[inst];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
+                s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
+            }
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
+            }
+        }
+        if constexpr (KMODE == EQM_AMP_ENV) {
+            if ((size_t)so % r.fpc == 0) {   // a new tick (wave-uniform: chunks are whole ticks): its Envelope state, per lane
+                const size_t tk = ((size_t)begin + (size_t)so) / r.fpc;
+                cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
+                const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so;
+                el = env_lane_coeffs(d.env, cur, t, r.fpc);
+                el.k0 = (uint32_t)so; el.t_chunk = r.t0 + (uint64_t)begin;
+                envk = __ballot(active && so < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so < len && el.flat == 0u) == 0ull ? 1 : 2);
+            }
+            if (envk == 1) eq_tile_compute<KMODE, 1, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            else if (envk == 2) eq_tile_compute<KMODE, 2, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            else eq_tile_compute<KMODE, 3, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+        } else {
+            eq_tile_compute<KMODE, 0, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+        }
+        eq_tile_store<KSTEREO != 0>(c, buf, so);
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rec->end[k] = s.lo[k]; rec->end[4 + k] = s.hi[k]; }
+        rec->xmin = xmin; rec->xmax = xmax;
+    }
 }
 
 // ---- repair ----
@@ -411,7 +681,7 @@ static size_t eq_warm_len(double f) {
     return (size_t)-1;
 }
 
-bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPlan& plan) {
+bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan) {
     plan = EqSpecPlan{1u, 0u, 0u, 0u};
     if (!n || !frames) return false;
     size_t W = std::max(eq_warm_len(lo_f), eq_warm_len(hi_f));
@@ -425,8 +695,12 @@ bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPla
     // sample, so a wave takes (C + W) * 180 cycles whether 1 or 64 of its lanes are active; waves queue on 1024 SIMDs.
     // One lane per instance (no speculation) is a dependent chain of ~110 cycles per sample, 64 instances per wave.
     const double c_issue = 180.0, c_lat = 110.0, simds = 1024.0;
+    // chunk lengths are whole ticks (an inline Envelope's state is read once per tick and every lane of a wave crosses its
+    // tick boundaries at the same step) when that is also a multiple of 16 samples, else multiples of 32 samples
+    const size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
+    auto chunk_of = [&](size_t nc) { return ((frames + nc - 1) / nc + unit - 1) / unit * unit; };
     auto cost = [&](size_t nc) {
-        const size_t C = ((frames + nc - 1) / nc + 31) / 32 * 32;
+        const size_t C = chunk_of(nc);
         const double waves = (double)n * (double)((nc + 63) / 64);
         const double per_simd = std::ceil(waves / simds);
         return (double)(C + W) * std::max(c_lat, c_issue * per_simd);
@@ -441,8 +715,8 @@ bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPla
         }
     }
     if (best < 2) return false;
-    size_t C = ((frames + best - 1) / best + 31) / 32 * 32;
-    if (C < W) C = (W + 31) / 32 * 32;
+    size_t C = chunk_of(best);
+    if (C < W) C = (W + unit - 1) / unit * unit;
     plan.chunk = (uint32_t)C; plan.warm = (uint32_t)W;
     plan.n_chunks = (uint32_t)((frames + C - 1) / C);
     return plan.n_chunks >= 2;
@@ -450,11 +724,41 @@ bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPla
 
 size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan) { return (size_t)n * plan.n_chunks * sizeof(EqChunkRec); }
 
-void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, void* scratch, uint64_t* stats, hipStream_t s) {
+int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl) {
+    const int mode = epi != 2u ? EQM_PLAIN : ((flags & MX_EQF_ENV) ? EQM_AMP_ENV : (has_ctl ? EQM_AMP_CTL : EQM_AMP_CONST));
+    const int stereo = !(epi == 0u || (flags & MX_EQF_MONO_DUP));
+    return mode * 2 + stereo;
+}
+
+void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode, void* scratch, uint64_t* stats, hipStream_t s) {
     if (!n || !r.frames) return;
     const uint32_t wpi = (plan.n_chunks + 63) / 64;
     EqChunkRec* recs = (EqChunkRec*)scratch;
-    hipLaunchKernelGGL(k_eq_three_spec, dim3(n * wpi), dim3(64), 0, s, d, (const EqState*)st, r, plan, wpi, recs);
+    static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
+    const int um = uniform_mode;
+    const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % EQ_SB == 0 && plan.warm % EQ_SB == 0 &&
+                       r.frames < (1ull << 31) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % EQ_SB == 0 && plan.chunk % r.fpc == 0));
+    if (tiled) {
+        const size_t lds = 2 * EQ_TILE * sizeof(float);
+#define MX_GT(M, S) hipLaunchKernelGGL((k_eq_three_spec_tiled<M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs)
+        switch (um) {
+        case 0: MX_GT(EQM_PLAIN, 0); break;     case 1: MX_GT(EQM_PLAIN, 1); break;
+        case 2: MX_GT(EQM_AMP_CONST, 0); break; case 3: MX_GT(EQM_AMP_CONST, 1); break;
+        case 6: MX_GT(EQM_AMP_ENV, 0); break;   default: MX_GT(EQM_AMP_ENV, 1); break;
+        }
+#undef MX_GT
+        hipLaunchKernelGGL(k_eq_three_repair, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
+        return;
+    }
+#define MX_GO(M, S) hipLaunchKernelGGL((k_eq_three_spec<M, S>), dim3(n * wpi), dim3(64), 0, s, d, (const EqState*)st, r, plan, wpi, recs)
+    switch (uniform_mode) {
+    case 0: MX_GO(EQM_PLAIN, 0); break;     case 1: MX_GO(EQM_PLAIN, 1); break;
+    case 2: MX_GO(EQM_AMP_CONST, 0); break; case 3: MX_GO(EQM_AMP_CONST, 1); break;
+    case 4: MX_GO(EQM_AMP_CTL, 0); break;   case 5: MX_GO(EQM_AMP_CTL, 1); break;
+    case 6: MX_GO(EQM_AMP_ENV, 0); break;   case 7: MX_GO(EQM_AMP_ENV, 1); break;
+    default: MX_GO(-1, -1); break;
+    }
+#undef MX_GO
     hipLaunchKernelGGL(k_eq_three_repair, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
 }
 

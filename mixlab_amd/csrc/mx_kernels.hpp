@@ -109,10 +109,11 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s);
 // speculative time-parallel EXACT mode (k_eq_three_spec + k_eq_three_repair): see mx_k_eq_three.hip
 struct EqSpecPlan { uint32_t n_chunks; uint32_t chunk; uint32_t warm; uint32_t pad; };
-bool eq_plan_spec(uint32_t n, size_t frames, double lo_f, double hi_f, EqSpecPlan& plan);   // false: one lane per instance (launch_eq_three_exact)
+bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan);   // false: one lane per instance (launch_eq_three_exact)
 size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan);
-void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, void* scratch,
-                          uint64_t* stats /* [2]: chunks run, chunks repaired */, hipStream_t s);
+int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl);   // 0..7: (epilogue kind) * 2 + (stereo store); the specialisation key
+void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode /* 0..7, or -1: mixed */,
+                          void* scratch, uint64_t* stats /* [2]: chunks run, chunks repaired */, hipStream_t s);
 void eq_plan_split(uint32_t n, size_t frames, double lo_f, double hi_f, EqSplit& sp);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
 void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch /* most channels of any mixer in the group */, size_t frames,
