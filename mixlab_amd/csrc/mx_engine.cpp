@@ -643,10 +643,15 @@ void Graph::schedule_params(uint32_t node, uint32_t tick, const void* params, si
     Node& n = nodes_[node];
     if (len != n.params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
     if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
+    if (n.kind == MX_KIND_TRIGGER) {
+        mx_trigger_params tp; std::memcpy(&tp, params, sizeof tp);
+        n.gate_sched.emplace_back(tick, tp.gate_open ? 1u : 0u);
+        ++gates_version_;
+        return;
+    }
     Node::SchedEv ev; ev.tick = tick;
     ev.params.assign((const uint8_t*)params, (const uint8_t*)params + len);
     n.sched.push_back(std::move(ev));
-    if (n.kind == MX_KIND_TRIGGER) ++gates_version_;
 }
 
 // H2D copy on the graph's stream out of page-locked staging: the caller's buffer is free on return, nothing waits for the device
@@ -692,12 +697,22 @@ void Graph::refresh_gates(Group& g, uint32_t run_calls) {
         bool open = tp.gate_open != 0;
         uint32_t c = 0;
         uint32_t* row = bits.data() + i * words;
-        auto fill_to = [&](uint32_t end) { if (open) for (; c < end; ++c) row[c >> 5] |= 1u << (c & 31); else c = end; };
-        for (const Node::SchedEv& ev : T.sched) {           // stable by tick: submission order decides among updates for one tick
-            const uint32_t at = ev.tick < run_calls ? ev.tick : run_calls;
+        auto fill_to = [&](uint32_t end) {   // bits [c, end) = open, a word at a time
+            if (open && end > c) {
+                uint32_t a = c, b = end;
+                while (a < b) {
+                    const uint32_t w = a >> 5, lo = a & 31, hi = std::min<uint32_t>(32, lo + (b - a));
+                    const uint32_t mask = (hi == 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+                    row[w] |= mask;
+                    a += hi - lo;
+                }
+            }
+            c = end;
+        };
+        for (const auto& ev : T.gate_sched) {               // stable by tick: submission order decides among updates for one tick
+            const uint32_t at = ev.first < run_calls ? ev.first : run_calls;
             if (at > c) fill_to(at);
-            mx_trigger_params np; std::memcpy(&np, ev.params.data(), sizeof np);
-            open = np.gate_open != 0;
+            open = ev.second != 0;
         }
         fill_to(run_calls);
     }
@@ -760,7 +775,7 @@ static bool group_launches(const Group& g);
 
 void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, float* ms_total) {
     const size_t frames = fpc * (size_t)n_calls;
-    auto drop_schedules = [&] { for (Node& n : nodes_) n.sched.clear(); };
+    auto drop_schedules = [&] { for (Node& n : nodes_) { n.sched.clear(); n.gate_sched.clear(); } };
     if (frames > cap_frames_) { drop_schedules(); throw Error(MX_ERR_INVALID, "n_ticks exceeds max_ticks_per_run"); }
     if (n_calls == 0 || fpc == 0) { drop_schedules(); last_calls_ = n_calls; last_frames_per_call_ = fpc; return; }
     hip_check(hipSetDevice(device_), "hipSetDevice");
@@ -770,12 +785,20 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     // the update is applied (ModuleT::update) between the span that ends before its tick and the span that starts with it.
     std::vector<uint32_t> cuts;   // span starts > 0
     bool any_sched = false;
+    const char* beyond = "a scheduled parameter update lies beyond the run (tick_in_run >= n_ticks)";
     for (Node& n : nodes_) {
+        if (!n.gate_sched.empty()) {
+            any_sched = true;
+            bool sorted = true;
+            for (size_t i = 1; i < n.gate_sched.size(); ++i) sorted = sorted && n.gate_sched[i - 1].first <= n.gate_sched[i].first;
+            if (!sorted) std::stable_sort(n.gate_sched.begin(), n.gate_sched.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            if (n.gate_sched.back().first >= n_calls) { drop_schedules(); throw Error(MX_ERR_INVALID, beyond); }
+        }
         if (n.sched.empty()) continue;
         any_sched = true;
         std::stable_sort(n.sched.begin(), n.sched.end(), [](const Node::SchedEv& x, const Node::SchedEv& y) { return x.tick < y.tick; });
-        if (n.sched.back().tick >= n_calls) { drop_schedules(); throw Error(MX_ERR_INVALID, "a scheduled parameter update lies beyond the run (tick_in_run >= n_ticks)"); }
-        if (n.kind != MX_KIND_TRIGGER) for (const Node::SchedEv& ev : n.sched) if (ev.tick) cuts.push_back(ev.tick);
+        if (n.sched.back().tick >= n_calls) { drop_schedules(); throw Error(MX_ERR_INVALID, beyond); }
+        for (const Node::SchedEv& ev : n.sched) if (ev.tick) cuts.push_back(ev.tick);
     }
     std::sort(cuts.begin(), cuts.end());
     cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
@@ -833,8 +856,12 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     // the modules keep the last scheduled params (a Trigger's are read by the next run's GateBits)
     if (any_sched) {
         for (Node& n : nodes_) {
-            if (n.sched.empty()) continue;
-            if (n.kind == MX_KIND_TRIGGER) { std::memcpy(n.params.data(), n.sched.back().params.data(), n.params.size()); ++gates_version_; }
+            if (!n.gate_sched.empty()) {
+                mx_trigger_params tp{}; tp.gate_open = n.gate_sched.back().second;
+                std::memcpy(n.params.data(), &tp, sizeof tp);
+                ++gates_version_;
+                n.gate_sched.clear();
+            }
             n.sched.clear();
         }
     }

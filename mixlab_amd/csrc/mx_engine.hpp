@@ -36,6 +36,7 @@ struct Node {
     // parameter updates queued for ticks inside the next run (Engine::client_update between two ticks, src/engine.rs:192-214)
     struct SchedEv { uint32_t tick; std::vector<uint8_t> params; };
     std::vector<SchedEv> sched;
+    std::vector<std::pair<uint32_t, uint32_t>> gate_sched;   // Trigger: (tick, gate_open) -- a bench step queues ~70 000 of these, no allocation each
     // plotter
     uint64_t plot_count = 0;
     std::vector<uint8_t> plot_fired;          // per call of the last run

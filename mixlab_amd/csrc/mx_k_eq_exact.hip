@@ -377,8 +377,17 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
 // ---------------------------------------------------------------------------------------------
 typedef const float __attribute__((address_space(1)))* mx_gfp1;
 typedef float __attribute__((address_space(3)))* mx_lfp3;
-constexpr int EQ_SB = 32;                 // samples per lane per super-block
-constexpr int EQ_TILE = 64 * EQ_SB;       // floats per tile buffer
+// SB = samples per lane per super-block: 32 (one 128-byte line per chunk, 16 KiB of LDS per wave: 10 waves per CU) or 16 (half
+// lines, 8 KiB per wave: the register file, not the LDS, bounds the occupancy).  S = SB / 4 sixteen-byte slots per row; row c
+// keeps piece p in slot p ^ sw(c), sw(c) = (c >> log2(16 / S)) & (S - 1): conflict-free ds_read_b128 for either S.
+template <int SB> struct EqTileGeo {
+    static constexpr int S = SB / 4;                       // slots per row = lanes per row in a DMA instruction
+    static constexpr int ROWS = 64 / S;                    // rows per DMA instruction (1 KiB)
+    static constexpr int N_INSTR = S;                      // DMA instructions per tile
+    static constexpr int SHIFT = S == 8 ? 1 : 2;
+    static constexpr int TILE = 64 * SB;                   // floats per tile buffer
+    static __device__ __forceinline__ int sw(int row) { return (row >> SHIFT) & (S - 1); }
+};
 
 struct EqTileCtx {
     const float* in; float* out;          // stream bases of the instance
@@ -387,12 +396,14 @@ struct EqTileCtx {
 };
 
 // stage-in of the super-block whose first sample sits `so` samples from each chunk's begin (negative during the warm-up)
+template <int SB>
 __device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, int so) {
-    const int s = c.lane & 7;
+    typedef EqTileGeo<SB> G;
+    const int s = c.lane % G::S;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int cj = 8 * k + (c.lane >> 3);
-        const int pce = s ^ ((4 * k + (c.lane >> 4)) & 7);            // = s ^ ((cj >> 1) & 7): the piece that belongs in slot s of row cj
+    for (int k = 0; k < G::N_INSTR; ++k) {
+        const int cj = G::ROWS * k + c.lane / G::S;
+        const int pce = s ^ G::sw(cj);                                // the piece that belongs in slot s of row cj
         long long idx = (long long)(c.chunk0 + (uint32_t)cj) * (long long)c.C + (long long)so + 4 * pce;
         idx = idx < 0 ? 0 : idx;                                      // before the stream (chunk 0's warm-up) / past it (lanes beyond the last
         idx = idx > (long long)c.F - 4 ? (long long)c.F - 4 : idx;    // chunk): never used, keep the address legal
@@ -401,18 +412,19 @@ __device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, in
 }
 
 // compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
-template <int MODE, int ENVK, bool WARM>
+template <int SB, int MODE, int ENVK, bool WARM>
 __device__ __forceinline__ void eq_tile_compute(const EqDesc& d, const EqRun& r, float* buf, const int lane, const int so, const int len,
                                                 const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     const double g_lo = d.gain_lo, g_mid = d.gain_mid, g_hi = d.gain_hi, lo_f = r.lo_f, hi_f = r.hi_f;
     const double one_minus = d.amp_one_minus, mod_depth = d.amp_mod_depth, amplitude = d.amp_amplitude;
     const double depth_const = one_minus + mod_depth * 1.0;           // Disconnected control: mod value 1.0 (amplifier.rs:54)
-    const int sw = (lane >> 1) & 7;
-    f4v* row = reinterpret_cast<f4v*>(buf + lane * EQ_SB);
+    typedef EqTileGeo<SB> G;
+    const int sw = G::sw(lane);
+    f4v* row = reinterpret_cast<f4v*>(buf + lane * SB);
     f4v x4 = row[0 ^ sw];
 #pragma unroll 1
-    for (int pce = 0; pce < 8; ++pce) {
-        const f4v xn = row[((pce + 1) & 7) ^ sw];                     // next piece travels while this one is computed
+    for (int pce = 0; pce < G::S; ++pce) {
+        const f4v xn = row[((pce + 1) & (G::S - 1)) ^ sw];            // next piece travels while this one is computed
         if (WARM || so + 4 * pce < len) {
             f4v v;
 #pragma unroll
@@ -444,14 +456,16 @@ __device__ __forceinline__ void eq_tile_compute(const EqDesc& d, const EqRun& r,
 }
 
 // stage-out of a computed tile: whole lines, eight lanes per chunk line
-template <bool STEREO>
+template <int SB, bool STEREO>
 __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* buf, int so) {
-    const int s = c.lane & 7;
+    typedef EqTileGeo<SB> G;
+    const int s = c.lane % G::S;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < G::N_INSTR; ++k) {
         const f4v o = *reinterpret_cast<const f4v*>(buf + k * 256 + c.lane * 4);
-        const uint32_t chunk = c.chunk0 + (uint32_t)(8 * k + (c.lane >> 3));
-        const int pce = s ^ ((4 * k + (c.lane >> 4)) & 7);
+        const int cj = G::ROWS * k + c.lane / G::S;
+        const uint32_t chunk = c.chunk0 + (uint32_t)cj;
+        const int pce = s ^ G::sw(cj);
         const long long idx = (long long)chunk * (long long)c.C + (long long)so + 4 * pce;
         if (chunk < c.n_chunks && idx + 4 <= (long long)c.F) {
             if (STEREO) {
@@ -465,10 +479,11 @@ __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* b
     }
 }
 
-template <int KMODE, int KSTEREO>
+template <int SB, int KMODE, int KSTEREO>
 __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                                 uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
-    extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][EQ_TILE]
+    extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][TILE]
+    constexpr int EQ_SB = SB, EQ_TILE = EqTileGeo<SB>::TILE;
     const uint32_t inst = blockIdx.x / waves_per_inst;
     const EqDesc& d = descs[inst];
     EqTileCtx c;
@@ -493,15 +508,16 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
     int envk = 0;
     EqChunkRec* rec = recs + (size_t)inst * plan.n_chunks + (active ? j : 0);
 
-    eq_tile_issue(c, eq_tiles, -(int)plan.warm);
+    eq_tile_issue<SB>(c, eq_tiles, -(int)plan.warm);
     for (int g = 0; g < total; ++g) {
         float* buf = eq_tiles + (g & 1) * EQ_TILE;
         const int so = (g - n_warm) * EQ_SB;
-        if (g + 1 < total) eq_tile_issue(c, eq_tiles + ((g + 1) & 1) * EQ_TILE, so + EQ_SB);   // its previous tenant was stored one step ago
-        // everything but the 8 DMA just issued has landed: this super-block's tile, and the stores of the one before
-        if (g + 1 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g + 1 < total) eq_tile_issue<SB>(c, eq_tiles + ((g + 1) & 1) * EQ_TILE, so + EQ_SB);   // its previous tenant was stored one step ago
+        // everything but the DMA just issued has landed: this super-block's tile, and the stores of the one before
+        if (g + 1 < total) { if (SB == 32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (g < n_warm) {
-            if (j != 0) eq_tile_compute<EQM_PLAIN, 0, true>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            if (j != 0) eq_tile_compute<SB, EQM_PLAIN, 0, true>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
             continue;
         }
         if (g == n_warm) {   // first sample of my chunk: chunk 0 takes the carried state, the others record where the warm-up took them
@@ -525,13 +541,13 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
                 el.k0 = (uint32_t)so; el.t_chunk = r.t0 + (uint64_t)begin;
                 envk = __ballot(active && so < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so < len && el.flat == 0u) == 0ull ? 1 : 2);
             }
-            if (envk == 1) eq_tile_compute<KMODE, 1, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-            else if (envk == 2) eq_tile_compute<KMODE, 2, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-            else eq_tile_compute<KMODE, 3, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            if (envk == 1) eq_tile_compute<SB, KMODE, 1, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            else if (envk == 2) eq_tile_compute<SB, KMODE, 2, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            else eq_tile_compute<SB, KMODE, 3, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
         } else {
-            eq_tile_compute<KMODE, 0, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            eq_tile_compute<SB, KMODE, 0, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
         }
-        eq_tile_store<KSTEREO != 0>(c, buf, so);
+        eq_tile_store<SB, KSTEREO != 0>(c, buf, so);
     }
     if (active) {
 #pragma unroll
@@ -691,28 +707,27 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     const int force_c = env_int("MX_EQ_SPEC_CHUNKS", 0);     // tuning / tests: chunks per instance (1 = never speculate)
     if (force_c == 1) return false;
     if (frames < 2 * W || frames < 64) return false;          // a stream shorter than two warm-ups: one lane per instance
-    // Cost model (cycles, per SIMD): a wave issues one f64 instruction per 4 cycles and a chunk lane needs ~45 of them per
-    // sample, so a wave takes (C + W) * 180 cycles whether 1 or 64 of its lanes are active; waves queue on 1024 SIMDs.
-    // One lane per instance (no speculation) is a dependent chain of ~110 cycles per sample, 64 instances per wave.
-    const double c_issue = 180.0, c_lat = 110.0, simds = 1024.0;
-    // chunk lengths are whole ticks (an inline Envelope's state is read once per tick and every lane of a wave crosses its
-    // tick boundaries at the same step) when that is also a multiple of 16 samples, else multiples of 32 samples
+    // Plan (measured on MI355X, 1024 strips x 2048 ticks: 4.3 - 4.7 ms for 2 .. 7 waves per SIMD, 5.8 ms at 1): about three waves
+    // per SIMD over the chip (one wave = 64 chunks of one instance), chunks no shorter than three warm-ups (<= 1/3 extra work),
+    // whole ticks when that is a multiple of 16 samples (an inline Envelope's state is read once per tick and every lane of a wave
+    // crosses its tick boundaries at the same step), else multiples of 32 samples.
     const size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
     auto chunk_of = [&](size_t nc) { return ((frames + nc - 1) / nc + unit - 1) / unit * unit; };
-    auto cost = [&](size_t nc) {
-        const size_t C = chunk_of(nc);
-        const double waves = (double)n * (double)((nc + 63) / 64);
-        const double per_simd = std::ceil(waves / simds);
-        return (double)(C + W) * std::max(c_lat, c_issue * per_simd);
-    };
-    size_t best = 1; double best_cost = (double)frames * c_lat * std::ceil((double)((n + 63) / 64) / simds);
     const size_t nc_max = frames / W;                          // C >= W: a warm-up never reaches before the stream
+    size_t best;
     if (force_c > 1) best = std::min<size_t>((size_t)force_c, nc_max);
     else {
-        for (size_t nc = 2; nc <= nc_max && nc <= 4096; nc = nc < 64 ? nc + 1 : nc + 64) {
-            const double c = cost(nc);
-            if (c < best_cost * 0.999) { best_cost = c; best = nc; }
-        }
+        const size_t waves_wanted = 3 * 1024;
+        const size_t wpi = std::max<size_t>(1, (waves_wanted + n / 2) / n);
+        best = std::min<size_t>(wpi * 64, std::max<size_t>(frames / (3 * W), 1));
+        // few waves (at most ~1 per SIMD): a wave runs at its dependency latency whether 1 or 64 of its lanes work, so shorter chunks
+        // -- more lanes of the one wave, down to a chunk of one warm-up -- only shorten it
+        if ((size_t)n * ((best + 63) / 64) <= 1536) best = std::max<size_t>(best, std::min<size_t>(64, nc_max));
+        // one lane per instance (no speculation) costs `frames` dependent steps of ~110 cycles, 64 instances per wave; a chunk lane
+        // (C + W) steps of ~300 cycles when its wave has a SIMD to itself
+        const double seq = (double)frames * 110.0 * std::ceil((double)((n + 63) / 64) / 1024.0);
+        const double spec = (double)(chunk_of(best) + W) * 300.0 * std::max(1.0, (double)n * (double)((best + 63) / 64) / 3072.0);
+        if (best < 2 || spec >= seq) return false;
     }
     if (best < 2) return false;
     size_t C = chunk_of(best);
@@ -736,11 +751,13 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     EqChunkRec* recs = (EqChunkRec*)scratch;
     static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
     const int um = uniform_mode;
-    const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % EQ_SB == 0 && plan.warm % EQ_SB == 0 &&
-                       r.frames < (1ull << 31) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % EQ_SB == 0 && plan.chunk % r.fpc == 0));
+    const int sb = env_int("MX_EQ_SPEC_SB", 16) == 32 ? 32 : 16;   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
+    const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
+                       r.frames < (1ull << 31) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
     if (tiled) {
-        const size_t lds = 2 * EQ_TILE * sizeof(float);
-#define MX_GT(M, S) hipLaunchKernelGGL((k_eq_three_spec_tiled<M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs)
+        const size_t lds = 2 * 64 * (size_t)sb * sizeof(float);
+#define MX_GT(M, S) { if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
+                      else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
         switch (um) {
         case 0: MX_GT(EQM_PLAIN, 0); break;     case 1: MX_GT(EQM_PLAIN, 1); break;
         case 2: MX_GT(EQM_AMP_CONST, 0); break; case 3: MX_GT(EQM_AMP_CONST, 1); break;
