@@ -31,6 +31,16 @@ __device__ __forceinline__ float eq_step(EqPoles& s, const double lo_f, const do
     return (float)(l * g_lo + mid * g_mid + h * g_hi);
 }
 
+// the same sample with the delay-line value handed in (h0 = the input three samples back, eq_three.rs:66,80-83): callers that walk
+// four samples at a time keep the delay line as "the last three inputs" and never shift registers
+__device__ __forceinline__ float eq_step_h(EqPoles& s, const double lo_f, const double hi_f, const double g_lo, const double g_mid, const double g_hi,
+                                           const double sample, const double h0) {
+    const double l = pump(lo_f, s.lo, sample);
+    const double h = h0 - pump(hi_f, s.hi, sample);
+    const double mid = h0 - (h + l);
+    return (float)(l * g_lo + mid * g_mid + h * g_hi);
+}
+
 // Fused epilogue (see EqDesc): what StereoPanner (stereo_panner.rs:35-38), Amplifier (amplifier.rs:52-57,71-73) and -- with
 // MX_EQF_ENV -- the Envelope feeding its control (envelope.rs:34-58,117) would do to the f32 sample y the EQ just produced.
 struct EqEpi {

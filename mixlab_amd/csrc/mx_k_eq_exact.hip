@@ -178,7 +178,11 @@ __device__ __forceinline__ double env_lane_depth(const EnvParams& p, const EnvLa
     const double a = (e.on && ms < p.attack_ms) ? att : val;
     const float cc = (float)a;                                 // Envelope stores f32 (envelope.rs:117)
     const double d = one_minus + mod_depth * (double)cc;       // amplifier.rs:71-73
-    return e.flat ? e.depth : d;
+    // select, never branch: a wave that takes this form has a non-flat lane anyway, and a branch here would end the basic block --
+    // the scheduler could no longer lay the next sample's recurrence beside this sample's epilogue
+    const unsigned long long di = (unsigned long long)__double_as_longlong(d), fi = (unsigned long long)__double_as_longlong(e.depth);
+    const unsigned long long m = e.flat ? ~0ull : 0ull;
+    return __longlong_as_double((long long)((fi & m) | (di & ~m)));
 }
 
 // A run of `n` consecutive samples of one chunk through the recurrence and the epilogue: blocks of EQ_BLK samples with the next
@@ -411,12 +415,27 @@ __device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, in
     }
 }
 
+// The wave-uniform constants of the inner loops, pinned in SGPRs: read through the descriptor reference the compiler
+// re-loads them (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS queue) in the middle of the per-sample code.
+struct EqK { double lo_f, hi_f, g_lo, g_mid, g_hi, one_minus, mod_depth, amplitude, sr, rsr; EnvParams env; };
+__device__ __forceinline__ double pin_sgpr(double v) { asm volatile("; pinned %0" : "+s"(v)); return v; }
+__device__ __forceinline__ EqK eq_constants(const EqDesc& d, const EqRun& r) {
+    EqK k;
+    k.lo_f = pin_sgpr(r.lo_f); k.hi_f = pin_sgpr(r.hi_f);
+    k.g_lo = pin_sgpr(d.gain_lo); k.g_mid = pin_sgpr(d.gain_mid); k.g_hi = pin_sgpr(d.gain_hi);
+    k.one_minus = pin_sgpr(d.amp_one_minus); k.mod_depth = pin_sgpr(d.amp_mod_depth); k.amplitude = pin_sgpr(d.amp_amplitude);
+    k.sr = pin_sgpr(r.sr); k.rsr = pin_sgpr(r.rsr);
+    k.env.attack_ms = pin_sgpr(d.env.attack_ms); k.env.inv_attack = pin_sgpr(d.env.inv_attack); k.env.inv_decay = pin_sgpr(d.env.inv_decay);
+    k.env.sustain = pin_sgpr(d.env.sustain); k.env.one_minus_sustain = pin_sgpr(d.env.one_minus_sustain); k.env.inv_release = pin_sgpr(d.env.inv_release);
+    return k;
+}
+
 // compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
 template <int SB, int MODE, int ENVK, bool WARM>
-__device__ __forceinline__ void eq_tile_compute(const EqDesc& d, const EqRun& r, float* buf, const int lane, const int so, const int len,
+__device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const int lane, const int so, const int len,
                                                 const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
-    const double g_lo = d.gain_lo, g_mid = d.gain_mid, g_hi = d.gain_hi, lo_f = r.lo_f, hi_f = r.hi_f;
-    const double one_minus = d.amp_one_minus, mod_depth = d.amp_mod_depth, amplitude = d.amp_amplitude;
+    const double g_lo = K.g_lo, g_mid = K.g_mid, g_hi = K.g_hi, lo_f = K.lo_f, hi_f = K.hi_f;
+    const double one_minus = K.one_minus, mod_depth = K.mod_depth, amplitude = K.amplitude;
     const double depth_const = one_minus + mod_depth * 1.0;           // Disconnected control: mod value 1.0 (amplifier.rs:54)
     typedef EqTileGeo<SB> G;
     const int sw = G::sw(lane);
@@ -426,30 +445,33 @@ __device__ __forceinline__ void eq_tile_compute(const EqDesc& d, const EqRun& r,
     for (int pce = 0; pce < G::S; ++pce) {
         const f4v xn = row[((pce + 1) & (G::S - 1)) ^ sw];            // next piece travels while this one is computed
         if (WARM || so + 4 * pce < len) {
-            f4v v;
+            // the delay line is "the last three inputs" (s.h0, s.h1, s.h2 = x[i-3], x[i-2], x[i-1]): the four samples of a piece read
+            // s.h0, s.h1, s.h2 and the piece's own first input, then the piece's last three inputs become the delay line -- no shifts
+            const double dx[4] = {(double)x4[0], (double)x4[1], (double)x4[2], (double)x4[3]};
+            if (WARM) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = x4[e];
-                if (WARM) {
-                    const double xd = (double)x;
-                    pump(lo_f, s.lo, xd); pump(hi_f, s.hi, xd);
-                    s.h0 = s.h1; s.h1 = s.h2; s.h2 = xd;
-                } else {
-                    const uint32_t b = __float_as_uint(x); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
-                    const float y = eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x);
+                for (int e = 0; e < 4; ++e) { pump(lo_f, s.lo, dx[e]); pump(hi_f, s.hi, dx[e]); }
+            } else {
+                const double hh[4] = {s.h0, s.h1, s.h2, dx[0]};
+                f4v v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t b = __float_as_uint(x4[e]); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
+                    const float y = eq_step_h(s, lo_f, hi_f, g_lo, g_mid, g_hi, dx[e], hh[e]);
                     if (MODE == EQM_PLAIN) v[e] = y;
                     else {
                         double depth;
                         const uint32_t kk = (uint32_t)(so + 4 * pce + e);      // sample index inside the chunk; el.dt0 counts from the tick's first sample
                         if (MODE == EQM_AMP_CONST) depth = depth_const;
                         else if (ENVK == 1) depth = el.depth;
-                        else if (ENVK == 2) depth = env_lane_depth(d.env, el, kk - el.k0, one_minus, mod_depth, r.sr, r.rsr);
-                        else depth = env_depth(d.env, cur, one_minus, mod_depth, el.t_chunk + kk, r.sr, r.rsr);
+                        else if (ENVK == 2) depth = env_lane_depth(K.env, el, kk - el.k0, one_minus, mod_depth, K.sr, K.rsr);
+                        else depth = env_depth(K.env, cur, one_minus, mod_depth, el.t_chunk + kk, K.sr, K.rsr);
                         v[e] = amp_apply(y, depth, amplitude);
                     }
                 }
+                row[pce ^ sw] = v;
             }
-            if (!WARM) row[pce ^ sw] = v;
+            s.h0 = dx[1]; s.h1 = dx[2]; s.h2 = dx[3];
         }
         x4 = xn;
     }
@@ -486,6 +508,7 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
     constexpr int EQ_SB = SB, EQ_TILE = EqTileGeo<SB>::TILE;
     const uint32_t inst = blockIdx.x / waves_per_inst;
     const EqDesc& d = descs[inst];
+    const EqK K = eq_constants(d, r);
     EqTileCtx c;
     c.in = d.in; c.out = d.out;
     c.chunk0 = (blockIdx.x % waves_per_inst) * 64u; c.n_chunks = plan.n_chunks; c.C = plan.chunk; c.F = (uint32_t)r.frames;
@@ -517,7 +540,7 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
         if (g + 1 < total) { if (SB == 32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (g < n_warm) {
-            if (j != 0) eq_tile_compute<SB, EQM_PLAIN, 0, true>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            if (j != 0) eq_tile_compute<SB, EQM_PLAIN, 0, true>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
             continue;
         }
         if (g == n_warm) {   // first sample of my chunk: chunk 0 takes the carried state, the others record where the warm-up took them
@@ -537,15 +560,15 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
                 const size_t tk = ((size_t)begin + (size_t)so) / r.fpc;
                 cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
                 const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so;
-                el = env_lane_coeffs(d.env, cur, t, r.fpc);
+                el = env_lane_coeffs(K.env, cur, t, r.fpc);
                 el.k0 = (uint32_t)so; el.t_chunk = r.t0 + (uint64_t)begin;
                 envk = __ballot(active && so < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so < len && el.flat == 0u) == 0ull ? 1 : 2);
             }
-            if (envk == 1) eq_tile_compute<SB, KMODE, 1, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-            else if (envk == 2) eq_tile_compute<SB, KMODE, 2, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-            else eq_tile_compute<SB, KMODE, 3, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            if (envk == 1) eq_tile_compute<SB, KMODE, 1, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            else if (envk == 2) eq_tile_compute<SB, KMODE, 2, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            else eq_tile_compute<SB, KMODE, 3, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
         } else {
-            eq_tile_compute<SB, KMODE, 0, false>(d, r, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            eq_tile_compute<SB, KMODE, 0, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
         }
         eq_tile_store<SB, KSTEREO != 0>(c, buf, so);
     }
