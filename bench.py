@@ -1,23 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the per-tick module-graph hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): 1024 channel strips
+Workload (BASELINE.json configs[1]; SURVEY.md section 8d config 2 AS WRITTEN): 1024 channel strips
   Trigger -> Envelope ;  Source(noise) -> EqThree -> StereoPanner(L=R) -> Amplifier(ctl = Envelope) -> Mixer(1024)
-at 48 kHz (SPT = 800), T ticks batched per submission ("step" = one pass of the whole graph over T
-ticks of synthetic input already resident in HBM).  Metric: audio channels mixed per second =
+at 48 kHz (SPT = 800), every strip's gate toggling every 30 ticks with phase k mod 60 -- applied BETWEEN ticks of the
+batch through mx_graph_schedule_params_batch (the reference's client_update between two ticks, src/engine.rs:192-214) --
+T ticks batched per submission ("step" = one pass of the whole graph over T ticks of synthetic input already resident in
+HBM).  EqThree runs in the reference's exact order (the library default).  Metric: audio channels mixed per second =
 strip-ticks (one stereo strip processed and mixed for one 1/60 s tick) per second, whole job.
 
-N > 1 (BASELINE.json configs[4]): the 1024 strips are sharded contiguously over the
-ranks (strong scaling), each rank runs Mixer(1024/N) over its strips, and the partial Master/Cue buses
-are summed in rank order by a Mixer(N, unity) -- i.e. the reference-expressible hierarchical graph
-N x Mixer(1024/N) -> Mixer(N) -- with every rank ending up with the whole bus.  Exchange over RCCL: an
-all-to-all of time slices, the ordered sum of the own slice, an all-gather of the finished slices
-(the ordered form of reduce-scatter + all-gather; --exchange allgather gathers whole partials instead).
+N > 1 (BASELINE.json configs[4]): the 1024 strips are sharded contiguously over the ranks (strong
+scaling), each rank runs Mixer(1024/N) over its strips, and the partial Master / Cue buses are combined by
+mixlab_amd/exchange.py (rank-ordered sum = the reference-expressible graph N x Mixer(1024/N) -> Mixer(N); --exchange
+allreduce is the north-star's non-parity collective).
 
-One JSON line on rank 0; see the task contract for the fields.  `roofline` describes the kernel
-that took the most device time in the timed region (hipEvents on the graph's stream);
-`cpu_baseline` is the CPU oracle (a C port of the reference algorithms, one thread like the
-reference's engine thread) timed on a bounded sample of the same workload.
+One JSON line on rank 0; see the task contract for the fields.  `roofline` describes the launch group that took the most
+device time in the timed region (hipEvents on the graph's stream, recorded inside the timed region); `roofline.per_kernel`
+lists MOVED-byte fractions for every kernel family; `repeats` shows the spread of further repetitions of the same K steps;
+`held_gates` is the same job with every gate held (the round-1 configuration); `cpu_baseline` is the CPU oracle (a C port of
+the reference algorithms, one thread like the reference's engine thread, built on this host) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -36,15 +37,15 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
-# algorithmic (module-boundary) bytes per instance per frame: every input port read once + every
-# output port written once; mixer is per input channel, +16/frame for its two outputs
+# algorithmic (module-boundary) bytes per instance per frame: every input port read once + every output port written once
+# (SURVEY.md section 8d); mixer is per input channel, +16 / frame for its two outputs.  Used only with --no-fuse, where every
+# port really is materialised.
 BYTES_PER_FRAME = {"trigger": 4, "envelope": 8, "eq_three": 8, "stereo_panner": 16, "amplifier": 20, "mixer": 8}
-# with the graph compiler's fusion (default): Trigger folded into Envelope (gate never materialised),
-# StereoPanner + Amplifier folded into the EqThree kernel (reads source + control, writes the stereo strip)
-# Trigger + Envelope + StereoPanner + Amplifier all folded into the EqThree kernel, whose stereo result
-# (L == R) is stored as one float per frame: it reads the source and writes 4 B per frame; the Mixer reads 4 B
-BYTES_PER_FRAME_FUSED = {"envelope": 4, "eq_three": 4 + 4, "mixer": 4}
-STRIP_BYTES_FUSED_48K = (8 + 4) * 800   # per strip-tick: fused EQ (in, out) + mixer read
+# default (graph-compiler fusion): Trigger + Envelope + EqThree + StereoPanner + Amplifier are ONE kernel that reads the source
+# (4 B / frame) and writes the strip as one float per frame (L == R): 8 B / frame = SURVEY 8d's 2M per EqThree channel-tick;
+# the Mixer reads those 4 B.  These are bytes that move.
+BYTES_PER_FRAME_FUSED = {"eq_three": 4 + 4, "mixer": 4}
+F64_VALU_PEAK_TOPS = 39.3   # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz f64 instructions / s (an FMA counts once)
 
 
 def gate_open(tick, k):
@@ -54,24 +55,26 @@ def gate_open(tick, k):
 
 def gate_events(abi, trigs, first_strip, t0, n_ticks):
     """The toggles of every strip's Trigger that fall INSIDE ticks (t0, t0 + n_ticks) as one mx_param_event array for
-    mx_graph_schedule_params_batch (the state at t0 itself is what the previous step left, or the initial params).
-    Returns (ctypes array, keep-alive list) or None."""
+    mx_graph_schedule_params_batch (the gate at t0 itself is what the previous step left, or the initial params).
+    Returns (ctypes pointer, count, keep-alive tuple) or None.  Built with numpy: ~70 000 events per 2048-tick step."""
     import ctypes as C
     p_open, p_closed = abi.TriggerParams(1), abi.TriggerParams(0)
-    po, pc = C.cast(C.pointer(p_open), C.c_void_p), C.cast(C.pointer(p_closed), C.c_void_p)
-    ev = []
-    for j, tr in enumerate(trigs):
-        k = first_strip + j
-        c = 30 - (t0 + k) % 30                      # first toggle after t0
-        while c < n_ticks:
-            ev.append((tr, c, po if gate_open(t0 + c, k) else pc))
-            c += 30
-    if not ev:
+    po, pc = C.addressof(p_open), C.addressof(p_closed)
+    k = first_strip + np.arange(len(trigs), dtype=np.int64)
+    first = 30 - (t0 + k) % 30                                    # first toggle after t0, per strip
+    n_ev = np.maximum(0, (n_ticks - first + 29) // 30)            # toggles at first, first + 30, ... < n_ticks
+    total = int(n_ev.sum())
+    if total == 0:
         return None
-    arr = (abi.ParamEvent * len(ev))()
-    for i, (tr, c, pp) in enumerate(ev):
-        arr[i].node = tr; arr[i].tick_in_run = c; arr[i].params = pp; arr[i].params_len = C.sizeof(abi.TriggerParams)
-    return arr, (p_open, p_closed)
+    strip = np.repeat(np.arange(len(trigs)), n_ev)
+    j = np.arange(total) - np.repeat(np.cumsum(n_ev) - n_ev, n_ev)
+    tick = first[strip] + 30 * j
+    opens = ((t0 + tick + k[strip]) // 30) % 2 == 1
+    ev = np.zeros(total, dtype=np.dtype([("node", "<u4"), ("tick_in_run", "<u4"), ("params", "<u8"), ("params_len", "<u8")], align=True))
+    assert ev.dtype.itemsize == C.sizeof(abi.ParamEvent)
+    ev["node"] = np.asarray(trigs, dtype=np.uint32)[strip]; ev["tick_in_run"] = tick
+    ev["params"] = np.where(opens, po, pc); ev["params_len"] = C.sizeof(abi.TriggerParams)
+    return ev.ctypes.data_as(C.POINTER(abi.ParamEvent)), total, (ev, p_open, p_closed)
 
 
 def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=None, total=None, want_trigs=False):
@@ -105,28 +108,51 @@ def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=N
     return ws, mix, srcs
 
 
-def cpu_baseline(Workspace, synth, abi, n_strips, sample_rate, target_seconds=12.0):
-    """Time the CPU oracle's graph runner (C, one thread) on a bounded sample of the same workload."""
+def native_oracle():
+    """Build the CPU oracle ON THIS HOST with -O3 -march=native (same sources, same -ffp-contract=off -fno-fast-math: same
+    results) for the timed baselines; falls back to the library shipped with the repo.  Must run before `import oracle`."""
+    import subprocess
+    import tempfile
+    out = pathlib.Path(tempfile.gettempdir()) / f"libmixlab_oracle_native_{os.getpid()}.so"
+    try:
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "ARCH=native", f"OUT={out}"], check=True, capture_output=True)
+        os.environ["MIXLAB_ORACLE_LIB"] = str(out)
+        return "gcc -O3 -march=native -ffp-contract=off -fno-fast-math, built on this host"
+    except (OSError, subprocess.CalledProcessError):
+        return "library shipped with the repo (-O3 -march=x86-64-v3)"
+
+
+def cpu_baseline(Workspace, synth, abi, n_strips, sample_rate, build_note, target_seconds=12.0):
+    """Time the CPU oracle's graph runner (C, one thread) on a bounded sample of the same workload, gates toggling every
+    30 ticks (ModuleT::update between ticks, as the reference's client_update does)."""
     import oracle  # test infrastructure: used here only as the timed CPU baseline
 
-    ws, mix, srcs = build_strips(abi, Workspace, synth, n_strips, 0, sample_rate)
+    ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, n_strips, 0, sample_rate, want_trigs=True)
     og = oracle.OracleGraph(ws)
     spt = ws.spt
     noise = [synth.noise(k, spt) for k in range(n_strips)]
     for s, nz in zip(srcs, noise):
         og.set_source(s, nz)
-    # calibrate on a few ticks, then run a bounded number
+    p_open, p_closed = abi.TriggerParams(1), abi.TriggerParams(0)
+
+    def tick(t):
+        for k in range(n_strips):                      # the strips whose gate toggles before this tick
+            if t and (t + k) % 30 == 0:
+                og.update_params(trigs[k], p_open if gate_open(t, k) else p_closed)
+        og.run_tick(t)
+
     t0 = time.perf_counter()
     for t in range(4):
-        og.run_tick(t)
+        tick(t)
     per_tick = (time.perf_counter() - t0) / 4
     n_ticks = int(max(8, min(4000, target_seconds / max(per_tick, 1e-6))))
     t0 = time.perf_counter()
-    og.run_ticks(4, n_ticks)
+    for t in range(4, 4 + n_ticks):
+        tick(t)
     dt = time.perf_counter() - t0
     return {
-        "value": n_strips * n_ticks / dt, "unit": "channel-ticks/s", "cores": 1, "kind": "port",
-        "sample": f"{n_strips} strips x {n_ticks} ticks @ {sample_rate} Hz, single thread (the reference engine is one thread, src/engine.rs:78), {dt:.1f} s",
+        "value": n_strips * n_ticks / dt, "unit": "channel-ticks/s", "cores": 1, "kind": "port", "build": build_note,
+        "sample": f"{n_strips} strips x {n_ticks} ticks @ {sample_rate} Hz, gates toggling every 30 ticks, single thread (the reference engine is one thread, src/engine.rs:78), {dt:.1f} s",
         "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
     }
 
@@ -189,17 +215,19 @@ def cpu_baseline_all_cores(Workspace, synth, abi, shard, n_strips, sample_rate, 
     dt = timed(n_ticks)
     return {"value": n_strips * n_ticks / dt, "unit": "channel-ticks/s", "cores": n_thr, "kind": "port",
             "cpu_quota_cores": quota, "host_logical_cpus": os.cpu_count(),
-            "sample": f"{n_strips} strips in {n_thr} contiguous shards (one thread each) x {n_ticks} ticks @ {sample_rate} Hz, {dt:.1f} s"}
+            "sample": f"{n_strips} strips in {n_thr} contiguous shards (one thread each) x {n_ticks} ticks @ {sample_rate} Hz, gates held, {dt:.1f} s"}
 
 
 VIDEO_FADERS = [1.0, 0.75, 0.5, 0.5, 0.25, 0.9, 0.1]
 VIDEO_MATRIX = [3900, 150, 46, 4096, 60, 3980, 56, -2048, 20, 120, 3956, 0]
 
 
-def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
+def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16):
     """BASELINE.json configs[3]: 8 layers (6 x 1080p + 2 x 720p) every tick ->
     cascade of 7 reference VideoMixer cross-fades (scale + letterbox for the 720p layers) ->
     build-specified YUV420P->RGBA + colour matrix.  One composited 1080p RGBA frame per tick.
+    Every source delivers a NEW frame each tick out of a ring of `n_sets` distinct frames (16 sets x 21.4 MB = 342 MB > the
+    256 MiB Infinity Cache), so the layers come from HBM, not from cache.
     N > 1: every rank composites its own independent 8-layer stream (independent VideoMixer
     instances) -- no exchange step, weak scaling."""
     import synth   # seeded synthetic patterns (numpy only)
@@ -220,10 +248,12 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
     g = ws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
     keep = []
     for k, (w, h) in enumerate(sizes):
-        y, u, v = synth.yuv_pattern(w, h, k, seed=3)
-        d = video.DFrame(w, h).upload(y, u, v)
-        keep.append(d)
-        video.graph_set_video_source(g, srcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)
+        ring = []
+        for r in range(n_sets):
+            y, u, v = synth.yuv_pattern(w, h, k, seed=3 + r)
+            ring.append(video.DFrame(w, h).upload(y, u, v))
+        keep.append(ring)
+        video.graph_set_video_source_ring(g, srcs[k], ring, dur=(1, 60), off=(0, 1))
     steps = max(1, frames // T)
     for i in range(max(1, warmup)):
         g.run_ticks(i * T, T)
@@ -246,18 +276,25 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup):
         dt = float(tt.item())
     F = 1920 * 1080 * 3 // 2
     F720 = 1280 * 720 * 3 // 2
-    # algorithmic bytes per composited frame, module-boundary accounting:
-    # 7 cross-fades x 3F + 2 scales (F720 in + F out) + RGBA (F in + 4wh out)
+    # bytes per composited frame.  Module-boundary accounting (every VideoMixer output materialised):
+    # 7 cross-fades x 3F + 2 scales (F720 in + F out) + RGBA (F in + 4wh out).  MOVED by the two fused kernels: the batched scaler
+    # reads 2 x F720 and writes 2 x F; the chain kernel reads 8 F (six layers + the two scaled ones) and writes the RGBA frame.
     alg = 7 * 3 * F + 2 * (F720 + F) + (F + 1920 * 1080 * 4)
-    dev_ms = by_kind.get("video_mixer", 0.0) / max(1, n_prof) / T   # device time per composited frame
+    moved_scaler = 2 * (F720 + F)
+    moved_chain = 8 * F + 1920 * 1080 * 4
+    dev_ms = by_kind.get("video_mixer", 0.0) / max(1, n_prof) / T   # device time per composited frame (scaler + chain)
     n_frames = steps * T * world
     return {
         "metric": "1080p_composited_fps", "value": n_frames / dt, "unit": "frames/s", "scaling": "weak",
         "workload": "8 layers (6x1080p + 2x720p yuv420p) -> 7 VideoMixer cross-fades (+2 bicubic letterbox scales) -> YUV->RGBA + 3x4 matrix",
+        "inputs": f"a new frame per layer per tick out of rings of {n_sets} distinct device frames ({n_sets * (6 * F + 2 * F720) / 1e6:.0f} MB in all: HBM-resident, beyond the 256 MiB Infinity Cache)",
         "frames": n_frames, "realtime_1080p60_streams_equiv": n_frames / dt / 60.0,
-        "device_us_per_frame": round(dev_ms * 1e3, 2), "algorithmic_bytes_per_frame": alg,
-        "hbm_frac_device": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
-        "hbm_frac_wall": round(alg * n_frames / world / dt / 1e9 / HBM_PEAK_GBS, 4),
+        "device_us_per_frame": round(dev_ms * 1e3, 2),
+        "moved_bytes_per_frame": moved_scaler + moved_chain, "module_boundary_bytes_per_frame": alg,
+        "hbm_frac_moved_bytes_device": round((moved_scaler + moved_chain) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
+        "hbm_frac_moved_bytes_wall": round((moved_scaler + moved_chain) * n_frames / world / dt / 1e9 / HBM_PEAK_GBS, 4),
+        "per_kernel_moved_bytes": {"k_scale_bicubic_tiled (2 layers, one launch)": moved_scaler, "k_fade_chain_rgba": moved_chain,
+                                   "note": "per-kernel durations and PMC traffic: profiles/r02 (the hipEvents here bracket the whole per-tick video section)"},
     }
 
 
@@ -457,31 +494,22 @@ def fir_cpu_baseline(T_ref_ticks=8, n_ch=8):
             "sample": f"{n_ch} of the 256 stereo channels x {n_ticks} ticks, single thread, {dt:.1f} s"}
 
 
-class _DevArray:
-    """zero-copy torch view of a device buffer owned by libmixlab_gpu (plumbing for RCCL)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
-def dev_view(torch, ptr, n):
-    return torch.as_tensor(_DevArray(ptr, n), device="cuda")
-
-
-def pmc_traffic(dom, args, world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json,
-    collected with this same command under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`); None when the run's configuration
-    differs from the profiled one -- counters cannot be read from inside the process."""
+def pmc_traffic(kernel, args, world, toggling):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r02/pmc_traffic.json, collected
+    with this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide streaming reads); None when the run's configuration differs from the profiled one
+    -- counters cannot be read from inside the process."""
     try:
-        rec = json.load(open(ROOT / "profiles" / "r01" / "pmc_traffic.json"))
+        rec = json.load(open(ROOT / "profiles" / "r02" / "pmc_traffic.json"))
     except (OSError, ValueError):
         return None, None
     c = rec.get("config", {})
     same = (c.get("strips") == args.strips and c.get("ticks_per_step") == args.ticks_per_step and c.get("sample_rate") == args.sample_rate
-            and c.get("fused") == (not args.no_fuse) and c.get("eq_exact") == bool(args.eq_exact) and c.get("n_gpus") == world)
-    if not same or dom not in rec.get("bytes_per_launch", {}):
+            and c.get("fused") == (not args.no_fuse) and c.get("eq_fast") == bool(args.eq_fast) and c.get("n_gpus") == world
+            and c.get("gates_toggle") == bool(toggling))
+    if not same or kernel not in rec.get("bytes_per_launch", {}):
         return None, None
-    return rec["bytes_per_launch"][dom], "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    return rec["bytes_per_launch"][kernel], "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
 
 
 def _cpu_model():
@@ -502,14 +530,16 @@ def main():
     ap.add_argument("--strips", type=int, default=1024)
     ap.add_argument("--ticks-per-step", type=int, default=2048, help="ticks batched per submission (SURVEY 8d: throughput mode; 1 = real-time mode)")
     ap.add_argument("--sample-rate", type=int, default=48000)
-    ap.add_argument("--eq-exact", action="store_true", help="strictly sequential EqThree (bit-exact order) instead of the time-parallel scan")
+    ap.add_argument("--eq-fast", action="store_true", help="MX_FLAG_EQ_FAST: the time-parallel EqThree scan (<= 1 ULP, NOT bit-exact) instead of the exact default")
+    ap.add_argument("--hold-gates", action="store_true", help="no per-tick gate schedule: every gate held for the whole run (the round-1 configuration)")
     ap.add_argument("--no-fuse", action="store_true", help="materialise every port (MX_FLAG_NO_FUSE): module-boundary traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", choices=["auto", "slices", "allgather"], default="auto",
-                    help="N > 1 bus exchange: ordered reduce-scatter + all-gather over time slices (2(N-1)/N bus lengths received per rank; auto: N >= 4) "
-                         "or one all-gather of the whole partial buses (N-1 bus lengths; auto: N < 4)")
-    ap.add_argument("--force-combine", action="store_true", help="debug: run the N>1 all-gather + combine path at N=1 (single-rank RCCL group)")
+    ap.add_argument("--exchange", choices=["auto", "slices", "allgather", "allreduce"], default="auto",
+                    help="N > 1 bus exchange (mixlab_amd/exchange.py): ordered reduce-scatter + all-gather over time slices (auto: N >= 4), one all-gather of "
+                         "the whole partial buses (auto: N < 4), or ncclAllReduce (NOT the sum order of a reference graph: non-parity)")
+    ap.add_argument("--force-combine", action="store_true", help="run the N > 1 exchange path at N = 1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
+    ap.add_argument("--repeats", type=int, default=4, help="further repetitions of the K timed steps after the headline region (spread of the clock)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the one-tick-per-submission leg (hundreds of tiny dispatches: slow under a counter-collecting profiler)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 240-strip + 8-layer real-time leg")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
@@ -541,10 +571,11 @@ def main():
     T, SR = args.ticks_per_step, args.sample_rate
     spt = SR // 60
     first, local_strips = shard.strip_range(rank, world, args.strips)
+    toggling = not args.hold_gates
 
     stream = torch.cuda.Stream()
-    flags = (abi.FLAG_EQ_EXACT if args.eq_exact else 0) | (abi.FLAG_NO_FUSE if args.no_fuse else 0)
-    ws, mix, srcs = build_strips(abi, Workspace, synth, local_strips, first, SR)
+    flags = (abi.FLAG_EQ_FAST if args.eq_fast else 0) | (abi.FLAG_NO_FUSE if args.no_fuse else 0)
+    ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, local_strips, first, SR, want_trigs=True)
     g = ws.build(max_ticks_per_run=T, flags=flags, device=local_rank, stream=stream.cuda_stream)
 
     # synthetic sources, resident in HBM before the timed region (uploaded once, re-read every step)
@@ -554,131 +585,110 @@ def main():
         blk = synth.noise(first + j, base_ticks * spt)
         g.write_source(s, np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt], T)
 
-    # N > 1: the partial buses of all ranks are summed in rank order -- Mixer(N, unity gains) -- and every rank ends with the
-    # whole bus.  Exchange (mixlab_amd/shard.py): the ordered form of reduce-scatter + all-gather when the step divides into
-    # N time slices (an all-to-all hands rank j slice j of every partial, rank j sums them, an all-gather distributes the
-    # finished slices: 2 (N-1)/N bus lengths received per rank), else one all-gather of the whole partials ((N-1) bus lengths).
-    combine = None
-    exchange = None
+    ex = None
     if use_dist:
-        # The exchange is pipelined against the next step's compute: partial buses are packed into one of two
-        # buffers on the compute stream, and a second stream runs the collectives and the rank-ordered Mixer(N)
-        # while the compute stream is already on step i+1.  Steady-state step time = max(compute, exchange).
-        m_ptr, fpt = g.output_device_ptr(mix, 0)
-        c_ptr, _ = g.output_device_ptr(mix, 1)
-        n_fl = fpt * T
-        m_view, c_view = dev_view(torch, m_ptr, n_fl), dev_view(torch, c_ptr, n_fl)
-        # Master and Cue are neighbours in the graph's slab: one device-to-device copy packs both
-        mc_view = dev_view(torch, m_ptr, 2 * n_fl) if c_ptr == m_ptr + 4 * n_fl else None
-        comm = torch.cuda.Stream()
-        sliced = (args.exchange == "slices" or (args.exchange == "auto" and world >= 4)) and T % world == 0
-        exchange = "alltoall + ordered sum + allgather (slices)" if sliced else "allgather + ordered sum"
-        slots = []
-        for _slot in range(2):
-            cws = Workspace(SR, 60)
-            fm = cws.mixer(shard.combine_channels(world))   # unity gains: the f32 sum of partials in rank order
-            fc = cws.mixer(shard.combine_channels(world))
-            c_srcs_m = [cws.source_stereo() for _ in range(world)]
-            c_srcs_c = [cws.source_stereo() for _ in range(world)]
-            for r in range(world):
-                cws.connect(c_srcs_m[r], 0, fm, r)
-                cws.connect(c_srcs_c[r], 0, fc, r)
-            if sliced:
-                L, offs = shard.slice_layout(world, n_fl)
-                t_slice = T // world
-                send = torch.empty(world * 2 * L, dtype=torch.float32, device="cuda")
-                recv = torch.empty(world * 2 * L, dtype=torch.float32, device="cuda")
-                fin = torch.empty(2 * L, dtype=torch.float32, device="cuda")
-                final_all = torch.empty(world * 2 * L, dtype=torch.float32, device="cuda")
-                cg = cws.build(max_ticks_per_run=t_slice, device=local_rank, stream=comm.cuda_stream)
-                for r in range(world):
-                    cg.bind_source_device(c_srcs_m[r], recv.data_ptr() + offs[r][0] * 4)
-                    cg.bind_source_device(c_srcs_c[r], recv.data_ptr() + offs[r][1] * 4)
-                fm_ptr, _ = cg.output_device_ptr(fm, 0)
-                fc_ptr, _ = cg.output_device_ptr(fc, 0)
-                slots.append({"send": send, "recv": recv, "fin": fin, "final_all": final_all, "cg": cg, "t_slice": t_slice, "L": L,
-                              "fm_view": dev_view(torch, fm_ptr, L), "fc_view": dev_view(torch, fc_ptr, L),
-                              "packed": torch.cuda.Event(), "done": torch.cuda.Event(), "used": False})
-            else:
-                part_len, offs = shard.packed_layout(world, n_fl)
-                part = torch.empty(part_len, dtype=torch.float32, device="cuda")
-                gathered = torch.empty(world * part_len, dtype=torch.float32, device="cuda")
-                cg = cws.build(max_ticks_per_run=T, device=local_rank, stream=comm.cuda_stream)
-                for r in range(world):
-                    cg.bind_source_device(c_srcs_m[r], gathered.data_ptr() + offs[r][0] * 4)
-                    cg.bind_source_device(c_srcs_c[r], gathered.data_ptr() + offs[r][1] * 4)
-                slots.append({"part": part, "gathered": gathered, "cg": cg, "packed": torch.cuda.Event(), "done": torch.cuda.Event(), "used": False})
+        from mixlab_amd.exchange import BusExchange
+        ex = BusExchange(torch, dist, g, mix, T, SR, local_rank, stream, mode=args.exchange)
 
-        def combine(i):
-            sl = slots[i % 2]
-            if sl["used"]:
-                stream.wait_event(sl["done"])          # the exchange that last used this slot has finished
-            if sliced:                                 # device-to-device pack on the compute stream: [dest][master slice | cue slice]
-                sv = sl["send"].view(world, 2, sl["L"])
-                sv[:, 0, :].copy_(m_view.view(world, sl["L"]))
-                sv[:, 1, :].copy_(c_view.view(world, sl["L"]))
-            elif mc_view is not None:
-                sl["part"].copy_(mc_view)              # device-to-device pack of (master, cue) on the compute stream
-            else:
-                sl["part"][:n_fl].copy_(m_view)
-                sl["part"][n_fl:].copy_(c_view)
-            sl["packed"].record(stream)
-            with torch.cuda.stream(comm):
-                comm.wait_event(sl["packed"])
-                if sliced:
-                    dist.all_to_all_single(sl["recv"], sl["send"])            # slice j of every rank's partial buses -> rank j
-                    sl["cg"].run_ticks(0, sl["t_slice"])                      # rank-ordered f32 sum of my slice: Mixer(N, unity)
-                    sl["fin"][: sl["L"]].copy_(sl["fm_view"]); sl["fin"][sl["L"]:].copy_(sl["fc_view"])
-                    dist.all_gather_into_tensor(sl["final_all"], sl["fin"])   # every rank ends with the whole Master and Cue
-                else:
-                    dist.all_gather_into_tensor(sl["gathered"], sl["part"])   # ONE all-gather per step (RCCL over xGMI)
-                    sl["cg"].run_ticks(0, T)                                   # rank-ordered f32 sum: Mixer(N, unity)
-                sl["done"].record(comm)
-            sl["used"] = True
+    # every step's gate toggles, built before any clock starts (the schedule is host data, like the params a UI would send)
+    n_regions = 1 + (max(0, args.repeats) if not use_dist else 0)
+    n_sched = args.warmup + args.steps * n_regions + 4
+    events = [gate_events(abi, trigs, first, i * T, T) if toggling else None for i in range(n_sched)]
 
-    def step(i):
+    def step(i, scheduled=True):
+        if scheduled and events[i] is not None:
+            g.schedule_params_batch(events[i][0], events[i][1])
         g.run_ticks(i * T, T)
-        if combine is not None:
-            combine(i)
+        if ex is not None:
+            ex.submit(i)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    def timed_region(i0, k, scheduled=True):
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(i0 + i, scheduled)
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0
+
+    held = None
     with torch.cuda.stream(stream):
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
-        barrier()
         # per-kernel hipEvents cost a few us of stream time each: at N = 1 they sit inside the timed region (the
         # roofline contract), at N > 1 -- where a step is ~8x shorter -- they are taken on extra steps after it
         prof_in_region = not args.no_profile and not use_dist
         g.profile_enable(prof_in_region)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
+        dt = timed_region(args.warmup, args.steps)                      # THE timed region: exactly K steps
+        nxt = args.warmup + args.steps
         if use_dist and not args.no_profile:
             g.profile_enable(True)
             for i in range(3):
-                step(args.warmup + args.steps + i)
+                step(nxt + i)
             torch.cuda.synchronize()
         g.profile_enable(False)
         by_kind, prof_total_ms, n_prof = g.profile_collect()
+        spec_ran, spec_repaired = g.eq_spec_stats()
+        # the spread of the clock: the same K steps again, a few times (not part of `value`)
+        rep_ms = [dt / args.steps * 1e3]
+        if not use_dist:
+            for r in range(max(0, args.repeats)):
+                rep_ms.append(timed_region(nxt, args.steps) / args.steps * 1e3)
+                nxt += args.steps
+        # the same job with every gate held where it stands (round 1 measured this): the Envelope is flat most of the time
+        if toggling and not use_dist:
+            g.profile_enable(not args.no_profile)
+            dt_h = timed_region(nxt, min(args.steps, 10), scheduled=False)
+            g.profile_enable(False)
+            hk, _ht, hn = g.profile_collect()
+            held = {"ms_per_step": dt_h / min(args.steps, 10) * 1e3, "value": args.strips * T * min(args.steps, 10) / dt_h, "unit": "channel-ticks/s",
+                    "kernel_ms_per_step": {k: round(v / max(1, hn), 5) for k, v in sorted(hk.items()) if v > 0},
+                    "note": "gates held for the whole run: the inline Envelope is flat (sustain / silent) except for the first seconds"}
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    exch = None
+    if ex is not None:
+        # what the exchange costs on its own stream: K more steps with an event pair around the exchange of each
+        with torch.cuda.stream(stream):
+            evs = []
+            for i in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g.run_ticks((nxt + i) * T, T)
+                with torch.cuda.stream(ex.comm):
+                    pass
+                ex.comm.wait_stream(stream)
+                e0.record(ex.comm)
+                ex.submit(nxt + i)
+                e1.record(ex.comm)
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+        ex_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+        exch = {"mode": ex.mode, "rccl_ranks": dist.get_world_size(), "bytes_received_per_rank_per_step": ex.bytes_received_per_step(),
+                "exchange_ms_per_step": round(ex_ms, 4), "parity": "rank-ordered f32 sum (the graph N x Mixer(strips/N) -> Mixer(N))" if ex.mode != "allreduce"
+                else "NONE: ncclAllReduce order is not a reference graph's"}
+        if ex.mode == "allreduce" and world > 1:
+            # measured deviation of the all-reduce from the ordered sum of the same partial buses
+            ordered = BusExchange(torch, dist, g, mix, T, SR, local_rank, stream, mode="allgather")
+            with torch.cuda.stream(stream):
+                g.run_ticks((nxt + 8) * T, T); ex.submit(0); ordered.submit(0)
+                torch.cuda.synchronize()
+            exch["max_ulp_vs_ordered_sum"] = ex.max_ulp_vs(0, *ordered.result(0))
+
     # real-time regime: one 60 Hz tick per submission, synchronised every tick like a live engine
     realtime = None
     if not use_dist and not args.no_realtime:
         with torch.cuda.stream(stream):
-            base_t = (args.warmup + args.steps + 4) * T
+            base_t = (nxt + 16) * T
             for i in range(20):
                 g.run_ticks(base_t + i, 1)
             g.sync()
@@ -689,7 +699,7 @@ def main():
                 g.sync()
             tick_us = (time.perf_counter() - t0) / n_rt * 1e6
         realtime = {"ticks_per_submission": 1, "tick_us": round(tick_us, 1), "tick_budget_us": round(1e6 / 60.0, 1),
-                    "headroom": round(1e6 / 60.0 / tick_us, 1), "note": "submit + wait per tick (host-paired), same 1024-strip graph"}
+                    "headroom": round(1e6 / 60.0 / tick_us, 1), "note": "submit + wait per tick (host-paired), same 1024-strip graph, exact EqThree"}
 
     video = None
     if args.video_frames > 0:
@@ -709,38 +719,49 @@ def main():
     if rank == 0:
         units = args.strips * T * args.steps
         value = units / dt
-        # dominant kernel of the timed region
-        dom = max(by_kind, key=by_kind.get) if by_kind else None
+        frames = T * spt
+        bpf = BYTES_PER_FRAME if args.no_fuse else BYTES_PER_FRAME_FUSED
+        k_ms = {k: v / n_prof for k, v in by_kind.items() if v > 0} if n_prof else {}
+
+        def moved_bytes(kind):   # bytes one launch of this kind's group has to move on this rank
+            if kind == "mixer":
+                return (bpf["mixer"] * local_strips + 16) * frames
+            return bpf.get(kind, 0) * local_strips * frames
+
+        dom = max(k_ms, key=k_ms.get) if k_ms else None
         roof = None
-        if dom is not None and n_prof:
-            avg_ms = by_kind[dom] / n_prof
-            frames = T * spt
-            bpf = BYTES_PER_FRAME if args.no_fuse else BYTES_PER_FRAME_FUSED
-            if dom == "mixer":
-                alg = (bpf["mixer"] * local_strips + 16) * frames
-            else:
-                alg = bpf.get(dom, 0) * local_strips * frames
+        if dom is not None:
+            avg_ms = k_ms[dom]
+            alg = moved_bytes(dom)
             ach = alg / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(dom, args, world)
-            roof = {"kernel": dom + ("" if args.no_fuse or dom == "mixer" else " (fused group)"), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            traffic, traffic_src = pmc_traffic(dom, args, world, toggling)
+            per_kernel = {}
+            for k, ms in sorted(k_ms.items()):
+                b = moved_bytes(k)
+                if b:
+                    per_kernel[k] = {"moved_bytes_per_launch": b, "ms": round(ms, 5), "tb_per_s": round(b / (ms * 1e-3) / 1e12, 3),
+                                     "hbm_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            roof = {"kernel": dom + ("" if args.no_fuse or dom == "mixer" else " launch group (fused Trigger + Envelope + EqThree + StereoPanner + Amplifier: k_env_ticks + k_eq_three_spec_tiled + k_eq_three_repair)"),
+                    "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": alg,
-                    "kernel_ms_per_step": {k: round(v / n_prof, 5) for k, v in sorted(by_kind.items()) if v > 0},
+                    "algorithmic_bytes_per_unit": "2M = 8 B per sample per strip (SURVEY 8d: EqThree channel-tick; source read + strip written as one float per frame)",
+                    "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
-                    "limiter": ("f64 VALU issue + dependent-chain latency of the 8-pole recurrence (PMC: the VALU issues 69% of the kernel's cycles, "
-                                "traffic = 1.02x algorithmic); HBM is the roof only nominally" if dom == "eq_three" else "HBM")}
-            if dom == "eq_three" and not args.eq_exact:
-                # the bound that actually applies: f64 VALU.  ~52 f64 instructions per sample: exact recurrence 8 poles x
-                # (sub, mul, add) = 24, band split + gains + conversions ~12, chunk-state dot products 8 (FMA), scan hops ~4,
-                # fused epilogue ~4.  Peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T f64 instructions/s
-                f64_ops = 52.0 * local_strips * frames
-                roof["f64_valu"] = {"ops_per_launch": f64_ops, "achieved_tops": round(f64_ops / (avg_ms * 1e-3) / 1e12, 2),
-                                    "peak_tops": 39.3, "frac": round(f64_ops / (avg_ms * 1e-3) / 1e12 / 39.3, 3),
-                                    "note": "f64 VALU instruction rate (an FMA counts once); per-sample count is analytic, see DESIGN.md 5.2"}
-        # bytes of one step on one rank: module-boundary accounting (every port materialised) and, when the
-        # graph compiler fused, the bytes the fused kernels actually have to move
-        whole_alg = 51200 * (SR / 48000.0) * local_strips * T
-        fused_alg = STRIP_BYTES_FUSED_48K * (SR / 48000.0) * local_strips * T
+                    "limiter": ("f64 VALU issue: PMC (profiles/r02) 72 VALU instructions per sample with toggling gates (52 with held gates), HBM traffic = 1.00x algorithmic; "
+                                "HBM is the roof only nominally" if dom == "eq_three" else "HBM"),
+                    "per_kernel": per_kernel}
+            if dom == "eq_three":
+                # the bound that applies: f64 VALU.  Reference arithmetic per strip-sample: EqThree 36 f64 operations (2 x 4 poles x (sub, mul, add)
+                # + VSA adds + band split + gains + 2 conversions), Amplifier 6 (conversions, depth, 2 products), Envelope closed form ~13 on the
+                # ~70 % of samples where it is not flat (25/500/0.8/200 ms, gates toggling every 30 ticks)
+                ops = 36.0 + 6.0 + (13.0 * 0.7 if toggling else 0.0)
+                f64_ops = ops * local_strips * frames
+                roof["f64_valu"] = {"ops_per_sample_reference": ops, "ops_per_launch": f64_ops, "achieved_tops": round(f64_ops / (avg_ms * 1e-3) / 1e12, 2),
+                                    "peak_tops": F64_VALU_PEAK_TOPS, "frac": round(f64_ops / (avg_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TOPS, 3),
+                                    "note": "f64 operations of the reference's arithmetic per second against the f64 VALU instruction rate (an FMA would count once; none is allowed here)"}
+        moved = sum(moved_bytes(k) for k in k_ms)
+        rep_sorted = sorted(rep_ms)
         out = {
             "metric": "audio_ch_mixed_per_sec", "value": value, "unit": "channel-ticks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -748,13 +769,20 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.strips}-channel Mixer + EqThree + Envelope chain (Trigger->Envelope; noise->EqThree->StereoPanner->Amplifier->Mixer), {SR} Hz f32",
                        "strips": args.strips, "ticks_per_step": T, "samples_per_tick": spt,
-                       "eq_mode": "exact-sequential" if args.eq_exact else "time-parallel",
+                       "gates": "toggle every 30 ticks, phase k mod 60, applied between ticks inside the batch (mx_graph_schedule_params_batch)" if toggling else "held for the whole run",
+                       "eq_mode": "time-parallel scan (<= 1 ULP, MX_FLAG_EQ_FAST)" if args.eq_fast else "exact order (default): speculative time-parallel kernel, verified bit-exact",
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
-                       "parallelism": f"strips sharded x{world}" + (f", {exchange}" if exchange else "")},
+                       "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else ""),
+                       "rccl_ranks": dist.get_world_size() if use_dist else 0},
             "realtime_channels_equiv": value / 60.0,
-            "graph_hbm_frac_module_boundary_bytes": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-            "graph_hbm_frac_moved_bytes": round((whole_alg if args.no_fuse else fused_alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "graph_hbm_frac_moved_bytes": round(moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "eq_spec": {"chunks_run": spec_ran, "chunks_repaired": spec_repaired},
             "roofline": roof,
+            "repeats": {"what": f"ms per step of {len(rep_ms)} consecutive regions of {args.steps} steps (the first is the timed region)", "ms_per_step": [round(v, 4) for v in rep_ms],
+                        "median": round(rep_sorted[len(rep_sorted) // 2], 4), "min": round(rep_sorted[0], 4), "max": round(rep_sorted[-1], 4),
+                        "spread_pct": round((rep_sorted[-1] - rep_sorted[0]) / rep_sorted[len(rep_sorted) // 2] * 100.0, 2)},
+            "held_gates": held,
+            "exchange": exch,
             "realtime": realtime,
             "north_star_realtime": north,
             "video": video,
@@ -763,13 +791,14 @@ def main():
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
         else:
+            note = native_oracle()
             if video is not None:
-                video["cpu_baseline"] = video_cpu_baseline()
+                video["cpu_baseline"] = dict(video_cpu_baseline(), build=note)
             if fir is not None:
-                fir["cpu_baseline"] = fir_cpu_baseline()
-            out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(Workspace, synth, abi, shard, args.strips, SR,
-                                                                   1.0 / max(out["cpu_baseline"]["value"], 1.0))
+                fir["cpu_baseline"] = dict(fir_cpu_baseline(), build=note)
+            out["cpu_baseline"] = cpu_baseline(Workspace, synth, abi, args.strips, SR, note)
+            out["cpu_baseline_all_cores"] = dict(cpu_baseline_all_cores(Workspace, synth, abi, shard, args.strips, SR,
+                                                                        1.0 / max(out["cpu_baseline"]["value"], 1.0)), build=note)
         # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe):
         # drain it first so the JSON line is the LAST line of stdout
         import ctypes

@@ -288,6 +288,11 @@ void mx_video_mixer_destroy(mx_video_mixer* m);
  * synthetic 60 fps input).  frame NULL clears it.  The graph retains the frame. */
 int mx_graph_set_video_source(mx_graph* g, uint32_t node, mx_dframe* frame, int64_t dur_num, int64_t dur_den,
                               int64_t off_num, int64_t off_den, int repeat);
+/* A source that delivers a NEW frame on every tick, cycling through `n` frames (a decoder feeding the graph: MediaSource emits
+ * at most one VideoFrame per tick, media_source.rs:93-126): tick k of the graph's life emits frames[k mod n] with the given
+ * duration hint and offset.  The graph retains the frames.  n = 0 clears the source. */
+int mx_graph_set_video_source_ring(mx_graph* g, uint32_t node, mx_dframe* const* frames, size_t n, int64_t dur_num, int64_t dur_den,
+                                   int64_t off_num, int64_t off_den);
 /* Output port of a video node after the last tick: one reference for the caller, NULL = None. */
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out);
 /* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame). */

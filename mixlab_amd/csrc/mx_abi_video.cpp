@@ -275,6 +275,16 @@ int mx_graph_set_video_source(mx_graph* g, uint32_t node, mx_dframe* frame, int6
                                mx::Rational::make(off_num, off_den ? off_den : 1), repeat != 0);
     });
 }
+int mx_graph_set_video_source_ring(mx_graph* g, uint32_t node, mx_dframe* const* frames, size_t n, int64_t dur_num, int64_t dur_den,
+                                   int64_t off_num, int64_t off_den) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        REQUIRE(frames || !n, "frames is NULL");
+        std::vector<mx::DFrame*> v(n);
+        for (size_t i = 0; i < n; ++i) { REQUIRE(frames[i], "a frame of the ring is NULL"); v[i] = D(frames[i]); }
+        g->g->set_video_source_ring(node, v.data(), n, mx::Rational::make(dur_num, dur_den ? dur_den : 1), mx::Rational::make(off_num, off_den ? off_den : 1));
+    });
+}
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out) {
     return guard([&] {
         REQUIRE(g && out, "NULL argument");

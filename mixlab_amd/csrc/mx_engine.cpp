@@ -229,6 +229,8 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         n.slot = (uint32_t)groups_.back().nodes.size();
         groups_.back().nodes.push_back(id);
     }
+    for (uint32_t id = 0; id < nodes_.size(); ++id) if (nodes_[id].kind == MX_KIND_PLOTTER && nodes_[id].group >= 0) plotter_nodes_.push_back(id);
+    for (uint32_t id : order_) if (nodes_[id].kind == MX_KIND_VIDEO_MIXER || nodes_[id].kind == MX_KIND_SOURCE_VIDEO || nodes_[id].kind == MX_KIND_VIDEO_TO_RGBA) video_order_.push_back(id);
     // video nodes: per-node state lives on the host, pixels on the graph's stream
     for (Node& n : nodes_) {
         if (n.kind == MX_KIND_VIDEO_MIXER) {
@@ -287,7 +289,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
 Graph::~Graph() {
     flush_scales(stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); }
+    for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); n.vsrc_ring.clear(); }
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
     for (Stage& st : stage_) { if (st.done) (void)hipEventDestroy(st.done); if (st.host) (void)hipHostFree(st.host); }
@@ -643,6 +645,7 @@ void Graph::schedule_params(uint32_t node, uint32_t tick, const void* params, si
     Node& n = nodes_[node];
     if (len != n.params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
     if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
+    if (n.sched.empty() && n.gate_sched.empty()) sched_nodes_.push_back(node);
     if (n.kind == MX_KIND_TRIGGER) {
         mx_trigger_params tp; std::memcpy(&tp, params, sizeof tp);
         n.gate_sched.emplace_back(tick, tp.gate_open ? 1u : 0u);
@@ -775,7 +778,7 @@ static bool group_launches(const Group& g);
 
 void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, float* ms_total) {
     const size_t frames = fpc * (size_t)n_calls;
-    auto drop_schedules = [&] { for (Node& n : nodes_) { n.sched.clear(); n.gate_sched.clear(); } };
+    auto drop_schedules = [&] { for (uint32_t id : sched_nodes_) { nodes_[id].sched.clear(); nodes_[id].gate_sched.clear(); } sched_nodes_.clear(); };
     if (frames > cap_frames_) { drop_schedules(); throw Error(MX_ERR_INVALID, "n_ticks exceeds max_ticks_per_run"); }
     if (n_calls == 0 || fpc == 0) { drop_schedules(); last_calls_ = n_calls; last_frames_per_call_ = fpc; return; }
     hip_check(hipSetDevice(device_), "hipSetDevice");
@@ -786,7 +789,8 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     std::vector<uint32_t> cuts;   // span starts > 0
     bool any_sched = false;
     const char* beyond = "a scheduled parameter update lies beyond the run (tick_in_run >= n_ticks)";
-    for (Node& n : nodes_) {
+    for (uint32_t sid : sched_nodes_) {
+        Node& n = nodes_[sid];
         if (!n.gate_sched.empty()) {
             any_sched = true;
             bool sorted = true;
@@ -804,7 +808,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
     auto apply_at = [&](uint32_t tick) {   // every non-Trigger update scheduled for `tick`, in submission order
         bool any = false;
-        for (uint32_t id = 0; id < nodes_.size(); ++id) {
+        for (uint32_t id : sched_nodes_) {
             Node& n = nodes_[id];
             if (n.kind == MX_KIND_TRIGGER) continue;
             for (const Node::SchedEv& ev : n.sched) if (ev.tick == tick) { if (!any) { sync(); any = true; } apply_params(id, ev.params.data(), ev.params.size()); }
@@ -814,8 +818,8 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
 
     // Plotter bookkeeping is host logic (plotter.rs:37-40): count += 1 per call, fire on every 6th
     size_t total_fired = 0;
-    for (Node& n : nodes_) {
-        if (n.kind != MX_KIND_PLOTTER || n.group < 0) continue;
+    for (uint32_t pid : plotter_nodes_) {
+        Node& n = nodes_[pid];
         n.plot_fired.assign(n_calls, 0);
         n.plot_slot.assign(n_calls, -1);
         const bool connected = n.in_src[0].node >= 0;
@@ -855,7 +859,8 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     }
     // the modules keep the last scheduled params (a Trigger's are read by the next run's GateBits)
     if (any_sched) {
-        for (Node& n : nodes_) {
+        for (uint32_t sid : sched_nodes_) {
+            Node& n = nodes_[sid];
             if (!n.gate_sched.empty()) {
                 mx_trigger_params tp{}; tp.gate_open = n.gate_sched.back().second;
                 std::memcpy(n.params.data(), &tp, sizeof tp);
@@ -864,6 +869,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
             }
             n.sched.clear();
         }
+        sched_nodes_.clear();
     }
     hip_check(hipGetLastError(), "kernel launch");
     last_calls_ = n_calls;
@@ -1071,7 +1077,7 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
             nn.vmixer->rebind(stream_, nn.vlazy, tps_);   // the old graph's stream may be gone after this call; this graph's fusion plan and tick rate apply
             nn.vmixer->update(p);
         }
-        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
+        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc_ring = on.vsrc_ring; nn.vsrc_ring_pos = on.vsrc_ring_pos; nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
     }
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
@@ -1188,12 +1194,17 @@ int Graph::read_plotter(uint32_t node, uint32_t call, float* left, float* right)
 // video sub-graph: one Engine::run_tick pass over the video nodes in run order
 // ---------------------------------------------------------------------------------------------
 void Graph::run_video_tick(uint64_t t) {
-    for (uint32_t id : order_) {
+    for (uint32_t id : video_order_) {
         Node& n = nodes_[id];
         switch (n.kind) {
         case MX_KIND_SOURCE_VIDEO: {
             // Output::from_line_type(Video) = None every tick (io.rs:76); the source fills it when a frame is due
             n.vout[0] = Node::VOut{};
+            if (!n.vsrc_ring.empty()) {   // a decoder's stream: the next frame of the ring, every tick
+                n.vout[0].frame = n.vsrc_ring[n.vsrc_ring_pos]; n.vout[0].dur = n.vsrc_dur; n.vout[0].off = n.vsrc_off;
+                n.vsrc_ring_pos = (n.vsrc_ring_pos + 1) % n.vsrc_ring.size();
+                break;
+            }
             if (n.vsrc && (n.vsrc_repeat || n.vsrc_pending)) {
                 n.vout[0].frame = n.vsrc; n.vout[0].dur = n.vsrc_dur; n.vout[0].off = n.vsrc_off;
                 n.vsrc_pending = false;
@@ -1259,6 +1270,15 @@ void Graph::set_video_source(uint32_t node, DFrame* frame, Rational dur, Rationa
     Node& n = nodes_[node];
     n.vsrc = frame ? FrameRef(frame, true) : FrameRef();
     n.vsrc_dur = dur; n.vsrc_off = off; n.vsrc_repeat = repeat; n.vsrc_pending = frame != nullptr;
+}
+
+void Graph::set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_SOURCE_VIDEO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_VIDEO");
+    Node& nd = nodes_[node];
+    nd.vsrc_ring.clear(); nd.vsrc_ring_pos = 0;
+    for (size_t i = 0; i < n; ++i) nd.vsrc_ring.push_back(FrameRef(frames[i], true));
+    nd.vsrc_dur = dur; nd.vsrc_off = off;
+    if (n) { nd.vsrc = FrameRef(); nd.vsrc_pending = false; nd.vsrc_repeat = false; }
 }
 
 FrameRef Graph::video_output(uint32_t node, uint32_t port) {

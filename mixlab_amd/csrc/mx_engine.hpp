@@ -55,6 +55,7 @@ struct Node {
     bool vlazy = false;                       // VIDEO_MIXER: program output handed over as an unevaluated cross-fade chain (graph compiler)
     std::vector<VOut> vout;                   // this tick's video outputs (empty FrameRef = None)
     FrameRef vsrc; Rational vsrc_dur, vsrc_off; bool vsrc_repeat = false, vsrc_pending = false;   // SOURCE_VIDEO
+    std::vector<FrameRef> vsrc_ring; size_t vsrc_ring_pos = 0;                                       // SOURCE_VIDEO: a new frame every tick, cycling
     DevBuf rgba; uint32_t rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;                       // VIDEO_TO_RGBA
 };
 
@@ -124,6 +125,7 @@ public:
     void set_input_enabled(uint32_t node, uint32_t port, bool enabled);
     // video nodes
     void set_video_source(uint32_t node, DFrame* frame, Rational dur, Rational off, bool repeat);
+    void set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off);
     FrameRef video_output(uint32_t node, uint32_t port);
     void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 
@@ -163,6 +165,9 @@ private:
     struct Stage { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
     Stage stage_[4]; uint32_t stage_next_ = 0;
     uint32_t prof_runs_count_ = 0;
+    std::vector<uint32_t> sched_nodes_;     // nodes with a pending schedule (a 60 000-node graph must not be walked per tick)
+    std::vector<uint32_t> plotter_nodes_;   // launched Plotter nodes
+    std::vector<uint32_t> video_order_;     // the video nodes of order_, in run order
     bool prof_this_run_ = false;
     size_t plot_job_off_ = 0;
     size_t zero_off_ = 0;

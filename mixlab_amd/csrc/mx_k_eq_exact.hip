@@ -97,34 +97,6 @@ void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, u
 }
 
 // ---------------------------------------------------------------------------------------------
-// one lane per instance, strictly sequential (short streams; what the speculative form degenerates to at one chunk)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r) {
-    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
-    if (inst >= n_inst) return;
-    const EqDesc d = descs[inst];
-    EqSeqEmit em;
-    em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
-    em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
-    em.seek(0);
-    EqState st = states[inst];
-    EqPoles s;
-    for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
-    s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
-    for (size_t i = 0; i < r.frames; ++i) {
-        const float x = d.in ? d.in[i] : 0.f;
-        em.emit(i, eq_step(s, r.lo_f, r.hi_f, d.gain_lo, d.gain_mid, d.gain_hi, x));
-    }
-    for (int k = 0; k < 4; ++k) { st.lo[k] = s.lo[k]; st.hi[k] = s.hi[k]; }
-    st.history[0] = s.h0; st.history[1] = s.h1; st.history[2] = s.h2;
-    states[inst] = st;
-}
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s) {
-    if (!n || !r.frames) return;
-    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
-}
-
-// ---------------------------------------------------------------------------------------------
 // speculative time-parallel exact form
 // ---------------------------------------------------------------------------------------------
 // what a chunk's lane leaves for the repair pass
@@ -295,6 +267,37 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
         else eq_spec_span<MODE, STEREO, 2>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
         i += n; off = 0; ++call;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one lane per instance, strictly sequential: short streams (the real-time regime: a tick at a time).  The lane walks its stream
+// with the chunk loop above -- sixteen samples of loads in flight while the previous sixteen are computed, outputs stored four at
+// a time; lanes of a wave may belong to instances with different epilogues (the switch is per lane).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r) {
+    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= n_inst) return;
+    const EqDesc d = descs[inst];
+    EqState st = states[inst];
+    EqPoles s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
+    s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
+    uint32_t xmin = 0xffffffffu, xmax = 0u;
+    const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
+    const bool stereo = !(d.epi == 0u || (d.flags & MX_EQF_MONO_DUP));
+    const int mode = d.epi != 2u ? EQM_PLAIN : ((d.flags & MX_EQF_ENV) ? EQM_AMP_ENV : (d.ctl ? EQM_AMP_CTL : EQM_AMP_CONST));
+#define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true>(d, r, ticks, 0, r.frames, s, xmin, xmax); else eq_spec_chunk<M, false>(d, r, ticks, 0, r.frames, s, xmin, xmax); break
+    switch (mode) { MX_EQ_CASE(EQM_PLAIN); MX_EQ_CASE(EQM_AMP_CONST); MX_EQ_CASE(EQM_AMP_CTL); default: MX_EQ_CASE(EQM_AMP_ENV); }
+#undef MX_EQ_CASE
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { st.lo[k] = s.lo[k]; st.hi[k] = s.hi[k]; }
+    st.history[0] = s.h0; st.history[1] = s.h1; st.history[2] = s.h2;
+    states[inst] = st;
+}
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s) {
+    if (!n || !r.frames) return;
+    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
 }
 
 // KMODE / KSTEREO >= 0: every instance of the launch has that epilogue (the usual case: a bank of equal strips) and the kernel is

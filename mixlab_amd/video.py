@@ -51,6 +51,7 @@ _proto("mx_device_download", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_vo
 
 
 _proto("mx_graph_set_video_source", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int)
+_proto("mx_graph_set_video_source_ring", C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_size_t, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
 _proto("mx_graph_video_output", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p))
 _proto("mx_graph_rgba_output", C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 
@@ -70,6 +71,12 @@ def to_rgba_params(matrix_q12=None) -> VideoToRgbaParams:
 # ---- video nodes of an abi.Graph ----
 def graph_set_video_source(g, node, frame, dur=(1, 60), off=(0, 1), repeat=False):
     check(lib.mx_graph_set_video_source(g._h, node, frame.handle if frame is not None else None, dur[0], dur[1], off[0], off[1], 1 if repeat else 0))
+
+
+def graph_set_video_source_ring(g, node, frames, dur=(1, 60), off=(0, 1)):
+    """A new frame on every tick, cycling through `frames` (a decoder's stream)."""
+    arr = (C.c_void_p * max(1, len(frames)))(*[f.handle for f in frames])
+    check(lib.mx_graph_set_video_source_ring(g._h, node, arr, len(frames), dur[0], dur[1], off[0], off[1]))
 
 
 def graph_video_output(g, node, port=0):

@@ -12,6 +12,10 @@ _LIB = ROOT / "oracle" / "libmixlab_oracle.so"
 
 
 def _load():
+    import os
+    override = os.environ.get("MIXLAB_ORACLE_LIB")   # bench.py's cpu_baseline: the same sources built on the timing host with -march=native
+    if override and pathlib.Path(override).exists():
+        return C.CDLL(override)
     srcs = list((ROOT / "oracle").glob("*.c")) + list((ROOT / "oracle").glob("*.h"))
     if not _LIB.exists() or any(s.stat().st_mtime > _LIB.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)

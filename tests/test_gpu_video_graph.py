@@ -84,3 +84,24 @@ def test_video_edge_type_is_checked():
     with pytest.raises(abi.MxError) as ei:
         ws.build()
     assert ei.value.code == abi.MX_ERR_TYPE
+
+
+def test_video_source_ring_delivers_a_new_frame_every_tick_cycling():
+    ws = Workspace(44100, 60)
+    s = ws.source_video(); m = ws.video_mixer(a=0, b=None, fader=1.0)
+    ws.connect(s, 0, m, 0)
+    g = ws.build(max_ticks_per_run=4)
+    hosts = [ov.HostFrame(64, 48).fill(k, seed=9) for k in range(3)]
+    ring = [upload(h) for h in hosts]
+    video.graph_set_video_source_ring(g, s, ring, dur=(1, 60), off=(0, 1))
+    for tick in range(7):          # one tick per run: the program output of tick k is frame k mod 3 (fader 1.0 = all A)
+        g.run_ticks(tick, 1)
+        got = video.graph_video_output(g, m, 0)
+        for a, b in zip(got.download(), hosts[tick % 3].visible()):
+            assert np.array_equal(a, b), f"tick {tick}"
+    g.run_ticks(7, 4)              # a batched run advances the ring four times: ticks 7..10 -> frames 1, 2, 0, 1
+    for a, b in zip(video.graph_video_output(g, m, 0).download(), hosts[10 % 3].visible()):
+        assert np.array_equal(a, b)
+    video.graph_set_video_source_ring(g, s, [], dur=(1, 60), off=(0, 1))   # cleared: the stored frame expires, then None
+    g.run_ticks(11, 2)
+    assert video.graph_video_output(g, m, 0) is None

@@ -44,13 +44,13 @@ def main():
             g.write_source(s, np.tile(blk, (T + base - 1) // base)[: T * spt], T)
         ev = [gate_events(abi, trigs, 0, i * T, T) if args.toggle else None for i in range(args.steps + 2)]
         for i in range(2):
-            if ev[i]: g.schedule_params_batch(ev[i][0])
+            if ev[i]: g.schedule_params_batch(ev[i][0], ev[i][1])
             g.run_ticks(i * T, T)
         g.sync()
         g.profile_enable(True)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            if ev[2 + i]: g.schedule_params_batch(ev[2 + i][0])
+            if ev[2 + i]: g.schedule_params_batch(ev[2 + i][0], ev[2 + i][1])
             g.run_ticks((2 + i) * T, T)
         g.sync()
         dt = (time.perf_counter() - t0) / args.steps
