@@ -120,41 +120,46 @@ constexpr int EQ_BLK = 16;   // samples per block: four 16-byte loads in flight 
 // (lanes of a wave sit in different ticks and Envelope phases; branches would also fence the recurrence's instruction stream):
 //   On  (envelope.rs:37-49):  ms < attack_ms ? inv_attack * ms : sustain + (1 - sustain) * (1 - clamp(inv_decay * (ms - attack_ms)))
 //   Off (envelope.rs:51-56):  off_amplitude * (1 - clamp(inv_release * ms))
-// Both are  A + B * (1 - clamp(k * (ms - m0)))  with (A, B, k, m0) = (sustain, 1 - sustain, inv_decay, attack_ms) resp.
-// (0, off_amplitude, inv_release, 0): for Off the two extra operations are exact identities (ms - 0.0 == ms; 0.0 + p == p for
-// every p but -0.0, which off_amplitude * [0, 1] cannot be when off_amplitude >= +0.0 -- env_lane_coeffs() falls back to the
-// general form otherwise).  ms = (dt as f64) / SR * 1000 with dt = dt0 + sample index (u32; spans whose dt leaves 32 bits also
-// take the general form).
+//   Initial (envelope.rs:36): 0.0
+// All three are  A + B * (1 - min(k * (ms - m0), 1))  with (A, B, k, m0) = (sustain, 1 - sustain, inv_decay, attack_ms),
+// (0, off_amplitude, inv_release, 0), (0, 0, 0, 0):
+//   * Off / Initial: the extra operations are exact identities (ms - 0.0 == ms; 0.0 + p == p for every p but -0.0, which
+//     off_amplitude * [0, 1] cannot be when off_amplitude >= +0.0);
+//   * clamp()'s lower bound (envelope.rs:23-24) never acts where the value is used: with k >= 0, k * (ms - m0) < 0 only for an On
+//     lane before attack_ms, where the attack ramp is selected instead;
+//   * a FLAT lane (sustain reached, release finished, never triggered) needs no special case: saturation means min() returns 1.0
+//     and the formula yields the same constant the reference computes, operation for operation.
+// Preconditions (else the general form, env_depth): finite parameters with inv_decay, inv_release >= 0 (env_params_nice),
+// off_amplitude >= +0.0, and a sample distance that stays in 32 bits.  ms = (dt as f64) / SR * 1000, dt = dt0 + sample index.
 struct EnvLane { double A, B, k, m0, depth; uint32_t dt0; uint32_t on; uint32_t flat; uint32_t general;
                  uint32_t k0 = 0; uint64_t t_chunk = 0; /* tiled kernel: chunk-relative index of the tick's first sample; absolute time of the chunk's */ };
-__device__ __forceinline__ EnvLane env_lane_coeffs(const EnvParams& p, const EnvTick& c, uint64_t t_begin, size_t n) {
+__device__ __forceinline__ bool env_params_nice(const EnvParams& p) {
+    auto fin = [](double v) { return v == v && fabs(v) < 1.0e300; };
+    return fin(p.attack_ms) && fin(p.inv_attack) && fin(p.inv_decay) && fin(p.sustain) && fin(p.one_minus_sustain) && fin(p.inv_release) &&
+           p.inv_decay >= 0.0 && p.inv_release >= 0.0;
+}
+__device__ __forceinline__ EnvLane env_lane_coeffs(const EnvParams& p, const EnvTick& c, uint64_t t_begin, size_t n, bool nice) {
     EnvLane e;
     e.depth = c.depth; e.flat = c.flat; e.on = c.tag == 1u ? 1u : 0u;
-    e.A = e.on ? p.sustain : 0.0; e.B = e.on ? p.one_minus_sustain : c.off_amp;
-    e.k = e.on ? p.inv_decay : p.inv_release; e.m0 = e.on ? p.attack_ms : 0.0;
+    const bool off = c.tag == 2u;
+    e.A = e.on ? p.sustain : 0.0; e.B = e.on ? p.one_minus_sustain : (off ? c.off_amp : 0.0);
+    e.k = e.on ? p.inv_decay : (off ? p.inv_release : 0.0); e.m0 = e.on ? p.attack_ms : 0.0;
     const uint64_t d0 = t_begin - c.seq;
-    e.dt0 = (uint32_t)d0;
-    const bool off_ok = !(c.off_amp < 0.0) && (c.off_amp == c.off_amp) && !signbit(c.off_amp);
-    e.general = (c.tag != 0u && !c.flat && ((((d0 + n) >> 32) != 0) || (c.tag == 2u && !off_ok))) ? 1u : 0u;
+    e.dt0 = c.tag != 0u ? (uint32_t)d0 : 0u;
+    const bool off_ok = !(c.off_amp < 0.0) && (c.off_amp == c.off_amp) && !signbit(c.off_amp) && fabs(c.off_amp) < 1.0e300;
+    e.general = (!nice || (c.tag != 0u && ((((d0 + n) >> 32) != 0) || (off && !off_ok)))) ? 1u : 0u;
     return e;
 }
 // amplifier depth() for sample k of the span (branch-free form; `e.general` lanes are handled by the caller)
 __device__ __forceinline__ double env_lane_depth(const EnvParams& p, const EnvLane& e, uint32_t k, double one_minus, double mod_depth, double sr, double rsr) {
     const double ms = ms_of_u32(e.dt0 + k, sr, rsr);
     const double tt = e.k * (ms - e.m0);
-    double c = tt;
-    c = tt > 1.0 ? 1.0 : c;                                    // clamp(), envelope.rs:20-28 (a NaN passes through like there)
-    c = tt < 0.0 ? 0.0 : c;
+    const double c = __builtin_fmin(tt, 1.0);                  // clamp()'s upper bound (envelope.rs:21-22); no NaN here, see above
     const double val = e.A + e.B * (1.0 - c);
     const double att = p.inv_attack * ms;
     const double a = (e.on && ms < p.attack_ms) ? att : val;
     const float cc = (float)a;                                 // Envelope stores f32 (envelope.rs:117)
-    const double d = one_minus + mod_depth * (double)cc;       // amplifier.rs:71-73
-    // select, never branch: a wave that takes this form has a non-flat lane anyway, and a branch here would end the basic block --
-    // the scheduler could no longer lay the next sample's recurrence beside this sample's epilogue
-    const unsigned long long di = (unsigned long long)__double_as_longlong(d), fi = (unsigned long long)__double_as_longlong(e.depth);
-    const unsigned long long m = e.flat ? ~0ull : 0ull;
-    return __longlong_as_double((long long)((fi & m) | (di & ~m)));
+    return one_minus + mod_depth * (double)cc;                 // amplifier.rs:71-73
 }
 
 // A run of `n` consecutive samples of one chunk through the recurrence and the epilogue: blocks of EQ_BLK samples with the next
@@ -253,13 +258,14 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
         return;
     }
     const size_t fpc = r.fpc;
+    const bool nice = env_params_nice(d.env);
     uint32_t call = (uint32_t)(begin / fpc);
     size_t off = begin % fpc;                                                  // 0 when chunks are whole ticks; the walk is general
     for (size_t i = 0; i < len;) {
         const size_t n = (fpc - off) < (len - i) ? (fpc - off) : (len - i);
         const EnvTick cur = ticks[call];                                       // one 32-byte load per tick of 800 samples
         const uint64_t t = r.t0 + begin + i;
-        const EnvLane el = env_lane_coeffs(d.env, cur, t, n);
+        const EnvLane el = env_lane_coeffs(d.env, cur, t, n, nice);
         float* const o = outm + (STEREO ? 2 * i : i);
         // wave-level choice of the span's form (lanes that left the loop already do not vote)
         if (__ballot(el.general != 0u) != 0ull) eq_spec_span<MODE, STEREO, 3>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
     const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
     EnvTick cur{}; EnvLane el{};
     int envk = 0;
+    const bool nice = env_params_nice(d.env);
     EqChunkRec* rec = recs + (size_t)inst * plan.n_chunks + (active ? j : 0);
 
     eq_tile_issue<SB>(c, eq_tiles, -(int)plan.warm);
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
                 const size_t tk = ((size_t)begin + (size_t)so) / r.fpc;
                 cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
                 const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so;
-                el = env_lane_coeffs(K.env, cur, t, r.fpc);
+                el = env_lane_coeffs(K.env, cur, t, r.fpc, nice);
                 el.k0 = (uint32_t)so; el.t_chunk = r.t0 + (uint64_t)begin;
                 envk = __ballot(active && so < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so < len && el.flat == 0u) == 0ull ? 1 : 2);
             }

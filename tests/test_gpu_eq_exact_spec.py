@@ -189,3 +189,36 @@ def test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate):
             assert_bit_exact(got[k][sl], w, f"{k} tick {t}")
     ran, _ = g.eq_spec_stats()
     assert ran > 0
+
+
+@pytest.mark.parametrize("env_p", [(25.0, 500.0, 0.8, 200.0), (0.0, 100.0, 0.5, 50.0), (5.0, 0.0, 0.7, 0.0), (10.0, 40.0, 1.5, 30.0),
+                                   (3.0, 20.0, -0.25, 15.0), (1e-3, 1e-3, 0.0, 1e-3), (400.0, 3000.0, 0.3, 2500.0)])
+def test_spec_eq_inline_envelope_with_unusual_parameters_matches_the_oracle(env_p):
+    """The inline Envelope's branch-free form assumes finite parameters with non-negative slopes and a non-negative
+    off_amplitude; everything else (zero attack / decay / release times -> infinite slopes, sustain outside [0, 1]) must fall
+    back to the general form and still be the reference's arithmetic.  Gates toggle inside the batch."""
+    SR, SPT, T = 48000, 800, 240
+    ws = Workspace(SR, 60)
+    src = ws.source_mono(); eq = ws.eq_three(2.0, -1.0, 3.0); pan = ws.stereo_panner()
+    trig = ws.trigger(False); env = ws.envelope(*env_p); amp = ws.amplifier(0.9, 0.8)
+    ws.connect(src, 0, eq, 0); ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1); ws.connect(pan, 0, amp, 0)
+    ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp, 1)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    x = synth.noise(870, T * SPT)
+    g.write_source(src, x, T)
+    toggles = {7: 1, 45: 0, 46: 1, 47: 0, 120: 1, 200: 0}
+    for t, v in toggles.items():
+        g.schedule_params(trig, t, abi.TriggerParams(v))
+    g.run_ticks(0, T)
+    got = g.read_output(amp, 0, T, True)
+    for t in range(T):
+        if t in toggles:
+            og.update_params(trig, abi.TriggerParams(toggles[t]))
+        og.set_source(src, x[t * SPT:(t + 1) * SPT])
+        og.run_tick(t)
+        w = og.output(amp, 0)
+        ok = ~np.isnan(w)
+        assert np.array_equal(np.isnan(got[t * 2 * SPT:(t + 1) * 2 * SPT]), np.isnan(w)), f"tick {t}: NaNs at different samples"
+        assert_bit_exact(got[t * 2 * SPT:(t + 1) * 2 * SPT][ok], w[ok], f"tick {t} (envelope {env_p})")
+    assert g.eq_spec_stats()[0] > 0
