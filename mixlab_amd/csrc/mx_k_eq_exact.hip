@@ -450,7 +450,7 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
     const int sw = G::sw(lane);
     f4v* row = reinterpret_cast<f4v*>(buf + lane * SB);
     f4v x4 = row[0 ^ sw];
-#pragma unroll 1
+#pragma unroll 1   // (unrolling the row fully, or by two, was measured: no faster -- the moves at the back edge go, the code grows 4x)
     for (int pce = 0; pce < G::S; ++pce) {
         const f4v xn = row[((pce + 1) & (G::S - 1)) ^ sw];            // next piece travels while this one is computed
         if (WARM || so + 4 * pce < len) {
