@@ -264,6 +264,11 @@ int mx_video_scaler_scale(mx_video_scaler* sc, const mx_dframe* in, mx_dframe** 
 void mx_video_scaler_destroy(mx_video_scaler* sc);
 int mx_video_scale_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                             uint32_t* scaled_w, uint32_t* scaled_h, uint32_t* letterbox_x, uint32_t* letterbox_y);   /* encode.rs:354-374 */
+/* The scaler's tap table for one axis (DESIGN.md "Scaler"): *n_taps coefficients (Q14, summing to 16384) per output sample and the
+ * index of the first source sample each set applies to.  first: [dst], coef: [dst][*n_taps] with room for mx_video_scaler_tap_count()
+ * entries per sample.  Host-only (no device needed): what the tests pin against tests/golden/bicubic_taps_*.json. */
+uint32_t mx_video_scaler_tap_count(uint32_t src, uint32_t dst);
+int mx_video_scaler_taps(uint32_t src, uint32_t dst, int32_t* first, int32_t* coef, uint32_t* n_taps);
 /* BUILD-SPECIFIED (no reference counterpart): BT.709 limited-range YUV420P -> RGBA8 (+ optional Q12 3x4 matrix). */
 int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride, const int32_t* matrix_q12 /* 12 or NULL */, void* stream);
 int mx_video_sync(void* stream);

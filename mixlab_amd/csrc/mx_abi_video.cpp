@@ -267,6 +267,19 @@ void mx_video_mixer_destroy(mx_video_mixer* m) {
     (void)guard([&] { delete m; });
 }
 
+uint32_t mx_video_scaler_tap_count(uint32_t src, uint32_t dst) { return (src && dst) ? mx::scaler_tap_count(src, dst) : 0u; }
+int mx_video_scaler_taps(uint32_t src, uint32_t dst, int32_t* first, int32_t* coef, uint32_t* n_taps) {
+    return guard([&] {
+        REQUIRE(src && dst && first && coef && n_taps, "NULL or zero argument");
+        REQUIRE(src <= 16384 && dst <= 16384, "plane too large");
+        std::vector<int32_t> f, c;
+        mx::scaler_taps(src, dst, f, c);
+        *n_taps = mx::scaler_tap_count(src, dst);
+        std::memcpy(first, f.data(), f.size() * sizeof(int32_t));
+        std::memcpy(coef, c.data(), c.size() * sizeof(int32_t));
+    });
+}
+
 int mx_graph_set_video_source(mx_graph* g, uint32_t node, mx_dframe* frame, int64_t dur_num, int64_t dur_den,
                               int64_t off_num, int64_t off_den, int repeat) {
     return guard([&] {

@@ -221,6 +221,9 @@ static void make_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, s
     }
 }
 
+uint32_t scaler_tap_count(uint32_t src, uint32_t dst) { return tap_count(src, dst); }
+void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef) { make_taps(src, dst, first, coef); }
+
 void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
     in_w_ = in_w; in_h_ = in_h;
     geo_ = scaler_geometry(in_w, in_h, out_w_, out_h_);

@@ -141,6 +141,8 @@ struct ScaleGeometry { uint32_t scaled_w, scaled_h, letterbox_x, letterbox_y; };
 ScaleGeometry scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h);   // encode.rs:354-374
 void unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t& w, uint32_t& h);   // video_mixer.rs:276-297
 uint8_t crossfade_factor(double fader);   // video_mixer.rs:168
+uint32_t scaler_tap_count(uint32_t src, uint32_t dst);
+void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef);   // DESIGN.md "Scaler"
 
 // DynamicScaler (src/video/encode.rs:311-398)
 class Scaler {

@@ -238,3 +238,51 @@ def test_oracle_bicubic_is_identity_preserving_and_bounded():
     out = ov.HostFrame(64, 64); ov.dynamic_scale(chk, out)
     y = out.visible()[0][4:-4, 4:-4].astype(int)
     assert abs(int(y.mean()) - 125) <= 2 and y.max() - y.min() <= 6
+
+
+# ------------------------------------------------------------------------------------------------
+# the scaler SPEC, pinned independently of both implementations: tap tables derived from the text of DESIGN.md section 6 with
+# exact rationals (tests/golden/make_bicubic_taps.py) -- the oracle's and the product's generators must both reproduce them
+# ------------------------------------------------------------------------------------------------
+def _golden_taps():
+    import json
+    return [json.loads(p.read_text()) for p in sorted((ROOT / "tests" / "golden").glob("bicubic_taps_*.json"))]
+
+
+def test_bicubic_tap_golden_files_cover_up_down_identity_and_odd_sizes():
+    geos = {(g["src"], g["dst"]) for g in _golden_taps()}
+    assert {(720, 1080), (1080, 1080), (1000, 1001), (1080, 635), (1280, 100), (959, 539)} <= geos
+    for g in _golden_taps():
+        assert len(g["first"]) == g["dst"] and all(len(c) == g["n_taps"] and sum(c) == 16384 for c in g["coef"])
+
+
+def test_oracle_bicubic_taps_equal_the_exact_rational_spec():
+    import ctypes as C
+    import oracle
+    oracle.lib.orc_bicubic_taps_n.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    oracle.lib.orc_bicubic_tap_count.argtypes = [C.c_uint32, C.c_uint32]
+    oracle.lib.orc_bicubic_tap_count.restype = C.c_uint32
+    for g in _golden_taps():
+        n = oracle.lib.orc_bicubic_tap_count(g["src"], g["dst"])
+        assert n == g["n_taps"]
+        first = C.c_int32(); coef = (C.c_int32 * n)()
+        for o in range(g["dst"]):
+            oracle.lib.orc_bicubic_taps_n(o, g["src"], g["dst"], C.byref(first), coef)
+            assert first.value == g["first"][o] and list(coef) == g["coef"][o], f"oracle taps {g['src']} -> {g['dst']}, output {o}"
+
+
+def test_product_scaler_taps_equal_the_exact_rational_spec():
+    import ctypes as C
+    from mixlab_amd import abi
+    lib = abi.lib
+    lib.mx_video_scaler_tap_count.argtypes = [C.c_uint32, C.c_uint32]
+    lib.mx_video_scaler_tap_count.restype = C.c_uint32
+    lib.mx_video_scaler_taps.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    for g in _golden_taps():
+        n = lib.mx_video_scaler_tap_count(g["src"], g["dst"])
+        assert n == g["n_taps"]
+        first = (C.c_int32 * g["dst"])(); coef = (C.c_int32 * (g["dst"] * n))(); nt = C.c_uint32()
+        assert lib.mx_video_scaler_taps(g["src"], g["dst"], first, coef, C.byref(nt)) == 0 and nt.value == n
+        assert list(first) == g["first"], f"product first-tap indices {g['src']} -> {g['dst']}"
+        got = [list(coef[o * n:(o + 1) * n]) for o in range(g["dst"])]
+        assert got == g["coef"], f"product coefficients {g['src']} -> {g['dst']}"
