@@ -264,6 +264,13 @@ int mx_video_scaler_scale(mx_video_scaler* sc, const mx_dframe* in, mx_dframe** 
 void mx_video_scaler_destroy(mx_video_scaler* sc);
 int mx_video_scale_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                             uint32_t* scaled_w, uint32_t* scaled_h, uint32_t* letterbox_x, uint32_t* letterbox_y);   /* encode.rs:354-374 */
+/* Row band of DynamicScaler::scale for a picture composited over several GPUs by rows (mixlab_amd/shard.py):
+ * luma rows [row0, row0 + out_band height) of the (full_w x full_h) letterboxed result, computed from a SLICE that holds luma rows
+ * [src_row0, src_row0 + slice height) of a source in_full_h rows high.  Tap indices clamp against the full source plane, exactly as
+ * the unsharded scale does, so stitched bands are the unsharded frame bit for bit; a slice that lacks a row the band's vertical
+ * taps reach is MX_ERR_INVALID.  All row counts even (whole chroma rows); out_band is as wide as the full picture.  Synchronous. */
+int mx_video_scale_band(const mx_dframe* in_slice, uint32_t in_full_h, uint32_t src_row0, mx_dframe* out_band,
+                        uint32_t full_w, uint32_t full_h, uint32_t row0, void* stream);
 /* The scaler's tap table for one axis (DESIGN.md "Scaler"): *n_taps coefficients (Q14, summing to 16384) per output sample and the
  * index of the first source sample each set applies to.  first: [dst], coef: [dst][*n_taps] with room for mx_video_scaler_tap_count()
  * entries per sample.  Host-only (no device needed): what the tests pin against tests/golden/bicubic_taps_*.json. */

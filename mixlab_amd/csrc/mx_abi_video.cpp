@@ -267,6 +267,13 @@ void mx_video_mixer_destroy(mx_video_mixer* m) {
     (void)guard([&] { delete m; });
 }
 
+int mx_video_scale_band(const mx_dframe* in_slice, uint32_t in_full_h, uint32_t src_row0, mx_dframe* out_band,
+                        uint32_t full_w, uint32_t full_h, uint32_t row0, void* stream) {
+    return guard([&] {
+        REQUIRE(in_slice && out_band, "NULL argument");
+        mx::scale_band(D(in_slice), in_full_h, src_row0, D(out_band), full_w, full_h, row0, S(stream));
+    });
+}
 uint32_t mx_video_scaler_tap_count(uint32_t src, uint32_t dst) { return (src && dst) ? mx::scaler_tap_count(src, dst) : 0u; }
 int mx_video_scaler_taps(uint32_t src, uint32_t dst, int32_t* first, int32_t* coef, uint32_t* n_taps) {
     return guard([&] {

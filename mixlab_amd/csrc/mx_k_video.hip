@@ -406,9 +406,9 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
 // hn * vn source reads per pixel.  Same arithmetic as the 4-tap kernels; outputs are monitor-sized, this is not a hot path.
 __global__ __launch_bounds__(256) void k_scale_wide_h(ScaleArgs a) {
     const ScalePlane p = a.p[blockIdx.z];
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= p.dw || y >= p.sh) return;
-    const uint8_t* row = p.src + (size_t)y * p.src_stride;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = p.h_row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.dw || y >= p.h_row0 + p.h_rows) return;
+    const uint8_t* row = p.src + (ptrdiff_t)y * (ptrdiff_t)p.src_stride;   // a band's `src` is the slice's base minus src_row0 rows: only rows of the slice are touched
     const int32_t* c = p.hcoef + (size_t)x * p.hn;
     const int f = p.hfirst[x], sw1 = (int)p.sw - 1;
     int acc = 0;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_scale_wide_v(ScaleArgs a) {
 }
 void launch_scale_wide(const ScaleArgs& a, hipStream_t s) {
     uint32_t mw = 0, msh = 0, mdh = 0;
-    for (int i = 0; i < 3; ++i) { mw = std::max(mw, a.p[i].dw); msh = std::max(msh, a.p[i].sh); mdh = std::max(mdh, a.p[i].dh); }
+    for (int i = 0; i < 3; ++i) { mw = std::max(mw, a.p[i].dw); msh = std::max(msh, a.p[i].h_rows); mdh = std::max(mdh, a.p[i].dh); }
     if (!mw || !msh || !mdh) return;
     hipLaunchKernelGGL(k_scale_wide_h, dim3((mw + 63) / 64, (msh + 3) / 4, 3), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_scale_wide_v, dim3((mw + 63) / 64, (mdh + 3) / 4, 3), dim3(256), 0, s, a);

@@ -224,6 +224,60 @@ static void make_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, s
 uint32_t scaler_tap_count(uint32_t src, uint32_t dst) { return tap_count(src, dst); }
 void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef) { make_taps(src, dst, first, coef); }
 
+void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFrame* out, uint32_t full_w, uint32_t full_h, uint32_t row0, hipStream_t s) {
+    if (!slice || !out) throw Error(MX_ERR_INVALID, "NULL frame");
+    if (out->width != full_w) throw Error(MX_ERR_INVALID, "a band frame is as wide as the full picture");
+    if ((row0 & 1) || (src_row0 & 1) || (in_full_h & 1) || (full_h & 1) || row0 + out->height > full_h || src_row0 + slice->height > in_full_h)
+        throw Error(MX_ERR_INVALID, "band / slice rows must be whole chroma rows inside their pictures");
+    const ScaleGeometry geo = scaler_geometry(slice->width, in_full_h, full_w, full_h);
+    launch_blank(out->data[0], out->plane_bytes[0], out->data[1], out->plane_bytes[1], out->data[2], out->plane_bytes[2], s);   // AvFrame::blank: the letterbox bars
+    if (!geo.scaled_w || !geo.scaled_h) { hip_check(hipStreamSynchronize(s), "hipStreamSynchronize"); return; }
+    std::vector<int32_t> blob; size_t offs[2][4]; uint32_t taps[2][2];
+    std::vector<int32_t> vf_host[2];
+    for (int c = 0; c < 2; ++c) {
+        std::vector<int32_t> hf, hc, vf, vc;
+        make_taps(slice->width >> c, geo.scaled_w >> c, hf, hc);
+        make_taps(in_full_h >> c, geo.scaled_h >> c, vf, vc);
+        taps[c][0] = tap_count(slice->width >> c, geo.scaled_w >> c); taps[c][1] = tap_count(in_full_h >> c, geo.scaled_h >> c);
+        vf_host[c] = vf;
+        auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
+        offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
+    }
+    DevBuf tabs, tmp;
+    tabs.alloc(blob.size() * sizeof(int32_t));
+    hip_check(hipMemcpy(tabs.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(band taps)");
+    size_t tmp_off[3], tmp_total = 0;
+    for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; tmp_off[p] = tmp_total; tmp_total += (size_t)(geo.scaled_w >> c) * (in_full_h >> c); }
+    tmp.alloc(tmp_total * sizeof(int32_t));
+    ScaleArgs a{};
+    bool any = false;
+    for (int p = 0; p < 3; ++p) {
+        const int c = p ? 1 : 0;
+        ScalePlane& sp = a.p[p];
+        const uint32_t b0 = row0 >> c, b1 = (row0 + out->height) >> c;                     // the band in this plane's rows
+        const uint32_t s0 = geo.letterbox_y >> c, s1 = (geo.letterbox_y + geo.scaled_h) >> c;   // the scaled picture's rows
+        const uint32_t ra = std::max(b0, s0), rb = std::min(b1, s1);
+        if (ra >= rb) { sp.dw = sp.dh = 0; sp.h_rows = 0; continue; }                       // this band lies in the letterbox bars
+        const uint32_t sh = in_full_h >> c, vn = taps[c][1];
+        const int32_t lo = std::min<int32_t>(std::max<int32_t>(vf_host[c][ra - s0], 0), (int32_t)sh - 1);
+        const int32_t hi = std::min<int32_t>(std::max<int32_t>(vf_host[c][rb - 1 - s0] + (int32_t)vn - 1, 0), (int32_t)sh - 1);
+        const uint32_t sl0 = src_row0 >> c, sl1 = (src_row0 + slice->height) >> c;
+        if ((uint32_t)lo < sl0 || (uint32_t)hi >= sl1) throw Error(MX_ERR_INVALID, "the source slice lacks a row the band's vertical taps reach (see shard.band_source_rows)");
+        sp.src = slice->data[p] - (ptrdiff_t)sl0 * (ptrdiff_t)slice->stride[p];           // virtual base of the full plane: only rows [lo, hi] are read
+        sp.src_stride = slice->stride[p]; sp.sw = slice->pw(p); sp.sh = sh;
+        sp.dst = out->data[p] + (size_t)(ra - b0) * out->stride[p] + (geo.letterbox_x >> c);
+        sp.dst_stride = out->stride[p]; sp.dw = geo.scaled_w >> c; sp.dh = rb - ra;
+        sp.hfirst = (const int32_t*)tabs.p + offs[c][0]; sp.hcoef = (const int32_t*)tabs.p + offs[c][1];
+        sp.vfirst = (const int32_t*)tabs.p + offs[c][2] + (ra - s0); sp.vcoef = (const int32_t*)tabs.p + offs[c][3] + (size_t)(ra - s0) * vn;
+        sp.hn = taps[c][0]; sp.vn = vn; sp.tmp = (int32_t*)tmp.p + tmp_off[p];
+        sp.h_row0 = (uint32_t)lo; sp.h_rows = (uint32_t)(hi - lo + 1);
+        any = true;
+    }
+    if (any) launch_scale_wide(a, s);
+    hip_check(hipGetLastError(), "band scale launch");
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");   // the tables and the row buffer die here
+}
+
 void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
     in_w_ = in_w; in_h_ = in_h;
     geo_ = scaler_geometry(in_w, in_h, out_w_, out_h_);
@@ -273,6 +327,7 @@ FrameRef Scaler::scale(const FrameRef& in) {
         sp.dst_stride = frame_->stride[p]; sp.dw = geo_.scaled_w >> c; sp.dh = geo_.scaled_h >> c;
         sp.hfirst = tab_[c][0]; sp.hcoef = tab_[c][1]; sp.vfirst = tab_[c][2]; sp.vcoef = tab_[c][3];
         sp.hn = taps_[c][0]; sp.vn = taps_[c][1]; sp.tmp = tmp_plane_[p];
+        sp.h_row0 = 0; sp.h_rows = sp.sh;
     }
     if (tmp_plane_[0]) {                    // widened kernel (downscale): two passes, launched in stream order
         flush_scales(stream_);

@@ -29,6 +29,7 @@ struct ScalePlane {
     const int32_t* vfirst; const int32_t* vcoef;   // [dh], [dh][vn]
     uint32_t hn, vn;                               // taps per output sample: 4, or 2*ceil(2*src/dst)+2 on a downscaled axis
     int32_t* tmp;                                  // wide path only: [sh][dw] H-filtered rows
+    uint32_t h_row0, h_rows;                       // wide path only: the source rows the H pass filters (a row band reads a slice of the plane)
 };
 struct ScaleArgs { ScalePlane p[3]; };
 enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
@@ -143,6 +144,9 @@ void unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, 
 uint8_t crossfade_factor(double fader);   // video_mixer.rs:168
 uint32_t scaler_tap_count(uint32_t src, uint32_t dst);
 void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef);   // DESIGN.md "Scaler"
+// Row band of DynamicScaler::scale (multi-GPU row bands): luma rows [row0, row0 + out->height) of the (full_w x full_h)
+// letterboxed result from a slice holding luma rows [src_row0, src_row0 + slice->height) of a source in_full_h rows high.  Synchronous.
+void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFrame* out, uint32_t full_w, uint32_t full_h, uint32_t row0, hipStream_t s);
 
 // DynamicScaler (src/video/encode.rs:311-398)
 class Scaler {

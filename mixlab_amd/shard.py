@@ -20,7 +20,11 @@ rank's partial buses, rank j adds them in rank order 0..world-1 (same Mixer kern
 finished slices.  Every output sample is still the rank-ordered f32 sum of the same partials -- bit for bit the
 hierarchical graph above -- but a rank receives 2 (world-1)/world bus lengths instead of (world-1).
 
-Video does not exchange anything: ranks run independent VideoMixer instances (or row bands).
+Video does not exchange anything: ranks run independent VideoMixer instances, or -- one picture over all ranks -- ROW BANDS:
+a cross-fade cascade is not associative (each stage truncates to u8), so the picture is not split by layer but by rows, in units
+of one chroma row (two luma rows): 1080p = 540 chroma rows over 8 ranks = 68, 68, 68, 68, 67, 67, 67, 67.  Cross-fade and
+colour conversion are per pixel, so a band needs exactly its own rows of every same-size layer; a layer that is SCALED into the
+picture needs, per plane, the source rows its band's vertical taps reach (band_source_rows: the halo).
 """
 from __future__ import annotations
 
@@ -66,3 +70,64 @@ def unpack_slices(final_all, world: int):
     L = final_all.numel() // (2 * world)
     v = final_all.view(world, 2, L).transpose(0, 1)
     return v[0].reshape(-1), v[1].reshape(-1)
+
+
+def row_bands(height: int, world: int) -> list[tuple[int, int]]:
+    """(first luma row, luma rows) of each rank's band of a yuv420p picture `height` rows high: whole chroma rows, sizes differing
+    by at most one chroma row, the larger bands first."""
+    if height % 2:
+        raise ValueError("a yuv420p picture has an even number of luma rows")
+    ch = height // 2
+    base, rem = divmod(ch, world)
+    out, row = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((2 * row, 2 * n))
+        row += n
+    return out
+
+
+def _tap_span(o: int, src: int, dst: int) -> tuple[int, int]:
+    """[first, first + n) source indices output sample o reads (before clamping), from the scaler's spec (DESIGN.md "Scaler")."""
+    pos = ((2 * o + 1) * src * 65536) // (2 * dst) - 32768
+    ip = pos >> 16
+    if src <= dst:
+        return ip - 1, ip + 3
+    n = 2 * -(-2 * src // dst) + 2
+    return ip - n // 2 + 1, ip + n // 2 + 1
+
+
+def scale_geometry(in_w: int, in_h: int, out_w: int, out_h: int) -> tuple[int, int, int, int]:
+    """DynamicScaler geometry (src/video/encode.rs:354-374): (scaled_w, scaled_h, letterbox_x, letterbox_y), all even."""
+    if out_w * in_h <= out_h * in_w:
+        num, den = out_w, in_w
+    else:
+        num, den = out_h, in_h
+    sw, sh = (num * in_w // den) & ~1, (num * in_h // den) & ~1
+    return sw, sh, ((out_w - sw) // 2) & ~1, ((out_h - sh) // 2) & ~1
+
+
+def band_source_rows(band: tuple[int, int], in_w: int, in_h: int, out_w: int, out_h: int) -> tuple[int, int] | None:
+    """The slice of a SCALED layer a band needs: (first luma row, luma rows) of the (in_w x in_h) source whose letterboxed scale into
+    (out_w x out_h) the band (first luma row, rows) cuts -- the union over the three planes of the rows the band's vertical taps
+    reach after clamping to the plane, widened to whole chroma rows.  None when the band lies entirely in the letterbox bars."""
+    _sw, sh, _lx, ly = scale_geometry(in_w, in_h, out_w, out_h)
+    lo, hi = None, None
+    for c in (0, 1):                                     # luma, chroma
+        b0, b1 = band[0] >> c, (band[0] + band[1]) >> c
+        s0, s1 = ly >> c, (ly + sh) >> c
+        a, b = max(b0, s0), min(b1, s1)
+        if a >= b:
+            continue
+        src_h, dst_h = in_h >> c, sh >> c
+        f0, _ = _tap_span(a - s0, src_h, dst_h)
+        _, l1 = _tap_span(b - 1 - s0, src_h, dst_h)
+        r0 = min(max(f0, 0), src_h - 1) << c
+        r1 = (min(max(l1 - 1, 0), src_h - 1) + 1) << c
+        lo = r0 if lo is None else min(lo, r0)
+        hi = r1 if hi is None else max(hi, r1)
+    if lo is None:
+        return None
+    lo &= ~1
+    hi = (hi + 1) & ~1
+    return lo, hi - lo

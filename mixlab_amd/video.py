@@ -32,6 +32,7 @@ _proto("mx_dframe_planes", C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER
 _proto("mx_video_blank", C.c_int, C.c_void_p, C.c_void_p)
 _proto("mx_video_crossfade", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p)
 _proto("mx_video_scale", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_proto("mx_video_scale_band", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 _proto("mx_video_scaler_create", C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p))
 _proto("mx_video_scaler_scale", C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p))
 _proto("mx_video_scaler_destroy", None, C.c_void_p)
@@ -166,6 +167,11 @@ def crossfade(out: DFrame, a: DFrame | None, b: DFrame | None, fader: float, str
 
 def scale(src: DFrame, dst: DFrame, stream=None):
     check(lib.mx_video_scale(src._h, dst._h, stream))
+
+
+def scale_band(slice_: DFrame, in_full_h: int, src_row0: int, out_band: DFrame, full_w: int, full_h: int, row0: int, stream=None):
+    """Rows [row0, row0 + out_band.height) of the letterboxed (full_w x full_h) scale, from a slice of the source (mx_video_scale_band)."""
+    check(lib.mx_video_scale_band(slice_._h, in_full_h, src_row0, out_band._h, full_w, full_h, row0, stream))
 
 
 class Scaler:

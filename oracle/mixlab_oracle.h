@@ -174,6 +174,11 @@ uint32_t orc_bicubic_tap_count(uint32_t src, uint32_t dst);
 void orc_bicubic_taps_n(uint32_t o, uint32_t src, uint32_t dst, int32_t* first, int32_t* coef);
 void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
                              uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh);
+/* BUILD-SPECIFIED row-band forms (multi-GPU sharding of one picture): rows [row0, row0 + rows) of the same
+ * scale from a source SLICE (rows [src_row0, src_row0 + src_rows) of the plane); -1 when the slice lacks a needed row */
+int orc_scale_plane_bicubic_rows(const uint8_t* slice, int32_t src_stride, uint32_t sw, uint32_t sh, uint32_t src_row0, uint32_t src_rows,
+                                 uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh, uint32_t row0, uint32_t rows);
+int orc_dynamic_scale_band(const orc_frame* in_slice, uint32_t in_full_h, uint32_t src_row0, orc_frame* out, uint32_t full_w, uint32_t full_h, uint32_t row0);
 /* src/video/encode.rs:338-397: identity when sizes match (copies), else blank + scale into letterbox */
 void orc_dynamic_scale(const orc_frame* in, orc_frame* out);
 /* BUILD-SPECIFIED (no reference counterpart): BT.709 limited-range integer YUV420P -> RGBA8,

@@ -186,6 +186,65 @@ void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw
     free(hfirst); free(hc); free(tmp); free(vc);
 }
 
+/* BUILD-SPECIFIED (multi-GPU row bands): output rows [row0, row0 + rows) of the same scale, reading the
+ * source through a SLICE that holds source rows [src_row0, src_row0 + src_rows) of a plane that is `sh` rows high -- tap indices
+ * clamp against the FULL plane (as the unsharded scale does), then must fall inside the slice (the caller's halo).  Returns -1
+ * if a needed row lies outside the slice.  dst points at output row `row0`. */
+int orc_scale_plane_bicubic_rows(const uint8_t* slice, int32_t src_stride, uint32_t sw, uint32_t sh, uint32_t src_row0, uint32_t src_rows,
+                                 uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh, uint32_t row0, uint32_t rows) {
+    const uint32_t hn = orc_bicubic_tap_count(sw, dw), vn = orc_bicubic_tap_count(sh, dh);
+    int32_t* hfirst = (int32_t*)malloc(sizeof(int32_t) * dw);
+    int32_t* hc = (int32_t*)malloc(sizeof(int32_t) * hn * dw);
+    for (uint32_t x = 0; x < dw; x++) orc_bicubic_taps_n(x, sw, dw, &hfirst[x], &hc[(size_t)hn * x]);
+    int32_t* vc = (int32_t*)malloc(sizeof(int32_t) * vn);
+    int32_t* trow = (int32_t*)malloc(sizeof(int32_t) * (size_t)dw * vn);
+    int rc = 0;
+    for (uint32_t y = row0; y < row0 + rows && y < dh && rc == 0; y++) {
+        int32_t vfirst;
+        orc_bicubic_taps_n(y, sh, dh, &vfirst, vc);
+        for (uint32_t k = 0; k < vn; k++) {             /* the H-filtered source rows this output row reads */
+            int32_t sy = clampi(vfirst + (int32_t)k, 0, (int32_t)sh - 1);
+            if (sy < (int32_t)src_row0 || sy >= (int32_t)(src_row0 + src_rows)) { rc = -1; break; }
+            const uint8_t* row = slice + (size_t)(sy - (int32_t)src_row0) * src_stride;
+            for (uint32_t x = 0; x < dw; x++) {
+                int32_t acc = 0;
+                for (uint32_t j = 0; j < hn; j++) acc += hc[(size_t)hn * x + j] * (int32_t)row[clampi(hfirst[x] + (int32_t)j, 0, (int32_t)sw - 1)];
+                trow[(size_t)k * dw + x] = (acc + 64) >> 7;
+            }
+        }
+        if (rc) break;
+        uint8_t* drow = dst + (size_t)(y - row0) * dst_stride;
+        for (uint32_t x = 0; x < dw; x++) {
+            int32_t acc = 0;
+            for (uint32_t k = 0; k < vn; k++) acc += vc[k] * trow[(size_t)k * dw + x];
+            drow[x] = (uint8_t)clampi((acc + (1 << 20)) >> 21, 0, 255);
+        }
+    }
+    free(hfirst); free(hc); free(vc); free(trow);
+    return rc;
+}
+
+/* The band of DynamicScaler::scale (encode.rs:338-397) a rank of a row-band sharded job computes: luma rows [row0, row0 + out->height)
+ * of the (full_w x full_h) letterboxed result, from a source slice holding luma rows [src_row0, src_row0 + in_slice->height) of a frame
+ * that is in_full_h rows high (chroma: halves).  out->width == full_w.  Returns -1 when the slice lacks a row the band needs. */
+int orc_dynamic_scale_band(const orc_frame* in_slice, uint32_t in_full_h, uint32_t src_row0, orc_frame* out, uint32_t full_w, uint32_t full_h, uint32_t row0) {
+    orc_scale_geometry g;
+    orc_scaler_geometry(in_slice->width, in_full_h, full_w, full_h, &g);
+    orc_frame_blank(out);
+    int rc = 0;
+    for (int p = 0; p < 3 && rc == 0; p++) {
+        const uint32_t c = p ? 1 : 0;
+        const uint32_t b0 = row0 >> c, b1 = (row0 + out->height) >> c;             /* the band in this plane's rows */
+        const uint32_t s0 = g.letterbox_y >> c, s1 = (g.letterbox_y + g.scaled_h) >> c; /* the scaled picture's rows */
+        const uint32_t a = b0 > s0 ? b0 : s0, b = b1 < s1 ? b1 : s1;
+        if (a >= b) continue;                                                       /* the band lies in the letterbox bars */
+        rc = orc_scale_plane_bicubic_rows(in_slice->data[p], in_slice->stride[p], in_slice->width >> c, in_full_h >> c, src_row0 >> c, in_slice->height >> c,
+                                          out->data[p] + (size_t)(a - b0) * out->stride[p] + (g.letterbox_x >> c), out->stride[p],
+                                          g.scaled_w >> c, g.scaled_h >> c, a - s0, b - a);
+    }
+    return rc;
+}
+
 /* DynamicScaler::scale, src/video/encode.rs:338-397: equal settings => the frame itself (here: a
  * copy of the visible area); otherwise blank output (encode.rs:382) and scale into the letterboxed
  * sub-frame (encode.rs:386-392; sub-frame plane offsets, frame.rs:253-278). */

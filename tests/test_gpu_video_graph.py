@@ -105,3 +105,55 @@ def test_video_source_ring_delivers_a_new_frame_every_tick_cycling():
     video.graph_set_video_source_ring(g, s, [], dur=(1, 60), off=(0, 1))   # cleared: the stored frame expires, then None
     g.run_ticks(11, 2)
     assert video.graph_video_output(g, m, 0) is None
+
+
+@pytest.mark.parametrize("full,small,world", [((320, 180), (212, 120), 4), ((1920, 1080), (1280, 720), 8)])
+def test_row_band_compositing_on_the_device_equals_the_unsharded_picture(full, small, world):
+    """What the ranks of a row-band sharded job run (mixlab_amd/shard.py), all on one GPU here: every band gets its own rows of the
+    same-size layers and only the halo slice of the scaled layers (mx_video_scale_band), runs the same VideoMixer cascade + RGBA
+    sink on band-sized frames; stitched, the bands must be the unsharded oracle picture bit for bit."""
+    from mixlab_amd import shard
+    from test_cpu_video_bands import rows_of, cascade as oracle_cascade
+    W, H = full
+    layers = [ov.HostFrame(W, H).fill(k, seed=4) for k in range(6)] + [ov.HostFrame(*small).fill(k, seed=4) for k in (6, 7)]
+    whole = []
+    for f in layers:
+        o = f
+        if (f.w, f.h) != (W, H):
+            o = ov.HostFrame(W, H); ov.dynamic_scale(f, o)
+        whole.append(o)
+    want = oracle_cascade(whole)
+    want_rgba = ov.to_rgba(want, MATRIX)
+    got_rgba = np.zeros_like(want_rgba)
+    got_planes = [np.zeros_like(p) for p in want.visible()]
+    for (row0, rows) in shard.row_bands(H, world):
+        ws, srcs, mixers, rgba = cascade([(W, rows)] * 8, MATRIX)
+        g = ws.build()
+        keep = []
+        for k, f in enumerate(layers):
+            if (f.w, f.h) == (W, H):
+                d = upload(rows_of(f, row0, rows))
+            else:
+                d = video.DFrame(W, rows)
+                need = shard.band_source_rows((row0, rows), f.w, f.h, W, H)
+                if need is not None:
+                    sl = upload(rows_of(f, need[0], need[1]))
+                    video.scale_band(sl, f.h, need[0], d, W, H, row0)
+                    keep.append(sl)
+            keep.append(d)
+            video.graph_set_video_source(g, srcs[k], d, dur=(1, 60), off=(0, 1), repeat=True)
+        g.run_ticks(0, 1)
+        band = video.graph_video_output(g, mixers[-1], 0)
+        for p, a in enumerate(band.download()):
+            c = 1 if p else 0
+            got_planes[p][row0 >> c:(row0 + rows) >> c, :] = a
+        got_rgba[row0:row0 + rows] = video.graph_rgba_output(g, rgba)
+    for p, (a, b) in enumerate(zip(got_planes, want.visible())):
+        assert np.array_equal(a, b), f"plane {p}: stitched device bands differ from the unsharded picture"
+    assert np.array_equal(got_rgba, want_rgba)
+    # a slice without its halo is refused, not read past
+    f = layers[6]
+    band = shard.row_bands(H, world)[1]
+    need = shard.band_source_rows(band, f.w, f.h, W, H)
+    with pytest.raises(abi.MxError):
+        video.scale_band(upload(rows_of(f, need[0] + 2, need[1] - 2)), f.h, need[0] + 2, video.DFrame(W, band[1]), W, H, band[0])
