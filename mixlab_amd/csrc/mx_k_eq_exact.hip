@@ -740,26 +740,35 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     const int force_c = env_int("MX_EQ_SPEC_CHUNKS", 0);     // tuning / tests: chunks per instance (1 = never speculate)
     if (force_c == 1) return false;
     if (frames < 2 * W || frames < 64) return false;          // a stream shorter than two warm-ups: one lane per instance
-    // Plan (measured on MI355X, 1024 strips x 2048 ticks: 4.3 - 4.7 ms for 2 .. 7 waves per SIMD, 5.8 ms at 1): about three waves
-    // per SIMD over the chip (one wave = 64 chunks of one instance), chunks no shorter than three warm-ups (<= 1/3 extra work),
-    // whole ticks when that is a multiple of 16 samples (an inline Envelope's state is read once per tick and every lane of a wave
-    // crosses its tick boundaries at the same step), else multiples of 32 samples.
+    // Chunk lengths are whole ticks when that is a multiple of 16 samples (an inline Envelope's state is read once per tick and every
+    // lane of a wave crosses its tick boundaries at the same step), else multiples of 32 samples.
     const size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
     auto chunk_of = [&](size_t nc) { return ((frames + nc - 1) / nc + unit - 1) / unit * unit; };
     const size_t nc_max = frames / W;                          // C >= W: a warm-up never reaches before the stream
     size_t best;
     if (force_c > 1) best = std::min<size_t>((size_t)force_c, nc_max);
     else {
-        const size_t waves_wanted = 3 * 1024;
-        const size_t wpi = std::max<size_t>(1, (waves_wanted + n / 2) / n);
-        best = std::min<size_t>(wpi * 64, std::max<size_t>(frames / (3 * W), 1));
-        // few waves (at most ~1 per SIMD): a wave runs at its dependency latency whether 1 or 64 of its lanes work, so shorter chunks
-        // -- more lanes of the one wave, down to a chunk of one warm-up -- only shorten it
-        if ((size_t)n * ((best + 63) / 64) <= 1536) best = std::max<size_t>(best, std::min<size_t>(64, nc_max));
+        // Cost of a plan with nc chunks per instance: the samples every lane walks, warm-ups included, over how full the chip is --
+        // the VALU pipes saturate at about 3 waves per SIMD (measured: 1 wave 5.8 ms, 2 waves 4.7, 3 waves 4.3, 4 - 7 waves 4.4 - 4.7 for
+        // 1024 strips x 2048 ticks); a wave is 64 chunks of one instance.  Few instances => more, shorter chunks, down to one warm-up
+        // (the rank of an 8-GPU job: 128 strips run 1024 chunks of two ticks).  Below one wave per SIMD a wave runs at its own
+        // pace whether 1 or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
+        auto cost = [&](size_t nc) {
+            const double waves = (double)n * (double)((nc + 63) / 64);
+            const double occ = std::min(1.0, waves / 3072.0);
+            return ((double)nc * (double)(chunk_of(nc) + W)) / occ;     // ~ frames + nc * W, with the chunk rounding
+        };
+        best = std::min<size_t>(64, nc_max);
+        double best_cost = cost(best);
+        for (size_t nc = 128; nc <= nc_max && nc <= 8192; nc += 64) {
+            const double c = cost(nc);
+            if (c < best_cost * 0.98) { best_cost = c; best = nc; }
+        }
         // one lane per instance (no speculation) costs `frames` dependent steps of ~110 cycles, 64 instances per wave; a chunk lane
-        // (C + W) steps of ~300 cycles when its wave has a SIMD to itself
+        // (C + W) steps of ~460 cycles when its wave has a SIMD to itself, ~190 per resident wave when the pipes are shared
         const double seq = (double)frames * 110.0 * std::ceil((double)((n + 63) / 64) / 1024.0);
-        const double spec = (double)(chunk_of(best) + W) * 300.0 * std::max(1.0, (double)n * (double)((best + 63) / 64) / 3072.0);
+        const double per_simd = std::max(1.0, (double)n * (double)((best + 63) / 64) / 1024.0);
+        const double spec = (double)(chunk_of(best) + W) * (per_simd <= 1.0 ? 460.0 : 190.0 * per_simd);
         if (best < 2 || spec >= seq) return false;
     }
     if (best < 2) return false;
