@@ -1243,7 +1243,7 @@ void Graph::run_video_tick(uint64_t t) {
             mx_video_to_rgba_params p; std::memcpy(&p, n.params.data(), sizeof p);
             if (d->lazy) {   // the composite only exists as a cross-fade chain: evaluate it straight into RGBA
                 ChainRgbaArgs c;
-                fill_chain_sources(*d->lazy, c.src, c.n_src, c.fade, c.v_is_a);
+                fill_chain_rgba_sources(*d->lazy, c, stream_);   // layers that are unevaluated scaler outputs are resampled inside the kernel
                 c.rgba = (uint8_t*)n.rgba.p; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
                 c.use_matrix = p.use_matrix;
                 for (int k = 0; k < 12; ++k) c.m[k] = p.matrix_q12[k];
@@ -1251,6 +1251,7 @@ void Graph::run_video_tick(uint64_t t) {
                 n.rgba_w = d->width; n.rgba_h = d->height; n.rgba_stride = stride;
                 break;
             }
+            d->ensure_pixels(stream_);
             RgbaArgs a;
             a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = (uint8_t*)n.rgba.p;
             a.y_stride = d->stride[0]; a.u_stride = d->stride[1]; a.v_stride = d->stride[2]; a.rgba_stride = (uint32_t)stride;

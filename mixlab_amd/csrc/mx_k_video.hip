@@ -164,17 +164,163 @@ __device__ __forceinline__ uint32_t yuv_px(const int* m, int Y, int U, int V) {
                      m[8] * R + m[9] * G + m[10] * B + m[11] + 2048, 12);
 }
 
-template <int MM>
+#define SC_TW 128
+#define SC_TH 32
+// ---- the 4-tap two-pass resampler on a 128 x 32 tile (shared by the stand-alone tiled scaler and the chain kernel's inline layers) ----
+// Arithmetic of DESIGN.md "Scaler":  H pass t = (sum hc*S + 64) >> 7,  V pass D = clip8((sum vc*t + 2^20) >> 21), Q14 taps that sum to
+// 16384.  The kernels evaluate the SAME integers with gfx950's packed dot products (a wave64 VALU instruction occupies the 16-lane
+// SIMD for four cycles: the instruction count is what these latency-sized kernels pay for):
+//   H  the window is staged as s' = S - 128 (bytes ^ 0x80, signed); a tap c = 256 ch + cl with cl in [-128, 127] (host-packed, i8 x 4):
+//        sum c S = 256 dot4(s', ch) + dot4(s', cl) + 128 * 16384    -- two v_dot4_i32_i8 instead of four unpack + multiply-add pairs;
+//      the H-filtered value is kept as t' = t - 16384, an i16 (the host checks the range from the actual taps).
+//   V  rows of t' are stored in PAIRS: T2[p] holds (t'[p], t'[p+1]) per column, for every p, so the four taps of an output row whose
+//      first tap row is vf are the two dwords T2[vf], T2[vf+2]:  sum vc t = dot2(T2[vf], vc01) + dot2(T2[vf+2], vc23) + 16384 * 16384
+//      -- two v_dot2_i32_i16 per pixel.  Every intermediate stays below 2^31 (|vc| < 2^15, |t'| < 2^15, four terms).
+// Host side: ScaleTables::lean holds the packed taps; contexts whose taps do not fit use the gather kernel.
+// first tap of output o (DESIGN.md "Scaler"): ((floor((2o+1) src 65536 / (2 dst)) - 32768) >> 16) - 1  ==  floor(((2o+1) src + dst) / (2 dst)) - 2
+// (the -32768 is half a source sample; adding 2 dst keeps the numerator positive).  32-bit: frames are at most 16384 wide.  The quotient
+// is an f32 estimate (relative error < 2^-22, quotient < 2^15: off by at most one) corrected with the exact remainder.
+__host__ __device__ __forceinline__ int sc_first_tap(uint32_t o, uint32_t src, uint32_t dst, float rcp2d /* 1.0f / (2 dst), IEEE */) {
+    const uint32_t n = (2u * o + 1u) * src + dst, d = 2u * dst;
+    uint32_t q = (uint32_t)((float)n * rcp2d);
+    const int32_t r = (int32_t)(n - q * d);
+    q += (r >= (int32_t)d) ? 1u : 0u;
+    q -= (r < 0) ? 1u : 0u;
+    return (int)q - 2;
+}
+bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first /* host copy of the tap table */) {
+    const float rcp = 1.0f / (float)(2u * dst);
+    for (uint32_t o = 0; o < dst; ++o)     // every output: the inline resampler's windows start wherever the letterbox offset puts them
+        if (sc_first_tap(o, src, dst, rcp) != first[o]) return false;
+    return true;
+}
+struct ScWin { int cxa, nc4, ry0, nr; };   // source window of a tile part: columns [cxa, cxa + 4 nc4) (cxa on a 16-byte boundary), rows [ry0, ry0 + nr)
+__device__ __forceinline__ ScWin sc_window(int oxa, int oxb, int oya, int oyb, uint32_t sw, uint32_t dw, uint32_t sh, uint32_t dh) {   // outputs [oxa, oxb) x [oya, oyb)
+    const float rh = 1.0f / (float)(2u * dw), rv = 1.0f / (float)(2u * dh);
+    const int cx0 = sc_first_tap((uint32_t)oxa, sw, dw, rh), cxl = sc_first_tap((uint32_t)(oxb - 1), sw, dw, rh);
+    const int ry0 = sc_first_tap((uint32_t)oya, sh, dh, rv), ryl = sc_first_tap((uint32_t)(oyb - 1), sh, dh, rv);
+    ScWin w; w.cxa = cx0 & ~15; w.nc4 = (cxl + 4 - w.cxa + 3) >> 2; w.ry0 = ry0; w.nr = ryl + 4 - ry0;
+    return w;
+}
+// stage the window as signed bytes s' = S - 128 (edge replication here).  16 lanes per window row, 16 bytes each: slot q of a lane is
+// row (tid >> 4) + 16 q, chunk tid & 15; the window starts on a 16-byte boundary of the source row (ScWin::cxa).  All interior
+// chunks of a lane are requested back to back (no control flow between the loads: a loop that loads and stores per iteration pays one
+// memory round trip per iteration); border chunks -- only in tiles at the picture's edges -- are assembled from clamped byte loads
+// afterwards.
+template <int Q>
+__device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride, int sw, int sh, const ScWin& g, uint8_t* S, int s_stride, int tid) {
+    const int sw1 = sw - 1, sh1 = sh - 1;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15u) == 0 && sw >= 16;
+    const int c16 = tid & 15, x = g.cxa + 16 * c16;
+    const bool col_ok = 4 * c16 < g.nc4, interior = aligned && x >= 0 && x + 15 <= sw1;
+    const int xs = aligned ? (min(max(x, 0), sw1 - 15) & ~15) : 0;                // always a readable chunk of the row when `aligned`
+    uint4 w[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int r = (tid >> 4) + 16 * q;
+        const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+        w[q] = aligned ? *reinterpret_cast<const uint4*>(row + xs) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int r = (tid >> 4) + 16 * q;
+        if (r < g.nr && col_ok) {
+            if (!interior) {                                                    // edge replication
+                const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+                uint32_t d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    d[k] = (uint32_t)row[min(max(x + 4 * k, 0), sw1)] | ((uint32_t)row[min(max(x + 4 * k + 1, 0), sw1)] << 8) |
+                           ((uint32_t)row[min(max(x + 4 * k + 2, 0), sw1)] << 16) | ((uint32_t)row[min(max(x + 4 * k + 3, 0), sw1)] << 24);
+                w[q] = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            *reinterpret_cast<uint4*>(S + (size_t)r * s_stride + 16 * c16) =
+                make_uint4(w[q].x ^ 0x80808080u, w[q].y ^ 0x80808080u, w[q].z ^ 0x80808080u, w[q].w ^ 0x80808080u);
+        }
+    }
+}
+// H pass of tile column i over window rows: T2[p][i] = (t'[p], t'[p+1]) for p in [p0, p1) -- a thread walks its rows in order, so every
+// H-filtered value costs one dot-product group and one LDS store of the pair it closes.
+__device__ __forceinline__ int sc_hdot(const uint8_t* Srow, int hb, uint32_t sh8, const uint2 hpk) {   // (t - 16384) << 7, low bits kept
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(Srow + hb);
+    const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], sh8);                         // s' of taps hf .. hf + 3
+    const int hi = __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, false);                       // sum ch s'
+    return __builtin_amdgcn_sdot4((int)w, (int)hpk.y, hi * 256 + 64, false);                  // 256 sum ch s' + sum cl s' + 64
+}
+__device__ __forceinline__ void sc_hcol(const uint8_t* S, int s_stride, int hf /* first tap - cxa */, const uint2 hpk, uint32_t* T2, int t_cols, int i, int p0, int p1) {
+    if (p0 >= p1) return;
+    const int hb = hf & ~3; const uint32_t sh8 = (uint32_t)(hf & 3);
+    const uint8_t* Srow = S + (size_t)p0 * s_stride;
+    uint32_t* out = T2 + p0 * t_cols + i;
+    uint32_t prev = (uint32_t)sc_hdot(Srow, hb, sh8, hpk) >> 7;
+#pragma unroll 2
+    for (int p = p0; p < p1; ++p) {
+        Srow += s_stride;
+        const uint32_t cur = (uint32_t)sc_hdot(Srow, hb, sh8, hpk) >> 7;
+        *out = __builtin_amdgcn_perm(cur, prev, 0x05040100u);                                  // (t'[p] & 0xffff) | (t'[p+1] << 16)
+        out += t_cols; prev = cur;
+    }
+}
+typedef short sc_s2 __attribute__((ext_vector_type(2)));
+// V pass: four pixels at tile columns col .. col + 3 of the output row whose first tap row (relative to the window) is vf
+__device__ __forceinline__ uint32_t sc_vquad(const uint32_t* T2, int t_cols, int vf, int col, const uint2 vpk) {
+    const uint32_t* P = T2 + vf * t_cols + col;
+    const uint4 p0 = *reinterpret_cast<const uint4*>(P), p1 = *reinterpret_cast<const uint4*>(P + 2 * t_cols);
+    const sc_s2 c01 = __builtin_bit_cast(sc_s2, vpk.x), c23 = __builtin_bit_cast(sc_s2, vpk.y);
+    const int K = 16384 * 16384 + (1 << 20);
+    auto px = [&](uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(sc_s2, b), c23, __builtin_amdgcn_sdot2(__builtin_bit_cast(sc_s2, a), c01, K, false), false); };
+    // clip8(sum >> 21) x 4 -> one dword: two v_ashr_pk_u8_i32 (explicit builtin, see pack_rgba)
+    const uint32_t lo = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(px(p0.x, p1.x), px(p0.y, p1.y), 21);
+    const uint32_t hi = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(px(p0.z, p1.z), px(p0.w, p1.w), 21);
+    return lo | (hi << 16);
+}
+
+// ---- inline resampling of chain layers (ChainScale) ----
+// A block of the RGBA chain owns a 128 x 32 luma tile (64 x 16 chroma).  Per scaled layer: the source windows of the three planes are
+// staged in LDS, the H pass filters every window row once per tile column, the V pass leaves each lane's own pixels in registers in
+// the layout the chain evaluates (L[k][0..5]).  Pixels outside the scaled picture (letterbox bars) are the blank constant
+// (encode.rs:382-396).
+#define CS_SY_STRIDE 160
+#define CS_SY_ROWS 36
+#define CS_SC_STRIDE 96
+#define CS_SC_ROWS 20
+#define CS_S_BYTES (CS_SY_ROWS * CS_SY_STRIDE + 2 * CS_SC_ROWS * CS_SC_STRIDE)              /* 9600 per scaled layer */
+#define CS_TY_DW (CS_SY_ROWS * 128)                                                        /* row pairs (p, p + 1), dwords */
+#define CS_TC_DW (CS_SC_ROWS * 64)
+#define CS_T_BYTES ((CS_TY_DW + 2 * CS_TC_DW) * 4)                                          /* 28672, shared by the layers */
+struct CsGeo { int xa, xb, ya, yb; ScWin w; };   // in-tile part of the scaled picture (plane coordinates) and its source window
+__device__ __forceinline__ CsGeo cs_geo(const ChainScale& s, int c, int X0, int Y0, int TW, int TH) {
+    CsGeo g;
+    const int lx = (int)s.lx[c], ly = (int)s.ly[c];
+    g.xa = max(X0, lx); g.xb = min(X0 + TW, lx + (int)s.dw[c]);
+    g.ya = max(Y0, ly); g.yb = min(Y0 + TH, ly + (int)s.dh[c]);
+    g.w.cxa = 0; g.w.nc4 = 0; g.w.ry0 = 0; g.w.nr = 0;
+    if (g.xa < g.xb && g.ya < g.yb) g.w = sc_window(g.xa - lx, g.xb - lx, g.ya - ly, g.yb - ly, s.sw[c], s.dw[c], s.sh[c], s.dh[c]);
+    return g;
+}
+__device__ __forceinline__ uint32_t cs_bytes_below(int n) { return n <= 0 ? 0u : (n >= 4 ? 0xffffffffu : ((1u << (8 * n)) - 1u)); }
+// keep the bytes of `quad` whose pixel x0 + b lies in [xa, xb); the others are `blank`
+__device__ __forceinline__ uint32_t cs_mask_quad(uint32_t quad, uint32_t blank, int x0, int xa, int xb) {
+    const uint32_t m = cs_bytes_below(xb - x0) & ~cs_bytes_below(xa - x0);
+    return (quad & m) | (blank & ~m);
+}
+
+template <int MM, bool SC>
 __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
-    const uint32_t xb = blockIdx.x * 64 + (threadIdx.x & 63);     // 8-pixel column block
-    const uint32_t yb = blockIdx.y * 4 + (threadIdx.x >> 6);       // row pair
-    if (xb * 8 >= a.width || yb * 2 >= a.height) return;
+    // tile of 128 x 32 luma pixels; a lane owns 8 pixels x 2 rows and their 4 + 4 chroma samples
+    const int tid = threadIdx.x;
+    const int cb = tid & 15, rp = tid >> 4;
+    const int X0 = blockIdx.x * 128, Y0 = blockIdx.y * 32;
+    const uint32_t xb = (uint32_t)(X0 / 8 + cb);     // 8-pixel column block
+    const uint32_t yb = (uint32_t)(Y0 / 2 + rp);     // row pair
+    const bool valid = xb * 8 < a.width && yb * 2 < a.height;
+    if (!SC && !valid) return;
     // per source: 2 dwords of Y for each of the two rows, one dword of U, one of V  (6 dwords)
     uint32_t L[MX_CHAIN_MAX_SRC][6];
 #pragma unroll
     for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
         L[k][0] = L[k][1] = L[k][2] = L[k][3] = 0u; L[k][4] = L[k][5] = 0x80808080u;
-        if (k < (int)a.n_src) {
+        if (k < (int)a.n_src && valid) {
             const ChainSrc& s = a.src[k];
             if (s.p[0]) {
                 const uint2 r0 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)(2 * yb) * s.stride[0] + xb * 8);
@@ -184,6 +330,95 @@ __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
             if (s.p[1]) L[k][4] = *reinterpret_cast<const uint32_t*>(s.p[1] + (size_t)yb * s.stride[1] + xb * 4);
             if (s.p[2]) L[k][5] = *reinterpret_cast<const uint32_t*>(s.p[2] + (size_t)yb * s.stride[2] + xb * 4);
         }
+    }
+    if (SC) {
+        extern __shared__ __attribute__((aligned(16))) uint8_t cs_smem[];
+        uint32_t* const Ty = reinterpret_cast<uint32_t*>(cs_smem);       // [36][128] pairs of H-filtered rows (p, p + 1)
+        uint32_t* const Tu = Ty + CS_TY_DW;                               // [20][64]
+        uint32_t* const Tv = Tu + CS_TC_DW;
+        uint8_t* const S0 = cs_smem + CS_T_BYTES;
+        CsGeo gy[MX_CHAIN_MAX_SCALED], gc[MX_CHAIN_MAX_SCALED];
+        // every table entry a lane will need, requested before anything waits
+        uint2 hpY[MX_CHAIN_MAX_SCALED], hpC[MX_CHAIN_MAX_SCALED], vpY[MX_CHAIN_MAX_SCALED][2], vpC[MX_CHAIN_MAX_SCALED];
+        int hfY[MX_CHAIN_MAX_SCALED], hfC[MX_CHAIN_MAX_SCALED], vfY[MX_CHAIN_MAX_SCALED][2], vfC[MX_CHAIN_MAX_SCALED];
+#pragma unroll
+        for (int j = 0; j < MX_CHAIN_MAX_SCALED; ++j) {
+            if (j < (int)a.n_scaled) {
+                const ChainScale& s = a.sc[j];
+                const int oxY = min(max(X0 + (tid & 127) - (int)s.lx[0], 0), (int)s.dw[0] - 1), oxC = min(max(X0 / 2 + (tid & 63) - (int)s.lx[1], 0), (int)s.dw[1] - 1);
+                hpY[j] = s.hpk[0][oxY]; hfY[j] = s.hfirst[0][oxY];
+                hpC[j] = s.hpk[1][oxC]; hfC[j] = s.hfirst[1][oxC];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int oy = min(max(Y0 + 2 * rp + r - (int)s.ly[0], 0), (int)s.dh[0] - 1);
+                    vpY[j][r] = s.vpk[0][oy]; vfY[j][r] = s.vfirst[0][oy];
+                }
+                const int oyC = min(max(Y0 / 2 + rp - (int)s.ly[1], 0), (int)s.dh[1] - 1);
+                vpC[j] = s.vpk[1][oyC]; vfC[j] = s.vfirst[1][oyC];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MX_CHAIN_MAX_SCALED; ++j) {
+            if (j < (int)a.n_scaled) {
+                const ChainScale& s = a.sc[j];
+                gy[j] = cs_geo(s, 0, X0, Y0, 128, 32);
+                gc[j] = cs_geo(s, 1, X0 / 2, Y0 / 2, 64, 16);
+                uint8_t* Sy = S0 + j * CS_S_BYTES; uint8_t* Su = Sy + CS_SY_ROWS * CS_SY_STRIDE; uint8_t* Sv = Su + CS_SC_ROWS * CS_SC_STRIDE;
+                sc_stage<3>(s.src[0], s.src_stride[0], (int)s.sw[0], (int)s.sh[0], gy[j].w, Sy, CS_SY_STRIDE, tid);
+                sc_stage<2>(s.src[1], s.src_stride[1], (int)s.sw[1], (int)s.sh[1], gc[j].w, Su, CS_SC_STRIDE, tid);
+                sc_stage<2>(s.src[2], s.src_stride[2], (int)s.sw[1], (int)s.sh[1], gc[j].w, Sv, CS_SC_STRIDE, tid);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MX_CHAIN_MAX_SCALED; ++j) {
+            if (j < (int)a.n_scaled) {
+                const CsGeo Gy = gy[j], Gc = gc[j];
+                const uint8_t* Sy = S0 + j * CS_S_BYTES; const uint8_t* Su = Sy + CS_SY_ROWS * CS_SY_STRIDE; const uint8_t* Sv = Su + CS_SC_ROWS * CS_SC_STRIDE;
+                {   // H pass, luma: column i of the tile; the two threads of a column take half of the row pairs each
+                    const int i = tid & 127, x = X0 + i, np = Gy.w.nr - 1, half = (np + 1) >> 1, part = tid >> 7;
+                    if (x >= Gy.xa && x < Gy.xb)
+                        sc_hcol(Sy, CS_SY_STRIDE, hfY[j] - Gy.w.cxa, hpY[j], Ty, 128, i, part * half, min(part * half + half, np));
+                }
+                {   // H pass, chroma (U and V share the taps): column i; threads 0-127 U, 128-255 V, two per column
+                    const int i = tid & 63, x = X0 / 2 + i, np = Gc.w.nr - 1, half = (np + 1) >> 1, part = (tid >> 6) & 1;
+                    if (x >= Gc.xa && x < Gc.xb)
+                        sc_hcol((tid & 128) ? Sv : Su, CS_SC_STRIDE, hfC[j] - Gc.w.cxa, hpC[j], (tid & 128) ? Tv : Tu, 64, i, part * half, min(part * half + half, np));
+                }
+                __syncthreads();
+                uint32_t R[6] = {0u, 0u, 0u, 0u, 0x80808080u, 0x80808080u};
+                const bool edge_y = Gy.xa > X0 || Gy.xb < X0 + 128, edge_c = Gc.xa > X0 / 2 || Gc.xb < X0 / 2 + 64;   // block-uniform: a letterbox edge crosses the tile
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {   // V pass, luma
+                    const int y = Y0 + 2 * rp + r;
+                    if (Gy.xa < Gy.xb && y >= Gy.ya && y < Gy.yb) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            uint32_t quad = sc_vquad(Ty, 128, vfY[j][r] - Gy.w.ry0, cb * 8 + 4 * q, vpY[j][r]);
+                            if (edge_y) quad = cs_mask_quad(quad, 0u, X0 + cb * 8 + 4 * q, Gy.xa, Gy.xb);
+                            R[2 * r + q] = quad;
+                        }
+                    }
+                }
+                {   // V pass, chroma
+                    const int y = Y0 / 2 + rp;
+                    if (Gc.xa < Gc.xb && y >= Gc.ya && y < Gc.yb) {
+                        uint32_t qu = sc_vquad(Tu, 64, vfC[j] - Gc.w.ry0, cb * 4, vpC[j]), qv = sc_vquad(Tv, 64, vfC[j] - Gc.w.ry0, cb * 4, vpC[j]);
+                        if (edge_c) { qu = cs_mask_quad(qu, 0x80808080u, X0 / 2 + cb * 4, Gc.xa, Gc.xb); qv = cs_mask_quad(qv, 0x80808080u, X0 / 2 + cb * 4, Gc.xa, Gc.xb); }
+                        R[4] = qu; R[5] = qv;
+                    }
+                }
+                const uint32_t at = a.scaled_src[j];
+#pragma unroll
+                for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k)
+                    if ((uint32_t)k == at) {
+#pragma unroll
+                        for (int w = 0; w < 6; ++w) L[k][w] = R[w];
+                    }
+                if (j + 1 < (int)a.n_scaled) __syncthreads();   // T is reused by the next layer
+            }
+        }
+        if (!valid) return;
     }
     uint32_t v[6];
     chain_eval<6>(v, L, a.n_src, a.fade, a.v_is_a);
@@ -215,10 +450,17 @@ void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
         for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
         a.use_matrix = fits ? 2 : 1;
     }
-    const dim3 grid(((a.width + 7) / 8 + 63) / 64, ((a.height + 1) / 2 + 3) / 4);
-    if (a.use_matrix == 2) hipLaunchKernelGGL(k_fade_chain_rgba<2>, grid, dim3(256), 0, s, a);
-    else if (a.use_matrix) hipLaunchKernelGGL(k_fade_chain_rgba<1>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_fade_chain_rgba<0>, grid, dim3(256), 0, s, a);
+    const dim3 grid((a.width + 127) / 128, (a.height + 31) / 32);
+    if (a.n_scaled) {
+        const size_t lds = CS_T_BYTES + (size_t)a.n_scaled * CS_S_BYTES;
+        if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, true>), grid, dim3(256), lds, s, a);
+        else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_fade_chain_rgba<0, true>), grid, dim3(256), lds, s, a);
+        return;
+    }
+    if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), grid, dim3(256), 0, s, a);
+    else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_fade_chain_rgba<0, false>), grid, dim3(256), 0, s, a);
 }
 
 // Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
@@ -254,24 +496,6 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 // origin is COMPUTED from the tap spec instead of fetched -- the source loads do not wait for a table
 // round trip -- and every coefficient a lane will need is requested in the same burst.
 // Used when the window fits 64 KB of LDS (scale ratio <= 2); LDS is sized per launch.
-#define SC_TW 128
-#define SC_TH 32
-// first tap of output o (DESIGN.md "Scaler"): ((floor((2o+1) * src * 65536 / (2 dst)) - 32768) >> 16) - 1, evaluated in f64:
-// numerator and denominator are exact (< 2^49), the quotient is corrected with an exact fma remainder, and the rest
-// are exact operations on integers below 2^53 -- a 64-bit integer division costs several hundred VALU cycles here.
-// Scaler::retarget checks it against the integer tap tables for every tile origin it can be asked for.
-__host__ __device__ __forceinline__ int sc_first_tap(uint32_t o, uint32_t src, uint32_t dst) {
-    const double n = (double)(2u * o + 1u) * ((double)src * 65536.0), d = 2.0 * (double)dst;
-    double q = floor(n / d);
-    const double r = fma(-q, d, n);          // exact: |r| < 2 d
-    q += (r >= d) ? 1.0 : ((r < 0.0) ? -1.0 : 0.0);
-    return (int)floor((q - 32768.0) * (1.0 / 65536.0)) - 1;
-}
-bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first /* host copy of the tap table */) {
-    for (uint32_t o = 0; o < dst; ++o)
-        if ((o % SC_TW == 0 || o % SC_TH == 0 || o + 1 == dst || (o + 1) % SC_TW == 0 || (o + 1) % SC_TH == 0) && sc_first_tap(o, src, dst) != first[o]) return false;
-    return true;
-}
 __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     int plane = 0;
 #pragma unroll
@@ -280,68 +504,38 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     const uint32_t tile = blockIdx.x - a.tile_start[plane];
     const int ox0 = (int)(tile % a.tiles_x[plane]) * SC_TW, oy0 = (int)(tile / a.tiles_x[plane]) * SC_TH;
     extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
-    uint8_t* const S = sc_smem;                                                       // [s_rows][s_stride] source window
-    int* const T = reinterpret_cast<int*>(sc_smem + (size_t)a.s_rows * a.s_stride);   // [s_rows][SC_TW] H-filtered rows
+    uint32_t* const T2 = reinterpret_cast<uint32_t*>(sc_smem);                 // [s_rows][SC_TW] pairs (p, p + 1) of H-filtered rows
+    uint8_t* const S = sc_smem + (size_t)a.s_rows * SC_TW * 4;                 // [s_rows][s_stride] source window, signed bytes
     const int tid = threadIdx.x;
-    const int oxl = min(ox0 + SC_TW - 1, (int)p.dw - 1), oyl = min(oy0 + SC_TH - 1, (int)p.dh - 1);
-    // window origin / extent from the tap spec (tap tables are monotone); columns start on a dword of the source row
-    const int cx0 = sc_first_tap((uint32_t)ox0, p.sw, p.dw), cxl = sc_first_tap((uint32_t)oxl, p.sw, p.dw);
-    const int ry0 = sc_first_tap((uint32_t)oy0, p.sh, p.dh), ryl = sc_first_tap((uint32_t)oyl, p.sh, p.dh);
-    const int cxa = cx0 & ~3;
-    const int nc4 = min((cxl + 4 - cxa + 3) >> 2, (int)a.s_stride >> 2), nr = min(ryl + 4 - ry0, (int)a.s_rows);
+    const int oxe = min(ox0 + SC_TW, (int)p.dw), oye = min(oy0 + SC_TH, (int)p.dh);
+    ScWin w = sc_window(ox0, oxe, oy0, oye, p.sw, p.dw, p.sh, p.dh);
+    w.nc4 = min(w.nc4, (int)a.s_stride >> 2); w.nr = min(w.nr, (int)a.s_rows);
     // every table entry this lane will need, in one burst
     const int oxi = tid & (SC_TW - 1), ox = min(ox0 + oxi, (int)p.dw - 1);
-    const int4 hc = reinterpret_cast<const int4*>(p.hcoef)[ox];
-    const int hf = p.hfirst[ox] - cxa;
+    const uint2 hpk = p.hpk[ox];
+    const int hf = p.hfirst[ox] - w.cxa;
     const int cg = tid & 31, oyr = tid >> 5;                  // V pass: pixel group (4 columns) and first row; rows oyr + 8k
-    int4 vc[4]; int vf[4];
+    uint2 vpk[4]; int vf[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int oy = min(oy0 + oyr + 8 * k, (int)p.dh - 1);
-        vc[k] = reinterpret_cast<const int4*>(p.vcoef)[oy];
-        vf[k] = p.vfirst[oy] - ry0;
+        vpk[k] = p.vpk[oy];
+        vf[k] = p.vfirst[oy] - w.ry0;
     }
-    const int sw1 = (int)p.sw - 1, sh1 = (int)p.sh - 1;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(p.src) | p.src_stride) & 3u) == 0;
-    for (int r = tid >> 5; r < nr; r += 8) {                 // 32 lanes per window row, one dword each (no index division)
-        const uint8_t* row = p.src + (size_t)min(max(ry0 + r, 0), sh1) * p.src_stride;
-        for (int c4 = tid & 31; c4 < nc4; c4 += 32) {
-            const int x = cxa + 4 * c4;
-            uint32_t w;
-            if (aligned && x >= 0 && x + 3 <= sw1) w = *reinterpret_cast<const uint32_t*>(row + x);
-            else w = (uint32_t)row[min(max(x, 0), sw1)] | ((uint32_t)row[min(max(x + 1, 0), sw1)] << 8) |
-                     ((uint32_t)row[min(max(x + 2, 0), sw1)] << 16) | ((uint32_t)row[min(max(x + 3, 0), sw1)] << 24);   // edge replication
-            *reinterpret_cast<uint32_t*>(S + (size_t)r * a.s_stride + 4 * c4) = w;
-        }
+    sc_stage<3>(p.src, p.src_stride, (int)p.sw, (int)p.sh, w, S, (int)a.s_stride, tid);   // launcher: s_rows <= 48, s_stride <= 256
+    __syncthreads();
+    if (ox0 + oxi < (int)p.dw) {   // the two threads of a column take half of the row pairs each
+        const int np = w.nr - 1, half = (np + 1) >> 1, part = tid >> 7;
+        sc_hcol(S, (int)a.s_stride, hf, hpk, T2, SC_TW, oxi, part * half, min(part * half + half, np));
     }
     __syncthreads();
-    if (ox0 + oxi < (int)p.dw) {   // H pass: t = (sum hc * S + 64) >> 7; the 4 taps come out of two aligned dwords
-        const int hb = hf & ~3;
-        for (int r = tid >> 7; r < nr; r += 2) {
-            const uint32_t* sp = reinterpret_cast<const uint32_t*>(S + (size_t)r * a.s_stride + hb);
-            const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], (uint32_t)(hf & 3));   // bytes hf .. hf+3
-            // 24-bit products (full rate; v_mul_lo_u32 is quarter rate): Q14 coefficients x bytes
-            const int acc = __mul24(hc.x, (int)(w & 0xffu)) + __mul24(hc.y, (int)((w >> 8) & 0xffu)) + __mul24(hc.z, (int)((w >> 16) & 0xffu)) + __mul24(hc.w, (int)(w >> 24));
-            T[r * SC_TW + oxi] = (acc + 64) >> 7;
-        }
-    }
-    __syncthreads();
-    // V pass: D = clip8((sum vc * t + 2^20) >> 21), four pixels per lane and row
     const int oxg = cg * 4;
     if (ox0 + oxg < (int)p.dw) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int oyk = oy0 + oyr + 8 * k;
             if (oyk >= (int)p.dh) break;
-            const int4 t0 = *reinterpret_cast<const int4*>(&T[(vf[k] + 0) * SC_TW + oxg]), t1 = *reinterpret_cast<const int4*>(&T[(vf[k] + 1) * SC_TW + oxg]);
-            const int4 t2 = *reinterpret_cast<const int4*>(&T[(vf[k] + 2) * SC_TW + oxg]), t3 = *reinterpret_cast<const int4*>(&T[(vf[k] + 3) * SC_TW + oxg]);
-            const int4 c = vc[k];
-            // Q14 coefficients x H-filtered values (|t| < 2^16): 24-bit products are the int32 ones
-            auto col = [&](int a0, int a1, int a2, int a3) { return __mul24(c.x, a0) + __mul24(c.y, a1) + __mul24(c.z, a2) + __mul24(c.w, a3) + (1 << 20); };
-            // clip8(sum >> 21) x 4 -> one dword: two v_ashr_pk_u8_i32 (explicit builtin, see pack_rgba)
-            const uint32_t lo = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(col(t0.x, t1.x, t2.x, t3.x), col(t0.y, t1.y, t2.y, t3.y), 21);
-            const uint32_t hi = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(col(t0.z, t1.z, t2.z, t3.z), col(t0.w, t1.w, t2.w, t3.w), 21);
-            const uint32_t quad = lo | (hi << 16);
+            const uint32_t quad = sc_vquad(T2, SC_TW, vf[k], oxg, vpk[k]);
             uint8_t* o = p.dst + (size_t)oyk * p.dst_stride + ox0 + oxg;
             if (ox0 + oxg + 4 <= (int)p.dw && (reinterpret_cast<uintptr_t>(o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = quad;
             else for (int j = 0; j < 4 && ox0 + oxg + j < (int)p.dw; ++j) o[j] = (uint8_t)(quad >> (8 * j));
@@ -379,14 +573,16 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
         if (!p.dw || !p.dh) continue;
         // window of a 128 x 32 tile: taps of its first and last output + 4, columns widened to whole dwords
         const uint32_t rows = (uint32_t)(((uint64_t)SC_TH * p.sh + p.dh - 1) / p.dh) + 6;
-        const uint32_t cols = (uint32_t)(((uint64_t)SC_TW * p.sw + p.dw - 1) / p.dw) + 6 + 3 + 4;   // + the H pass's second dword
+        const uint32_t cols = (uint32_t)(((uint64_t)SC_TW * p.sw + p.dw - 1) / p.dw) + 6 + 15 + 4;   // 16-byte window start + the H pass's second dword
         s_rows = rows > s_rows ? rows : s_rows; s_stride = cols > s_stride ? cols : s_stride;
     }
     if (!a.n || !mw || !mh) return;
     s_stride = (s_stride + 15u) & ~15u;               // rows * stride stays a multiple of 16: T is read as int4
-    const size_t lds = (size_t)s_rows * s_stride + (size_t)s_rows * SC_TW * sizeof(int);
+    const size_t lds = (size_t)s_rows * s_stride + (size_t)s_rows * SC_TW * sizeof(int);   // both pair layouts of t' = one int per (row, column)
     static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
-    if (lds <= 64 * 1024 && !force_simple) {
+    bool lean = true;                                 // packed taps exist for every plane (ScaleTables::lean)
+    for (uint32_t i = 0; i < a.n; ++i) if (a.p[i].dw && a.p[i].dh && (!a.p[i].hpk || !a.p[i].vpk)) lean = false;
+    if (lds <= 64 * 1024 && s_rows <= 48 && s_stride <= 256 && !force_simple && lean) {   // the staging slots of sc_stage<3>
         ScaleBatchArgs b = a;
         uint32_t total = 0;
         for (uint32_t i = 0; i < a.n; ++i) {

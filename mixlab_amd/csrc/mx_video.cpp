@@ -2,6 +2,7 @@
 #include "mx_video.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -37,15 +38,15 @@ bool Rational::operator>=(const Rational& o) const {
 // deferred scaling: jobs queue per stream and leave as one batched launch when pixels are needed
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct PendingScales { ScaleBatchArgs args{}; std::vector<FrameRef> keep; };
+struct PendingScales { ScaleBatchArgs args{}; std::vector<FrameRef> keep; std::vector<std::shared_ptr<const ScaleTables>> keep_tabs; };
 std::mutex g_scale_mu;
 std::map<hipStream_t, PendingScales> g_scale_q;
 void flush_locked(hipStream_t s, PendingScales& q) {
     if (q.args.n) { launch_scale_batch(q.args, s); q.args.n = 0; }
-    q.keep.clear();
+    q.keep.clear(); q.keep_tabs.clear();
 }
 }  // namespace
-void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst) {
+void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs) {
     std::lock_guard<std::mutex> lk(g_scale_mu);
     PendingScales& q = g_scale_q[s];
     bool conflict = q.args.n + 3 > MX_SCALE_BATCH_PLANES;
@@ -53,6 +54,7 @@ void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const F
     if (conflict) flush_locked(s, q);
     for (int i = 0; i < 3; ++i) q.args.p[q.args.n++] = a.p[i];
     q.keep.push_back(src); q.keep.push_back(dst);
+    if (tabs) q.keep_tabs.push_back(std::move(tabs));   // the job reads these tables when it leaves
 }
 void flush_scales(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_scale_mu);
@@ -109,7 +111,20 @@ void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], u
     for (size_t k = c.steps.size(); k < MX_CHAIN_MAX_SRC - 1; ++k) { fade[k] = 0; v_is_a[k] = 1; }
 }
 
+DFrame* DFrame::create_lazy_scale(uint32_t w, uint32_t h, std::shared_ptr<LazyScale> sc) {
+    std::unique_ptr<DFrame> f(new DFrame());
+    f->width = w; f->height = h;
+    f->lazy_scale = std::move(sc);
+    return f.release();
+}
+
+static void chain_layers_need_pixels(const LazyChain& c, hipStream_t s) {   // k_fade_chain reads planes: unevaluated scaler outputs are computed first
+    if (c.base && c.base->lazy_scale) c.base->ensure_pixels(s);
+    for (const auto& st : c.steps) if (st.other && st.other->lazy_scale) st.other->ensure_pixels(s);
+}
+
 static void launch_chain_into(const LazyChain& c, DFrame* o, hipStream_t s) {
+    chain_layers_need_pixels(c, s);
     ChainArgs a;
     fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a);
     for (int p = 0; p < 3; ++p) {
@@ -122,10 +137,48 @@ static void launch_chain_into(const LazyChain& c, DFrame* o, hipStream_t s) {
 }
 
 void DFrame::ensure_pixels(hipStream_t s) {
+    if (lazy_scale) {   // the scaler's own output frame receives the pixels (encode.rs:386-396) and this frame becomes a view of it
+        const std::shared_ptr<LazyScale> sc = std::move(lazy_scale);
+        lazy_scale.reset();
+        scale_into(sc->src, sc->t, sc->target, nullptr, s);
+        alias = sc->target;
+        for (int p = 0; p < 3; ++p) { data[p] = alias->data[p]; stride[p] = alias->stride[p]; plane_bytes[p] = alias->plane_bytes[p]; }
+        return;
+    }
     if (!lazy) return;
     alloc_planes(this);
     launch_chain_into(*lazy, this, s);
     lazy.reset();
+}
+
+static void chain_scale_of(const LazyScale& sc, ChainScale& o) {
+    const ScaleTables& t = *sc.t;
+    for (int p = 0; p < 3; ++p) { o.src[p] = sc.src->data[p]; o.src_stride[p] = sc.src->stride[p]; }
+    for (int c = 0; c < 2; ++c) {
+        o.sw[c] = t.in_w >> c; o.sh[c] = t.in_h >> c;
+        o.dw[c] = t.geo.scaled_w >> c; o.dh[c] = t.geo.scaled_h >> c;
+        o.lx[c] = t.geo.letterbox_x >> c; o.ly[c] = t.geo.letterbox_y >> c;
+        o.hfirst[c] = t.tab[c][0]; o.hpk[c] = t.hpk[c]; o.vfirst[c] = t.tab[c][2]; o.vpk[c] = t.vpk[c];
+    }
+}
+
+void fill_chain_rgba_sources(const LazyChain& c, ChainRgbaArgs& a, hipStream_t s) {
+    a.n_scaled = 0;
+    for (uint32_t j = 0; j < MX_CHAIN_MAX_SCALED; ++j) { a.scaled_src[j] = 0xffffffffu; std::memset(&a.sc[j], 0, sizeof a.sc[j]); }
+    // Measured: the resampling VALU work is the same wherever it runs and the fused kernel holds 2 waves per SIMD, so
+    // resampling inside the chain kernel is SLOWER on MI355X (28.7 us per 1080p frame against 12.1 + 10.5 us for scaler + chain) -- kept
+    // as an opt-in (MX_SCALE_INLINE=1, read per call so tests can switch it), bit-exact either way.
+    const char* const inl = getenv("MX_SCALE_INLINE");
+    const bool no_inline = !(inl && atoi(inl) != 0);
+    auto take = [&](const FrameRef& f, uint32_t k) {
+        if (!f || !f->lazy_scale) return;
+        if (no_inline || a.n_scaled == MX_CHAIN_MAX_SCALED || !f->lazy_scale->t->four_tap || !f->lazy_scale->src->data[0]) { f->ensure_pixels(s); return; }
+        chain_scale_of(*f->lazy_scale, a.sc[a.n_scaled]);
+        a.scaled_src[a.n_scaled++] = k;
+    };
+    take(c.base, 0);
+    for (size_t k = 0; k < c.steps.size(); ++k) take(c.steps[k].other, (uint32_t)k + 1);
+    fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a);   // an inline-scaled layer has no planes: nullptr here, as a blank one
 }
 
 // (a, b, fade) -> chain; a lazy operand's own chain is extended instead of being evaluated
@@ -280,61 +333,104 @@ void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFra
 
 void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
     in_w_ = in_w; in_h_ = in_h;
-    geo_ = scaler_geometry(in_w, in_h, out_w_, out_h_);
+    auto t = std::make_shared<ScaleTables>();
+    t->in_w = in_w; t->in_h = in_h; t->out_w = out_w_; t->out_h = out_h_;
+    t->geo = scaler_geometry(in_w, in_h, out_w_, out_h_);
+    const ScaleGeometry& geo = t->geo;
+    flush_scales(stream_);             // queued jobs write the old output frame
     frame_ = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
     // tap tables: [luma h, luma v, chroma h, chroma v]
     std::vector<int32_t> blob;
     size_t offs[2][4];
+    bool four = geo.scaled_w && geo.scaled_h;
+    size_t pk_off[2][2] = {{0, 0}, {0, 0}};
     for (int c = 0; c < 2; ++c) {
         std::vector<int32_t> hf, hc, vf, vc;
-        make_taps(in_w >> c, geo_.scaled_w >> c, hf, hc);
-        make_taps(in_h >> c, geo_.scaled_h >> c, vf, vc);
-        taps_[c][0] = tap_count(in_w >> c, geo_.scaled_w >> c); taps_[c][1] = tap_count(in_h >> c, geo_.scaled_h >> c);
-        if (taps_[c][0] == 4 && taps_[c][1] == 4 &&
-            (!scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_h >> c, geo_.scaled_h >> c, vf.data())))
-            throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
+        make_taps(in_w >> c, geo.scaled_w >> c, hf, hc);
+        make_taps(in_h >> c, geo.scaled_h >> c, vf, vc);
+        t->taps[c][0] = tap_count(in_w >> c, geo.scaled_w >> c); t->taps[c][1] = tap_count(in_h >> c, geo.scaled_h >> c);
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
+        if (t->taps[c][0] != 4 || t->taps[c][1] != 4) { four = false; continue; }
+        if (!scale_tile_origins_match(in_w >> c, geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_h >> c, geo.scaled_h >> c, vf.data()))
+            throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
+        // packed taps of the tiled / inline kernels; every bound their arithmetic relies on is checked on the actual tables
+        std::vector<int32_t> hp, vp;
+        for (size_t o = 0; o < hf.size(); ++o) {
+            uint32_t hi = 0, lo = 0; int64_t pos = 0, neg = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int32_t cc = hc[4 * o + k], ch = (cc + 128) >> 8, cl = cc - 256 * ch;
+                if (ch < -128 || ch > 127) four = false;
+                hi |= (uint32_t)(ch & 0xff) << (8 * k); lo |= (uint32_t)(cl & 0xff) << (8 * k);
+                (cc > 0 ? pos : neg) += cc;
+            }
+            if (((pos * 255 + 64) >> 7) - 16384 > 32767 || ((neg * 255 + 64) >> 7) - 16384 < -32768) four = false;   // t - 16384 is an i16
+            hp.push_back((int32_t)hi); hp.push_back((int32_t)lo);
+        }
+        for (size_t o = 0; o < vf.size(); ++o) {
+            int64_t mag = 0;
+            for (int k = 0; k < 4; ++k) { const int32_t cc = vc[4 * o + k]; if (cc < -32768 || cc > 32767) four = false; mag += cc < 0 ? -cc : cc; }
+            if (mag * 32768 + ((int64_t)16384 * 16384 + (1 << 20)) > 0x7fffffffLL) four = false;                    // the V accumulator stays in i32
+            vp.push_back((int32_t)(((uint32_t)vc[4 * o] & 0xffffu) | ((uint32_t)vc[4 * o + 1] << 16)));
+            vp.push_back((int32_t)(((uint32_t)vc[4 * o + 2] & 0xffffu) | ((uint32_t)vc[4 * o + 3] << 16)));
+        }
+        pk_off[c][0] = put(hp); pk_off[c][1] = put(vp);
     }
-    flush_scales(stream_);
-    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // a previous scale may still read the old tables
-    tabs_.alloc(blob.size() * sizeof(int32_t));
-    hip_check(hipMemcpy(tabs_.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(taps)");
-    for (int c = 0; c < 2; ++c) for (int k = 0; k < 4; ++k) tab_[c][k] = (const int32_t*)tabs_.p + offs[c][k];
+    t->four_tap = four;
+    t->tabs.alloc(blob.size() * sizeof(int32_t));   // the previous tables stay alive with whoever still holds them (frames, queued jobs)
+    hip_check(hipMemcpy(t->tabs.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(taps)");
+    for (int c = 0; c < 2; ++c) for (int k = 0; k < 4; ++k) t->tab[c][k] = (const int32_t*)t->tabs.p + offs[c][k];
+    if (four) for (int c = 0; c < 2; ++c) {
+        t->hpk[c] = reinterpret_cast<const uint2*>((const int32_t*)t->tabs.p + pk_off[c][0]);
+        t->vpk[c] = reinterpret_cast<const uint2*>((const int32_t*)t->tabs.p + pk_off[c][1]);
+    }
     // downscaling on any axis: the two-pass path keeps the H-filtered rows of each plane in device memory
-    const bool wide = taps_[0][0] > 4 || taps_[0][1] > 4 || taps_[1][0] > 4 || taps_[1][1] > 4;
+    const bool wide = t->taps[0][0] > 4 || t->taps[0][1] > 4 || t->taps[1][0] > 4 || t->taps[1][1] > 4;
     tmp_plane_[0] = tmp_plane_[1] = tmp_plane_[2] = nullptr;
     if (wide) {
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // a previous widened scale may still use the row buffer
         size_t off[3], total = 0;
-        for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; off[p] = total; total += (size_t)(geo_.scaled_w >> c) * (in_h >> c); }
+        for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; off[p] = total; total += (size_t)(geo.scaled_w >> c) * (in_h >> c); }
         tmp_.alloc(total * sizeof(int32_t));
         for (int p = 0; p < 3; ++p) tmp_plane_[p] = (int32_t*)tmp_.p + off[p];
     }
+    t_ = std::move(t);
 }
 
-FrameRef Scaler::scale(const FrameRef& in) {
-    if (in->width == out_w_ && in->height == out_h_) return in;                 // encode.rs:342-345
-    in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
-    if (!frame_ || in_w_ != in->width || in_h_ != in->height) retarget(in->width, in->height);   // encode.rs:347-384
-    if (geo_.scaled_w == 0 || geo_.scaled_h == 0) return frame_;
+void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp, const FrameRef& target, int32_t* const tmp_plane[3], hipStream_t s) {
+    const ScaleTables& t = *tp;
     ScaleArgs a;
     for (int p = 0; p < 3; ++p) {
         const int c = p ? 1 : 0;
         ScalePlane& sp = a.p[p];
         sp.src = in->data[p]; sp.src_stride = in->stride[p]; sp.sw = in->pw(p); sp.sh = in->ph(p);
         // sub-frame view at the letterbox offset (frame.rs:253-278)
-        sp.dst = frame_->data[p] + (size_t)(geo_.letterbox_y >> c) * frame_->stride[p] + (geo_.letterbox_x >> c);
-        sp.dst_stride = frame_->stride[p]; sp.dw = geo_.scaled_w >> c; sp.dh = geo_.scaled_h >> c;
-        sp.hfirst = tab_[c][0]; sp.hcoef = tab_[c][1]; sp.vfirst = tab_[c][2]; sp.vcoef = tab_[c][3];
-        sp.hn = taps_[c][0]; sp.vn = taps_[c][1]; sp.tmp = tmp_plane_[p];
+        sp.dst = target->data[p] + (size_t)(t.geo.letterbox_y >> c) * target->stride[p] + (t.geo.letterbox_x >> c);
+        sp.dst_stride = target->stride[p]; sp.dw = t.geo.scaled_w >> c; sp.dh = t.geo.scaled_h >> c;
+        sp.hfirst = t.tab[c][0]; sp.hcoef = t.tab[c][1]; sp.vfirst = t.tab[c][2]; sp.vcoef = t.tab[c][3];
+        sp.hn = t.taps[c][0]; sp.vn = t.taps[c][1]; sp.tmp = tmp_plane ? tmp_plane[p] : nullptr;
         sp.h_row0 = 0; sp.h_rows = sp.sh;
+        sp.hpk = t.hpk[c]; sp.vpk = t.vpk[c];
     }
-    if (tmp_plane_[0]) {                    // widened kernel (downscale): two passes, launched in stream order
-        flush_scales(stream_);
-        launch_scale_wide(a, stream_);
-        return frame_;
+    if (tmp_plane && tmp_plane[0]) {        // widened kernel (downscale): two passes, launched in stream order
+        flush_scales(s);
+        launch_scale_wide(a, s);
+        return;
     }
-    queue_scale(a, stream_, in, frame_);   // leaves with the other scales of this tick as one launch
+    queue_scale(a, s, in, target, tp);      // leaves with the other scales of this tick as one launch
+}
+
+FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
+    if (in->width == out_w_ && in->height == out_h_) return in;                 // encode.rs:342-345
+    in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
+    if (!frame_ || in_w_ != in->width || in_h_ != in->height) retarget(in->width, in->height);   // encode.rs:347-384
+    if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
+    if (may_defer && t_->four_tap) {
+        auto sc = std::make_shared<LazyScale>();
+        sc->src = in; sc->t = t_; sc->target = frame_;
+        return FrameRef(DFrame::create_lazy_scale(out_w_, out_h_, std::move(sc)), false);
+    }
+    scale_into(in, t_, frame_, tmp_plane_, stream_);
     return frame_;
 }
 
@@ -355,7 +451,7 @@ VideoMixer::~VideoMixer() {
 
 void VideoMixer::rebind(hipStream_t s, bool lazy_program, uint32_t ticks_per_second) {
     if (!s) throw Error(MX_ERR_INVALID, "VideoMixer::rebind needs a stream");
-    for (auto& c : ch_) if (c.has_stored && c.stored.frame && c.stored.frame->lazy) c.stored.frame->ensure_pixels(stream_);   // a symbolic frame of the old graph must exist before that graph goes
+    for (auto& c : ch_) if (c.has_stored && c.stored.frame) c.stored.frame->ensure_pixels(stream_);   // a symbolic frame of the old graph must exist before that graph goes
     flush_scales(stream_);
     if (stream_) hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // everything queued on the old stream has run
     for (auto& c : ch_) if (c.scaler) c.scaler->rebind(s);
@@ -376,7 +472,7 @@ FrameRef VideoMixer::fresh_output(uint32_t w, uint32_t h) {
 void VideoMixer::rescale(Channel& ch, uint32_t tw, uint32_t th) {   // Channel::rescale, video_mixer.rs:261-274
     if (!ch.scaler || ch.scaler->out_w() != tw || ch.scaler->out_h() != th) {
         ch.scaler.reset(new Scaler(tw, th, stream_));
-        if (ch.has_stored) ch.stored.frame = ch.scaler->scale(ch.stored.frame);
+        if (ch.has_stored) ch.stored.frame = ch.scaler->scale(ch.stored.frame, lazy_program_);
     }
 }
 
@@ -413,7 +509,7 @@ void VideoMixer::run_tick(uint64_t t, const VideoInput in[4], FrameRef& out, Fra
                 const Rational life = in[i].tick_offset + in[i].duration_hint, one_tick = Rational::make(1, (int64_t)tps_);
                 if (!(one_tick >= life)) f->ensure_pixels(stream_);
             }
-            c.stored.frame = c.scaler->scale(f);
+            c.stored.frame = c.scaler->scale(f, lazy_program_);
             c.stored.active_until = now + in[i].tick_offset + in[i].duration_hint;
             c.has_stored = true;
         } else {

@@ -30,6 +30,7 @@ struct ScalePlane {
     uint32_t hn, vn;                               // taps per output sample: 4, or 2*ceil(2*src/dst)+2 on a downscaled axis
     int32_t* tmp;                                  // wide path only: [sh][dw] H-filtered rows
     uint32_t h_row0, h_rows;                       // wide path only: the source rows the H pass filters (a row band reads a slice of the plane)
+    const uint2* hpk; const uint2* vpk;            // tiled path: packed taps (ScaleTables::lean), nullptr = not available
 };
 struct ScaleArgs { ScalePlane p[3]; };
 enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
@@ -48,7 +49,7 @@ struct RgbaArgs {
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s);
 void launch_scale_wide(const ScaleArgs& a, hipStream_t s);   // two passes through ScalePlane::tmp, any tap counts
-bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first);   // f64 window-origin formula of the tiled scaler == tap table
+bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first);   // f64 window-origin formula of the tiled / inline scalers == tap table, every output
 
 // A chain of cross-fades evaluated per pixel in registers:  v = src[0];  for k >= 1:
 //   v = v_is_a[k-1] ? fade(v, src[k]) : fade(src[k], v)   with fade(a,b) = (a*f + b*(255-f)) / 255, f = fade[k-1]
@@ -63,11 +64,23 @@ struct ChainArgs {
     uint8_t* out[3]; uint32_t out_stride[3];
     uint32_t chunks[3], chunks_per_row[3];
 };
+// A chain layer that is the DynamicScaler's letterboxed output of a smaller (or equal-sized) picture, resampled INSIDE the chain kernel
+// (4-tap axes only): the scaled frame is never written.  Index [0] = luma, [1] = both chroma planes.
+enum { MX_CHAIN_MAX_SCALED = 4 };
+struct ChainScale {
+    const uint8_t* src[3]; uint32_t src_stride[3];
+    uint32_t sw[2], sh[2];                         // source plane size
+    uint32_t dw[2], dh[2];                         // scaled size (encode.rs:354-364)
+    uint32_t lx[2], ly[2];                         // letterbox offset of the scaled picture in the output plane (encode.rs:366-374)
+    const int32_t* hfirst[2]; const uint2* hpk[2]; const int32_t* vfirst[2]; const uint2* vpk[2];   // packed taps, ScaleTables::lean
+};
 struct ChainRgbaArgs {   // the same chain feeding the build-specified YUV420P -> RGBA (+ matrix) directly: no YUV frame is written
     ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t n_src;
     uint32_t fade[MX_CHAIN_MAX_SRC - 1]; uint32_t v_is_a[MX_CHAIN_MAX_SRC - 1];
     uint8_t* rgba; uint32_t rgba_stride, width, height;
     int32_t use_matrix; int32_t m[12];
+    uint32_t n_scaled; uint32_t scaled_src[MX_CHAIN_MAX_SCALED];   // chain position of each inline-scaled layer (its ChainSrc planes are nullptr)
+    ChainScale sc[MX_CHAIN_MAX_SCALED];
 };
 void launch_fade_chain(const ChainArgs& a, hipStream_t s);
 void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s);
@@ -76,7 +89,8 @@ void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s);
 void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s);
 // deferred scaling: Scaler::scale queues its planes per stream; every reader of frame pixels flushes first
 struct FrameRef;
-void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst);
+struct ScaleTables;
+void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs = nullptr);
 void flush_scales(hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
@@ -104,6 +118,7 @@ struct FrameRef {   // intrusive handle
     explicit operator bool() const { return f != nullptr; }
     DFrame* operator->() const { return f; }
 };
+struct ScaleGeometry { uint32_t scaled_w, scaled_h, letterbox_x, letterbox_y; };
 // A frame whose pixels have not been computed yet: the cross-fade chain that defines them.  Created
 // only for VideoMixer program outputs whose single consumer is another video node of the same graph
 // (decided at graph build), and always evaluated inside the tick that created it.
@@ -113,9 +128,30 @@ struct LazyChain {
     std::vector<Step> steps;
 };
 
+// tap tables + geometry of one (input settings -> output settings) scaler context; shared by the Scaler and the frames it defines
+struct ScaleTables {
+    uint32_t in_w = 0, in_h = 0, out_w = 0, out_h = 0;
+    ScaleGeometry geo{};
+    DevBuf tabs;                         // tap tables for luma and chroma
+    uint32_t taps[2][2] = {{4, 4}, {4, 4}};   // [luma/chroma][h, v]
+    const int32_t* tab[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [luma/chroma][hfirst,hcoef,vfirst,vcoef]
+    // 4-tap contexts whose taps fit the packed-dot-product form of the tiled / inline kernels (mx_k_video.hip):
+    //   H: {ch0..3 as i8 x 4, cl0..3 as i8 x 4} with c = 256 ch + cl;  V: {(c0, c1), (c2, c3)} as i16 x 2
+    bool four_tap = false;
+    const uint2* hpk[2] = {nullptr, nullptr}; const uint2* vpk[2] = {nullptr, nullptr};
+};
+// A frame that is the DynamicScaler's output of `src` and has not been computed: chain kernels resample it inline; anyone else
+// materialises it into the scaler's own output frame (`target`, encode.rs:382-396 -- the reference reuses that frame too).
+struct LazyScale {
+    FrameRef src; std::shared_ptr<ScaleTables> t; FrameRef target;   // only 4-tap contexts are deferred (ScaleTables::four_tap)
+};
+
 struct DFrame {
     std::atomic<int> rc{1};
     std::shared_ptr<LazyChain> lazy;     // non-null => data[] are nullptr until ensure_pixels()
+    std::shared_ptr<LazyScale> lazy_scale;   // non-null => likewise; after ensure_pixels() data[] alias `alias`'s planes
+    FrameRef alias;
+    static DFrame* create_lazy_scale(uint32_t w, uint32_t h, std::shared_ptr<LazyScale> sc);
     static DFrame* create_lazy(uint32_t w, uint32_t h, std::shared_ptr<LazyChain> c);
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (even)
@@ -137,8 +173,10 @@ inline FrameRef::~FrameRef() { if (f) f->release(); }
 std::shared_ptr<LazyChain> make_chain(const FrameRef& a, const FrameRef& b, uint8_t fade, hipStream_t s);
 void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], uint32_t& n_src,
                         uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1]);
+// the RGBA sink's form: layers that are unevaluated scaler outputs are handed over as ChainScale (up to MX_CHAIN_MAX_SCALED; the rest
+// and every layer the inline resampler cannot take are materialised on `s` first)
+void fill_chain_rgba_sources(const LazyChain& c, ChainRgbaArgs& a, hipStream_t s);
 
-struct ScaleGeometry { uint32_t scaled_w, scaled_h, letterbox_x, letterbox_y; };
 ScaleGeometry scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h);   // encode.rs:354-374
 void unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t& w, uint32_t& h);   // video_mixer.rs:276-297
 uint8_t crossfade_factor(double fader);   // video_mixer.rs:168
@@ -157,7 +195,8 @@ public:
     uint32_t out_h() const { return out_h_; }
     // returns the frame itself when its settings equal the output's (encode.rs:342-345), else the
     // scaler's own letterboxed output frame (encode.rs:386-396)
-    FrameRef scale(const FrameRef& in);
+    // may_defer: the caller's consumers are chain kernels, which resample a 4-tap scale inline -- the result may be a frame without pixels
+    FrameRef scale(const FrameRef& in, bool may_defer = false);
     // a topology edit moved the owning VideoMixer to another graph: queued work leaves on the old stream first
     void rebind(hipStream_t s) { flush_scales(stream_); stream_ = s; }
 private:
@@ -165,14 +204,13 @@ private:
     uint32_t out_w_, out_h_;
     hipStream_t stream_;
     uint32_t in_w_ = 0, in_h_ = 0;   // settings the cached context was built for (encode.rs:347-352)
-    ScaleGeometry geo_{};
     FrameRef frame_;                 // cached blank output frame (encode.rs:382)
-    DevBuf tabs_;                    // tap tables for luma and chroma
+    std::shared_ptr<ScaleTables> t_;
     DevBuf tmp_;                     // downscaling: H-filtered rows of the three planes
     int32_t* tmp_plane_[3] = {nullptr, nullptr, nullptr};
-    uint32_t taps_[2][2] = {{4, 4}, {4, 4}};   // [luma/chroma][h, v]
-    const int32_t* tab_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [luma/chroma][hfirst,hcoef,vfirst,vcoef]
 };
+// the scale of `src` into `target` under tables `t`, queued (4-tap) or launched (widened) on s
+void scale_into(const FrameRef& src, const std::shared_ptr<const ScaleTables>& t, const FrameRef& target, int32_t* const tmp_plane[3], hipStream_t s);
 
 struct VideoInput { DFrame* frame = nullptr; Rational duration_hint; Rational tick_offset; };   // engine::VideoFrame, io.rs:12-17
 

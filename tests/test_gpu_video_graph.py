@@ -33,8 +33,16 @@ def upload(hf):
     return video.DFrame(hf.w, hf.h).upload(y, u, v)
 
 
-@pytest.mark.parametrize("sizes", [[(320, 180)] * 6 + [(212, 120)] * 2, [(1920, 1080)] * 6 + [(1280, 720)] * 2])
-def test_config4_eight_layer_cascade_bit_exact(sizes):
+MIXED = [(320, 180), (160, 120), (320, 100), (100, 180), (212, 120), (318, 178), (2, 2), (64, 64)]   # pillar / letter boxes, 7 scaled layers (> MX_CHAIN_MAX_SCALED)
+GROWING = [(64, 64), (128, 72), (130, 40), (322, 182), (322, 182), (200, 182), (322, 100), (640, 360)]   # the running composite itself is rescaled; the last layer is DOWNscaled
+
+
+@pytest.mark.parametrize("sizes", [[(320, 180)] * 6 + [(212, 120)] * 2, [(1920, 1080)] * 6 + [(1280, 720)] * 2, MIXED, GROWING,
+                                   [(1920, 1080), (1440, 1080), (1920, 800), (1280, 720), (1918, 1078), (960, 1080), (1920, 1080), (1000, 1000)]],
+                         ids=["180p", "1080p", "mixed-boxes", "growing", "1080p-boxes"])
+@pytest.mark.parametrize("inline", ["0", "1"], ids=["scaler-kernel", "resampled-in-chain"])
+def test_config4_eight_layer_cascade_bit_exact(sizes, inline, monkeypatch):
+    monkeypatch.setenv("MX_SCALE_INLINE", inline)   # layers resampled by the stand-alone scaler (default) / inside the RGBA chain kernel
     ws, srcs, mixers, rgba = cascade(sizes, MATRIX)
     g = ws.build(max_ticks_per_run=4)
     layers = [ov.HostFrame(w, h).fill(k, seed=3) for k, (w, h) in enumerate(sizes)]
@@ -56,6 +64,44 @@ def test_config4_eight_layer_cascade_bit_exact(sizes):
     for p, (a, b) in enumerate(zip(got.download(), want.visible())):
         assert np.array_equal(a, b), f"plane {p} of the final composite differs"
     assert np.array_equal(video.graph_rgba_output(g, rgba), ov.to_rgba(want, MATRIX))
+
+
+@pytest.mark.parametrize("inline", ["0", "1"], ids=["scaler-kernel", "resampled-in-chain"])
+def test_scaled_layers_held_over_several_ticks_and_replaced(inline, monkeypatch):
+    """A layer that the chain kernel may resample itself stays an unevaluated scaler output while it is the channel's stored frame:
+    ticks without a new input frame re-use it (video_mixer.rs:94-101,122-148), a new frame of another size re-targets the scaler
+    (encode.rs:347-384).  Both ways of computing it must be the oracle's picture."""
+    monkeypatch.setenv("MX_SCALE_INLINE", inline)
+    sizes = [(320, 180), (160, 120), (212, 120), (320, 180)]
+    ws, srcs, mixers, rgba = cascade(sizes, MATRIX)
+    g = ws.build()
+    oms = [ov.OracleVideoMixer(a=0, b=1, fader=FADERS[k]) for k in range(len(sizes) - 1)]
+    # tick -> {layer: (size, seed)}: layers live 3 ticks; layer 1 is replaced by another size on tick 2, everything expires by tick 6
+    plan = {0: {0: ((320, 180), 1), 1: ((160, 120), 2), 2: ((212, 120), 3), 3: ((320, 180), 4)},
+            2: {1: ((100, 180), 5)}, 3: {0: ((320, 180), 6), 2: ((212, 120), 7)}, 4: {3: ((300, 100), 8)}}
+    keep = []
+    for tick in range(7):
+        new = {}
+        for k, (size, seed) in plan.get(tick, {}).items():
+            hf = ov.HostFrame(*size).fill(k, seed=seed)
+            d = upload(hf); keep.append(d)
+            video.graph_set_video_source(g, srcs[k], d, dur=(3, 60), off=(0, 1), repeat=False)
+            new[k] = hf
+        g.run_ticks(tick, 1)
+        prev = (new[0], (3, 60), (0, 1)) if 0 in new else None
+        for k in range(len(sizes) - 1):
+            b = (new[k + 1], (3, 60), (0, 1)) if (k + 1) in new else None
+            out = oms[k].run_tick(tick * 735, [prev, b, None, None])
+            prev = (out, (1, 60), (0, 1)) if out is not None else None
+        want = prev[0] if prev else None
+        got = video.graph_rgba_output(g, rgba)
+        if want is None:
+            assert got is None or got.size == 0, f"tick {tick}"
+            continue
+        assert np.array_equal(got, ov.to_rgba(want, MATRIX)), f"tick {tick}: RGBA differs"
+        prog = video.graph_video_output(g, mixers[-1], 0)
+        for p, (a, b) in enumerate(zip(prog.download(), want.visible())):
+            assert np.array_equal(a, b), f"tick {tick} plane {p}"
 
 
 def test_video_source_single_shot_then_none_and_passthrough():
