@@ -231,13 +231,23 @@ typedef struct {
     int64_t off_num, off_den;        /* VideoFrame.tick_offset (src/engine/io.rs:12-17) */
 } mx_frame;
 
+/* Pixel formats a device frame can hold (codec/src/ffmpeg/pixfmt.rs:8-36 wraps AVPixelFormat; planar 8-bit YUV here).  Everything the
+ * VideoMixer PRODUCES is yuv420p (src/module/video_mixer.rs:282-283); its INPUTS carry their own format in their picture settings and
+ * the DynamicScaler's context converts implicitly (codec/src/ffmpeg/scale.rs:16-39, src/video/encode.rs:342-352: the settings compare
+ * unequal when only the format differs).  Here that conversion is the build-specified scaler applied per plane: each chroma plane is
+ * resampled from ITS size to the output's chroma size (DESIGN.md "Scaler" -- parity unpinned, like the scaler itself). */
+typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P = 2 } mx_pixfmt;
+
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer
  * keeps inputs past the call by retaining them.  Frames are immutable once handed to a mixer.
  * All stateless pixel calls take a hipStream_t (`stream`, NULL = the library's default video
  * stream) and are asynchronous on it unless stated. */
 typedef struct mx_dframe mx_dframe;
-int mx_dframe_create(uint32_t width, uint32_t height, void* stream, mx_dframe** out);  /* blank: Y=0 U=V=0x80 (frame.rs:76-138) */
+int mx_dframe_create(uint32_t width, uint32_t height, void* stream, mx_dframe** out);  /* yuv420p; blank: Y=0 U=V=0x80 (frame.rs:76-138) */
+/* any mx_pixfmt: width / height must be multiples of the chroma subsampling (pixfmt.rs:97-111); mx_frame planes follow the device frame's format */
+int mx_dframe_create_fmt(uint32_t width, uint32_t height, mx_pixfmt fmt, void* stream, mx_dframe** out);
+int mx_dframe_format(const mx_dframe* f, mx_pixfmt* fmt);
 int mx_dframe_retain(mx_dframe* f);
 void mx_dframe_release(mx_dframe* f);
 int mx_dframe_upload(mx_dframe* f, const mx_frame* host, void* stream);       /* visible area; synchronous */

@@ -65,6 +65,17 @@ int mx_dframe_create(uint32_t width, uint32_t height, void* stream, mx_dframe** 
         *out = H(DFrame::create(width, height, S(stream)));
     });
 }
+int mx_dframe_create_fmt(uint32_t width, uint32_t height, mx_pixfmt fmt, void* stream, mx_dframe** out) {
+    return guard([&] {
+        REQUIRE(out, "out is NULL");
+        *out = nullptr;
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_YUV444P, "unknown pixel format");
+        *out = H(DFrame::create(width, height, S(stream), (uint8_t)fmt));
+    });
+}
+int mx_dframe_format(const mx_dframe* f, mx_pixfmt* fmt) {
+    return guard([&] { REQUIRE(f && fmt, "NULL argument"); *fmt = (mx_pixfmt)D(f)->fmt; });
+}
 int mx_dframe_retain(mx_dframe* f) {
     return guard([&] { REQUIRE(f, "frame is NULL"); D(f)->retain(); });
 }
@@ -125,8 +136,9 @@ int mx_video_crossfade(mx_dframe* out, const mx_dframe* a, const mx_dframe* b, d
         DFrame* o = D(out);
         const DFrame* fa = a ? D(a) : nullptr;
         const DFrame* fb = b ? D(b) : nullptr;
-        for (const DFrame* x : {fa, fb})
-            if (x && (x->width != o->width || x->height != o->height)) throw Error(MX_ERR_INVALID, "cross-fade inputs must have the output's size");
+        for (const DFrame* x : {fa, fb, (const DFrame*)o})
+            if (x && (x->width != o->width || x->height != o->height || x->fmt != MX_PIXFMT_YUV420P))
+                throw Error(MX_ERR_INVALID, "cross-fade inputs must have the output's size, all yuv420p (video_mixer.rs:282-283)");
         FrameRef ra(const_cast<DFrame*>(fa), fa != nullptr), rb(const_cast<DFrame*>(fb), fb != nullptr);
         if (ra) ra->ensure_pixels(S(stream));
         if (rb) rb->ensure_pixels(S(stream));
@@ -159,6 +171,7 @@ int mx_video_scale(const mx_dframe* in, mx_dframe* out, void* stream) {
     return guard([&] {
         REQUIRE(in && out, "NULL argument");
         DFrame* o = D(out);
+        REQUIRE(o->fmt == MX_PIXFMT_YUV420P, "the scaler's output picture is yuv420p");
         hipStream_t s = S(stream);
         mx::Scaler sc(o->width, o->height, s);
         FrameRef src(const_cast<DFrame*>(D(in)), true);
@@ -208,6 +221,7 @@ int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride
     return guard([&] {
         REQUIRE(in && device_rgba, "NULL argument");
         const DFrame* d = D(in);
+        REQUIRE(d->fmt == MX_PIXFMT_YUV420P, "YUV -> RGBA takes yuv420p (scale a frame of another format first)");
         if (rgba_stride < (int32_t)(d->width * 4) || (rgba_stride & 15) || ((uintptr_t)device_rgba & 15))
             throw Error(MX_ERR_INVALID, "rgba buffer must be 16-byte aligned with stride >= 4 * width, stride % 16 == 0");
         mx::RgbaArgs a;

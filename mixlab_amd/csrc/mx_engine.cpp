@@ -1252,6 +1252,7 @@ void Graph::run_video_tick(uint64_t t) {
                 break;
             }
             d->ensure_pixels(stream_);
+            if (d->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "VIDEO_TO_RGBA takes yuv420p (a VideoMixer output); put a VideoMixer in front of a source of another format");
             RgbaArgs a;
             a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = (uint8_t*)n.rgba.p;
             a.y_stride = d->stride[0]; a.u_stride = d->stride[1]; a.v_stride = d->stride[2]; a.rgba_stride = (uint32_t)stride;

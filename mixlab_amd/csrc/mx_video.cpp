@@ -68,7 +68,7 @@ void flush_scales(hipStream_t s) {
 static void alloc_planes(DFrame* f) {
     size_t off[3], total = 0;
     for (int p = 0; p < 3; ++p) {
-        const uint32_t pw = p ? f->width >> 1 : f->width, ph = p ? f->height >> 1 : f->height;
+        const uint32_t pw = f->pw(p), ph = f->ph(p);
         f->stride[p] = (pw + 63u) & ~63u;               // rows 64-byte aligned (the reference asserts 32, video_mixer.rs:196-201)
         f->plane_bytes[p] = (size_t)f->stride[p] * ph;
         off[p] = total;
@@ -78,10 +78,13 @@ static void alloc_planes(DFrame* f) {
     for (int p = 0; p < 3; ++p) f->data[p] = (uint8_t*)f->mem.p + off[p];
 }
 
-DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s) {
-    if (w == 0 || h == 0 || (w & 1) || (h & 1)) throw Error(MX_ERR_INVALID, "yuv420p frame size must be even and non-zero");
-    if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
+DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
+    if (fmt > MX_PIXFMT_YUV444P) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
+    f->fmt = fmt;
+    if (w == 0 || h == 0 || (w & ((1u << f->cw()) - 1u)) || (h & ((1u << f->chs()) - 1u)))
+        throw Error(MX_ERR_INVALID, "frame size must be non-zero and a multiple of the chroma subsampling (yuv420p: even)");
+    if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
     f->width = w; f->height = h;
     alloc_planes(f.get());
     launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s);
@@ -155,7 +158,7 @@ static void chain_scale_of(const LazyScale& sc, ChainScale& o) {
     const ScaleTables& t = *sc.t;
     for (int p = 0; p < 3; ++p) { o.src[p] = sc.src->data[p]; o.src_stride[p] = sc.src->stride[p]; }
     for (int c = 0; c < 2; ++c) {
-        o.sw[c] = t.in_w >> c; o.sh[c] = t.in_h >> c;
+        o.sw[c] = c ? t.in_w >> t.in_cw : t.in_w; o.sh[c] = c ? t.in_h >> t.in_ch : t.in_h;
         o.dw[c] = t.geo.scaled_w >> c; o.dh[c] = t.geo.scaled_h >> c;
         o.lx[c] = t.geo.letterbox_x >> c; o.ly[c] = t.geo.letterbox_y >> c;
         o.hfirst[c] = t.tab[c][0]; o.hpk[c] = t.hpk[c]; o.vfirst[c] = t.tab[c][2]; o.vpk[c] = t.vpk[c];
@@ -279,6 +282,7 @@ void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::v
 
 void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFrame* out, uint32_t full_w, uint32_t full_h, uint32_t row0, hipStream_t s) {
     if (!slice || !out) throw Error(MX_ERR_INVALID, "NULL frame");
+    if (slice->fmt != MX_PIXFMT_YUV420P || out->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "row bands are cut from yuv420p pictures");
     if (out->width != full_w) throw Error(MX_ERR_INVALID, "a band frame is as wide as the full picture");
     if ((row0 & 1) || (src_row0 & 1) || (in_full_h & 1) || (full_h & 1) || row0 + out->height > full_h || src_row0 + slice->height > in_full_h)
         throw Error(MX_ERR_INVALID, "band / slice rows must be whole chroma rows inside their pictures");
@@ -331,10 +335,12 @@ void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFra
     hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");   // the tables and the row buffer die here
 }
 
-void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
-    in_w_ = in_w; in_h_ = in_h;
+void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
+    in_w_ = in_w; in_h_ = in_h; in_fmt_ = in_fmt;
     auto t = std::make_shared<ScaleTables>();
     t->in_w = in_w; t->in_h = in_h; t->out_w = out_w_; t->out_h = out_h_;
+    t->in_cw = in_fmt == MX_PIXFMT_YUV444P ? 0u : 1u; t->in_ch = in_fmt == MX_PIXFMT_YUV420P ? 1u : 0u;
+    const uint32_t src_w[2] = {in_w, in_w >> t->in_cw}, src_h[2] = {in_h, in_h >> t->in_ch};   // the planes of the input format
     t->geo = scaler_geometry(in_w, in_h, out_w_, out_h_);
     const ScaleGeometry& geo = t->geo;
     flush_scales(stream_);             // queued jobs write the old output frame
@@ -346,13 +352,13 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
     size_t pk_off[2][2] = {{0, 0}, {0, 0}};
     for (int c = 0; c < 2; ++c) {
         std::vector<int32_t> hf, hc, vf, vc;
-        make_taps(in_w >> c, geo.scaled_w >> c, hf, hc);
-        make_taps(in_h >> c, geo.scaled_h >> c, vf, vc);
-        t->taps[c][0] = tap_count(in_w >> c, geo.scaled_w >> c); t->taps[c][1] = tap_count(in_h >> c, geo.scaled_h >> c);
+        make_taps(src_w[c], geo.scaled_w >> c, hf, hc);
+        make_taps(src_h[c], geo.scaled_h >> c, vf, vc);
+        t->taps[c][0] = tap_count(src_w[c], geo.scaled_w >> c); t->taps[c][1] = tap_count(src_h[c], geo.scaled_h >> c);
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
         if (t->taps[c][0] != 4 || t->taps[c][1] != 4) { four = false; continue; }
-        if (!scale_tile_origins_match(in_w >> c, geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_h >> c, geo.scaled_h >> c, vf.data()))
+        if (!scale_tile_origins_match(src_w[c], geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match(src_h[c], geo.scaled_h >> c, vf.data()))
             throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
         // packed taps of the tiled / inline kernels; every bound their arithmetic relies on is checked on the actual tables
         std::vector<int32_t> hp, vp;
@@ -390,7 +396,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h) {
     if (wide) {
         hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");   // a previous widened scale may still use the row buffer
         size_t off[3], total = 0;
-        for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; off[p] = total; total += (size_t)(geo.scaled_w >> c) * (in_h >> c); }
+        for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; off[p] = total; total += (size_t)(geo.scaled_w >> c) * src_h[c]; }
         tmp_.alloc(total * sizeof(int32_t));
         for (int p = 0; p < 3; ++p) tmp_plane_[p] = (int32_t*)tmp_.p + off[p];
     }
@@ -421,9 +427,9 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
 }
 
 FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
-    if (in->width == out_w_ && in->height == out_h_) return in;                 // encode.rs:342-345
+    if (in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;   // equal picture settings, encode.rs:342-345
     in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
-    if (!frame_ || in_w_ != in->width || in_h_ != in->height) retarget(in->width, in->height);   // encode.rs:347-384
+    if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);   // encode.rs:347-384
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
     if (may_defer && t_->four_tap) {
         auto sc = std::make_shared<LazyScale>();

@@ -131,6 +131,7 @@ struct LazyChain {
 // tap tables + geometry of one (input settings -> output settings) scaler context; shared by the Scaler and the frames it defines
 struct ScaleTables {
     uint32_t in_w = 0, in_h = 0, out_w = 0, out_h = 0;
+    uint32_t in_cw = 1, in_ch = 1;       // the input format's chroma subsampling (the output is yuv420p)
     ScaleGeometry geo{};
     DevBuf tabs;                         // tap tables for luma and chroma
     uint32_t taps[2][2] = {{4, 4}, {4, 4}};   // [luma/chroma][h, v]
@@ -154,16 +155,19 @@ struct DFrame {
     static DFrame* create_lazy_scale(uint32_t w, uint32_t h, std::shared_ptr<LazyScale> sc);
     static DFrame* create_lazy(uint32_t w, uint32_t h, std::shared_ptr<LazyChain> c);
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
-    uint32_t width = 0, height = 0;      // luma size (even)
+    uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
+    uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
+    uint32_t cw() const { return fmt == MX_PIXFMT_YUV444P ? 0u : 1u; }    // log2_chroma_w, pixfmt.rs:97-100
+    uint32_t chs() const { return fmt == MX_PIXFMT_YUV420P ? 1u : 0u; }   // log2_chroma_h, pixfmt.rs:102-105
     uint8_t* data[3] = {nullptr, nullptr, nullptr};
     uint32_t stride[3] = {0, 0, 0};
     size_t plane_bytes[3] = {0, 0, 0};
     DevBuf mem;
-    static DFrame* create(uint32_t w, uint32_t h, hipStream_t s);   // blank-filled (frame.rs:76-138)
+    static DFrame* create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt = MX_PIXFMT_YUV420P);   // blank-filled (frame.rs:76-138)
     void retain() { rc.fetch_add(1, std::memory_order_relaxed); }
     void release() { if (rc.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
-    uint32_t pw(int p) const { return p ? width >> 1 : width; }
-    uint32_t ph(int p) const { return p ? height >> 1 : height; }
+    uint32_t pw(int p) const { return p ? width >> cw() : width; }
+    uint32_t ph(int p) const { return p ? height >> chs() : height; }
 };
 inline FrameRef::FrameRef(DFrame* p, bool add_ref) : f(p) { if (f && add_ref) f->retain(); }
 inline FrameRef::FrameRef(const FrameRef& o) : f(o.f) { if (f) f->retain(); }
@@ -200,10 +204,11 @@ public:
     // a topology edit moved the owning VideoMixer to another graph: queued work leaves on the old stream first
     void rebind(hipStream_t s) { flush_scales(stream_); stream_ = s; }
 private:
-    void retarget(uint32_t in_w, uint32_t in_h);
+    void retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt);
     uint32_t out_w_, out_h_;
     hipStream_t stream_;
     uint32_t in_w_ = 0, in_h_ = 0;   // settings the cached context was built for (encode.rs:347-352)
+    uint8_t in_fmt_ = MX_PIXFMT_YUV420P;
     FrameRef frame_;                 // cached blank output frame (encode.rs:382)
     std::shared_ptr<ScaleTables> t_;
     DevBuf tmp_;                     // downscaling: H-filtered rows of the three planes

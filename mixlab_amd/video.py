@@ -24,6 +24,8 @@ def _proto(name, restype, *argtypes):
 
 
 _proto("mx_dframe_create", C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_dframe_create_fmt", C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_dframe_format", C.c_int, C.c_void_p, C.POINTER(C.c_int))
 _proto("mx_dframe_retain", C.c_int, C.c_void_p)
 _proto("mx_dframe_release", None, C.c_void_p)
 _proto("mx_dframe_upload", C.c_int, C.c_void_p, C.POINTER(abi.Frame), C.c_void_p)
@@ -110,16 +112,23 @@ def _host_frame(planes, w, h):
     return f
 
 
-class DFrame:
-    """Device-resident yuv420p frame (one reference owned by this object)."""
+PIXFMT_YUV420P, PIXFMT_YUV422P, PIXFMT_YUV444P = 0, 1, 2   # mx_pixfmt
 
-    def __init__(self, width=None, height=None, stream=None, handle=None):
+
+class DFrame:
+    """Device-resident planar YUV frame (one reference owned by this object); yuv420p unless `fmt` says otherwise."""
+
+    def __init__(self, width=None, height=None, stream=None, handle=None, fmt=PIXFMT_YUV420P):
         self.stream = stream
         if handle is not None:
             self._h = C.c_void_p(handle)
         else:
             self._h = C.c_void_p()
-            check(lib.mx_dframe_create(width, height, stream, C.byref(self._h)))
+            check(lib.mx_dframe_create_fmt(width, height, fmt, stream, C.byref(self._h)))
+        f = C.c_int()
+        check(lib.mx_dframe_format(self._h, C.byref(f)))
+        self.fmt = f.value
+        self.cw, self.ch = (0 if self.fmt == PIXFMT_YUV444P else 1), (1 if self.fmt == PIXFMT_YUV420P else 0)
         w, h = C.c_uint32(), C.c_uint32()
         self._data = (C.c_void_p * 3)()
         self._stride = (C.c_int32 * 3)()
@@ -148,7 +157,7 @@ class DFrame:
         return self
 
     def download(self):
-        planes = [np.empty((self.height >> (1 if p else 0), self.width >> (1 if p else 0)), np.uint8) for p in range(3)]
+        planes = [np.empty((self.height >> (self.ch if p else 0), self.width >> (self.cw if p else 0)), np.uint8) for p in range(3)]
         hf = _host_frame(planes, self.width, self.height)
         check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
         return planes

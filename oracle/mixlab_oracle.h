@@ -153,7 +153,12 @@ typedef struct {
     uint32_t width, height;     /* luma dimensions (codec/src/ffmpeg/frame.rs:180-186) */
     uint8_t* data[3];           /* Y, U, V plane bases (frame.rs:188-197) */
     int32_t stride[3];          /* bytes per row, multiple of 32 (video_mixer.rs:196-201) */
+    uint32_t fmt;               /* 0 = yuv420p (everything the VideoMixer produces, video_mixer.rs:282-283), 1 = yuv422p, 2 = yuv444p:
+                                   formats a scaler INPUT may have (codec/src/ffmpeg/scale.rs:16-39 carries the input pixel format) */
 } orc_frame;
+/* chroma subsampling of a format (codec/src/ffmpeg/pixfmt.rs:97-105) */
+static inline uint32_t orc_fmt_cw(uint32_t fmt) { return fmt == 2 ? 0u : 1u; }
+static inline uint32_t orc_fmt_ch(uint32_t fmt) { return fmt == 0 ? 1u : 0u; }
 
 /* codec/src/ffmpeg/frame.rs:76-138: Y=0x00, U=V=0x80 over stride*(h-1)+w bytes of each plane */
 void orc_frame_blank(orc_frame* f);

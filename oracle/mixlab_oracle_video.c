@@ -18,8 +18,8 @@
 void orc_frame_blank(orc_frame* f) {
     for (int plane = 0; plane < 3; plane++) {
         int is_chroma = plane > 0;                                  /* frame.rs:103-106 */
-        size_t width = is_chroma ? (f->width >> 1) : f->width;      /* frame.rs:108-112, log2_chroma_w = 1 */
-        size_t height = is_chroma ? (f->height >> 1) : f->height;   /* frame.rs:114-118 */
+        size_t width = is_chroma ? (f->width >> orc_fmt_cw(f->fmt)) : f->width;      /* frame.rs:108-112, log2_chroma_w */
+        size_t height = is_chroma ? (f->height >> orc_fmt_ch(f->fmt)) : f->height;   /* frame.rs:114-118 */
         size_t stride = (size_t)f->stride[plane];
         size_t size = stride * (height ? height - 1 : 0) + width;   /* saturating_sub(1) */
         memset(f->data[plane], is_chroma ? 0x80 : 0x00, size);
@@ -249,7 +249,8 @@ int orc_dynamic_scale_band(const orc_frame* in_slice, uint32_t in_full_h, uint32
  * copy of the visible area); otherwise blank output (encode.rs:382) and scale into the letterboxed
  * sub-frame (encode.rs:386-392; sub-frame plane offsets, frame.rs:253-278). */
 void orc_dynamic_scale(const orc_frame* in, orc_frame* out) {
-    if (in->width == out->width && in->height == out->height) {
+    /* equal picture settings -- size AND pixel format (encode.rs:342-345); the output is always yuv420p */
+    if (in->width == out->width && in->height == out->height && in->fmt == 0) {
         for (int p = 0; p < 3; p++) {
             uint32_t w = p ? in->width >> 1 : in->width, h = p ? in->height >> 1 : in->height;
             for (uint32_t y = 0; y < h; y++)
@@ -263,8 +264,9 @@ void orc_dynamic_scale(const orc_frame* in, orc_frame* out) {
     for (int p = 0; p < 3; p++) {
         uint32_t sh_ = p ? 1 : 0;
         uint8_t* dst = out->data[p] + (size_t)(g.letterbox_y >> sh_) * out->stride[p] + (g.letterbox_x >> sh_);
-        orc_scale_plane_bicubic(in->data[p], in->stride[p], in->width >> sh_, in->height >> sh_,
-                                dst, out->stride[p], g.scaled_w >> sh_, g.scaled_h >> sh_);
+        /* BUILD-SPECIFIED format conversion: every plane is resampled from ITS size in the input format to its size in the yuv420p output */
+        uint32_t sw = p ? in->width >> orc_fmt_cw(in->fmt) : in->width, sh = p ? in->height >> orc_fmt_ch(in->fmt) : in->height;
+        orc_scale_plane_bicubic(in->data[p], in->stride[p], sw, sh, dst, out->stride[p], g.scaled_w >> sh_, g.scaled_h >> sh_);
     }
 }
 
@@ -319,7 +321,7 @@ int orc_rational_cmp(orc_rational a, orc_rational b) {
 /* VideoMixer::run_tick, src/module/video_mixer.rs:70-250, as a plain state machine over owned
  * frame copies (an AVFrame refcount clone of an immutable frame is observationally a copy). */
 static void vm_frame_alloc(orc_frame* f, uint32_t w, uint32_t h) {
-    f->width = w; f->height = h;
+    f->width = w; f->height = h; f->fmt = 0;   /* yuv420p, video_mixer.rs:282-283 */
     for (int p = 0; p < 3; ++p) {
         uint32_t pw = p ? w >> 1 : w, ph = p ? h >> 1 : h;
         f->stride[p] = (int32_t)((pw + 63u) & ~63u);

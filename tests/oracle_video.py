@@ -36,24 +36,26 @@ def align(v, a):
 
 
 class HostFrame:
-    """yuv420p frame in host memory with 64-byte-aligned strides (padding zero-initialised)."""
+    """planar YUV frame (fmt 0 yuv420p -- the default and everything a VideoMixer produces --, 1 yuv422p, 2 yuv444p) in host memory with
+    64-byte-aligned strides (padding zero-initialised)."""
 
-    def __init__(self, w, h):
-        self.w, self.h = w, h
-        self.planes = [np.zeros((h >> (1 if p else 0), align(w >> (1 if p else 0), 64)), np.uint8) for p in range(3)]
+    def __init__(self, w, h, fmt=0):
+        self.w, self.h, self.fmt = w, h, fmt
+        self.cw, self.ch = (0 if fmt == 2 else 1), (1 if fmt == 0 else 0)
+        self.planes = [np.zeros((h >> (self.ch if p else 0), align(w >> (self.cw if p else 0), 64)), np.uint8) for p in range(3)]
         self.c = OFrame()
-        self.c.width, self.c.height = w, h
+        self.c.width, self.c.height, self.c.fmt = w, h, fmt
         for p in range(3):
             self.c.data[p] = self.planes[p].ctypes.data
             self.c.stride[p] = self.planes[p].shape[1]
 
     def visible(self):
-        return [self.planes[p][:, : self.w >> (1 if p else 0)] for p in range(3)]
+        return [self.planes[p][:, : self.w >> (self.cw if p else 0)] for p in range(3)]
 
     def fill(self, layer, seed=0):
         """SURVEY.md section 8d config 4 pattern: Y(x,y) = (x + 2y + 31*layer + LCG noise) mod 256, U/V similar at half res."""
         import synth
-        for p, a in enumerate(synth.yuv_pattern(self.w, self.h, layer, seed)):
+        for p, a in enumerate(synth.yuv_pattern(self.w, self.h, layer, seed, self.fmt)):
             self.planes[p][:, : a.shape[1]] = a
         return self
 

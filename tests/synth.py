@@ -35,12 +35,13 @@ def ulp_diff(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return np.abs(key(a) - key(b))
 
 
-def yuv_pattern(w: int, h: int, layer: int, seed: int = 0):
-    """SURVEY.md section 8d config 4 pattern, planar yuv420p: Y(x,y) = (x + 2y + 31*layer + LCG noise) mod 256, U/V alike at
-    half resolution.  Pure numpy -- bench.py and the tests' HostFrame.fill share it."""
+def yuv_pattern(w: int, h: int, layer: int, seed: int = 0, fmt: int = 0):
+    """SURVEY.md section 8d config 4 pattern, planar YUV (fmt 0 yuv420p, 1 yuv422p, 2 yuv444p): Y(x,y) = (x + 2y + 31*layer + LCG
+    noise) mod 256, U/V alike at the format's chroma resolution.  Pure numpy -- bench.py and the tests' HostFrame.fill share it."""
     planes = []
+    cw, ch = (0 if fmt == 2 else 1), (1 if fmt == 0 else 0)
     for p in range(3):
-        hh, ww = h >> (1 if p else 0), w >> (1 if p else 0)
+        hh, ww = h >> (ch if p else 0), w >> (cw if p else 0)
         yy, xx = np.mgrid[0:hh, 0:ww].astype(np.uint32)
         lcg = ((xx * np.uint32(1664525) + yy * np.uint32(1013904223) + np.uint32(seed * 7919 + layer * 104729 + p * 31337)) >> np.uint32(13)) & np.uint32(15)
         planes.append(((xx + 2 * yy + 31 * layer + 57 * p + lcg) & np.uint32(255)).astype(np.uint8))

@@ -104,6 +104,35 @@ def test_scaled_layers_held_over_several_ticks_and_replaced(inline, monkeypatch)
             assert np.array_equal(a, b), f"tick {tick} plane {p}"
 
 
+@pytest.mark.parametrize("inline", ["0", "1"], ids=["scaler-kernel", "resampled-in-chain"])
+def test_mixer_inputs_of_other_pixel_formats(inline, monkeypatch):
+    """Layers arrive as yuv422p / yuv444p (decoders produce them): each VideoMixer channel's scaler converts while it fits the layer into
+    the yuv420p output picture -- also when the layer already has the output's size (encode.rs:342-352 compares the whole settings)."""
+    monkeypatch.setenv("MX_SCALE_INLINE", inline)
+    spec = [((320, 180), 0), ((320, 180), 2), ((160, 90), 1), ((320, 180), 1), ((212, 120), 2), ((640, 360), 2)]
+    ws, srcs, mixers, rgba = cascade([s for s, _ in spec], MATRIX)
+    g = ws.build(max_ticks_per_run=4)
+    layers = [ov.HostFrame(w, h, fmt).fill(k, seed=6) for k, ((w, h), fmt) in enumerate(spec)]
+    keep = []
+    for s, hf in zip(srcs, layers):
+        d = video.DFrame(hf.w, hf.h, fmt=hf.fmt).upload(*hf.visible()); keep.append(d)
+        video.graph_set_video_source(g, s, d, dur=(1, 60), off=(0, 1), repeat=True)
+    g.run_ticks(0, 2)
+    oms = [ov.OracleVideoMixer(a=0, b=1, fader=FADERS[k]) for k in range(len(spec) - 1)]
+    want = None
+    for tick in range(2):
+        prev = (layers[0], (1, 60), (0, 1))
+        for k in range(len(spec) - 1):
+            out = oms[k].run_tick(tick * 735, [prev, (layers[k + 1], (1, 60), (0, 1)), None, None])
+            prev = (out, (1, 60), (0, 1))
+        want = prev[0]
+    got = video.graph_video_output(g, mixers[-1], 0)
+    assert (got.width, got.height, got.fmt) == (want.w, want.h, 0)
+    for p, (a, b) in enumerate(zip(got.download(), want.visible())):
+        assert np.array_equal(a, b), f"plane {p} differs"
+    assert np.array_equal(video.graph_rgba_output(g, rgba), ov.to_rgba(want, MATRIX))
+
+
 def test_video_source_single_shot_then_none_and_passthrough():
     ws = Workspace(44100, 60)
     s = ws.source_video(); m = ws.video_mixer(a=0, b=None, fader=1.0)

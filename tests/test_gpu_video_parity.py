@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_video as ov
-from mixlab_amd import video
+from mixlab_amd import abi, video
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,40 @@ def test_dynamic_scale_letterbox_bit_exact_vs_build_spec(geom):
     dsrc, out = upload(src), video.DFrame(ow, oh)
     video.scale(dsrc, out)
     assert_frame_equal(out, want, f"scale {geom}")
+
+
+@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV422P, video.PIXFMT_YUV444P], ids=["yuv422p", "yuv444p"])
+@pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((320, 180), (320, 180)), ((640, 480), (1920, 1080)), ((1920, 1080), (560, 350)),
+                                  ((66, 34), (640, 640)), ((1922, 1082), (1920, 1080))])
+def test_scaler_input_of_another_pixel_format_is_converted_plane_by_plane(geom, fmt):
+    """SwsContext::new(input, output) carries the input's pixel format (codec/src/ffmpeg/scale.rs:16-39) and the DynamicScaler's
+    settings compare unequal when only the format differs (encode.rs:342-352): a 4:2:2 / 4:4:4 frame -- also one of the output's own
+    size -- comes out as the letterboxed yuv420p picture, every plane resampled from its own size (build-specified, DESIGN "Scaler")."""
+    (iw, ih), (ow, oh) = geom
+    src = ov.HostFrame(iw, ih, fmt).fill(4, seed=2)
+    want = ov.HostFrame(ow, oh); ov.dynamic_scale(src, want)
+    dsrc = video.DFrame(iw, ih, fmt=fmt).upload(*src.visible())
+    assert [a.shape for a in dsrc.download()] == [a.shape for a in src.visible()]
+    for a, b in zip(dsrc.download(), src.visible()):
+        assert np.array_equal(a, b)
+    out = video.DFrame(ow, oh)
+    video.scale(dsrc, out)
+    assert_frame_equal(out, want, f"scale {geom} fmt {fmt}")
+    sc = video.Scaler(ow, oh)                     # the persistent scaler: the input is never "the frame itself" when its format differs
+    res = sc.scale(dsrc)
+    assert res.device_planes()[0] != dsrc.device_planes()[0]
+    assert_frame_equal(res, want, f"persistent scaler {geom} fmt {fmt}")
+
+
+def test_frame_formats_are_validated():
+    with pytest.raises(abi.MxError):
+        video.DFrame(33, 32, fmt=video.PIXFMT_YUV422P)      # 4:2:2 needs an even width
+    video.DFrame(33, 17, fmt=video.PIXFMT_YUV444P)          # 4:4:4 takes any size
+    f444 = video.DFrame(64, 64, fmt=video.PIXFMT_YUV444P)
+    with pytest.raises(abi.MxError):
+        video.crossfade(video.DFrame(64, 64), f444, None, 0.5)   # the cross-fade works on VideoMixer pictures: yuv420p
+    with pytest.raises(abi.MxError):
+        video.scale(video.DFrame(64, 64), f444)                  # the scaler's output picture is yuv420p
 
 
 def test_persistent_scaler_is_the_monitor_rescale_and_follows_input_changes():
