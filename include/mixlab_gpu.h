@@ -315,6 +315,14 @@ int mx_graph_set_video_source(mx_graph* g, uint32_t node, mx_dframe* frame, int6
  * duration hint and offset.  The graph retains the frames.  n = 0 clears the source. */
 int mx_graph_set_video_source_ring(mx_graph* g, uint32_t node, mx_dframe* const* frames, size_t n, int64_t dur_num, int64_t dur_den,
                                    int64_t off_num, int64_t off_den);
+/* Row-band sharding of one composited picture over ranks (mixlab_amd/shard.py): a rank's graph is the cascade at (full_w x
+ * band_rows).  Layers of the picture's own size are fed as their band rows; a SMALLER layer is fed as the halo slice its band needs
+ * (luma rows [src_row0, src_row0 + slice_rows) of an in_w x in_full_h yuv420p source, shard.band_source_rows) and this call makes
+ * the source node deliver, on every tick it has a frame, luma rows [row0, row0 + band_rows) of that layer's letterboxed scale into
+ * (full_w x full_h) -- what DynamicScaler::scale (encode.rs:338-397) gives the unsharded VideoMixer, cut to the band; asynchronous,
+ * on the graph's stream.  band_rows = 0 removes the transform. */
+int mx_graph_set_video_source_band(mx_graph* g, uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows,
+                                   uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows);
 /* Output port of a video node after the last tick: one reference for the caller, NULL = None. */
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out);
 /* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame). */

@@ -319,6 +319,13 @@ int mx_graph_set_video_source_ring(mx_graph* g, uint32_t node, mx_dframe* const*
         g->g->set_video_source_ring(node, v.data(), n, mx::Rational::make(dur_num, dur_den ? dur_den : 1), mx::Rational::make(off_num, off_den ? off_den : 1));
     });
 }
+int mx_graph_set_video_source_band(mx_graph* g, uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows,
+                                   uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        g->g->set_video_source_band(node, in_w, in_full_h, src_row0, slice_rows, full_w, full_h, row0, band_rows);
+    });
+}
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out) {
     return guard([&] {
         REQUIRE(g && out, "NULL argument");

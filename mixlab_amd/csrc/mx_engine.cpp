@@ -1077,7 +1077,7 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
             nn.vmixer->rebind(stream_, nn.vlazy, tps_);   // the old graph's stream may be gone after this call; this graph's fusion plan and tick rate apply
             nn.vmixer->update(p);
         }
-        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc_ring = on.vsrc_ring; nn.vsrc_ring_pos = on.vsrc_ring_pos; nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
+        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc_ring = on.vsrc_ring; nn.vsrc_ring_pos = on.vsrc_ring_pos; nn.vband = on.vband; nn.vband_pool = on.vband_pool; nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
     }
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
@@ -1203,11 +1203,20 @@ void Graph::run_video_tick(uint64_t t) {
             if (!n.vsrc_ring.empty()) {   // a decoder's stream: the next frame of the ring, every tick
                 n.vout[0].frame = n.vsrc_ring[n.vsrc_ring_pos]; n.vout[0].dur = n.vsrc_dur; n.vout[0].off = n.vsrc_off;
                 n.vsrc_ring_pos = (n.vsrc_ring_pos + 1) % n.vsrc_ring.size();
-                break;
-            }
-            if (n.vsrc && (n.vsrc_repeat || n.vsrc_pending)) {
+            } else if (n.vsrc && (n.vsrc_repeat || n.vsrc_pending)) {
                 n.vout[0].frame = n.vsrc; n.vout[0].dur = n.vsrc_dur; n.vout[0].off = n.vsrc_off;
                 n.vsrc_pending = false;
+            }
+            if (n.vband && n.vout[0].frame) {   // row-band sharding: the frame is a halo slice of a smaller layer; deliver this rank's band of its scale
+                FrameRef o;
+                for (auto& f : n.vband_pool) if (f->rc.load(std::memory_order_acquire) == 1) { o = f; break; }   // only the pool holds it
+                if (!o) {
+                    if (n.vband_pool.size() >= 8) n.vband_pool.erase(n.vband_pool.begin());
+                    n.vband_pool.push_back(FrameRef(DFrame::create(n.vband->full_w(), n.vband->band_rows(), stream_), false));
+                    o = n.vband_pool.back();
+                }
+                n.vband->run(n.vout[0].frame.f, o.f, stream_);
+                n.vout[0].frame = o;
             }
             break;
         }
@@ -1272,6 +1281,15 @@ void Graph::set_video_source(uint32_t node, DFrame* frame, Rational dur, Rationa
     Node& n = nodes_[node];
     n.vsrc = frame ? FrameRef(frame, true) : FrameRef();
     n.vsrc_dur = dur; n.vsrc_off = off; n.vsrc_repeat = repeat; n.vsrc_pending = frame != nullptr;
+}
+
+void Graph::set_video_source_band(uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows,
+                                  uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_SOURCE_VIDEO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_VIDEO");
+    Node& nd = nodes_[node];
+    sync();                                     // a previous band scaler's row buffer may be in use
+    nd.vband.reset(); nd.vband_pool.clear();
+    if (band_rows) nd.vband = std::make_shared<BandScaler>(in_w, in_full_h, src_row0, slice_rows, full_w, full_h, row0, band_rows);
 }
 
 void Graph::set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off) {

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     uint8_t* const S = sc_smem + (size_t)a.s_rows * SC_TW * 4;                 // [s_rows][s_stride] source window, signed bytes
     const int tid = threadIdx.x;
     const int oxe = min(ox0 + SC_TW, (int)p.dw), oye = min(oy0 + SC_TH, (int)p.dh);
-    ScWin w = sc_window(ox0, oxe, oy0, oye, p.sw, p.dw, p.sh, p.dh);
+    ScWin w = sc_window(ox0, oxe, oy0 + (int)p.oy_base, oye + (int)p.oy_base, p.sw, p.dw, p.sh, p.dh_full ? p.dh_full : p.dh);
     w.nc4 = min(w.nc4, (int)a.s_stride >> 2); w.nr = min(w.nr, (int)a.s_rows);
     // every table entry this lane will need, in one burst
     const int oxi = tid & (SC_TW - 1), ox = min(ox0 + oxi, (int)p.dw - 1);
@@ -572,7 +572,8 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
         mw = p.dw > mw ? p.dw : mw; mh = p.dh > mh ? p.dh : mh;
         if (!p.dw || !p.dh) continue;
         // window of a 128 x 32 tile: taps of its first and last output + 4, columns widened to whole dwords
-        const uint32_t rows = (uint32_t)(((uint64_t)SC_TH * p.sh + p.dh - 1) / p.dh) + 6;
+        const uint32_t dhf = p.dh_full ? p.dh_full : p.dh;   // a row band scales with the ratio of the full plane
+        const uint32_t rows = (uint32_t)(((uint64_t)SC_TH * p.sh + dhf - 1) / dhf) + 6;
         const uint32_t cols = (uint32_t)(((uint64_t)SC_TW * p.sw + p.dw - 1) / p.dw) + 6 + 15 + 4;   // 16-byte window start + the H pass's second dword
         s_rows = rows > s_rows ? rows : s_rows; s_stride = cols > s_stride ? cols : s_stride;
     }

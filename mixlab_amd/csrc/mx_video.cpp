@@ -280,57 +280,121 @@ static void make_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, s
 uint32_t scaler_tap_count(uint32_t src, uint32_t dst) { return tap_count(src, dst); }
 void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::vector<int32_t>& coef) { make_taps(src, dst, first, coef); }
 
-void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFrame* out, uint32_t full_w, uint32_t full_h, uint32_t row0, hipStream_t s) {
-    if (!slice || !out) throw Error(MX_ERR_INVALID, "NULL frame");
-    if (slice->fmt != MX_PIXFMT_YUV420P || out->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "row bands are cut from yuv420p pictures");
-    if (out->width != full_w) throw Error(MX_ERR_INVALID, "a band frame is as wide as the full picture");
-    if ((row0 & 1) || (src_row0 & 1) || (in_full_h & 1) || (full_h & 1) || row0 + out->height > full_h || src_row0 + slice->height > in_full_h)
+// Packed taps of the tiled / inline kernels (mx_k_video.hip): H {ch0..3 as i8 x 4, cl0..3 as i8 x 4} with c = 256 ch + cl; V {(c0, c1), (c2, c3)}
+// as i16 x 2.  Every bound that arithmetic relies on is checked on the actual tables; false = these taps do not fit.
+static bool pack_lean_taps(const std::vector<int32_t>& hc, const std::vector<int32_t>& vc, std::vector<int32_t>& hp, std::vector<int32_t>& vp) {
+    bool ok = true;
+    for (size_t o = 0; o < hc.size() / 4; ++o) {
+        uint32_t hi = 0, lo = 0; int64_t pos = 0, neg = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t cc = hc[4 * o + k], ch = (cc + 128) >> 8, cl = cc - 256 * ch;
+            if (ch < -128 || ch > 127) ok = false;
+            hi |= (uint32_t)(ch & 0xff) << (8 * k); lo |= (uint32_t)(cl & 0xff) << (8 * k);
+            (cc > 0 ? pos : neg) += cc;
+        }
+        if (((pos * 255 + 64) >> 7) - 16384 > 32767 || ((neg * 255 + 64) >> 7) - 16384 < -32768) ok = false;   // t - 16384 is an i16
+        hp.push_back((int32_t)hi); hp.push_back((int32_t)lo);
+    }
+    for (size_t o = 0; o < vc.size() / 4; ++o) {
+        int64_t mag = 0;
+        for (int k = 0; k < 4; ++k) { const int32_t cc = vc[4 * o + k]; if (cc < -32768 || cc > 32767) ok = false; mag += cc < 0 ? -cc : cc; }
+        if (mag * 32768 + ((int64_t)16384 * 16384 + (1 << 20)) > 0x7fffffffLL) ok = false;                    // the V accumulator stays in i32
+        vp.push_back((int32_t)(((uint32_t)vc[4 * o] & 0xffffu) | ((uint32_t)vc[4 * o + 1] << 16)));
+        vp.push_back((int32_t)(((uint32_t)vc[4 * o + 2] & 0xffffu) | ((uint32_t)vc[4 * o + 3] << 16)));
+    }
+    return ok;
+}
+
+// Row band of DynamicScaler::scale.  The plan (tap tables, which rows of which plane) depends only on the geometry; run() binds frames.
+BandScaler::BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows, uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows)
+    : in_w_(in_w), src_row0_(src_row0), slice_rows_(slice_rows), full_w_(full_w), band_rows_(band_rows) {
+    if (!in_w || !in_full_h || (in_w & 1) || (row0 & 1) || (src_row0 & 1) || (in_full_h & 1) || (full_h & 1) || (band_rows & 1) || (slice_rows & 1) || !band_rows || !slice_rows ||
+        row0 + band_rows > full_h || src_row0 + slice_rows > in_full_h)
         throw Error(MX_ERR_INVALID, "band / slice rows must be whole chroma rows inside their pictures");
-    const ScaleGeometry geo = scaler_geometry(slice->width, in_full_h, full_w, full_h);
-    launch_blank(out->data[0], out->plane_bytes[0], out->data[1], out->plane_bytes[1], out->data[2], out->plane_bytes[2], s);   // AvFrame::blank: the letterbox bars
-    if (!geo.scaled_w || !geo.scaled_h) { hip_check(hipStreamSynchronize(s), "hipStreamSynchronize"); return; }
-    std::vector<int32_t> blob; size_t offs[2][4]; uint32_t taps[2][2];
+    geo_ = scaler_geometry(in_w, in_full_h, full_w, full_h);
+    if (!geo_.scaled_w || !geo_.scaled_h) return;
+    std::vector<int32_t> blob; size_t offs[2][4], pk_off[2][2] = {{0, 0}, {0, 0}}; uint32_t taps[2][2];
     std::vector<int32_t> vf_host[2];
+    tiled_ = true;                                  // every axis 4 taps and the taps fit the packed form: the batched tiled kernel takes the band
     for (int c = 0; c < 2; ++c) {
         std::vector<int32_t> hf, hc, vf, vc;
-        make_taps(slice->width >> c, geo.scaled_w >> c, hf, hc);
-        make_taps(in_full_h >> c, geo.scaled_h >> c, vf, vc);
-        taps[c][0] = tap_count(slice->width >> c, geo.scaled_w >> c); taps[c][1] = tap_count(in_full_h >> c, geo.scaled_h >> c);
+        make_taps(in_w >> c, geo_.scaled_w >> c, hf, hc);
+        make_taps(in_full_h >> c, geo_.scaled_h >> c, vf, vc);
+        taps[c][0] = tap_count(in_w >> c, geo_.scaled_w >> c); taps[c][1] = tap_count(in_full_h >> c, geo_.scaled_h >> c);
         vf_host[c] = vf;
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
+        std::vector<int32_t> hp, vp;
+        if (taps[c][0] != 4 || taps[c][1] != 4 || !pack_lean_taps(hc, vc, hp, vp) ||
+            !scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_full_h >> c, geo_.scaled_h >> c, vf.data())) { tiled_ = false; continue; }
+        pk_off[c][0] = put(hp); pk_off[c][1] = put(vp);
     }
-    DevBuf tabs, tmp;
-    tabs.alloc(blob.size() * sizeof(int32_t));
-    hip_check(hipMemcpy(tabs.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(band taps)");
+    needs_blank_ = geo_.scaled_w != full_w;         // letterbox bars inside the band (encode.rs:382): the blank fill is only paid for when there are any
+    tabs_.alloc(blob.size() * sizeof(int32_t));
+    hip_check(hipMemcpy(tabs_.p, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(band taps)");
     size_t tmp_off[3], tmp_total = 0;
-    for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; tmp_off[p] = tmp_total; tmp_total += (size_t)(geo.scaled_w >> c) * (in_full_h >> c); }
-    tmp.alloc(tmp_total * sizeof(int32_t));
-    ScaleArgs a{};
-    bool any = false;
+    for (int p = 0; p < 3; ++p) { const int c = p ? 1 : 0; tmp_off[p] = tmp_total; tmp_total += (size_t)(geo_.scaled_w >> c) * (in_full_h >> c); }
+    tmp_.alloc(tmp_total * sizeof(int32_t));
     for (int p = 0; p < 3; ++p) {
         const int c = p ? 1 : 0;
-        ScalePlane& sp = a.p[p];
-        const uint32_t b0 = row0 >> c, b1 = (row0 + out->height) >> c;                     // the band in this plane's rows
-        const uint32_t s0 = geo.letterbox_y >> c, s1 = (geo.letterbox_y + geo.scaled_h) >> c;   // the scaled picture's rows
+        ScalePlane& sp = plan_.p[p];
+        sp = ScalePlane{};
+        const uint32_t b0 = row0 >> c, b1 = (row0 + band_rows) >> c;                          // the band in this plane's rows
+        const uint32_t s0 = geo_.letterbox_y >> c, s1 = (geo_.letterbox_y + geo_.scaled_h) >> c;   // the scaled picture's rows
         const uint32_t ra = std::max(b0, s0), rb = std::min(b1, s1);
-        if (ra >= rb) { sp.dw = sp.dh = 0; sp.h_rows = 0; continue; }                       // this band lies in the letterbox bars
+        if (ra > b0 || rb < b1) needs_blank_ = true;
+        if (ra >= rb) continue;                                                              // this band lies in the letterbox bars
         const uint32_t sh = in_full_h >> c, vn = taps[c][1];
         const int32_t lo = std::min<int32_t>(std::max<int32_t>(vf_host[c][ra - s0], 0), (int32_t)sh - 1);
         const int32_t hi = std::min<int32_t>(std::max<int32_t>(vf_host[c][rb - 1 - s0] + (int32_t)vn - 1, 0), (int32_t)sh - 1);
-        const uint32_t sl0 = src_row0 >> c, sl1 = (src_row0 + slice->height) >> c;
+        const uint32_t sl0 = src_row0 >> c, sl1 = (src_row0 + slice_rows) >> c;
         if ((uint32_t)lo < sl0 || (uint32_t)hi >= sl1) throw Error(MX_ERR_INVALID, "the source slice lacks a row the band's vertical taps reach (see shard.band_source_rows)");
-        sp.src = slice->data[p] - (ptrdiff_t)sl0 * (ptrdiff_t)slice->stride[p];           // virtual base of the full plane: only rows [lo, hi] are read
-        sp.src_stride = slice->stride[p]; sp.sw = slice->pw(p); sp.sh = sh;
-        sp.dst = out->data[p] + (size_t)(ra - b0) * out->stride[p] + (geo.letterbox_x >> c);
-        sp.dst_stride = out->stride[p]; sp.dw = geo.scaled_w >> c; sp.dh = rb - ra;
-        sp.hfirst = (const int32_t*)tabs.p + offs[c][0]; sp.hcoef = (const int32_t*)tabs.p + offs[c][1];
-        sp.vfirst = (const int32_t*)tabs.p + offs[c][2] + (ra - s0); sp.vcoef = (const int32_t*)tabs.p + offs[c][3] + (size_t)(ra - s0) * vn;
-        sp.hn = taps[c][0]; sp.vn = vn; sp.tmp = (int32_t*)tmp.p + tmp_off[p];
+        sp.sw = in_w >> c; sp.sh = sh; sp.dw = geo_.scaled_w >> c; sp.dh = rb - ra;
+        sp.hfirst = (const int32_t*)tabs_.p + offs[c][0]; sp.hcoef = (const int32_t*)tabs_.p + offs[c][1];
+        sp.vfirst = (const int32_t*)tabs_.p + offs[c][2] + (ra - s0); sp.vcoef = (const int32_t*)tabs_.p + offs[c][3] + (size_t)(ra - s0) * vn;
+        sp.hn = taps[c][0]; sp.vn = vn; sp.tmp = (int32_t*)tmp_.p + tmp_off[p];
         sp.h_row0 = (uint32_t)lo; sp.h_rows = (uint32_t)(hi - lo + 1);
-        any = true;
+        sp.dh_full = geo_.scaled_h >> c; sp.oy_base = ra - s0;                                                                // the band's first row of this plane, in rows of the scaled picture
+        if (tiled_) {
+            sp.hpk = reinterpret_cast<const uint2*>((const int32_t*)tabs_.p + pk_off[c][0]);
+            sp.vpk = reinterpret_cast<const uint2*>((const int32_t*)tabs_.p + pk_off[c][1]) + (ra - s0);
+        }
+        dst_row_[p] = ra - b0;
+        any_ = true;
     }
-    if (any) launch_scale_wide(a, s);
+}
+
+void BandScaler::run(const DFrame* slice, DFrame* out, hipStream_t s) {
+    if (!slice || !out) throw Error(MX_ERR_INVALID, "NULL frame");
+    if (slice->fmt != MX_PIXFMT_YUV420P || out->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "row bands are cut from yuv420p pictures");
+    if (slice->width != in_w_ || slice->height != slice_rows_ || out->width != full_w_ || out->height != band_rows_ || !slice->data[0] || !out->data[0])
+        throw Error(MX_ERR_INVALID, "frames do not have the sizes this band scaler was planned for");
+    if (needs_blank_ || !any_) launch_blank(out->data[0], out->plane_bytes[0], out->data[1], out->plane_bytes[1], out->data[2], out->plane_bytes[2], s);   // AvFrame::blank: the letterbox bars
+    if (!any_) return;
+    ScaleArgs a = plan_;
+    for (int p = 0; p < 3; ++p) {
+        const int c = p ? 1 : 0;
+        ScalePlane& sp = a.p[p];
+        if (!sp.dw || !sp.dh) continue;
+        sp.src = slice->data[p] - (ptrdiff_t)(src_row0_ >> c) * (ptrdiff_t)slice->stride[p];   // virtual base of the full plane: only rows of the slice are read
+        sp.src_stride = slice->stride[p];
+        sp.dst = out->data[p] + (size_t)dst_row_[p] * out->stride[p] + (geo_.letterbox_x >> c);
+        sp.dst_stride = out->stride[p];
+    }
+    if (tiled_) {              // leaves with the other scales of this tick as one launch (flushed by whoever reads the pixels)
+        queue_scale(a, s, FrameRef(const_cast<DFrame*>(slice), true), FrameRef(out, true));
+        return;
+    }
+    launch_scale_wide(a, s);   // two passes through the row buffer, launched in stream order: one run at a time per BandScaler
+    hip_check(hipGetLastError(), "band scale launch");
+}
+
+void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFrame* out, uint32_t full_w, uint32_t full_h, uint32_t row0, hipStream_t s) {
+    if (!slice || !out) throw Error(MX_ERR_INVALID, "NULL frame");
+    if (out->width != full_w) throw Error(MX_ERR_INVALID, "a band frame is as wide as the full picture");
+    BandScaler bs(slice->width, in_full_h, src_row0, slice->height, full_w, full_h, row0, out->height);
+    bs.run(slice, out, s);
+    flush_scales(s);
     hip_check(hipGetLastError(), "band scale launch");
     hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");   // the tables and the row buffer die here
 }
@@ -360,26 +424,8 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
         if (t->taps[c][0] != 4 || t->taps[c][1] != 4) { four = false; continue; }
         if (!scale_tile_origins_match(src_w[c], geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match(src_h[c], geo.scaled_h >> c, vf.data()))
             throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
-        // packed taps of the tiled / inline kernels; every bound their arithmetic relies on is checked on the actual tables
         std::vector<int32_t> hp, vp;
-        for (size_t o = 0; o < hf.size(); ++o) {
-            uint32_t hi = 0, lo = 0; int64_t pos = 0, neg = 0;
-            for (int k = 0; k < 4; ++k) {
-                const int32_t cc = hc[4 * o + k], ch = (cc + 128) >> 8, cl = cc - 256 * ch;
-                if (ch < -128 || ch > 127) four = false;
-                hi |= (uint32_t)(ch & 0xff) << (8 * k); lo |= (uint32_t)(cl & 0xff) << (8 * k);
-                (cc > 0 ? pos : neg) += cc;
-            }
-            if (((pos * 255 + 64) >> 7) - 16384 > 32767 || ((neg * 255 + 64) >> 7) - 16384 < -32768) four = false;   // t - 16384 is an i16
-            hp.push_back((int32_t)hi); hp.push_back((int32_t)lo);
-        }
-        for (size_t o = 0; o < vf.size(); ++o) {
-            int64_t mag = 0;
-            for (int k = 0; k < 4; ++k) { const int32_t cc = vc[4 * o + k]; if (cc < -32768 || cc > 32767) four = false; mag += cc < 0 ? -cc : cc; }
-            if (mag * 32768 + ((int64_t)16384 * 16384 + (1 << 20)) > 0x7fffffffLL) four = false;                    // the V accumulator stays in i32
-            vp.push_back((int32_t)(((uint32_t)vc[4 * o] & 0xffffu) | ((uint32_t)vc[4 * o + 1] << 16)));
-            vp.push_back((int32_t)(((uint32_t)vc[4 * o + 2] & 0xffffu) | ((uint32_t)vc[4 * o + 3] << 16)));
-        }
+        if (!pack_lean_taps(hc, vc, hp, vp)) four = false;
         pk_off[c][0] = put(hp); pk_off[c][1] = put(vp);
     }
     t->four_tap = four;
@@ -416,7 +462,7 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
         sp.hfirst = t.tab[c][0]; sp.hcoef = t.tab[c][1]; sp.vfirst = t.tab[c][2]; sp.vcoef = t.tab[c][3];
         sp.hn = t.taps[c][0]; sp.vn = t.taps[c][1]; sp.tmp = tmp_plane ? tmp_plane[p] : nullptr;
         sp.h_row0 = 0; sp.h_rows = sp.sh;
-        sp.hpk = t.hpk[c]; sp.vpk = t.vpk[c];
+        sp.hpk = t.hpk[c]; sp.vpk = t.vpk[c]; sp.oy_base = 0; sp.dh_full = 0;
     }
     if (tmp_plane && tmp_plane[0]) {        // widened kernel (downscale): two passes, launched in stream order
         flush_scales(s);

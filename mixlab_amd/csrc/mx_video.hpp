@@ -31,6 +31,7 @@ struct ScalePlane {
     int32_t* tmp;                                  // wide path only: [sh][dw] H-filtered rows
     uint32_t h_row0, h_rows;                       // wide path only: the source rows the H pass filters (a row band reads a slice of the plane)
     const uint2* hpk; const uint2* vpk;            // tiled path: packed taps (ScaleTables::lean), nullptr = not available
+    uint32_t oy_base, dh_full;                     // tiled path, row bands: index of dst's first row in rows of the scaled plane, and that plane's full height (0 = dh)
 };
 struct ScaleArgs { ScalePlane p[3]; };
 enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
@@ -189,6 +190,23 @@ void scaler_taps(uint32_t src, uint32_t dst, std::vector<int32_t>& first, std::v
 // Row band of DynamicScaler::scale (multi-GPU row bands): luma rows [row0, row0 + out->height) of the (full_w x full_h)
 // letterboxed result from a slice holding luma rows [src_row0, src_row0 + slice->height) of a source in_full_h rows high.  Synchronous.
 void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFrame* out, uint32_t full_w, uint32_t full_h, uint32_t row0, hipStream_t s);
+
+// The same band, planned once and run asynchronously every tick (a rank of a row-band sharded job scales its halo slice of every smaller
+// layer per tick).  One run at a time per object (the H-filtered rows live in its buffer): runs are ordered by the stream.
+class BandScaler {
+public:
+    BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows, uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows);
+    void run(const DFrame* slice, DFrame* out, hipStream_t s);
+    uint32_t full_w() const { return full_w_; }
+    uint32_t band_rows() const { return band_rows_; }
+private:
+    uint32_t in_w_, src_row0_, slice_rows_, full_w_, band_rows_;
+    ScaleGeometry geo_{};
+    DevBuf tabs_, tmp_;
+    ScaleArgs plan_{};
+    uint32_t dst_row_[3] = {0, 0, 0};
+    bool any_ = false, tiled_ = false, needs_blank_ = true;
+};
 
 // DynamicScaler (src/video/encode.rs:311-398)
 class Scaler {

@@ -76,6 +76,14 @@ def graph_set_video_source(g, node, frame, dur=(1, 60), off=(0, 1), repeat=False
     check(lib.mx_graph_set_video_source(g._h, node, frame.handle if frame is not None else None, dur[0], dur[1], off[0], off[1], 1 if repeat else 0))
 
 
+_proto("mx_graph_set_video_source_band", C.c_int, C.c_void_p, *([C.c_uint32] * 9))
+
+
+def graph_set_video_source_band(g, node, in_w, in_full_h, src_row0, slice_rows, full_w, full_h, row0, band_rows):
+    """The source's frames are halo slices of a smaller layer; it delivers this rank's row band of the layer's letterboxed scale."""
+    check(lib.mx_graph_set_video_source_band(g._h, node, in_w, in_full_h, src_row0, slice_rows, full_w, full_h, row0, band_rows))
+
+
 def graph_set_video_source_ring(g, node, frames, dur=(1, 60), off=(0, 1)):
     """A new frame on every tick, cycling through `frames` (a decoder's stream)."""
     arr = (C.c_void_p * max(1, len(frames)))(*[f.handle for f in frames])

@@ -232,3 +232,46 @@ def test_row_band_compositing_on_the_device_equals_the_unsharded_picture(full, s
     need = shard.band_source_rows(band, f.w, f.h, W, H)
     with pytest.raises(abi.MxError):
         video.scale_band(upload(rows_of(f, need[0] + 2, need[1] - 2)), f.h, need[0] + 2, video.DFrame(W, band[1]), W, H, band[0])
+
+
+@pytest.mark.parametrize("full,small,world", [((320, 180), (212, 120), 4), ((1920, 1080), (1280, 720), 8)])
+def test_row_band_job_with_band_scaling_sources_in_one_submission(full, small, world):
+    """The sharded job as a rank runs it: the smaller layers enter the graph as halo slices, their SOURCE nodes scale them to the band
+    every tick (mx_graph_set_video_source_band) inside a multi-tick submission; layers change every tick (rings of 2).  Stitched, the
+    last tick's bands are the unsharded oracle picture of that tick."""
+    from mixlab_amd import shard
+    from test_cpu_video_bands import rows_of, cascade as oracle_cascade
+    W, H = full
+    n_ticks = 3
+    sets = [[ov.HostFrame(W, H).fill(k, seed=4 + r) for k in range(6)] + [ov.HostFrame(*small).fill(k, seed=4 + r) for k in (6, 7)] for r in range(2)]
+    last = sets[(n_ticks - 1) % 2]
+    whole = []
+    for f in last:
+        o = f
+        if (f.w, f.h) != (W, H):
+            o = ov.HostFrame(W, H); ov.dynamic_scale(f, o)
+        whole.append(o)
+    want_rgba = ov.to_rgba(oracle_cascade(whole), MATRIX)
+    got_rgba = np.zeros_like(want_rgba)
+    for (row0, rows) in shard.row_bands(H, world):
+        ws, srcs, mixers, rgba = cascade([(W, rows)] * 8, MATRIX)
+        g = ws.build(max_ticks_per_run=4)
+        keep = []
+        for k in range(8):
+            ring = []
+            for r in range(2):
+                f = sets[r][k]
+                if (f.w, f.h) == (W, H):
+                    ring.append(upload(rows_of(f, row0, rows)))
+                else:
+                    need = shard.band_source_rows((row0, rows), f.w, f.h, W, H)
+                    ring.append(upload(rows_of(f, need[0], need[1])))
+            if (sets[0][k].w, sets[0][k].h) != (W, H):
+                f = sets[0][k]
+                need = shard.band_source_rows((row0, rows), f.w, f.h, W, H)
+                video.graph_set_video_source_band(g, srcs[k], f.w, f.h, need[0], need[1], W, H, row0, rows)
+            keep.append(ring)
+            video.graph_set_video_source_ring(g, srcs[k], ring, dur=(1, 60), off=(0, 1))
+        g.run_ticks(0, n_ticks)
+        got_rgba[row0:row0 + rows] = video.graph_rgba_output(g, rgba)
+    assert np.array_equal(got_rgba, want_rgba)
