@@ -774,7 +774,7 @@ def main():
                     "algorithmic_bytes_per_unit": "2M = 8 B per sample per strip (SURVEY 8d: EqThree channel-tick; source read + strip written as one float per frame)",
                     "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
-                    "limiter": ("f64 VALU issue: PMC (profiles/r02) 72 VALU instructions per sample with toggling gates (52 with held gates), HBM traffic = 1.00x algorithmic; "
+                    "limiter": ("f64 VALU issue: PMC (profiles/r02) 72 VALU instructions per sample with toggling gates (52 with held gates), HBM traffic = 1.17x algorithmic (the warm-up re-read); "
                                 "HBM is the roof only nominally" if dom == "eq_three" else "HBM"),
                     "per_kernel": per_kernel}
             if dom == "eq_three":

@@ -67,7 +67,7 @@ struct ChainArgs {
 };
 // A chain layer that is the DynamicScaler's letterboxed output of a smaller (or equal-sized) picture, resampled INSIDE the chain kernel
 // (4-tap axes only): the scaled frame is never written.  Index [0] = luma, [1] = both chroma planes.
-enum { MX_CHAIN_MAX_SCALED = 4 };
+enum { MX_CHAIN_MAX_SCALED = 2 };
 struct ChainScale {
     const uint8_t* src[3]; uint32_t src_stride[3];
     uint32_t sw[2], sh[2];                         // source plane size
