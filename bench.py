@@ -553,6 +553,7 @@ def main():
     ap.add_argument("--ticks-per-step", type=int, default=2048, help="ticks batched per submission (SURVEY 8d: throughput mode; 1 = real-time mode)")
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-fast", action="store_true", help="MX_FLAG_EQ_FAST: the time-parallel EqThree scan (<= 1 ULP, NOT bit-exact) instead of the exact default")
+    ap.add_argument("--no-held-leg", action="store_true", help="skip the held-gates comparison leg (counter passes: keep the dispatches of one kind)")
     ap.add_argument("--hold-gates", action="store_true", help="no per-tick gate schedule: every gate held for the whole run (the round-1 configuration)")
     ap.add_argument("--no-fuse", action="store_true", help="materialise every port (MX_FLAG_NO_FUSE): module-boundary traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -667,7 +668,7 @@ def main():
                 rep_ms.append(timed_region(nxt, args.steps) / args.steps * 1e3)
                 nxt += args.steps
         # the same job with every gate held where it stands (round 1 measured this): the Envelope is flat most of the time
-        if toggling and not use_dist:
+        if toggling and not use_dist and not args.no_held_leg:
             g.profile_enable(not args.no_profile)
             dt_h = timed_region(nxt, min(args.steps, 10), scheduled=False)
             g.profile_enable(False)

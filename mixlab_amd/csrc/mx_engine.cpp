@@ -972,7 +972,11 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
     }
     (void)run_calls;
     // video sub-graph: tick by tick (frames arrive per tick; nothing to batch over time)
-    if (has_video_) { for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc); flush_scales(stream_); }
+    if (has_video_) {
+        for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc);
+        flush_scales(stream_);
+        for (uint32_t id : video_order_) if (nodes_[id].rgba_pending) launch_pending_rgba(nodes_[id], false);   // the last tick's sinks
+    }
     if (prof && has_video_) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
     if (prof) prof_runs_.push_back(std::move(ev));
 }
@@ -1248,7 +1252,7 @@ void Graph::run_video_tick(uint64_t t) {
             DFrame* d = v.frame.f;
             const int32_t stride = (int32_t)(((size_t)d->width * 4 + 15) & ~(size_t)15);
             const size_t need = (size_t)stride * d->height;
-            if (n.rgba.bytes < need) { sync(); n.rgba.alloc(need); }
+            if (n.rgba.bytes < need) { if (n.rgba_pending) launch_pending_rgba(n, false); sync(); n.rgba.alloc(need); }
             mx_video_to_rgba_params p; std::memcpy(&p, n.params.data(), sizeof p);
             if (d->lazy) {   // the composite only exists as a cross-fade chain: evaluate it straight into RGBA
                 ChainRgbaArgs c;
@@ -1256,10 +1260,17 @@ void Graph::run_video_tick(uint64_t t) {
                 c.rgba = (uint8_t*)n.rgba.p; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
                 c.use_matrix = p.use_matrix;
                 for (int k = 0; k < 12; ++k) c.m[k] = p.matrix_q12[k];
-                launch_fade_chain_rgba(c, stream_);
+                // Inside a batched run the sink runs ONE TICK LATE: the chain of tick k leaves together with the scaler tiles tick k + 1
+                // queues (one launch instead of two dependent ones, mx_k_video.hip k_scale_then_chain_rgba); the scales tick k itself
+                // needed left with the chain of tick k - 1.  Scaler outputs alternate between two frames, so the scales of tick k + 1
+                // never write what this chain reads.  The last tick's chain is launched when the run ends (Graph::run_span).
+                if (n.rgba_pending) launch_pending_rgba(n, true);
+                else flush_scales(stream_);                       // first tick of the run: this tick's scales have nothing to leave with
+                n.rgba_args = c; n.rgba_keep = d->lazy; n.rgba_pending = true;
                 n.rgba_w = d->width; n.rgba_h = d->height; n.rgba_stride = stride;
                 break;
             }
+            if (n.rgba_pending) launch_pending_rgba(n, false);
             d->ensure_pixels(stream_);
             if (d->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "VIDEO_TO_RGBA takes yuv420p (a VideoMixer output); put a VideoMixer in front of a source of another format");
             RgbaArgs a;
@@ -1274,6 +1285,12 @@ void Graph::run_video_tick(uint64_t t) {
         default: break;
         }
     }
+}
+
+void Graph::launch_pending_rgba(Node& n, bool with_queued_scales) {
+    if (with_queued_scales) launch_chain_rgba_after_queued_scales(n.rgba_args, stream_);
+    else launch_fade_chain_rgba(n.rgba_args, stream_);
+    n.rgba_pending = false; n.rgba_keep.reset();
 }
 
 void Graph::set_video_source(uint32_t node, DFrame* frame, Rational dur, Rational off, bool repeat) {
@@ -1305,7 +1322,11 @@ FrameRef Graph::video_output(uint32_t node, uint32_t port) {
     if (node >= nodes_.size() || port >= nodes_[node].vout.size() || nodes_[node].out_type[port] != MX_VIDEO)
         throw Error(MX_ERR_INVALID, "not a video output terminal");
     FrameRef r = nodes_[node].vout[port].frame;
-    if (r) r->ensure_pixels(stream_);   // a frame crossing the ABI must have pixels
+    if (r) {   // a frame crossing the ABI must have pixels -- and they must be there: the caller reads them on whatever stream it likes
+        r->ensure_pixels(stream_);
+        flush_scales(stream_);
+        sync();
+    }
     return r;
 }
 

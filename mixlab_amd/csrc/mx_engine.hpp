@@ -58,6 +58,7 @@ struct Node {
     std::vector<FrameRef> vsrc_ring; size_t vsrc_ring_pos = 0;                                       // SOURCE_VIDEO: a new frame every tick, cycling
     std::shared_ptr<BandScaler> vband; std::vector<FrameRef> vband_pool;                             // SOURCE_VIDEO: frames are halo slices, delivered as this rank's row band of the scaled picture
     DevBuf rgba; uint32_t rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;                       // VIDEO_TO_RGBA
+    bool rgba_pending = false; ChainRgbaArgs rgba_args{}; std::shared_ptr<LazyChain> rgba_keep;     // VIDEO_TO_RGBA: the chain of the last tick, not launched yet (run_video_tick)
 };
 
 struct Group {
@@ -139,6 +140,7 @@ private:
     void build_descriptors();
     void upload_group(Group& g);
     void run_video_tick(uint64_t t);
+    void launch_pending_rgba(Node& n, bool with_queued_scales);
     // one launch sequence over ticks [call_off, call_off + n_calls) of the current run
     void run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_calls, uint32_t run_calls);
     void apply_params(uint32_t node, const void* params, size_t len);   // update_params without the synchronisation

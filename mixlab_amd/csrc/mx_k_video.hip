@@ -306,11 +306,11 @@ __device__ __forceinline__ uint32_t cs_mask_quad(uint32_t quad, uint32_t blank, 
 }
 
 template <int MM, bool SC>
-__global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
+__device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const int bx, const int by) {
     // tile of 128 x 32 luma pixels; a lane owns 8 pixels x 2 rows and their 4 + 4 chroma samples
     const int tid = threadIdx.x;
     const int cb = tid & 15, rp = tid >> 4;
-    const int X0 = blockIdx.x * 128, Y0 = blockIdx.y * 32;
+    const int X0 = bx * 128, Y0 = by * 32;
     const uint32_t xb = (uint32_t)(X0 / 8 + cb);     // 8-pixel column block
     const uint32_t yb = (uint32_t)(Y0 / 2 + rp);     // row pair
     const bool valid = xb * 8 < a.width && yb * 2 < a.height;
@@ -441,6 +441,9 @@ __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) {
         }
     }
 }
+template <int MM, bool SC>
+__global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) { chain_rgba_tile<MM, SC>(a, (int)blockIdx.x, (int)blockIdx.y); }
+
 void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
     flush_scales(s);
     if (!a0.width || !a0.height) return;
@@ -496,12 +499,12 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 // origin is COMPUTED from the tap spec instead of fetched -- the source loads do not wait for a table
 // round trip -- and every coefficient a lane will need is requested in the same burst.
 // Used when the window fits 64 KB of LDS (scale ratio <= 2); LDS is sized per launch.
-__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
+__device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32_t block) {
     int plane = 0;
 #pragma unroll
-    for (int k = 1; k < MX_SCALE_BATCH_PLANES; ++k) if (k < (int)a.n && blockIdx.x >= a.tile_start[k]) plane = k;   // scalar search
+    for (int k = 1; k < MX_SCALE_BATCH_PLANES; ++k) if (k < (int)a.n && block >= a.tile_start[k]) plane = k;   // scalar search
     const ScalePlane p = a.p[plane];
-    const uint32_t tile = blockIdx.x - a.tile_start[plane];
+    const uint32_t tile = block - a.tile_start[plane];
     const int ox0 = (int)(tile % a.tiles_x[plane]) * SC_TW, oy0 = (int)(tile / a.tiles_x[plane]) * SC_TH;
     extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
     uint32_t* const T2 = reinterpret_cast<uint32_t*>(sc_smem);                 // [s_rows][SC_TW] pairs (p, p + 1) of H-filtered rows
@@ -543,6 +546,25 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) { scale_tile(a, blockIdx.x); }
+
+// One launch, two jobs that do not depend on each other: the scaler tiles of THIS tick's smaller layers first, then the chain tiles of the
+// PREVIOUS tick's composite (Graph defers the RGBA sink by one tick inside a batched run).  Two dependent launches of this size cost
+// their sum plus a launch gap each; inside one launch the chain's tiles start as the scaler's tiles drain and the two bodies -- one
+// VALU-heavy, one waiting for bytes -- share the CUs.
+// Block order: the scaler's tiles, then the chain's (K = 0).  MX_VIDEO_FUSED_ORDER=1 interleaves one chain tile with three scaler tiles
+// for the first 4 K blocks (K = min(chain tiles, scaler tiles / 3)) so that every CU holds both kinds at once -- measured slower.
+template <int MM>
+__global__ __launch_bounds__(256) void k_scale_then_chain_rgba(ScaleBatchArgs sa, ChainRgbaArgs ca, uint32_t n_scale_tiles, uint32_t n_chain_tiles, uint32_t chain_tiles_x, uint32_t K) {
+    const uint32_t b = blockIdx.x;
+    uint32_t st, ct; bool is_chain;
+    if (b < 4u * K) { const uint32_t g = b >> 2, r = b & 3u; is_chain = r == 0u; ct = g; st = 3u * g + (r - 1u); }
+    else { const uint32_t rest = b - 4u * K, sr = n_scale_tiles - 3u * K; is_chain = rest >= sr; st = 3u * K + rest; ct = K + (rest - sr); }
+    (void)n_chain_tiles;
+    if (!is_chain) { scale_tile(sa, st); return; }
+    chain_rgba_tile<MM, false>(ca, (int)(ct % chain_tiles_x), (int)(ct / chain_tiles_x));
+}
+
 __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {   // simple gather form, any ratio
     const ScalePlane p = a.p[blockIdx.z];
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -565,8 +587,10 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {
 
 // All planes of all queued scale jobs of a stream go out as ONE launch (grid.z = plane): these
 // kernels are latency-bound, so N jobs cost about as much as one.
-void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
-    uint32_t mw = 0, mh = 0, s_rows = 0, s_stride = 0;
+// tile plan of a batch for the tiled kernel: false = this batch needs the gather kernel
+static bool plan_scale_tiles(const ScaleBatchArgs& a, ScaleBatchArgs& b, uint32_t& total, size_t& lds, uint32_t& mw, uint32_t& mh) {
+    uint32_t s_rows = 0, s_stride = 0;
+    mw = mh = 0; total = 0; lds = 0;
     for (uint32_t i = 0; i < a.n; ++i) {
         const ScalePlane& p = a.p[i];
         mw = p.dw > mw ? p.dw : mw; mh = p.dh > mh ? p.dh : mh;
@@ -577,26 +601,55 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
         const uint32_t cols = (uint32_t)(((uint64_t)SC_TW * p.sw + p.dw - 1) / p.dw) + 6 + 15 + 4;   // 16-byte window start + the H pass's second dword
         s_rows = rows > s_rows ? rows : s_rows; s_stride = cols > s_stride ? cols : s_stride;
     }
-    if (!a.n || !mw || !mh) return;
+    if (!a.n || !mw || !mh) return false;
     s_stride = (s_stride + 15u) & ~15u;               // rows * stride stays a multiple of 16: T is read as int4
-    const size_t lds = (size_t)s_rows * s_stride + (size_t)s_rows * SC_TW * sizeof(int);   // both pair layouts of t' = one int per (row, column)
+    lds = (size_t)s_rows * s_stride + (size_t)s_rows * SC_TW * sizeof(int);   // both pair layouts of t' = one int per (row, column)
     static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
     bool lean = true;                                 // packed taps exist for every plane (ScaleTables::lean)
     for (uint32_t i = 0; i < a.n; ++i) if (a.p[i].dw && a.p[i].dh && (!a.p[i].hpk || !a.p[i].vpk)) lean = false;
-    if (lds <= 64 * 1024 && s_rows <= 48 && s_stride <= 256 && !force_simple && lean) {   // the staging slots of sc_stage<3>
-        ScaleBatchArgs b = a;
-        uint32_t total = 0;
-        for (uint32_t i = 0; i < a.n; ++i) {
-            b.tile_start[i] = total;
-            b.tiles_x[i] = (a.p[i].dw + SC_TW - 1) / SC_TW;
-            total += b.tiles_x[i] * ((a.p[i].dh + SC_TH - 1) / SC_TH);
-        }
-        for (uint32_t i = a.n; i <= MX_SCALE_BATCH_PLANES; ++i) { b.tile_start[i] = total; if (i < MX_SCALE_BATCH_PLANES) b.tiles_x[i] = 1; }
-        b.s_rows = s_rows; b.s_stride = s_stride;
+    if (!(lds <= 64 * 1024 && s_rows <= 48 && s_stride <= 256 && !force_simple && lean)) return false;   // the staging slots of sc_stage<3>
+    b = a;
+    for (uint32_t i = 0; i < a.n; ++i) {
+        b.tile_start[i] = total;
+        b.tiles_x[i] = (a.p[i].dw + SC_TW - 1) / SC_TW;
+        total += b.tiles_x[i] * ((a.p[i].dh + SC_TH - 1) / SC_TH);
+    }
+    for (uint32_t i = a.n; i <= MX_SCALE_BATCH_PLANES; ++i) { b.tile_start[i] = total; if (i < MX_SCALE_BATCH_PLANES) b.tiles_x[i] = 1; }
+    b.s_rows = s_rows; b.s_stride = s_stride;
+    return true;
+}
+// All planes of all queued scale jobs of a stream go out as ONE launch: these
+// kernels are latency-bound, so N jobs cost about as much as one.
+void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
+    ScaleBatchArgs b; uint32_t total, mw, mh; size_t lds;
+    if (plan_scale_tiles(a, b, total, lds, mw, mh)) {
         if (total) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3(total), dim3(256), lds, s, b);
-    } else {
+    } else if (a.n && mw && mh) {
         hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
     }
+}
+// the batch `sa` (may be empty) and then the chain `ca0` in one launch when both take their tiled forms; else one after the other
+void launch_scale_then_chain_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs& ca0, hipStream_t s) {
+    ScaleBatchArgs b; uint32_t total = 0, mw, mh; size_t lds = 0;
+    static const int no_fuse = env_int("MX_VIDEO_NO_LAUNCH_FUSION", 0);
+    if (no_fuse || !sa.n || ca0.n_scaled || !ca0.width || !ca0.height || !plan_scale_tiles(sa, b, total, lds, mw, mh) || !total) {
+        if (sa.n) launch_scale_batch(sa, s);
+        launch_fade_chain_rgba(ca0, s);
+        return;
+    }
+    ChainRgbaArgs a = ca0;
+    if (a.use_matrix) {
+        bool fits = true;
+        for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
+        a.use_matrix = fits ? 2 : 1;
+    }
+    const uint32_t tx = (a.width + 127) / 128, ty = (a.height + 31) / 32, nc = tx * ty;
+    static const int order = env_int("MX_VIDEO_FUSED_ORDER", 0);          // 0 scaler tiles first (default: 19.8 us per 1080p frame), 1 interleaved (26.6 us)
+    const uint32_t K = order ? std::min(nc, total / 3u) : 0u;
+    const dim3 grid(total + nc);
+    if (a.use_matrix == 2) hipLaunchKernelGGL(k_scale_then_chain_rgba<2>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
+    else if (a.use_matrix) hipLaunchKernelGGL(k_scale_then_chain_rgba<1>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
+    else hipLaunchKernelGGL(k_scale_then_chain_rgba<0>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
 }
 // Downscaling: the kernel widens with the scale factor (hn / vn taps, DESIGN.md "Scaler").  Two plain passes through
 // ScalePlane::tmp -- the H pass filters every source row once, the V pass reads vn of those rows per pixel -- instead of
