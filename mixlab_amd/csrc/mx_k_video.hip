@@ -548,19 +548,19 @@ __device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32
 
 __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) { scale_tile(a, blockIdx.x); }
 
-// One launch, two jobs that do not depend on each other: the scaler tiles of THIS tick's smaller layers first, then the chain tiles of the
+// One launch, two jobs that do not depend on each other: the scaler tiles of THIS tick's smaller layers and the chain tiles of the
 // PREVIOUS tick's composite (Graph defers the RGBA sink by one tick inside a batched run).  Two dependent launches of this size cost
 // their sum plus a launch gap each; inside one launch the chain's tiles start as the scaler's tiles drain and the two bodies -- one
 // VALU-heavy, one waiting for bytes -- share the CUs.
-// Block order: the scaler's tiles, then the chain's (K = 0).  MX_VIDEO_FUSED_ORDER=1 interleaves one chain tile with three scaler tiles
-// for the first 4 K blocks (K = min(chain tiles, scaler tiles / 3)) so that every CU holds both kinds at once -- measured slower.
+// Block order (measured, MX_VIDEO_FUSED_ORDER): the chain's tiles first -- they wait for their bytes while the scaler's tiles, dispatched
+// behind them, do arithmetic (18.5 us per 1080p frame); the scaler's first (K = 0): 19.5; one chain tile per three scaler tiles: 26.6.
 template <int MM>
 __global__ __launch_bounds__(256) void k_scale_then_chain_rgba(ScaleBatchArgs sa, ChainRgbaArgs ca, uint32_t n_scale_tiles, uint32_t n_chain_tiles, uint32_t chain_tiles_x, uint32_t K) {
     const uint32_t b = blockIdx.x;
     uint32_t st, ct; bool is_chain;
-    if (b < 4u * K) { const uint32_t g = b >> 2, r = b & 3u; is_chain = r == 0u; ct = g; st = 3u * g + (r - 1u); }
+    if (K != 0xffffffffu && b < 4u * K) { const uint32_t g = b >> 2, r = b & 3u; is_chain = r == 0u; ct = g; st = 3u * g + (r - 1u); }
+    else if (K == 0xffffffffu) { is_chain = b < n_chain_tiles; ct = b; st = b - n_chain_tiles; }   // the chain's tiles first
     else { const uint32_t rest = b - 4u * K, sr = n_scale_tiles - 3u * K; is_chain = rest >= sr; st = 3u * K + rest; ct = K + (rest - sr); }
-    (void)n_chain_tiles;
     if (!is_chain) { scale_tile(sa, st); return; }
     chain_rgba_tile<MM, false>(ca, (int)(ct % chain_tiles_x), (int)(ct / chain_tiles_x));
 }
@@ -644,8 +644,8 @@ void launch_scale_then_chain_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs&
         a.use_matrix = fits ? 2 : 1;
     }
     const uint32_t tx = (a.width + 127) / 128, ty = (a.height + 31) / 32, nc = tx * ty;
-    static const int order = env_int("MX_VIDEO_FUSED_ORDER", 0);          // 0 scaler tiles first (default: 19.8 us per 1080p frame), 1 interleaved (26.6 us)
-    const uint32_t K = order ? std::min(nc, total / 3u) : 0u;
+    static const int order = env_int("MX_VIDEO_FUSED_ORDER", 2);          // 2 chain tiles first (default: 18.5 us per 1080p frame), 0 scaler tiles first (19.5), 1 interleaved (26.6)
+    const uint32_t K = order == 2 ? 0xffffffffu : (order ? std::min(nc, total / 3u) : 0u);
     const dim3 grid(total + nc);
     if (a.use_matrix == 2) hipLaunchKernelGGL(k_scale_then_chain_rgba<2>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
     else if (a.use_matrix) hipLaunchKernelGGL(k_scale_then_chain_rgba<1>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
