@@ -25,4 +25,8 @@ for mode in "" "--hold-gates"; do
   timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d /tmp/sq$tag -- python $REPO/bench.py $COMMON $mode > /dev/null 2>&1
   python $REPO/tools/pmc_summary.py $(find /tmp/sq$tag -name "*counter_collection.csv" | head -1) > $OUT/pmc_sq_$tag.txt
 done
+# 5. the clock the chip sustains under the headline kernel: busy cycles per SE / duration (GRBM_GUI_ACTIVE: per XCD)
+timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d /tmp/clk -- python $REPO/bench.py $COMMON > /dev/null 2>&1
+python $REPO/tools/pmc_summary.py $(find /tmp/clk -name "*counter_collection.csv" | head -1) > $OUT/pmc_clock.txt
+cp $(find /tmp/clk -name "*kernel_trace.csv" | head -1) $OUT/pmc_clock_kernel_trace.csv 2>/dev/null
 ls -la $OUT
