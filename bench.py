@@ -305,7 +305,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
                 "shard": f"row bands: rank {rank} of {band_as[1] if band_as else world} composites luma rows [{row0}, {row0 + rows}) of every frame; the 720p layers enter as halo slices and are scaled to the band per tick (two-pass kernel)",
                 "workload": "8 layers (6x1080p + 2x720p yuv420p) -> 7 VideoMixer cross-fades (+2 bicubic letterbox scales) -> YUV->RGBA + 3x4 matrix, ONE stream over all ranks",
                 "frames": n_frames, "device_us_per_frame_rank0": round(dev_ms * 1e3, 2),
-                "note": "a 1080p frame is ~23 us of device work on one GPU: cut 8 ways a band is launch-sized, so this mode is for pictures far larger than 1080p; it is measured here to show the sharded job runs"}
+                "note": "a 1080p frame is ~18 us of device work on one GPU: cut 8 ways a band is launch-sized (~7 us), so this mode pays for pictures far larger than 1080p"}
     return {
         "metric": "1080p_composited_fps", "value": n_frames / dt, "unit": "frames/s", "scaling": "weak",
         "workload": "8 layers (6x1080p + 2x720p yuv420p) -> 7 VideoMixer cross-fades (+2 bicubic letterbox scales) -> YUV->RGBA + 3x4 matrix",
