@@ -775,7 +775,8 @@ def main():
                     "algorithmic_bytes_per_unit": "2M = 8 B per sample per strip (SURVEY 8d: EqThree channel-tick; source read + strip written as one float per frame)",
                     "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
-                    "limiter": ("f64 VALU issue: PMC (profiles/r02) 72 VALU instructions per sample with toggling gates (52 with held gates), HBM traffic = 1.17x algorithmic (the warm-up re-read); "
+                    "limiter": ("f64 VALU issue: PMC (profiles/r02) 79 VALU instructions per output sample with toggling gates (59 held), 59 of the hot loop's 63.5 per sample are the reference's own operations, "
+                                "VALU pipes 86 % busy at the 1.8 GHz the chip sustains under this kernel; HBM traffic = 1.16x algorithmic (the warm-up re-read); "
                                 "HBM is the roof only nominally" if dom == "eq_three" else "HBM"),
                     "per_kernel": per_kernel}
             if dom == "eq_three":
@@ -786,7 +787,10 @@ def main():
                 f64_ops = ops * local_strips * frames
                 roof["f64_valu"] = {"ops_per_sample_reference": ops, "ops_per_launch": f64_ops, "achieved_tops": round(f64_ops / (avg_ms * 1e-3) / 1e12, 2),
                                     "peak_tops": F64_VALU_PEAK_TOPS, "frac": round(f64_ops / (avg_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TOPS, 3),
-                                    "note": "f64 operations of the reference's arithmetic per second against the f64 VALU instruction rate (an FMA would count once; none is allowed here)"}
+                                    "note": "f64 operations of the reference's arithmetic per second against the f64 VALU instruction rate at the 2.4 GHz peak clock (an FMA would count once; none is allowed here)",
+                                    "sustained_clock": {"ghz": 1.82, "peak_tops_at_that_clock": round(F64_VALU_PEAK_TOPS * 1.82 / 2.4, 1),
+                                                        "frac_at_that_clock": round(f64_ops / (avg_ms * 1e-3) / 1e12 / (F64_VALU_PEAK_TOPS * 1.82 / 2.4), 3),
+                                                        "source": "profiles/r02/pmc_clock.txt: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled (2.15 GHz under the HBM-bound mixer); a committed measurement, not read live"}}
         moved = sum(moved_bytes(k) for k in k_ms)
         rep_sorted = sorted(rep_ms)
         out = {

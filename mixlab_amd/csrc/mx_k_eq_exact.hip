@@ -301,6 +301,10 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
     st.history[0] = s.h0; st.history[1] = s.h1; st.history[2] = s.h2;
     states[inst] = st;
 }
+// (A systolic variant -- the eight poles of an instance in eight lanes, one DPP shift per step, outputs eight at a time -- was built and
+// measured for the one-tick-per-submission regime: bit-exact, and no faster (70 vs 75 us for 1 024 strips x 800 samples): with one
+// wave per SIMD the step is a chain of five dependent f64 instructions plus LDS round trips, as long as the 52 independent-enough
+// instructions it replaces.  Removed)
 void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s) {
     if (!n || !r.frames) return;
     hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
