@@ -553,6 +553,8 @@ def main():
     ap.add_argument("--ticks-per-step", type=int, default=2048, help="ticks batched per submission (SURVEY 8d: throughput mode; 1 = real-time mode)")
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-fast", action="store_true", help="MX_FLAG_EQ_FAST: the time-parallel EqThree scan (<= 1 ULP, NOT bit-exact) instead of the exact default")
+    ap.add_argument("--overlap-tail", action="store_true",
+                    help="MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k on a second stream beside step k + 1's EqThree group (measured SLOWER: 6.53 vs 6.00 ms per step, DESIGN.md 5.2)")
     ap.add_argument("--no-held-leg", action="store_true", help="skip the held-gates comparison leg (counter passes: keep the dispatches of one kind)")
     ap.add_argument("--hold-gates", action="store_true", help="no per-tick gate schedule: every gate held for the whole run (the round-1 configuration)")
     ap.add_argument("--no-fuse", action="store_true", help="materialise every port (MX_FLAG_NO_FUSE): module-boundary traffic")
@@ -601,6 +603,9 @@ def main():
 
     stream = torch.cuda.Stream()
     flags = (abi.FLAG_EQ_FAST if args.eq_fast else 0) | (abi.FLAG_NO_FUSE if args.no_fuse else 0)
+    overlap = args.overlap_tail and not (world > 1 or args.force_combine)   # the exchange packs the buses on the compute stream: one stream there
+    if overlap:
+        flags |= abi.FLAG_OVERLAP_TAIL
     ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, local_strips, first, SR, want_trigs=True)
     g = ws.build(max_ticks_per_run=T, flags=flags, device=local_rank, stream=stream.cuda_stream)
 
@@ -803,6 +808,7 @@ def main():
                        "gates": "toggle every 30 ticks, phase k mod 60, applied between ticks inside the batch (mx_graph_schedule_params_batch)" if toggling else "held for the whole run",
                        "eq_mode": "time-parallel scan (<= 1 ULP, MX_FLAG_EQ_FAST)" if args.eq_fast else "exact order (default): speculative time-parallel kernel, verified bit-exact",
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
+                       "overlap": "MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k runs on a second stream beside step k + 1's EqThree group (strip ports double-buffered)" if overlap else "off",
                        "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else ""),
                        "rccl_ranks": dist.get_world_size() if use_dist else 0},
             "realtime_channels_equiv": value / 60.0,

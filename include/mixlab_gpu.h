@@ -97,6 +97,12 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
 #define MX_FLAG_EQ_EXACT 1u
 #define MX_FLAG_EQ_FAST 4u
 
+#define MX_FLAG_OVERLAP_TAIL 8u /* throughput mode for batched runs: the LAST launch group, when it is a Mixer bank, runs on a second
+                                  stream beside the NEXT run's earlier groups (an HBM-bound kernel beside a VALU-bound one); the ports it
+                                  reads are double-buffered and alternate per run.  Results are unchanged bit for bit; mx_graph_sync, every
+                                  read-back and mx_graph_run_ticks' own ordering cover both streams.  mx_graph_output_device_ptr of a port
+                                  the tail READS names the buffer of the last run only (it alternates); the tail's own outputs do not move.
+                                  A consumer on another stream of the tail's outputs orders itself after mx_graph_tail_stream(). */
 #define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
                                 [-> Amplifier [<- Envelope <- Trigger]] into the EQ kernel, a single-consumer Trigger into
                                 its Envelope, and stores an L == R stereo result that only Mixers read as one float per
@@ -130,6 +136,9 @@ void mx_graph_destroy(mx_graph* g);
 
 int mx_graph_samples_per_tick(const mx_graph* g, size_t* spt);                 /* SAMPLES_PER_TICK, src/engine.rs:55 */
 int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n); /* DFS order of src/engine.rs:421-457 */
+
+/* MX_FLAG_OVERLAP_TAIL: the stream the last launch group runs on (NULL when the mode is off or the graph has no such group). */
+int mx_graph_tail_stream(mx_graph* g, void** stream);
 
 /* ModuleT::update (src/module/mod.rs:16): replace one node's params between ticks. */
 int mx_graph_update_params(mx_graph* g, uint32_t node, const void* params, size_t params_len);

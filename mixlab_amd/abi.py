@@ -32,6 +32,7 @@ WAVE_ON, WAVE_OFF, WAVE_SINE, WAVE_SQUARE, WAVE_TRIANGLE, WAVE_SAW = range(6)
 FLAG_EQ_EXACT = 1   # the default (kept as a no-op name)
 FLAG_NO_FUSE = 2
 FLAG_EQ_FAST = 4    # time-parallel EqThree: <= 1 ULP, not bit-exact
+FLAG_OVERLAP_TAIL = 8   # the last Mixer bank runs on a second stream beside the next run's earlier groups
 
 
 class MixerChannelParams(C.Structure):
@@ -119,6 +120,7 @@ _proto("mx_graph_read_output", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_
 _proto("mx_graph_read_output_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_write_source_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_output_device_ptr", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+_proto("mx_graph_tail_stream", C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
 _proto("mx_graph_read_plotter", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int))
 _proto("mx_graph_profile_run", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
 _proto("mx_graph_profile_enable", C.c_int, C.c_void_p, C.c_int)
@@ -260,6 +262,12 @@ class Graph:
         n = C.c_size_t()
         check(lib.mx_graph_output_device_ptr(self._h, node, port, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def tail_stream(self):
+        """MX_FLAG_OVERLAP_TAIL: the stream the last launch group runs on (None when the mode is off)."""
+        p = C.c_void_p()
+        check(lib.mx_graph_tail_stream(self._h, C.byref(p)))
+        return p.value
 
     def read_plotter(self, node, tick_in_run):
         l = np.empty(self.spt, dtype=np.float32)

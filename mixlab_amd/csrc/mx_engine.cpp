@@ -116,6 +116,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         kind_ports(n.kind, n.params.size(), n.in_type, n.out_type);
         n.in_src.assign(n.in_type.size(), PortRef{});
         n.out_off.assign(n.out_type.size(), 0);
+        n.out_off2.assign(n.out_type.size(), SIZE_MAX);
     }
     for (size_t e = 0; e < n_edges; ++e) {
         const mx_edge& ed = edges[e];
@@ -282,13 +283,44 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         eq_tabs_.alloc(tabs.size() * sizeof(EqScanTab));
         hip_check(hipMemcpy(eq_tabs_.p, tabs.data(), tabs.size() * sizeof(EqScanTab), hipMemcpyHostToDevice), "hipMemcpy(eq tabs)");
     }
+    // MX_FLAG_OVERLAP_TAIL: the last launch group, if it is a Mixer bank alone on the highest level of an audio-only graph, may run beside
+    // the next run's earlier groups; every port it reads gets a second buffer (the next run must not overwrite what it is still reading)
+    if ((flags_ & MX_FLAG_OVERLAP_TAIL) && !has_video_ && groups_.size() >= 2 && groups_.back().kind == MX_KIND_MIXER &&
+        groups_[groups_.size() - 2].level < groups_.back().level && plotter_nodes_.empty()) {
+        bool ok = true;
+        std::vector<std::pair<uint32_t, uint32_t>> ports;
+        for (uint32_t id : groups_.back().nodes)
+            for (const PortRef& pr : nodes_[id].in_src) {
+                if (pr.node < 0) continue;
+                const Node& sn = nodes_[pr.node];
+                if (sn.kind == MX_KIND_SOURCE_MONO || sn.kind == MX_KIND_SOURCE_STEREO || sn.group == (int)groups_.size() - 1) { ok = false; break; }   // a source is rewritten by the caller while the tail may still read it
+                ports.push_back({(uint32_t)pr.node, pr.port});
+            }
+        if (ok) {
+            tail_gi_ = (int)groups_.size() - 1;
+            for (auto& pp : ports) nodes_[pp.first].out_off2[pp.second] = 0;   // marked; layout_slab gives it its offset
+            hip_check(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking), "hipStreamCreate(tail)");
+            hip_check(hipEventCreateWithFlags(&ev_head_done_, hipEventDisableTiming), "hipEventCreate");
+            for (auto& e : ev_tail_done_) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        }
+    }
     layout_slab();
     build_descriptors();
 }
 
+void Graph::wait_tail(int parity_or_all) {
+    for (int p = 0; p < 2; ++p)
+        if ((parity_or_all < 0 || parity_or_all == p) && tail_pending_[p]) {
+            hip_check(hipStreamWaitEvent(stream_, ev_tail_done_[p], 0), "hipStreamWaitEvent");
+            tail_pending_[p] = false;
+        }
+}
+
 Graph::~Graph() {
     flush_scales(stream_);
+    if (tail_stream_) (void)hipStreamSynchronize(tail_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (tail_stream_) { (void)hipStreamDestroy(tail_stream_); (void)hipEventDestroy(ev_head_done_); for (auto& e : ev_tail_done_) (void)hipEventDestroy(e); }
     for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); n.vsrc_ring.clear(); }
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
@@ -391,7 +423,11 @@ void Graph::layout_slab() {
     zero_off_ = bump(2 * zero_frames);
     for (Node& n : nodes_)
         for (size_t k = 0; k < n.out_type.size(); ++k)
-            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump((n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * (cap_frames_ * n.dom_num / n.dom_den + 1));
+        {
+            const size_t fl = (n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * (cap_frames_ * n.dom_num / n.dom_den + 1);
+            n.out_off[k] = n.out_elided[k] ? SIZE_MAX : bump(fl);
+            if (n.out_off2[k] != SIZE_MAX) n.out_off2[k] = n.out_elided[k] ? SIZE_MAX : bump(fl);
+        }
     slab_floats_ = off;
     slab_.alloc(off * sizeof(float));
     hip_check(hipMemsetAsync(slab_.p, 0, off * sizeof(float), stream_), "hipMemsetAsync(slab)");
@@ -404,7 +440,8 @@ float* Graph::out_ptr(const Node& n, uint32_t port) const {
     const size_t fpf = n.out_dup[port] ? 1 : floats_per_frame(n.out_type[port]);
     const size_t off = fpf * (run_off_frames_ * n.dom_num / n.dom_den);
     if (n.bound && port == 0) return const_cast<float*>(n.bound) + off;
-    return (float*)slab_.p + n.out_off[port] + off;
+    const bool alt = (building_alt_ || (parity_ && !building_main_)) && n.out_off2[port] != SIZE_MAX;
+    return (float*)slab_.p + (alt ? n.out_off2[port] : n.out_off[port]) + off;
 }
 const float* Graph::in_ptr(const Node& n, uint32_t port, bool null_if_disconnected) const {
     const PortRef pr = n.in_src[port];
@@ -414,7 +451,7 @@ const float* Graph::in_ptr(const Node& n, uint32_t port, bool null_if_disconnect
 
 static double db_to_linear(double db) { return std::pow(10.0, db / 20.0); }   // protocol/src/lib.rs:469-471
 
-void Graph::upload_group(Group& g) {
+void Graph::upload_group_one(Group& g) {
     const size_t n = g.nodes.size();
     auto up = [&](DevBuf& b, const void* src, size_t bytes) {
         if (b.bytes < bytes || !b.p) b.alloc(bytes);
@@ -428,7 +465,7 @@ void Graph::upload_group(Group& g) {
             mx_amplifier_params p; std::memcpy(&p, nd.params.data(), sizeof p);
             d[i] = AmpDesc{in_ptr(nd, 0, false), in_ptr(nd, 1, true), out_ptr(nd, 0), p.amplitude, p.mod_depth};
         }
-        up(g.desc, d.data(), n * sizeof(AmpDesc));
+        up(desc_buf(g), d.data(), n * sizeof(AmpDesc));
         break;
     }
     case MX_KIND_ENVELOPE: {
@@ -445,7 +482,7 @@ void Graph::upload_group(Group& g) {
                            EnvParams{p.attack_ms, 1.0 / p.attack_ms, 1.0 / p.decay_ms,
                                      p.sustain_amplitude, 1.0 - p.sustain_amplitude, 1.0 / p.release_ms}};
         }
-        up(g.desc, d.data(), n * sizeof(EnvDesc));
+        up(desc_buf(g), d.data(), n * sizeof(EnvDesc));
         if (!g.state.p) { g.state.alloc(n * sizeof(EnvState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EnvState)), "hipMemset"); }
         break;
     }
@@ -485,7 +522,7 @@ void Graph::upload_group(Group& g) {
             const int em = eq_epilogue_mode(e.epi, e.flags, e.ctl != nullptr);
             g.eq_mode = i == 0 ? em : (g.eq_mode == em ? em : -1);
         }
-        up(g.desc, d.data(), n * sizeof(EqDesc));
+        up(desc_buf(g), d.data(), n * sizeof(EqDesc));
         if (any_env) up(g.tick_desc, td.data(), n * sizeof(EnvTickDesc));
         if (!g.state.p) { g.state.alloc(n * sizeof(EqState)); hip_check(hipMemset(g.state.p, 0, n * sizeof(EqState)), "hipMemset"); }
         break;
@@ -499,14 +536,15 @@ void Graph::upload_group(Group& g) {
             const double freq_mid = p.freq_lo + freq_amp;            // fm_sine.rs:43
             d[i] = FmDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), freq_mid, freq_amp};
         }
-        up(g.desc, d.data(), n * sizeof(FmDesc));
+        up(desc_buf(g), d.data(), n * sizeof(FmDesc));
         break;
     }
     case MX_KIND_MIXER: {
         size_t total = 0;
         for (uint32_t id : g.nodes) total += nodes_[id].in_type.size();
         std::vector<MixChan> ch(total ? total : 1);
-        if (g.extra.bytes < ch.size() * sizeof(MixChan) || !g.extra.p) g.extra.alloc(ch.size() * sizeof(MixChan));
+        DevBuf& xb = extra_buf(g);
+        if (xb.bytes < ch.size() * sizeof(MixChan) || !xb.p) xb.alloc(ch.size() * sizeof(MixChan));
         std::vector<MixDesc> d(n);
         size_t o = 0, n_dup = 0;
         for (size_t i = 0; i < n; ++i) {
@@ -520,14 +558,14 @@ void Graph::upload_group(Group& g) {
                 n_dup += dup;
                 ch[o + c] = MixChan{in_ptr(nd, (uint32_t)c, false), cp.fader * db_to_linear(cp.gain_db), cp.cue ? 1u : 0u, dup};  // mixer.rs:59
             }
-            d[i] = MixDesc{(const MixChan*)g.extra.p + o, (uint32_t)nch, 0u, out_ptr(nd, 0), out_ptr(nd, 1)};
+            d[i] = MixDesc{(const MixChan*)xb.p + o, (uint32_t)nch, 0u, out_ptr(nd, 0), out_ptr(nd, 1)};
             o += nch;
         }
         g.dup_mode = n_dup == 0 ? 0 : (n_dup == total ? 1 : 2);
         g.max_taps = 0;
         for (uint32_t id : g.nodes) g.max_taps = std::max<uint32_t>(g.max_taps, (uint32_t)nodes_[id].in_type.size());   // Mixer: most channels
-        hip_check(hipMemcpy(g.extra.p, ch.data(), ch.size() * sizeof(MixChan), hipMemcpyHostToDevice), "hipMemcpy(mixchan)");
-        up(g.desc, d.data(), n * sizeof(MixDesc));
+        hip_check(hipMemcpy(xb.p, ch.data(), ch.size() * sizeof(MixChan), hipMemcpyHostToDevice), "hipMemcpy(mixchan)");
+        up(desc_buf(g), d.data(), n * sizeof(MixDesc));
         break;
     }
     case MX_KIND_OSCILLATOR: {
@@ -537,19 +575,19 @@ void Graph::upload_group(Group& g) {
             mx_oscillator_params p; std::memcpy(&p, nd.params.data(), sizeof p);
             d[i] = OscDesc{out_ptr(nd, 0), out_ptr(nd, 1), p.freq, p.waveform, 0u};
         }
-        up(g.desc, d.data(), n * sizeof(OscDesc));
+        up(desc_buf(g), d.data(), n * sizeof(OscDesc));
         break;
     }
     case MX_KIND_STEREO_PANNER: {
         std::vector<PanDesc> d(n);
         for (size_t i = 0; i < n; ++i) { const Node& nd = nodes_[g.nodes[i]]; d[i] = PanDesc{in_ptr(nd, 0, false), in_ptr(nd, 1, false), out_ptr(nd, 0)}; }
-        up(g.desc, d.data(), n * sizeof(PanDesc));
+        up(desc_buf(g), d.data(), n * sizeof(PanDesc));
         break;
     }
     case MX_KIND_STEREO_SPLITTER: {
         std::vector<SplitDesc> d(n);
         for (size_t i = 0; i < n; ++i) { const Node& nd = nodes_[g.nodes[i]]; d[i] = SplitDesc{in_ptr(nd, 0, false), out_ptr(nd, 0), out_ptr(nd, 1)}; }
-        up(g.desc, d.data(), n * sizeof(SplitDesc));
+        up(desc_buf(g), d.data(), n * sizeof(SplitDesc));
         break;
     }
     case MX_KIND_TRIGGER: {
@@ -560,7 +598,7 @@ void Graph::upload_group(Group& g) {
             d[i] = TrigDesc{out_ptr(nd, 0), p.gate_open ? 1.0f : 0.0f, 0u};   // trigger.rs:38-41
         }
         g.has_gates = true;
-        up(g.desc, d.data(), n * sizeof(TrigDesc));
+        up(desc_buf(g), d.data(), n * sizeof(TrigDesc));
         break;
     }
     case MX_KIND_FIR: {
@@ -579,7 +617,7 @@ void Graph::upload_group(Group& g) {
             o += h.n_taps;
         }
         hip_check(hipMemcpy(g.extra.p, taps.data(), tt * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(fir taps)");
-        up(g.desc, d.data(), n * sizeof(FirDesc));
+        up(desc_buf(g), d.data(), n * sizeof(FirDesc));
         break;
     }
     case MX_KIND_RESAMPLE: {
@@ -605,10 +643,21 @@ void Graph::upload_group(Group& g) {
             o += cnt; oh += h.taps_per_phase;
         }
         hip_check(hipMemcpy(g.extra.p, taps.data(), tt * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(resample taps)");
-        up(g.desc, d.data(), n * sizeof(ResampleDesc));
+        up(desc_buf(g), d.data(), n * sizeof(ResampleDesc));
         break;
     }
     default: break;  // PLOTTER (jobs built per run), SOURCE_* (no launch)
+    }
+}
+
+void Graph::upload_group(Group& g) {
+    building_main_ = true;
+    upload_group_one(g);
+    building_main_ = false;
+    if (tail_gi_ >= 0) {   // the same descriptors with the double-buffered ports at their second buffer
+        building_alt_ = true;
+        upload_group_one(g);
+        building_alt_ = false;
     }
 }
 
@@ -764,7 +813,11 @@ void Graph::set_input_enabled(uint32_t node, uint32_t port, bool enabled) {
     if (n.group >= 0) upload_group(groups_[n.group]);
 }
 
-void Graph::sync() { flush_scales(stream_); hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+void Graph::sync() {
+    flush_scales(stream_);
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    if (tail_stream_) { hip_check(hipStreamSynchronize(tail_stream_), "hipStreamSynchronize"); tail_pending_[0] = tail_pending_[1] = false; }
+}
 
 void Graph::ensure_capacity(size_t frames) {
     if (frames <= cap_frames_) return;
@@ -838,6 +891,11 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
 
     const bool prof = ms_by_kind != nullptr || prof_on_;
     prof_this_run_ = prof;
+    // MX_FLAG_OVERLAP_TAIL: an uncut run alternates the double-buffered ports and leaves its tail on the second stream; before its
+    // earlier groups overwrite a buffer, the tail that last read THAT buffer (two runs ago) must be done -- not the previous run's
+    overlap_this_run_ = tail_gi_ >= 0 && cuts.empty();
+    if (overlap_this_run_) { parity_ ^= 1u; wait_tail((int)parity_); }
+    else if (tail_gi_ >= 0) wait_tail(-1);
     if (cuts.empty()) {
         run_span(t0, fpc, 0, n_calls, n_calls);
     } else {
@@ -899,8 +957,8 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         const size_t gfpc = fpc * g.dom_num / g.dom_den;    // ... per tick
         const GateBits gates{(const uint32_t*)g.gates.p, g.gate_words, call_off};
         switch (g.kind) {
-        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)g.desc.p, n, gf, stream_); break;
-        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)g.desc.p, (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_); break;
+        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)desc_of(g), n, gf, stream_); break;
+        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)desc_of(g), (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_); break;
         case MX_KIND_EQ_THREE: {
             EqRun r{gf, gfpc, n_calls, 0u, t0, sample_rate_, 1.0 / sample_rate_, lo_f_, hi_f_, nullptr};
             if (g.state2.p) {   // Envelopes folded into the epilogue: their state entering every tick of this span
@@ -915,9 +973,9 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                     const size_t need = eq_spec_scratch_bytes(n, plan);
                     if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
                     if (!eq_stats_.p) { eq_stats_.alloc(2 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 2 * sizeof(uint64_t)), "hipMemset"); }
-                    launch_eq_three_spec((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
+                    launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
                 } else {
-                    launch_eq_three_exact((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, stream_);
+                    launch_eq_three_exact((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, stream_);
                 }
             } else {
                 EqSplit sp{1u, 5u, 0u, 0u, gf, gf, nullptr, nullptr, nullptr};
@@ -931,19 +989,31 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                     toeplitz_pow((long double)lo_f_, sp.span, pp.lo);
                     toeplitz_pow((long double)hi_f_, sp.span, pp.hi);
                 }
-                launch_eq_three_scan((const EqDesc*)g.desc.p, (EqState*)g.state.p, n, r, (const EqScanTab*)eq_tabs_.p, sp, pp, stream_);
+                launch_eq_three_scan((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, (const EqScanTab*)eq_tabs_.p, sp, pp, stream_);
             }
             break;
         }
-        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
-        case MX_KIND_MIXER: launch_mixer((const MixDesc*)g.desc.p, n, g.max_taps /* = most channels */, gf, g.dup_mode, stream_); break;
-        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)g.desc.p, n, gf, t0, sample_rate_, stream_); break;
-        case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)g.desc.p, n, gf, stream_); break;
-        case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)g.desc.p, n, gf, stream_); break;
-        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)g.desc.p, n, gf, gfpc, &gates, stream_); break;
-        case MX_KIND_FIR: launch_fir((const FirDesc*)g.desc.p, n, g.max_taps, gf, stream_); break;
+        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_); break;
+        case MX_KIND_MIXER:
+            if (overlap_this_run_ && (int)gi == tail_gi_) {   // beside the next run's earlier groups (HBM-bound beside VALU-bound)
+                hip_check(hipEventRecord(ev_head_done_, stream_), "hipEventRecord");
+                hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
+                launch_mixer((const MixDesc*)desc_of(g), n, g.max_taps, gf, g.dup_mode, tail_stream_);
+                hip_check(hipEventRecord(ev_tail_done_[parity_], tail_stream_), "hipEventRecord");
+                tail_pending_[parity_] = true;
+                if (prof) hip_check(hipEventRecord(ev[gi + 1], tail_stream_), "hipEventRecord");
+                ++gi;
+                continue;
+            }
+            launch_mixer((const MixDesc*)desc_of(g), n, g.max_taps /* = most channels */, gf, g.dup_mode, stream_);
+            break;
+        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_); break;
+        case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)desc_of(g), n, gf, stream_); break;
+        case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)desc_of(g), n, gf, stream_); break;
+        case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)desc_of(g), n, gf, gfpc, &gates, stream_); break;
+        case MX_KIND_FIR: launch_fir((const FirDesc*)desc_of(g), n, g.max_taps, gf, stream_); break;
         case MX_KIND_RESAMPLE:
-            launch_resample((const ResampleDesc*)g.desc.p, n, g.max_taps, g.rs_tab_doubles, g.rs_win_frames, frames * g.in_dom_num / g.in_dom_den, gf,
+            launch_resample((const ResampleDesc*)desc_of(g), n, g.max_taps, g.rs_tab_doubles, g.rs_win_frames, frames * g.in_dom_num / g.in_dom_den, gf,
                             t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_);
             break;
         case MX_KIND_PLOTTER: {
@@ -1127,6 +1197,7 @@ Graph::Perf Graph::performance_info(uint64_t* module_us, size_t cap) {
 }
 
 void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames) {
+    wait_tail(-1);
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
     if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
@@ -1145,6 +1216,7 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
 }
 
 void Graph::read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t frames) {
+    wait_tail(-1);
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
     if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");

@@ -27,6 +27,7 @@ struct Node {
     std::vector<PortRef> in_src;              // workspace.connections (back-edges already cut)
     std::vector<PortRef> in_src_orig;         // in_src before set_input_enabled() toggles
     std::vector<size_t> out_off;              // float offset of each output port in the slab
+    std::vector<size_t> out_off2;             // MX_FLAG_OVERLAP_TAIL: second buffer of a port the tail group reads (SIZE_MAX: none)
     const float* bound = nullptr;             // SOURCE_*: caller-bound device buffer
     int level = 0;
     uint32_t dom_num = 1, dom_den = 1;        // sample-rate domain of the OUTPUT ports relative to the graph's rate (Resample changes it)
@@ -69,6 +70,7 @@ struct Group {
     uint32_t rs_tab_doubles = 0, rs_win_frames = 0;   // Resample: LDS plan of the staged kernel (largest table / input window of the group)
     std::vector<uint32_t> nodes;
     DevBuf desc;     // kind-specific descriptor array
+    DevBuf desc_alt, extra_alt;   // MX_FLAG_OVERLAP_TAIL: the same for the other parity of the double-buffered ports (extra_alt: Mixer only)
     DevBuf state;    // EnvState[] / EqState[]
     DevBuf extra;    // Mixer: MixChan arrays
     DevBuf state2;   // EqThree: EnvState[] of Envelopes folded into the epilogue
@@ -94,6 +96,7 @@ public:
     size_t cap_frames() const { return cap_frames_; }
     const std::vector<uint32_t>& run_order() const { return order_; }
     hipStream_t stream() const { return stream_; }
+    hipStream_t tail_stream() const { return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL
     size_t n_nodes() const { return nodes_.size(); }
     bool eq_exact() const { return (flags_ & MX_FLAG_EQ_EXACT) || !(flags_ & MX_FLAG_EQ_FAST); }   // the default is the reference's order
     const Node& node(uint32_t i) const { return nodes_.at(i); }
@@ -138,7 +141,8 @@ private:
     void plan_fusion();
     void layout_slab();
     void build_descriptors();
-    void upload_group(Group& g);
+    void upload_group(Group& g);          // descriptors of one group (both parities under MX_FLAG_OVERLAP_TAIL)
+    void upload_group_one(Group& g);
     void run_video_tick(uint64_t t);
     void launch_pending_rgba(Node& n, bool with_queued_scales);
     // one launch sequence over ticks [call_off, call_off + n_calls) of the current run
@@ -163,6 +167,20 @@ private:
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
     DevBuf slab_;
+    // MX_FLAG_OVERLAP_TAIL (see mixlab_gpu.h): the last launch group on a second stream, beside the next run's earlier groups
+    int tail_gi_ = -1;                    // index of that group in groups_, -1 = mode off
+    uint32_t parity_ = 0;                 // which buffer of the double-buffered ports the current / last run uses
+    bool building_alt_ = false;           // upload_group is filling desc_alt / extra_alt
+    bool building_main_ = false;          // ... desc / extra (first buffers whatever the current parity is)
+    hipStream_t tail_stream_ = nullptr;
+    hipEvent_t ev_head_done_ = nullptr;   // recorded on stream_ when a run's earlier groups are queued
+    hipEvent_t ev_tail_done_[2] = {nullptr, nullptr};   // recorded on tail_stream_ after the tail of a run (by parity)
+    bool tail_pending_[2] = {false, false};
+    bool overlap_this_run_ = false;
+    void wait_tail(int parity_or_all);    // stream_ waits for the tail launches that have not been waited for (-1: both)
+    DevBuf& desc_buf(Group& g) { return building_alt_ ? g.desc_alt : g.desc; }
+    DevBuf& extra_buf(Group& g) { return (building_alt_ && g.kind == MX_KIND_MIXER) ? g.extra_alt : g.extra; }
+    const void* desc_of(const Group& g) const { return (parity_ && g.desc_alt.p) ? g.desc_alt.p : g.desc.p; }
     size_t run_off_frames_ = 0;   // base-rate frames before the span being launched (a run cut at scheduled parameter updates)
     uint64_t gates_version_ = 0;  // bumped whenever a Trigger's params or schedule change
     DevBuf eq_stats_;             // [2] u64 counters of the speculative EqThree kernel

@@ -1,0 +1,98 @@
+"""MX_FLAG_OVERLAP_TAIL: the last Mixer bank of a batched run executes on a second stream beside the NEXT run's earlier groups; the
+ports it reads are double-buffered and alternate per run.  Nothing observable may change: every run's buses are the oracle's bit for
+bit, whether runs are queued back to back (really overlapping) or read back one by one, fused or not, and across a run that is cut
+by a scheduled non-Trigger update (which falls back to one stream)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from mixlab_amd import abi
+from test_gpu_audio_parity import assert_bit_exact, strips
+from test_gpu_schedule import gate_open, schedule_gates
+
+pytestmark = pytest.mark.gpu
+
+SR, SPT = 48000, 800
+
+
+def oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch, eq_update=None):
+    og = oracle.OracleGraph(ws)
+    out = []
+    for r in range(n_runs):
+        m, c = [], []
+        for kk in range(batch):
+            tick = r * batch + kk
+            if eq_update and eq_update[0] == tick:
+                og.update_params(eq_update[1], eq_update[2])
+            for k, tr in enumerate(trigs):
+                og.update_params(tr, abi.TriggerParams(1 if gate_open(tick, k) else 0))
+            for k, s in enumerate(srcs):
+                og.set_source(s, noise[k][tick * SPT:(tick + 1) * SPT])
+            og.run_tick(tick)
+            m.append(og.output(mix, 0).copy()); c.append(og.output(mix, 1).copy())
+        out.append((np.concatenate(m), np.concatenate(c)))
+    return out
+
+
+@pytest.mark.parametrize("flags", [0, abi.FLAG_NO_FUSE], ids=["fused", "unfused"])
+@pytest.mark.parametrize("readback", ["every-run", "last-run-only"])
+def test_overlapped_tail_runs_are_the_oracles(flags, readback):
+    n_strips, batch, n_runs = 24, 16, 6
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch)
+    g = ws.build(max_ticks_per_run=batch, flags=flags | abi.FLAG_OVERLAP_TAIL)
+    assert g.tail_stream() is not None
+    plain = ws.build(max_ticks_per_run=batch, flags=flags)
+    assert plain.tail_stream() is None
+    amp = mix + 6                                    # strip 0's Amplifier: a port the tail reads
+    seen = set()
+    for r in range(n_runs):
+        schedule_gates(g, trigs, r * batch, batch)
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+        g.run_ticks(r * batch, batch)
+        if flags & abi.FLAG_NO_FUSE:                 # (fused, the port is stored one float per frame and has no public pointer)
+            seen.add(g.output_device_ptr(amp, 0)[0])
+        if readback == "every-run" or r == n_runs - 1:
+            assert_bit_exact(g.read_output(mix, 0, batch, True), want[r][0], f"master of run {r}")
+            assert_bit_exact(g.read_output(mix, 1, batch, True), want[r][1], f"cue of run {r}")
+    assert len(seen) in (0, 2)                       # the strip ports alternate between two buffers
+
+
+def test_a_run_cut_by_a_scheduled_update_between_overlapped_runs():
+    n_strips, batch, n_runs = 12, 16, 5
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    eq0 = mix + 4                                    # strip 0 EqThree (test_gpu_audio_parity.strips layout)
+    assert ws.nodes[eq0][0] == abi.KIND_EQ_THREE
+    new_eq = abi.EqThreeParams(-6.0, 3.0, 1.5)
+    cut_tick = 2 * batch + 5                         # inside run 2
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch, eq_update=(cut_tick, eq0, new_eq))
+    g = ws.build(max_ticks_per_run=batch, flags=abi.FLAG_OVERLAP_TAIL)
+    for r in range(n_runs):
+        schedule_gates(g, trigs, r * batch, batch)
+        if r == 2:
+            g.schedule_params(eq0, cut_tick - r * batch, new_eq)
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+        g.run_ticks(r * batch, batch)
+        if r in (1, 2, 4):
+            assert_bit_exact(g.read_output(mix, 0, batch, True), want[r][0], f"master of run {r}")
+            assert_bit_exact(g.read_output(mix, 1, batch, True), want[r][1], f"cue of run {r}")
+
+
+def test_mode_is_refused_silently_where_it_does_not_apply():
+    # a Mixer that reads a source directly, or no Mixer at the end: the flag is accepted and the graph runs on one stream
+    from mixlab_amd.workspace import Workspace
+    ws = Workspace(SR, 60)
+    s = ws.source_stereo(); m = ws.mixer([(0.0, 1.0, False)])
+    ws.connect(s, 0, m, 0)
+    g = ws.build(max_ticks_per_run=4, flags=abi.FLAG_OVERLAP_TAIL)
+    assert g.tail_stream() is None
+    x = synth.noise(3, 4 * 2 * SPT)
+    g.write_source(s, x, 4); g.run_ticks(0, 4)
+    assert_bit_exact(g.read_output(m, 0, 4, True), x, "unity mixer")
