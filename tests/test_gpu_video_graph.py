@@ -275,3 +275,52 @@ def test_row_band_job_with_band_scaling_sources_in_one_submission(full, small, w
         g.run_ticks(0, n_ticks)
         got_rgba[row0:row0 + rows] = video.graph_rgba_output(g, rgba)
     assert np.array_equal(got_rgba, want_rgba)
+
+
+def test_two_rgba_sinks_missing_frames_and_a_size_change_inside_one_submission():
+    """The RGBA sink of a batched run is launched one tick late, together with the next tick's scaler tiles.  Two sinks on
+    two cascades, a tick on which one cascade has no frame at all, and a sink whose picture grows mid-run (its buffer is reallocated
+    with a chain still pending): after the run each sink holds what the in-order schedule gives -- its last tick's picture."""
+    ws = Workspace(44100, 60)
+    sa, sb, sc = ws.source_video(), ws.source_video(), ws.source_video()
+    m1 = ws.video_mixer(a=0, b=1, fader=0.6); ws.connect(sa, 0, m1, 0); ws.connect(sb, 0, m1, 1)
+    m2 = ws.video_mixer(a=0, b=1, fader=0.3); ws.connect(sc, 0, m2, 0); ws.connect(sb, 0, m2, 1)
+    r1, r2 = ws.video_to_rgba(MATRIX), ws.video_to_rgba(None)
+    ws.connect(m1, 0, r1, 0); ws.connect(m2, 0, r2, 0)
+    g = ws.build(max_ticks_per_run=8)
+    o1, o2 = ov.OracleVideoMixer(a=0, b=1, fader=0.6), ov.OracleVideoMixer(a=0, b=1, fader=0.3)
+    big = [ov.HostFrame(320, 180).fill(k, seed=21) for k in range(4)]
+    small = [ov.HostFrame(212, 120).fill(k, seed=22) for k in range(4)]
+    huge = [ov.HostFrame(640, 360).fill(k, seed=23) for k in range(2)]
+    keep = [upload(f) for f in big + small + huge]
+    dbig, dsmall, dhuge = keep[:4], keep[4:8], keep[8:]
+    # sa: a new 320x180 frame every tick; sb: a 212x120 frame every tick (scaled into both cascades); sc: short-lived frames that
+    # leave gaps (cascade 2 has no picture on some ticks), and a 640x360 one from tick 5 on (sink 2's buffer grows)
+    video.graph_set_video_source_ring(g, sa, dbig, dur=(1, 60), off=(0, 1))
+    video.graph_set_video_source_ring(g, sb, dsmall, dur=(1, 60), off=(0, 1))
+    T = 8
+    want1 = want2 = None
+    # sc is driven per run segment: ticks 0-1 small single shots, 2-4 nothing (sb alone keeps cascade 2 alive), 5-7 the huge ring
+    def oracle_tick(t, c_frame):
+        nonlocal want1, want2
+        a, b = big[t % 4], small[t % 4]
+        out1 = o1.run_tick(t * 735, [(a, (1, 60), (0, 1)), (b, (1, 60), (0, 1)), None, None])
+        out2 = o2.run_tick(t * 735, [(c_frame, (1, 60), (0, 1)) if c_frame is not None else None, (b, (1, 60), (0, 1)), None, None])
+        want1, want2 = out1, out2
+    video.graph_set_video_source(g, sc, dsmall[0], dur=(1, 60), off=(0, 1), repeat=True)
+    g.run_ticks(0, 2)
+    for t in (0, 1):
+        oracle_tick(t, small[0])
+    video.graph_set_video_source(g, sc, None, dur=(1, 60), off=(0, 1), repeat=False)
+    g.run_ticks(2, 3)
+    for t in (2, 3, 4):
+        oracle_tick(t, None)
+    assert np.array_equal(video.graph_rgba_output(g, r2), ov.to_rgba(want2, None))
+    video.graph_set_video_source_ring(g, sc, dhuge, dur=(1, 60), off=(0, 1))
+    g.run_ticks(5, 3)
+    for t in (5, 6, 7):
+        oracle_tick(t, huge[(t - 5) % 2])
+    got1, got2 = video.graph_rgba_output(g, r1), video.graph_rgba_output(g, r2)
+    assert got2.shape[:2] == (360, 640)
+    assert np.array_equal(got1, ov.to_rgba(want1, MATRIX))
+    assert np.array_equal(got2, ov.to_rgba(want2, None))
