@@ -324,3 +324,64 @@ def test_two_rgba_sinks_missing_frames_and_a_size_change_inside_one_submission()
     assert got2.shape[:2] == (360, 640)
     assert np.array_equal(got1, ov.to_rgba(want1, MATRIX))
     assert np.array_equal(got2, ov.to_rgba(want2, None))
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("inline", ["0", "1"], ids=["scaler-kernel", "resampled-in-chain"])
+def test_random_cascade_scenarios_in_random_batches(seed, inline, monkeypatch):
+    """Seeded scenarios over a 4-layer cascade: every layer gets frames of random size / pixel format / life time at random ticks (with
+    gaps, re-targets and downscales), the graph is run in random batches of 1-4 ticks, and at the end of every batch the RGBA sink and
+    the program frame must be the oracle cascade's of that tick (stored frames, expiry, lazy frames, alternating scaler outputs and the
+    deferred sink launch all interact here)."""
+    monkeypatch.setenv("MX_SCALE_INLINE", inline)
+    rng = np.random.default_rng(1000 + seed)
+    n_layers, n_ticks = 4, 18
+    sizes = [(320, 180), (212, 120), (160, 120), (320, 100), (100, 180), (640, 360), (322, 182)]
+    ws, srcs, mixers, rgba = cascade([(320, 180)] * n_layers, None)
+    g = ws.build(max_ticks_per_run=4)
+    oms = [ov.OracleVideoMixer(a=0, b=1, fader=FADERS[k]) for k in range(n_layers - 1)]
+    # plan[tick][layer] = HostFrame or absent; the first tick always has layer 0
+    plan = []
+    for t in range(n_ticks):
+        row = {}
+        for k in range(n_layers):
+            if (t == 0 and k == 0) or rng.random() < 0.45:
+                w, h = sizes[int(rng.integers(len(sizes)))]
+                fmt = int(rng.integers(3)) if (w % 2 == 0 and h % 2 == 0) else 0
+                row[k] = (ov.HostFrame(w, h, fmt).fill(k, seed=int(rng.integers(1 << 12))), int(rng.integers(1, 4)))
+        plan.append(row)
+    keep = []
+    t = 0
+    while t < n_ticks:
+        batch = int(min(rng.integers(1, 5), n_ticks - t))
+        # a batch delivers at most one new frame per layer (on its first tick): later plan rows inside the batch are moved to its start
+        new = {}
+        for tt in range(t, t + batch):
+            for k, v in plan[tt].items():
+                new.setdefault(k, v)
+        for k in range(n_layers):
+            if k in new:
+                hf, life = new[k]
+                d = video.DFrame(hf.w, hf.h, fmt=hf.fmt).upload(*hf.visible()); keep.append(d)
+                video.graph_set_video_source(g, srcs[k], d, dur=(life, 60), off=(0, 1), repeat=False)
+            else:
+                video.graph_set_video_source(g, srcs[k], None, dur=(1, 60), off=(0, 1), repeat=False)
+        g.run_ticks(t, batch)
+        want = None
+        for tt in range(t, t + batch):
+            first = tt == t
+            prev = (new[0][0], (new[0][1], 60), (0, 1)) if (first and 0 in new) else None
+            for k in range(n_layers - 1):
+                b = (new[k + 1][0], (new[k + 1][1], 60), (0, 1)) if (first and (k + 1) in new) else None
+                out = oms[k].run_tick(tt * 735, [prev, b, None, None])
+                prev = (out, (1, 60), (0, 1)) if out is not None else None
+            want = prev[0] if prev else None
+        got = video.graph_rgba_output(g, rgba)
+        if want is None:
+            assert got is None, f"tick {t + batch - 1}: a picture where the oracle has none"
+        else:
+            assert got is not None and np.array_equal(got, ov.to_rgba(want, None)), f"batch ending at tick {t + batch - 1}: RGBA differs"
+            prog = video.graph_video_output(g, mixers[-1], 0)
+            for p, (a, b) in enumerate(zip(prog.download(), want.visible())):
+                assert np.array_equal(a, b), f"batch ending at tick {t + batch - 1}: plane {p}"
+        t += batch
