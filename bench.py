@@ -305,7 +305,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
                 "shard": f"row bands: rank {rank} of {band_as[1] if band_as else world} composites luma rows [{row0}, {row0 + rows}) of every frame; the 720p layers enter as halo slices and are scaled to the band per tick (two-pass kernel)",
                 "workload": "8 layers (6x1080p + 2x720p yuv420p) -> 7 VideoMixer cross-fades (+2 bicubic letterbox scales) -> YUV->RGBA + 3x4 matrix, ONE stream over all ranks",
                 "frames": n_frames, "device_us_per_frame_rank0": round(dev_ms * 1e3, 2),
-                "note": "a 1080p frame is ~18 us of device work on one GPU: cut 8 ways a band is launch-sized (~7 us), so this mode pays for pictures far larger than 1080p"}
+                "note": "a 1080p frame is ~15 us of device work on one GPU: cut 8 ways a band is launch-sized (~4.5 us), so this mode pays for pictures far larger than 1080p"}
     return {
         "metric": "1080p_composited_fps", "value": n_frames / dt, "unit": "frames/s", "scaling": "weak",
         "workload": "8 layers (6x1080p + 2x720p yuv420p) -> 7 VideoMixer cross-fades (+2 bicubic letterbox scales) -> YUV->RGBA + 3x4 matrix",
@@ -315,7 +315,8 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
         "moved_bytes_per_frame": moved_scaler + moved_chain, "module_boundary_bytes_per_frame": alg,
         "hbm_frac_moved_bytes_device": round((moved_scaler + moved_chain) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
         "hbm_frac_moved_bytes_wall": round((moved_scaler + moved_chain) * n_frames / world / dt / 1e9 / HBM_PEAK_GBS, 4),
-        "per_kernel_moved_bytes": {"k_scale_bicubic_tiled (2 layers, one launch)": moved_scaler, "k_fade_chain_rgba": moved_chain,
+        "per_kernel_moved_bytes": {"scaler tiles (2 layers)": moved_scaler, "chain tiles": moved_chain,
+                                   "launches": "k_scale_then_chain_rgba: the chains of two ticks and the scaler tiles of the two after them in ONE launch (DESIGN.md 5.3)",
                                    "note": "per-kernel durations and PMC traffic: profiles/r02 (the hipEvents here bracket the whole per-tick video section)"},
     }
 

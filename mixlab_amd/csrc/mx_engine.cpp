@@ -1045,7 +1045,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
     if (has_video_) {
         for (uint32_t c = 0; c < n_calls; ++c) run_video_tick(t0 + (uint64_t)c * fpc);
         flush_scales(stream_);
-        for (uint32_t id : video_order_) if (nodes_[id].rgba_pending) launch_pending_rgba(nodes_[id], false);   // the last tick's sinks
+        for (uint32_t id : video_order_) { Node& vn = nodes_[id]; if (!vn.rgba_pending.empty()) launch_pending_rgba(vn, vn.rgba_pending.size(), false); vn.rgba_calls = 0; }   // the last ticks' sinks
     }
     if (prof && has_video_) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
     if (prof) prof_runs_.push_back(std::move(ev));
@@ -1318,35 +1318,47 @@ void Graph::run_video_tick(uint64_t t) {
         case MX_KIND_VIDEO_TO_RGBA: {
             const PortRef pr = n.in_src[0];
             n.rgba_w = n.rgba_h = 0;
-            if (pr.node < 0) break;
-            const Node::VOut& v = nodes_[pr.node].vout[pr.port];
-            if (!v.frame) break;
-            DFrame* d = v.frame.f;
+            const Node::VOut* vp = pr.node < 0 ? nullptr : &nodes_[pr.node].vout[pr.port];
+            if (!vp || !vp->frame) {   // no picture this tick: nothing will follow the pending chains soon -- let them go (with whatever scales are queued)
+                if (!n.rgba_pending.empty()) { flush_scales(stream_); launch_pending_rgba(n, n.rgba_pending.size(), false); }
+                break;
+            }
+            DFrame* d = vp->frame.f;
             const int32_t stride = (int32_t)(((size_t)d->width * 4 + 15) & ~(size_t)15);
             const size_t need = (size_t)stride * d->height;
-            if (n.rgba.bytes < need) { if (n.rgba_pending) launch_pending_rgba(n, false); sync(); n.rgba.alloc(need); }
+            if (n.rgba[0].bytes < need) {
+                if (!n.rgba_pending.empty()) { flush_scales(stream_); launch_pending_rgba(n, n.rgba_pending.size(), false); }
+                sync();
+                n.rgba[0].alloc(need); n.rgba[1].alloc(need);
+            }
             mx_video_to_rgba_params p; std::memcpy(&p, n.params.data(), sizeof p);
+            n.rgba_cur ^= 1u;
+            uint8_t* const out = (uint8_t*)n.rgba[n.rgba_cur].p;
             if (d->lazy) {   // the composite only exists as a cross-fade chain: evaluate it straight into RGBA
                 ChainRgbaArgs c;
                 fill_chain_rgba_sources(*d->lazy, c, stream_);   // layers that are unevaluated scaler outputs are resampled inside the kernel
-                c.rgba = (uint8_t*)n.rgba.p; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
+                c.rgba = out; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
                 c.use_matrix = p.use_matrix;
                 for (int k = 0; k < 12; ++k) c.m[k] = p.matrix_q12[k];
-                // Inside a batched run the sink runs ONE TICK LATE: the chain of tick k leaves together with the scaler tiles tick k + 1
-                // queues (one launch instead of two dependent ones, mx_k_video.hip k_scale_then_chain_rgba); the scales tick k itself
-                // needed left with the chain of tick k - 1.  Scaler outputs alternate between two frames, so the scales of tick k + 1
-                // never write what this chain reads.  The last tick's chain is launched when the run ends (Graph::run_span).
-                if (n.rgba_pending) launch_pending_rgba(n, true);
-                else flush_scales(stream_);                       // first tick of the run: this tick's scales have nothing to leave with
-                n.rgba_args = c; n.rgba_keep = d->lazy; n.rgba_pending = true;
+                // Inside a batched run the sink runs LATE and in pairs: the chains of ticks k and k + 1 leave in ONE launch together with the
+                // scaler tiles ticks k + 2 and k + 3 queued (mx_k_video.hip k_scale_then_chain_rgba) -- the launch floor of these small kernels
+                // is paid once per two frames.  Every second sink call is an event: it takes ALL queued scales along (so the scales a
+                // chain needs left at its own call or the next one) and, once four chains are pending, the two oldest -- always at least
+                // two calls old.  A Scaler writes four output frames in turn and the sink two RGBA buffers, so nothing in one launch
+                // writes what something else in it reads or writes.  What is still pending when the run ends is launched then.
+                n.rgba_pending.push_back(Node::PendingRgba{c, d->lazy});
+                if ((++n.rgba_calls & 1u) == 0) {
+                    if (n.rgba_pending.size() >= 4) launch_pending_rgba(n, 2, true);
+                    else flush_scales(stream_);
+                }
                 n.rgba_w = d->width; n.rgba_h = d->height; n.rgba_stride = stride;
                 break;
             }
-            if (n.rgba_pending) launch_pending_rgba(n, false);
+            if (!n.rgba_pending.empty()) { flush_scales(stream_); launch_pending_rgba(n, n.rgba_pending.size(), false); }
             d->ensure_pixels(stream_);
             if (d->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "VIDEO_TO_RGBA takes yuv420p (a VideoMixer output); put a VideoMixer in front of a source of another format");
             RgbaArgs a;
-            a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = (uint8_t*)n.rgba.p;
+            a.y = d->data[0]; a.u = d->data[1]; a.v = d->data[2]; a.rgba = out;
             a.y_stride = d->stride[0]; a.u_stride = d->stride[1]; a.v_stride = d->stride[2]; a.rgba_stride = (uint32_t)stride;
             a.width = d->width; a.height = d->height; a.use_matrix = p.use_matrix;
             for (int k = 0; k < 12; ++k) a.m[k] = p.matrix_q12[k];
@@ -1359,10 +1371,18 @@ void Graph::run_video_tick(uint64_t t) {
     }
 }
 
-void Graph::launch_pending_rgba(Node& n, bool with_queued_scales) {
-    if (with_queued_scales) launch_chain_rgba_after_queued_scales(n.rgba_args, stream_);
-    else launch_fade_chain_rgba(n.rgba_args, stream_);
-    n.rgba_pending = false; n.rgba_keep.reset();
+void Graph::launch_pending_rgba(Node& n, size_t count, bool with_queued_scales) {
+    count = std::min(count, n.rgba_pending.size());
+    size_t i = 0;
+    while (i < count) {
+        const int m = (int)std::min<size_t>(2, count - i);
+        ChainRgbaArgs c[2];
+        for (int k = 0; k < m; ++k) c[k] = n.rgba_pending[i + k].args;
+        if (with_queued_scales && i == 0) launch_chains_rgba_after_queued_scales(c, m, stream_);
+        else { ScaleBatchArgs none{}; launch_scale_then_chains_rgba(none, c, m, stream_); }
+        i += m;
+    }
+    n.rgba_pending.erase(n.rgba_pending.begin(), n.rgba_pending.begin() + count);
 }
 
 void Graph::set_video_source(uint32_t node, DFrame* frame, Rational dur, Rational off, bool repeat) {
@@ -1405,7 +1425,7 @@ FrameRef Graph::video_output(uint32_t node, uint32_t port) {
 void Graph::rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h) {
     if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_VIDEO_TO_RGBA) throw Error(MX_ERR_INVALID, "node is not a VIDEO_TO_RGBA");
     const Node& n = nodes_[node];
-    if (dev) *dev = n.rgba_w ? n.rgba.p : nullptr;
+    if (dev) *dev = n.rgba_w ? n.rgba[n.rgba_cur].p : nullptr;
     if (stride) *stride = n.rgba_stride;
     if (w) *w = n.rgba_w;
     if (h) *h = n.rgba_h;

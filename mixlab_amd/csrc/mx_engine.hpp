@@ -58,8 +58,10 @@ struct Node {
     FrameRef vsrc; Rational vsrc_dur, vsrc_off; bool vsrc_repeat = false, vsrc_pending = false;   // SOURCE_VIDEO
     std::vector<FrameRef> vsrc_ring; size_t vsrc_ring_pos = 0;                                       // SOURCE_VIDEO: a new frame every tick, cycling
     std::shared_ptr<BandScaler> vband; std::vector<FrameRef> vband_pool;                             // SOURCE_VIDEO: frames are halo slices, delivered as this rank's row band of the scaled picture
-    DevBuf rgba; uint32_t rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;                       // VIDEO_TO_RGBA
-    bool rgba_pending = false; ChainRgbaArgs rgba_args{}; std::shared_ptr<LazyChain> rgba_keep;     // VIDEO_TO_RGBA: the chain of the last tick, not launched yet (run_video_tick)
+    DevBuf rgba[2]; uint32_t rgba_cur = 0, rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;      // VIDEO_TO_RGBA: two buffers, written alternately (two ticks' chains may share a launch); rgba_cur = the last tick's
+    struct PendingRgba { ChainRgbaArgs args; std::shared_ptr<LazyChain> keep; };
+    std::vector<PendingRgba> rgba_pending;     // VIDEO_TO_RGBA: chains of the last ticks, not launched yet, oldest first (run_video_tick)
+    uint32_t rgba_calls = 0;                   // sink calls that queued a chain in this run
 };
 
 struct Group {
@@ -144,7 +146,7 @@ private:
     void upload_group(Group& g);          // descriptors of one group (both parities under MX_FLAG_OVERLAP_TAIL)
     void upload_group_one(Group& g);
     void run_video_tick(uint64_t t);
-    void launch_pending_rgba(Node& n, bool with_queued_scales);
+    void launch_pending_rgba(Node& n, size_t count, bool with_queued_scales);   // the `count` oldest pending chains of a sink
     // one launch sequence over ticks [call_off, call_off + n_calls) of the current run
     void run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_calls, uint32_t run_calls);
     void apply_params(uint32_t node, const void* params, size_t len);   // update_params without the synchronisation

@@ -552,17 +552,20 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) {
 // PREVIOUS tick's composite (Graph defers the RGBA sink by one tick inside a batched run).  Two dependent launches of this size cost
 // their sum plus a launch gap each; inside one launch the chain's tiles start as the scaler's tiles drain and the two bodies -- one
 // VALU-heavy, one waiting for bytes -- share the CUs.
-// Block order (measured, MX_VIDEO_FUSED_ORDER): the chain's tiles first -- they wait for their bytes while the scaler's tiles, dispatched
-// behind them, do arithmetic (18.5 us per 1080p frame); the scaler's first (K = 0): 19.5; one chain tile per three scaler tiles: 26.6.
+// Block order (measured, MX_VIDEO_FUSED_ORDER): the chains' tiles first -- they wait for their bytes while the scaler's tiles, dispatched
+// behind them, do arithmetic (18.4 us per 1080p frame with one chain per launch); the scaler's first: 19.5; interleaved 1 : 3: 26.6.
 template <int MM>
-__global__ __launch_bounds__(256) void k_scale_then_chain_rgba(ScaleBatchArgs sa, ChainRgbaArgs ca, uint32_t n_scale_tiles, uint32_t n_chain_tiles, uint32_t chain_tiles_x, uint32_t K) {
-    const uint32_t b = blockIdx.x;
-    uint32_t st, ct; bool is_chain;
-    if (K != 0xffffffffu && b < 4u * K) { const uint32_t g = b >> 2, r = b & 3u; is_chain = r == 0u; ct = g; st = 3u * g + (r - 1u); }
-    else if (K == 0xffffffffu) { is_chain = b < n_chain_tiles; ct = b; st = b - n_chain_tiles; }   // the chain's tiles first
-    else { const uint32_t rest = b - 4u * K, sr = n_scale_tiles - 3u * K; is_chain = rest >= sr; st = 3u * K + rest; ct = K + (rest - sr); }
-    if (!is_chain) { scale_tile(sa, st); return; }
-    chain_rgba_tile<MM, false>(ca, (int)(ct % chain_tiles_x), (int)(ct / chain_tiles_x));
+__global__ __launch_bounds__(256) void k_scale_then_chain_rgba(ScaleBatchArgs sa, ChainRgbaArgs c0, ChainRgbaArgs c1, uint32_t n_scale_tiles, uint32_t n0, uint32_t n1,
+                                                               uint32_t tx0, uint32_t tx1, uint32_t order) {
+    // roles by block index.  order 2 (default): the chains' tiles first, the scaler's behind them; 0: the scaler's first
+    uint32_t b = blockIdx.x;
+    const uint32_t nc = n0 + n1;
+    bool is_chain; uint32_t t;
+    if (order == 2u) { is_chain = b < nc; t = is_chain ? b : b - nc; }
+    else { is_chain = b >= n_scale_tiles; t = is_chain ? b - n_scale_tiles : b; }
+    if (!is_chain) { scale_tile(sa, t); return; }
+    if (t < n0) chain_rgba_tile<MM, false>(c0, (int)(t % tx0), (int)(t / tx0));
+    else { t -= n0; chain_rgba_tile<MM, false>(c1, (int)(t % tx1), (int)(t / tx1)); }
 }
 
 __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {   // simple gather form, any ratio
@@ -628,28 +631,43 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
     }
 }
-// the batch `sa` (may be empty) and then the chain `ca0` in one launch when both take their tiled forms; else one after the other
-void launch_scale_then_chain_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs& ca0, hipStream_t s) {
-    ScaleBatchArgs b; uint32_t total = 0, mw, mh; size_t lds = 0;
+// the batch `sa` (may be empty) and up to two chains that do not read it, in one launch when all take their tiled forms; else one after
+// the other (the batch, then the chains in order)
+static int chain_matrix_mode(ChainRgbaArgs& a) {
+    if (!a.use_matrix) return 0;
+    bool fits = true;
+    for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
+    a.use_matrix = fits ? 2 : 1;
+    return a.use_matrix;
+}
+void launch_scale_then_chains_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
+    ScaleBatchArgs b{}; uint32_t total = 0, mw, mh; size_t lds = 0;
     static const int no_fuse = env_int("MX_VIDEO_NO_LAUNCH_FUSION", 0);
-    if (no_fuse || !sa.n || ca0.n_scaled || !ca0.width || !ca0.height || !plan_scale_tiles(sa, b, total, lds, mw, mh) || !total) {
+    bool fuse = !no_fuse && n_chains >= 1 && n_chains <= 2;
+    ChainRgbaArgs c[2];
+    int mm = -1;
+    for (int k = 0; k < n_chains && k < 2; ++k) {
+        c[k] = chains[k];
+        if (c[k].n_scaled || !c[k].width || !c[k].height) fuse = false;
+        const int m = chain_matrix_mode(c[k]);
+        if (mm >= 0 && m != mm) fuse = false;
+        mm = m;
+    }
+    const bool have_scales = sa.n != 0 && plan_scale_tiles(sa, b, total, lds, mw, mh) && total;
+    if (!fuse || (sa.n && !have_scales) || (!have_scales && n_chains < 2)) {
         if (sa.n) launch_scale_batch(sa, s);
-        launch_fade_chain_rgba(ca0, s);
+        for (int k = 0; k < n_chains; ++k) launch_fade_chain_rgba(chains[k], s);
         return;
     }
-    ChainRgbaArgs a = ca0;
-    if (a.use_matrix) {
-        bool fits = true;
-        for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
-        a.use_matrix = fits ? 2 : 1;
-    }
-    const uint32_t tx = (a.width + 127) / 128, ty = (a.height + 31) / 32, nc = tx * ty;
-    static const int order = env_int("MX_VIDEO_FUSED_ORDER", 2);          // 2 chain tiles first (default: 18.5 us per 1080p frame), 0 scaler tiles first (19.5), 1 interleaved (26.6)
-    const uint32_t K = order == 2 ? 0xffffffffu : (order ? std::min(nc, total / 3u) : 0u);
-    const dim3 grid(total + nc);
-    if (a.use_matrix == 2) hipLaunchKernelGGL(k_scale_then_chain_rgba<2>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
-    else if (a.use_matrix) hipLaunchKernelGGL(k_scale_then_chain_rgba<1>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
-    else hipLaunchKernelGGL(k_scale_then_chain_rgba<0>, grid, dim3(256), lds, s, b, a, total, nc, tx, K);
+    if (!have_scales) { b = ScaleBatchArgs{}; total = 0; lds = 0; }
+    if (n_chains < 2) { c[1] = c[0]; }
+    const uint32_t tx0 = (c[0].width + 127) / 128, n0 = tx0 * ((c[0].height + 31) / 32);
+    const uint32_t tx1 = n_chains == 2 ? (c[1].width + 127) / 128 : 1u, n1 = n_chains == 2 ? tx1 * ((c[1].height + 31) / 32) : 0u;
+    static const int order = env_int("MX_VIDEO_FUSED_ORDER", 2);          // 2 chain tiles first (default: 18.4 us per 1080p frame with one chain), 0 scaler tiles first (19.5)
+    const dim3 grid(total + n0 + n1);
+    if (mm == 2) hipLaunchKernelGGL(k_scale_then_chain_rgba<2>, grid, dim3(256), lds, s, b, c[0], c[1], total, n0, n1, tx0, tx1, (uint32_t)order);
+    else if (mm == 1) hipLaunchKernelGGL(k_scale_then_chain_rgba<1>, grid, dim3(256), lds, s, b, c[0], c[1], total, n0, n1, tx0, tx1, (uint32_t)order);
+    else hipLaunchKernelGGL(k_scale_then_chain_rgba<0>, grid, dim3(256), lds, s, b, c[0], c[1], total, n0, n1, tx0, tx1, (uint32_t)order);
 }
 // Downscaling: the kernel widens with the scale factor (hn / vn taps, DESIGN.md "Scaler").  Two plain passes through
 // ScalePlane::tmp -- the H pass filters every source row once, the V pass reads vn of those rows per pixel -- instead of

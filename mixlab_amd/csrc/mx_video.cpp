@@ -63,14 +63,14 @@ void flush_scales(hipStream_t s) {
 }
 // The queued scales of the stream leave TOGETHER with an RGBA chain that does not read them (Graph::run_video_tick: the chain of the tick
 // before) -- one launch instead of two dependent ones (mx_k_video.hip k_scale_then_chain_rgba).
-void launch_chain_rgba_after_queued_scales(const ChainRgbaArgs& c, hipStream_t s) {
+void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
     PendingScales taken;
     {
         std::lock_guard<std::mutex> lk(g_scale_mu);
         auto it = g_scale_q.find(s);
         if (it != g_scale_q.end()) { taken = std::move(it->second); it->second = PendingScales{}; }
     }
-    launch_scale_then_chain_rgba(taken.args, c, s);   // `taken` keeps the frames and tables until the launch is queued (a later free synchronises)
+    launch_scale_then_chains_rgba(taken.args, chains, n_chains, s);   // `taken` keeps the frames and tables until the launch is queued (a later free synchronises)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,8 +419,8 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     t->geo = scaler_geometry(in_w, in_h, out_w_, out_h_);
     const ScaleGeometry& geo = t->geo;
     flush_scales(stream_);             // queued jobs write the old output frames
-    frame_ = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
-    frame_alt_ = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);
+    for (auto& f : ring_) f = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
+    ring_pos_ = 0; frame_ = ring_[0];
     // tap tables: [luma h, luma v, chroma h, chroma v]
     std::vector<int32_t> blob;
     size_t offs[2][4];
@@ -489,7 +489,7 @@ FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
     in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);   // encode.rs:347-384
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
-    std::swap(frame_, frame_alt_);             // not the frame the previous call wrote: the RGBA chain that reads that one may be launched AFTER this scale (Graph defers it by a tick)
+    ring_pos_ = (ring_pos_ + 1) & 3u; frame_ = ring_[ring_pos_];   // not a frame the last three calls wrote: the RGBA chains that read those may be launched AFTER this scale (Graph defers them)
     if (may_defer && t_->four_tap) {
         auto sc = std::make_shared<LazyScale>();
         sc->src = in; sc->t = t_; sc->target = frame_;

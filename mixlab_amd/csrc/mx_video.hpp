@@ -93,8 +93,8 @@ struct FrameRef;
 struct ScaleTables;
 void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs = nullptr);
 void flush_scales(hipStream_t s);
-void launch_scale_then_chain_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs& ca, hipStream_t s);   // one launch when both take their tiled forms
-void launch_chain_rgba_after_queued_scales(const ChainRgbaArgs& c, hipStream_t s);
+void launch_scale_then_chains_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);   // one launch when all take their tiled forms
+void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
 
@@ -229,8 +229,9 @@ private:
     hipStream_t stream_;
     uint32_t in_w_ = 0, in_h_ = 0;   // settings the cached context was built for (encode.rs:347-352)
     uint8_t in_fmt_ = MX_PIXFMT_YUV420P;
-    FrameRef frame_;                 // cached blank output frame (encode.rs:382) -- the one the next scale() writes
-    FrameRef frame_alt_;             // and the one the previous scale() wrote: the two alternate (a deferred reader of that one may be launched after this scale)
+    FrameRef frame_;                 // cached blank output frame (encode.rs:382) -- the one the latest scale() wrote
+    FrameRef ring_[4];               // four of them, used in turn: the RGBA chains that read the last two may be launched together with the next two scales
+    uint32_t ring_pos_ = 0;
     std::shared_ptr<ScaleTables> t_;
     DevBuf tmp_;                     // downscaling: H-filtered rows of the three planes
     int32_t* tmp_plane_[3] = {nullptr, nullptr, nullptr};
