@@ -174,3 +174,33 @@ def test_config3_full_size_256_channels_fir_then_resampler_spot_checked_against_
     want_m, want_c = oracle.mixer_run([(0.0, 1.0, k % 2 == 0) for k in range(n_ch)], dev_r, 2 * T * 800)
     assert np.array_equal(bits(g.read_output(mix, 0, T, True, rate=(160, 147))), bits(want_m))
     assert np.array_equal(bits(g.read_output(mix, 1, T, True, rate=(160, 147))), bits(want_c))
+
+
+def test_config2_at_the_benchmarked_batch_length_2048_ticks_bit_exact():
+    """bench.py's submission shape at full length: 2048 ticks of 48 kHz in ONE run, gates toggling every 30 ticks inside it -- the
+    speculative tiled EqThree kernel with the inline branch-free Envelope over tens of chunks per strip -- against the oracle ticked
+    tick by tick with its gate updates between ticks.  16 strips keep the oracle at a second of CPU."""
+    from test_gpu_schedule import gate_open, schedule_gates
+    SR, SPT, T, n_strips = 48000, 800, 2048, 16
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    g = ws.build(max_ticks_per_run=T)
+    noise = [synth.noise(100 + k, T * SPT) for k in range(n_strips)]
+    n_ev = schedule_gates(g, trigs, 0, T)
+    assert n_ev >= n_strips * (T // 30 - 2)
+    for k, s in enumerate(srcs):
+        g.write_source(s, noise[k], T)
+    g.run_ticks(0, T)
+    ran, repaired = g.eq_spec_stats()
+    assert ran >= 16 * n_strips and repaired == 0          # the time-parallel kernel ran, and proved itself without repairs
+    got_m, got_c = g.read_output(mix, 0, T, True), g.read_output(mix, 1, T, True)
+    og = oracle.OracleGraph(ws)
+    for tick in range(T):
+        for k, tr in enumerate(trigs):
+            if tick == 0 or gate_open(tick, k) != gate_open(tick - 1, k):
+                og.update_params(tr, abi.TriggerParams(1 if gate_open(tick, k) else 0))
+        for k, s in enumerate(srcs):
+            og.set_source(s, noise[k][tick * SPT:(tick + 1) * SPT])
+        og.run_tick(tick)
+        sl = slice(tick * 2 * SPT, (tick + 1) * 2 * SPT)
+        assert np.array_equal(got_m[sl].view(np.uint32), og.output(mix, 0).view(np.uint32)), f"master differs in tick {tick}"
+        assert np.array_equal(got_c[sl].view(np.uint32), og.output(mix, 1).view(np.uint32)), f"cue differs in tick {tick}"
