@@ -96,7 +96,9 @@ def test_random_graph_matches_the_oracle_on_every_port(seed):
     order = og.run_order()
     graphs = {"fused": ws.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_EXACT),
               "unfused": ws.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_EXACT | abi.FLAG_NO_FUSE),
-              "ticked": ws.build(max_ticks_per_run=1, flags=abi.FLAG_EQ_EXACT)}
+              "ticked": ws.build(max_ticks_per_run=1, flags=abi.FLAG_EQ_EXACT),
+              # where the graph ends in a Mixer bank fed by computed ports, that bank runs on a second stream (else the flag changes nothing)
+              "overlap": ws.build(max_ticks_per_run=T, flags=abi.FLAG_EQ_EXACT | abi.FLAG_OVERLAP_TAIL)}
     for g in graphs.values():
         assert g.run_order() == order
     data = {n: synth.noise(4000 + 31 * seed + n, runs * T * SPT * (1 if ty == MONO else 2)) for (n, ty) in sources}
