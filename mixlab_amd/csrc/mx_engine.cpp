@@ -975,7 +975,13 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                     if (!eq_stats_.p) { eq_stats_.alloc(2 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 2 * sizeof(uint64_t)), "hipMemset"); }
                     launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
                 } else {
-                    launch_eq_three_exact((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, stream_);
+                    void* scratch = nullptr;
+                    if (eq_use_poles_split(n, gf)) {     // short streams, few instances: two lanes per instance + a sample-parallel epilogue kernel
+                        const size_t need = eq_poles_scratch_bytes(n, gf);
+                        if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
+                        scratch = g.spec.p;
+                    }
+                    launch_eq_three_exact((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, scratch, stream_);
                 }
             } else {
                 EqSplit sp{1u, 5u, 0u, 0u, gf, gf, nullptr, nullptr, nullptr};

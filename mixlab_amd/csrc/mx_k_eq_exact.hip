@@ -301,12 +301,97 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
     st.history[0] = s.h0; st.history[1] = s.h1; st.history[2] = s.h2;
     states[inst] = st;
 }
-// (A systolic variant -- the eight poles of an instance in eight lanes, one DPP shift per step, outputs eight at a time -- was built and
-// measured for the one-tick-per-submission regime: bit-exact, and no faster (70 vs 75 us for 1 024 strips x 800 samples): with one
-// wave per SIMD the step is a chain of five dependent f64 instructions plus LDS round trips, as long as the 52 independent-enough
-// instructions it replaces.  Removed)
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// Short streams, few instances (the real-time regime: a tick at a time): the serial part is cut to what IS serial.  The two cascades of an
+// instance are independent filters of the same input (eq_three.rs:68-74), so they run in two LANES -- identical code, own coefficient and
+// poles -- and leave their last pole per sample (l, the high cascade's p[3]) in a scratch stream; everything after that (band mix
+// eq_three.rs:76-88, Panner, Amplifier, Envelope) has no recurrence and runs as a second, sample-parallel kernel.  14 dependent-enough
+// instructions per sample and lane instead of 52-72; same operations on the same operands, bit for bit.
+// (A systolic variant -- the eight poles in eight lanes, one DPP shift per step -- was also built and measured: bit-exact, no faster than
+// one lane per instance: its step is a chain of five dependent f64 instructions plus LDS round trips.  Removed.)
+// ---------------------------------------------------------------------------------------------
+struct EqPolesScratch { double* p3; double* hist_old; };   // [n][2][frames] last pole per cascade and sample; [n][3] the delay line before the run
+__global__ __launch_bounds__(64) void k_eq_three_poles(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r, EqPolesScratch sc) {
+    const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= 2u * n_inst) return;
+    const uint32_t inst = id >> 1, c = id & 1u;
+    typedef const float __attribute__((address_space(1)))* gfp;
+    const gfp in = (gfp)descs[inst].in;
+    EqState& st = states[inst];
+    double p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = c ? st.hi[k] : st.lo[k];
+    const double f = c ? r.hi_f : r.lo_f;
+    const size_t N = r.frames;
+    double* __restrict__ out = sc.p3 + ((size_t)inst * 2 + c) * N;
+    if (c == 0) {   // the delay line: what the epilogue kernel needs from before the run, and what the next run needs from this one
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc.hist_old[(size_t)inst * 3 + k] = st.history[k];
+    }
+    size_t i = 0;
+    f4v xa[4];
+    if (N >= 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = *reinterpret_cast<const f4v __attribute__((address_space(1)))*>(in + 4 * q);
+    }
+    for (; i + 16 <= N; i += 16) {                      // sixteen samples of loads in flight while the previous sixteen are computed
+        f4v xb[4];
+        const size_t nb = i + 32 <= N ? i + 16 : i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[q] = *reinterpret_cast<const f4v __attribute__((address_space(1)))*>(in + nb + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pump(f, p, (double)xa[q][e]);
+            typedef double __attribute__((ext_vector_type(2))) d2v;
+            __builtin_nontemporal_store(d2v{o[0], o[1]}, reinterpret_cast<d2v*>(out + i + 4 * q));
+            __builtin_nontemporal_store(d2v{o[2], o[3]}, reinterpret_cast<d2v*>(out + i + 4 * q + 2));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = xb[q];
+    }
+    for (; i < N; ++i) out[i] = pump(f, p, (double)in[i]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (c) st.hi[k] = p[k]; else st.lo[k] = p[k]; }
+    if (c == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {   // x[N-3 .. N-1]; a run shorter than the delay line keeps part of the old one
+            const long long j = (long long)N - 3 + k;
+            st.history[k] = j >= 0 ? (double)in[j] : sc.hist_old[(size_t)inst * 3 + (size_t)(j + 3)];
+        }
+    }
+}
+// sample-parallel: the band mix and the folded modules for sample i of instance blockIdx.y
+__global__ __launch_bounds__(256) void k_eq_three_emit(const EqDesc* __restrict__ descs, uint32_t n_inst, EqRun r, EqPolesScratch sc) {
+    const uint32_t inst = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (inst >= n_inst || i >= r.frames) return;
+    const EqDesc& d = descs[inst];
+    const double l = sc.p3[((size_t)inst * 2) * r.frames + i], hp = sc.p3[((size_t)inst * 2 + 1) * r.frames + i];
+    const double h0 = i >= 3 ? (double)d.in[i - 3] : sc.hist_old[(size_t)inst * 3 + i];   // eq_three.rs:66,80-83: the input three samples back
+    const double h = h0 - hp;
+    const double mid = h0 - (h + l);
+    const float y = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);          // eq_three.rs:76-88
+    EqSeqEmit em;
+    em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
+    em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
+    em.seek(i);
+    em.emit(i, y);
+}
+size_t eq_poles_scratch_bytes(uint32_t n, size_t frames) { return ((size_t)n * 2 * frames + (size_t)n * 3) * sizeof(double); }
+bool eq_use_poles_split(uint32_t n, size_t frames) {   // few instances (the chip is mostly idle under one lane per instance), scratch within reason
+    static const int below = env_int("MX_EQ_POLES_BELOW", 4097);        // instances; 0 = never (measured: 1 024 strips x 1 tick 77 -> 44 us; 10 240: 104 -> 315 us)
+    return (int)n < below && frames >= 1 && eq_poles_scratch_bytes(n, frames) <= ((size_t)768 << 20);
+}
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, void* scratch, hipStream_t s) {
     if (!n || !r.frames) return;
+    if (scratch) {
+        EqPolesScratch sc{(double*)scratch, (double*)scratch + (size_t)n * 2 * r.frames};
+        hipLaunchKernelGGL(k_eq_three_poles, dim3((2 * n + 63) / 64), dim3(64), 0, s, d, st, n, r, sc);
+        hipLaunchKernelGGL(k_eq_three_emit, dim3((unsigned)((r.frames + 255) / 256), n), dim3(256), 0, s, d, n, r, sc);
+        return;
+    }
     hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
 }
 

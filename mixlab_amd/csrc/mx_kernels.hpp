@@ -103,7 +103,10 @@ void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, 
 void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s);
 // what every EqThree launch needs beyond the descriptors: the per-tick Envelope table (null when no instance folds one)
 struct EqRun { size_t frames; size_t fpc /* samples per tick (call) */; uint32_t n_calls; uint32_t pad; uint64_t t0; double sr, rsr /* RN(1 / sr), host */, lo_f, hi_f; const EnvTick* ticks /* [n][n_calls] */; };
-void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, hipStream_t s);
+// scratch != nullptr: the split-cascade form for few instances (eq_use_poles_split; eq_poles_scratch_bytes of scratch); else one lane per instance
+void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, void* scratch, hipStream_t s);
+bool eq_use_poles_split(uint32_t n, size_t frames);
+size_t eq_poles_scratch_bytes(uint32_t n, size_t frames);
 int eq_scan_log2l(size_t frames);
 void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r,
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s);
