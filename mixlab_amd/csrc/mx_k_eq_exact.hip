@@ -376,13 +376,16 @@ __global__ __launch_bounds__(256) void k_eq_three_emit(const EqDesc* __restrict_
     EqSeqEmit em;
     em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
     em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
-    em.seek(i);
+    if ((em.E.flags & MX_EQF_ENV) && em.E.epi == 2u) {   // EqSeqEmit::seek with 32-bit arithmetic (the launcher keeps frames below 2^31: a 64-bit division per sample costs more than the sample)
+        const uint32_t fpc = (uint32_t)r.fpc, call = (uint32_t)i / fpc;
+        em.call = call; em.left = fpc - ((uint32_t)i - call * fpc); em.cur = em.E.ticks[call];
+    }
     em.emit(i, y);
 }
 size_t eq_poles_scratch_bytes(uint32_t n, size_t frames) { return ((size_t)n * 2 * frames + (size_t)n * 3) * sizeof(double); }
 bool eq_use_poles_split(uint32_t n, size_t frames) {   // few instances (the chip is mostly idle under one lane per instance), scratch within reason
     static const int below = env_int("MX_EQ_POLES_BELOW", 4097);        // instances; 0 = never (measured: 1 024 strips x 1 tick 77 -> 44 us; 10 240: 104 -> 315 us)
-    return (int)n < below && frames >= 1 && eq_poles_scratch_bytes(n, frames) <= ((size_t)768 << 20);
+    return (int)n < below && frames >= 1 && frames < ((size_t)1 << 31) && eq_poles_scratch_bytes(n, frames) <= ((size_t)768 << 20);
 }
 void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, void* scratch, hipStream_t s) {
     if (!n || !r.frames) return;
