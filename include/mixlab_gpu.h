@@ -245,7 +245,9 @@ typedef struct {
  * the DynamicScaler's context converts implicitly (codec/src/ffmpeg/scale.rs:16-39, src/video/encode.rs:342-352: the settings compare
  * unequal when only the format differs).  Here that conversion is the build-specified scaler applied per plane: each chroma plane is
  * resampled from ITS size to the output's chroma size (DESIGN.md "Scaler" -- parity unpinned, like the scaler itself). */
-typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P = 2 } mx_pixfmt;
+typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P = 2,
+               MX_PIXFMT_NV12 = 3 /* semi-planar 4:2:0, what hardware decoders deliver: plane 1 = interleaved U,V rows of `width` bytes, no plane 2
+                                     (mx_frame.data[2] is ignored, mx_dframe_planes reports it NULL) */ } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer

@@ -69,7 +69,7 @@ int mx_dframe_create_fmt(uint32_t width, uint32_t height, mx_pixfmt fmt, void* s
     return guard([&] {
         REQUIRE(out, "out is NULL");
         *out = nullptr;
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_YUV444P, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_NV12, "unknown pixel format");
         *out = H(DFrame::create(width, height, S(stream), (uint8_t)fmt));
     });
 }
@@ -86,17 +86,17 @@ void mx_dframe_release(mx_dframe* f) {
 static void check_host_frame(const DFrame* d, const mx_frame* h) {
     REQUIRE(d && h, "NULL argument");
     if (h->width != d->width || h->height != d->height) throw Error(MX_ERR_INVALID, "host frame size differs from the device frame");
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < d->stored_planes(); ++p) {
         REQUIRE(h->data[p], "host plane pointer is NULL");
-        if (h->stride[p] < (int32_t)d->pw(p)) throw Error(MX_ERR_INVALID, "host stride smaller than the plane width");
+        if (h->stride[p] < (int32_t)d->stored_row_bytes(p)) throw Error(MX_ERR_INVALID, "host stride smaller than the plane width");
     }
 }
 int mx_dframe_upload(mx_dframe* f, const mx_frame* host, void* stream) {
     return guard([&] {
         check_host_frame(D(f), host);
         DFrame* d = D(f);
-        for (int p = 0; p < 3; ++p)
-            mx::hip_check(hipMemcpy2DAsync(d->data[p], d->stride[p], host->data[p], (size_t)host->stride[p], d->pw(p), d->ph(p),
+        for (int p = 0; p < d->stored_planes(); ++p)
+            mx::hip_check(hipMemcpy2DAsync(d->data[p], d->stride[p], host->data[p], (size_t)host->stride[p], d->stored_row_bytes(p), d->ph(p),
                                            hipMemcpyHostToDevice, S(stream)), "hipMemcpy2DAsync(H2D frame)");
         mx::hip_check(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
     });
@@ -105,8 +105,8 @@ int mx_dframe_download(const mx_dframe* f, mx_frame* host, void* stream) {
     return guard([&] {
         check_host_frame(D(f), host);
         const DFrame* d = D(f);
-        for (int p = 0; p < 3; ++p)
-            mx::hip_check(hipMemcpy2DAsync(host->data[p], (size_t)host->stride[p], d->data[p], d->stride[p], d->pw(p), d->ph(p),
+        for (int p = 0; p < d->stored_planes(); ++p)
+            mx::hip_check(hipMemcpy2DAsync(host->data[p], (size_t)host->stride[p], d->data[p], d->stride[p], d->stored_row_bytes(p), d->ph(p),
                                            hipMemcpyDeviceToHost, S(stream)), "hipMemcpy2DAsync(D2H frame)");
         mx::hip_check(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
     });
@@ -117,7 +117,11 @@ int mx_dframe_planes(const mx_dframe* f, uint32_t* width, uint32_t* height, void
         const DFrame* d = D(f);
         if (width) *width = d->width;
         if (height) *height = d->height;
-        for (int p = 0; p < 3; ++p) { if (device_data) device_data[p] = d->data[p]; if (stride) stride[p] = (int32_t)d->stride[p]; }
+        for (int p = 0; p < 3; ++p) {
+            const bool stored = p < d->stored_planes();
+            if (device_data) device_data[p] = stored ? d->data[p] : nullptr;
+            if (stride) stride[p] = stored ? (int32_t)d->stride[p] : 0;
+        }
     });
 }
 

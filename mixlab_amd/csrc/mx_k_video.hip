@@ -208,30 +208,44 @@ __device__ __forceinline__ ScWin sc_window(int oxa, int oxb, int oya, int oyb, u
 // memory round trip per iteration); border chunks -- only in tiles at the picture's edges -- are assembled from clamped byte loads
 // afterwards.
 template <int Q>
-__device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride, int sw, int sh, const ScWin& g, uint8_t* S, int s_stride, int tid) {
+__device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride, int sw, int sh, const ScWin& g, uint8_t* S, int s_stride, int tid,
+                                         const uint32_t sxs = 0u /* samples are 1 + sxs bytes apart ... */, const uint32_t sxo = 0u /* ... from byte sxo of a row (nv12 chroma) */) {
     const int sw1 = sw - 1, sh1 = sh - 1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15u) == 0 && sw >= 16;
     const int c16 = tid & 15, x = g.cxa + 16 * c16;
     const bool col_ok = 4 * c16 < g.nc4, interior = aligned && x >= 0 && x + 15 <= sw1;
     const int xs = aligned ? (min(max(x, 0), sw1 - 15) & ~15) : 0;                // always a readable chunk of the row when `aligned`
     uint4 w[Q];
+    if (sxs == 0u) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int r = (tid >> 4) + 16 * q;
-        const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
-        w[q] = aligned ? *reinterpret_cast<const uint4*>(row + xs) : make_uint4(0u, 0u, 0u, 0u);
+        for (int q = 0; q < Q; ++q) {
+            const int r = (tid >> 4) + 16 * q;
+            const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+            w[q] = aligned ? *reinterpret_cast<const uint4*>(row + xs) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {   // interleaved samples: 16 of them are the even (sxo = 0) or odd (1) bytes of 32 source bytes -- two loads and four byte permutes
+        const uint32_t sel = sxo ? 0x07050301u : 0x06040200u;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = (tid >> 4) + 16 * q;
+            const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+            uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+            if (aligned) { a = *reinterpret_cast<const uint4*>(row + 2 * xs); b = *reinterpret_cast<const uint4*>(row + 2 * xs + 16); }
+            w[q] = make_uint4(__builtin_amdgcn_perm(a.y, a.x, sel), __builtin_amdgcn_perm(a.w, a.z, sel), __builtin_amdgcn_perm(b.y, b.x, sel), __builtin_amdgcn_perm(b.w, b.z, sel));
+        }
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int r = (tid >> 4) + 16 * q;
         if (r < g.nr && col_ok) {
             if (!interior) {                                                    // edge replication
-                const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+                const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride + sxo;
+                const int st = 1 + (int)sxs;
                 uint32_t d[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    d[k] = (uint32_t)row[min(max(x + 4 * k, 0), sw1)] | ((uint32_t)row[min(max(x + 4 * k + 1, 0), sw1)] << 8) |
-                           ((uint32_t)row[min(max(x + 4 * k + 2, 0), sw1)] << 16) | ((uint32_t)row[min(max(x + 4 * k + 3, 0), sw1)] << 24);
+                    d[k] = (uint32_t)row[st * min(max(x + 4 * k, 0), sw1)] | ((uint32_t)row[st * min(max(x + 4 * k + 1, 0), sw1)] << 8) |
+                           ((uint32_t)row[st * min(max(x + 4 * k + 2, 0), sw1)] << 16) | ((uint32_t)row[st * min(max(x + 4 * k + 3, 0), sw1)] << 24);
                 w[q] = make_uint4(d[0], d[1], d[2], d[3]);
             }
             *reinterpret_cast<uint4*>(S + (size_t)r * s_stride + 16 * c16) =
@@ -525,7 +539,7 @@ __device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32
         vpk[k] = p.vpk[oy];
         vf[k] = p.vfirst[oy] - w.ry0;
     }
-    sc_stage<3>(p.src, p.src_stride, (int)p.sw, (int)p.sh, w, S, (int)a.s_stride, tid);   // launcher: s_rows <= 48, s_stride <= 256
+    sc_stage<3>(p.src, p.src_stride, (int)p.sw, (int)p.sh, w, S, (int)a.s_stride, tid, p.sxs, p.sxo);   // launcher: s_rows <= 48, s_stride <= 256
     __syncthreads();
     if (ox0 + oxi < (int)p.dw) {   // the two threads of a column take half of the row pairs each
         const int np = w.nr - 1, half = (np + 1) >> 1, part = tid >> 7;
@@ -582,7 +596,8 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint8_t* row = p.src + (size_t)min(max(vf + k, 0), sh1) * p.src_stride;
-        t[k] = (hc.x * (int)row[x0] + hc.y * (int)row[x1] + hc.z * (int)row[x2] + hc.w * (int)row[x3] + 64) >> 7;
+        const int st = 1 + (int)p.sxs; const uint8_t* rs = row + p.sxo;   // nv12 chroma: interleaved samples
+        t[k] = (hc.x * (int)rs[st * x0] + hc.y * (int)rs[st * x1] + hc.z * (int)rs[st * x2] + hc.w * (int)rs[st * x3] + 64) >> 7;
     }
     const int v = (vc.x * t[0] + vc.y * t[1] + vc.z * t[2] + vc.w * t[3] + (1 << 20)) >> 21;
     p.dst[(size_t)y * p.dst_stride + x] = (uint8_t)min(max(v, 0), 255);
@@ -680,7 +695,8 @@ __global__ __launch_bounds__(256) void k_scale_wide_h(ScaleArgs a) {
     const int32_t* c = p.hcoef + (size_t)x * p.hn;
     const int f = p.hfirst[x], sw1 = (int)p.sw - 1;
     int acc = 0;
-    for (uint32_t k = 0; k < p.hn; ++k) acc += c[k] * (int)row[min(max(f + (int)k, 0), sw1)];
+    const int st = 1 + (int)p.sxs;   // nv12 chroma: interleaved samples
+    for (uint32_t k = 0; k < p.hn; ++k) acc += c[k] * (int)row[p.sxo + st * min(max(f + (int)k, 0), sw1)];
     p.tmp[(size_t)y * p.dw + x] = (acc + 64) >> 7;
 }
 __global__ __launch_bounds__(256) void k_scale_wide_v(ScaleArgs a) {

@@ -78,19 +78,21 @@ void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_c
 // ---------------------------------------------------------------------------------------------
 static void alloc_planes(DFrame* f) {
     size_t off[3], total = 0;
-    for (int p = 0; p < 3; ++p) {
-        const uint32_t pw = f->pw(p), ph = f->ph(p);
-        f->stride[p] = (pw + 63u) & ~63u;               // rows 64-byte aligned (the reference asserts 32, video_mixer.rs:196-201)
+    const int np = f->stored_planes();
+    for (int p = 0; p < np; ++p) {
+        const uint32_t rb = f->stored_row_bytes(p), ph = f->ph(p);
+        f->stride[p] = (rb + 63u) & ~63u;               // rows 64-byte aligned (the reference asserts 32, video_mixer.rs:196-201)
         f->plane_bytes[p] = (size_t)f->stride[p] * ph;
         off[p] = total;
         total += (f->plane_bytes[p] + 255) & ~(size_t)255;
     }
     f->mem.alloc(total);
-    for (int p = 0; p < 3; ++p) f->data[p] = (uint8_t*)f->mem.p + off[p];
+    for (int p = 0; p < np; ++p) f->data[p] = (uint8_t*)f->mem.p + off[p];
+    if (np == 2) { f->data[2] = f->data[1]; f->stride[2] = f->stride[1]; f->plane_bytes[2] = 0; }   // nv12: V = the odd bytes of the UV plane
 }
 
 DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
-    if (fmt > MX_PIXFMT_YUV444P) throw Error(MX_ERR_INVALID, "unknown pixel format");
+    if (fmt > MX_PIXFMT_NV12) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
     f->fmt = fmt;
     if (w == 0 || h == 0 || (w & ((1u << f->cw()) - 1u)) || (h & ((1u << f->chs()) - 1u)))
@@ -186,7 +188,7 @@ void fill_chain_rgba_sources(const LazyChain& c, ChainRgbaArgs& a, hipStream_t s
     const bool no_inline = !(inl && atoi(inl) != 0);
     auto take = [&](const FrameRef& f, uint32_t k) {
         if (!f || !f->lazy_scale) return;
-        if (no_inline || a.n_scaled == MX_CHAIN_MAX_SCALED || !f->lazy_scale->t->four_tap || !f->lazy_scale->src->data[0]) { f->ensure_pixels(s); return; }
+        if (no_inline || a.n_scaled == MX_CHAIN_MAX_SCALED || !f->lazy_scale->t->four_tap || !f->lazy_scale->src->data[0] || f->lazy_scale->src->semi()) { f->ensure_pixels(s); return; }
         chain_scale_of(*f->lazy_scale, a.sc[a.n_scaled]);
         a.scaled_src[a.n_scaled++] = k;
     };
@@ -414,7 +416,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     in_w_ = in_w; in_h_ = in_h; in_fmt_ = in_fmt;
     auto t = std::make_shared<ScaleTables>();
     t->in_w = in_w; t->in_h = in_h; t->out_w = out_w_; t->out_h = out_h_;
-    t->in_cw = in_fmt == MX_PIXFMT_YUV444P ? 0u : 1u; t->in_ch = in_fmt == MX_PIXFMT_YUV420P ? 1u : 0u;
+    t->in_cw = in_fmt == MX_PIXFMT_YUV444P ? 0u : 1u; t->in_ch = (in_fmt == MX_PIXFMT_YUV420P || in_fmt == MX_PIXFMT_NV12) ? 1u : 0u;
     const uint32_t src_w[2] = {in_w, in_w >> t->in_cw}, src_h[2] = {in_h, in_h >> t->in_ch};   // the planes of the input format
     t->geo = scaler_geometry(in_w, in_h, out_w_, out_h_);
     const ScaleGeometry& geo = t->geo;
@@ -475,6 +477,7 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
         sp.hn = t.taps[c][0]; sp.vn = t.taps[c][1]; sp.tmp = tmp_plane ? tmp_plane[p] : nullptr;
         sp.h_row0 = 0; sp.h_rows = sp.sh;
         sp.hpk = t.hpk[c]; sp.vpk = t.vpk[c]; sp.oy_base = 0; sp.dh_full = 0;
+        sp.sxs = in->xstep(p) - 1u; sp.sxo = in->xoff(p);
     }
     if (tmp_plane && tmp_plane[0]) {        // widened kernel (downscale): two passes, launched in stream order
         flush_scales(s);

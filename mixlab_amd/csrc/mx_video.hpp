@@ -31,6 +31,7 @@ struct ScalePlane {
     int32_t* tmp;                                  // wide path only: [sh][dw] H-filtered rows
     uint32_t h_row0, h_rows;                       // wide path only: the source rows the H pass filters (a row band reads a slice of the plane)
     const uint2* hpk; const uint2* vpk;            // tiled path: packed taps (ScaleTables::lean), nullptr = not available
+    uint32_t sxs, sxo;                             // source samples are (1 + sxs) bytes apart starting at byte sxo of a row (nv12 chroma: 1, 0 | 1)
     uint32_t oy_base, dh_full;                     // tiled path, row bands: index of dst's first row in rows of the scaled plane, and that plane's full height (0 = dh)
 };
 struct ScaleArgs { ScalePlane p[3]; };
@@ -161,7 +162,13 @@ struct DFrame {
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
     uint32_t cw() const { return fmt == MX_PIXFMT_YUV444P ? 0u : 1u; }    // log2_chroma_w, pixfmt.rs:97-100
-    uint32_t chs() const { return fmt == MX_PIXFMT_YUV420P ? 1u : 0u; }   // log2_chroma_h, pixfmt.rs:102-105
+    uint32_t chs() const { return (fmt == MX_PIXFMT_YUV420P || fmt == MX_PIXFMT_NV12) ? 1u : 0u; }   // log2_chroma_h, pixfmt.rs:102-105
+    // nv12: the two chroma "planes" are the even / odd bytes of ONE stored plane (data[1]; data[2] aliases it): samples xstep bytes apart from xoff
+    bool semi() const { return fmt == MX_PIXFMT_NV12; }
+    uint32_t xstep(int p) const { return (semi() && p) ? 2u : 1u; }
+    uint32_t xoff(int p) const { return (semi() && p == 2) ? 1u : 0u; }
+    int stored_planes() const { return semi() ? 2 : 3; }
+    uint32_t stored_row_bytes(int p) const { return (semi() && p == 1) ? width : pw(p); }
     uint8_t* data[3] = {nullptr, nullptr, nullptr};
     uint32_t stride[3] = {0, 0, 0};
     size_t plane_bytes[3] = {0, 0, 0};

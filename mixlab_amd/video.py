@@ -112,7 +112,7 @@ def _host_frame(planes, w, h):
     """abi.Frame over three contiguous uint8 plane arrays (rows = plane height, stride = array row length)."""
     f = abi.Frame()
     f.width, f.height = w, h
-    for p in range(3):
+    for p in range(len(planes)):
         a = planes[p]
         assert a.dtype == np.uint8 and a.flags.c_contiguous and a.ndim == 2
         f.data[p] = a.ctypes.data
@@ -120,7 +120,7 @@ def _host_frame(planes, w, h):
     return f
 
 
-PIXFMT_YUV420P, PIXFMT_YUV422P, PIXFMT_YUV444P = 0, 1, 2   # mx_pixfmt
+PIXFMT_YUV420P, PIXFMT_YUV422P, PIXFMT_YUV444P, PIXFMT_NV12 = 0, 1, 2, 3   # mx_pixfmt (nv12: plane 1 = interleaved U,V, no plane 2)
 
 
 class DFrame:
@@ -136,7 +136,7 @@ class DFrame:
         f = C.c_int()
         check(lib.mx_dframe_format(self._h, C.byref(f)))
         self.fmt = f.value
-        self.cw, self.ch = (0 if self.fmt == PIXFMT_YUV444P else 1), (1 if self.fmt == PIXFMT_YUV420P else 0)
+        self.cw, self.ch = (0 if self.fmt == PIXFMT_YUV444P else 1), (1 if self.fmt in (PIXFMT_YUV420P, PIXFMT_NV12) else 0)
         w, h = C.c_uint32(), C.c_uint32()
         self._data = (C.c_void_p * 3)()
         self._stride = (C.c_int32 * 3)()
@@ -158,14 +158,18 @@ class DFrame:
         except Exception:
             pass
 
-    def upload(self, y, u, v):
-        planes = [np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v)]
+    def upload(self, y, u, v=None):
+        """planar formats: (y, u, v); nv12: (y, uv) with uv the interleaved chroma rows of `width` bytes"""
+        planes = [np.ascontiguousarray(a, dtype=np.uint8) for a in ((y, u) if self.fmt == PIXFMT_NV12 else (y, u, v))]
         hf = _host_frame(planes, self.width, self.height)
         check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
         return self
 
     def download(self):
-        planes = [np.empty((self.height >> (self.ch if p else 0), self.width >> (self.cw if p else 0)), np.uint8) for p in range(3)]
+        if self.fmt == PIXFMT_NV12:
+            planes = [np.empty((self.height, self.width), np.uint8), np.empty((self.height >> 1, self.width), np.uint8)]
+        else:
+            planes = [np.empty((self.height >> (self.ch if p else 0), self.width >> (self.cw if p else 0)), np.uint8) for p in range(3)]
         hf = _host_frame(planes, self.width, self.height)
         check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
         return planes

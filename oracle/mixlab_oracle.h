@@ -153,12 +153,12 @@ typedef struct {
     uint32_t width, height;     /* luma dimensions (codec/src/ffmpeg/frame.rs:180-186) */
     uint8_t* data[3];           /* Y, U, V plane bases (frame.rs:188-197) */
     int32_t stride[3];          /* bytes per row, multiple of 32 (video_mixer.rs:196-201) */
-    uint32_t fmt;               /* 0 = yuv420p (everything the VideoMixer produces, video_mixer.rs:282-283), 1 = yuv422p, 2 = yuv444p:
+    uint32_t fmt;               /* 0 = yuv420p (everything the VideoMixer produces, video_mixer.rs:282-283), 1 = yuv422p, 2 = yuv444p, 3 = nv12 (data[1] = interleaved UV, data[2] unused):
                                    formats a scaler INPUT may have (codec/src/ffmpeg/scale.rs:16-39 carries the input pixel format) */
 } orc_frame;
 /* chroma subsampling of a format (codec/src/ffmpeg/pixfmt.rs:97-105) */
 static inline uint32_t orc_fmt_cw(uint32_t fmt) { return fmt == 2 ? 0u : 1u; }
-static inline uint32_t orc_fmt_ch(uint32_t fmt) { return fmt == 0 ? 1u : 0u; }
+static inline uint32_t orc_fmt_ch(uint32_t fmt) { return (fmt == 0 || fmt == 3) ? 1u : 0u; }
 
 /* codec/src/ffmpeg/frame.rs:76-138: Y=0x00, U=V=0x80 over stride*(h-1)+w bytes of each plane */
 void orc_frame_blank(orc_frame* f);
@@ -177,6 +177,8 @@ void orc_scaler_geometry(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t 
 /* taps per output sample on one axis: 4, or 2*ceil(2*src/dst)+2 when downscaling (widened kernel) */
 uint32_t orc_bicubic_tap_count(uint32_t src, uint32_t dst);
 void orc_bicubic_taps_n(uint32_t o, uint32_t src, uint32_t dst, int32_t* first, int32_t* coef);
+void orc_scale_plane_bicubic_step(const uint8_t* src, int32_t src_stride, uint32_t xstep, uint32_t sw, uint32_t sh,
+                                  uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh);
 void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
                              uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh);
 /* BUILD-SPECIFIED row-band forms (multi-GPU sharding of one picture): rows [row0, row0 + rows) of the same

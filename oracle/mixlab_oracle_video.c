@@ -159,6 +159,11 @@ void orc_bicubic_taps_n(uint32_t o, uint32_t src, uint32_t dst, int32_t* first, 
 
 void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw, uint32_t sh,
                              uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh) {
+    orc_scale_plane_bicubic_step(src, src_stride, 1, sw, sh, dst, dst_stride, dw, dh);
+}
+/* the same with source samples `xstep` bytes apart (the interleaved chroma plane of nv12: U at even, V at odd bytes) */
+void orc_scale_plane_bicubic_step(const uint8_t* src, int32_t src_stride, uint32_t xstep, uint32_t sw, uint32_t sh,
+                                  uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh) {
     const uint32_t hn = orc_bicubic_tap_count(sw, dw), vn = orc_bicubic_tap_count(sh, dh);
     int32_t* hfirst = (int32_t*)malloc(sizeof(int32_t) * dw);
     int32_t* hc = (int32_t*)malloc(sizeof(int32_t) * hn * dw);
@@ -168,7 +173,7 @@ void orc_scale_plane_bicubic(const uint8_t* src, int32_t src_stride, uint32_t sw
         const uint8_t* row = src + (size_t)y * src_stride;
         for (uint32_t x = 0; x < dw; x++) {
             int32_t acc = 0;
-            for (uint32_t k = 0; k < hn; k++) acc += hc[(size_t)hn * x + k] * (int32_t)row[clampi(hfirst[x] + (int32_t)k, 0, (int32_t)sw - 1)];
+            for (uint32_t k = 0; k < hn; k++) acc += hc[(size_t)hn * x + k] * (int32_t)row[(size_t)xstep * (size_t)clampi(hfirst[x] + (int32_t)k, 0, (int32_t)sw - 1)];
             tmp[(size_t)y * dw + x] = (acc + 64) >> 7;
         }
     }
@@ -266,7 +271,10 @@ void orc_dynamic_scale(const orc_frame* in, orc_frame* out) {
         uint8_t* dst = out->data[p] + (size_t)(g.letterbox_y >> sh_) * out->stride[p] + (g.letterbox_x >> sh_);
         /* BUILD-SPECIFIED format conversion: every plane is resampled from ITS size in the input format to its size in the yuv420p output */
         uint32_t sw = p ? in->width >> orc_fmt_cw(in->fmt) : in->width, sh = p ? in->height >> orc_fmt_ch(in->fmt) : in->height;
-        orc_scale_plane_bicubic(in->data[p], in->stride[p], sw, sh, dst, out->stride[p], g.scaled_w >> sh_, g.scaled_h >> sh_);
+        if (in->fmt == 3 && p)   /* nv12: both chroma planes live interleaved in data[1] (U even bytes, V odd bytes) */
+            orc_scale_plane_bicubic_step(in->data[1] + (p - 1), in->stride[1], 2, sw, sh, dst, out->stride[p], g.scaled_w >> sh_, g.scaled_h >> sh_);
+        else
+            orc_scale_plane_bicubic(in->data[p], in->stride[p], sw, sh, dst, out->stride[p], g.scaled_w >> sh_, g.scaled_h >> sh_);
     }
 }
 

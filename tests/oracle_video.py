@@ -36,25 +36,36 @@ def align(v, a):
 
 
 class HostFrame:
-    """planar YUV frame (fmt 0 yuv420p -- the default and everything a VideoMixer produces --, 1 yuv422p, 2 yuv444p) in host memory with
-    64-byte-aligned strides (padding zero-initialised)."""
+    """YUV frame (fmt 0 yuv420p -- the default and everything a VideoMixer produces --, 1 yuv422p, 2 yuv444p, 3 nv12: plane 1 = interleaved
+    U,V, no plane 2) in host memory with 64-byte-aligned strides (padding zero-initialised)."""
 
     def __init__(self, w, h, fmt=0):
         self.w, self.h, self.fmt = w, h, fmt
-        self.cw, self.ch = (0 if fmt == 2 else 1), (1 if fmt == 0 else 0)
-        self.planes = [np.zeros((h >> (self.ch if p else 0), align(w >> (self.cw if p else 0), 64)), np.uint8) for p in range(3)]
+        self.cw, self.ch = (0 if fmt == 2 else 1), (1 if fmt in (0, 3) else 0)
+        if fmt == 3:
+            self.planes = [np.zeros((h, align(w, 64)), np.uint8), np.zeros((h >> 1, align(w, 64)), np.uint8)]
+        else:
+            self.planes = [np.zeros((h >> (self.ch if p else 0), align(w >> (self.cw if p else 0), 64)), np.uint8) for p in range(3)]
         self.c = OFrame()
         self.c.width, self.c.height, self.c.fmt = w, h, fmt
-        for p in range(3):
+        for p in range(len(self.planes)):
             self.c.data[p] = self.planes[p].ctypes.data
             self.c.stride[p] = self.planes[p].shape[1]
 
     def visible(self):
+        if self.fmt == 3:
+            return [self.planes[0][:, : self.w], self.planes[1][:, : self.w]]
         return [self.planes[p][:, : self.w >> (self.cw if p else 0)] for p in range(3)]
 
     def fill(self, layer, seed=0):
-        """SURVEY.md section 8d config 4 pattern: Y(x,y) = (x + 2y + 31*layer + LCG noise) mod 256, U/V similar at half res."""
+        """SURVEY.md section 8d config 4 pattern: Y(x,y) = (x + 2y + 31*layer + LCG noise) mod 256, U/V similar at chroma resolution."""
         import synth
+        if self.fmt == 3:
+            y, u, v = synth.yuv_pattern(self.w, self.h, layer, seed, 0)
+            self.planes[0][:, : self.w] = y
+            self.planes[1][:, 0: self.w: 2] = u
+            self.planes[1][:, 1: self.w: 2] = v
+            return self
         for p, a in enumerate(synth.yuv_pattern(self.w, self.h, layer, seed, self.fmt)):
             self.planes[p][:, : a.shape[1]] = a
         return self

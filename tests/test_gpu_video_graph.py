@@ -109,7 +109,7 @@ def test_mixer_inputs_of_other_pixel_formats(inline, monkeypatch):
     """Layers arrive as yuv422p / yuv444p (decoders produce them): each VideoMixer channel's scaler converts while it fits the layer into
     the yuv420p output picture -- also when the layer already has the output's size (encode.rs:342-352 compares the whole settings)."""
     monkeypatch.setenv("MX_SCALE_INLINE", inline)
-    spec = [((320, 180), 0), ((320, 180), 2), ((160, 90), 1), ((320, 180), 1), ((212, 120), 2), ((640, 360), 2)]
+    spec = [((320, 180), 0), ((320, 180), 2), ((160, 90), 1), ((320, 180), 3), ((212, 120), 3), ((640, 360), 2), ((640, 360), 3)]
     ws, srcs, mixers, rgba = cascade([s for s, _ in spec], MATRIX)
     g = ws.build(max_ticks_per_run=4)
     layers = [ov.HostFrame(w, h, fmt).fill(k, seed=6) for k, ((w, h), fmt) in enumerate(spec)]
@@ -347,7 +347,7 @@ def test_random_cascade_scenarios_in_random_batches(seed, inline, monkeypatch):
         for k in range(n_layers):
             if (t == 0 and k == 0) or rng.random() < 0.45:
                 w, h = sizes[int(rng.integers(len(sizes)))]
-                fmt = int(rng.integers(3)) if (w % 2 == 0 and h % 2 == 0) else 0
+                fmt = int(rng.integers(4)) if (w % 2 == 0 and h % 2 == 0) else 0
                 row[k] = (ov.HostFrame(w, h, fmt).fill(k, seed=int(rng.integers(1 << 12))), int(rng.integers(1, 4)))
         plan.append(row)
     keep = []

@@ -72,7 +72,7 @@ def test_dynamic_scale_letterbox_bit_exact_vs_build_spec(geom):
     assert_frame_equal(out, want, f"scale {geom}")
 
 
-@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV422P, video.PIXFMT_YUV444P], ids=["yuv422p", "yuv444p"])
+@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV422P, video.PIXFMT_YUV444P, video.PIXFMT_NV12], ids=["yuv422p", "yuv444p", "nv12"])
 @pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((320, 180), (320, 180)), ((640, 480), (1920, 1080)), ((1920, 1080), (560, 350)),
                                   ((66, 34), (640, 640)), ((1922, 1082), (1920, 1080))])
 def test_scaler_input_of_another_pixel_format_is_converted_plane_by_plane(geom, fmt):
@@ -89,6 +89,13 @@ def test_scaler_input_of_another_pixel_format_is_converted_plane_by_plane(geom, 
     out = video.DFrame(ow, oh)
     video.scale(dsrc, out)
     assert_frame_equal(out, want, f"scale {geom} fmt {fmt}")
+    if fmt == video.PIXFMT_NV12:                  # semi-planar is a storage layout: the same samples as planar 4:2:0 give the same picture
+        y, uv = src.visible()
+        planar = ov.HostFrame(iw, ih); planar.planes[0][:, :iw] = y; planar.planes[1][:, :iw // 2] = uv[:, 0::2]; planar.planes[2][:, :iw // 2] = uv[:, 1::2]
+        if (iw, ih) != (ow, oh):
+            ref = ov.HostFrame(ow, oh); ov.dynamic_scale(planar, ref)
+            for a, b in zip(want.visible(), ref.visible()):
+                assert np.array_equal(a, b)
     sc = video.Scaler(ow, oh)                     # the persistent scaler: the input is never "the frame itself" when its format differs
     res = sc.scale(dsrc)
     assert res.device_planes()[0] != dsrc.device_planes()[0]
