@@ -181,21 +181,27 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_mixer_coop(const MixDesc* __r
 
     // descriptors of my share of a batch: one channel per lane (lanes < PER), broadcast with v_readlane at use; channels past
     // the end repeat the last one with gain 0 and no cue (+0.0 terms).  Disconnected inputs point at the graph's zero buffer.
-    uint64_t p_nxt, g_nxt; uint32_t cue_nxt;
     const int prod = wave - 1;                                        // producer index of waves 1..15 (wave 0: -1, loads nothing)
-    auto fetch_desc = [&](uint32_t b) {
-        const uint32_t c = b * BATCH + (prod < 0 ? 0 : prod) * PER + (lane < PER ? lane : 0);
+    struct Desc { uint64_t p, g; uint32_t cue; bool valid; };
+    struct Inflight { float v[PER][FW]; uint64_t g; uint32_t cue; };  // loads of one batch in flight + what landing them needs
+    // Nothing in the producers' steady state may sit under a condition or use a value the moment it is requested: the compiler's wait
+    // counters are exact only along straight-line code, and a conservative vmcnt(0) before every landing made each step one full
+    // memory latency long (measured: 1.7 us per batch of 120 channels whatever the prefetch depth; PMC: the waves waited 62 % of
+    // their cycles).  So: descriptors are requested a step before the loads that need them, three batches of samples are in flight,
+    // every request is unconditional (past the end the last channel is re-read and lands as +0.0), and the loop is unrolled by three
+    // so that register sets are named, not indexed.
+    auto fetch = [&](Desc& dsc, uint32_t b) {
+        const uint32_t c = b * BATCH + (uint32_t)prod * PER + (lane < PER ? lane : 0);
         const MixChan* mc = ch + (c < n_ch ? c : n_ch - 1);
-        p_nxt = (uint64_t)mc->in;
-        g_nxt = (uint64_t)__double_as_longlong(c < n_ch ? mc->gain : 0.0);
-        cue_nxt = (uint32_t)__ballot(c < n_ch && mc->cue != 0);
+        dsc.p = (uint64_t)mc->in;
+        dsc.g = (uint64_t)__double_as_longlong(mc->gain);
+        dsc.cue = mc->cue;
+        dsc.valid = c < n_ch;
     };
-    // loads of one batch in flight + what landing them needs; two sets: a batch has two iterations to arrive
-    struct Inflight { float v[PER][FW]; uint64_t g; uint32_t cue; };
-    Inflight A, B;
-    auto issue = [&](Inflight& st) {                                  // the batch whose descriptors fetch_desc() brought last
-        st.g = g_nxt; st.cue = cue_nxt;
-        const uint64_t pl = p_nxt;
+    auto issue = [&](Inflight& st, const Desc& dsc) {
+        st.g = dsc.valid ? dsc.g : (uint64_t)__double_as_longlong(0.0);
+        st.cue = (uint32_t)__ballot(dsc.valid && dsc.cue != 0);
+        const uint64_t pl = dsc.p;
 #pragma unroll
         for (int u = 0; u < PER; ++u) ldw<FW>(bcast_u64(pl, u), foff, st.v[u]);
     };
@@ -218,52 +224,63 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_mixer_coop(const MixDesc* __r
         }
     };
 
-    if (prod >= 0 && n_ch) {   // a Mixer with no channels (params_len 0) sharing the launch: nothing to fetch, its buses stay +0.0 (mixer.rs:54-55)
-        fetch_desc(0); issue(A);
-        if (n_batch > 1) { fetch_desc(1); issue(B); }
-        if (n_batch > 2) fetch_desc(2);
-        land(A, 0);
-    }
-    __syncthreads();
-
-    Slot acc;                                                         // {master[FW], cue[FW]}: both ordered sums in one packed add per channel
-#pragma unroll
-    for (int k = 0; k < 2 * FW; ++k) acc[k] = 0.f;                    // util::zero(master/cue), mixer.rs:54-55
-    // one step: batch b sits in LDS, `nx` holds batch b+1 in flight, `fr` is free; the descriptors of batch b+2 are fetched
-    auto step = [&](Inflight& fr, const Inflight& nx, uint32_t b) {
-        if (prod >= 0 && b + 2 < n_batch) { issue(fr); if (b + 3 < n_batch) fetch_desc(b + 3); }
-        if (wave == 0) {
-            const Slot* src = lds + (size_t)(b & 1) * BATCH * 64 + lane;
-            const uint32_t c0 = b * BATCH, cnt = n_ch - c0 < (uint32_t)BATCH ? n_ch - c0 : (uint32_t)BATCH;
-            uint32_t u = 0;
-            if (cnt >= 8) {                                           // groups of 8, the next group's LDS reads in flight under this group's adds
-                Slot t[8], nxt8[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = src[(size_t)j * 64];
-                for (; u + 16 <= cnt; u += 8) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) nxt8[j] = src[(size_t)(u + 8 + j) * 64];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += t[j];          // channel order
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t[j] = nxt8[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc += t[j];
-                u += 8;
+    if (wave != 0) {
+        // ---- producers ----
+        if (n_ch) {   // a Mixer with no channels (params_len 0) sharing the launch: nothing to fetch, its buses stay +0.0 (mixer.rs:54-55)
+            // ring of three: batch k travels in register set k % 3 (more sets were measured: no faster)
+            Desc D0, D1, D2; Inflight S0, S1, S2;
+            fetch(D0, 0); fetch(D1, 1); fetch(D2, 2);
+            issue(S0, D0); issue(S1, D1); issue(S2, D2);
+            fetch(D0, 3);
+            land(S0, 0);
+            __syncthreads();
+            // step s: descriptors of batch s + 4, samples of batch s + 3 (descriptors a step old), landing of batch s + 1 (samples two steps old)
+            auto step = [&](uint32_t s_, Inflight& sx, const Desc& dx, Desc& dy, const Inflight& sn) {
+                fetch(dy, s_ + 4);
+                issue(sx, dx);
+                if (s_ + 1 < n_batch) { land(sn, s_ + 1); __syncthreads(); }          // the other LDS buffer: wave 0 finished with it one barrier ago
+            };
+            for (uint32_t b = 0; b < n_batch; b += 3) {
+                step(b, S0, D0, D1, S1);
+                step(b + 1, S1, D1, D2, S2);
+                step(b + 2, S2, D2, D0, S0);
             }
-            for (; u < cnt; ++u) acc += src[(size_t)u * 64];
-        }
-        if (b + 1 < n_batch) {
-            if (prod >= 0) land(nx, b + 1);                           // the other buffer: wave 0 finished with it one barrier ago
+        } else {
             __syncthreads();
         }
-    };
-    for (uint32_t b = 0; b < n_batch; b += 2) {
-        step(A, B, b);
-        if (b + 1 < n_batch) step(B, A, b + 1);
+        return;
     }
-    if (wave == 0 && live) {
+
+    // ---- wave 0: the ordered sums ----
+    __syncthreads();
+    Slot acc;                                                         // {master[FW], cue[FW]}: both ordered sums in one packed add per channel (scalar add chains were measured: no faster)
+#pragma unroll
+    for (int k = 0; k < 2 * FW; ++k) acc[k] = 0.f;                    // util::zero(master/cue), mixer.rs:54-55
+    auto add_slot = [&](const Slot& t) { acc += t; };
+    for (uint32_t b = 0; b < n_batch; ++b) {
+        const Slot* src = lds + (size_t)(b & 1) * BATCH * 64 + lane;
+        const uint32_t c0 = b * BATCH, cnt = n_ch - c0 < (uint32_t)BATCH ? n_ch - c0 : (uint32_t)BATCH;
+        uint32_t u = 0;
+        if (cnt >= 8) {                                               // groups of 8, the next group's LDS reads in flight under this group's adds
+            Slot t[8], nxt8[8];
+#pragma unroll
+            for (int jx = 0; jx < 8; ++jx) t[jx] = src[(size_t)jx * 64];
+            for (; u + 16 <= cnt; u += 8) {
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) nxt8[jx] = src[(size_t)(u + 8 + jx) * 64];
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) add_slot(t[jx]);       // channel order
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) t[jx] = nxt8[jx];
+            }
+#pragma unroll
+            for (int jx = 0; jx < 8; ++jx) add_slot(t[jx]);
+            u += 8;
+        }
+        for (; u < cnt; ++u) add_slot(src[(size_t)u * 64]);
+        if (b + 1 < n_batch) __syncthreads();
+    }
+    if (live) {
         float2* om = reinterpret_cast<float2*>(m.master) + f0 + lane;
         float2* oc = reinterpret_cast<float2*>(m.cue) + f0 + lane;
         if constexpr (DUP) { *om = make_float2(acc[0], acc[0]); *oc = make_float2(acc[1], acc[1]); }   // L == R inputs: one chain is both
