@@ -222,3 +222,20 @@ def test_spec_eq_inline_envelope_with_unusual_parameters_matches_the_oracle(env_
         assert np.array_equal(np.isnan(got[t * 2 * SPT:(t + 1) * 2 * SPT]), np.isnan(w)), f"tick {t}: NaNs at different samples"
         assert_bit_exact(got[t * 2 * SPT:(t + 1) * 2 * SPT][ok], w[ok], f"tick {t} (envelope {env_p})")
     assert g.eq_spec_stats()[0] > 0
+
+
+def test_one_lane_per_instance_kernel_still_matches_the_oracle():
+    """Short streams of FEW instances now take the split-cascade path (k_eq_three_poles + k_eq_three_emit); k_eq_three_exact -- one lane
+    per instance -- remains the path of short streams with thousands of instances (bench.py's 10 240-strip real-time graph).  The
+    switch is read once per process, so the one-lane kernel is exercised by a child pytest with MX_EQ_POLES_BELOW=0 over the tests that
+    pin EqThree: the reference's golden pair, state carried across calls, and the config-2 strips at both rates."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MX_EQ_POLES_BELOW="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_audio_parity.py"), "-k", "eq_three or config2_strips_exact or config1"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
