@@ -34,7 +34,8 @@ enum {
     MX_ERR_TYPE = -2,     /* port line-type mismatch: the reference panics (src/engine/io.rs:40-41,49-50) or refuses the connection (src/engine/workspace.rs:97-114) */
     MX_ERR_DEVICE = -3,   /* HIP runtime error */
     MX_ERR_NOMEM = -4,
-    MX_ERR_INTERNAL = -5  /* C++ exception caught at the boundary ("panic") */
+    MX_ERR_INTERNAL = -5, /* C++ exception caught at the boundary ("panic") */
+    MX_ERR_FULL = -6      /* a bounded ingest queue is full: where the reference's sender blocks (sync_channel) or gets Err (ring push) */
 };
 
 /* ---- line types: protocol LineType, src/engine/io.rs:19-24 ---- */
@@ -334,6 +335,78 @@ int mx_graph_set_video_source_ring(mx_graph* g, uint32_t node, mx_dframe* const*
  * on the graph's stream.  band_rows = 0 removes the transform. */
 int mx_graph_set_video_source_band(mx_graph* g, uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows,
                                    uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows);
+/* One frame due on one tick of a SOURCE_VIDEO node: tick `tick` (absolute, as in mx_graph_run_ticks' first_tick + k) emits `frame` with the
+ * given duration hint and tick offset; ticks without an entry emit None.  Entries are queued in ascending tick order, one per tick
+ * (MX_ERR_INVALID otherwise), and while any is queued they take the place of mx_graph_set_video_source[_ring].  What
+ * mx_media_source_feed / mx_stream_input_feed use; the graph retains the frame until its tick has run. */
+int mx_graph_queue_video_source(mx_graph* g, uint32_t node, uint64_t tick, mx_dframe* frame, int64_t dur_num, int64_t dur_den,
+                                int64_t off_num, int64_t off_den);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* timed ingest: decoded frames with rational timestamps enter the engine  */
+/* ---------------------------------------------------------------------------------------------- */
+
+/* MediaSource::run_tick (src/module/media_source.rs:93-126): the decode thread sends (frame, pts, duration) over a channel of TWO
+ * (sync_channel(2), :140); every tick takes at most one frame off the channel, moves its pts by the epoch -- the engine time of the
+ * tick the FIRST frame was received on (:104-107) -- and emits the oldest buffered frame once its pts lies before the end of the tick
+ * (:113-121), with tick_offset = pts - start of tick (negative for a late frame).  Timestamps are exact rationals in seconds
+ * (util/src/time.rs:10-75); sample_rate / ticks_per_second 0 => 44100 / 60 (src/engine.rs:53-54). */
+typedef struct mx_media_source mx_media_source;
+int mx_media_source_create(uint32_t sample_rate, uint32_t ticks_per_second, mx_media_source** out);
+void mx_media_source_destroy(mx_media_source* m);
+/* MediaSourceEvent::SetMedia (:85-91): present = 1 installs a fresh OpenMedia (empty channel, no epoch, empty buffer, :140-147), 0 = None. */
+int mx_media_source_set_media(mx_media_source* m, int present);
+/* the decode thread's tx.send (:271): MX_ERR_FULL while two frames wait (the reference blocks), MX_ERR_INVALID without media (the
+ * reference's thread ends, :272-276).  The source retains the frame.  Safe from another thread than the run_tick caller. */
+int mx_media_source_send(mx_media_source* m, mx_dframe* frame, int64_t pts_num, int64_t pts_den, int64_t dur_num, int64_t dur_den);
+/* One run_tick at engine time t (samples).  out->frame NULL = None; else it carries one reference for the caller. */
+int mx_media_source_run_tick(mx_media_source* m, uint64_t t, mx_video_input* out);
+/* n_ticks run_tick calls for ticks first_tick .. first_tick + n_ticks - 1, their frames queued on SOURCE_VIDEO `node`
+ * (mx_graph_queue_video_source) for the mx_graph_run_ticks(first_tick, n_ticks) that follows. */
+int mx_media_source_feed(mx_media_source* m, mx_graph* g, uint32_t node, uint64_t first_tick, uint32_t n_ticks);
+
+/* StreamInput::run_tick (src/module/stream_input.rs:72-147) with both of its rings (src/source.rs:97-98, 65536 frames each): audio
+ * frames (source id, source time, i16 samples of any length) are re-blocked to ticks exactly as mx_pcm_ring does; a frame from a source
+ * id other than the one the tick started with re-bases the epoch = engine time - its source time (:100-106); the next video frame is due
+ * at tick_offset = source time + epoch - engine time (< 0 or no source yet => 0, :127-133) and is held back while that lies beyond the
+ * tick (:135-138). */
+typedef struct mx_stream_input mx_stream_input;
+int mx_stream_input_create(uint32_t sample_rate, mx_stream_input** out);
+void mx_stream_input_destroy(mx_stream_input* s);
+/* StreamInput::update with another mountpoint (:57-70): listening = 1 replaces both rings by empty ones, 0 leaves none (every write is
+ * MX_ERR_FULL, every tick reads silence); the held frames and the source timing stay. */
+int mx_stream_input_listen(mx_stream_input* s, int listening);
+/* SourceSend::write_audio / write_video (src/source.rs:158-190); source_id != 0 (NonZeroUsize, :35).  MX_ERR_FULL = Err(()).
+ * Safe from another thread than the run_tick caller. */
+int mx_stream_input_write_audio(mx_stream_input* s, uint64_t source_id, int64_t ts_num, int64_t ts_den, const int16_t* interleaved, size_t n_samples);
+int mx_stream_input_write_video(mx_stream_input* s, uint64_t source_id, int64_t ts_num, int64_t ts_den, mx_dframe* frame, int64_t dur_num, int64_t dur_den);
+/* One run_tick at engine time t: audio_out[n_out] (n_out = 2 * SPT) receives the tick's interleaved i16 samples -- convert_sample's
+ * input (:167-173) -- zero where the queue ran dry (*zero_filled samples); video_out as in mx_media_source_run_tick.  Host only. */
+int mx_stream_input_run_tick(mx_stream_input* s, uint64_t t, int16_t* audio_out, size_t n_out, mx_video_input* video_out, size_t* zero_filled);
+/* n_ticks run_tick calls: audio into SOURCE_STEREO `audio_node` (H2D as i16 from page-locked memory, / 32768 on the device), frames
+ * queued on SOURCE_VIDEO `video_node` (UINT32_MAX = the video output is not connected). */
+int mx_stream_input_feed(mx_stream_input* s, mx_graph* g, uint32_t audio_node, uint32_t video_node, uint64_t first_tick, uint32_t n_ticks,
+                         size_t* zero_filled);
+
+/* H2D staging ring for decoded frames (the reference moves frames between threads through rings, src/source.rs:97-98): `upload` packs the
+ * host planes into the next page-locked slot, laid out like the device frame, and sends it as ONE asynchronous copy on the stager's own
+ * stream; *out is a device frame (one reference for the caller) from a pool -- a frame nobody holds any more is written again, after
+ * what the last fenced stream has queued.  A consumer stream must be fenced before it reads frames uploaded since the last fence.
+ * A slot is reused only once its copy has completed (upload blocks until then): `slots` bounds the frames in flight. */
+typedef struct mx_frame_stager mx_frame_stager;
+int mx_frame_stager_create(uint32_t slots, mx_frame_stager** out);
+void mx_frame_stager_destroy(mx_frame_stager* st);
+int mx_frame_stager_upload(mx_frame_stager* st, const mx_frame* host, mx_pixfmt fmt, mx_dframe** out);
+/* The copy-free form, for a decoder that can be given its picture buffers (AVCodecContext.get_buffer2): `acquire` hands out the plane
+ * pointers and strides of a page-locked slot (rows 64-byte aligned, padding already blank), the decoder writes the picture there, `commit`
+ * sends the slot as one asynchronous copy and returns the device frame.  Several slots may be held at once (reference pictures);
+ * MX_ERR_FULL when all are.  A slot's memory is the caller's from acquire until commit. */
+int mx_frame_stager_acquire(mx_frame_stager* st, uint32_t width, uint32_t height, mx_pixfmt fmt, mx_frame* host, uint32_t* ticket);
+int mx_frame_stager_commit(mx_frame_stager* st, uint32_t ticket, mx_dframe** out);
+int mx_frame_stager_fence(mx_frame_stager* st, void* stream);
+int mx_frame_stager_fence_graph(mx_frame_stager* st, mx_graph* g);
+int mx_frame_stager_sync(mx_frame_stager* st);
+
 /* Output port of a video node after the last tick: one reference for the caller, NULL = None. */
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out);
 /* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame). */

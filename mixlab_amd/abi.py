@@ -21,7 +21,7 @@ if not LIB_PATH.exists():
 lib = C.CDLL(str(LIB_PATH))
 
 # ---- constants (include/mixlab_gpu.h) ----
-MX_OK, MX_ERR_INVALID, MX_ERR_TYPE, MX_ERR_DEVICE, MX_ERR_NOMEM, MX_ERR_INTERNAL = 0, -1, -2, -3, -4, -5
+MX_OK, MX_ERR_INVALID, MX_ERR_TYPE, MX_ERR_DEVICE, MX_ERR_NOMEM, MX_ERR_INTERNAL, MX_ERR_FULL = 0, -1, -2, -3, -4, -5, -6
 MX_DISCONNECTED, MX_MONO, MX_STEREO, MX_VIDEO = 0, 1, 2, 3
 (KIND_AMPLIFIER, KIND_ENVELOPE, KIND_EQ_THREE, KIND_FM_SINE, KIND_MIXER, KIND_OSCILLATOR, KIND_PLOTTER,
  KIND_STEREO_PANNER, KIND_STEREO_SPLITTER, KIND_TRIGGER, KIND_VIDEO_MIXER, KIND_SOURCE_MONO,

@@ -321,7 +321,7 @@ Graph::~Graph() {
     if (tail_stream_) (void)hipStreamSynchronize(tail_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (tail_stream_) { (void)hipStreamDestroy(tail_stream_); (void)hipEventDestroy(ev_head_done_); for (auto& e : ev_tail_done_) (void)hipEventDestroy(e); }
-    for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); n.vsrc_ring.clear(); }
+    for (Node& n : nodes_) { n.vmixer.reset(); n.vout.clear(); n.vsrc = FrameRef(); n.vsrc_ring.clear(); n.vsrc_sched.clear(); }
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
     for (Stage& st : stage_) { if (st.done) (void)hipEventDestroy(st.done); if (st.host) (void)hipHostFree(st.host); }
@@ -1157,7 +1157,7 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
             nn.vmixer->rebind(stream_, nn.vlazy, tps_);   // the old graph's stream may be gone after this call; this graph's fusion plan and tick rate apply
             nn.vmixer->update(p);
         }
-        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc_ring = on.vsrc_ring; nn.vsrc_ring_pos = on.vsrc_ring_pos; nn.vband = on.vband; nn.vband_pool = on.vband_pool; nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
+        if (nn.kind == MX_KIND_SOURCE_VIDEO) { nn.vsrc_ring = on.vsrc_ring; nn.vsrc_ring_pos = on.vsrc_ring_pos; nn.vsrc_sched = on.vsrc_sched; nn.vband = on.vband; nn.vband_pool = on.vband_pool; nn.vsrc = on.vsrc; nn.vsrc_dur = on.vsrc_dur; nn.vsrc_off = on.vsrc_off; nn.vsrc_repeat = on.vsrc_repeat; nn.vsrc_pending = on.vsrc_pending; }
     }
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
@@ -1282,7 +1282,15 @@ void Graph::run_video_tick(uint64_t t) {
         case MX_KIND_SOURCE_VIDEO: {
             // Output::from_line_type(Video) = None every tick (io.rs:76); the source fills it when a frame is due
             n.vout[0] = Node::VOut{};
-            if (!n.vsrc_ring.empty()) {   // a decoder's stream: the next frame of the ring, every tick
+            const uint64_t tick = t / spt_;
+            while (!n.vsrc_sched.empty() && n.vsrc_sched.front().tick < tick) n.vsrc_sched.pop_front();   // a tick that was never run
+            if (!n.vsrc_sched.empty()) {   // paced ingest: the tick a MediaSource / StreamInput emitted the frame on, or None
+                if (n.vsrc_sched.front().tick == tick) {
+                    Node::VSched& e = n.vsrc_sched.front();
+                    n.vout[0].frame = e.frame; n.vout[0].dur = e.dur; n.vout[0].off = e.off;
+                    n.vsrc_sched.pop_front();
+                }
+            } else if (!n.vsrc_ring.empty()) {   // a decoder's stream: the next frame of the ring, every tick
                 n.vout[0].frame = n.vsrc_ring[n.vsrc_ring_pos]; n.vout[0].dur = n.vsrc_dur; n.vout[0].off = n.vsrc_off;
                 n.vsrc_ring_pos = (n.vsrc_ring_pos + 1) % n.vsrc_ring.size();
             } else if (n.vsrc && (n.vsrc_repeat || n.vsrc_pending)) {
@@ -1405,6 +1413,14 @@ void Graph::set_video_source_band(uint32_t node, uint32_t in_w, uint32_t in_full
     sync();                                     // a previous band scaler's row buffer may be in use
     nd.vband.reset(); nd.vband_pool.clear();
     if (band_rows) nd.vband = std::make_shared<BandScaler>(in_w, in_full_h, src_row0, slice_rows, full_w, full_h, row0, band_rows);
+}
+
+void Graph::queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rational dur, Rational off) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_SOURCE_VIDEO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_VIDEO");
+    if (!frame) throw Error(MX_ERR_INVALID, "frame is NULL");
+    Node& nd = nodes_[node];
+    if (!nd.vsrc_sched.empty() && nd.vsrc_sched.back().tick >= tick) throw Error(MX_ERR_INVALID, "video source frames must be queued in tick order, one per tick");
+    nd.vsrc_sched.push_back(Node::VSched{tick, FrameRef(frame, true), dur, off});
 }
 
 void Graph::set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off) {

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "mx_common.hpp"
@@ -57,6 +58,8 @@ struct Node {
     std::vector<VOut> vout;                   // this tick's video outputs (empty FrameRef = None)
     FrameRef vsrc; Rational vsrc_dur, vsrc_off; bool vsrc_repeat = false, vsrc_pending = false;   // SOURCE_VIDEO
     std::vector<FrameRef> vsrc_ring; size_t vsrc_ring_pos = 0;                                       // SOURCE_VIDEO: a new frame every tick, cycling
+    struct VSched { uint64_t tick; FrameRef frame; Rational dur, off; };
+    std::deque<VSched> vsrc_sched;                                                                   // SOURCE_VIDEO: frames due on given ticks (MediaSource / StreamInput pacing), oldest first
     std::shared_ptr<BandScaler> vband; std::vector<FrameRef> vband_pool;                             // SOURCE_VIDEO: frames are halo slices, delivered as this rank's row band of the scaled picture
     DevBuf rgba[2]; uint32_t rgba_cur = 0, rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;      // VIDEO_TO_RGBA: two buffers, written alternately (two ticks' chains may share a launch); rgba_cur = the last tick's
     struct PendingRgba { ChainRgbaArgs args; std::shared_ptr<LazyChain> keep; };
@@ -134,6 +137,7 @@ public:
     void set_video_source(uint32_t node, DFrame* frame, Rational dur, Rational off, bool repeat);
     void set_video_source_band(uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows, uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows);
     void set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off);
+    void queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rational dur, Rational off);
     FrameRef video_output(uint32_t node, uint32_t port);
     void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 

@@ -30,6 +30,10 @@ Rational Rational::operator+(const Rational& o) const {
     const int64_t lcm = den / g * o.den;
     return make(num * (lcm / den) + o.num * (lcm / o.den), lcm);
 }
+Rational Rational::operator-(const Rational& o) const {
+    Rational n = o; n.num = -n.num;
+    return *this + n;
+}
 bool Rational::operator>=(const Rational& o) const {
     return (__int128)num * o.den >= (__int128)o.num * den;
 }
@@ -91,7 +95,7 @@ static void alloc_planes(DFrame* f) {
     if (np == 2) { f->data[2] = f->data[1]; f->stride[2] = f->stride[1]; f->plane_bytes[2] = 0; }   // nv12: V = the odd bytes of the UV plane
 }
 
-DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
+DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
     if (fmt > MX_PIXFMT_NV12) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
     f->fmt = fmt;
@@ -100,6 +104,11 @@ DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
     if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
     f->width = w; f->height = h;
     alloc_planes(f.get());
+    return f.release();
+}
+
+DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
+    std::unique_ptr<DFrame> f(create_unfilled(w, h, fmt));
     launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s);
     return f.release();
 }

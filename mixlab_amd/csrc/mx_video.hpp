@@ -104,7 +104,10 @@ struct Rational {
     int64_t num = 0, den = 1;
     static Rational make(int64_t n, int64_t d);
     Rational operator+(const Rational& o) const;
+    Rational operator-(const Rational& o) const;
     bool operator>=(const Rational& o) const;
+    bool operator<(const Rational& o) const { return !(*this >= o); }
+    bool operator>(const Rational& o) const { return o < *this; }
 };
 
 // ---- device frame: the AvFrame<Video> stand-in (codec/src/ffmpeg/frame.rs) ----
@@ -174,6 +177,8 @@ struct DFrame {
     size_t plane_bytes[3] = {0, 0, 0};
     DevBuf mem;
     static DFrame* create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt = MX_PIXFMT_YUV420P);   // blank-filled (frame.rs:76-138)
+    static DFrame* create_unfilled(uint32_t w, uint32_t h, uint8_t fmt);   // planes allocated, contents undefined: for a caller that overwrites every byte (FrameStager)
+    size_t plane_offset(int p) const { return (size_t)(data[p] - (uint8_t*)mem.p); }
     void retain() { rc.fetch_add(1, std::memory_order_relaxed); }
     void release() { if (rc.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
     uint32_t pw(int p) const { return p ? width >> cw() : width; }

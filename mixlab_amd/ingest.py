@@ -1,0 +1,192 @@
+"""ctypes binding of the timed-ingest part of include/mixlab_gpu.h: MediaSource / StreamInput pacing and the frame staging ring
+(plumbing for tests; the host mirror of src/module/media_source.rs and src/module/stream_input.rs)."""
+from __future__ import annotations
+
+import ctypes as C
+from fractions import Fraction
+
+import numpy as np
+
+from . import abi
+from .abi import check, lib
+from .video import DFrame, VideoInput, _host_frame, PIXFMT_YUV420P, PIXFMT_NV12
+
+MX_ERR_FULL = -6
+NO_VIDEO_NODE = 0xFFFFFFFF
+
+
+def _proto(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+
+
+_I64 = C.c_int64
+_proto("mx_graph_queue_video_source", C.c_int, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, _I64, _I64, _I64, _I64)
+_proto("mx_media_source_create", C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p))
+_proto("mx_media_source_destroy", None, C.c_void_p)
+_proto("mx_media_source_set_media", C.c_int, C.c_void_p, C.c_int)
+_proto("mx_media_source_send", C.c_int, C.c_void_p, C.c_void_p, _I64, _I64, _I64, _I64)
+_proto("mx_media_source_run_tick", C.c_int, C.c_void_p, C.c_uint64, C.POINTER(VideoInput))
+_proto("mx_media_source_feed", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32)
+_proto("mx_stream_input_create", C.c_int, C.c_uint32, C.POINTER(C.c_void_p))
+_proto("mx_stream_input_destroy", None, C.c_void_p)
+_proto("mx_stream_input_listen", C.c_int, C.c_void_p, C.c_int)
+_proto("mx_stream_input_write_audio", C.c_int, C.c_void_p, C.c_uint64, _I64, _I64, C.c_void_p, C.c_size_t)
+_proto("mx_stream_input_write_video", C.c_int, C.c_void_p, C.c_uint64, _I64, _I64, C.c_void_p, _I64, _I64)
+_proto("mx_stream_input_run_tick", C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(VideoInput), C.POINTER(C.c_size_t))
+_proto("mx_stream_input_feed", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_size_t))
+_proto("mx_frame_stager_create", C.c_int, C.c_uint32, C.POINTER(C.c_void_p))
+_proto("mx_frame_stager_destroy", None, C.c_void_p)
+_proto("mx_frame_stager_upload", C.c_int, C.c_void_p, C.POINTER(abi.Frame), C.c_int, C.POINTER(C.c_void_p))
+_proto("mx_frame_stager_acquire", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(abi.Frame), C.POINTER(C.c_uint32))
+_proto("mx_frame_stager_commit", C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
+_proto("mx_frame_stager_fence", C.c_int, C.c_void_p, C.c_void_p)
+_proto("mx_frame_stager_fence_graph", C.c_int, C.c_void_p, C.c_void_p)
+_proto("mx_frame_stager_sync", C.c_int, C.c_void_p)
+
+
+def _q(x) -> tuple[int, int]:
+    f = Fraction(x) if not isinstance(x, tuple) else Fraction(x[0], x[1])
+    return f.numerator, f.denominator
+
+
+def _tick_video(v: VideoInput):
+    """-> None or (DFrame owning the returned reference, duration_hint, tick_offset) with exact Fractions"""
+    if not v.frame:
+        return None
+    return DFrame(handle=v.frame), Fraction(v.dur_num, v.dur_den), Fraction(v.off_num, v.off_den)
+
+
+def graph_queue_video_source(g, node, tick, frame, dur=(1, 60), off=(0, 1)):
+    d, o = _q(dur), _q(off)
+    check(lib.mx_graph_queue_video_source(g._h, node, tick, frame.handle, d[0], d[1], o[0], o[1]))
+
+
+class _Handle:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            getattr(lib, self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MediaSource(_Handle):
+    """MediaSource::run_tick (src/module/media_source.rs:93-126)."""
+    _destroy = "mx_media_source_destroy"
+
+    def __init__(self, sample_rate=44100, ticks_per_second=60):
+        self._h = C.c_void_p()
+        check(lib.mx_media_source_create(sample_rate, ticks_per_second, C.byref(self._h)))
+
+    def set_media(self, present=True):
+        check(lib.mx_media_source_set_media(self._h, 1 if present else 0))
+
+    def send(self, frame: DFrame, pts, dur) -> bool:
+        """False = the channel holds two frames already (the reference's decode thread blocks there)"""
+        p, d = _q(pts), _q(dur)
+        rc = lib.mx_media_source_send(self._h, frame.handle, p[0], p[1], d[0], d[1])
+        if rc == MX_ERR_FULL:
+            return False
+        check(rc)
+        return True
+
+    def run_tick(self, t: int):
+        v = VideoInput()
+        check(lib.mx_media_source_run_tick(self._h, t, C.byref(v)))
+        return _tick_video(v)
+
+    def feed(self, graph, node, first_tick, n_ticks):
+        check(lib.mx_media_source_feed(self._h, graph._h, node, first_tick, n_ticks))
+
+
+class StreamInput(_Handle):
+    """StreamInput::run_tick (src/module/stream_input.rs:72-147)."""
+    _destroy = "mx_stream_input_destroy"
+
+    def __init__(self, sample_rate=44100):
+        self._h = C.c_void_p()
+        check(lib.mx_stream_input_create(sample_rate, C.byref(self._h)))
+
+    def listen(self, listening=True):
+        check(lib.mx_stream_input_listen(self._h, 1 if listening else 0))
+
+    def write_audio(self, source_id, source_time, samples) -> bool:
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        t = _q(source_time)
+        rc = lib.mx_stream_input_write_audio(self._h, source_id, t[0], t[1], a.ctypes.data_as(C.c_void_p), a.size)
+        if rc == MX_ERR_FULL:
+            return False
+        check(rc)
+        return True
+
+    def write_video(self, source_id, source_time, frame: DFrame, dur) -> bool:
+        t, d = _q(source_time), _q(dur)
+        rc = lib.mx_stream_input_write_video(self._h, source_id, t[0], t[1], frame.handle, d[0], d[1])
+        if rc == MX_ERR_FULL:
+            return False
+        check(rc)
+        return True
+
+    def run_tick(self, t: int, n_out: int):
+        """-> (i16 samples [n_out], None or (frame, dur, off), samples zero-filled)"""
+        out = np.empty(n_out, np.int16)
+        v, z = VideoInput(), C.c_size_t()
+        check(lib.mx_stream_input_run_tick(self._h, t, out.ctypes.data_as(C.c_void_p), n_out, C.byref(v), C.byref(z)))
+        return out, _tick_video(v), z.value
+
+    def feed(self, graph, audio_node, video_node, first_tick, n_ticks) -> int:
+        z = C.c_size_t()
+        check(lib.mx_stream_input_feed(self._h, graph._h, audio_node, NO_VIDEO_NODE if video_node is None else video_node,
+                                       first_tick, n_ticks, C.byref(z)))
+        return z.value
+
+
+class FrameStager(_Handle):
+    """Page-locked H2D staging ring for decoded frames."""
+    _destroy = "mx_frame_stager_destroy"
+
+    def __init__(self, slots=4):
+        self._h = C.c_void_p()
+        check(lib.mx_frame_stager_create(slots, C.byref(self._h)))
+
+    def upload(self, planes, width, height, fmt=PIXFMT_YUV420P) -> DFrame:
+        ps = [np.ascontiguousarray(a, dtype=np.uint8) for a in planes]
+        assert len(ps) == (2 if fmt == PIXFMT_NV12 else 3)
+        hf = _host_frame(ps, width, height)
+        h = C.c_void_p()
+        check(lib.mx_frame_stager_upload(self._h, C.byref(hf), fmt, C.byref(h)))
+        return DFrame(handle=h.value)
+
+    def acquire(self, width, height, fmt=PIXFMT_YUV420P):
+        """-> (ticket, [numpy views of the slot's planes, rows x stride bytes]): write the picture into them, then commit(ticket)"""
+        hf, ticket = abi.Frame(), C.c_uint32()
+        check(lib.mx_frame_stager_acquire(self._h, width, height, fmt, C.byref(hf), C.byref(ticket)))
+        cw, ch = (0 if fmt == 2 else 1), (1 if fmt in (0, 3) else 0)
+        views = []
+        for p in range(2 if fmt == PIXFMT_NV12 else 3):
+            rows = height if p == 0 else height >> ch
+            buf = (C.c_uint8 * (rows * hf.stride[p])).from_address(hf.data[p])
+            views.append(np.frombuffer(buf, np.uint8).reshape(rows, hf.stride[p]))
+        return ticket.value, views
+
+    def commit(self, ticket) -> DFrame:
+        h = C.c_void_p()
+        check(lib.mx_frame_stager_commit(self._h, ticket, C.byref(h)))
+        return DFrame(handle=h.value)
+
+    def fence(self, stream=None):
+        check(lib.mx_frame_stager_fence(self._h, stream))
+
+    def fence_graph(self, graph):
+        check(lib.mx_frame_stager_fence_graph(self._h, graph._h))
+
+    def sync(self):
+        check(lib.mx_frame_stager_sync(self._h))

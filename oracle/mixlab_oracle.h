@@ -211,4 +211,21 @@ int orc_rational_cmp(orc_rational a, orc_rational b);
 #ifdef __cplusplus
 }
 #endif
+/* ---- timed ingest (mixlab_oracle_ingest.c): which frame leaves on which tick ---- */
+typedef struct { int64_t frame_id; orc_rational time; orc_rational duration_hint; } orc_timed_frame;       /* media_source.rs:151-155 */
+typedef struct { int64_t frame_id; /* 0 = None */ orc_rational duration_hint, tick_offset; } orc_tick_video;   /* engine::VideoFrame, io.rs:12-17 */
+typedef struct orc_media_source orc_media_source;
+orc_media_source* orc_media_source_new(uint32_t sample_rate, uint32_t ticks_per_second);
+void orc_media_source_free(orc_media_source* m);
+void orc_media_source_set_media(orc_media_source* m, int present);
+int orc_media_source_send(orc_media_source* m, int64_t frame_id, orc_rational pts, orc_rational duration_hint);   /* 1 sent, 0 would block, -1 no receiver */
+orc_tick_video orc_media_source_run_tick(orc_media_source* m, uint64_t t);
+typedef struct orc_stream_input orc_stream_input;
+orc_stream_input* orc_stream_input_new(uint32_t sample_rate);
+void orc_stream_input_free(orc_stream_input* s);
+void orc_stream_input_listen(orc_stream_input* s, int listening);
+int orc_stream_input_write_audio(orc_stream_input* s, uint64_t source_id, orc_rational source_time, const int16_t* data, size_t n);
+int orc_stream_input_write_video(orc_stream_input* s, uint64_t source_id, orc_rational source_time, int64_t frame_id, orc_rational duration_hint);
+orc_tick_video orc_stream_input_run_tick(orc_stream_input* s, uint64_t t, int16_t* audio_out, size_t n_out, size_t* zero_filled);
+
 #endif

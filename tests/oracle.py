@@ -233,3 +233,90 @@ def resample_run(taps2d, up, down, hist: np.ndarray, in_base, out_base, x: np.nd
     lib.orc_resample_run(_p(t), C.c_uint32(up), C.c_uint32(down), C.c_uint32(t.shape[1]), _p(hist), C.c_uint64(in_base), C.c_uint64(out_base),
                          _p(x), C.c_size_t(x.size // 2), _p(out), C.c_size_t(out_frames))
     return out
+
+
+# ---- timed ingest (oracle/mixlab_oracle_ingest.c) ----
+class TickVideo(C.Structure):
+    _fields_ = [("frame_id", C.c_int64), ("duration_hint", Rational), ("tick_offset", Rational)]
+
+
+lib.orc_media_source_new.restype = C.c_void_p
+lib.orc_media_source_new.argtypes = [C.c_uint32, C.c_uint32]
+lib.orc_media_source_free.argtypes = [C.c_void_p]
+lib.orc_media_source_set_media.argtypes = [C.c_void_p, C.c_int]
+lib.orc_media_source_send.restype = C.c_int
+lib.orc_media_source_send.argtypes = [C.c_void_p, C.c_int64, Rational, Rational]
+lib.orc_media_source_run_tick.restype = TickVideo
+lib.orc_media_source_run_tick.argtypes = [C.c_void_p, C.c_uint64]
+lib.orc_stream_input_new.restype = C.c_void_p
+lib.orc_stream_input_new.argtypes = [C.c_uint32]
+lib.orc_stream_input_free.argtypes = [C.c_void_p]
+lib.orc_stream_input_listen.argtypes = [C.c_void_p, C.c_int]
+lib.orc_stream_input_write_audio.restype = C.c_int
+lib.orc_stream_input_write_audio.argtypes = [C.c_void_p, C.c_uint64, Rational, C.c_void_p, C.c_size_t]
+lib.orc_stream_input_write_video.restype = C.c_int
+lib.orc_stream_input_write_video.argtypes = [C.c_void_p, C.c_uint64, Rational, C.c_int64, Rational]
+lib.orc_stream_input_run_tick.restype = TickVideo
+lib.orc_stream_input_run_tick.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+
+
+def _rat(x):
+    from fractions import Fraction
+    f = Fraction(x)
+    return lib.orc_rational_new(f.numerator, f.denominator)
+
+
+def _tick_video(v):
+    from fractions import Fraction
+    if v.frame_id == 0:
+        return None
+    return v.frame_id, Fraction(v.duration_hint.num, v.duration_hint.den), Fraction(v.tick_offset.num, v.tick_offset.den)
+
+
+class OMediaSource:
+    """orc_media_source_*: MediaSource::run_tick (src/module/media_source.rs:93-126) over opaque frame ids"""
+
+    def __init__(self, sample_rate=44100, ticks_per_second=60):
+        self._h = C.c_void_p(lib.orc_media_source_new(sample_rate, ticks_per_second))
+
+    def __del__(self):
+        if self._h:
+            lib.orc_media_source_free(self._h)
+            self._h = None
+
+    def set_media(self, present=True):
+        lib.orc_media_source_set_media(self._h, 1 if present else 0)
+
+    def send(self, frame_id, pts, dur):
+        return lib.orc_media_source_send(self._h, frame_id, _rat(pts), _rat(dur))   # 1 sent, 0 would block, -1 no receiver
+
+    def run_tick(self, t):
+        return _tick_video(lib.orc_media_source_run_tick(self._h, t))
+
+
+class OStreamInput:
+    """orc_stream_input_*: StreamInput::run_tick (src/module/stream_input.rs:72-147) over opaque frame ids"""
+
+    def __init__(self, sample_rate=44100):
+        self._h = C.c_void_p(lib.orc_stream_input_new(sample_rate))
+
+    def __del__(self):
+        if self._h:
+            lib.orc_stream_input_free(self._h)
+            self._h = None
+
+    def listen(self, listening=True):
+        lib.orc_stream_input_listen(self._h, 1 if listening else 0)
+
+    def write_audio(self, source_id, source_time, samples):
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        return lib.orc_stream_input_write_audio(self._h, source_id, _rat(source_time), a.ctypes.data_as(C.c_void_p), a.size) == 1
+
+    def write_video(self, source_id, source_time, frame_id, dur):
+        return lib.orc_stream_input_write_video(self._h, source_id, _rat(source_time), frame_id, _rat(dur)) == 1
+
+    def run_tick(self, t, n_out):
+        out = np.empty(n_out, np.int16)
+        z = C.c_size_t()
+        v = lib.orc_stream_input_run_tick(self._h, t, out.ctypes.data_as(C.c_void_p), n_out, C.byref(z))
+        return out, _tick_video(v), z.value
