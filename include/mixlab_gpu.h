@@ -61,7 +61,11 @@ enum {
     MX_KIND_FIR = 15,             /* BUILD-SPECIFIED (BASELINE configs[2]; no reference module): K-tap FIR on a stereo stream  in: Stereo  out: Stereo */
     MX_KIND_RESAMPLE = 16,        /* BUILD-SPECIFIED rational polyphase resampler (44.1 -> 48 kHz = up 160 / down 147; the reference has only
                                      `TODO implement resampling`, src/icecast/mod.rs:94-97)  in: Stereo  out: Stereo at rate * up / down */
-    MX_KIND_COUNT = 17
+    MX_KIND_MONITOR = 17,         /* the hand-off of Monitor / StreamOutput (src/module/monitor.rs:113-139, stream_output.rs:154-158) and the first steps of
+                                     their codec threads (monitor.rs:226-236; encode.rs:183-195 f32->i16, :287-295 DynamicScaler to the
+                                     encoder's picture): keeps every tick's program frame, scaled, and serves the mix as i16
+                                     in: Video, Stereo  out: --   params: mx_monitor_params */
+    MX_KIND_COUNT = 18
 };
 
 /* protocol/src/lib.rs:233-241, bincode variant order */
@@ -77,6 +81,7 @@ typedef struct { double freq_lo, freq_hi; } mx_fm_sine_params;                  
 typedef struct { uint32_t gate_open; } mx_trigger_params;                                              /* GateState :304-308 */
 typedef struct { int32_t a, b; /* -1 = None */ double fader; } mx_video_mixer_params;                  /* VideoMixerParams :405-410 */
 typedef struct { int32_t use_matrix; int32_t matrix_q12[12]; } mx_video_to_rgba_params;                /* build-specified, DESIGN.md "Colour" */
+typedef struct { uint32_t width, height; } mx_monitor_params;   /* the encoder's picture: 560 x 350 (monitor.rs:21-22), 1120 x 700 (stream_output.rs:23-24); even */
 /* Build-specified audio extras (DESIGN.md "FIR and resampler").  Both are variable-length blobs: the header below
  * followed by the f64 coefficients.  Arithmetic: f32 widened to f64, accumulated in f64 in ascending tap index with
  * separate multiply and add, rounded once to f32 -- the reference's own convention (mixer.rs:62, amplifier.rs:56). */
@@ -411,6 +416,18 @@ int mx_frame_stager_sync(mx_frame_stager* st);
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out);
 /* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame). */
 int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t* stride, uint32_t* width, uint32_t* height);
+
+/* MX_KIND_MONITOR after a run.  Tick `tick_in_run` of the last mx_graph_run_ticks as the codec thread would see it:
+ * ts = the tick's timestamp relative to the node's epoch -- the first tick it ever ran (monitor.rs:121-123); when the Video input carried
+ * a frame: *frame = that picture through the node's DynamicScaler (the input itself when it already has the encoder's size,
+ * encode.rs:342-345; one reference for the caller, still on the device: download it or hand it to a device encoder), frame_ts = ts +
+ * tick_offset (monitor.rs:229), dur = its duration hint; else video_present = 0 and *frame = NULL.  The reference DROPS a tick when its
+ * codec thread lags (try_send on a channel of two, monitor.rs:163-177); nothing is dropped here. */
+typedef struct { int32_t video_present; int64_t ts_num, ts_den, frame_ts_num, frame_ts_den, dur_num, dur_den; } mx_monitor_tick;
+int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run, mx_monitor_tick* info, mx_dframe** frame);
+/* The mix the node received over the first n_ticks ticks of the last run, as the encoder's PCM: clamp to [-1, 1], * 32767, truncate
+ * (encode.rs:183-195), converted on the device: audio[n_ticks * 2 * SPT].  A Disconnected input reads zeros (io.rs:56-57). */
+int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, uint32_t n_ticks);
 
 /* plain device memory for consumers of mx_video_to_rgba (tests, bench) */
 int mx_device_alloc(size_t bytes, void** device_ptr);

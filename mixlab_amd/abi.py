@@ -25,9 +25,9 @@ MX_OK, MX_ERR_INVALID, MX_ERR_TYPE, MX_ERR_DEVICE, MX_ERR_NOMEM, MX_ERR_INTERNAL
 MX_DISCONNECTED, MX_MONO, MX_STEREO, MX_VIDEO = 0, 1, 2, 3
 (KIND_AMPLIFIER, KIND_ENVELOPE, KIND_EQ_THREE, KIND_FM_SINE, KIND_MIXER, KIND_OSCILLATOR, KIND_PLOTTER,
  KIND_STEREO_PANNER, KIND_STEREO_SPLITTER, KIND_TRIGGER, KIND_VIDEO_MIXER, KIND_SOURCE_MONO,
- KIND_SOURCE_STEREO, KIND_SOURCE_VIDEO, KIND_VIDEO_TO_RGBA, KIND_FIR, KIND_RESAMPLE, KIND_COUNT) = range(18)
+ KIND_SOURCE_STEREO, KIND_SOURCE_VIDEO, KIND_VIDEO_TO_RGBA, KIND_FIR, KIND_RESAMPLE, KIND_MONITOR, KIND_COUNT) = range(19)
 KIND_NAMES = ["amplifier", "envelope", "eq_three", "fm_sine", "mixer", "oscillator", "plotter", "stereo_panner",
-              "stereo_splitter", "trigger", "video_mixer", "source_mono", "source_stereo", "source_video", "video_to_rgba", "fir", "resample"]
+              "stereo_splitter", "trigger", "video_mixer", "source_mono", "source_stereo", "source_video", "video_to_rgba", "fir", "resample", "monitor"]
 WAVE_ON, WAVE_OFF, WAVE_SINE, WAVE_SQUARE, WAVE_TRIANGLE, WAVE_SAW = range(6)
 FLAG_EQ_EXACT = 1   # the default (kept as a no-op name)
 FLAG_NO_FUSE = 2

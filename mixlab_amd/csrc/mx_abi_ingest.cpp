@@ -163,6 +163,26 @@ int mx_stream_input_feed(mx_stream_input* s, mx_graph* g, uint32_t audio_node, u
     });
 }
 
+/* ---- Monitor / StreamOutput hand-off ---- */
+int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run, mx_monitor_tick* info, mx_dframe** frame) {
+    return guard([&] {
+        REQUIRE(g && info && frame, "NULL argument");
+        *frame = nullptr; std::memset(info, 0, sizeof *info);
+        info->ts_den = info->frame_ts_den = info->dur_den = 1;
+        const mx::Node::MonTick& m = g->g->monitor_tick(node, tick_in_run);
+        info->ts_num = m.ts.num; info->ts_den = m.ts.den;
+        if (!m.present) return;
+        info->video_present = 1;
+        info->frame_ts_num = m.frame_ts.num; info->frame_ts_den = m.frame_ts.den;
+        info->dur_num = m.dur.num; info->dur_den = m.dur.den;
+        m.frame->retain();
+        *frame = H(m.frame.f);
+    });
+}
+int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, uint32_t n_ticks) {
+    return guard([&] { REQUIRE(g, "NULL argument"); g->g->read_monitor_audio_i16(node, audio, n_ticks); });
+}
+
 /* ---- frame staging ---- */
 int mx_frame_stager_create(uint32_t slots, mx_frame_stager** out) {
     return guard([&] { REQUIRE(out, "out is NULL"); *out = nullptr; *out = new mx_frame_stager(slots); });

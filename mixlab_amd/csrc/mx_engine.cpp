@@ -52,6 +52,7 @@ static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& i
     case MX_KIND_FIR: in = {MX_STEREO}; out = {MX_STEREO}; break;        // blob checked in the constructor
     case MX_KIND_RESAMPLE: in = {MX_STEREO}; out = {MX_STEREO}; break;
     case MX_KIND_VIDEO_TO_RGBA: need(sizeof(mx_video_to_rgba_params), "mx_video_to_rgba_params"); in = {MX_VIDEO}; out = {}; break;
+    case MX_KIND_MONITOR: need(sizeof(mx_monitor_params), "mx_monitor_params"); in = {MX_VIDEO, MX_STEREO}; out = {}; break;   // monitor.rs:99-102
     default: throw Error(MX_ERR_INVALID, "unknown module kind");
     }
 }
@@ -231,14 +232,20 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         groups_.back().nodes.push_back(id);
     }
     for (uint32_t id = 0; id < nodes_.size(); ++id) if (nodes_[id].kind == MX_KIND_PLOTTER && nodes_[id].group >= 0) plotter_nodes_.push_back(id);
-    for (uint32_t id : order_) if (nodes_[id].kind == MX_KIND_VIDEO_MIXER || nodes_[id].kind == MX_KIND_SOURCE_VIDEO || nodes_[id].kind == MX_KIND_VIDEO_TO_RGBA) video_order_.push_back(id);
+    for (uint32_t id : order_) if (nodes_[id].kind == MX_KIND_VIDEO_MIXER || nodes_[id].kind == MX_KIND_SOURCE_VIDEO || nodes_[id].kind == MX_KIND_VIDEO_TO_RGBA || nodes_[id].kind == MX_KIND_MONITOR) video_order_.push_back(id);
     // video nodes: per-node state lives on the host, pixels on the graph's stream
     for (Node& n : nodes_) {
         if (n.kind == MX_KIND_VIDEO_MIXER) {
             mx_video_mixer_params p; std::memcpy(&p, n.params.data(), sizeof p);
             n.vmixer.reset(new VideoMixer(p, sr, stream_));
         }
-        if (n.kind == MX_KIND_VIDEO_MIXER || n.kind == MX_KIND_SOURCE_VIDEO || n.kind == MX_KIND_VIDEO_TO_RGBA) has_video_ = true;
+        if (n.kind == MX_KIND_MONITOR) {
+            mx_monitor_params p; std::memcpy(&p, n.params.data(), sizeof p);
+            if (p.width == 0 || p.height == 0 || (p.width & 1) || (p.height & 1) || p.width > 16384 || p.height > 16384)
+                throw Error(MX_ERR_INVALID, "monitor picture must be non-zero, even and at most 16384 a side");
+            n.mon_scaler = std::make_shared<Scaler>(p.width, p.height, stream_);
+        }
+        if (n.kind == MX_KIND_VIDEO_MIXER || n.kind == MX_KIND_SOURCE_VIDEO || n.kind == MX_KIND_VIDEO_TO_RGBA || n.kind == MX_KIND_MONITOR) has_video_ = true;
         n.vout.resize(n.out_type.size());
     }
     // a VideoMixer whose program output feeds exactly one video node of this graph hands it over as an
@@ -868,6 +875,7 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
         }
     };
     if (any_sched) apply_at(0);
+    for (uint32_t id : video_order_) if (nodes_[id].kind == MX_KIND_MONITOR) nodes_[id].mon_ticks.clear();
 
     // Plotter bookkeeping is host logic (plotter.rs:37-40): count += 1 per call, fire on every 6th
     size_t total_fired = 0;
@@ -1060,7 +1068,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
 static bool group_launches(const Group& g) {
     switch (g.kind) {
     case MX_KIND_SOURCE_MONO: case MX_KIND_SOURCE_STEREO: case MX_KIND_SOURCE_VIDEO:
-    case MX_KIND_VIDEO_MIXER: case MX_KIND_VIDEO_TO_RGBA: return false;   // bound buffers / the per-tick video section
+    case MX_KIND_VIDEO_MIXER: case MX_KIND_VIDEO_TO_RGBA: case MX_KIND_MONITOR: return false;   // bound buffers / the per-tick video section
     default: return true;
     }
 }
@@ -1151,6 +1159,7 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
             if (a[k].bytes == b[k].bytes && a[k].bytes)   // a filter whose length changed starts from silence
                 hip_check(hipMemcpyAsync(a[k].p, b[k].p, a[k].bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(adopt state)");
         if (nn.kind == MX_KIND_PLOTTER) nn.plot_count = on.plot_count;          // plotter.rs:37-40
+        if (nn.kind == MX_KIND_MONITOR) { nn.mon_has_epoch = on.mon_has_epoch; nn.mon_epoch = on.mon_epoch; }   // Monitor.epoch (monitor.rs:122)
         if (nn.kind == MX_KIND_VIDEO_MIXER && on.vmixer) {                       // stored frames, scalers, expiry times
             mx_video_mixer_params p; std::memcpy(&p, nn.params.data(), sizeof p);
             nn.vmixer = std::move(on.vmixer);
@@ -1193,7 +1202,7 @@ Graph::Perf Graph::performance_info(uint64_t* module_us, size_t cap) {
     }
     if (has_video_ && perf_group_ms_.size() > groups_.size()) {   // the per-tick video section
         std::vector<uint32_t> members;
-        for (size_t i = 0; i < nodes_.size(); ++i) if (nodes_[i].kind == MX_KIND_VIDEO_MIXER || nodes_[i].kind == MX_KIND_VIDEO_TO_RGBA) members.push_back((uint32_t)i);
+        for (size_t i = 0; i < nodes_.size(); ++i) if (nodes_[i].kind == MX_KIND_VIDEO_MIXER || nodes_[i].kind == MX_KIND_VIDEO_TO_RGBA || nodes_[i].kind == MX_KIND_MONITOR) members.push_back((uint32_t)i);
         const double us = perf_group_ms_[groups_.size()] * 1000.0 / calls;
         accounted += us;
         if (module_us) for (uint32_t id : members) module_us[id] += (uint64_t)(us / (double)members.size() + 0.5);
@@ -1329,6 +1338,23 @@ void Graph::run_video_tick(uint64_t t) {
             if (b && p.b >= 0 && p.b < 4) n.vout[2] = Node::VOut{b, in[p.b].duration_hint, in[p.b].tick_offset};
             break;
         }
+        case MX_KIND_MONITOR: {
+            // Monitor::run_tick (monitor.rs:113-139) + the codec thread's use of the Tick (monitor.rs:226-236)
+            Node::MonTick mt;
+            const Rational absolute = Rational::make((int64_t)t, (int64_t)sample_rate_);
+            if (!n.mon_has_epoch) { n.mon_epoch = absolute; n.mon_has_epoch = true; }       // epoch.get_or_insert
+            mt.ts = absolute - n.mon_epoch;                                                  // remove_epoch
+            const PortRef pr = n.in_src[0];
+            const Node::VOut* vp = pr.node < 0 ? nullptr : &nodes_[pr.node].vout[pr.port];   // Disconnected => None (io.rs:56-57)
+            if (vp && vp->frame) {
+                mt.present = true;
+                mt.frame_ts = mt.ts + vp->off;                                               // tick.timestamp + tick_offset
+                mt.dur = vp->dur;
+                mt.frame = n.mon_scaler->scale_keep(vp->frame);                              // VideoCtx::send_frame -> DynamicScaler::scale (encode.rs:287-295)
+            }
+            n.mon_ticks.push_back(std::move(mt));
+            break;
+        }
         case MX_KIND_VIDEO_TO_RGBA: {
             const PortRef pr = n.in_src[0];
             n.rgba_w = n.rgba_h = 0;
@@ -1421,6 +1447,24 @@ void Graph::queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rati
     Node& nd = nodes_[node];
     if (!nd.vsrc_sched.empty() && nd.vsrc_sched.back().tick >= tick) throw Error(MX_ERR_INVALID, "video source frames must be queued in tick order, one per tick");
     nd.vsrc_sched.push_back(Node::VSched{tick, FrameRef(frame, true), dur, off});
+}
+
+const Node::MonTick& Graph::monitor_tick(uint32_t node, uint32_t tick_in_run) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_MONITOR) throw Error(MX_ERR_INVALID, "node is not a MONITOR");
+    if (tick_in_run >= nodes_[node].mon_ticks.size()) throw Error(MX_ERR_INVALID, "tick_in_run beyond the last run");
+    flush_scales(stream_);
+    sync();          // the caller reads the frame on streams of its own
+    return nodes_[node].mon_ticks[tick_in_run];
+}
+
+void Graph::read_monitor_audio_i16(uint32_t node, int16_t* host, uint32_t n_ticks) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_MONITOR) throw Error(MX_ERR_INVALID, "node is not a MONITOR");
+    if (n_ticks > last_calls_) throw Error(MX_ERR_INVALID, "more ticks than the last run had");
+    if (n_ticks && !host) throw Error(MX_ERR_INVALID, "audio is NULL");
+    const PortRef pr = nodes_[node].in_src[1];
+    const size_t per_tick = 2 * last_frames_per_call_;
+    if (pr.node < 0) { std::memset(host, 0, (size_t)n_ticks * per_tick * sizeof(int16_t)); return; }   // InputRef::Disconnected: the zero buffer
+    read_output_i16((uint32_t)pr.node, (uint32_t)pr.port, host, (size_t)n_ticks * last_frames_per_call_);
 }
 
 void Graph::set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off) {

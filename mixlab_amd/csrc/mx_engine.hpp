@@ -65,6 +65,11 @@ struct Node {
     struct PendingRgba { ChainRgbaArgs args; std::shared_ptr<LazyChain> keep; };
     std::vector<PendingRgba> rgba_pending;     // VIDEO_TO_RGBA: chains of the last ticks, not launched yet, oldest first (run_video_tick)
     uint32_t rgba_calls = 0;                   // sink calls that queued a chain in this run
+    // MONITOR: what the sink kept of every tick of the last run
+    struct MonTick { bool present = false; FrameRef frame; Rational ts, frame_ts, dur; };
+    std::vector<MonTick> mon_ticks;
+    bool mon_has_epoch = false; Rational mon_epoch;
+    std::shared_ptr<Scaler> mon_scaler;
 };
 
 struct Group {
@@ -138,6 +143,8 @@ public:
     void set_video_source_band(uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows, uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows);
     void set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off);
     void queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rational dur, Rational off);
+    const Node::MonTick& monitor_tick(uint32_t node, uint32_t tick_in_run);
+    void read_monitor_audio_i16(uint32_t node, int16_t* host, uint32_t n_ticks);
     FrameRef video_output(uint32_t node, uint32_t port);
     void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 

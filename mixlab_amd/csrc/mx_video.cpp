@@ -432,6 +432,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     flush_scales(stream_);             // queued jobs write the old output frames
     for (auto& f : ring_) f = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
     ring_pos_ = 0; frame_ = ring_[0];
+    keep_pool_.clear();                // their borders belong to the old letterbox
     // tap tables: [luma h, luma v, chroma h, chroma v]
     std::vector<int32_t> blob;
     size_t offs[2][4];
@@ -509,6 +510,18 @@ FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
     }
     scale_into(in, t_, frame_, tmp_plane_, stream_);
     return frame_;
+}
+
+FrameRef Scaler::scale_keep(const FrameRef& in) {
+    if (in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) { in->ensure_pixels(stream_); return in; }
+    in->ensure_pixels(stream_);
+    if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);
+    FrameRef out;
+    for (auto& f : keep_pool_) if (f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }   // only the pool holds it
+    if (!out) { keep_pool_.push_back(FrameRef(DFrame::create(out_w_, out_h_, stream_), false)); out = keep_pool_.back(); }
+    if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return out;
+    scale_into(in, t_, out, tmp_plane_, stream_);
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------

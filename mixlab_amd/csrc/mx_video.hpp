@@ -233,6 +233,8 @@ public:
     // scaler's own letterboxed output frame (encode.rs:386-396)
     // may_defer: the caller's consumers are chain kernels, which resample a 4-tap scale inline -- the result may be a frame without pixels
     FrameRef scale(const FrameRef& in, bool may_defer = false);
+    // the same picture in a frame nobody else holds, so that a sink can keep every tick's picture of a batch (Monitor)
+    FrameRef scale_keep(const FrameRef& in);
     // a topology edit moved the owning VideoMixer to another graph: queued work leaves on the old stream first
     void rebind(hipStream_t s) { flush_scales(stream_); stream_ = s; }
 private:
@@ -242,6 +244,7 @@ private:
     uint32_t in_w_ = 0, in_h_ = 0;   // settings the cached context was built for (encode.rs:347-352)
     uint8_t in_fmt_ = MX_PIXFMT_YUV420P;
     FrameRef frame_;                 // cached blank output frame (encode.rs:382) -- the one the latest scale() wrote
+    std::vector<FrameRef> keep_pool_; // scale_keep's outputs: blank frames of this context's letterbox geometry, reused once released
     FrameRef ring_[4];               // four of them, used in turn: the RGBA chains that read the last two may be launched together with the next two scales
     uint32_t ring_pos_ = 0;
     std::shared_ptr<ScaleTables> t_;

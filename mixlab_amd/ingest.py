@@ -46,6 +46,31 @@ _proto("mx_frame_stager_fence_graph", C.c_int, C.c_void_p, C.c_void_p)
 _proto("mx_frame_stager_sync", C.c_int, C.c_void_p)
 
 
+class MonitorTick(C.Structure):
+    _fields_ = [("video_present", C.c_int32), ("ts_num", _I64), ("ts_den", _I64), ("frame_ts_num", _I64), ("frame_ts_den", _I64),
+                ("dur_num", _I64), ("dur_den", _I64)]
+
+
+_proto("mx_graph_read_monitor_tick", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(MonitorTick), C.POINTER(C.c_void_p))
+_proto("mx_graph_read_monitor_audio_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32)
+
+
+def graph_read_monitor_tick(g, node, tick_in_run):
+    """-> (ts, None) or (ts, (DFrame, frame_ts, dur)) with exact Fractions"""
+    info, h = MonitorTick(), C.c_void_p()
+    check(lib.mx_graph_read_monitor_tick(g._h, node, tick_in_run, C.byref(info), C.byref(h)))
+    ts = Fraction(info.ts_num, info.ts_den)
+    if not info.video_present:
+        return ts, None
+    return ts, (DFrame(handle=h.value), Fraction(info.frame_ts_num, info.frame_ts_den), Fraction(info.dur_num, info.dur_den))
+
+
+def graph_read_monitor_audio_i16(g, node, n_ticks, spt):
+    out = np.empty(n_ticks * 2 * spt, np.int16)
+    check(lib.mx_graph_read_monitor_audio_i16(g._h, node, out.ctypes.data_as(C.c_void_p), n_ticks))
+    return out
+
+
 def _q(x) -> tuple[int, int]:
     f = Fraction(x) if not isinstance(x, tuple) else Fraction(x[0], x[1])
     return f.numerator, f.denominator

@@ -99,6 +99,11 @@ class Workspace:
     def source_video(self) -> int:
         return self.add(abi.KIND_SOURCE_VIDEO, None)
 
+    def monitor(self, width=560, height=350) -> int:
+        """Monitor (560 x 350, monitor.rs:21-22) / StreamOutput (1120 x 700, stream_output.rs:23-24) hand-off: in Video, Stereo"""
+        import struct
+        return self.add(abi.KIND_MONITOR, struct.pack("<II", width, height))
+
     def video_to_rgba(self, matrix_q12=None) -> int:
         from .video import to_rgba_params
         return self.add(abi.KIND_VIDEO_TO_RGBA, to_rgba_params(matrix_q12))
