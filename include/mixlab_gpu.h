@@ -425,6 +425,13 @@ int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t
  * codec thread lags (try_send on a channel of two, monitor.rs:163-177); nothing is dropped here. */
 typedef struct { int32_t video_present; int64_t ts_num, ts_den, frame_ts_num, frame_ts_den, dur_num, dur_den; } mx_monitor_tick;
 int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run, mx_monitor_tick* info, mx_dframe** frame);
+/* All kept pictures of ticks [first_tick, first_tick + n_ticks) of the last run in ONE read-back: one gather launch on the device, one
+ * D2H copy.  frames[n_ticks * frame_bytes]: slot k holds tick first_tick + k's picture in the layout mx_graph_monitor_layout reports (rows
+ * 64-byte aligned: an AVFrame.linesize an encoder takes as is); present[k] = 0 leaves slot k untouched.  A page-locked `frames` avoids
+ * the runtime's staging copy. */
+typedef struct { uint32_t width, height; size_t frame_bytes; size_t plane_offset[3]; int32_t stride[3]; } mx_monitor_layout;
+int mx_graph_monitor_layout(mx_graph* g, uint32_t node, mx_monitor_layout* out);
+int mx_graph_read_monitor_video(mx_graph* g, uint32_t node, uint32_t first_tick, uint32_t n_ticks, uint8_t* frames, uint8_t* present);
 /* The mix the node received over the first n_ticks ticks of the last run, as the encoder's PCM: clamp to [-1, 1], * 32767, truncate
  * (encode.rs:183-195), converted on the device: audio[n_ticks * 2 * SPT].  A Disconnected input reads zeros (io.rs:56-57). */
 int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, uint32_t n_ticks);
@@ -433,6 +440,10 @@ int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, 
 int mx_device_alloc(size_t bytes, void** device_ptr);
 void mx_device_free(void* device_ptr);
 int mx_device_download(void* host, const void* device_ptr, size_t bytes, void* stream);   /* synchronous */
+/* page-locked host memory for the buffers that cross PCIe every submission (mx_graph_read_monitor_video's `frames`, PCM, sources):
+ * copies from / to it are one DMA, without the runtime's staging through its own pinned bounce buffers */
+int mx_host_alloc(size_t bytes, void** host_ptr);
+void mx_host_free(void* host_ptr);
 
 /* ---- per-module compatibility path: one ModuleT instance, host pointers in and out ---- */
 

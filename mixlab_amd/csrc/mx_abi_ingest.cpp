@@ -183,6 +183,29 @@ int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, 
     return guard([&] { REQUIRE(g, "NULL argument"); g->g->read_monitor_audio_i16(node, audio, n_ticks); });
 }
 
+int mx_graph_monitor_layout(mx_graph* g, uint32_t node, mx_monitor_layout* out) {
+    return guard([&] {
+        REQUIRE(g && out, "NULL argument");
+        const mx::Graph::MonitorLayout l = g->g->monitor_layout(node);
+        out->width = l.width; out->height = l.height; out->frame_bytes = l.frame_bytes;
+        for (int p = 0; p < 3; ++p) { out->plane_offset[p] = l.plane_offset[p]; out->stride[p] = (int32_t)l.stride[p]; }
+    });
+}
+int mx_graph_read_monitor_video(mx_graph* g, uint32_t node, uint32_t first_tick, uint32_t n_ticks, uint8_t* frames, uint8_t* present) {
+    return guard([&] { REQUIRE(g, "NULL argument"); g->g->read_monitor_video(node, first_tick, n_ticks, frames, present); });
+}
+
+int mx_host_alloc(size_t bytes, void** host_ptr) {
+    return guard([&] {
+        REQUIRE(host_ptr, "host_ptr is NULL");
+        *host_ptr = nullptr;
+        hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+        if (e == hipErrorOutOfMemory) { *host_ptr = nullptr; throw Error(MX_ERR_NOMEM, "hipHostMalloc: out of page-locked memory"); }
+        mx::hip_check(e, "hipHostMalloc");
+    });
+}
+void mx_host_free(void* host_ptr) { (void)guard([&] { if (host_ptr) mx::hip_check(hipHostFree(host_ptr), "hipHostFree"); }); }
+
 /* ---- frame staging ---- */
 int mx_frame_stager_create(uint32_t slots, mx_frame_stager** out) {
     return guard([&] { REQUIRE(out, "out is NULL"); *out = nullptr; *out = new mx_frame_stager(slots); });

@@ -1457,6 +1457,54 @@ const Node::MonTick& Graph::monitor_tick(uint32_t node, uint32_t tick_in_run) {
     return nodes_[node].mon_ticks[tick_in_run];
 }
 
+Graph::MonitorLayout Graph::monitor_layout(uint32_t node) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_MONITOR) throw Error(MX_ERR_INVALID, "node is not a MONITOR");
+    const Scaler& sc = *nodes_[node].mon_scaler;
+    MonitorLayout l{};
+    l.width = sc.out_w(); l.height = sc.out_h();
+    size_t total = 0;                                   // DFrame's own layout for yuv420p (mx_video.cpp alloc_planes): what every kept frame has
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t rb = p ? l.width >> 1 : l.width, rows = p ? l.height >> 1 : l.height;
+        l.stride[p] = (rb + 63u) & ~63u;
+        l.plane_offset[p] = total;
+        total += ((size_t)l.stride[p] * rows + 255) & ~(size_t)255;
+    }
+    l.frame_bytes = total;
+    return l;
+}
+
+void Graph::read_monitor_video(uint32_t node, uint32_t first_tick, uint32_t n_ticks, uint8_t* frames, uint8_t* present) {
+    const MonitorLayout l = monitor_layout(node);
+    Node& n = nodes_[node];
+    if ((size_t)first_tick + n_ticks > n.mon_ticks.size()) throw Error(MX_ERR_INVALID, "ticks beyond the last run");
+    if (n_ticks && (!frames || !present)) throw Error(MX_ERR_INVALID, "NULL argument");
+    if (!n_ticks) return;
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    const size_t need = (size_t)n_ticks * l.frame_bytes;
+    if (n.mon_pack.bytes < need) { sync(); n.mon_pack.alloc(need); }
+    uint32_t any = 0;
+    for (uint32_t k0 = 0; k0 < n_ticks; k0 += 224) {
+        GatherArgs a{};
+        a.n = std::min<uint32_t>(224u, n_ticks - k0);
+        a.dst = reinterpret_cast<uint4*>((uint8_t*)n.mon_pack.p + (size_t)k0 * l.frame_bytes);
+        a.q_per_frame = (uint32_t)(l.frame_bytes / 16);
+        for (uint32_t k = 0; k < a.n; ++k) {
+            const Node::MonTick& mt = n.mon_ticks[first_tick + k0 + k];
+            present[k0 + k] = mt.present ? 1 : 0;
+            a.src[k] = nullptr;
+            if (!mt.present) continue;
+            const DFrame* f = mt.frame.f;
+            if (f->mem.bytes != l.frame_bytes || f->plane_offset(1) != l.plane_offset[1] || f->plane_offset(2) != l.plane_offset[2])
+                throw Error(MX_ERR_INTERNAL, "a kept monitor frame does not have the monitor layout");
+            a.src[k] = reinterpret_cast<const uint4*>(f->mem.p);
+            ++any;
+        }
+        launch_gather_frames(a, stream_);
+    }
+    if (any) hip_check(hipMemcpyAsync(frames, n.mon_pack.p, need, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H monitor frames)");
+    sync();
+}
+
 void Graph::read_monitor_audio_i16(uint32_t node, int16_t* host, uint32_t n_ticks) {
     if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_MONITOR) throw Error(MX_ERR_INVALID, "node is not a MONITOR");
     if (n_ticks > last_calls_) throw Error(MX_ERR_INVALID, "more ticks than the last run had");

@@ -70,6 +70,7 @@ struct Node {
     std::vector<MonTick> mon_ticks;
     bool mon_has_epoch = false; Rational mon_epoch;
     std::shared_ptr<Scaler> mon_scaler;
+    DevBuf mon_pack;                           // the packed read-back's device staging
 };
 
 struct Group {
@@ -145,6 +146,9 @@ public:
     void queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rational dur, Rational off);
     const Node::MonTick& monitor_tick(uint32_t node, uint32_t tick_in_run);
     void read_monitor_audio_i16(uint32_t node, int16_t* host, uint32_t n_ticks);
+    struct MonitorLayout { uint32_t width, height; size_t frame_bytes, plane_offset[3]; uint32_t stride[3]; };
+    MonitorLayout monitor_layout(uint32_t node);
+    void read_monitor_video(uint32_t node, uint32_t first_tick, uint32_t n_ticks, uint8_t* frames, uint8_t* present);
     FrameRef video_output(uint32_t node, uint32_t port);
     void rgba_output(uint32_t node, void** dev, int32_t* stride, uint32_t* w, uint32_t* h);
 

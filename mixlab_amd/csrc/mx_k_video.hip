@@ -742,6 +742,19 @@ void launch_copy_planes(const CopyArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_copy_planes, dim3(((mb + 15) / 16 + 255) / 256, mr, 3), dim3(256), 0, s, a);
 }
 
+// n frame allocations of q_per_frame 16-byte words each, copied back to back into dst (blockIdx.y = frame; src[k] null = skip)
+__global__ __launch_bounds__(256) void k_gather_frames(GatherArgs a) {
+    const uint4* src = a.src[blockIdx.y];
+    if (!src) return;
+    uint4* dst = a.dst + (size_t)blockIdx.y * a.q_per_frame;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.q_per_frame; i += gridDim.x * 256) dst[i] = src[i];
+}
+void launch_gather_frames(const GatherArgs& a, hipStream_t s) {
+    flush_scales(s);
+    if (!a.n || !a.q_per_frame) return;
+    hipLaunchKernelGGL(k_gather_frames, dim3(grid_x(a.q_per_frame, 256, 64), a.n), dim3(256), 0, s, a);
+}
+
 // ---------------------------------------------------------------------------------------------
 // YUV420P -> RGBA8 -- BUILD-SPECIFIED (no reference counterpart): BT.709 limited range, integer,
 // nearest chroma, optional Q12 3x4 colour matrix (DESIGN.md "Colour").  4 pixels per lane: one

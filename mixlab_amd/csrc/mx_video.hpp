@@ -97,6 +97,9 @@ void flush_scales(hipStream_t s);
 void launch_scale_then_chains_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);   // one launch when all take their tiled forms
 void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
+// whole frame allocations (equal size, 16-byte multiples) gathered back to back: the packed read-back of a sink's kept frames
+struct GatherArgs { const uint4* src[224]; uint4* dst; uint32_t q_per_frame, n; };
+void launch_gather_frames(const GatherArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
 
 // ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----

@@ -65,6 +65,60 @@ def graph_read_monitor_tick(g, node, tick_in_run):
     return ts, (DFrame(handle=h.value), Fraction(info.frame_ts_num, info.frame_ts_den), Fraction(info.dur_num, info.dur_den))
 
 
+class MonitorLayout(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("frame_bytes", C.c_size_t), ("plane_offset", C.c_size_t * 3), ("stride", C.c_int32 * 3)]
+
+
+_proto("mx_graph_monitor_layout", C.c_int, C.c_void_p, C.c_uint32, C.POINTER(MonitorLayout))
+_proto("mx_graph_read_monitor_video", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
+
+
+_proto("mx_host_alloc", C.c_int, C.c_size_t, C.POINTER(C.c_void_p))
+_proto("mx_host_free", None, C.c_void_p)
+
+
+class PinnedBuffer:
+    """page-locked host bytes as a numpy array (.a)"""
+
+    def __init__(self, nbytes):
+        self._p = C.c_void_p()
+        check(lib.mx_host_alloc(nbytes, C.byref(self._p)))
+        self.a = np.frombuffer((C.c_uint8 * nbytes).from_address(self._p.value), np.uint8)
+
+    def __del__(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.a = None
+            lib.mx_host_free(self._p)
+            self._p = C.c_void_p()
+
+
+def graph_monitor_layout(g, node) -> MonitorLayout:
+    l = MonitorLayout()
+    check(lib.mx_graph_monitor_layout(g._h, node, C.byref(l)))
+    return l
+
+
+def graph_read_monitor_video(g, node, first_tick, n_ticks, out=None):
+    """-> list of None or [Y, U, V] visible planes (views into one packed read-back), one entry per tick; `out`: uint8 array of
+    n_ticks * frame_bytes to read into (a PinnedBuffer's for speed)"""
+    l = graph_monitor_layout(g, node)
+    buf = np.empty(n_ticks * l.frame_bytes, np.uint8) if out is None else out
+    assert buf.size >= n_ticks * l.frame_bytes
+    present = np.zeros(n_ticks, np.uint8)
+    check(lib.mx_graph_read_monitor_video(g._h, node, first_tick, n_ticks, buf.ctypes.data_as(C.c_void_p), present.ctypes.data_as(C.c_void_p)))
+    out = []
+    for k in range(n_ticks):
+        if not present[k]:
+            out.append(None); continue
+        fr = buf[k * l.frame_bytes:(k + 1) * l.frame_bytes]
+        planes = []
+        for p in range(3):
+            rows, w = (l.height, l.width) if p == 0 else (l.height >> 1, l.width >> 1)
+            planes.append(fr[l.plane_offset[p]: l.plane_offset[p] + rows * l.stride[p]].reshape(rows, l.stride[p])[:, :w])
+        out.append(planes)
+    return out
+
+
 def graph_read_monitor_audio_i16(g, node, n_ticks, spt):
     out = np.empty(n_ticks * 2 * spt, np.int16)
     check(lib.mx_graph_read_monitor_audio_i16(g._h, node, out.ctypes.data_as(C.c_void_p), n_ticks))

@@ -90,6 +90,19 @@ def test_monitor_keeps_every_tick_of_a_submission(prog, mon):
             for p, (x, y) in enumerate(zip(frame.download(), want.visible())):
                 assert np.array_equal(x, y), f"run {run} tick {k}: plane {p} differs"
             pics[(run, k)] = frame
+        # the packed read-back: every kept picture of the submission in one copy
+        packed = ingest.graph_read_monitor_video(g, m, 0, T)
+        for k in range(T):
+            ts, vid = ingest.graph_read_monitor_tick(g, m, k)
+            assert (packed[k] is None) == (vid is None)
+            if vid is not None:
+                for x, y in zip(packed[k], vid[0].download()):
+                    assert np.array_equal(x, y)
+        part = ingest.graph_read_monitor_video(g, m, 2, 3)
+        for k in range(3):
+            assert (part[k] is None) == (packed[2 + k] is None)
+            if part[k] is not None:
+                assert all(np.array_equal(x, y) for x, y in zip(part[k], packed[2 + k]))
     assert len(pics) >= 8
 
 

@@ -39,5 +39,14 @@ for mon in ((560, 350), (1120, 700)):
         ts, vid = ingest.graph_read_monitor_tick(g, m, k)
         small.append(vid[0].download())
     dr = (time.perf_counter() - t1) / T
+    lay = ingest.graph_monitor_layout(g, m)
+    for name, buf in (("pageable", np.zeros(T * lay.frame_bytes, np.uint8)), ("page-locked", ingest.PinnedBuffer(T * lay.frame_bytes))):
+        arr = buf if isinstance(buf, np.ndarray) else buf.a
+        ingest.graph_read_monitor_video(g, m, 0, T, out=arr)
+        t2 = time.perf_counter()
+        for _ in range(5):
+            ingest.graph_read_monitor_video(g, m, 0, T, out=arr)
+        db = (time.perf_counter() - t2) / (5 * T)
+        print(f"monitor {mon[0]}x{mon[1]}: packed read-back of the {T} kept frames into {name} memory: {db * 1e6:6.1f} us per frame ({lay.frame_bytes / db / 1e9:.1f} GB/s)")
     print(f"monitor {mon[0]}x{mon[1]}: {dt * 1e6:7.1f} us per tick on the device (cross-fade of two 1080p layers + DynamicScaler), "
           f"{dr * 1e6:7.1f} us per tick to read the frame and the PCM back (synchronous, python)")
