@@ -165,6 +165,11 @@ FrameRef FrameStager::take_frame(uint32_t w, uint32_t h, uint8_t fmt) {
 }
 
 uint32_t FrameStager::acquire(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data[3], int32_t stride[3]) {
+    std::lock_guard<std::mutex> lk(mu_);
+    return acquire_locked(w, h, fmt, data, stride);
+}
+
+uint32_t FrameStager::acquire_locked(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data[3], int32_t stride[3]) {
     FrameRef f = take_frame(w, h, fmt);
     uint32_t k = next_, tries = 0;
     while (slots_[k].held) {                       // slots a decoder still writes are skipped
@@ -194,6 +199,11 @@ uint32_t FrameStager::acquire(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data
 }
 
 DFrame* FrameStager::commit(uint32_t ticket) {
+    std::lock_guard<std::mutex> lk(mu_);
+    return commit_locked(ticket);
+}
+
+DFrame* FrameStager::commit_locked(uint32_t ticket) {
     if (ticket == 0 || ticket > slots_.size() || !slots_[ticket - 1].held) throw Error(MX_ERR_INVALID, "not a ticket of an acquired slot");
     Slot& s = slots_[ticket - 1];
     FrameRef f = s.target;
@@ -207,8 +217,9 @@ DFrame* FrameStager::commit(uint32_t ticket) {
 }
 
 DFrame* FrameStager::upload(uint32_t w, uint32_t h, uint8_t fmt, const uint8_t* const data[3], const int32_t stride[3]) {
+    std::lock_guard<std::mutex> lk(mu_);
     uint8_t* dst[3]; int32_t dst_stride[3];
-    const uint32_t ticket = acquire(w, h, fmt, dst, dst_stride);
+    const uint32_t ticket = acquire_locked(w, h, fmt, dst, dst_stride);
     const DFrame* f = slots_[ticket - 1].target.f;
     try {
         for (int p = 0; p < f->stored_planes(); ++p) {
@@ -222,10 +233,11 @@ DFrame* FrameStager::upload(uint32_t w, uint32_t h, uint8_t fmt, const uint8_t* 
         slots_[ticket - 1].held = false; slots_[ticket - 1].target = FrameRef();
         throw;
     }
-    return commit(ticket);
+    return commit_locked(ticket);
 }
 
 void FrameStager::fence(hipStream_t consumer) {
+    std::lock_guard<std::mutex> lk(mu_);
     consumer_ = consumer; have_consumer_ = true;
     if (any_) hip_check(hipStreamWaitEvent(consumer, last_, 0), "hipStreamWaitEvent(stager)");
 }

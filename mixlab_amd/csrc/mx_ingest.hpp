@@ -59,6 +59,7 @@ private:
 
 // Page-locked staging ring for decoded frames: rows are packed into a slot laid out like the device frame (strides, blank padding),
 // and the slot crosses PCIe as ONE asynchronous copy on the stager's own stream, beside whatever the consumer stream is doing.
+// Thread-safe: a decode thread may acquire / commit / upload while the engine thread fences.
 class FrameStager {
 public:
     explicit FrameStager(uint32_t slots);
@@ -73,6 +74,9 @@ public:
 private:
     struct Slot { uint8_t* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool in_flight = false, held = false; FrameRef target; size_t padded_for = 0; uint32_t pw = 0, ph = 0; uint8_t pfmt = 0; };
     FrameRef take_frame(uint32_t w, uint32_t h, uint8_t fmt);
+    uint32_t acquire_locked(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data[3], int32_t stride[3]);
+    DFrame* commit_locked(uint32_t ticket);
+    std::mutex mu_;                     // the decode thread acquires / commits, the engine thread fences
     std::vector<Slot> slots_; uint32_t next_ = 0;
     std::vector<FrameRef> pool_;        // device frames handed out before: one nobody else holds any more is written again
     hipStream_t stream_ = nullptr; hipEvent_t last_ = nullptr; bool any_ = false;

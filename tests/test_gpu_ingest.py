@@ -275,3 +275,54 @@ def test_queue_video_source_validates_order():
     assert video.graph_video_output(g, mx, 0) is None        # ticks 0 and 1: None
     g.run_ticks(2, 1)
     assert video.graph_video_output(g, mx, 0) is not None
+
+
+def test_decode_thread_and_engine_thread_run_concurrently():
+    """The shape of the real thing: a decode thread writes pictures into staging slots, commits them and sends them down the channel of two
+    (retrying while it is full) while the engine thread fences, feeds and runs submissions.  Timing decides WHICH tick a frame leaves on;
+    whatever it decides, the frames a Monitor node kept are the medium's pictures, complete, in order, none twice."""
+    import threading
+    import time
+    N, T = 40, 4
+    ws = Workspace(SR, 60)
+    sv = ws.source_video()
+    mon = ws.monitor(96, 64)                 # the medium's own size: the node keeps the frames themselves
+    ws.connect(sv, 0, mon, 0)
+    g = ws.build(max_ticks_per_run=T)
+    st = ingest.FrameStager(slots=3)
+    st.fence_graph(g)
+    ms = ingest.MediaSource(SR, 60)
+    ms.set_media(True)
+    pics = [ov.HostFrame(96, 64).fill(k, seed=77) for k in range(N)]
+    errors = []
+
+    def decode():
+        try:
+            for k in range(N):
+                ticket, views = st.acquire(96, 64)
+                for v, src in zip(views, pics[k].visible()):
+                    v[:, : src.shape[1]] = src
+                d = st.commit(ticket)
+                while not ms.send(d, F(k, 50), F(1, 50)):
+                    time.sleep(0.0002)
+        except Exception as e:          # surfaced by the main thread
+            errors.append(e)
+
+    th = threading.Thread(target=decode)
+    th.start()
+    got, tick = [], 0
+    deadline = time.time() + 60
+    while len(got) < N and time.time() < deadline:
+        st.fence_graph(g)
+        ms.feed(g, sv, tick, T)
+        g.run_ticks(tick, T)
+        for k, planes in enumerate(ingest.graph_read_monitor_video(g, mon, 0, T)):
+            if planes is not None:
+                got.append(planes)
+        tick += T
+    th.join()
+    assert not errors, errors
+    assert len(got) == N
+    for k, planes in enumerate(got):
+        for a, b in zip(planes, pics[k].visible()):
+            assert np.array_equal(a, b), f"frame {k} differs"
