@@ -104,3 +104,40 @@ def test_stream_input_offset_equal_to_tick_is_delivered():
     assert s.run_tick(0, 2 * 735)[1] is None                        # 2/60 > 1/60
     s.write_audio(5, F(1, 60), np.zeros(2 * 735, np.int16))
     assert s.run_tick(735, 2 * 735)[1] == (1, F(1, 30), F(1, 60))   # exactly one tick ahead: delivered
+
+
+# ------------------------------------------------------------------------------------------------
+# the C-ABI's host state machines need no device: StreamInput's audio side and its source timing on CPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_stream_input_abi_audio_side_equals_oracle_without_a_gpu(seed):
+    from mixlab_amd import ingest
+    acts = [[a for a in tick if a[0] != "video"] for tick in im.stream_scenario(seed)]   # device frames need a GPU; the rest does not
+
+    class Abi:
+        def __init__(self):
+            self.s = ingest.StreamInput(44100)
+
+        def listen(self, on):
+            self.s.listen(on)
+
+        def write_audio(self, sid, ts, samples):
+            return self.s.write_audio(sid, ts, samples)
+
+        def run_tick(self, t, n_out):
+            return self.s.run_tick(t, n_out)
+
+    got = play_stream(Abi(), acts)
+    want = play_stream(oracle.OStreamInput(44100), acts)
+    assert got == want
+    assert any(x[2] for x in want)
+
+
+def test_media_source_abi_without_frames_needs_no_gpu():
+    from mixlab_amd import ingest
+    m = ingest.MediaSource(48000, 60)
+    assert m.run_tick(0) is None
+    m.set_media(True)
+    assert [m.run_tick(k * 800) for k in range(5)] == [None] * 5
+    m.set_media(False)
+    assert m.run_tick(4000) is None
