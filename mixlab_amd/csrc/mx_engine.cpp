@@ -1150,14 +1150,26 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
     }
     old.sync(); sync();
     hip_check(hipSetDevice(device_), "hipSetDevice");
+    std::vector<CopyJob> jobs;   // thousands of small states (a 1024-strip graph: 2048 of 24 - 136 bytes): one launch, not one copy each
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t j = old_of_new[i];
+        if (j < 0) continue;
+        const auto a = state_locs((uint32_t)i), b = old.state_locs((uint32_t)j);
+        for (size_t k = 0; k < a.size() && k < b.size(); ++k)
+            if (a[k].bytes == b[k].bytes && a[k].bytes)   // a filter whose length changed starts from silence
+                jobs.push_back(CopyJob{a[k].p, b[k].p, a[k].bytes});
+    }
+    DevBuf job_buf;
+    if (!jobs.empty()) {
+        job_buf.alloc(jobs.size() * sizeof(CopyJob));
+        hip_check(hipMemcpyAsync(job_buf.p, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(adopt jobs)");
+        launch_copy_jobs((const CopyJob*)job_buf.p, (uint32_t)jobs.size(), stream_);
+        sync();                   // `jobs` and job_buf go out of scope
+    }
     for (size_t i = 0; i < n; ++i) {
         const int32_t j = old_of_new[i];
         if (j < 0) continue;
         Node& nn = nodes_[i]; Node& on = old.nodes_[j];
-        const auto a = state_locs((uint32_t)i), b = old.state_locs((uint32_t)j);
-        for (size_t k = 0; k < a.size() && k < b.size(); ++k)
-            if (a[k].bytes == b[k].bytes && a[k].bytes)   // a filter whose length changed starts from silence
-                hip_check(hipMemcpyAsync(a[k].p, b[k].p, a[k].bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(adopt state)");
         if (nn.kind == MX_KIND_PLOTTER) nn.plot_count = on.plot_count;          // plotter.rs:37-40
         if (nn.kind == MX_KIND_MONITOR) { nn.mon_has_epoch = on.mon_has_epoch; nn.mon_epoch = on.mon_epoch; }   // Monitor.epoch (monitor.rs:122)
         if (nn.kind == MX_KIND_VIDEO_MIXER && on.vmixer) {                       // stored frames, scalers, expiry times

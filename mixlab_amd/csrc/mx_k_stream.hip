@@ -225,4 +225,22 @@ void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_i16_to_f32, dim3(grid_x(n, 256, 4096)), dim3(256), 0, s, in, out, n);
 }
 
+// a list of small device-to-device copies as ONE launch (a topology edit carries thousands of modules' states over, mx_graph_adopt_state):
+// block b copies job b; 4-byte words when both ends and the length allow, bytes otherwise
+__global__ __launch_bounds__(64) void k_copy_jobs(const CopyJob* __restrict__ jobs) {
+    const CopyJob j = jobs[blockIdx.x];
+    const bool words = ((((uintptr_t)j.dst) | ((uintptr_t)j.src) | j.bytes) & 3u) == 0;
+    if (words) {
+        const uint32_t* s = (const uint32_t*)j.src; uint32_t* d = (uint32_t*)j.dst;
+        for (size_t i = threadIdx.x; i < j.bytes / 4; i += 64) d[i] = s[i];
+    } else {
+        const uint8_t* s = (const uint8_t*)j.src; uint8_t* d = (uint8_t*)j.dst;
+        for (size_t i = threadIdx.x; i < j.bytes; i += 64) d[i] = s[i];
+    }
+}
+void launch_copy_jobs(const CopyJob* device_jobs, uint32_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_copy_jobs, dim3(n), dim3(64), 0, s, device_jobs);
+}
+
 }  // namespace mx

@@ -128,6 +128,8 @@ void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, size_t fpc, co
 void launch_plotter(const PlotJob* d, uint32_t n, size_t spt, hipStream_t s);
 void launch_f32_to_i16(const float* in, int16_t* out, size_t n, int dup, hipStream_t s);
 void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s);
+struct CopyJob { void* dst; const void* src; size_t bytes; };
+void launch_copy_jobs(const CopyJob* device_jobs, uint32_t n, hipStream_t s);   // one block per job
 void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s);
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles /* max up * taps_per_phase */,
                      uint32_t win_frames /* max 255 * down / up + 2 + taps_per_phase */, size_t in_frames, size_t out_frames,
