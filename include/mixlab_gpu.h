@@ -314,7 +314,8 @@ int mx_video_mixer_create(const mx_video_mixer_params* params, uint32_t sample_r
 int mx_video_mixer_update(mx_video_mixer* m, const mx_video_mixer_params* params);
 /* One VideoMixer::run_tick (video_mixer.rs:70-250).  Returned frames carry one reference for the
  * caller (mx_dframe_release when done); NULL = None.  The program frame has duration 1/60 and
- * tick_offset 0 (video_mixer.rs:241-247). */
+ * tick_offset 0 (video_mixer.rs:241-247).  The pixels are produced asynchronously on the mixer's stream (mx_video_mixer_create; NULL = the
+ * library's default video stream, the one every entry point with a NULL stream uses): consume them there, or mx_video_mixer_sync first. */
 int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input inputs[4],
                             mx_dframe** out_program, mx_dframe** out_a, mx_dframe** out_b);
 int mx_video_mixer_sync(mx_video_mixer* m);

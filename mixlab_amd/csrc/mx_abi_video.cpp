@@ -248,7 +248,7 @@ int mx_video_mixer_create(const mx_video_mixer_params* params, uint32_t sample_r
         REQUIRE(params && out, "NULL argument");
         *out = nullptr;
         auto h = std::make_unique<mx_video_mixer>();
-        h->m = std::make_unique<mx::VideoMixer>(*params, sample_rate, (hipStream_t)stream);
+        h->m = std::make_unique<mx::VideoMixer>(*params, sample_rate, S(stream));   // NULL = the library's default video stream, like every stateless entry point: ordered with mx_dframe_upload / download on NULL
         *out = h.release();
     });
 }
@@ -270,6 +270,8 @@ int mx_video_mixer_run_tick(mx_video_mixer* m, uint64_t t, const mx_video_input 
         FrameRef o, a, b;
         m->m->run_tick(t, in, o, a, b);
         mx::flush_scales(m->m->stream());
+        // a mixer created without a stream works on one of its own, which no caller can order against: its frames are complete on return
+        if (m->m->owns_stream()) mx::hip_check(hipStreamSynchronize(m->m->stream()), "hipStreamSynchronize");
         auto give = [](FrameRef& r, mx_dframe** dst) {
             if (!dst) return;
             *dst = nullptr;

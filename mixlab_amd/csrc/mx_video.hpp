@@ -264,6 +264,7 @@ class VideoMixer {
 public:
     VideoMixer(const mx_video_mixer_params& p, uint32_t sample_rate, hipStream_t s);
     void update(const mx_video_mixer_params& p) { params_ = p; }   // video_mixer.rs:65-68
+    bool owns_stream() const { return own_stream_; }
     // program output as an unevaluated chain (graph compiler: single in-graph video consumer)
     void set_lazy_program(bool on, uint32_t ticks_per_second) { lazy_program_ = on; tps_ = ticks_per_second ? ticks_per_second : 60; }
     // returns program / A / B frames (null FrameRef = None)
