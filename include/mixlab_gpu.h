@@ -415,7 +415,8 @@ int mx_frame_stager_sync(mx_frame_stager* st);
 
 /* Output port of a video node after the last tick: one reference for the caller, NULL = None. */
 int mx_graph_video_output(mx_graph* g, uint32_t node, uint32_t port, mx_dframe** out);
-/* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame). */
+/* RGBA8 device buffer a VIDEO_TO_RGBA node wrote on the last tick (width/height 0 = no frame).  Written asynchronously on the graph's
+ * stream: read it there, or after mx_graph_sync. */
 int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t* stride, uint32_t* width, uint32_t* height);
 
 /* MX_KIND_MONITOR after a run.  Tick `tick_in_run` of the last mx_graph_run_ticks as the codec thread would see it:
