@@ -433,6 +433,12 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     for (auto& f : ring_) f = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
     ring_pos_ = 0; frame_ = ring_[0];
     keep_pool_.clear();                // their borders belong to the old letterbox
+    if (geo.scaled_w == 0 || geo.scaled_h == 0) {   // a picture so thin that its aligned scaled size has no rows or columns: scale() hands out the blank frame
+        // (the reference passes the zero dimension to sws_getContext, gets NULL and panics, codec/src/ffmpeg/scale.rs:22-33)
+        tmp_plane_[0] = tmp_plane_[1] = tmp_plane_[2] = nullptr;
+        t_ = std::move(t);
+        return;
+    }
     // tap tables: [luma h, luma v, chroma h, chroma v]
     std::vector<int32_t> blob;
     size_t offs[2][4];

@@ -266,6 +266,9 @@ void orc_dynamic_scale(const orc_frame* in, orc_frame* out) {
     orc_scale_geometry g;
     orc_scaler_geometry(in->width, in->height, out->width, out->height, &g);
     orc_frame_blank(out);
+    /* A picture so thin that its aligned scaled size has no rows or columns: the reference hands sws_getContext a zero dimension, gets
+     * NULL and panics (codec/src/ffmpeg/scale.rs:22-33).  BUILD-SPECIFIED instead of a panic: the blank letterbox frame. */
+    if (g.scaled_w == 0 || g.scaled_h == 0) return;
     for (int p = 0; p < 3; p++) {
         uint32_t sh_ = p ? 1 : 0;
         uint8_t* dst = out->data[p] + (size_t)(g.letterbox_y >> sh_) * out->stride[p] + (g.letterbox_x >> sh_);

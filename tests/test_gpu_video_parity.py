@@ -102,6 +102,26 @@ def test_scaler_input_of_another_pixel_format_is_converted_plane_by_plane(geom, 
     assert_frame_equal(res, want, f"persistent scaler {geom} fmt {fmt}")
 
 
+@pytest.mark.parametrize("geom", [((128, 6), (2, 220)), ((6, 128), (220, 2)), ((1920, 2), (64, 64))])
+def test_scaled_size_without_rows_or_columns_is_the_blank_letterbox(geom):
+    """A picture so thin that its aligned scaled size is zero rows or columns: the reference would panic (sws_getContext returns NULL for a
+    zero dimension, scale.rs:22-33); build-specified: the blank output frame, from every entry point."""
+    (iw, ih), (ow, oh) = geom
+    g = video.scale_geometry(iw, ih, ow, oh)
+    assert g == ov.scaler_geometry(iw, ih, ow, oh) and (g[0] == 0 or g[1] == 0)
+    src = ov.HostFrame(iw, ih).fill(3, seed=1)
+    want = ov.HostFrame(ow, oh); ov.dynamic_scale(src, want)
+    assert not want.visible()[0].any() and (want.visible()[1] == 0x80).all()
+    d = upload(src)
+    out = video.DFrame(ow, oh); video.scale(d, out)
+    assert_frame_equal(out, want, f"scale {geom}")
+    assert_frame_equal(video.Scaler(ow, oh).scale(d), want, f"persistent scaler {geom}")
+    gm, om = video.VideoMixer(a=0, b=1, fader=0.5), ov.OracleVideoMixer(a=0, b=1, fader=0.5)
+    big = ov.HostFrame(ow, oh).fill(9, seed=2)
+    prog, _, _ = gm.run_tick(0, [(upload(big), (1, 30), (0, 1)), (d, (1, 30), (0, 1)), None, None])
+    assert_frame_equal(prog, om.run_tick(0, [(big, (1, 30), (0, 1)), (src, (1, 30), (0, 1)), None, None]), f"mixer {geom}")
+
+
 def test_frame_formats_are_validated():
     with pytest.raises(abi.MxError):
         video.DFrame(33, 32, fmt=video.PIXFMT_YUV422P)      # 4:2:2 needs an even width
