@@ -209,8 +209,9 @@ __device__ __forceinline__ ScWin sc_window(int oxa, int oxb, int oya, int oyb, u
 // afterwards.
 template <int Q>
 __device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride, int sw, int sh, const ScWin& g, uint8_t* S, int s_stride, int tid,
-                                         const uint32_t sxs = 0u /* samples are 1 + sxs bytes apart ... */, const uint32_t sxo = 0u /* ... from byte sxo of a row (nv12 chroma) */) {
-    const int sw1 = sw - 1, sh1 = sh - 1;
+                                         const uint32_t sxs = 0u /* samples are 1 + sxs bytes apart ... */, const uint32_t sxo = 0u /* ... from byte sxo of a row (nv12 chroma) */,
+                                         const int row_lo = 0, const int row_hi = 0x7fffffff /* rows that exist behind `src` (a row band's slice); the slots load Q * 16 rows whether the tile needs them or not */) {
+    const int sw1 = sw - 1, sh1 = min(sh - 1, row_hi), sh0 = max(0, row_lo);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15u) == 0 && sw >= 16;
     const int c16 = tid & 15, x = g.cxa + 16 * c16;
     const bool col_ok = 4 * c16 < g.nc4, interior = aligned && x >= 0 && x + 15 <= sw1;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int r = (tid >> 4) + 16 * q;
-            const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+            const uint8_t* row = src + (size_t)min(max(g.ry0 + r, sh0), sh1) * src_stride;
             w[q] = aligned ? *reinterpret_cast<const uint4*>(row + xs) : make_uint4(0u, 0u, 0u, 0u);
         }
     } else {   // interleaved samples: 16 of them are the even (sxo = 0) or odd (1) bytes of 32 source bytes -- two loads and four byte permutes
@@ -228,7 +229,7 @@ __device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int r = (tid >> 4) + 16 * q;
-            const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride;
+            const uint8_t* row = src + (size_t)min(max(g.ry0 + r, sh0), sh1) * src_stride;
             uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
             if (aligned) { a = *reinterpret_cast<const uint4*>(row + 2 * xs); b = *reinterpret_cast<const uint4*>(row + 2 * xs + 16); }
             w[q] = make_uint4(__builtin_amdgcn_perm(a.y, a.x, sel), __builtin_amdgcn_perm(a.w, a.z, sel), __builtin_amdgcn_perm(b.y, b.x, sel), __builtin_amdgcn_perm(b.w, b.z, sel));
@@ -239,7 +240,7 @@ __device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride
         const int r = (tid >> 4) + 16 * q;
         if (r < g.nr && col_ok) {
             if (!interior) {                                                    // edge replication
-                const uint8_t* row = src + (size_t)min(max(g.ry0 + r, 0), sh1) * src_stride + sxo;
+                const uint8_t* row = src + (size_t)min(max(g.ry0 + r, sh0), sh1) * src_stride + sxo;
                 const int st = 1 + (int)sxs;
                 uint32_t d[4];
 #pragma unroll
@@ -539,7 +540,7 @@ __device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32
         vpk[k] = p.vpk[oy];
         vf[k] = p.vfirst[oy] - w.ry0;
     }
-    sc_stage<3>(p.src, p.src_stride, (int)p.sw, (int)p.sh, w, S, (int)a.s_stride, tid, p.sxs, p.sxo);   // launcher: s_rows <= 48, s_stride <= 256
+    sc_stage<3>(p.src, p.src_stride, (int)p.sw, (int)p.sh, w, S, (int)a.s_stride, tid, p.sxs, p.sxo, (int)p.h_row0, (int)(p.h_row0 + p.h_rows) - 1);   // launcher: s_rows <= 48, s_stride <= 256
     __syncthreads();
     if (ox0 + oxi < (int)p.dw) {   // the two threads of a column take half of the row pairs each
         const int np = w.nr - 1, half = (np + 1) >> 1, part = tid >> 7;

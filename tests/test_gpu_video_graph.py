@@ -234,6 +234,26 @@ def test_row_band_compositing_on_the_device_equals_the_unsharded_picture(full, s
         video.scale_band(upload(rows_of(f, need[0] + 2, need[1] - 2)), f.h, need[0] + 2, video.DFrame(W, band[1]), W, H, band[0])
 
 
+def test_row_band_of_a_strongly_upscaled_layer_reads_only_its_slice():
+    """200x212 into 1920x1080 over 8 bands: a 128 x 32 output tile needs ~11 source rows, the tiled scaler's staging slots load 48 -- rows
+    that do not exist behind a band's halo slice must be clamped away, not read (found by tools/stress_bands.py as a GPU memory fault)."""
+    from mixlab_amd import shard
+    from test_cpu_video_bands import rows_of
+    W, H, world = 1920, 1080, 8
+    layer = ov.HostFrame(200, 212).fill(22, seed=22)
+    want = ov.HostFrame(W, H); ov.dynamic_scale(layer, want)
+    got = [np.zeros_like(p) for p in want.visible()]
+    for (row0, rows) in shard.row_bands(H, world):
+        need = shard.band_source_rows((row0, rows), layer.w, layer.h, W, H)
+        d = video.DFrame(W, rows)
+        video.scale_band(upload(rows_of(layer, need[0], need[1])), layer.h, need[0], d, W, H, row0)
+        for p, a in enumerate(d.download()):
+            c = 1 if p else 0
+            got[p][row0 >> c:(row0 + rows) >> c, :] = a
+    for p, (a, b) in enumerate(zip(got, want.visible())):
+        assert np.array_equal(a, b), f"plane {p}"
+
+
 @pytest.mark.parametrize("full,small,world", [((320, 180), (212, 120), 4), ((1920, 1080), (1280, 720), 8)])
 def test_row_band_job_with_band_scaling_sources_in_one_submission(full, small, world):
     """The sharded job as a rank runs it: the smaller layers enter the graph as halo slices, their SOURCE nodes scale them to the band
