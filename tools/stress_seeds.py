@@ -13,6 +13,7 @@ import test_gpu_video_parity as vp
 import test_gpu_video_graph as vg
 import test_gpu_ingest as gi
 import test_ingest_oracle as io_
+import test_gpu_fir_resample as fr
 
 mp = pytest.MonkeyPatch()
 jobs = [
@@ -21,11 +22,15 @@ jobs = [
     ("video mixer scenario", lambda s: vp.test_video_mixer_random_scenarios_match_oracle(s)),
     ("cascade scenario", lambda s: vg.test_random_cascade_scenarios_in_random_batches(s, "0", mp)),
     ("cascade scenario inline", lambda s: vg.test_random_cascade_scenarios_in_random_batches(s, "1", mp)),
+    ("fir / resampler chains", lambda s: fr.test_random_resampler_and_fir_chains_match_oracle_graph(s)),
     ("media source", lambda s: gi.test_media_source_pacing_equals_oracle(s)),
     ("stream input", lambda s: gi.test_stream_input_pacing_and_reblocking_equal_oracle(s)),
 ]
 bad = 0
+only = [a[7:] for a in sys.argv if a.startswith("--only=")]
 for name, fn in jobs:
+    if only and name not in only:
+        continue
     ok = 0
     for seed in range(first, first + count):
         try:
