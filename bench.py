@@ -54,14 +54,14 @@ def gate_open(tick, k):
 
 
 def gate_events(abi, trigs, first_strip, t0, n_ticks):
-    """The toggles of every strip's Trigger that fall INSIDE ticks (t0, t0 + n_ticks) as one mx_param_event array for
-    mx_graph_schedule_params_batch (the gate at t0 itself is what the previous step left, or the initial params).
-    Returns (ctypes pointer, count, keep-alive tuple) or None.  Built with numpy: ~70 000 events per 2048-tick step."""
+    """The toggles of every strip's Trigger that fall on ticks [t0, t0 + n_ticks) as one mx_param_event array for
+    mx_graph_schedule_params_batch (tick_in_run 0 = the boundary before the submission's first tick: a strip whose toggle falls exactly
+    on t0 gets it there).  Returns (ctypes pointer, count, keep-alive tuple) or None.  Built with numpy: ~70 000 events per 2048-tick step."""
     import ctypes as C
     p_open, p_closed = abi.TriggerParams(1), abi.TriggerParams(0)
     po, pc = C.addressof(p_open), C.addressof(p_closed)
     k = first_strip + np.arange(len(trigs), dtype=np.int64)
-    first = 30 - (t0 + k) % 30                                    # first toggle after t0, per strip
+    first = (30 - (t0 + k) % 30) % 30                             # first toggle at or after t0, per strip
     n_ev = np.maximum(0, (n_ticks - first + 29) // 30)            # toggles at first, first + 30, ... < n_ticks
     total = int(n_ev.sum())
     if total == 0:
@@ -566,6 +566,7 @@ def main():
     ap.add_argument("--force-combine", action="store_true", help="run the N > 1 exchange path at N = 1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
     ap.add_argument("--repeats", type=int, default=4, help="further repetitions of the K timed steps after the headline region (spread of the clock)")
+    ap.add_argument("--no-t-sweep", action="store_true", help="skip the shorter-submission legs (T = 64 and 1024 ticks, SURVEY 8d)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the one-tick-per-submission leg (hundreds of tiny dispatches: slow under a counter-collecting profiler)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 240-strip + 8-layer real-time leg")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
@@ -733,6 +734,33 @@ def main():
         realtime = {"ticks_per_submission": 1, "tick_us": round(tick_us, 1), "tick_budget_us": round(1e6 / 60.0, 1),
                     "headroom": round(1e6 / 60.0 / tick_us, 1), "note": "submit + wait per tick (host-paired), same 1024-strip graph, exact EqThree"}
 
+    # shorter submissions of the same graph (T in {1, 64, 1024}; T = 1 is the real-time leg above), gates toggling as in the headline
+    t_sweep = None
+    if not use_dist and not args.no_t_sweep:
+        t_sweep = {}
+        with torch.cuda.stream(stream):
+            tick0 = (nxt + 64) * T
+            for Ts in (64, 1024):
+                if Ts >= T:
+                    continue
+                n_sub = 12 if Ts >= 512 else 60
+                evs = [gate_events(abi, trigs, first, tick0 + i * Ts, Ts) if toggling else None for i in range(n_sub + 3)]
+
+                def sub(i):
+                    if evs[i] is not None:
+                        g.schedule_params_batch(evs[i][0], evs[i][1])
+                    g.run_ticks(tick0 + i * Ts, Ts)
+                for i in range(3):
+                    sub(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(3, n_sub + 3):
+                    sub(i)
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - t0
+                t_sweep[str(Ts)] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub}
+                tick0 += (n_sub + 3) * Ts
+
     video = None
     if args.video_frames > 0:
         with torch.cuda.stream(stream):
@@ -822,6 +850,7 @@ def main():
             "held_gates": held,
             "exchange": exch,
             "realtime": realtime,
+            "t_sweep": t_sweep,
             "north_star_realtime": north,
             "video": video,
             "fir_resample": fir,

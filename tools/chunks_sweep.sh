@@ -1,4 +1,4 @@
 for nc in 128 192 256 384; do
   echo -n "chunks=$nc "
-  MX_EQ_SPEC_CHUNKS=$nc timeout 300 python bench.py --no-cpu-baseline --fir-ticks 0 --no-realtime --no-north-star --video-frames 0 --no-held-leg --repeats 0 --steps 10 --warmup 2 2>&1 | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],3), d["roofline"]["kernel_ms_per_step"], d["eq_spec"])'
+  MX_EQ_SPEC_CHUNKS=$nc timeout 300 python bench.py --no-cpu-baseline --fir-ticks 0 --no-realtime --no-t-sweep --no-north-star --video-frames 0 --no-held-leg --repeats 0 --steps 10 --warmup 2 2>&1 | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],3), d["roofline"]["kernel_ms_per_step"], d["eq_spec"])'
 done

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-realtime --no-north-star --no-held-leg --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 320"
+COMMON="--no-cpu-baseline --no-realtime --no-t-sweep --no-north-star --no-held-leg --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 320"
 # 1. the default command, as the driver runs it
 timeout 900 python $REPO/bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 # 2. the same command under the kernel trace
