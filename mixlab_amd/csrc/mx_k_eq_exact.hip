@@ -411,20 +411,26 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
     const size_t begin = (size_t)j * C;
     const size_t len = r.frames - begin < C ? r.frames - begin : C;
     EqPoles s;
-    if (j == 0) {
+    // A chunk whose warm-up window would reach the stream's start warms up from THERE, from the carried state: exact, not a guess
+    // (chunks may be shorter than the warm-up, eq_plan_spec).  Chunk 0 is that case with nothing to walk.
+    const bool from_start = begin <= W;
+    const size_t wlen = from_start ? begin : W;
+    if (from_start) {
         const EqState& st = states[inst];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
         s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
     } else {
-        // warm-up: the exact recurrence over the W samples before my chunk, from a zero state (C >= W: they exist)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s.lo[k] = 0.0; s.hi[k] = 0.0; }
-        const float* __restrict__ in = d.in + (begin - W);
+    }
+    if (wlen) {
+        // the exact recurrence over the wlen samples before my chunk (a multiple of EQ_BLK: chunks are multiples of 32 samples)
+        const float* __restrict__ in = d.in + (begin - wlen);
         f4v xa[EQ_BLK / 4];
 #pragma unroll
         for (int q = 0; q < EQ_BLK / 4; ++q) xa[q] = ld_stream4(in + 4 * q);
-        const size_t n_blk = W / EQ_BLK;
+        const size_t n_blk = wlen / EQ_BLK;
         for (size_t b = 0; b < n_blk; ++b) {
             f4v xb[EQ_BLK / 4];
             const size_t nb = (b + 1 < n_blk ? b + 1 : b) * EQ_BLK;
@@ -532,7 +538,7 @@ __device__ __forceinline__ EqK eq_constants(const EqDesc& d, const EqRun& r) {
 }
 
 // compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
-template <int SB, int MODE, int ENVK, bool WARM>
+template <int SB, int MODE, int ENVK, bool WARM>   // WARM: `len` is the (negative) chunk-relative index of the lane's first warm-up sample
 __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const int lane, const int so, const int len,
                                                 const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     const double g_lo = K.g_lo, g_mid = K.g_mid, g_hi = K.g_hi, lo_f = K.lo_f, hi_f = K.hi_f;
@@ -545,7 +551,7 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
 #pragma unroll 1   // (unrolling the row fully, or by two, was measured: no faster -- the moves at the back edge go, the code grows 4x)
     for (int pce = 0; pce < G::S; ++pce) {
         const f4v xn = row[((pce + 1) & (G::S - 1)) ^ sw];            // next piece travels while this one is computed
-        if (WARM || so + 4 * pce < len) {
+        if (WARM ? (so + 4 * pce >= len) : (so + 4 * pce < len)) {
             // the delay line is "the last three inputs" (s.h0, s.h1, s.h2 = x[i-3], x[i-2], x[i-1]): the four samples of a piece read
             // s.h0, s.h1, s.h2 and the piece's own first input, then the piece's last three inputs become the delay line -- no shifts
             const double dx[4] = {(double)x4[0], (double)x4[1], (double)x4[2], (double)x4[3]};
@@ -626,6 +632,16 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s.lo[k] = 0.0; s.hi[k] = 0.0; }
     s.h0 = s.h1 = s.h2 = 0.0;
+    // A chunk whose warm-up window would reach the stream's start warms up from THERE, from the carried state (exact); chunk 0 is that
+    // case with nothing to walk.  warm_from: chunk-relative index of my first warm-up sample (a multiple of 4: chunks are multiples of 32).
+    const bool from_start = begin <= (long long)plan.warm;
+    const int warm_from = from_start ? -(int)begin : -(int)plan.warm;
+    if (from_start) {
+        const EqState& st = states[inst];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
+        s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
+    }
     uint32_t xmin = 0xffffffffu, xmax = 0u;
     const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
     EnvTick cur{}; EnvLane el{};
@@ -642,16 +658,10 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
         if (g + 1 < total) { if (SB == 32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (g < n_warm) {
-            if (j != 0) eq_tile_compute<SB, EQM_PLAIN, 0, true>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            eq_tile_compute<SB, EQM_PLAIN, 0, true>(K, buf, c.lane, so, warm_from, cur, el, s, xmin, xmax);
             continue;
         }
-        if (g == n_warm) {   // first sample of my chunk: chunk 0 takes the carried state, the others record where the warm-up took them
-            if (j == 0) {
-                const EqState& st = states[inst];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
-                s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
-            }
+        if (g == n_warm) {   // first sample of my chunk: record where the warm-up took me (chunks that started at the stream's start: the exact state)
             if (active) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
@@ -836,7 +846,10 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     // lane of a wave crosses its tick boundaries at the same step), else multiples of 32 samples.
     const size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
     auto chunk_of = [&](size_t nc) { return ((frames + nc - 1) / nc + unit - 1) / unit * unit; };
-    const size_t nc_max = frames / W;                          // C >= W: a warm-up never reaches before the stream
+    // Chunks may be SHORTER than the warm-up (a chunk whose window would reach the stream's start warms up from there, from the carried
+    // state): short submissions get a wave of 64 chunks per strip where C >= W allowed 40.  Not below 256 samples.
+    const size_t c_min = std::max<size_t>(unit, 256);
+    const size_t nc_max = frames / c_min;
     size_t best;
     if (force_c > 1) best = std::min<size_t>((size_t)force_c, nc_max);
     else {
@@ -847,7 +860,8 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
         // pace whether 1 or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
         auto cost = [&](size_t nc) {
             const double waves = (double)n * (double)((nc + 63) / 64);
-            const double occ = std::min(1.0, waves / 3072.0);
+            const double rounds = std::ceil(waves / 3072.0);            // waves beyond one round of 3 per SIMD wait for a second one
+            const double occ = waves / (rounds * 3072.0);
             return ((double)nc * (double)(chunk_of(nc) + W)) / occ;     // ~ frames + nc * W, with the chunk rounding
         };
         best = std::min<size_t>(64, nc_max);
@@ -865,7 +879,7 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     }
     if (best < 2) return false;
     size_t C = chunk_of(best);
-    if (C < W) C = (W + unit - 1) / unit * unit;
+    if (C < c_min) C = (c_min + unit - 1) / unit * unit;
     plan.chunk = (uint32_t)C; plan.warm = (uint32_t)W;
     plan.n_chunks = (uint32_t)((frames + C - 1) / C);
     return plan.n_chunks >= 2;

@@ -144,6 +144,53 @@ def test_spec_eq_nan_and_infinity_poison_the_poles_exactly_like_the_sequential_f
 
 
 @pytest.mark.parametrize("rate", RATES)
+@pytest.mark.parametrize("chunks", ["0", "24"])
+def test_spec_eq_chunks_shorter_than_the_warm_up(rate, chunks, monkeypatch):
+    """A short submission (24 ticks) cut into one-tick chunks: 735 / 800 samples against a warm-up of 1 280.  The chunks whose warm-up
+    window would reach the stream's start warm up from there, from the carried state (exact); the others speculate as always.  Every
+    epilogue form (the tiled kernel and -- with a control BUFFER -- the direct one), two submissions so that the state carries."""
+    SR, SPT = rate
+    T = 24
+    monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", chunks)
+    ws = Workspace(SR, 60)
+    src = [ws.source_mono() for _ in range(3)]; ctl_src = ws.source_mono()
+    eq = [ws.eq_three(3.0 - k, -2.0 + k, 1.5 * k) for k in range(3)]
+    pan = [ws.stereo_panner() for _ in range(2)]
+    for s_, e in zip(src, eq):
+        ws.connect(s_, 0, e, 0)
+    for k in range(2):
+        ws.connect(eq[k + 1], 0, pan[k], 0); ws.connect(eq[k + 1], 0, pan[k], 1)
+    amp_buf = ws.amplifier(0.9, 0.6); ws.connect(pan[0], 0, amp_buf, 0); ws.connect(ctl_src, 0, amp_buf, 1)
+    trig = ws.trigger(True); env = ws.envelope(5.0, 80.0, 0.6, 40.0)
+    amp_env = ws.amplifier(1.0, 0.5); ws.connect(pan[1], 0, amp_env, 0); ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp_env, 1)
+    mix = ws.mixer([(0.0, 1.0, True)]); ws.connect(amp_env, 0, mix, 0)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    outs = {"eq": (eq[0], 0, False), "amp_buf": (amp_buf, 0, True), "master": (mix, 0, True)}
+    for run in range(2):
+        x = [synth.noise(860 + 3 * run + k, T * SPT) for k in range(3)]
+        ctl = np.abs(synth.noise(870 + run, T * SPT))
+        for s_, v in zip(src, x):
+            g.write_source(s_, v, T)
+        g.write_source(ctl_src, ctl, T)
+        g.schedule_params(trig, 7, abi.TriggerParams(run)); g.schedule_params(trig, 15, abi.TriggerParams(1 - run))
+        g.run_ticks(run * T, T)
+        got = {k: g.read_output(nd, port, T, st) for k, (nd, port, st) in outs.items()}
+        for t in range(T):
+            if t == 7: og.update_params(trig, abi.TriggerParams(run))
+            if t == 15: og.update_params(trig, abi.TriggerParams(1 - run))
+            for s_, v in zip(src, x):
+                og.set_source(s_, v[t * SPT:(t + 1) * SPT])
+            og.set_source(ctl_src, ctl[t * SPT:(t + 1) * SPT])
+            og.run_tick(run * T + t)
+            for k, (nd, port, st) in outs.items():
+                w = og.output(nd, port)
+                assert_bit_exact(got[k][t * w.size:(t + 1) * w.size], w, f"run {run} {k} tick {t}")
+    ran, _ = g.eq_spec_stats()
+    assert ran >= 2 * 3 * 20       # one-tick chunks: the plan really is shorter than the warm-up
+
+
+@pytest.mark.parametrize("rate", RATES)
 def test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate):
     """The chunk loop's four epilogue modes on long streams: plain EQ; EQ -> Panner (stereo store); -> Amplifier with a control
     BUFFER; -> Amplifier with a Disconnected control; -> Amplifier whose control is an inline Envelope (per-tick states), the last
