@@ -11,8 +11,8 @@ strip-ticks (one stereo strip processed and mixed for one 1/60 s tick) per secon
 
 N > 1 (BASELINE.json configs[4]): the 1024 strips are sharded contiguously over the ranks (strong
 scaling), each rank runs Mixer(1024/N) over its strips, and the partial Master / Cue buses are combined by
-mixlab_amd/exchange.py (rank-ordered sum = the reference-expressible graph N x Mixer(1024/N) -> Mixer(N); --exchange
-allreduce is the north-star's non-parity collective).
+the library's own exchange (mx_exchange_*, RCCL called from libmixlab_gpu.so: rank-ordered sum = the reference-expressible
+graph N x Mixer(1024/N) -> Mixer(N); --exchange allreduce is the north-star's non-parity collective).
 
 One JSON line on rank 0; see the task contract for the fields.  `roofline` describes the launch group that took the most
 device time in the timed region (hipEvents on the graph's stream, recorded inside the timed region); `roofline.per_kernel`
@@ -561,7 +561,7 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="materialise every port (MX_FLAG_NO_FUSE): module-boundary traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["auto", "slices", "allgather", "allreduce"], default="auto",
-                    help="N > 1 bus exchange (mixlab_amd/exchange.py): ordered reduce-scatter + all-gather over time slices (auto: N >= 4), one all-gather of "
+                    help="N > 1 bus exchange (mx_exchange_*): ordered reduce-scatter + all-gather over time slices (auto: N >= 4), one all-gather of "
                          "the whole partial buses (auto: N < 4), or ncclAllReduce (NOT the sum order of a reference graph: non-parity)")
     ap.add_argument("--force-combine", action="store_true", help="run the N > 1 exchange path at N = 1 (single-rank RCCL group)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
@@ -619,9 +619,16 @@ def main():
         g.write_source(s, np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt], T)
 
     ex = None
+    nccl_id = None
     if use_dist:
-        from mixlab_amd.exchange import BusExchange
-        ex = BusExchange(torch, dist, g, mix, T, SR, local_rank, stream, mode=args.exchange)
+        # the exchange is the library's (mx_exchange_*: RCCL called from libmixlab_gpu.so); torch.distributed only carries the
+        # job's ncclUniqueId from rank 0 to the others, the barriers and the max-over-ranks of the clock
+        from mixlab_amd.exchange import BusExchange, unique_id
+        box = [unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        nccl_id = box[0]
+        ex = BusExchange(g, mix, T, rank, world, mode=args.exchange, nccl_id=nccl_id)
 
     # every step's gate toggles, built before any clock starts (the schedule is host data, like the params a UI would send)
     n_regions = 1 + (max(0, args.repeats) if not use_dist else 0)
@@ -691,31 +698,30 @@ def main():
 
     exch = None
     if ex is not None:
-        # what the exchange costs on its own stream: K more steps with an event pair around the exchange of each
+        # what the exchange costs on its own stream: 4 more steps, the library's own event pair around the exchange of each
         with torch.cuda.stream(stream):
-            evs = []
             for i in range(4):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 g.run_ticks((nxt + i) * T, T)
-                with torch.cuda.stream(ex.comm):
-                    pass
-                ex.comm.wait_stream(stream)
-                e0.record(ex.comm)
                 ex.submit(nxt + i)
-                e1.record(ex.comm)
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-        ex_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
-        exch = {"mode": ex.mode, "rccl_ranks": dist.get_world_size(), "bytes_received_per_rank_per_step": ex.bytes_received_per_step(),
+                torch.cuda.synchronize()
+                if i == 0:
+                    ex_ms_all = []
+                ex_ms_all.append(ex.elapsed_ms(nxt + i))
+        ex_ms = sorted(ex_ms_all)[len(ex_ms_all) // 2]
+        exch = {"mode": ex.mode, "rccl_ranks": ex.world, "transport": "RCCL, called by libmixlab_gpu.so (mx_exchange_*)",
+                "bytes_received_per_rank_per_step": ex.bytes_received_per_step(),
                 "exchange_ms_per_step": round(ex_ms, 4), "parity": "rank-ordered f32 sum (the graph N x Mixer(strips/N) -> Mixer(N))" if ex.mode != "allreduce"
                 else "NONE: ncclAllReduce order is not a reference graph's"}
         if ex.mode == "allreduce" and world > 1:
             # measured deviation of the all-reduce from the ordered sum of the same partial buses
-            ordered = BusExchange(torch, dist, g, mix, T, SR, local_rank, stream, mode="allgather")
+            box = [unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ordered = BusExchange(g, mix, T, rank, world, mode="allgather", nccl_id=box[0])
             with torch.cuda.stream(stream):
-                g.run_ticks((nxt + 8) * T, T); ex.submit(0); ordered.submit(0)
+                g.run_ticks((nxt + 8) * T, T); ex.submit(nxt + 8); ordered.submit(0)
                 torch.cuda.synchronize()
-            exch["max_ulp_vs_ordered_sum"] = ex.max_ulp_vs(0, *ordered.result(0))
+            exch["max_ulp_vs_ordered_sum"] = ex.max_ulp_vs(nxt + 8, *ordered.result(0))
+            ordered.close()
 
     # real-time regime: one 60 Hz tick per submission, synchronised every tick like a live engine
     realtime = None
@@ -839,7 +845,7 @@ def main():
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
                        "overlap": "MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k runs on a second stream beside step k + 1's EqThree group (strip ports double-buffered)" if overlap else "off",
                        "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else ""),
-                       "rccl_ranks": dist.get_world_size() if use_dist else 0},
+                       "rccl_ranks": ex.world if ex is not None else 0},
             "realtime_channels_equiv": value / 60.0,
             "graph_hbm_frac_moved_bytes": round(moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "eq_spec": {"chunks_run": spec_ran, "chunks_repaired": spec_repaired},

@@ -143,6 +143,8 @@ void mx_graph_destroy(mx_graph* g);
 int mx_graph_samples_per_tick(const mx_graph* g, size_t* spt);                 /* SAMPLES_PER_TICK, src/engine.rs:55 */
 int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n); /* DFS order of src/engine.rs:421-457 */
 
+/* The hipStream_t the graph launches on (the one given in mx_graph_opts, or its own): for ordering other device work against a run. */
+int mx_graph_stream(mx_graph* g, void** stream);
 /* MX_FLAG_OVERLAP_TAIL: the stream the last launch group runs on (NULL when the mode is off or the graph has no such group). */
 int mx_graph_tail_stream(mx_graph* g, void** stream);
 
@@ -437,6 +439,58 @@ int mx_graph_read_monitor_video(mx_graph* g, uint32_t node, uint32_t first_tick,
 /* The mix the node received over the first n_ticks ticks of the last run, as the encoder's PCM: clamp to [-1, 1], * 32767, truncate
  * (encode.rs:183-195), converted on the device: audio[n_ticks * 2 * SPT].  A Disconnected input reads zeros (io.rs:56-57). */
 int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, uint32_t n_ticks);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* multi-GPU: the bus exchange of a strip-sharded job                       */
+/* ---------------------------------------------------------------------------------------------- */
+
+/* One process per GPU, the reference's single engine thread (src/engine.rs:78-96) in each.  Strips are partitioned contiguously
+ * over the ranks; the sharded job is DEFINED as the reference-expressible graph  N x Mixer(strips / N) -> Mixer(N, unity gains):
+ * every sample of the whole Master / Cue bus is the f32 sum of the N partial buses in rank order 0 .. N-1 (Mixer::run_tick,
+ * src/module/mixer.rs:57-68, applied to the partials), and every rank ends with it.  The exchange runs on its own stream,
+ * pipelined against the next step's compute: two steps may be in flight.
+ *   MX_EXCHANGE_ALLGATHER  one ncclAllGather of the [master | cue] partials, then the rank-ordered sum: (N - 1) bus lengths received
+ *   MX_EXCHANGE_SLICES     ordered reduce-scatter + all-gather: the step's ticks are cut into N time slices, rank j receives slice j
+ *                          of every partial (grouped ncclSend / ncclRecv), sums it in rank order, an all-gather distributes the
+ *                          finished slices: 2 (N - 1) / N bus lengths received.  Bit-identical to ALLGATHER.  n_ticks % N == 0.
+ *   MX_EXCHANGE_ALLREDUCE  ncclAllReduce(sum): NOT the summation order of any graph the reference can express (non-parity mode)
+ *   MX_EXCHANGE_AUTO       SLICES when N >= 4 and the ticks divide, else ALLGATHER */
+enum { MX_EXCHANGE_AUTO = 0, MX_EXCHANGE_ALLGATHER = 1, MX_EXCHANGE_SLICES = 2, MX_EXCHANGE_ALLREDUCE = 3 };
+#define MX_EXCHANGE_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+typedef struct mx_exchange mx_exchange;
+typedef struct mx_loopback_group mx_loopback_group;
+
+/* ncclGetUniqueId: rank 0 makes the job's id and hands the 128 bytes to the other ranks by any means it has (the reference's
+ * hosts already talk over sockets); every rank passes them to mx_exchange_create, which is collective (ncclCommInitRank). */
+int mx_exchange_unique_id(void* id_out /* MX_EXCHANGE_ID_BYTES */);
+/* In-process transport for `world` exchanges of ONE process (virtual ranks on one GPU, or one thread driving several GPUs):
+ * device-to-device copies stand in for the collectives; buffers, combine and pipelining are the RCCL path's.  Every member
+ * submits step k before any member submits step k + 1.  Destroy the group after its exchanges. */
+int mx_loopback_group_create(uint32_t world, mx_loopback_group** out);
+void mx_loopback_group_destroy(mx_loopback_group* grp);
+
+/* Exchange of Mixer `mixer_node`'s two output buses of `g` over steps of `n_ticks` ticks (<= max_ticks_per_run).  Exactly one of
+ * nccl_unique_id / loopback is given.  `g` must outlive the exchange; not with MX_FLAG_OVERLAP_TAIL. */
+int mx_exchange_create(mx_graph* g, uint32_t mixer_node, uint32_t n_ticks, uint32_t rank, uint32_t world,
+                       const void* nccl_unique_id, mx_loopback_group* loopback, uint32_t mode, mx_exchange** out);
+void mx_exchange_destroy(mx_exchange* x);
+/* After mx_graph_run_ticks of step `step` (any increasing numbering): pack the partial buses on the graph's stream and queue the
+ * exchange + combine behind them on the exchange's stream.  Asynchronous.  Steps `step` and `step - 1` stay readable. */
+int mx_exchange_submit(mx_exchange* x, uint64_t step);
+/* Make `stream` (NULL = the graph's stream) wait for step `step`'s combined bus. */
+int mx_exchange_wait(mx_exchange* x, uint64_t step, void* stream);
+/* Device pointers of the combined Master / Cue of step `step` (n_ticks tick buffers each, interleaved stereo): valid on a stream
+ * that waited (mx_exchange_wait), until step + 2 is submitted -- or, when the consumer reads them on a stream of its own, until
+ * the point it marks with mx_exchange_release (the exchange orders its next write of those buffers after that point). */
+int mx_exchange_result(mx_exchange* x, uint64_t step, void** master_device, void** cue_device, size_t* floats_per_bus);
+int mx_exchange_release(mx_exchange* x, uint64_t step, void* stream);
+/* The same to host memory, synchronously (either pointer may be NULL). */
+int mx_exchange_read_result(mx_exchange* x, uint64_t step, float* master, float* cue);
+/* Device time of step `step`'s exchange on its own stream (collectives + combine), ms; waits for it. */
+int mx_exchange_elapsed_ms(mx_exchange* x, uint64_t step, float* ms);
+int mx_exchange_sync(mx_exchange* x);
+typedef struct { uint32_t mode, rank, world, loopback; uint64_t floats_per_bus, bytes_received_per_step; } mx_exchange_info;
+int mx_exchange_get_info(const mx_exchange* x, mx_exchange_info* out);
 
 /* plain device memory for consumers of mx_video_to_rgba (tests, bench) */
 int mx_device_alloc(size_t bytes, void** device_ptr);

@@ -121,6 +121,7 @@ _proto("mx_graph_read_output_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, 
 _proto("mx_graph_write_source_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_output_device_ptr", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 _proto("mx_graph_tail_stream", C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
+_proto("mx_graph_stream", C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
 _proto("mx_graph_read_plotter", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int))
 _proto("mx_graph_profile_run", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
 _proto("mx_graph_profile_enable", C.c_int, C.c_void_p, C.c_int)
@@ -262,6 +263,12 @@ class Graph:
         n = C.c_size_t()
         check(lib.mx_graph_output_device_ptr(self._h, node, port, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def stream(self):
+        """the hipStream_t the graph launches on"""
+        p = C.c_void_p()
+        check(lib.mx_graph_stream(self._h, C.byref(p)))
+        return p.value
 
     def tail_stream(self):
         """MX_FLAG_OVERLAP_TAIL: the stream the last launch group runs on (None when the mode is off)."""

@@ -90,6 +90,9 @@ int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n
     });
 }
 
+int mx_graph_stream(mx_graph* g, void** stream) {
+    return guard([&] { REQUIRE(g && stream, "NULL argument"); *stream = (void*)g->g->stream(); });
+}
 int mx_graph_tail_stream(mx_graph* g, void** stream) {
     return guard([&] { REQUIRE(g && stream, "NULL argument"); *stream = (void*)g->g->tail_stream(); });
 }

@@ -107,6 +107,8 @@ public:
     size_t cap_frames() const { return cap_frames_; }
     const std::vector<uint32_t>& run_order() const { return order_; }
     hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
+    uint32_t ticks_per_second() const { return tps_; }
     hipStream_t tail_stream() const { return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL
     size_t n_nodes() const { return nodes_.size(); }
     bool eq_exact() const { return (flags_ & MX_FLAG_EQ_EXACT) || !(flags_ & MX_FLAG_EQ_FAST); }   // the default is the reference's order
