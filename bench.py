@@ -253,7 +253,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
         prev = m
     rgba = ws.video_to_rgba(VIDEO_MATRIX)
     ws.connect(prev, 0, rgba, 0)
-    T = 64
+    T = 256   # ticks per submission (a throughput knob like the audio leg's: the video pipeline fills and drains once per run)
     g = ws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
     keep = []
     for k, (w, h) in enumerate(sizes):

@@ -108,6 +108,8 @@ int mx_graph_schedule_params_batch(mx_graph* g, const mx_param_event* events, si
     return guard([&] {
         REQUIRE(g, "graph is NULL");
         REQUIRE(events || !n_events, "events is NULL");
+        // all or nothing: every event is validated before the first one is queued
+        for (size_t i = 0; i < n_events; ++i) g->g->check_schedule(events[i].node, events[i].params, events[i].params_len);
         for (size_t i = 0; i < n_events; ++i) g->g->schedule_params(events[i].node, events[i].tick_in_run, events[i].params, events[i].params_len);
     });
 }
@@ -133,7 +135,12 @@ int mx_graph_bind_source_device(mx_graph* g, uint32_t node, const void* device_p
 int mx_graph_run_ticks(mx_graph* g, uint64_t first_tick, uint32_t n_ticks) {
     return guard([&] {
         REQUIRE(g, "graph is NULL");
-        g->g->run(first_tick * (uint64_t)g->g->spt(), g->g->spt(), n_ticks);   // t = tick * SPT, src/engine.rs:490
+        try {
+            g->g->run(first_tick * (uint64_t)g->g->spt(), g->g->spt(), n_ticks);   // t = tick * SPT, src/engine.rs:490
+        } catch (...) {
+            g->g->drop_schedules();   // a run that failed part-way must not leave its updates queued for the next one
+            throw;
+        }
     });
 }
 

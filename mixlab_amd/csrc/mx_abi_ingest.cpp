@@ -96,6 +96,10 @@ int mx_media_source_feed(mx_media_source* m, mx_graph* g, uint32_t node, uint64_
     return guard([&] {
         REQUIRE(m && g, "NULL argument");
         REQUIRE(node < g->g->n_nodes() && g->g->node(node).kind == MX_KIND_SOURCE_VIDEO, "node is not a SOURCE_VIDEO");
+        // everything that can fail is checked BEFORE a frame leaves the pacing state machine: a rejected feed loses no media
+        REQUIRE((double)m->m.sample_rate() == g->g->sample_rate() && m->m.ticks_per_second() == g->g->ticks_per_second(),
+                "the media source and the graph run at different sample / tick rates");
+        g->g->check_video_queue(node, first_tick);
         for (uint32_t k = 0; k < n_ticks; ++k) {
             mx::TickVideo v = m->m.run_tick((first_tick + k) * (uint64_t)g->g->spt());   // t of tick k, src/engine.rs:490
             if (v.frame) g->g->queue_video_source(node, first_tick + k, v.frame.f, v.duration_hint, v.tick_offset);
@@ -145,6 +149,9 @@ int mx_stream_input_feed(mx_stream_input* s, mx_graph* g, uint32_t audio_node, u
         const bool with_video = video_node != UINT32_MAX;
         if (with_video) REQUIRE(video_node < g->g->n_nodes() && g->g->node(video_node).kind == MX_KIND_SOURCE_VIDEO, "video node is not a SOURCE_VIDEO");
         REQUIRE((double)s->sr == g->g->sample_rate(), "the stream input and the graph run at different sample rates");
+        // everything that can fail is checked BEFORE the rings are drained: a rejected feed loses no media
+        g->g->check_source_write(audio_node, (size_t)n_ticks * g->g->spt());
+        if (with_video) g->g->check_video_queue(video_node, first_tick);
         const size_t per_tick = 2 * g->g->spt(), need = per_tick * (size_t)n_ticks;
         if (need > s->stage_cap) {
             if (s->stage) { (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_cap = 0; }

@@ -696,11 +696,22 @@ void Graph::apply_params(uint32_t node, const void* params, size_t len) {
     if (o != (int32_t)node && nodes_[o].group >= 0) upload_group(groups_[nodes_[o].group]);
 }
 
-void Graph::schedule_params(uint32_t node, uint32_t tick, const void* params, size_t len) {
+void Graph::check_schedule(uint32_t node, const void* params, size_t len) const {
     if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
-    Node& n = nodes_[node];
+    const Node& n = nodes_[node];
     if (len != n.params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
     if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
+}
+
+void Graph::drop_schedules() {
+    for (uint32_t id : sched_nodes_) { nodes_[id].sched.clear(); nodes_[id].gate_sched.clear(); }
+    if (!sched_nodes_.empty()) ++gates_version_;
+    sched_nodes_.clear();
+}
+
+void Graph::schedule_params(uint32_t node, uint32_t tick, const void* params, size_t len) {
+    check_schedule(node, params, len);
+    Node& n = nodes_[node];
     if (n.sched.empty() && n.gate_sched.empty()) sched_nodes_.push_back(node);
     if (n.kind == MX_KIND_TRIGGER) {
         mx_trigger_params tp; std::memcpy(&tp, params, sizeof tp);
@@ -788,6 +799,7 @@ void Graph::eq_spec_stats(uint64_t out[2]) {
 }
 
 void Graph::write_source(uint32_t node, const float* host, size_t frames) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
     Node& n = nodes_[node];
     if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
@@ -821,6 +833,7 @@ void Graph::set_input_enabled(uint32_t node, uint32_t port, bool enabled) {
 }
 
 void Graph::sync() {
+    hip_check(hipSetDevice(device_), "hipSetDevice");   // the current device is per thread: a graph may be driven from another thread than its creator's
     flush_scales(stream_);
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     if (tail_stream_) { hip_check(hipStreamSynchronize(tail_stream_), "hipStreamSynchronize"); tail_pending_[0] = tail_pending_[1] = false; }
@@ -1224,6 +1237,7 @@ Graph::Perf Graph::performance_info(uint64_t* module_us, size_t cap) {
 }
 
 void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     wait_tail(-1);
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
@@ -1243,6 +1257,7 @@ void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames
 }
 
 void Graph::read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t frames) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     wait_tail(-1);
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
@@ -1258,6 +1273,7 @@ void Graph::read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t 
 }
 
 void Graph::write_source_i16(uint32_t node, const int16_t* host, size_t frames) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
     Node& n = nodes_[node];
     if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
@@ -1378,13 +1394,16 @@ void Graph::run_video_tick(uint64_t t) {
             DFrame* d = vp->frame.f;
             const int32_t stride = (int32_t)(((size_t)d->width * 4 + 15) & ~(size_t)15);
             const size_t need = (size_t)stride * d->height;
-            if (n.rgba[0].bytes < need) {
+            const uint32_t K = video_batch_ticks();   // ticks whose chains share one launch inside a batched run
+            if (n.rgba.size() != K || n.rgba[0].bytes < need) {
                 if (!n.rgba_pending.empty()) { flush_scales(stream_); launch_pending_rgba(n, n.rgba_pending.size(), false); }
                 sync();
-                n.rgba[0].alloc(need); n.rgba[1].alloc(need);
+                n.rgba.clear(); n.rgba.resize(K);
+                for (DevBuf& b : n.rgba) b.alloc(need);
+                n.rgba_cur = 0;
             }
             mx_video_to_rgba_params p; std::memcpy(&p, n.params.data(), sizeof p);
-            n.rgba_cur ^= 1u;
+            n.rgba_cur = (n.rgba_cur + 1u) % K;
             uint8_t* const out = (uint8_t*)n.rgba[n.rgba_cur].p;
             if (d->lazy) {   // the composite only exists as a cross-fade chain: evaluate it straight into RGBA
                 ChainRgbaArgs c;
@@ -1392,15 +1411,16 @@ void Graph::run_video_tick(uint64_t t) {
                 c.rgba = out; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
                 c.use_matrix = p.use_matrix;
                 for (int k = 0; k < 12; ++k) c.m[k] = p.matrix_q12[k];
-                // Inside a batched run the sink runs LATE and in pairs: the chains of ticks k and k + 1 leave in ONE launch together with the
-                // scaler tiles ticks k + 2 and k + 3 queued (mx_k_video.hip k_scale_then_chain_rgba) -- the launch floor of these small kernels
-                // is paid once per two frames.  Every second sink call is an event: it takes ALL queued scales along (so the scales a
-                // chain needs left at its own call or the next one) and, once four chains are pending, the two oldest -- always at least
-                // two calls old.  A Scaler writes four output frames in turn and the sink two RGBA buffers, so nothing in one launch
-                // writes what something else in it reads or writes.  What is still pending when the run ends is launched then.
+                // Inside a batched run the sink runs LATE and K ticks at a time (K = video_batch_ticks(), 8): the chains of ticks k .. k + K - 1
+                // leave in ONE launch together with the scaler tiles ticks k + K .. k + 2K - 1 queued (mx_k_video.hip k_video_batch) -- the
+                // chip then holds waves of several frames in every phase at once instead of marching through load / compute / store in step.
+                // Every K-th sink call is an event: it takes ALL queued scales along (so the scales a chain needs left at its own event
+                // or an earlier one) and, once 2K chains are pending, the K oldest -- always at least K calls old.  A Scaler writes 2K output
+                // frames in turn and the sink K RGBA buffers, so nothing in one launch writes what something else in it reads or writes.
+                // What is still pending when the run ends is launched then.
                 n.rgba_pending.push_back(Node::PendingRgba{c, d->lazy});
-                if ((++n.rgba_calls & 1u) == 0) {
-                    if (n.rgba_pending.size() >= 4) launch_pending_rgba(n, 2, true);
+                if ((++n.rgba_calls % K) == 0) {
+                    if (n.rgba_pending.size() >= 2 * (size_t)K) launch_pending_rgba(n, K, true);
                     else flush_scales(stream_);
                 }
                 n.rgba_w = d->width; n.rgba_h = d->height; n.rgba_stride = stride;
@@ -1425,13 +1445,14 @@ void Graph::run_video_tick(uint64_t t) {
 
 void Graph::launch_pending_rgba(Node& n, size_t count, bool with_queued_scales) {
     count = std::min(count, n.rgba_pending.size());
+    const size_t K = std::min<size_t>(video_batch_ticks(), MX_VB_MAX_CHAINS);   // the sink's K RGBA buffers are written in turn: at most K chains per launch
+    std::vector<ChainRgbaArgs> c(K);
     size_t i = 0;
     while (i < count) {
-        const int m = (int)std::min<size_t>(2, count - i);
-        ChainRgbaArgs c[2];
+        const int m = (int)std::min(K, count - i);
         for (int k = 0; k < m; ++k) c[k] = n.rgba_pending[i + k].args;
-        if (with_queued_scales && i == 0) launch_chains_rgba_after_queued_scales(c, m, stream_);
-        else { ScaleBatchArgs none{}; launch_scale_then_chains_rgba(none, c, m, stream_); }
+        if (with_queued_scales && i == 0) launch_chains_rgba_after_queued_scales(c.data(), m, stream_);
+        else launch_video_batch(nullptr, 0, c.data(), m, stream_);
         i += m;
     }
     n.rgba_pending.erase(n.rgba_pending.begin(), n.rgba_pending.begin() + count);
@@ -1459,6 +1480,20 @@ void Graph::queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rati
     Node& nd = nodes_[node];
     if (!nd.vsrc_sched.empty() && nd.vsrc_sched.back().tick >= tick) throw Error(MX_ERR_INVALID, "video source frames must be queued in tick order, one per tick");
     nd.vsrc_sched.push_back(Node::VSched{tick, FrameRef(frame, true), dur, off});
+}
+
+void Graph::check_video_queue(uint32_t node, uint64_t first_tick) const {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_SOURCE_VIDEO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_VIDEO");
+    const Node& nd = nodes_[node];
+    if (!nd.vsrc_sched.empty() && nd.vsrc_sched.back().tick >= first_tick) throw Error(MX_ERR_INVALID, "video source frames must be queued in tick order, one per tick");
+}
+
+void Graph::check_source_write(uint32_t node, size_t frames) const {
+    if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
+    const Node& n = nodes_[node];
+    if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
+    if (n.bound) throw Error(MX_ERR_INVALID, "source is bound to a caller device buffer");
+    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
 }
 
 const Node::MonTick& Graph::monitor_tick(uint32_t node, uint32_t tick_in_run) {

@@ -61,7 +61,7 @@ struct Node {
     struct VSched { uint64_t tick; FrameRef frame; Rational dur, off; };
     std::deque<VSched> vsrc_sched;                                                                   // SOURCE_VIDEO: frames due on given ticks (MediaSource / StreamInput pacing), oldest first
     std::shared_ptr<BandScaler> vband; std::vector<FrameRef> vband_pool;                             // SOURCE_VIDEO: frames are halo slices, delivered as this rank's row band of the scaled picture
-    DevBuf rgba[2]; uint32_t rgba_cur = 0, rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;      // VIDEO_TO_RGBA: two buffers, written alternately (two ticks' chains may share a launch); rgba_cur = the last tick's
+    std::vector<DevBuf> rgba; uint32_t rgba_cur = 0, rgba_w = 0, rgba_h = 0; int32_t rgba_stride = 0;   // VIDEO_TO_RGBA: video_batch_ticks() buffers, written in turn (that many ticks' chains may share a launch); rgba_cur = the last tick's
     struct PendingRgba { ChainRgbaArgs args; std::shared_ptr<LazyChain> keep; };
     std::vector<PendingRgba> rgba_pending;     // VIDEO_TO_RGBA: chains of the last ticks, not launched yet, oldest first (run_video_tick)
     uint32_t rgba_calls = 0;                   // sink calls that queued a chain in this run
@@ -117,6 +117,8 @@ public:
     void update_params(uint32_t node, const void* params, size_t len);
     // ModuleT::update at the boundary before tick `tick_in_run` of the NEXT run (client_update between ticks, src/engine.rs:192-214)
     void schedule_params(uint32_t node, uint32_t tick_in_run, const void* params, size_t len);
+    void check_schedule(uint32_t node, const void* params, size_t len) const;   // schedule_params' validation alone
+    void drop_schedules();                                                      // forget every queued update (a run that failed must not leave them for the next)
     // counters of the speculative exact EqThree kernel since the graph was built: [0] chunks run, [1] chunks the repair pass had to re-run
     void eq_spec_stats(uint64_t out[2]);
     void write_source(uint32_t node, const float* host, size_t frames);
@@ -146,6 +148,9 @@ public:
     void set_video_source_band(uint32_t node, uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows, uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows);
     void set_video_source_ring(uint32_t node, DFrame* const* frames, size_t n, Rational dur, Rational off);
     void queue_video_source(uint32_t node, uint64_t tick, DFrame* frame, Rational dur, Rational off);
+    // what a feed checks BEFORE it takes frames out of a pacing state machine (a rejected feed must not lose media):
+    void check_video_queue(uint32_t node, uint64_t first_tick) const;   // queue_video_source(node, first_tick, ...) would be accepted
+    void check_source_write(uint32_t node, size_t frames) const;        // write_source[_i16](node, ..., frames) would be accepted
     const Node::MonTick& monitor_tick(uint32_t node, uint32_t tick_in_run);
     void read_monitor_audio_i16(uint32_t node, int16_t* host, uint32_t n_ticks);
     struct MonitorLayout { uint32_t width, height; size_t frame_bytes, plane_offset[3]; uint32_t stride[3]; };

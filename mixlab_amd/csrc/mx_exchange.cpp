@@ -39,7 +39,7 @@ static hipEvent_t make_event(bool timing) {
 }
 
 Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint32_t world, const void* uid, LoopbackGroup* lb, uint32_t mode)
-    : g_(g), lb_(lb), rank_(rank), world_(world), T_(n_ticks) {
+    : lb_(lb), rank_(rank), world_(world), T_(n_ticks) {
     if (world == 0 || rank >= world) throw Error(MX_ERR_INVALID, "rank must be below world");
     if (n_ticks == 0) throw Error(MX_ERR_INVALID, "n_ticks is 0");
     if (mode > MX_EXCHANGE_ALLREDUCE) throw Error(MX_ERR_INVALID, "unknown exchange mode");

@@ -70,7 +70,6 @@ private:
     void collective_rccl(Slot& sl);
     static void loopback_round(LoopbackGroup& grp, uint64_t step);
 
-    Graph& g_;
     LoopbackGroup* lb_ = nullptr;
     ncclComm* comm_ = nullptr;
     int device_ = 0;

@@ -135,6 +135,9 @@ TickVideo StreamInput::run_tick(uint64_t t, int16_t* audio_out, size_t n_out, si
 // ---------------------------------------------------------------------------------------------
 FrameStager::FrameStager(uint32_t slots) {
     if (slots == 0 || slots > 64) throw Error(MX_ERR_INVALID, "stager slots must be 1..64");
+    // HIP's current device is per THREAD (default 0): the decode thread that acquires / commits is not the one that created the
+    // stager, so every entry point selects the creator's device before it allocates, records or copies
+    hip_check(hipGetDevice(&device_), "hipGetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate(stager)");
     hip_check(hipEventCreateWithFlags(&last_, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&reuse_, hipEventDisableTiming), "hipEventCreate");
@@ -143,6 +146,7 @@ FrameStager::FrameStager(uint32_t slots) {
 }
 
 FrameStager::~FrameStager() {
+    (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (Slot& s : slots_) { if (s.host) (void)hipHostFree(s.host); if (s.done) (void)hipEventDestroy(s.done); }
     if (last_) (void)hipEventDestroy(last_);
@@ -170,6 +174,7 @@ uint32_t FrameStager::acquire(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data
 }
 
 uint32_t FrameStager::acquire_locked(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data[3], int32_t stride[3]) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     FrameRef f = take_frame(w, h, fmt);
     uint32_t k = next_, tries = 0;
     while (slots_[k].held) {                       // slots a decoder still writes are skipped
@@ -205,6 +210,7 @@ DFrame* FrameStager::commit(uint32_t ticket) {
 
 DFrame* FrameStager::commit_locked(uint32_t ticket) {
     if (ticket == 0 || ticket > slots_.size() || !slots_[ticket - 1].held) throw Error(MX_ERR_INVALID, "not a ticket of an acquired slot");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     Slot& s = slots_[ticket - 1];
     FrameRef f = s.target;
     s.held = false; s.target = FrameRef();
@@ -238,10 +244,11 @@ DFrame* FrameStager::upload(uint32_t w, uint32_t h, uint8_t fmt, const uint8_t* 
 
 void FrameStager::fence(hipStream_t consumer) {
     std::lock_guard<std::mutex> lk(mu_);
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     consumer_ = consumer; have_consumer_ = true;
     if (any_) hip_check(hipStreamWaitEvent(consumer, last_, 0), "hipStreamWaitEvent(stager)");
 }
 
-void FrameStager::sync() { hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(stager)"); }
+void FrameStager::sync() { hip_check(hipSetDevice(device_), "hipSetDevice"); hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(stager)"); }
 
 }  // namespace mx

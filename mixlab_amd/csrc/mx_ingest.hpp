@@ -23,6 +23,8 @@ public:
     bool send(DFrame* frame, Rational pts, Rational duration_hint);
     TickVideo run_tick(uint64_t t);
     size_t buffered() const { return buffer_.size(); }
+    uint32_t sample_rate() const { return sr_; }
+    uint32_t ticks_per_second() const { return tps_; }
 private:
     struct Timed { FrameRef frame; Rational pts, dur; };
     uint32_t sr_, tps_;
@@ -76,6 +78,7 @@ private:
     FrameRef take_frame(uint32_t w, uint32_t h, uint8_t fmt);
     uint32_t acquire_locked(uint32_t w, uint32_t h, uint8_t fmt, uint8_t* data[3], int32_t stride[3]);
     DFrame* commit_locked(uint32_t ticket);
+    int device_ = 0;                    // the creator's HIP device (the current device is per thread)
     std::mutex mu_;                     // the decode thread acquires / commits, the engine thread fences
     std::vector<Slot> slots_; uint32_t next_ = 0;
     std::vector<FrameRef> pool_;        // device frames handed out before: one nobody else holds any more is written again

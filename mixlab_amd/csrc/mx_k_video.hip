@@ -4,6 +4,9 @@
 // Frames are planar yuv420p, 8 bit, resident in HBM; every plane row starts 64-byte aligned
 // (stride % 64 == 0), so a lane moves 16 pixels (one dwordx4) and a wave 1 KiB per instruction.
 #include <algorithm>
+#include <cstddef>
+#include <map>
+#include <mutex>
 
 #include "mx_dev.hpp"
 #include "mx_video.hpp"
@@ -57,6 +60,15 @@ void launch_crossfade(const FadeArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_crossfade, dim3((total + 255) / 256), dim3(256), 0, s, a);
 }
 
+// Workgroup b of a launch is observed to run on XCD b % 8, each XCD with an L2 of its own (MI355X_MICROARCH.md "Workgroup dispatch":
+// a speed assumption, never a correctness one).  xcd_run hands every XCD a CONTIGUOUS run of the n work items, so that neighbouring
+// tiles -- which share cache lines (the two halves of a chroma line, the halo of a scaler window) -- meet in one L2 instead of each
+// fetching its own copy over the fabric.  A bijection of [0, n).
+__device__ __forceinline__ uint32_t xcd_run(uint32_t b, uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u, j = b >> 3;
+    return x * q + min(x, r) + j;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cross-fade chain: a cascade of VideoMixers (each `out = fade(A, B)` truncated to u8) evaluated in
 // one pass.  All layer loads of a lane are issued up-front (<= 8 dwordx4 in flight), the chain runs in
@@ -71,16 +83,21 @@ struct Px4 { u16x2 e, o; };   // bytes 0,2 and bytes 1,3 of a dword, each widene
 __device__ __forceinline__ Px4 px4_unpack(uint32_t w) {
     Px4 r;
     r.e = __builtin_bit_cast(u16x2, w & 0x00ff00ffu);
-    r.o = __builtin_bit_cast(u16x2, (w >> 8) & 0x00ff00ffu);
+    r.o = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c01u));   // (w >> 8) & 0x00ff00ff in one v_perm_b32
     return r;
 }
 __device__ __forceinline__ uint32_t px4_pack(Px4 v) {
     return __builtin_bit_cast(uint32_t, v.e) | (__builtin_bit_cast(uint32_t, v.o) << 8);
 }
 __device__ __forceinline__ u16x2 fade_pk(u16x2 a, u16x2 b, u16x2 fa, u16x2 fb) {
-    const u16x2 x = a * fa + b * fb;                          // <= 255 * 255: no u16 overflow, as in the reference
+    // x = a fa + b fb <= 255 * 255: no u16 overflow, as in the reference.  x / 255 == (x + 1 + (x >> 8)) >> 8 for x <= 65534, and with
+    // x1 = x + 1 that is (x1 + (x1 >> 8)) >> 8: the two differ only where x1 is a multiple of 256, and there both sums have the same
+    // high byte (checked for every x <= 65025 on the host, tests/test_fastdiv.py) -- the + 1 rides on the multiply-add: 2 v_pk_mad + 3.
     const u16x2 one = {1, 1};
-    return (u16x2)((x + one + (x >> 8)) >> 8);              // x / 255 for x <= 65534; the sum stays below 65536
+    uint32_t t = __builtin_bit_cast(uint32_t, (u16x2)(b * fb + one));
+    asm volatile("" : "+v"(t));                               // keeps the + 1 inside the first v_pk_mad_u16 (the optimiser would peel it off again)
+    const u16x2 x1 = a * fa + __builtin_bit_cast(u16x2, t);
+    return (u16x2)((x1 + (x1 >> 8)) >> 8);
 }
 __device__ __forceinline__ Px4 fade_px4(Px4 a, Px4 b, u16x2 fa, u16x2 fb) {
     Px4 r; r.e = fade_pk(a.e, b.e, fa, fb); r.o = fade_pk(a.o, b.o, fa, fb); return r;
@@ -99,6 +116,25 @@ __device__ __forceinline__ void chain_eval(uint32_t (&v)[NW], const uint32_t (*L
             // running value sits on only swaps the two (wave-uniform) factors, never the per-pixel code
             const unsigned short f = (unsigned short)(v_is_a[k - 1] ? fade[k - 1] : 255u - fade[k - 1]), g = (unsigned short)(255u - f);
             const u16x2 fa = {f, f}, fb = {g, g};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[w] = fade_px4(acc[w], px4_unpack(L[k][w]), fa, fb);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = px4_pack(acc[w]);
+}
+
+// the same with the per-step factors already packed by the launcher: fa_pk[k] = {f, f}, fb_pk[k] = {255 - f, 255 - f} as u16 x 2, f taken
+// from the side the running composite sits on -- no select, no subtract in the kernel, the factors are SGPR operands of the packed ops
+template <int NW>
+__device__ __forceinline__ void chain_eval_pk(uint32_t (&v)[NW], const uint32_t (*L)[NW], uint32_t n_src, const uint32_t* fa_pk, const uint32_t* fb_pk) {
+    Px4 acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = px4_unpack(L[0][w]);
+#pragma unroll
+    for (int k = 1; k < MX_CHAIN_MAX_SRC; ++k) {
+        if (k < (int)n_src) {
+            const u16x2 fa = __builtin_bit_cast(u16x2, fa_pk[k - 1]), fb = __builtin_bit_cast(u16x2, fb_pk[k - 1]);
 #pragma unroll
             for (int w = 0; w < NW; ++w) acc[w] = fade_px4(acc[w], px4_unpack(L[k][w]), fa, fb);
         }
@@ -320,8 +356,8 @@ __device__ __forceinline__ uint32_t cs_mask_quad(uint32_t quad, uint32_t blank, 
     return (quad & m) | (blank & ~m);
 }
 
-template <int MM, bool SC>
-__device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const int bx, const int by) {
+template <int MM, bool SC, class ArgsRef>   // ArgsRef: ChainRgbaArgs in kernel arguments, or in the constant address space (k_video_batch)
+__device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const int by) {
     // tile of 128 x 32 luma pixels; a lane owns 8 pixels x 2 rows and their 4 + 4 chroma samples
     const int tid = threadIdx.x;
     const int cb = tid & 15, rp = tid >> 4;
@@ -329,14 +365,32 @@ __device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const in
     const uint32_t xb = (uint32_t)(X0 / 8 + cb);     // 8-pixel column block
     const uint32_t yb = (uint32_t)(Y0 / 2 + rp);     // row pair
     const bool valid = xb * 8 < a.width && yb * 2 < a.height;
-    if (!SC && !valid) return;
     // per source: 2 dwords of Y for each of the two rows, one dword of U, one of V  (6 dwords)
     uint32_t L[MX_CHAIN_MAX_SRC][6];
+    if constexpr (!SC) {
+        // Every one of the 8 x 4 loads is issued unconditionally, back to back, with no control flow in between: the launcher points
+        // missing layers (None inputs, sources beyond n_src) at a blank row with stride 0 (chain_prepare), lanes outside the picture
+        // read the last column block / row pair.  The chain then consumes the layers in the order they were requested, so the waits
+        // count DOWN (s_waitcnt vmcnt(28), (24), ...) and a wave fades layers 0 .. k while k + 1 .. 7 are still on their way.
+        const uint32_t xc = min(xb, (a.width - 1u) >> 3), yc = min(yb, (a.height - 1u) >> 1);
+#pragma unroll
+        for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
+            // 32-bit offsets from the (scalar) plane base: one full-rate 24-bit multiply-add per plane (rows and strides are far below
+            // 2^24, a frame far below 4 GB): the loads take the saddr + voffset form
+            const auto& s = a.src[k];
+            const uint32_t o0 = __umul24(2u * yc, s.stride[0]) + xc * 8u;
+            const uint2 r0 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)o0);
+            const uint2 r1 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)(o0 + s.stride[0]));
+            L[k][0] = r0.x; L[k][1] = r0.y; L[k][2] = r1.x; L[k][3] = r1.y;
+            L[k][4] = *reinterpret_cast<const uint32_t*>(s.p[1] + (size_t)(__umul24(yc, s.stride[1]) + xc * 4u));
+            L[k][5] = *reinterpret_cast<const uint32_t*>(s.p[2] + (size_t)(__umul24(yc, s.stride[2]) + xc * 4u));
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
         L[k][0] = L[k][1] = L[k][2] = L[k][3] = 0u; L[k][4] = L[k][5] = 0x80808080u;
         if (k < (int)a.n_src && valid) {
-            const ChainSrc& s = a.src[k];
+            const auto& s = a.src[k];
             if (s.p[0]) {
                 const uint2 r0 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)(2 * yb) * s.stride[0] + xb * 8);
                 const uint2 r1 = *reinterpret_cast<const uint2*>(s.p[0] + (size_t)(2 * yb + 1) * s.stride[0] + xb * 8);
@@ -346,7 +400,8 @@ __device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const in
             if (s.p[2]) L[k][5] = *reinterpret_cast<const uint32_t*>(s.p[2] + (size_t)yb * s.stride[2] + xb * 4);
         }
     }
-    if (SC) {
+    }
+    if constexpr (SC) {
         extern __shared__ __attribute__((aligned(16))) uint8_t cs_smem[];
         uint32_t* const Ty = reinterpret_cast<uint32_t*>(cs_smem);       // [36][128] pairs of H-filtered rows (p, p + 1)
         uint32_t* const Tu = Ty + CS_TY_DW;                               // [20][64]
@@ -433,10 +488,15 @@ __device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const in
                 if (j + 1 < (int)a.n_scaled) __syncthreads();   // T is reused by the next layer
             }
         }
-        if (!valid) return;
     }
     uint32_t v[6];
-    chain_eval<6>(v, L, a.n_src, a.fade, a.v_is_a);
+    uint32_t fa[MX_CHAIN_MAX_SRC - 1], fb[MX_CHAIN_MAX_SRC - 1]; int mtx[12];   // wave-uniform copies: SGPRs
+#pragma unroll
+    for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) { fa[k] = a.fa_pk[k]; fb[k] = a.fb_pk[k]; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) mtx[k] = a.m[k];
+    chain_eval_pk<6>(v, L, a.n_src, fa, fb);
+    if (!valid) return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t yrow = 2 * yb + r;
@@ -449,7 +509,7 @@ __device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const in
             uint32_t px[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                px[k] = yuv_px<MM>(a.m, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
+                px[k] = yuv_px<MM>(mtx, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
             const uint32_t x = xb * 8 + g4 * 4;
             if (x + 4 <= a.width) *reinterpret_cast<uint4*>(o + g4 * 16) = make_uint4(px[0], px[1], px[2], px[3]);
             else for (uint32_t k = 0; x + k < a.width; ++k) reinterpret_cast<uint32_t*>(o + g4 * 16)[k] = px[k];
@@ -457,28 +517,84 @@ __device__ __forceinline__ void chain_rgba_tile(const ChainRgbaArgs& a, const in
     }
 }
 template <int MM, bool SC>
-__global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a) { chain_rgba_tile<MM, SC>(a, (int)blockIdx.x, (int)blockIdx.y); }
+__global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a, uint32_t tx, uint32_t n_tiles) {
+    const uint32_t t = xcd_run(blockIdx.x, n_tiles);
+    chain_rgba_tile<MM, SC>(a, (int)(t % tx), (int)(t / tx));
+}
 
+// A blank row per device (Y = 0x00, U = V = 0x80: what AvFrame::blank writes, frame.rs:128-132), 32 KB each, read with stride 0 by the
+// branch-free chain tiles in place of a layer that is not there (video_mixer.rs:180-188 reads the blank output plane).  Never freed.
+static const uint8_t* blank_row(int plane) {
+    static std::mutex mu;
+    static std::map<int, uint8_t*> rows;
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = rows.find(dev);
+    if (it == rows.end()) {
+        uint8_t* p = nullptr;
+        hip_check(hipMalloc((void**)&p, 65536), "hipMalloc(blank rows)");
+        hip_check(hipMemset(p, 0x00, 32768), "hipMemset");
+        hip_check(hipMemset(p + 32768, 0x80, 32768), "hipMemset");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        it = rows.emplace(dev, p).first;
+    }
+    return it->second + (plane ? 32768 : 0);
+}
+static void chain_blank_planes(ChainRgbaArgs& a) {   // kernels without inline-scaled layers: every plane pointer is readable
+    for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k)
+        for (int p = 0; p < 3; ++p)
+            if (k >= (int)a.n_src || !a.src[k].p[p]) { a.src[k].p[p] = blank_row(p); a.src[k].stride[p] = 0; }
+}
+// what the launcher derives from the arguments once per launch: the matrix mode (24-bit products when every entry fits) and the
+// per-step cross-fade factors as packed u16 pairs (chain_eval_pk)
+static int chain_matrix_mode(ChainRgbaArgs& a) {
+    // A step whose factor for the running composite is 255 returns it unchanged -- (255 v + 0 o) / 255 = v exactly -- and one whose factor
+    // is 0 returns the other layer exactly: a fader at either end of its travel (where a fader usually rests).  Such steps are dropped
+    // here, bit for bit the same picture: the first kind leaves its layer unread, the second restarts the chain at its layer.
+    if (!a.n_scaled && a.n_src >= 2) {
+        ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t fade[MX_CHAIN_MAX_SRC - 1], via[MX_CHAIN_MAX_SRC - 1]; uint32_t n = 1;
+        src[0] = a.src[0];
+        for (uint32_t k = 1; k < a.n_src; ++k) {
+            const uint32_t f = (a.v_is_a[k - 1] ? a.fade[k - 1] : 255u - a.fade[k - 1]) & 0xffu;   // the running composite's factor
+            if (f == 255u) continue;
+            if (f == 0u) { src[0] = a.src[k]; n = 1; continue; }
+            src[n] = a.src[k]; fade[n - 1] = a.fade[k - 1]; via[n - 1] = a.v_is_a[k - 1]; ++n;
+        }
+        for (uint32_t k = 0; k < n; ++k) a.src[k] = src[k];
+        for (uint32_t k = 0; k + 1 < n; ++k) { a.fade[k] = fade[k]; a.v_is_a[k] = via[k]; }
+        for (uint32_t k = n; k < MX_CHAIN_MAX_SRC; ++k) { for (int pl = 0; pl < 3; ++pl) { a.src[k].p[pl] = nullptr; a.src[k].stride[pl] = 0; } }
+        for (uint32_t k = n - 1; k < MX_CHAIN_MAX_SRC - 1; ++k) { a.fade[k] = 0; a.v_is_a[k] = 1; }
+        a.n_src = n;
+    }
+    for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) {
+        const uint32_t f = (a.v_is_a[k] ? a.fade[k] : 255u - a.fade[k]) & 0xffu, g = 255u - f;
+        a.fa_pk[k] = f * 0x10001u; a.fb_pk[k] = g * 0x10001u;
+    }
+    if (!a.use_matrix) return 0;
+    bool fits = true;
+    for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
+    a.use_matrix = fits ? 2 : 1;
+    return a.use_matrix;
+}
 void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
     flush_scales(s);
     if (!a0.width || !a0.height) return;
     ChainRgbaArgs a = a0;
-    if (a.use_matrix) {
-        bool fits = true;
-        for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
-        a.use_matrix = fits ? 2 : 1;
-    }
-    const dim3 grid((a.width + 127) / 128, (a.height + 31) / 32);
+    chain_matrix_mode(a);
+    const uint32_t tx = (a.width + 127) / 128, n_tiles = tx * ((a.height + 31) / 32);
+    const dim3 grid(n_tiles);
     if (a.n_scaled) {
         const size_t lds = CS_T_BYTES + (size_t)a.n_scaled * CS_S_BYTES;
-        if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, true>), grid, dim3(256), lds, s, a);
-        else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_fade_chain_rgba<0, true>), grid, dim3(256), lds, s, a);
+        if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
+        else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
+        else hipLaunchKernelGGL((k_fade_chain_rgba<0, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
         return;
     }
-    if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), grid, dim3(256), 0, s, a);
-    else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_fade_chain_rgba<0, false>), grid, dim3(256), 0, s, a);
+    chain_blank_planes(a);
+    if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), grid, dim3(256), 0, s, a, tx, n_tiles);
+    else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), grid, dim3(256), 0, s, a, tx, n_tiles);
+    else hipLaunchKernelGGL((k_fade_chain_rgba<0, false>), grid, dim3(256), 0, s, a, tx, n_tiles);
 }
 
 // Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
@@ -514,73 +630,185 @@ void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size
 // origin is COMPUTED from the tap spec instead of fetched -- the source loads do not wait for a table
 // round trip -- and every coefficient a lane will need is requested in the same burst.
 // Used when the window fits 64 KB of LDS (scale ratio <= 2); LDS is sized per launch.
-__device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32_t block) {
-    int plane = 0;
+// Window origin in integers (same value as sc_first_tap; checked against the tap table for every output on the host,
+// scale_tile_origins_match_m): q = floor(n / d), n = (2o+1) src + dst < 2^30, d = 2 dst, from M = floor(2^32 / d): mulhi(n, M) is q or
+// q - 1 (n M / 2^32 > n / d - 1/4), the remainder decides.  Every operand is wave-uniform where the tile kernel calls it: SALU only.
+__host__ __device__ __forceinline__ int sc_first_tap_m(uint32_t o, uint32_t src, uint32_t dst, uint32_t M) {
+    const uint32_t n = (2u * o + 1u) * src + dst, d = 2u * dst;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t q = __umulhi(n, M);
+#else
+    uint32_t q = (uint32_t)(((uint64_t)n * M) >> 32);
+#endif
+    q += (n - q * d >= d) ? 1u : 0u;
+    return (int)q - 2;
+}
+uint32_t scale_origin_magic(uint32_t dst) { return dst ? (uint32_t)((1ull << 32) / (2ull * dst)) : 0u; }
+bool scale_tile_origins_match_m(uint32_t src, uint32_t dst, const int32_t* first) {
+    if (!dst || src > 16384u || dst > 16384u) return false;
+    const uint32_t M = scale_origin_magic(dst);
+    for (uint32_t o = 0; o < dst; ++o)
+        if (sc_first_tap_m(o, src, dst, M) != first[o]) return false;
+    return true;
+}
+
+// H pass of one tile column with compile-time LDS strides (SS bytes per window row, SC_TW pairs per T2 row) over a FIXED number of rows
+// per thread: T2[p][i] = (t'[p], t'[p+1]) for the HR rows from p0 on.  The rows go in groups of eight: nine 8-byte LDS reads are
+// issued, then eight H values are computed and written -- the LDS round trip is paid once per group, not once per row (a loop that reads
+// and filters row by row waits lgkmcnt(0) in every iteration).  Rows beyond the tile's window are filtered too (stale LDS bytes in,
+// pairs out that the V pass never reads): no bounds, no exec masks, every address an immediate.
+template <int SS, int HR>
+__device__ __forceinline__ void sc_hcol_fixed(const uint8_t* S, int hf /* first tap - cxa */, const uint2 hpk, uint32_t* T2, int i, int p0) {
+    static_assert(HR % 8 == 0, "rows per thread go in groups of eight");
+    const int hb = hf & ~3; const uint32_t sh8 = (uint32_t)(hf & 3);
+    const uint8_t* Srow = S + p0 * SS + hb;
+    uint32_t* out = T2 + p0 * SC_TW + i;
+    uint32_t prev;
+    { const uint32_t* sp = reinterpret_cast<const uint32_t*>(Srow);
+      const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], sh8);
+      prev = (uint32_t)__builtin_amdgcn_sdot4((int)w, (int)hpk.y, __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, false) * 256 + 64, false) >> 7; }
 #pragma unroll
-    for (int k = 1; k < MX_SCALE_BATCH_PLANES; ++k) if (k < (int)a.n && block >= a.tile_start[k]) plane = k;   // scalar search
-    const ScalePlane p = a.p[plane];
-    const uint32_t tile = block - a.tile_start[plane];
-    const int ox0 = (int)(tile % a.tiles_x[plane]) * SC_TW, oy0 = (int)(tile / a.tiles_x[plane]) * SC_TH;
-    extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
-    uint32_t* const T2 = reinterpret_cast<uint32_t*>(sc_smem);                 // [s_rows][SC_TW] pairs (p, p + 1) of H-filtered rows
-    uint8_t* const S = sc_smem + (size_t)a.s_rows * SC_TW * 4;                 // [s_rows][s_stride] source window, signed bytes
-    const int tid = threadIdx.x;
-    const int oxe = min(ox0 + SC_TW, (int)p.dw), oye = min(oy0 + SC_TH, (int)p.dh);
-    ScWin w = sc_window(ox0, oxe, oy0 + (int)p.oy_base, oye + (int)p.oy_base, p.sw, p.dw, p.sh, p.dh_full ? p.dh_full : p.dh);
-    w.nc4 = min(w.nc4, (int)a.s_stride >> 2); w.nr = min(w.nr, (int)a.s_rows);
-    // every table entry this lane will need, in one burst
-    const int oxi = tid & (SC_TW - 1), ox = min(ox0 + oxi, (int)p.dw - 1);
-    const uint2 hpk = p.hpk[ox];
-    const int hf = p.hfirst[ox] - w.cxa;
-    const int cg = tid & 31, oyr = tid >> 5;                  // V pass: pixel group (4 columns) and first row; rows oyr + 8k
-    uint2 vpk[4]; int vf[4];
+    for (int g = 0; g < HR / 8; ++g) {
+        uint32_t lo[8], hi[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int oy = min(oy0 + oyr + 8 * k, (int)p.dh - 1);
-        vpk[k] = p.vpk[oy];
-        vf[k] = p.vfirst[oy] - w.ry0;
-    }
-    sc_stage<3>(p.src, p.src_stride, (int)p.sw, (int)p.sh, w, S, (int)a.s_stride, tid, p.sxs, p.sxo, (int)p.h_row0, (int)(p.h_row0 + p.h_rows) - 1);   // launcher: s_rows <= 48, s_stride <= 256
-    __syncthreads();
-    if (ox0 + oxi < (int)p.dw) {   // the two threads of a column take half of the row pairs each
-        const int np = w.nr - 1, half = (np + 1) >> 1, part = tid >> 7;
-        sc_hcol(S, (int)a.s_stride, hf, hpk, T2, SC_TW, oxi, part * half, min(part * half + half, np));
-    }
-    __syncthreads();
-    const int oxg = cg * 4;
-    if (ox0 + oxg < (int)p.dw) {
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(Srow + (8 * g + j + 1) * SS);
+            lo[j] = sp[0]; hi[j] = sp[1];
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int oyk = oy0 + oyr + 8 * k;
-            if (oyk >= (int)p.dh) break;
-            const uint32_t quad = sc_vquad(T2, SC_TW, vf[k], oxg, vpk[k]);
-            uint8_t* o = p.dst + (size_t)oyk * p.dst_stride + ox0 + oxg;
-            if (ox0 + oxg + 4 <= (int)p.dw && (reinterpret_cast<uintptr_t>(o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = quad;
-            else for (int j = 0; j < 4 && ox0 + oxg + j < (int)p.dw; ++j) o[j] = (uint8_t)(quad >> (8 * j));
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w = __builtin_amdgcn_alignbyte(hi[j], lo[j], sh8);                      // s' of taps hf .. hf + 3
+            const int a = __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, false);                    // sum ch s'
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_sdot4((int)w, (int)hpk.y, a * 256 + 64, false) >> 7;   // 256 sum ch s' + sum cl s' + 64
+            out[(8 * g + j) * SC_TW] = __builtin_amdgcn_perm(cur, prev, 0x05040100u);             // (t'[p] & 0xffff) | (t'[p+1] << 16)
+            prev = cur;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a) { scale_tile(a, blockIdx.x); }
+// The tile body.  CPR = 16-byte chunks staged per window row (8: windows up to 128 bytes wide -- every upscale by >= 1.27; 16: up to
+// 256), Q = staging passes of 256 / CPR rows each.  Interior tiles (the whole window inside the source row, 16-byte aligned planes)
+// stage with ONE predicated dwordx4 load per lane and pass -- nothing is fetched that the tile does not filter; tiles at the picture's
+// left / right edge, unaligned or interleaved (nv12 chroma) sources take sc_stage's general path into the same window.
+template <int CPR, int Q, int HR, class PlaneRef>
+__device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile, const uint32_t tiles_x, const int s_rows) {
+    constexpr int SS = CPR * 16, RPP = 256 / CPR;
+    constexpr int ROWS = 2 * HR;               // T2 rows in LDS (the launcher's s_rows <= ROWS); the window has one row more
+    const int ty = (int)(tile / tiles_x), tx = (int)(tile - (uint32_t)ty * tiles_x);
+    const int ox0 = tx * SC_TW, oy0 = ty * SC_TH;
+    extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
+    uint32_t* const T2 = reinterpret_cast<uint32_t*>(sc_smem);                 // [ROWS][SC_TW] pairs (p, p + 1) of H-filtered rows
+    uint8_t* const S = sc_smem + (size_t)ROWS * SC_TW * 4;                     // [ROWS + 1][SS] source window, signed bytes
+    const int tid = threadIdx.x;
+    const int dw = (int)p.dw, dh = (int)p.dh, sw = (int)p.sw, sh = (int)p.sh;
+    const int oxe = min(ox0 + SC_TW, dw), oye = min(oy0 + SC_TH, dh);
+    // source window of the tile: wave-uniform integer arithmetic
+    const uint32_t dhf = p.dh_full ? p.dh_full : p.dh;
+    const int cx0 = sc_first_tap_m((uint32_t)ox0, p.sw, p.dw, p.mh), cxl = sc_first_tap_m((uint32_t)(oxe - 1), p.sw, p.dw, p.mh);
+    const int ry0 = sc_first_tap_m((uint32_t)oy0 + p.oy_base, p.sh, dhf, p.mv), ryl = sc_first_tap_m((uint32_t)(oye - 1) + p.oy_base, p.sh, dhf, p.mv);
+    ScWin w;
+    w.cxa = cx0 & ~15; w.nc4 = min((cxl + 4 - w.cxa + 3) >> 2, SS / 4); w.ry0 = ry0; w.nr = min(ryl + 4 - ry0, s_rows);
+    // every table entry this lane will need, one 16-byte load per axis entry, in one burst
+    const int oxi = tid & (SC_TW - 1);
+    const uint4 hx = p.hx[min(ox0 + oxi, dw - 1)];
+    const int cg = tid & 31, oyr = tid >> 5;                  // V pass: pixel group (4 columns) and first row; rows oyr + 8k
+    uint4 vx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vx[k] = p.vx[min(oy0 + oyr + 8 * k, dh - 1)];
+    // ---- stage ----
+    const int row_lo = max(0, (int)p.h_row0), row_hi = min(sh - 1, (int)(p.h_row0 + p.h_rows) - 1);
+    const int n_chunks = (w.nc4 + 3) >> 2;
+    const bool fast = p.sxs == 0u && ((reinterpret_cast<uintptr_t>(p.src) | p.src_stride) & 15u) == 0 && w.cxa >= 0 && w.cxa + 16 * n_chunks <= sw;
+    if (fast) {
+        const int c = tid % CPR, r0 = tid / CPR;
+        const uint8_t* const col = p.src + w.cxa + 16 * c;
+        uint4 v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = r0 + q * RPP;
+            const int row = min(max(ry0 + r, row_lo), row_hi);
+            v[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < n_chunks && r < w.nr) v[q] = *reinterpret_cast<const uint4*>(col + (size_t)((uint32_t)row * p.src_stride));
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = r0 + q * RPP;
+            if (c < n_chunks && r < w.nr)
+                *reinterpret_cast<uint4*>(S + r * SS + 16 * c) = make_uint4(v[q].x ^ 0x80808080u, v[q].y ^ 0x80808080u, v[q].z ^ 0x80808080u, v[q].w ^ 0x80808080u);
+        }
+    } else {
+        sc_stage<3>(p.src, p.src_stride, sw, sh, w, S, SS, tid, p.sxs, p.sxo, (int)p.h_row0, (int)(p.h_row0 + p.h_rows) - 1);   // launcher: s_rows <= 48
+    }
+    __syncthreads();
+    // ---- H pass: the two threads of a column take HR row pairs each (columns beyond the picture repeat the last one) ----
+    sc_hcol_fixed<SS, HR>(S, (int)hx.z - w.cxa, make_uint2(hx.x, hx.y), T2, oxi, (tid >> 7) * HR);
+    __syncthreads();
+    // ---- V pass ----
+    const int oxg = cg * 4;
+    if (ox0 + oxg < dw) {
+        uint8_t* const o0 = p.dst + (size_t)((uint32_t)(oy0 + oyr) * p.dst_stride) + ox0 + oxg;
+        const bool whole = ox0 + oxg + 4 <= dw && ((reinterpret_cast<uintptr_t>(p.dst) | p.dst_stride) & 3u) == 0;   // ox0 + oxg is a multiple of 4
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (oy0 + oyr + 8 * k >= dh) break;
+            const uint32_t quad = sc_vquad(T2, SC_TW, (int)vx[k].z - ry0, oxg, make_uint2(vx[k].x, vx[k].y));
+            uint8_t* o = o0 + (size_t)((uint32_t)(8 * k) * p.dst_stride);
+            if (whole) *reinterpret_cast<uint32_t*>(o) = quad;
+            else for (int j = 0; j < 4 && ox0 + oxg + j < dw; ++j) o[j] = (uint8_t)(quad >> (8 * j));
+        }
+    }
+}
+// variant (launcher-chosen, wave-uniform): 0 = windows <= 128 bytes x 32 rows (the 720p -> 1080p class), 1 = 128 x 48, 2 = 256 x 48
+template <class PlaneRef>
+__device__ __forceinline__ void scale_tile_variant(const uint32_t variant, PlaneRef& p, const uint32_t tile, const uint32_t tiles_x, const int s_rows) {
+    if (variant == 0u) scale_tile_body<8, 1, 16>(p, tile, tiles_x, s_rows);
+    else if (variant == 1u) scale_tile_body<8, 2, 24>(p, tile, tiles_x, s_rows);
+    else scale_tile_body<16, 3, 24>(p, tile, tiles_x, s_rows);
+}
+__device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32_t block) {
+    int plane = 0;
+#pragma unroll
+    for (int k = 1; k < MX_SCALE_BATCH_PLANES; ++k) if (k < (int)a.n && block >= a.tile_start[k]) plane = k;   // scalar search
+    scale_tile_variant(a.variant, a.p[plane], block - a.tile_start[plane], a.tiles_x[plane], (int)a.s_rows);
+}
+// LDS of a tile body: [2 HR][128] row pairs + [2 HR + 1][SS] window
+static size_t scale_tile_lds(uint32_t variant) {
+    const size_t hr = variant == 0u ? 16 : 24, ss = variant == 2u ? 256 : 128;
+    return 2 * hr * SC_TW * 4 + (2 * hr + 1) * ss;
+}
 
-// One launch, two jobs that do not depend on each other: the scaler tiles of THIS tick's smaller layers and the chain tiles of the
-// PREVIOUS tick's composite (Graph defers the RGBA sink by one tick inside a batched run).  Two dependent launches of this size cost
-// their sum plus a launch gap each; inside one launch the chain's tiles start as the scaler's tiles drain and the two bodies -- one
-// VALU-heavy, one waiting for bytes -- share the CUs.
-// Block order (measured, MX_VIDEO_FUSED_ORDER): the chains' tiles first -- they wait for their bytes while the scaler's tiles, dispatched
-// behind them, do arithmetic (18.4 us per 1080p frame with one chain per launch); the scaler's first: 19.5; interleaved 1 : 3: 26.6.
+__global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a, uint32_t n_tiles) { scale_tile(a, xcd_run(blockIdx.x, n_tiles)); }
+
+// ONE launch for the video work of several ticks of a batched run (Graph defers the RGBA sink inside a run): the chain tiles of ticks
+// k .. k + K - 1 and the scaler tiles of the layers ticks k + K .. k + 2K - 1 will composite -- nothing in the launch reads what
+// something else in it writes.  What this buys is not the launch floor alone: a frame's chain is ~2 000 waves that all fit on the chip
+// at once, so alone they all request their bytes together, then all compute together, then all store; with several frames' chains and
+// scaler tiles in one grid the chip holds waves in every phase at once and the memory system and the VALUs work side by side
+// (measured: 14.3 us per composited 1080p frame at two frames per launch, 10.0 at sixteen).
+// Grid: blockIdx.y = which chain / scale job (chains first: they wait for bytes while scaler tiles, dispatched behind them, compute),
+// blockIdx.x = tile of it (rows shorter than the grid's width end at once); the width is a multiple of 8, so blockIdx.x % 8 is the
+// XCD in every row and xcd_run hands each XCD a contiguous run of a row's tiles.  The descriptor lives in device memory (it is far
+// beyond the 4 KB of kernel arguments) and is read through the constant address space: scalar loads.
+typedef const __attribute__((address_space(4))) VideoBatchDesc* VbDescPtr;
 template <int MM>
-__global__ __launch_bounds__(256) void k_scale_then_chain_rgba(ScaleBatchArgs sa, ChainRgbaArgs c0, ChainRgbaArgs c1, uint32_t n_scale_tiles, uint32_t n0, uint32_t n1,
-                                                               uint32_t tx0, uint32_t tx1, uint32_t order) {
-    // roles by block index.  order 2 (default): the chains' tiles first, the scaler's behind them; 0: the scaler's first
-    uint32_t b = blockIdx.x;
-    const uint32_t nc = n0 + n1;
-    bool is_chain; uint32_t t;
-    if (order == 2u) { is_chain = b < nc; t = is_chain ? b : b - nc; }
-    else { is_chain = b >= n_scale_tiles; t = is_chain ? b - n_scale_tiles : b; }
-    if (!is_chain) { scale_tile(sa, t); return; }
-    if (t < n0) chain_rgba_tile<MM, false>(c0, (int)(t % tx0), (int)(t / tx0));
-    else { t -= n0; chain_rgba_tile<MM, false>(c1, (int)(t % tx1), (int)(t / tx1)); }
+__global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc) {
+    VbDescPtr d = (VbDescPtr)desc;
+    const uint32_t y = blockIdx.y, x = blockIdx.x;
+    const uint32_t n_chains = d->n_chains;
+    if (y < n_chains) {
+        const uint32_t n = d->chain_tiles[y];
+        if (x >= n) return;
+        const uint32_t t = xcd_run(x, n), tx = d->chain_tx[y];
+        chain_rgba_tile<MM, false>(d->c[y], (int)(t % tx), (int)(t / tx));
+        return;
+    }
+    typedef const __attribute__((address_space(4))) ScaleJob* JobPtr;
+    const auto& j = ((JobPtr)((const __attribute__((address_space(4))) uint8_t*)d + d->jobs_off))[y - n_chains];
+    const uint32_t n = j.tile_start[3];
+    if (x >= n) return;
+    const uint32_t t = xcd_run(x, n);
+    const int plane = t >= j.tile_start[2] ? 2 : (t >= j.tile_start[1] ? 1 : 0);
+    scale_tile_variant(j.variant, j.p[plane], t - j.tile_start[plane], j.tiles_x[plane], (int)j.s_rows);
 }
 
 __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {   // simple gather form, any ratio
@@ -625,9 +853,13 @@ static bool plan_scale_tiles(const ScaleBatchArgs& a, ScaleBatchArgs& b, uint32_
     lds = (size_t)s_rows * s_stride + (size_t)s_rows * SC_TW * sizeof(int);   // both pair layouts of t' = one int per (row, column)
     static const int force_simple = env_int("MX_SCALE_SIMPLE", 0);
     bool lean = true;                                 // packed taps exist for every plane (ScaleTables::lean)
-    for (uint32_t i = 0; i < a.n; ++i) if (a.p[i].dw && a.p[i].dh && (!a.p[i].hpk || !a.p[i].vpk)) lean = false;
-    if (!(lds <= 64 * 1024 && s_rows <= 48 && s_stride <= 256 && !force_simple && lean)) return false;   // the staging slots of sc_stage<3>
+    for (uint32_t i = 0; i < a.n; ++i) if (a.p[i].dw && a.p[i].dh && (!a.p[i].hpk || !a.p[i].vpk || !a.p[i].hx || !a.p[i].vx)) lean = false;
+    if (!(s_rows <= 48 && s_stride <= 256 && !force_simple && lean)) return false;   // the staging slots of sc_stage<3>
     b = a;
+    // staging shape of the tile body (scale_tile2): windows up to 128 bytes wide stage 8 chunks per row, 32 rows per pass
+    b.variant = s_stride <= 128 ? (s_rows <= 32 ? 0u : 1u) : 2u;
+    s_stride = s_stride <= 128 ? 128u : 256u;
+    lds = scale_tile_lds(b.variant);
     for (uint32_t i = 0; i < a.n; ++i) {
         b.tile_start[i] = total;
         b.tiles_x[i] = (a.p[i].dw + SC_TW - 1) / SC_TW;
@@ -642,48 +874,100 @@ static bool plan_scale_tiles(const ScaleBatchArgs& a, ScaleBatchArgs& b, uint32_
 void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s) {
     ScaleBatchArgs b; uint32_t total, mw, mh; size_t lds;
     if (plan_scale_tiles(a, b, total, lds, mw, mh)) {
-        if (total) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3(total), dim3(256), lds, s, b);
+        if (total) hipLaunchKernelGGL(k_scale_bicubic_tiled, dim3(total), dim3(256), lds, s, b, total);
     } else if (a.n && mw && mh) {
         hipLaunchKernelGGL(k_scale_bicubic_batch, dim3((mw + 63) / 64, (mh + 3) / 4, a.n), dim3(256), 0, s, a);
     }
 }
-// the batch `sa` (may be empty) and up to two chains that do not read it, in one launch when all take their tiled forms; else one after
-// the other (the batch, then the chains in order)
-static int chain_matrix_mode(ChainRgbaArgs& a) {
-    if (!a.use_matrix) return 0;
-    bool fits = true;
-    for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
-    a.use_matrix = fits ? 2 : 1;
-    return a.use_matrix;
+// ---- several ticks' scale jobs and RGBA chains as one launch (k_video_batch) ----
+// tile plan of ONE job (the three planes of a scaled frame) for the tiled kernel; false = it needs the gather kernel
+static bool plan_scale_job(const ScaleArgs& a, ScaleJob& j) {
+    ScaleBatchArgs in{}, out{};
+    in.n = 3;
+    for (int i = 0; i < 3; ++i) in.p[i] = a.p[i];
+    uint32_t total = 0, mw = 0, mh = 0; size_t lds = 0;
+    if (!plan_scale_tiles(in, out, total, lds, mw, mh) || !total) return false;
+    for (int i = 0; i < 3; ++i) { j.p[i] = out.p[i]; j.tile_start[i] = out.tile_start[i]; j.tiles_x[i] = out.tiles_x[i]; }
+    j.tile_start[3] = total; j.variant = out.variant; j.s_rows = out.s_rows;
+    return true;
 }
-void launch_scale_then_chains_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
-    ScaleBatchArgs b{}; uint32_t total = 0, mw, mh; size_t lds = 0;
+// descriptor slots per stream: page-locked staging + its device copy; a slot is rewritten only after the launch that read it has finished
+namespace {
+struct DescSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; hipEvent_t done = nullptr, copied = nullptr; bool used = false; };
+struct DescRing { DescSlot slot[4]; uint32_t next = 0; hipStream_t copy = nullptr; };   // `copy`: the uploads' own stream -- they run beside the previous launch, not behind it
+std::mutex g_desc_mu;
+std::map<std::pair<int, hipStream_t>, DescRing> g_desc;
+constexpr size_t VB_HEADER = offsetof(VideoBatchDesc, c);
+constexpr size_t VB_BYTES = sizeof(VideoBatchDesc);
+}  // namespace
+static void launch_separately(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
+    for (int i = 0; i < n_jobs; i += 4) {
+        ScaleBatchArgs b{};
+        for (int k = i; k < n_jobs && k < i + 4; ++k) for (int pl = 0; pl < 3; ++pl) b.p[b.n++] = jobs[k].p[pl];
+        launch_scale_batch(b, s);
+    }
+    for (int k = 0; k < n_chains; ++k) launch_fade_chain_rgba(chains[k], s);
+}
+void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
+    if (n_jobs <= 0 && n_chains <= 0) return;
     static const int no_fuse = env_int("MX_VIDEO_NO_LAUNCH_FUSION", 0);
-    bool fuse = !no_fuse && n_chains >= 1 && n_chains <= 2;
-    ChainRgbaArgs c[2];
+    bool one = !no_fuse && n_jobs <= MX_VB_MAX_JOBS && n_chains <= MX_VB_MAX_CHAINS;
     int mm = -1;
-    for (int k = 0; k < n_chains && k < 2; ++k) {
-        c[k] = chains[k];
-        if (c[k].n_scaled || !c[k].width || !c[k].height) fuse = false;
-        const int m = chain_matrix_mode(c[k]);
-        if (mm >= 0 && m != mm) fuse = false;
+    for (int k = 0; k < n_chains && one; ++k) {
+        ChainRgbaArgs c = chains[k];
+        if (c.n_scaled || !c.width || !c.height) one = false;
+        const int m = chain_matrix_mode(c);
+        if (mm >= 0 && m != mm) one = false;
         mm = m;
     }
-    const bool have_scales = sa.n != 0 && plan_scale_tiles(sa, b, total, lds, mw, mh) && total;
-    if (!fuse || (sa.n && !have_scales) || (!have_scales && n_chains < 2)) {
-        if (sa.n) launch_scale_batch(sa, s);
-        for (int k = 0; k < n_chains; ++k) launch_fade_chain_rgba(chains[k], s);
-        return;
+    if (!one) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }
+    // the descriptor, built in a page-locked slot
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    DescSlot* sl; hipStream_t copy_stream;
+    {
+        std::lock_guard<std::mutex> lk(g_desc_mu);
+        DescRing& r = g_desc[{dev, s}];
+        if (!r.copy) hip_check(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking), "hipStreamCreate(descriptor uploads)");
+        sl = &r.slot[r.next]; r.next = (r.next + 1) & 3u; copy_stream = r.copy;
     }
-    if (!have_scales) { b = ScaleBatchArgs{}; total = 0; lds = 0; }
-    if (n_chains < 2) { c[1] = c[0]; }
-    const uint32_t tx0 = (c[0].width + 127) / 128, n0 = tx0 * ((c[0].height + 31) / 32);
-    const uint32_t tx1 = n_chains == 2 ? (c[1].width + 127) / 128 : 1u, n1 = n_chains == 2 ? tx1 * ((c[1].height + 31) / 32) : 0u;
-    static const int order = env_int("MX_VIDEO_FUSED_ORDER", 2);          // 2 chain tiles first (default: 18.4 us per 1080p frame with one chain), 0 scaler tiles first (19.5)
-    const dim3 grid(total + n0 + n1);
-    if (mm == 2) hipLaunchKernelGGL(k_scale_then_chain_rgba<2>, grid, dim3(256), lds, s, b, c[0], c[1], total, n0, n1, tx0, tx1, (uint32_t)order);
-    else if (mm == 1) hipLaunchKernelGGL(k_scale_then_chain_rgba<1>, grid, dim3(256), lds, s, b, c[0], c[1], total, n0, n1, tx0, tx1, (uint32_t)order);
-    else hipLaunchKernelGGL(k_scale_then_chain_rgba<0>, grid, dim3(256), lds, s, b, c[0], c[1], total, n0, n1, tx0, tx1, (uint32_t)order);
+    if (!sl->host) {
+        hip_check(hipEventCreateWithFlags(&sl->copied, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipHostMalloc((void**)&sl->host, VB_BYTES, hipHostMallocDefault), "hipHostMalloc(video batch descriptor)");
+        hip_check(hipMalloc((void**)&sl->dev, VB_BYTES), "hipMalloc(video batch descriptor)");
+        hip_check(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (sl->used) hip_check(hipEventSynchronize(sl->done), "hipEventSynchronize(video batch descriptor)");
+    VideoBatchDesc* d = reinterpret_cast<VideoBatchDesc*>(sl->host);
+    uint32_t gx = 0, variant_max = 0; bool any_job = false;
+    d->n_chains = (uint32_t)n_chains; d->n_jobs = (uint32_t)n_jobs; d->jobs_off = (uint32_t)(VB_HEADER + (size_t)n_chains * sizeof(ChainRgbaArgs)); d->_pad = 0;
+    for (int k = 0; k < n_chains; ++k) {
+        ChainRgbaArgs& c = d->c[k];
+        c = chains[k];
+        chain_matrix_mode(c); chain_blank_planes(c);
+        d->chain_tx[k] = (c.width + 127) / 128;
+        d->chain_tiles[k] = d->chain_tx[k] * ((c.height + 31) / 32);
+        gx = std::max(gx, d->chain_tiles[k]);
+    }
+    ScaleJob* dj = reinterpret_cast<ScaleJob*>(sl->host + d->jobs_off);
+    for (int k = 0; k < n_jobs; ++k) {
+        if (!plan_scale_job(jobs[k], dj[k])) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }   // (the slot stays free: nothing was launched from it)
+        gx = std::max(gx, dj[k].tile_start[3]); variant_max = std::max(variant_max, dj[k].variant); any_job = true;
+    }
+    const size_t bytes = d->jobs_off + (size_t)n_jobs * sizeof(ScaleJob);
+    // the upload goes on its own stream (the host runs ahead of the device: it executes while the previous launch still runs); the
+    // launch stream only waits for its event
+    hip_check(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, copy_stream), "hipMemcpyAsync(video batch descriptor)");
+    hip_check(hipEventRecord(sl->copied, copy_stream), "hipEventRecord");
+    hip_check(hipStreamWaitEvent(s, sl->copied, 0), "hipStreamWaitEvent");
+    const dim3 grid((gx + 7u) & ~7u, (uint32_t)(n_chains + n_jobs));
+    const size_t lds = any_job ? scale_tile_lds(variant_max) : 0;
+    const VideoBatchDesc* dd = reinterpret_cast<const VideoBatchDesc*>(sl->dev);
+    if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd);
+    else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd);
+    else hipLaunchKernelGGL(k_video_batch<0>, grid, dim3(256), lds, s, dd);
+    hip_check(hipEventRecord(sl->done, s), "hipEventRecord");
+    sl->used = true;
 }
 // Downscaling: the kernel widens with the scale factor (hn / vn taps, DESIGN.md "Scaler").  Two plain passes through
 // ScalePlane::tmp -- the H pass filters every source row once, the V pass reads vn of those rows per pixel -- instead of

@@ -41,22 +41,26 @@ bool Rational::operator>=(const Rational& o) const {
 // ---------------------------------------------------------------------------------------------
 // deferred scaling: jobs queue per stream and leave as one batched launch when pixels are needed
 // ---------------------------------------------------------------------------------------------
+uint32_t video_batch_ticks() {
+    static const uint32_t k = [] { const char* e = getenv("MX_VIDEO_BATCH"); const int v = e ? atoi(e) : 16; return (uint32_t)std::min(std::max(v, 1), (int)MX_VB_MAX_CHAINS); }();
+    return k;
+}
 namespace {
-struct PendingScales { ScaleBatchArgs args{}; std::vector<FrameRef> keep; std::vector<std::shared_ptr<const ScaleTables>> keep_tabs; };
+struct PendingScales { std::vector<ScaleArgs> jobs; std::vector<FrameRef> keep; std::vector<std::shared_ptr<const ScaleTables>> keep_tabs; };
 std::mutex g_scale_mu;
 std::map<hipStream_t, PendingScales> g_scale_q;
 void flush_locked(hipStream_t s, PendingScales& q) {
-    if (q.args.n) { launch_scale_batch(q.args, s); q.args.n = 0; }
+    if (!q.jobs.empty()) { launch_video_batch(q.jobs.data(), (int)q.jobs.size(), nullptr, 0, s); q.jobs.clear(); }
     q.keep.clear(); q.keep_tabs.clear();
 }
 }  // namespace
 void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs) {
     std::lock_guard<std::mutex> lk(g_scale_mu);
     PendingScales& q = g_scale_q[s];
-    bool conflict = q.args.n + 3 > MX_SCALE_BATCH_PLANES;
+    bool conflict = q.jobs.size() >= MX_VB_MAX_JOBS;
     for (const FrameRef& k : q.keep) if (k.f == src.f || k.f == dst.f) conflict = true;   // no ordering inside one launch
     if (conflict) flush_locked(s, q);
-    for (int i = 0; i < 3; ++i) q.args.p[q.args.n++] = a.p[i];
+    q.jobs.push_back(a);
     q.keep.push_back(src); q.keep.push_back(dst);
     if (tabs) q.keep_tabs.push_back(std::move(tabs));   // the job reads these tables when it leaves
 }
@@ -65,8 +69,8 @@ void flush_scales(hipStream_t s) {
     auto it = g_scale_q.find(s);
     if (it != g_scale_q.end()) flush_locked(s, it->second);
 }
-// The queued scales of the stream leave TOGETHER with an RGBA chain that does not read them (Graph::run_video_tick: the chain of the tick
-// before) -- one launch instead of two dependent ones (mx_k_video.hip k_scale_then_chain_rgba).
+// The queued scales of the stream leave TOGETHER with RGBA chains that do not read them (Graph::run_video_tick: the chains of earlier
+// ticks) -- one launch instead of dependent ones (mx_k_video.hip k_video_batch).
 void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
     PendingScales taken;
     {
@@ -74,7 +78,7 @@ void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_c
         auto it = g_scale_q.find(s);
         if (it != g_scale_q.end()) { taken = std::move(it->second); it->second = PendingScales{}; }
     }
-    launch_scale_then_chains_rgba(taken.args, chains, n_chains, s);   // `taken` keeps the frames and tables until the launch is queued (a later free synchronises)
+    launch_video_batch(taken.jobs.data(), (int)taken.jobs.size(), chains, n_chains, s);   // `taken` keeps the frames and tables until the launch is queued (a later free synchronises)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,6 +331,13 @@ static bool pack_lean_taps(const std::vector<int32_t>& hc, const std::vector<int
     return ok;
 }
 
+// {packed taps, first tap index, 0} per output sample: what a lane of the tiled kernel fetches with one 16-byte load (ScalePlane::hx / vx)
+static std::vector<int32_t> lean_entries(const std::vector<int32_t>& first, const std::vector<int32_t>& pk) {
+    std::vector<int32_t> x(4 * first.size());
+    for (size_t o = 0; o < first.size(); ++o) { x[4 * o] = pk[2 * o]; x[4 * o + 1] = pk[2 * o + 1]; x[4 * o + 2] = first[o]; x[4 * o + 3] = 0; }
+    return x;
+}
+
 // Row band of DynamicScaler::scale.  The plan (tap tables, which rows of which plane) depends only on the geometry; run() binds frames.
 BandScaler::BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uint32_t slice_rows, uint32_t full_w, uint32_t full_h, uint32_t row0, uint32_t band_rows)
     : in_w_(in_w), src_row0_(src_row0), slice_rows_(slice_rows), full_w_(full_w), band_rows_(band_rows) {
@@ -335,7 +346,7 @@ BandScaler::BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uin
         throw Error(MX_ERR_INVALID, "band / slice rows must be whole chroma rows inside their pictures");
     geo_ = scaler_geometry(in_w, in_full_h, full_w, full_h);
     if (!geo_.scaled_w || !geo_.scaled_h) return;
-    std::vector<int32_t> blob; size_t offs[2][4], pk_off[2][2] = {{0, 0}, {0, 0}}; uint32_t taps[2][2];
+    std::vector<int32_t> blob; size_t offs[2][4], pk_off[2][2] = {{0, 0}, {0, 0}}, x_off[2][2] = {{0, 0}, {0, 0}}; uint32_t taps[2][2];
     std::vector<int32_t> vf_host[2];
     tiled_ = true;                                  // every axis 4 taps and the taps fit the packed form: the batched tiled kernel takes the band
     for (int c = 0; c < 2; ++c) {
@@ -348,8 +359,10 @@ BandScaler::BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uin
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
         std::vector<int32_t> hp, vp;
         if (taps[c][0] != 4 || taps[c][1] != 4 || !pack_lean_taps(hc, vc, hp, vp) ||
-            !scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_full_h >> c, geo_.scaled_h >> c, vf.data())) { tiled_ = false; continue; }
+            !scale_tile_origins_match(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match(in_full_h >> c, geo_.scaled_h >> c, vf.data()) ||
+            !scale_tile_origins_match_m(in_w >> c, geo_.scaled_w >> c, hf.data()) || !scale_tile_origins_match_m(in_full_h >> c, geo_.scaled_h >> c, vf.data())) { tiled_ = false; continue; }
         pk_off[c][0] = put(hp); pk_off[c][1] = put(vp);
+        x_off[c][0] = put(lean_entries(hf, hp)); x_off[c][1] = put(lean_entries(vf, vp));
     }
     needs_blank_ = geo_.scaled_w != full_w;         // letterbox bars inside the band (encode.rs:382): the blank fill is only paid for when there are any
     tabs_.alloc(blob.size() * sizeof(int32_t));
@@ -380,6 +393,9 @@ BandScaler::BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uin
         if (tiled_) {
             sp.hpk = reinterpret_cast<const uint2*>((const int32_t*)tabs_.p + pk_off[c][0]);
             sp.vpk = reinterpret_cast<const uint2*>((const int32_t*)tabs_.p + pk_off[c][1]) + (ra - s0);
+            sp.hx = reinterpret_cast<const uint4*>((const int32_t*)tabs_.p + x_off[c][0]);
+            sp.vx = reinterpret_cast<const uint4*>((const int32_t*)tabs_.p + x_off[c][1]) + (ra - s0);
+            sp.mh = scale_origin_magic(geo_.scaled_w >> c); sp.mv = scale_origin_magic(geo_.scaled_h >> c);
         }
         dst_row_[p] = ra - b0;
         any_ = true;
@@ -430,6 +446,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     t->geo = scaler_geometry(in_w, in_h, out_w_, out_h_);
     const ScaleGeometry& geo = t->geo;
     flush_scales(stream_);             // queued jobs write the old output frames
+    ring_.assign(2 * (size_t)video_batch_ticks(), FrameRef());
     for (auto& f : ring_) f = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
     ring_pos_ = 0; frame_ = ring_[0];
     keep_pool_.clear();                // their borders belong to the old letterbox
@@ -443,7 +460,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     std::vector<int32_t> blob;
     size_t offs[2][4];
     bool four = geo.scaled_w && geo.scaled_h;
-    size_t pk_off[2][2] = {{0, 0}, {0, 0}};
+    size_t pk_off[2][2] = {{0, 0}, {0, 0}}, x_off[2][2] = {{0, 0}, {0, 0}};
     for (int c = 0; c < 2; ++c) {
         std::vector<int32_t> hf, hc, vf, vc;
         make_taps(src_w[c], geo.scaled_w >> c, hf, hc);
@@ -452,11 +469,13 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
         auto put = [&](const std::vector<int32_t>& v) { while (blob.size() & 3) blob.push_back(0); size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return o; };
         offs[c][0] = put(hf); offs[c][1] = put(hc); offs[c][2] = put(vf); offs[c][3] = put(vc);
         if (t->taps[c][0] != 4 || t->taps[c][1] != 4) { four = false; continue; }
-        if (!scale_tile_origins_match(src_w[c], geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match(src_h[c], geo.scaled_h >> c, vf.data()))
+        if (!scale_tile_origins_match(src_w[c], geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match(src_h[c], geo.scaled_h >> c, vf.data()) ||
+            !scale_tile_origins_match_m(src_w[c], geo.scaled_w >> c, hf.data()) || !scale_tile_origins_match_m(src_h[c], geo.scaled_h >> c, vf.data()))
             throw Error(MX_ERR_INTERNAL, "scaler: window-origin formula disagrees with the tap table");
         std::vector<int32_t> hp, vp;
         if (!pack_lean_taps(hc, vc, hp, vp)) four = false;
         pk_off[c][0] = put(hp); pk_off[c][1] = put(vp);
+        x_off[c][0] = put(lean_entries(hf, hp)); x_off[c][1] = put(lean_entries(vf, vp));
     }
     t->four_tap = four;
     t->tabs.alloc(blob.size() * sizeof(int32_t));   // the previous tables stay alive with whoever still holds them (frames, queued jobs)
@@ -465,6 +484,9 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     if (four) for (int c = 0; c < 2; ++c) {
         t->hpk[c] = reinterpret_cast<const uint2*>((const int32_t*)t->tabs.p + pk_off[c][0]);
         t->vpk[c] = reinterpret_cast<const uint2*>((const int32_t*)t->tabs.p + pk_off[c][1]);
+        t->hx[c] = reinterpret_cast<const uint4*>((const int32_t*)t->tabs.p + x_off[c][0]);
+        t->vx[c] = reinterpret_cast<const uint4*>((const int32_t*)t->tabs.p + x_off[c][1]);
+        t->mh[c] = scale_origin_magic(geo.scaled_w >> c); t->mv[c] = scale_origin_magic(geo.scaled_h >> c);
     }
     // downscaling on any axis: the two-pass path keeps the H-filtered rows of each plane in device memory
     const bool wide = t->taps[0][0] > 4 || t->taps[0][1] > 4 || t->taps[1][0] > 4 || t->taps[1][1] > 4;
@@ -493,6 +515,7 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
         sp.hn = t.taps[c][0]; sp.vn = t.taps[c][1]; sp.tmp = tmp_plane ? tmp_plane[p] : nullptr;
         sp.h_row0 = 0; sp.h_rows = sp.sh;
         sp.hpk = t.hpk[c]; sp.vpk = t.vpk[c]; sp.oy_base = 0; sp.dh_full = 0;
+        sp.hx = t.hx[c]; sp.vx = t.vx[c]; sp.mh = t.mh[c]; sp.mv = t.mv[c];
         sp.sxs = in->xstep(p) - 1u; sp.sxo = in->xoff(p);
     }
     if (tmp_plane && tmp_plane[0]) {        // widened kernel (downscale): two passes, launched in stream order
@@ -508,7 +531,7 @@ FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
     in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);   // encode.rs:347-384
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
-    ring_pos_ = (ring_pos_ + 1) & 3u; frame_ = ring_[ring_pos_];   // not a frame the last three calls wrote: the RGBA chains that read those may be launched AFTER this scale (Graph defers them)
+    ring_pos_ = (ring_pos_ + 1) % (uint32_t)ring_.size(); frame_ = ring_[ring_pos_];   // not a frame the last 2K - 1 calls wrote: the RGBA chains that read those may be launched AFTER this scale (Graph defers them)
     if (may_defer && t_->four_tap) {
         auto sc = std::make_shared<LazyScale>();
         sc->src = in; sc->t = t_; sc->target = frame_;

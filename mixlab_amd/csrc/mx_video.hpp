@@ -33,6 +33,10 @@ struct ScalePlane {
     const uint2* hpk; const uint2* vpk;            // tiled path: packed taps (ScaleTables::lean), nullptr = not available
     uint32_t sxs, sxo;                             // source samples are (1 + sxs) bytes apart starting at byte sxo of a row (nv12 chroma: 1, 0 | 1)
     uint32_t oy_base, dh_full;                     // tiled path, row bands: index of dst's first row in rows of the scaled plane, and that plane's full height (0 = dh)
+    // tiled path: one 16-byte entry per output column / row -- {packed taps (hpk / vpk), first tap index, 0} -- so a lane fetches what it needs
+    // of an axis with ONE load; and floor(2^32 / (2 dst)) per axis: the window origin of a tile is integer arithmetic on wave-uniform values (SALU)
+    const uint4* hx; const uint4* vx;
+    uint32_t mh, mv;
 };
 struct ScaleArgs { ScalePlane p[3]; };
 enum { MX_SCALE_BATCH_PLANES = 12 };   // up to 4 frames per launch
@@ -41,6 +45,7 @@ struct ScaleBatchArgs {
     uint32_t tile_start[MX_SCALE_BATCH_PLANES + 1];   // launcher-filled: flat block index -> (plane, tile), no empty blocks
     uint32_t tiles_x[MX_SCALE_BATCH_PLANES];
     uint32_t s_rows, s_stride;                        // launcher-filled: LDS window geometry of the tiled kernel
+    uint32_t variant;                                 // launcher-filled: staging shape of the tile body (mx_k_video.hip scale_tile)
 };
 struct CopyArgs { const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], rows[3], row_bytes[3]; };
 struct RgbaArgs {
@@ -51,7 +56,9 @@ struct RgbaArgs {
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s);
 void launch_scale_wide(const ScaleArgs& a, hipStream_t s);   // two passes through ScalePlane::tmp, any tap counts
-bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first);   // f64 window-origin formula of the tiled / inline scalers == tap table, every output
+bool scale_tile_origins_match(uint32_t src, uint32_t dst, const int32_t* first);
+uint32_t scale_origin_magic(uint32_t dst);   // floor(2^32 / (2 dst)): ScalePlane::mh / mv
+bool scale_tile_origins_match_m(uint32_t src, uint32_t dst, const int32_t* first);   // the integer form the tiled kernel uses == tap table, every output   // f64 window-origin formula of the tiled / inline scalers == tap table, every output
 
 // A chain of cross-fades evaluated per pixel in registers:  v = src[0];  for k >= 1:
 //   v = v_is_a[k-1] ? fade(v, src[k]) : fade(src[k], v)   with fade(a,b) = (a*f + b*(255-f)) / 255, f = fade[k-1]
@@ -79,11 +86,25 @@ struct ChainScale {
 struct ChainRgbaArgs {   // the same chain feeding the build-specified YUV420P -> RGBA (+ matrix) directly: no YUV frame is written
     ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t n_src;
     uint32_t fade[MX_CHAIN_MAX_SRC - 1]; uint32_t v_is_a[MX_CHAIN_MAX_SRC - 1];
+    uint32_t fa_pk[MX_CHAIN_MAX_SRC - 1], fb_pk[MX_CHAIN_MAX_SRC - 1];   // launcher-filled from fade / v_is_a: the step's two factors as u16 x 2
     uint8_t* rgba; uint32_t rgba_stride, width, height;
     int32_t use_matrix; int32_t m[12];
     uint32_t n_scaled; uint32_t scaled_src[MX_CHAIN_MAX_SCALED];   // chain position of each inline-scaled layer (its ChainSrc planes are nullptr)
     ChainScale sc[MX_CHAIN_MAX_SCALED];
 };
+// Several ticks' video work as ONE launch (mx_k_video.hip k_video_batch): up to MX_VB_MAX_CHAINS RGBA chains and MX_VB_MAX_JOBS scale jobs
+// (a job = the three planes of one scaled frame).  The descriptor is uploaded to device memory per launch.
+enum { MX_VB_MAX_CHAINS = 16, MX_VB_MAX_JOBS = 32 };
+struct ScaleJob { ScalePlane p[3]; uint32_t tile_start[4]; uint32_t tiles_x[3]; uint32_t variant, s_rows; };
+struct VideoBatchDesc {   // header | c[n_chains] | ScaleJob[n_jobs] at byte jobs_off: only the used part is uploaded
+    uint32_t n_chains, n_jobs, jobs_off, _pad;
+    uint32_t chain_tiles[MX_VB_MAX_CHAINS], chain_tx[MX_VB_MAX_CHAINS];
+    ChainRgbaArgs c[MX_VB_MAX_CHAINS];
+    ScaleJob j[MX_VB_MAX_JOBS];   // capacity only: the jobs follow the chains actually present
+};
+void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
+// K: how many ticks' RGBA chains (and the scale jobs of the K ticks after them) share one launch inside a batched run (MX_VIDEO_BATCH, default 16, 1..16)
+uint32_t video_batch_ticks();
 void launch_fade_chain(const ChainArgs& a, hipStream_t s);
 void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s);
 void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s);
@@ -94,7 +115,6 @@ struct FrameRef;
 struct ScaleTables;
 void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs = nullptr);
 void flush_scales(hipStream_t s);
-void launch_scale_then_chains_rgba(const ScaleBatchArgs& sa, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);   // one launch when all take their tiled forms
 void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
 // whole frame allocations (equal size, 16-byte multiples) gathered back to back: the packed read-back of a sink's kept frames
@@ -150,6 +170,8 @@ struct ScaleTables {
     //   H: {ch0..3 as i8 x 4, cl0..3 as i8 x 4} with c = 256 ch + cl;  V: {(c0, c1), (c2, c3)} as i16 x 2
     bool four_tap = false;
     const uint2* hpk[2] = {nullptr, nullptr}; const uint2* vpk[2] = {nullptr, nullptr};
+    const uint4* hx[2] = {nullptr, nullptr}; const uint4* vx[2] = {nullptr, nullptr};   // {packed taps, first tap, 0} per output (ScalePlane::hx / vx)
+    uint32_t mh[2] = {0, 0}, mv[2] = {0, 0};
 };
 // A frame that is the DynamicScaler's output of `src` and has not been computed: chain kernels resample it inline; anyone else
 // materialises it into the scaler's own output frame (`target`, encode.rs:382-396 -- the reference reuses that frame too).
@@ -248,7 +270,7 @@ private:
     uint8_t in_fmt_ = MX_PIXFMT_YUV420P;
     FrameRef frame_;                 // cached blank output frame (encode.rs:382) -- the one the latest scale() wrote
     std::vector<FrameRef> keep_pool_; // scale_keep's outputs: blank frames of this context's letterbox geometry, reused once released
-    FrameRef ring_[4];               // four of them, used in turn: the RGBA chains that read the last two may be launched together with the next two scales
+    std::vector<FrameRef> ring_;     // 2 * video_batch_ticks() of them, used in turn: the RGBA chains that read the last K may be launched together with the next K scales
     uint32_t ring_pos_ = 0;
     std::shared_ptr<ScaleTables> t_;
     DevBuf tmp_;                     // downscaling: H-filtered rows of the three planes
