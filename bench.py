@@ -297,7 +297,10 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
     # reads 2 x F720 and writes 2 x F; the chain kernel reads 8 F (six layers + the two scaled ones) and writes the RGBA frame.
     alg = 7 * 3 * F + 2 * (F720 + F) + (F + 1920 * 1080 * 4)
     moved_scaler = 2 * (F720 + F)
-    moved_chain = 8 * F + 1920 * 1080 * 4
+    # a step whose fader rests at an end of its travel returns one of its inputs exactly: the launcher drops it and never reads the other
+    # layer (mx_k_video.hip chain_matrix_mode).  SURVEY's config-4 faders start with 1.0, so 7 of the 8 layers are read.
+    layers_read = 8 - sum(1 for f in VIDEO_FADERS if f == 1.0)
+    moved_chain = layers_read * F + 1920 * 1080 * 4
     dev_ms = by_kind.get("video_mixer", 0.0) / max(1, n_prof) / T   # device time per composited frame (scaler + chain)
     n_frames = steps * T * (1 if bands else world)
     if bands:
@@ -316,8 +319,10 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
         "hbm_frac_moved_bytes_device": round((moved_scaler + moved_chain) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms > 0 else None,
         "hbm_frac_moved_bytes_wall": round((moved_scaler + moved_chain) * n_frames / world / dt / 1e9 / HBM_PEAK_GBS, 4),
         "per_kernel_moved_bytes": {"scaler tiles (2 layers)": moved_scaler, "chain tiles": moved_chain,
-                                   "launches": "k_scale_then_chain_rgba: the chains of two ticks and the scaler tiles of the two after them in ONE launch (DESIGN.md 5.3)",
-                                   "note": "per-kernel durations and PMC traffic: profiles/r02 (the hipEvents here bracket the whole per-tick video section)"},
+                                   "layers_read_by_the_chain": layers_read,
+                                   "launches": "k_video_batch: the chains of 16 ticks and the scaler tiles of the 16 ticks after them in ONE launch (MX_VIDEO_BATCH; DESIGN.md 5.3)",
+                                   "ticks_per_submission": T,
+                                   "note": "per-kernel durations and PMC traffic: profiles/r03 (the hipEvents here bracket the whole per-tick video section)"},
     }
 
 

@@ -670,9 +670,14 @@ __device__ __forceinline__ void sc_hcol_fixed(const uint8_t* S, int hf /* first 
 #pragma unroll
     for (int g = 0; g < HR / 8; ++g) {
         uint32_t lo[8], hi[8];
+        // one base address per group of eight rows, hidden from the optimiser: the eight 8-byte reads then carry their row offsets as
+        // instruction immediates (ds_read2_b32 reaches 1020 bytes) instead of one address computation each from a base rows away
+        uint32_t base = (uint32_t)(uintptr_t)(Srow + (8 * g + 1) * SS);
+        asm volatile("" : "+v"(base));
+        const __attribute__((address_space(3))) uint8_t* Sg = (const __attribute__((address_space(3))) uint8_t*)(uintptr_t)base;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t* sp = reinterpret_cast<const uint32_t*>(Srow + (8 * g + j + 1) * SS);
+            const __attribute__((address_space(3))) uint32_t* sp = reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(Sg + j * SS);
             lo[j] = sp[0]; hi[j] = sp[1];
         }
 #pragma unroll
@@ -746,13 +751,13 @@ __device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile
     // ---- V pass ----
     const int oxg = cg * 4;
     if (ox0 + oxg < dw) {
-        uint8_t* const o0 = p.dst + (size_t)((uint32_t)(oy0 + oyr) * p.dst_stride) + ox0 + oxg;
+        const uint32_t off0 = (uint32_t)(oy0 + oyr) * p.dst_stride + (uint32_t)(ox0 + oxg);   // 32-bit offsets from the (scalar) plane base
         const bool whole = ox0 + oxg + 4 <= dw && ((reinterpret_cast<uintptr_t>(p.dst) | p.dst_stride) & 3u) == 0;   // ox0 + oxg is a multiple of 4
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (oy0 + oyr + 8 * k >= dh) break;
             const uint32_t quad = sc_vquad(T2, SC_TW, (int)vx[k].z - ry0, oxg, make_uint2(vx[k].x, vx[k].y));
-            uint8_t* o = o0 + (size_t)((uint32_t)(8 * k) * p.dst_stride);
+            uint8_t* o = p.dst + (size_t)(off0 + (uint32_t)(8 * k) * p.dst_stride);
             if (whole) *reinterpret_cast<uint32_t*>(o) = quad;
             else for (int j = 0; j < 4 && ox0 + oxg + j < dw; ++j) o[j] = (uint8_t)(quad >> (8 * j));
         }

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-vpmc}
 mkdir -p $OUT
-for mode in fused unfused; do
+for mode in fused; do
   if [ $mode = unfused ]; then export MX_VIDEO_NO_LAUNCH_FUSION=1; else unset MX_VIDEO_NO_LAUNCH_FUSION; fi
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
@@ -16,4 +16,4 @@ for mode in fused unfused; do
     [ -n "$f" ] && python $R/tools/pmc_summary.py $f > $OUT/${mode}_set$i.txt
   done
 done
-grep -h -A9 "k_scale_then\|k_fade_chain_rgba\|k_scale_bicubic_tiled" $OUT/*.txt | head -150
+grep -h -A9 "k_video_batch<2>\|k_fade_chain_rgba\|k_scale_bicubic_tiled" $OUT/*.txt | head -150
