@@ -574,6 +574,7 @@ def main():
     ap.add_argument("--no-t-sweep", action="store_true", help="skip the shorter-submission legs (T = 64 and 1024 ticks, SURVEY 8d)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the one-tick-per-submission leg (hundreds of tiny dispatches: slow under a counter-collecting profiler)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 240-strip + 8-layer real-time leg")
+    ap.add_argument("--no-material-leg", action="store_true", help="skip the realistic-material (muted strips, silences) and poisoned-strip legs")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
     ap.add_argument("--video-band-as", default=None, metavar="R/W", help="single GPU: run the video leg as rank R of a W-rank row-band job")
@@ -638,7 +639,7 @@ def main():
     # every step's gate toggles, built before any clock starts (the schedule is host data, like the params a UI would send)
     n_regions = 1 + (max(0, args.repeats) if not use_dist else 0)
     n_sched = args.warmup + args.steps * n_regions + 4
-    events = [gate_events(abi, trigs, first, i * T, T) if toggling else None for i in range(n_sched)]
+    events = {i: (gate_events(abi, trigs, first, i * T, T) if toggling else None) for i in range(n_sched)}
 
     def step(i, scheduled=True):
         if scheduled and events[i] is not None:
@@ -772,6 +773,61 @@ def main():
                 t_sweep[str(Ts)] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub}
                 tick0 += (n_sub + 3) * Ts
 
+    # Realistic material and the repair pass's worst case, on the same graph (LAST: the poisoned strip's state stays NaN for ever).
+    # The headline's sources are seeded noise, on which every chunk boundary of the speculative EqThree proves itself; a desk also carries
+    # muted strips (exact zeros) and programme that falls silent and comes back -- the one input class the proof fails on (poles stall a few
+    # ulps from their fixed point) -- and may meet a NaN.  Not part of `value`.
+    material = None
+    if not use_dist and not args.no_material_leg:
+        material = {}
+        with torch.cuda.stream(stream):
+            rng = np.random.default_rng(0x4D58)
+            seg = 48000 * 3                                                     # signal 3 s / silence 2 s / signal ...
+            base_ticks = min(T, 256)
+            n_muted = n_gaps = 0
+            for j, sn in enumerate(srcs):
+                kind = j % 4                                                    # 0 muted, 1 programme with silences, 2 / 3 noise as in the headline
+                if kind == 0:
+                    buf = np.zeros(T * spt, dtype=np.float32); n_muted += 1
+                elif kind == 1:
+                    blk = synth.noise(first + j, base_ticks * spt)
+                    buf = np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt].copy()
+                    off = int(rng.integers(0, seg))
+                    pos = off
+                    while pos < buf.size:
+                        buf[pos: pos + 2 * 48000] = 0.0                         # two seconds of digital silence
+                        pos += seg + 2 * 48000
+                    n_gaps += 1
+                else:
+                    continue
+                g.write_source(sn, buf, T)
+            ran0, rep0 = g.eq_spec_stats()
+            base_i = nxt + 200
+            n_m = min(args.steps, 10)
+            for i in list(range(base_i, base_i + 2 + n_m)) + list(range(base_i + 20, base_i + 22 + n_m)):   # the schedules, before any clock starts
+                events[i] = gate_events(abi, trigs, first, i * T, T) if toggling else None
+            for i in range(2):
+                step(base_i + i)
+            dt_m = timed_region(base_i + 2, n_m)
+            ran1, rep1 = g.eq_spec_stats()
+            material["daw"] = {"what": f"{n_muted} strips muted (exact zeros), {n_gaps} with 3 s programme / 2 s digital silence alternating, the rest noise; gates toggling as in the headline",
+                               "ms_per_step": round(dt_m / n_m * 1e3, 4), "value": args.strips * T * n_m / dt_m, "unit": "channel-ticks/s",
+                               "eq_spec": {"chunks_run": ran1 - ran0, "chunks_repaired": rep1 - rep0}}
+            # one strip poisoned: a NaN in its source.  Its poles are NaN from then on (the state is carried from step to step), no chunk
+            # after the NaN can prove itself, and the repair pass fills the strip's remaining outputs with all 64 lanes of its wave
+            bad = np.array(synth.noise(first + 2, min(T, 256) * spt), dtype=np.float32)
+            bad = np.tile(bad, (T + min(T, 256) - 1) // min(T, 256))[: T * spt].copy()
+            bad[(T * spt) // 3] = np.float32("nan")
+            g.write_source(srcs[2], bad, T)
+            for i in range(2):
+                step(base_i + 20 + i)
+            ran2, rep2 = g.eq_spec_stats()
+            dt_p = timed_region(base_i + 22, n_m)
+            ran3, rep3 = g.eq_spec_stats()
+            material["one_strip_poisoned_by_a_nan"] = {"ms_per_step": round(dt_p / n_m * 1e3, 4), "value": args.strips * T * n_m / dt_p, "unit": "channel-ticks/s",
+                                                       "eq_spec": {"chunks_run": ran3 - ran2, "chunks_repaired": rep3 - rep2},
+                                                       "note": "on top of the daw material; the poisoned strip's whole stream is re-emitted by its repair wave (parallel fill) every step"}
+
     video = None
     if args.video_frames > 0:
         with torch.cuda.stream(stream):
@@ -862,6 +918,7 @@ def main():
             "exchange": exch,
             "realtime": realtime,
             "t_sweep": t_sweep,
+            "material": material,
             "north_star_realtime": north,
             "video": video,
             "fir_resample": fir,

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
 //   stage-out  the tile is read back linearly (lane l of step k holds slot l & 7 of chunk 8k + (l >> 3)) and stored with eight
 //              lanes per line: whole lines again.
 // The wave needs no barrier (a wave per workgroup; its own vmcnt orders the DMA before its ds_reads).  16 KiB of LDS per wave.
-// Conditions (launch_eq_three_spec): frames % 4 == 0, chunk % 32 == 0, frames < 2^31, no control BUFFER (EQM_AMP_CTL keeps the
+// Conditions (launch_eq_three_spec): frames % 4 == 0, chunk % 32 == 0, frames < 2^30, no control BUFFER (EQM_AMP_CTL keeps the
 // direct form), and with an inline Envelope samples-per-tick % 32 == 0 (48 kHz: 800).
 // ---------------------------------------------------------------------------------------------
 typedef const float __attribute__((address_space(1)))* mx_gfp1;
@@ -502,23 +502,34 @@ template <int SB> struct EqTileGeo {
 
 struct EqTileCtx {
     const float* in; float* out;          // stream bases of the instance
-    uint32_t chunk0, n_chunks, C, F;      // first chunk of the wave, chunks per instance, chunk length, stream length (samples)
+    uint32_t chunk0, n_chunks, C, F;      // first chunk of the wave, chunks per instance, chunk length, stream length (samples; < 2^30, launcher)
     int lane;
+    // loop-invariant part of the stream index instruction k of a stage-in / stage-out moves: chunk_k * C + 4 * piece_k (the super-block
+    // offset `so` is the only thing that changes from step to step: one 32-bit add and one clamp per DMA instruction)
+    int base[8];
 };
 
 // stage-in of the super-block whose first sample sits `so` samples from each chunk's begin (negative during the warm-up)
 template <int SB>
-__device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, int so) {
+__device__ __forceinline__ void eq_tile_bases(EqTileCtx& c) {
     typedef EqTileGeo<SB> G;
     const int s = c.lane % G::S;
 #pragma unroll
     for (int k = 0; k < G::N_INSTR; ++k) {
         const int cj = G::ROWS * k + c.lane / G::S;
         const int pce = s ^ G::sw(cj);                                // the piece that belongs in slot s of row cj
-        long long idx = (long long)(c.chunk0 + (uint32_t)cj) * (long long)c.C + (long long)so + 4 * pce;
-        idx = idx < 0 ? 0 : idx;                                      // before the stream (chunk 0's warm-up) / past it (lanes beyond the last
-        idx = idx > (long long)c.F - 4 ? (long long)c.F - 4 : idx;    // chunk): never used, keep the address legal
-        __builtin_amdgcn_global_load_lds((mx_gfp1)(c.in + idx), (mx_lfp3)(buf + k * 256), 16, 0, 0);
+        const long long b = (long long)(c.chunk0 + (uint32_t)cj) * (long long)c.C + 4 * pce;
+        c.base[k] = (int)(b > 0x3fffffffLL ? 0x3fffffffLL : b);       // lanes beyond the stream: any legal value (clamped again below, never used)
+    }
+}
+template <int SB>
+__device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, int so) {
+    typedef EqTileGeo<SB> G;
+#pragma unroll
+    for (int k = 0; k < G::N_INSTR; ++k) {
+        // before the stream (chunk 0's warm-up) / past it (lanes beyond the last chunk): never used, keep the address legal
+        const int idx = min(max(c.base[k] + so, 0), (int)c.F - 4);    // one v_med3_i32
+        __builtin_amdgcn_global_load_lds((mx_gfp1)(c.in + (size_t)(uint32_t)idx), (mx_lfp3)(buf + k * 256), 16, 0, 0);
     }
 }
 
@@ -588,15 +599,12 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
 template <int SB, bool STEREO>
 __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* buf, int so) {
     typedef EqTileGeo<SB> G;
-    const int s = c.lane % G::S;
 #pragma unroll
     for (int k = 0; k < G::N_INSTR; ++k) {
         const f4v o = *reinterpret_cast<const f4v*>(buf + k * 256 + c.lane * 4);
-        const int cj = G::ROWS * k + c.lane / G::S;
-        const uint32_t chunk = c.chunk0 + (uint32_t)cj;
-        const int pce = s ^ G::sw(cj);
-        const long long idx = (long long)chunk * (long long)c.C + (long long)so + 4 * pce;
-        if (chunk < c.n_chunks && idx + 4 <= (long long)c.F) {
+        const uint32_t chunk = c.chunk0 + (uint32_t)(G::ROWS * k + c.lane / G::S);
+        const int idx = c.base[k] + so;                               // so >= 0 here (stage-out only happens in the chunk proper)
+        if (chunk < c.n_chunks && idx + 4 <= (int)c.F) {
             if (STEREO) {
                 f4v a = {o[0], o[0], o[1], o[1]}, b = {o[2], o[2], o[3], o[3]};   // stereo_panner.rs:35-38
                 __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(c.out + 2 * idx));
@@ -620,6 +628,7 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
     c.in = d.in; c.out = d.out;
     c.chunk0 = (blockIdx.x % waves_per_inst) * 64u; c.n_chunks = plan.n_chunks; c.C = plan.chunk; c.F = (uint32_t)r.frames;
     c.lane = threadIdx.x;
+    eq_tile_bases<SB>(c);
     const uint32_t j = c.chunk0 + threadIdx.x;
     const bool active = j < plan.n_chunks;
     const long long begin = (long long)j * c.C;
@@ -649,6 +658,7 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
     const bool nice = env_params_nice(d.env);
     EqChunkRec* rec = recs + (size_t)inst * plan.n_chunks + (active ? j : 0);
 
+    int next_tick = 0;   // chunk-relative index of the next tick's first sample (chunks are whole ticks, ticks whole super-blocks)
     eq_tile_issue<SB>(c, eq_tiles, -(int)plan.warm);
     for (int g = 0; g < total; ++g) {
         float* buf = eq_tiles + (g & 1) * EQ_TILE;
@@ -668,7 +678,8 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
             }
         }
         if constexpr (KMODE == EQM_AMP_ENV) {
-            if ((size_t)so % r.fpc == 0) {   // a new tick (wave-uniform: chunks are whole ticks): its Envelope state, per lane
+            if (so == next_tick) {   // a new tick (wave-uniform: chunks are whole ticks): its Envelope state, per lane
+                next_tick += (int)r.fpc;
                 const size_t tk = ((size_t)begin + (size_t)so) / r.fpc;
                 cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
                 const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so;
@@ -723,54 +734,53 @@ __device__ __forceinline__ float eq_out_of(const Dual& s, double h0, double g_lo
     return (float)(l * g_lo + mid * g_mid + h * g_hi);
 }
 
-// One wave per instance.  First every boundary is checked in parallel against the SPECULATIVE end state of the chunk before
-// it: if all of them match, induction from chunk 0 (which started from the carried state) proves the whole stream.  Otherwise
-// lane 0 walks on from the first mismatch with the proven state in hand.
-__global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
-                                                         const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats) {
-    const uint32_t inst = blockIdx.x;
-    const int lane = threadIdx.x;
-    const EqDesc& d = descs[inst];
-    const EqChunkRec* rc = recs + (size_t)inst * plan.n_chunks;
+// ---- the walk: chunks [j0, j_limit) in order with the TRUE state E at the start of chunk j0 in hand ----
+// A chunk whose recorded start equals the true state is exact as the speculative lane left it (E moves to its recorded end); any
+// other is re-run from the true state beside the speculative trajectory: output samples whose f32 differs are rewritten, and the
+// two meet again as soon as the trajectories coalesce.  On return E is the true state at the start of chunk j_end; j_end = j_limit
+// unless the walk stopped in front of an ABSORBING state (all eight poles NaN: no later chunk can ever match -- the caller fills the
+// rest of the stream with the whole wave instead of walking it).  Chunks below `force_until` are rewritten sample for sample
+// whatever is recorded about them (a fallback after an island that started from a wrong assumption: memory there may hold that
+// island's rewrites, not the speculative outputs).
+struct EqWalk { uint32_t j_end; unsigned long long repaired; };
+// four samples from index i of a stream of n: one 16-byte load where all four exist, the ragged tail element by element
+__device__ __forceinline__ f4v eq_ld4(const float* __restrict__ p, size_t i, size_t n) {
+    if (i + 4 <= n) return *reinterpret_cast<const f4v*>(p + i);
+    f4v v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) v[0] = p[i];
+    if (i + 1 < n) v[1] = p[i + 1];
+    if (i + 2 < n) v[2] = p[i + 2];
+    return v;
+}
+__device__ __forceinline__ bool eq_all_nan(const double (&E)[8]) {
+    bool a = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a = a && (E[k] != E[k]);
+    return a;
+}
+__device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r, const EqSpecPlan& plan, const EqChunkRec* __restrict__ rc, uint32_t inst,
+                                                 uint32_t j0, uint32_t j_limit, uint32_t force_until, double (&E)[8]) {
     const size_t C = plan.chunk;
-    uint32_t first_fail = plan.n_chunks;
-    for (uint32_t j0 = 1; j0 < plan.n_chunks; j0 += 64) {
-        const uint32_t j = j0 + (uint32_t)lane;
-        bool ok = true;
-        if (j < plan.n_chunks) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ok = ok && __double_as_longlong(rc[j].start[k]) == __double_as_longlong(rc[j - 1].end[k]);
-        }
-        const uint64_t bad = __ballot(!ok);
-        if (bad) { first_fail = j0 + (uint32_t)__builtin_ctzll(bad); break; }
-    }
-    if (lane != 0) return;
-    double E[8];                                   // proven state at the end of the chunks walked so far
-    unsigned long long repaired = 0;
-    if (first_fail == plan.n_chunks) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) E[k] = rc[plan.n_chunks - 1].end[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) E[k] = rc[first_fail - 1].end[k];
-    }
-    for (uint32_t j = first_fail; j < plan.n_chunks; ++j) {
+    EqWalk w{j_limit, 0ull};
+    for (uint32_t j = j0; j < j_limit; ++j) {
         const EqChunkRec& R = rc[j];
-        if (same8(E, R.start)) {                   // the speculative chunk started from the true state: everything it wrote is exact
+        const bool force = j < force_until;
+        if (!force && same8(E, R.start)) {          // the speculative chunk started from the true state: everything it wrote is exact
 #pragma unroll
             for (int k = 0; k < 8; ++k) E[k] = R.end[k];
             continue;
         }
-        ++repaired;
+        if (eq_all_nan(E)) { w.j_end = j; return w; }
+        ++w.repaired;
         const size_t begin = (size_t)j * C;
         const size_t len = r.frames - begin < C ? r.frames - begin : C;
-        Dual A, B;                                 // A: from the proven state (the sequential order); B: the trajectory the chunk's lane ran
+        Dual A, B;                                 // A: from the true state (the sequential order); B: the trajectory the chunk's lane ran
         dual_load(A, E); dual_load(B, R.start);
         double h0 = (double)d.in[begin - 3], h1 = (double)d.in[begin - 2], h2 = (double)d.in[begin - 1];
-        if (R.xmin == R.xmax) {
+        if (R.xmin == R.xmax && !force) {
             // constant input over the whole chunk (digital silence, DC): if both trajectories already stand still under it, the
             // chunk's f32 outputs are a function of (state, delay-line value) only -- compare them for the four delay-line values
-            // the chunk sees; equal => what the lane wrote is the sequential order's, and the proven state stays where it is
+            // the chunk sees; equal => what the lane wrote is the sequential order's, and the true state stays where it is
             const double xc = (double)__uint_as_float(R.xmin);
             if (dual_stuck(A, r.lo_f, r.hi_f, xc) && dual_stuck(B, r.lo_f, r.hi_f, xc)) {
                 bool same = true;
@@ -787,17 +797,33 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
         em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
         bool coalesced = false, stuckA = false, stuckB = false;
         uint32_t prev_bits = 0; bool have_prev = false;
-        for (size_t i = 0; i < len; ++i) {
-            const float xf = d.in[begin + i];
-            const double x = (double)xf;
-            const bool rep = have_prev && __float_as_uint(xf) == prev_bits;     // same input as the previous sample
-            prev_bits = __float_as_uint(xf); have_prev = true;
-            if (!(rep && stuckA)) { const Dual o = A; pump(r.lo_f, A.lo, x); pump(r.hi_f, A.hi, x); stuckA = rep && dual_same(o, A); }
-            if (!(rep && stuckB)) { const Dual o = B; pump(r.lo_f, B.lo, x); pump(r.hi_f, B.hi, x); stuckB = rep && dual_same(o, B); }
-            const float ya = eq_out_of(A, h0, d.gain_lo, d.gain_mid, d.gain_hi), yb = eq_out_of(B, h0, d.gain_lo, d.gain_mid, d.gain_hi);
-            h0 = h1; h1 = h2; h2 = x;
-            if (__float_as_uint(ya) != __float_as_uint(yb)) { em.seek(begin + i); em.emit(begin + i, ya); }
-            if (dual_same(A, B)) { coalesced = true; break; }                   // from here on the lane's run IS the sequential order
+        // the input travels sixteen samples at a time, the next sixteen requested before these are walked: a load per sample would put a
+        // memory round trip (hundreds of ns) into every step of a walk that is already one dependent chain (chunks start on 64-byte lines)
+        const float* xin = d.in + begin;
+        f4v xa[4], xb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = eq_ld4(xin, (size_t)(4 * q), len);
+        for (size_t i0 = 0; i0 < len && !coalesced; i0 += 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xb[q] = eq_ld4(xin, i0 + 16 + (size_t)(4 * q), len);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t i = i0 + (size_t)e;
+                if (i < len && !coalesced) {
+                    const float xf = xa[e >> 2][e & 3];
+                    const double x = (double)xf;
+                    const bool rep = have_prev && __float_as_uint(xf) == prev_bits;     // same input as the previous sample
+                    prev_bits = __float_as_uint(xf); have_prev = true;
+                    if (!(rep && stuckA)) { const Dual o = A; pump(r.lo_f, A.lo, x); pump(r.hi_f, A.hi, x); stuckA = rep && dual_same(o, A); }
+                    if (!(rep && stuckB)) { const Dual o = B; pump(r.lo_f, B.lo, x); pump(r.hi_f, B.hi, x); stuckB = rep && dual_same(o, B); }
+                    const float ya = eq_out_of(A, h0, d.gain_lo, d.gain_mid, d.gain_hi), yb = eq_out_of(B, h0, d.gain_lo, d.gain_mid, d.gain_hi);
+                    h0 = h1; h1 = h2; h2 = x;
+                    if (force || __float_as_uint(ya) != __float_as_uint(yb)) { em.seek(begin + i); em.emit(begin + i, ya); }
+                    if (!force && dual_same(A, B)) coalesced = true;            // from here on the lane's run IS the sequential order
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xa[q] = xb[q];
         }
         if (coalesced) {
 #pragma unroll
@@ -807,14 +833,149 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
             for (int k = 0; k < 4; ++k) { E[k] = A.lo[k]; E[4 + k] = A.hi[k]; }
         }
     }
+    return w;
+}
+// the rest of the stream from chunk j on under an absorbing (all-NaN) state, all 64 lanes: every output is the EQ's f32 for (that
+// state pumped once with the sample's input, the sample's delay-line value) through the folded epilogue, sample by sample independently
+__device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, const EqSpecPlan& plan, uint32_t inst, uint32_t j, const double (&E)[8], int lane) {
+    const size_t begin = (size_t)j * plan.chunk;
+    Dual A0; dual_load(A0, E);
+    const size_t unit = r.fpc ? r.fpc : 1024;                      // a lane takes whole ticks: its Envelope cursor starts at a tick's first sample
+    const size_t n_units = (r.frames - begin + unit - 1) / unit;   // begin is a multiple of a tick when an Envelope is folded in (eq_plan_spec)
+    for (size_t u = (size_t)lane; u < n_units; u += 64) {
+        const size_t a = begin + u * unit, b = a + unit < r.frames ? a + unit : r.frames;
+        EqSeqEmit em;
+        em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
+        em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
+        em.seek(a);
+        double h0 = (double)d.in[a - 3], h1 = (double)d.in[a - 2], h2 = (double)d.in[a - 1];
+        for (size_t i0 = a; i0 < b; i0 += 16) {                                 // sixteen samples per request
+            f4v xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = eq_ld4(d.in, i0 + (size_t)(4 * q), b);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t i = i0 + (size_t)e;
+                if (i < b) {
+                    const double x = (double)xv[e >> 2][e & 3];
+                    Dual A = A0;
+                    pump(r.lo_f, A.lo, x); pump(r.hi_f, A.hi, x);
+                    em.emit(i, eq_out_of(A, h0, d.gain_lo, d.gain_mid, d.gain_hi));
+                    h0 = h1; h1 = h2; h2 = x;
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(u >> 32), src, 64);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// One wave per instance.  First every boundary is checked in parallel against the SPECULATIVE end state of the chunk before
+// it: if all of them match, induction from chunk 0 (which started from the carried state) proves the whole stream -- the only case
+// on live signals.  Where a boundary fails (the input was exactly CONSTANT for long: digital silence or DC after a signal -- the
+// poles stall a few ulps from the fixed point, on the side they came from, and trajectories stalled at different values never meet;
+// or a NaN) the stream is walked on from there with the true state in hand (eq_repair_walk).
+// ISLANDS.  Programme that falls silent and comes back -- a desk's normal material -- fails a few boundaries after every onset of
+// silence, seconds apart.  Each run of failures starts at a HEAD: a failing boundary whose predecessor matched.  If the chunk before a
+// head is exact, the true state at the head is that chunk's recorded end -- which every island can ASSUME and walk at once, one LANE per
+// head (up to 64 per round), each up to the next head.  The assumptions are then checked in stream order: island i held if island
+// i - 1 ended on the recorded end of its last chunk.  Where one did not, everything from there to the end of the round is walked again
+// in order from the true state, rewriting every sample (memory there may hold a wrong island's rewrites).  An absorbing all-NaN state
+// is never walked: the rest of the stream is filled by the whole wave (eq_nan_fill).
+__global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+                                                         const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats) {
+    const uint32_t inst = blockIdx.x;
+    const int lane = threadIdx.x;
+    const EqDesc& d = descs[inst];
+    const EqChunkRec* rc = recs + (size_t)inst * plan.n_chunks;
+    const uint32_t NC = plan.n_chunks;
+    __shared__ uint32_t heads[65];
+    auto fails = [&](uint32_t j) {                 // boundary j (1 <= j < NC): chunk j's recorded start differs from chunk j - 1's recorded end
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ok = ok && __double_as_longlong(rc[j].start[k]) == __double_as_longlong(rc[j - 1].end[k]);
+        return !ok;
+    };
+    double E[8];                                   // wave-uniform.  have_E: the true state at the start of chunk `pos`, and NOT chunk pos - 1's recorded end
+#pragma unroll
+    for (int k = 0; k < 8; ++k) E[k] = 0.0;
+    bool have_E = false;
+    uint32_t pos = 1, force_until = 0;             // every chunk before `pos` is proven
+    unsigned long long repaired = 0;
+    while (pos < NC) {
+        if (have_E) {
+            if (eq_all_nan(E)) { repaired += NC - pos; eq_nan_fill(d, r, plan, inst, pos, E, lane); pos = NC; break; }
+            // in order from the true state, by one lane: to the end of the round that went wrong (rewriting everything), else one chunk at a
+            // time -- as soon as a chunk ends on its recorded end the islands behind it are searched (and walked side by side) again
+            const uint32_t lim = force_until > pos ? force_until : pos + 1;
+            EqWalk w{lim, 0ull};
+            if (lane == 0) w = eq_repair_walk(d, r, plan, rc, inst, pos, lim, force_until, E);
+            w.j_end = (uint32_t)__shfl((int)w.j_end, 0, 64);
+            repaired += (unsigned long long)(uint32_t)__shfl((int)(uint32_t)w.repaired, 0, 64);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) E[k] = shfl_f64(E[k], 0);
+            pos = w.j_end;
+            have_E = pos >= NC || !same8(E, rc[pos - 1].end);   // at the end of the stream E stays the carried state
+            if (pos >= NC) { have_E = true; break; }
+            continue;
+        }
+        // the next (up to 64) heads at or after pos
+        uint32_t n_heads = 0, scan_end = NC;
+        for (uint32_t j0 = pos; j0 < NC; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const bool head = j < NC && fails(j) && (j == pos || !fails(j - 1));
+            uint64_t m = __ballot(head);
+            while (m && n_heads < 64) { const int b = __builtin_ctzll(m); if (lane == 0) heads[n_heads] = j0 + (uint32_t)b; ++n_heads; m &= m - 1; }
+            if (m) { scan_end = j0 + (uint32_t)__builtin_ctzll(m); break; }   // a 65th head: this round ends in front of it
+        }
+        if (n_heads == 0) { pos = NC; break; }     // every boundary from pos on matches: proven to the end
+        if (lane == 0) heads[n_heads] = scan_end;
+        __syncthreads();
+        // one lane per island, all at once, each from its predecessor chunk's recorded end, each up to the next head
+        double El[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) El[k] = 0.0;
+        EqWalk w{0u, 0ull};
+        bool in_sync = true;
+        if ((uint32_t)lane < n_heads) {
+            const uint32_t h = heads[lane], lim = heads[lane + 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) El[k] = rc[h - 1].end[k];
+            w = eq_repair_walk(d, r, plan, rc, inst, h, lim, 0u, El);
+            in_sync = w.j_end == lim && same8(El, rc[lim - 1].end);
+        }
+        // the assumptions, in stream order
+        uint32_t i = 0;
+        bool apart = false;
+        for (; i < n_heads; ++i) {
+            repaired += (unsigned long long)(uint32_t)__shfl((int)(uint32_t)w.repaired, (int)i, 64);
+            if (!__shfl((int)in_sync, (int)i, 64)) { apart = true; break; }
+        }
+        __syncthreads();                           // heads[] is rewritten by the next round
+        if (!apart) { pos = scan_end; continue; }
+        // island i ended apart, at chunk j_end with the true state in its lane: go on from there in order
+        pos = (uint32_t)__shfl((int)w.j_end, (int)i, 64);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) E[k] = shfl_f64(El[k], (int)i);
+        have_E = true;
+        force_until = i + 1 < n_heads ? scan_end : pos;   // the islands behind it in this round started from an assumption that did not hold
+    }
+    if (lane != 0) return;
     // the carried state (eq_three.rs:17-22): poles after the last sample, delay line = the last three inputs
     EqState st = states[inst];
+    if (!have_E) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) E[k] = rc[NC - 1].end[k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { st.lo[k] = E[k]; st.hi[k] = E[4 + k]; }
     const size_t F = r.frames;
     st.history[0] = (double)d.in[F - 3]; st.history[1] = (double)d.in[F - 2]; st.history[2] = (double)d.in[F - 1];   // F >= 2 warm-ups >= 3 samples
     states[inst] = st;
-    if (stats) { atomicAdd(&stats[0], (unsigned long long)plan.n_chunks); if (repaired) atomicAdd(&stats[1], repaired); }
+    if (stats) { atomicAdd(&stats[0], (unsigned long long)NC); if (repaired) atomicAdd(&stats[1], repaired); }
 }
 
 // warm-up length: the 4-pole cascade's response to a unit difference k samples back is at most C(k+3,3) p^k (p = 1 - f); W is
@@ -901,7 +1062,7 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     const int um = uniform_mode;
     const int sb = env_int("MX_EQ_SPEC_SB", 16) == 32 ? 32 : 16;   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
     const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
-                       r.frames < (1ull << 31) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
+                       r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
     if (tiled) {
         const size_t lds = 2 * 64 * (size_t)sb * sizeof(float);
 #define MX_GT(M, S) { if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \

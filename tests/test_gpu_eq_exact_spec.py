@@ -143,6 +143,50 @@ def test_spec_eq_nan_and_infinity_poison_the_poles_exactly_like_the_sequential_f
         assert np.isnan(got[-1])
 
 
+@pytest.mark.parametrize("chunks", ["0", "96", "400"])
+def test_spec_eq_programme_with_many_silences_islands_repaired_side_by_side(chunks, monkeypatch):
+    """Programme that falls silent and comes back, again and again (what a desk's strips carry): every onset of digital silence fails the
+    boundaries of the chunks behind it -- an island; the repair wave walks the islands of a strip side by side, one lane each, and checks
+    in stream order that each started from what it assumed.  Four shapes: gaps seconds apart (islands far from each other), gaps so
+    close that an island is still apart from the speculative run when the next begins (the in-order fallback that rewrites everything),
+    one long silence, and silences broken by single-sample clicks.  State carried over two runs; also with a folded Envelope + Amplifier."""
+    if chunks != "0":
+        monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", chunks)
+    SR, SPT = 48000, 800
+    n, T, runs = 8, 400, 2
+    gl = _gains(n, 93)
+    L = runs * T * SPT
+    sig = []
+    for k in range(n):
+        x = synth.noise(900 + k, L).copy()
+        kind = k % 4
+        if kind == 0:                                   # 0.9 s of programme, 0.6 s of silence
+            for a in range(20000, L, 72000):
+                x[a:a + 28800] = 0.0
+        elif kind == 1:                                 # short bursts between silences: 2 400 samples of signal, 9 000 of silence
+            for a in range(5000, L, 11400):
+                x[a:a + 9000] = 0.0
+        elif kind == 2:                                 # one long silence in the middle
+            x[L // 5: 4 * L // 5] = 0.0
+        else:                                           # silences with a click inside
+            for a in range(10000, L, 50000):
+                x[a:a + 30000] = 0.0
+                x[a + 15000] = np.float32(0.5)
+        sig.append(np.ascontiguousarray(x, dtype=np.float32))
+    ws, srcs, eqs, g = _eq_graph(SR, gl, T)
+    states = [oracle.eq_three_new(SR) for _ in range(n)]
+    for run in range(runs):
+        sl = slice(run * T * SPT, (run + 1) * T * SPT)
+        for k, s in enumerate(srcs):
+            g.write_source(s, sig[k][sl], T)
+        g.run_ticks(run * T, T)
+        for k, e in enumerate(eqs):
+            want = oracle.eq_three_run(states[k], gl[k], sig[k][sl])
+            assert_bit_exact(g.read_output(e, 0, T, False), want, f"instance {k} (shape {k % 4}), run {run}, chunks {chunks}")
+    ran, repaired = g.eq_spec_stats()
+    assert repaired > 0, "no chunk needed a repair: the islands were not exercised"
+
+
 @pytest.mark.parametrize("rate", RATES)
 @pytest.mark.parametrize("chunks", ["0", "24"])
 def test_spec_eq_chunks_shorter_than_the_warm_up(rate, chunks, monkeypatch):
