@@ -540,6 +540,49 @@ def pmc_traffic(kernel, args, world, toggling):
     return rec["bytes_per_launch"][kernel], "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
 
 
+def scaling_probe(torch, stream, local_rank, abi, Workspace, synth, strips, T, SR, toggling, flags, t1_ms):
+    """What ONE rank of an N-GPU job computes per step, measured on this GPU: its strip share (strips / N) for T ticks (strong scaling as the
+    driver runs it) and for T x N ticks (--scale-ticks: the chunk length per lane of the speculative EqThree stays what it is at N = 1).  The
+    exchange is not run here (one GPU): its time is modelled as bytes received per rank and step / 300 GB/s of xGMI and assumed hidden behind
+    the next step's compute when shorter (mx_exchange runs on its own stream).  N > 1 is a MODEL until a multi-GPU node runs it."""
+    spt = SR // 60
+    out = {"fixed_ticks": {}, "scale_ticks": {}}
+    for policy, mult in (("fixed_ticks", lambda n: 1), ("scale_ticks", lambda n: n)):
+        for n in (2, 4, 8):
+            if strips % n:
+                continue
+            Tn, sn = T * mult(n), strips // n
+            ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, sn, 0, SR, want_trigs=True)
+            g = ws.build(max_ticks_per_run=Tn, flags=flags, device=local_rank, stream=stream.cuda_stream)
+            gen = torch.Generator(device="cuda"); gen.manual_seed(0x4D58 + n)
+            noise = (torch.rand(Tn * spt, generator=gen, device="cuda", dtype=torch.float32) * 2.0 - 1.0).contiguous()
+            for s_ in srcs:
+                g.bind_source_device(s_, noise.data_ptr())             # every strip of the probe reads the same device-resident noise
+            k = 3
+            evs = [gate_events(abi, trigs, 0, i * Tn, Tn) if toggling else None for i in range(2 + k)]
+            for i in range(2 + k):
+                if i == 2:
+                    g.sync(); t0 = time.perf_counter()
+                if evs[i] is not None:
+                    g.schedule_params_batch(evs[i][0], evs[i][1])
+                g.run_ticks(i * Tn, Tn)
+            g.sync()
+            ms = (time.perf_counter() - t0) / k * 1e3
+            g.close(); del noise
+            bus = 2 * 2 * spt * Tn * 4                                   # Master + Cue, interleaved stereo f32, per step
+            recv = 2 * (n - 1) * bus // n if (n >= 4 and Tn % n == 0) else (n - 1) * bus
+            ex_ms = recv / 300e9 * 1e3
+            step_ms = max(ms, ex_ms)
+            out[policy][str(n)] = {"strips_per_rank": sn, "ticks_per_step": Tn, "rank_compute_ms_per_step": round(ms, 4),
+                                   "exchange_bytes_received_per_rank": recv, "exchange_ms_at_300GBps": round(ex_ms, 4),
+                                   "predicted_job_value": strips * Tn / (step_ms * 1e-3),
+                                   "predicted_speedup_vs_1_gpu": round((strips * Tn / step_ms) / (strips * T / t1_ms), 2)}
+    out["what"] = ("one GPU playing one rank: rank_compute_ms is measured here, the exchange is modelled (bytes / 300 GB/s, hidden when shorter than the compute); "
+                   "N > 1 is a model until a multi-GPU node runs the job")
+    out["one_gpu_ms_per_step"] = round(t1_ms, 4)
+    return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -569,6 +612,9 @@ def main():
                     help="N > 1 bus exchange (mx_exchange_*): ordered reduce-scatter + all-gather over time slices (auto: N >= 4), one all-gather of "
                          "the whole partial buses (auto: N < 4), or ncclAllReduce (NOT the sum order of a reference graph: non-parity)")
     ap.add_argument("--force-combine", action="store_true", help="run the N > 1 exchange path at N = 1 (single-rank RCCL group)")
+    ap.add_argument("--scale-ticks", action="store_true", help="N > 1: T = --ticks-per-step x N ticks per step, so that a rank's chunk length (and with it the share of "
+                    "warm-up samples its speculative EqThree runs) stays what it is on one GPU; the model line shows both policies")
+    ap.add_argument("--no-scaling-probe", action="store_true", help="skip the one-GPU measurement of what a rank of a 2 / 4 / 8-GPU job computes per step (scaling_model)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
     ap.add_argument("--repeats", type=int, default=4, help="further repetitions of the K timed steps after the headline region (spread of the clock)")
     ap.add_argument("--no-t-sweep", action="store_true", help="skip the shorter-submission legs (T = 64 and 1024 ticks, SURVEY 8d)")
@@ -604,7 +650,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    T, SR = args.ticks_per_step, args.sample_rate
+    T, SR = args.ticks_per_step * (world if args.scale_ticks else 1), args.sample_rate
     spt = SR // 60
     first, local_strips = shard.strip_range(rank, world, args.strips)
     toggling = not args.hold_gates
@@ -772,6 +818,32 @@ def main():
                 dts = time.perf_counter() - t0
                 t_sweep[str(Ts)] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub}
                 tick0 += (n_sub + 3) * Ts
+            # T = 64 again on a graph built with MX_FLAG_OVERLAP_TAIL: the Mixer bank of submission k on a second stream beside submission
+            # k + 1's EqThree group.  At T = 2048 that loses (the EqThree launch is exactly one round of three waves per SIMD and Mixer waves
+            # push part of it into a second round); a 64-tick submission is ONE EqThree wave per SIMD running a dependent f64 chain, with
+            # issue slots and the whole memory system idle beside it -- there the Mixer rides along.
+            if 64 < T and not overlap:
+                Ts, n_sub = 64, 60
+                g2 = ws.build(max_ticks_per_run=Ts, flags=flags | abi.FLAG_OVERLAP_TAIL, device=local_rank, stream=stream.cuda_stream)
+                for j, sn in enumerate(srcs):
+                    g2.write_source(sn, synth.noise(first + j, Ts * spt), Ts)
+                evs = [gate_events(abi, trigs, first, tick0 + i * Ts, Ts) if toggling else None for i in range(n_sub + 3)]
+
+                def sub2(i):
+                    if evs[i] is not None:
+                        g2.schedule_params_batch(evs[i][0], evs[i][1])
+                    g2.run_ticks(tick0 + i * Ts, Ts)
+                for i in range(3):
+                    sub2(i)
+                g2.sync()
+                t0 = time.perf_counter()
+                for i in range(3, n_sub + 3):
+                    sub2(i)
+                g2.sync()
+                dts = time.perf_counter() - t0
+                t_sweep["64_overlap_tail"] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub,
+                                              "flag": "MX_FLAG_OVERLAP_TAIL (the last Mixer bank on a second stream beside the next submission's EqThree group; bit-identical results)"}
+                g2.close()
 
     # Realistic material and the repair pass's worst case, on the same graph (LAST: the poisoned strip's state stays NaN for ever).
     # The headline's sources are seeded noise, on which every chunk boundary of the speculative EqThree proves itself; a desk also carries
@@ -827,6 +899,11 @@ def main():
             material["one_strip_poisoned_by_a_nan"] = {"ms_per_step": round(dt_p / n_m * 1e3, 4), "value": args.strips * T * n_m / dt_p, "unit": "channel-ticks/s",
                                                        "eq_spec": {"chunks_run": ran3 - ran2, "chunks_repaired": rep3 - rep2},
                                                        "note": "on top of the daw material; the poisoned strip's whole stream is re-emitted by its repair wave (parallel fill) every step"}
+
+    scaling = None
+    if not use_dist and not args.no_scaling_probe and not args.no_fuse and args.strips % 8 == 0:
+        with torch.cuda.stream(stream):
+            scaling = scaling_probe(torch, stream, local_rank, abi, Workspace, synth, args.strips, T, SR, toggling, flags & ~abi.FLAG_OVERLAP_TAIL, dt / args.steps * 1e3)
 
     video = None
     if args.video_frames > 0:
@@ -905,7 +982,7 @@ def main():
                        "eq_mode": "time-parallel scan (<= 1 ULP, MX_FLAG_EQ_FAST)" if args.eq_fast else "exact order (default): speculative time-parallel kernel, verified bit-exact",
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
                        "overlap": "MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k runs on a second stream beside step k + 1's EqThree group (strip ports double-buffered)" if overlap else "off",
-                       "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else ""),
+                       "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else "") + (", ticks per step scaled with N (--scale-ticks)" if args.scale_ticks else ""),
                        "rccl_ranks": ex.world if ex is not None else 0},
             "realtime_channels_equiv": value / 60.0,
             "graph_hbm_frac_moved_bytes": round(moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
@@ -919,6 +996,7 @@ def main():
             "realtime": realtime,
             "t_sweep": t_sweep,
             "material": material,
+            "scaling_model": scaling,
             "north_star_realtime": north,
             "video": video,
             "fir_resample": fir,
