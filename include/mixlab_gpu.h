@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MX_ABI_VERSION 1u
+#define MX_ABI_VERSION 2u   /* 2: mx_exchange_*, mx_monitor_tick.dropped, mx_monitor_params_ex, packed RGB pixel formats */
 
 /* ---- status codes (0 ok, <0 error; cf. MIXLAB_IOCTX_ERROR / MIXLAB_IOCTX_PANIC) ---- */
 enum {
@@ -82,6 +82,12 @@ typedef struct { uint32_t gate_open; } mx_trigger_params;                       
 typedef struct { int32_t a, b; /* -1 = None */ double fader; } mx_video_mixer_params;                  /* VideoMixerParams :405-410 */
 typedef struct { int32_t use_matrix; int32_t matrix_q12[12]; } mx_video_to_rgba_params;                /* build-specified, DESIGN.md "Colour" */
 typedef struct { uint32_t width, height; } mx_monitor_params;   /* the encoder's picture: 560 x 350 (monitor.rs:21-22), 1120 x 700 (stream_output.rs:23-24); even */
+/* The same with the reference's back-pressure (opt-in; params_len selects the form).  Monitor / StreamOutput hand every tick to their codec
+ * thread with try_send on a channel of TWO and DROP the tick when it is full (monitor.rs:163-177, stream_output.rs:316-320).  queue_depth > 0:
+ * the node holds at most that many ticks the consumer has not taken (mx_graph_monitor_consume); a tick that finds the queue full is dropped --
+ * no picture is scaled or kept, mx_monitor_tick.dropped = 1 -- exactly what the codec thread would never see.  queue_depth = 0 (and the short
+ * form): every tick of a submission is kept (one scaled frame per tick stays on the device until the next run: max_ticks_per_run x frame bytes). */
+typedef struct { uint32_t width, height, queue_depth, _pad; } mx_monitor_params_ex;
 /* Build-specified audio extras (DESIGN.md "FIR and resampler").  Both are variable-length blobs: the header below
  * followed by the f64 coefficients.  Arithmetic: f32 widened to f64, accumulated in f64 in ascending tap index with
  * separate multiply and add, rounded once to f32 -- the reference's own convention (mixer.rs:62, amplifier.rs:56). */
@@ -255,7 +261,11 @@ typedef struct {
  * resampled from ITS size to the output's chroma size (DESIGN.md "Scaler" -- parity unpinned, like the scaler itself). */
 typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P = 2,
                MX_PIXFMT_NV12 = 3 /* semi-planar 4:2:0, what hardware decoders deliver: plane 1 = interleaved U,V rows of `width` bytes, no plane 2
-                                     (mx_frame.data[2] is ignored, mx_dframe_planes reports it NULL) */ } mx_pixfmt;
+                                     (mx_frame.data[2] is ignored, mx_dframe_planes reports it NULL) */,
+               /* packed RGB, one plane (data[0]; data[1], data[2] NULL): scaler INPUTS only (a screen capture, an image file).  BUILD-SPECIFIED: the
+                * frame stands for the yuv444p frame of its per-pixel BT.709 limited-range conversion (DESIGN.md "Pixel formats"), which is then
+                * resampled like any 4:4:4 input -- libswscale's own RGB path is unknown here: parity unpinned, like the scaler */
+               MX_PIXFMT_RGB24 = 4 /* R, G, B bytes */, MX_PIXFMT_BGRA = 5 /* B, G, R, A bytes; alpha ignored */ } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer
@@ -427,8 +437,12 @@ int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t
  * encode.rs:342-345; one reference for the caller, still on the device: download it or hand it to a device encoder), frame_ts = ts +
  * tick_offset (monitor.rs:229), dur = its duration hint; else video_present = 0 and *frame = NULL.  The reference DROPS a tick when its
  * codec thread lags (try_send on a channel of two, monitor.rs:163-177); nothing is dropped here. */
-typedef struct { int32_t video_present; int64_t ts_num, ts_den, frame_ts_num, frame_ts_den, dur_num, dur_den; } mx_monitor_tick;
+typedef struct { int32_t video_present; int64_t ts_num, ts_den, frame_ts_num, frame_ts_den, dur_num, dur_den;
+                 int32_t dropped; /* mx_monitor_params_ex.queue_depth > 0: the queue was full, the codec thread never gets this tick (nor its audio) */ int32_t _pad; } mx_monitor_tick;
 int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run, mx_monitor_tick* info, mx_dframe** frame);
+/* queue_depth > 0: the consumer (the codec thread's rx.recv, monitor.rs:226) has taken n_ticks ticks off the node's queue: that many slots are free
+ * for the ticks of the next submissions.  More than are queued empties the queue. */
+int mx_graph_monitor_consume(mx_graph* g, uint32_t node, uint32_t n_ticks);
 /* All kept pictures of ticks [first_tick, first_tick + n_ticks) of the last run in ONE read-back: one gather launch on the device, one
  * D2H copy.  frames[n_ticks * frame_bytes]: slot k holds tick first_tick + k's picture in the layout mx_graph_monitor_layout reports (rows
  * 64-byte aligned: an AVFrame.linesize an encoder takes as is); present[k] = 0 leaves slot k untouched.  A page-locked `frames` avoids

@@ -178,6 +178,7 @@ int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run,
         info->ts_den = info->frame_ts_den = info->dur_den = 1;
         const mx::Node::MonTick& m = g->g->monitor_tick(node, tick_in_run);
         info->ts_num = m.ts.num; info->ts_den = m.ts.den;
+        info->dropped = m.dropped ? 1 : 0;
         if (!m.present) return;
         info->video_present = 1;
         info->frame_ts_num = m.frame_ts.num; info->frame_ts_den = m.frame_ts.den;
@@ -185,6 +186,9 @@ int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run,
         m.frame->retain();
         *frame = H(m.frame.f);
     });
+}
+int mx_graph_monitor_consume(mx_graph* g, uint32_t node, uint32_t n_ticks) {
+    return guard([&] { REQUIRE(g, "NULL argument"); g->g->monitor_consume(node, n_ticks); });
 }
 int mx_graph_read_monitor_audio_i16(mx_graph* g, uint32_t node, int16_t* audio, uint32_t n_ticks) {
     return guard([&] { REQUIRE(g, "NULL argument"); g->g->read_monitor_audio_i16(node, audio, n_ticks); });
@@ -222,14 +226,14 @@ int mx_frame_stager_upload(mx_frame_stager* st, const mx_frame* host, mx_pixfmt 
     return guard([&] {
         REQUIRE(st && host && out, "NULL argument");
         *out = nullptr;
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_NV12, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_BGRA, "unknown pixel format");
         *out = H(st->st.upload(host->width, host->height, (uint8_t)fmt, host->data, host->stride));
     });
 }
 int mx_frame_stager_acquire(mx_frame_stager* st, uint32_t width, uint32_t height, mx_pixfmt fmt, mx_frame* host, uint32_t* ticket) {
     return guard([&] {
         REQUIRE(st && host && ticket, "NULL argument");
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_NV12, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_BGRA, "unknown pixel format");
         *ticket = 0;
         std::memset(host, 0, sizeof *host);
         host->dur_den = 1; host->off_den = 1;

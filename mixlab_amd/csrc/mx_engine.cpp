@@ -52,7 +52,9 @@ static void kind_ports(uint32_t kind, size_t params_len, std::vector<uint8_t>& i
     case MX_KIND_FIR: in = {MX_STEREO}; out = {MX_STEREO}; break;        // blob checked in the constructor
     case MX_KIND_RESAMPLE: in = {MX_STEREO}; out = {MX_STEREO}; break;
     case MX_KIND_VIDEO_TO_RGBA: need(sizeof(mx_video_to_rgba_params), "mx_video_to_rgba_params"); in = {MX_VIDEO}; out = {}; break;
-    case MX_KIND_MONITOR: need(sizeof(mx_monitor_params), "mx_monitor_params"); in = {MX_VIDEO, MX_STEREO}; out = {}; break;   // monitor.rs:99-102
+    case MX_KIND_MONITOR:   // monitor.rs:99-102
+        if (params_len != sizeof(mx_monitor_params_ex)) need(sizeof(mx_monitor_params), "mx_monitor_params (or mx_monitor_params_ex)");
+        in = {MX_VIDEO, MX_STEREO}; out = {}; break;
     default: throw Error(MX_ERR_INVALID, "unknown module kind");
     }
 }
@@ -244,6 +246,10 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
             if (p.width == 0 || p.height == 0 || (p.width & 1) || (p.height & 1) || p.width > 16384 || p.height > 16384)
                 throw Error(MX_ERR_INVALID, "monitor picture must be non-zero, even and at most 16384 a side");
             n.mon_scaler = std::make_shared<Scaler>(p.width, p.height, stream_);
+            if (n.params.size() == sizeof(mx_monitor_params_ex)) { mx_monitor_params_ex px; std::memcpy(&px, n.params.data(), sizeof px); n.mon_depth = px.queue_depth; }
+            // without a queue depth every tick of a submission keeps its scaled picture on the device until the next run
+            const uint64_t kept = (uint64_t)(n.mon_depth ? n.mon_depth : std::max<uint32_t>(1u, o.max_ticks_per_run)) * (((uint64_t)p.width + 63) & ~63ull) * p.height * 3 / 2;
+            if (kept > (64ull << 30)) throw Error(MX_ERR_NOMEM, "a Monitor that keeps every tick of a submission would hold more than 64 GiB of pictures: give it a queue depth (mx_monitor_params_ex) or fewer ticks per run");
         }
         if (n.kind == MX_KIND_VIDEO_MIXER || n.kind == MX_KIND_SOURCE_VIDEO || n.kind == MX_KIND_VIDEO_TO_RGBA || n.kind == MX_KIND_MONITOR) has_video_ = true;
         n.vout.resize(n.out_type.size());
@@ -1184,7 +1190,7 @@ void Graph::adopt_state(Graph& old, const int32_t* old_of_new, size_t n) {
         if (j < 0) continue;
         Node& nn = nodes_[i]; Node& on = old.nodes_[j];
         if (nn.kind == MX_KIND_PLOTTER) nn.plot_count = on.plot_count;          // plotter.rs:37-40
-        if (nn.kind == MX_KIND_MONITOR) { nn.mon_has_epoch = on.mon_has_epoch; nn.mon_epoch = on.mon_epoch; }   // Monitor.epoch (monitor.rs:122)
+        if (nn.kind == MX_KIND_MONITOR) { nn.mon_has_epoch = on.mon_has_epoch; nn.mon_epoch = on.mon_epoch; nn.mon_queued = on.mon_queued; }   // Monitor.epoch (monitor.rs:122)
         if (nn.kind == MX_KIND_VIDEO_MIXER && on.vmixer) {                       // stored frames, scalers, expiry times
             mx_video_mixer_params p; std::memcpy(&p, nn.params.data(), sizeof p);
             nn.vmixer = std::move(on.vmixer);
@@ -1372,6 +1378,12 @@ void Graph::run_video_tick(uint64_t t) {
             const Rational absolute = Rational::make((int64_t)t, (int64_t)sample_rate_);
             if (!n.mon_has_epoch) { n.mon_epoch = absolute; n.mon_has_epoch = true; }       // epoch.get_or_insert
             mt.ts = absolute - n.mon_epoch;                                                  // remove_epoch
+            if (n.mon_depth && n.mon_queued >= n.mon_depth) {                                // try_send on a full channel: the tick is dropped (monitor.rs:163-177)
+                mt.dropped = true;
+                n.mon_ticks.push_back(std::move(mt));
+                break;
+            }
+            if (n.mon_depth) ++n.mon_queued;
             const PortRef pr = n.in_src[0];
             const Node::VOut* vp = pr.node < 0 ? nullptr : &nodes_[pr.node].vout[pr.port];   // Disconnected => None (io.rs:56-57)
             if (vp && vp->frame) {
@@ -1494,6 +1506,12 @@ void Graph::check_source_write(uint32_t node, size_t frames) const {
     if (n.kind != MX_KIND_SOURCE_MONO && n.kind != MX_KIND_SOURCE_STEREO) throw Error(MX_ERR_INVALID, "node is not a SOURCE_*");
     if (n.bound) throw Error(MX_ERR_INVALID, "source is bound to a caller device buffer");
     if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
+}
+
+void Graph::monitor_consume(uint32_t node, uint32_t n_ticks) {
+    if (node >= nodes_.size() || nodes_[node].kind != MX_KIND_MONITOR) throw Error(MX_ERR_INVALID, "node is not a MONITOR");
+    Node& n = nodes_[node];
+    n.mon_queued -= std::min(n.mon_queued, n_ticks);
 }
 
 const Node::MonTick& Graph::monitor_tick(uint32_t node, uint32_t tick_in_run) {

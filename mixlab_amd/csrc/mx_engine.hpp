@@ -66,7 +66,8 @@ struct Node {
     std::vector<PendingRgba> rgba_pending;     // VIDEO_TO_RGBA: chains of the last ticks, not launched yet, oldest first (run_video_tick)
     uint32_t rgba_calls = 0;                   // sink calls that queued a chain in this run
     // MONITOR: what the sink kept of every tick of the last run
-    struct MonTick { bool present = false; FrameRef frame; Rational ts, frame_ts, dur; };
+    struct MonTick { bool present = false, dropped = false; FrameRef frame; Rational ts, frame_ts, dur; };
+    uint32_t mon_depth = 0, mon_queued = 0;    // mx_monitor_params_ex.queue_depth (0 = keep every tick) and the ticks the consumer has not taken yet
     std::vector<MonTick> mon_ticks;
     bool mon_has_epoch = false; Rational mon_epoch;
     std::shared_ptr<Scaler> mon_scaler;
@@ -152,6 +153,7 @@ public:
     void check_video_queue(uint32_t node, uint64_t first_tick) const;   // queue_video_source(node, first_tick, ...) would be accepted
     void check_source_write(uint32_t node, size_t frames) const;        // write_source[_i16](node, ..., frames) would be accepted
     const Node::MonTick& monitor_tick(uint32_t node, uint32_t tick_in_run);
+    void monitor_consume(uint32_t node, uint32_t n_ticks);
     void read_monitor_audio_i16(uint32_t node, int16_t* host, uint32_t n_ticks);
     struct MonitorLayout { uint32_t width, height; size_t frame_bytes, plane_offset[3]; uint32_t stride[3]; };
     MonitorLayout monitor_layout(uint32_t node);

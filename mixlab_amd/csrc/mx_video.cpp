@@ -100,7 +100,7 @@ static void alloc_planes(DFrame* f) {
 }
 
 DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
-    if (fmt > MX_PIXFMT_NV12) throw Error(MX_ERR_INVALID, "unknown pixel format");
+    if (fmt > MX_PIXFMT_BGRA) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
     f->fmt = fmt;
     if (w == 0 || h == 0 || (w & ((1u << f->cw()) - 1u)) || (h & ((1u << f->chs()) - 1u)))
@@ -526,9 +526,24 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
     queue_scale(a, s, in, target, tp);      // leaves with the other scales of this tick as one launch
 }
 
-FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
-    if (in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;   // equal picture settings, encode.rs:342-345
-    in->ensure_pixels(stream_);                                                  // a symbolic frame must exist before it can be resampled
+// a packed RGB input is first turned into the yuv444p frame it stands for (build-specified conversion), into a frame nobody else holds
+FrameRef Scaler::planar_of(const FrameRef& in) {
+    if (!in->packed()) return in;
+    FrameRef out;
+    for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
+    if (!out) {
+        if (rgb_pool_.size() >= 2 * (size_t)video_batch_ticks() + 2) rgb_pool_.erase(rgb_pool_.begin());
+        rgb_pool_.push_back(FrameRef(DFrame::create_unfilled(in->width, in->height, MX_PIXFMT_YUV444P), false));
+        out = rgb_pool_.back();
+    }
+    launch_rgb_to_yuv444(in->data[0], in->stride[0], in->width, in->height, in->bpp(), in->fmt == MX_PIXFMT_BGRA ? 2u : 0u, out->data, out->stride, stream_);
+    return out;
+}
+
+FrameRef Scaler::scale(const FrameRef& in0, bool may_defer) {
+    if (in0->width == out_w_ && in0->height == out_h_ && in0->fmt == MX_PIXFMT_YUV420P) return in0;   // equal picture settings, encode.rs:342-345
+    in0->ensure_pixels(stream_);                                                 // a symbolic frame must exist before it can be resampled
+    const FrameRef in = planar_of(in0);
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);   // encode.rs:347-384
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
     ring_pos_ = (ring_pos_ + 1) % (uint32_t)ring_.size(); frame_ = ring_[ring_pos_];   // not a frame the last 2K - 1 calls wrote: the RGBA chains that read those may be launched AFTER this scale (Graph defers them)
@@ -541,9 +556,10 @@ FrameRef Scaler::scale(const FrameRef& in, bool may_defer) {
     return frame_;
 }
 
-FrameRef Scaler::scale_keep(const FrameRef& in) {
-    if (in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) { in->ensure_pixels(stream_); return in; }
-    in->ensure_pixels(stream_);
+FrameRef Scaler::scale_keep(const FrameRef& in0) {
+    if (in0->width == out_w_ && in0->height == out_h_ && in0->fmt == MX_PIXFMT_YUV420P) { in0->ensure_pixels(stream_); return in0; }
+    in0->ensure_pixels(stream_);
+    const FrameRef in = planar_of(in0);
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);
     FrameRef out;
     for (auto& f : keep_pool_) if (f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }   // only the pool holds it

@@ -121,6 +121,8 @@ void launch_copy_planes(const CopyArgs& a, hipStream_t s);
 struct GatherArgs { const uint4* src[224]; uint4* dst; uint32_t q_per_frame, n; };
 void launch_gather_frames(const GatherArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
+// packed RGB (rgb24: bpp 3, r_off 0; bgra: bpp 4, r_off 2) -> yuv444p planes, BUILD-SPECIFIED BT.709 limited range (DESIGN.md "Pixel formats")
+void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
 
 // ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----
 struct Rational {
@@ -189,14 +191,16 @@ struct DFrame {
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
-    uint32_t cw() const { return fmt == MX_PIXFMT_YUV444P ? 0u : 1u; }    // log2_chroma_w, pixfmt.rs:97-100
+    bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA; }   // one plane of 3 / 4 bytes per pixel: a scaler input only
+    uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : 1u); }
+    uint32_t cw() const { return (fmt == MX_PIXFMT_YUV444P || packed()) ? 0u : 1u; }    // log2_chroma_w, pixfmt.rs:97-100
     uint32_t chs() const { return (fmt == MX_PIXFMT_YUV420P || fmt == MX_PIXFMT_NV12) ? 1u : 0u; }   // log2_chroma_h, pixfmt.rs:102-105
     // nv12: the two chroma "planes" are the even / odd bytes of ONE stored plane (data[1]; data[2] aliases it): samples xstep bytes apart from xoff
     bool semi() const { return fmt == MX_PIXFMT_NV12; }
     uint32_t xstep(int p) const { return (semi() && p) ? 2u : 1u; }
     uint32_t xoff(int p) const { return (semi() && p == 2) ? 1u : 0u; }
-    int stored_planes() const { return semi() ? 2 : 3; }
-    uint32_t stored_row_bytes(int p) const { return (semi() && p == 1) ? width : pw(p); }
+    int stored_planes() const { return packed() ? 1 : (semi() ? 2 : 3); }
+    uint32_t stored_row_bytes(int p) const { return packed() ? width * bpp() : ((semi() && p == 1) ? width : pw(p)); }
     uint8_t* data[3] = {nullptr, nullptr, nullptr};
     uint32_t stride[3] = {0, 0, 0};
     size_t plane_bytes[3] = {0, 0, 0};
@@ -270,6 +274,8 @@ private:
     uint8_t in_fmt_ = MX_PIXFMT_YUV420P;
     FrameRef frame_;                 // cached blank output frame (encode.rs:382) -- the one the latest scale() wrote
     std::vector<FrameRef> keep_pool_; // scale_keep's outputs: blank frames of this context's letterbox geometry, reused once released
+    std::vector<FrameRef> rgb_pool_; // yuv444p frames a packed RGB input is converted into before it is resampled
+    FrameRef planar_of(const FrameRef& in);
     std::vector<FrameRef> ring_;     // 2 * video_batch_ticks() of them, used in turn: the RGBA chains that read the last K may be launched together with the next K scales
     uint32_t ring_pos_ = 0;
     std::shared_ptr<ScaleTables> t_;

@@ -48,18 +48,27 @@ _proto("mx_frame_stager_sync", C.c_int, C.c_void_p)
 
 class MonitorTick(C.Structure):
     _fields_ = [("video_present", C.c_int32), ("ts_num", _I64), ("ts_den", _I64), ("frame_ts_num", _I64), ("frame_ts_den", _I64),
-                ("dur_num", _I64), ("dur_den", _I64)]
+                ("dur_num", _I64), ("dur_den", _I64), ("dropped", C.c_int32), ("_pad", C.c_int32)]
 
 
+_proto("mx_graph_monitor_consume", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
 _proto("mx_graph_read_monitor_tick", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(MonitorTick), C.POINTER(C.c_void_p))
 _proto("mx_graph_read_monitor_audio_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32)
 
 
-def graph_read_monitor_tick(g, node, tick_in_run):
-    """-> (ts, None) or (ts, (DFrame, frame_ts, dur)) with exact Fractions"""
+def graph_monitor_consume(g, node, n_ticks):
+    """queue_depth > 0: the consumer took n_ticks ticks off the node's queue"""
+    check(lib.mx_graph_monitor_consume(g._h, node, n_ticks))
+
+
+def graph_read_monitor_tick(g, node, tick_in_run, with_dropped=False):
+    """-> (ts, None) or (ts, (DFrame, frame_ts, dur)) with exact Fractions; with_dropped: (ts, ..., dropped) -- the tick found the queue full"""
     info, h = MonitorTick(), C.c_void_p()
     check(lib.mx_graph_read_monitor_tick(g._h, node, tick_in_run, C.byref(info), C.byref(h)))
     ts = Fraction(info.ts_num, info.ts_den)
+    if with_dropped:
+        vid = None if not info.video_present else (DFrame(handle=h.value), Fraction(info.frame_ts_num, info.frame_ts_den), Fraction(info.dur_num, info.dur_den))
+        return ts, vid, bool(info.dropped)
     if not info.video_present:
         return ts, None
     return ts, (DFrame(handle=h.value), Fraction(info.frame_ts_num, info.frame_ts_den), Fraction(info.dur_num, info.dur_den))

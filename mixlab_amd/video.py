@@ -121,6 +121,7 @@ def _host_frame(planes, w, h):
 
 
 PIXFMT_YUV420P, PIXFMT_YUV422P, PIXFMT_YUV444P, PIXFMT_NV12 = 0, 1, 2, 3   # mx_pixfmt (nv12: plane 1 = interleaved U,V, no plane 2)
+PIXFMT_RGB24, PIXFMT_BGRA = 4, 5                                            # packed RGB, one plane: scaler inputs only
 
 
 class DFrame:
@@ -165,7 +166,22 @@ class DFrame:
         check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
         return self
 
+    def upload_packed(self, pix):
+        """packed RGB formats: pix (height, width, 3) rgb24 / (height, width, 4) bgra"""
+        a = np.ascontiguousarray(pix, dtype=np.uint8)
+        assert self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA) and a.shape == (self.height, self.width, 3 if self.fmt == PIXFMT_RGB24 else 4)
+        plane = a.reshape(self.height, -1)
+        hf = _host_frame([plane], self.width, self.height)
+        check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
+        return self
+
     def download(self):
+        if self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA):
+            bpp = 3 if self.fmt == PIXFMT_RGB24 else 4
+            plane = np.empty((self.height, self.width * bpp), np.uint8)
+            hf = _host_frame([plane], self.width, self.height)
+            check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
+            return [plane.reshape(self.height, self.width, bpp)]
         if self.fmt == PIXFMT_NV12:
             planes = [np.empty((self.height, self.width), np.uint8), np.empty((self.height >> 1, self.width), np.uint8)]
         else:

@@ -99,10 +99,14 @@ class Workspace:
     def source_video(self) -> int:
         return self.add(abi.KIND_SOURCE_VIDEO, None)
 
-    def monitor(self, width=560, height=350) -> int:
-        """Monitor (560 x 350, monitor.rs:21-22) / StreamOutput (1120 x 700, stream_output.rs:23-24) hand-off: in Video, Stereo"""
+    def monitor(self, width=560, height=350, queue_depth=None) -> int:
+        """Monitor (560 x 350, monitor.rs:21-22) / StreamOutput (1120 x 700, stream_output.rs:23-24) hand-off: in Video, Stereo.
+        queue_depth (mx_monitor_params_ex): ticks are dropped while that many wait for the consumer (try_send on a channel of two,
+        monitor.rs:163-177); None = keep every tick"""
         import struct
-        return self.add(abi.KIND_MONITOR, struct.pack("<II", width, height))
+        if queue_depth is None:
+            return self.add(abi.KIND_MONITOR, struct.pack("<II", width, height))
+        return self.add(abi.KIND_MONITOR, struct.pack("<IIII", width, height, queue_depth, 0))
 
     def video_to_rgba(self, matrix_q12=None) -> int:
         from .video import to_rgba_params

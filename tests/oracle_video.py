@@ -27,6 +27,7 @@ lib.orc_dynamic_scale.argtypes = [C.POINTER(OFrame), C.POINTER(OFrame)]
 lib.orc_scaler_geometry.argtypes = [C.c_uint32] * 4 + [C.POINTER(ScaleGeometry)]
 lib.orc_unify_picture_settings.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
 lib.orc_yuv420_to_rgba.argtypes = [C.POINTER(OFrame), C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+lib.orc_packed_rgb_to_yuv444.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OFrame)]
 lib.orc_bicubic_tap_count.argtypes = [C.c_uint32, C.c_uint32]
 lib.orc_bicubic_tap_count.restype = C.c_uint32
 
@@ -82,6 +83,15 @@ def crossfade(out: HostFrame, a: HostFrame | None, b: HostFrame | None, fader: f
 
 def dynamic_scale(src: HostFrame, dst: HostFrame):
     lib.orc_dynamic_scale(C.byref(src.c), C.byref(dst.c))
+
+
+def packed_rgb_to_yuv444(pix: np.ndarray, fmt: int) -> HostFrame:
+    """pix: (h, w, 3) rgb24 (fmt 4) or (h, w, 4) bgra (fmt 5) uint8 -> the yuv444p frame a scaler input of that format stands for"""
+    a = np.ascontiguousarray(pix, dtype=np.uint8)
+    h, w, bpp = a.shape
+    out = HostFrame(w, h, 2)
+    lib.orc_packed_rgb_to_yuv444(a.ctypes.data_as(C.c_void_p), w * bpp, w, h, fmt, C.byref(out.c))
+    return out
 
 
 def scaler_geometry(iw, ih, ow, oh):

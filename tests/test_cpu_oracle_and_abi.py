@@ -174,7 +174,7 @@ def test_abi_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_error_channel_without_gpu():
-    assert abi.lib.mx_abi_version() == 1
+    assert abi.lib.mx_abi_version() == 2
     n = abi.lib.mx_device_count()
     if n <= 0:   # CPU box: the call must fail cleanly and say why, not crash or fall back
         assert n == abi.MX_ERR_DEVICE and b"hip" in abi.lib.mx_last_error().lower()
@@ -286,3 +286,35 @@ def test_product_scaler_taps_equal_the_exact_rational_spec():
         assert list(first) == g["first"], f"product first-tap indices {g['src']} -> {g['dst']}"
         got = [list(coef[o * n:(o + 1) * n]) for o in range(g["dst"])]
         assert got == g["coef"], f"product coefficients {g['src']} -> {g['dst']}"
+
+
+def test_oracle_packed_rgb_conversion_equals_the_exact_rational_matrix():
+    """The build-specified packed RGB -> yuv444 conversion (what an rgb24 / bgra scaler input stands for): the oracle's hard-coded integers
+    against tests/golden/rgb_matrix_bt709.json, which make_rgb_matrix.py derives from the BT.709 primaries with exact rationals."""
+    import json
+    import pathlib
+    import numpy as np
+    import oracle_video as ov
+    m = json.load(open(pathlib.Path(__file__).parent / "golden" / "rgb_matrix_bt709.json"))
+    rng = np.random.default_rng(7)
+    rgb = rng.integers(0, 256, size=(6, 10, 3), dtype=np.uint8)
+    rgb[0, :4] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 0, 255]]
+    R, G, B = (rgb[..., k].astype(np.int64) for k in range(3))
+    want = [((m[key][0] * R + m[key][1] * G + m[key][2] * B + 128) >> 8) + off for key, off in (("y", 16), ("cb", 128), ("cr", 128))]
+    got = ov.packed_rgb_to_yuv444(rgb, 4).visible()
+    for p in range(3):
+        assert np.array_equal(got[p], want[p].astype(np.uint8)), f"plane {p}"
+    bgra = np.concatenate([rgb[..., ::-1], rng.integers(0, 256, size=(6, 10, 1), dtype=np.uint8)], axis=2)   # alpha is ignored
+    got2 = ov.packed_rgb_to_yuv444(bgra, 5).visible()
+    for p in range(3):
+        assert np.array_equal(got2[p], got[p])
+    assert int(want[0].min()) >= 16 and int(want[0].max()) <= 235
+
+
+def test_crossfade_division_identity_the_packed_kernel_relies_on():
+    """mx_k_video.hip fade_pk: x / 255 == (x1 + (x1 >> 8)) >> 8 with x1 = x + 1, for every x = a f + b (255 - f) <= 255 * 255, inside 16 bits."""
+    import numpy as np
+    x = np.arange(0, 255 * 255 + 1, dtype=np.int64)
+    x1 = x + 1
+    assert np.array_equal((x1 + (x1 >> 8)) >> 8, x // 255)
+    assert int((x1 + (x1 >> 8)).max()) < 65536

@@ -134,3 +134,47 @@ def test_monitor_passes_source_offsets_and_handles_disconnected_inputs():
         ingest.graph_read_monitor_tick(g, m, 4)                              # beyond the run
     with pytest.raises(abi.MxError):
         ingest.graph_read_monitor_tick(g, sv, 0)                             # not a monitor
+
+
+def test_monitor_with_a_queue_depth_drops_ticks_like_try_send_on_a_full_channel():
+    """mx_monitor_params_ex.queue_depth = 2: Monitor::run_tick hands the tick to its codec thread with try_send on a channel of TWO and drops it
+    when the thread lags (monitor.rs:163-177).  Model: a queue of capacity 2; a tick enters if there is room, else it is lost; the consumer takes
+    ticks between submissions (mx_graph_monitor_consume).  Dropped ticks keep their timestamp, carry no picture and scale nothing."""
+    T = 5
+    ws = Workspace(SR, 60)
+    sv = ws.source_video()
+    m = ws.monitor(64, 48, queue_depth=2)
+    keep_all = ws.monitor(64, 48)
+    ws.connect(sv, 0, m, 0); ws.connect(sv, 0, keep_all, 0)
+    g = ws.build(max_ticks_per_run=T)
+    frames = [upload(ov.HostFrame(32, 24).fill(k, seed=k)) for k in range(4 * T)]
+    queue, consumed_plan = 0, [0, 1, 5, 2]            # how many ticks the consumer takes after each submission
+    for run in range(4):
+        t0 = run * T
+        for k in range(T):
+            ingest.graph_queue_video_source(g, sv, t0 + k, frames[t0 + k], dur=(1, 60), off=(0, 1))
+        g.run_ticks(t0, T)
+        for k in range(T):
+            ts, vid, dropped = ingest.graph_read_monitor_tick(g, m, k, with_dropped=True)
+            ts_all, vid_all, dropped_all = ingest.graph_read_monitor_tick(g, keep_all, k, with_dropped=True)
+            want_drop = queue >= 2
+            if not want_drop:
+                queue += 1
+            assert dropped == want_drop, f"run {run} tick {k}"
+            assert ts == ts_all == F(t0 + k, 60) and not dropped_all and vid_all is not None
+            if want_drop:
+                assert vid is None
+            else:
+                assert vid is not None and vid[1] == ts
+                for x, y in zip(vid[0].download(), vid_all[0].download()):
+                    assert np.array_equal(x, y)                                  # a kept tick's picture is what the keep-everything node holds
+        n = consumed_plan[run]
+        ingest.graph_monitor_consume(g, m, n)
+        queue -= min(queue, n)
+    # the packed read-back skips dropped ticks like ticks without a picture
+    packed = ingest.graph_read_monitor_video(g, m, 0, T)
+    for k in range(T):
+        _ts, vid, _d = ingest.graph_read_monitor_tick(g, m, k, with_dropped=True)
+        assert (packed[k] is None) == (vid is None)
+    with pytest.raises(abi.MxError):
+        ingest.graph_monitor_consume(g, sv, 1)                                   # not a monitor

@@ -309,3 +309,38 @@ def test_video_mixer_random_scenarios_match_oracle(seed):
         assert (fa is None) == (a is None or ins_h[a] is None)
         assert (fb is None) == (b is None or ins_h[b] is None)
     assert shown > 5
+
+
+@pytest.mark.parametrize("fmt", [video.PIXFMT_RGB24, video.PIXFMT_BGRA], ids=["rgb24", "bgra"])
+@pytest.mark.parametrize("src,dst", [((320, 180), (480, 270)), ((322, 182), (320, 180)), ((64, 64), (320, 180)), ((1280, 720), (560, 350)), ((320, 180), (320, 180))],
+                         ids=["up-1.5x", "down-slightly", "pillarbox", "monitor-downscale", "same-size"])
+def test_packed_rgb_scaler_inputs_equal_the_oracle_composition(fmt, src, dst):
+    """A packed RGB scaler input (codec/src/ffmpeg/scale.rs:16-39 takes any input format) is BUILD-SPECIFIED as the yuv444p frame of its
+    per-pixel BT.709 conversion, resampled like any 4:4:4 input into the yuv420p output -- also when the sizes are equal (the picture
+    settings differ by the format, encode.rs:342-352).  Stateless call, persistent scaler and a VideoMixer input."""
+    rng = np.random.default_rng(src[0] * 7 + dst[0] + fmt)
+    w, h = src
+    bpp = 3 if fmt == video.PIXFMT_RGB24 else 4
+    pix = rng.integers(0, 256, size=(h, w, bpp), dtype=np.uint8)
+    pix[: h // 3] = (np.add.outer(np.arange(h // 3), np.arange(w))[..., None] * np.array([1, 2, 3, 1][:bpp])).astype(np.uint8)   # a smooth part too
+    d = video.DFrame(w, h, fmt=fmt).upload_packed(pix)
+    assert np.array_equal(d.download()[0], pix)
+    as444 = ov.packed_rgb_to_yuv444(pix, fmt)
+    want = ov.HostFrame(*dst); ov.blank(want); ov.dynamic_scale(as444, want)
+    out = video.DFrame(*dst)
+    video.scale(d, out)
+    for p, (x, y) in enumerate(zip(out.download(), want.visible())):
+        assert np.array_equal(x, y), f"stateless scale, plane {p}"
+    sc = video.Scaler(*dst)
+    for _ in range(2):
+        res = sc.scale(d)
+        for p, (x, y) in enumerate(zip(res.download(), want.visible())):
+            assert np.array_equal(x, y), f"persistent scaler, plane {p}"
+    # as a VideoMixer input beside a yuv420p layer of the output's size
+    other = ov.HostFrame(*dst).fill(3, seed=5)
+    m = video.VideoMixer(a=0, b=1, fader=0.4)
+    om = ov.OracleVideoMixer(a=0, b=1, fader=0.4)
+    prog, _a, _b = m.run_tick(0, [(d, (1, 30), (0, 1)), (video.DFrame(*dst).upload(*other.visible()), (1, 30), (0, 1)), None, None])
+    want_prog = om.run_tick(0, [(as444, (1, 30), (0, 1)), (other, (1, 30), (0, 1)), None, None])
+    for p, (x, y) in enumerate(zip(prog.download(), want_prog.visible())):
+        assert np.array_equal(x, y), f"VideoMixer program, plane {p}"
