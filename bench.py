@@ -452,6 +452,26 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup):
            "workload": "256 stereo channels @44.1 kHz: 128-tap FIR -> 160/147 polyphase resampler (16 taps/phase) -> Mixer(256) @48 kHz",
            "ticks_per_step": T, "ms_per_step": dt / steps * 1e3, "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
            "realtime_stereo_channels_equiv": n_ch * T * steps / dt / 60.0}
+    # per-kernel roofs: the f64 operations the spec prescribes against the f64 VALU rate, the bytes a kernel has to move against HBM, and the
+    # HBM traffic of the committed PMC passes (profiles/r03/fir_pmc_traffic.json) while the kernel sources are the ones it was collected on
+    traffic = {}
+    try:
+        rec = json.load(open(PROFILE_DIR / "fir_pmc_traffic.json"))
+        if rec.get("kernel_sources_sha16") == _kernel_hash("fir") and rec.get("config", {}).get("ticks_per_step") == T:
+            traffic = rec.get("bytes_per_launch", {})
+    except (OSError, ValueError):
+        pass
+    moved = {"fir": n_ch * frames_in * 8 * 2, "resample": n_ch * (frames_in + T * 800) * 8}
+    ops = {"fir": fir_ops, "resample": rs_ops}
+    roof = {}
+    for k in ("fir", "resample"):
+        if k in k_ms:
+            sec = k_ms[k] * 1e-3
+            roof[k] = {"ms": round(k_ms[k], 5), "f64_ops_per_launch": ops[k], "f64_tops": round(ops[k] / sec / 1e12, 2), "f64_frac": round(ops[k] / sec / 1e12 / F64_VALU_PEAK_TOPS, 3),
+                       "moved_bytes_per_launch": moved[k], "hbm_frac": round(moved[k] / sec / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": traffic.get(k), "bound": "f64 VALU (prescribed mul + add, no FMA by spec)" if k == "fir" else "LDS bandwidth (24 B of LDS per tap step and lane against four f64 operations)"}
+    out["roofline"] = {"per_kernel": roof, "f64_peak_tops": F64_VALU_PEAK_TOPS, "hbm_peak_gbs": HBM_PEAK_GBS,
+                       "traffic_source": "profiles/r03/fir_pmc_traffic.json" if traffic else None}
     if "fir" in k_ms:
         out["fir_f64_valu"] = {"ops_per_launch": fir_ops, "achieved_tops": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12, 2), "peak_tops": 39.3,
                                "frac": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12 / 39.3, 3), "note": "prescribed f64 mul + add only (no FMA by spec)"}
@@ -522,22 +542,49 @@ def fir_cpu_baseline(T_ref_ticks=8, n_ch=8):
             "sample": f"{n_ch} of the 256 stereo channels x {n_ticks} ticks, single thread, {dt:.1f} s"}
 
 
+PROFILE_DIR = ROOT / "profiles" / "r03"
+
+
+def _kernel_hash(family):
+    sys.path.insert(0, str(ROOT / "tools"))
+    from kernel_hash import kernel_hash
+    return kernel_hash(family)
+
+
 def pmc_traffic(kernel, args, world, toggling):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r02/pmc_traffic.json, collected
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r03/pmc_traffic.json, collected
     with this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide streaming reads); None when the run's configuration differs from the profiled one
-    -- counters cannot be read from inside the process."""
+    OR the kernel sources have changed since the profile was collected (their hash is recorded in the JSON) -- counters cannot be
+    read from inside the process, and a stale figure is worse than none."""
     try:
-        rec = json.load(open(ROOT / "profiles" / "r02" / "pmc_traffic.json"))
+        rec = json.load(open(PROFILE_DIR / "pmc_traffic.json"))
     except (OSError, ValueError):
         return None, None
+    if rec.get("kernel_sources_sha16") != _kernel_hash("audio"):
+        return None, "profiles/r03/pmc_traffic.json is STALE (kernel sources changed since it was collected): not copied"
     c = rec.get("config", {})
     same = (c.get("strips") == args.strips and c.get("ticks_per_step") == args.ticks_per_step and c.get("sample_rate") == args.sample_rate
             and c.get("fused") == (not args.no_fuse) and c.get("eq_fast") == bool(args.eq_fast) and c.get("n_gpus") == world
             and c.get("gates_toggle") == bool(toggling))
     if not same or kernel not in rec.get("bytes_per_launch", {}):
         return None, None
-    return rec["bytes_per_launch"][kernel], "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    return rec["bytes_per_launch"][kernel], "profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; kernel sources unchanged since)"
+
+
+def sustained_clock_ghz(kernel_substr):
+    """The clock the chip held under a kernel in the committed counter pass (profiles/r03/clock.json), or None when that profile was
+    collected on other kernel sources."""
+    try:
+        rec = json.load(open(PROFILE_DIR / "clock.json"))
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernel_sources_sha16") != _kernel_hash("audio"):
+        return None
+    for k, v in rec.get("ghz_by_kernel", {}).items():
+        if kernel_substr in k:
+            return v["ghz"]
+    return None
 
 
 def scaling_probe(torch, stream, local_rank, abi, Workspace, synth, strips, T, SR, toggling, flags, t1_ms):
@@ -953,9 +1000,9 @@ def main():
                     "algorithmic_bytes_per_unit": "2M = 8 B per sample per strip (SURVEY 8d: EqThree channel-tick; source read + strip written as one float per frame)",
                     "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
-                    "limiter": ("f64 VALU issue: PMC (profiles/r02) 79 VALU instructions per output sample with toggling gates (59 held), 59 of the hot loop's 63.5 per sample are the reference's own operations, "
-                                "VALU pipes 86 % busy at the 1.8 GHz the chip sustains under this kernel; HBM traffic = 1.16x algorithmic (the warm-up re-read); "
-                                "HBM is the roof only nominally" if dom == "eq_three" else "HBM"),
+                    "limiter": ("f64 VALU issue (profiles/r03, DESIGN.md 5.2 ledger): the hot loop is 63.5 VALU instructions per sample of which 59 are the reference's own operations in the reference's order, "
+                                "the warm-up of every chunk adds 14.5 % more lane-samples; the VALU pipes are busy most of the kernel at the clock the chip sustains under f64 issue; "
+                                "HBM traffic = 1.16x algorithmic (the warm-up re-read): HBM is the roof only nominally" if dom == "eq_three" else "HBM"),
                     "per_kernel": per_kernel}
             if dom == "eq_three":
                 # the bound that applies: f64 VALU.  Reference arithmetic per strip-sample: EqThree 36 f64 operations (2 x 4 poles x (sub, mul, add)
@@ -966,9 +1013,12 @@ def main():
                 roof["f64_valu"] = {"ops_per_sample_reference": ops, "ops_per_launch": f64_ops, "achieved_tops": round(f64_ops / (avg_ms * 1e-3) / 1e12, 2),
                                     "peak_tops": F64_VALU_PEAK_TOPS, "frac": round(f64_ops / (avg_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TOPS, 3),
                                     "note": "f64 operations of the reference's arithmetic per second against the f64 VALU instruction rate at the 2.4 GHz peak clock (an FMA would count once; none is allowed here)",
-                                    "sustained_clock": {"ghz": 1.82, "peak_tops_at_that_clock": round(F64_VALU_PEAK_TOPS * 1.82 / 2.4, 1),
-                                                        "frac_at_that_clock": round(f64_ops / (avg_ms * 1e-3) / 1e12 / (F64_VALU_PEAK_TOPS * 1.82 / 2.4), 3),
-                                                        "source": "profiles/r02/pmc_clock.txt: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled (2.15 GHz under the HBM-bound mixer); a committed measurement, not read live"}}
+                                    }
+                ghz = sustained_clock_ghz("k_eq_three_spec_tiled")
+                if ghz:
+                    roof["f64_valu"]["sustained_clock"] = {"ghz": ghz, "peak_tops_at_that_clock": round(F64_VALU_PEAK_TOPS * ghz / 2.4, 1),
+                                                           "frac_at_that_clock": round(f64_ops / (avg_ms * 1e-3) / 1e12 / (F64_VALU_PEAK_TOPS * ghz / 2.4), 3),
+                                                           "source": "profiles/r03/clock.json: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled; a committed measurement of these kernel sources, not read live"}
         moved = sum(moved_bytes(k) for k in k_ms)
         rep_sorted = sorted(rep_ms)
         out = {

@@ -6,13 +6,20 @@ FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half 
 import collections
 import csv
 import json
+import pathlib
 import sys
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
+from kernel_hash import kernel_hash  # noqa: E402
 
 GROUPS = {   # bench.py's launch groups (what its hipEvents bracket)
     "eq_three": ("k_env_ticks", "k_eq_three_spec", "k_eq_three_repair", "k_eq_three_scan", "k_eq_three_wave", "k_eq_three_exact"),
     "mixer": ("k_mixer",),
     "video_scaler": ("k_scale_bicubic",),
     "video_chain": ("k_fade_chain",),
+    "video_batch": ("k_video_batch<2>",),
+    "fir": ("k_fir(",),
+    "resample": ("k_resample(",),
 }
 
 
@@ -30,6 +37,7 @@ def per_kernel(path, counter):
 def main():
     fetch, write, out_json, out_md = sys.argv[1:5]
     config = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}
+    family = sys.argv[6] if len(sys.argv) > 6 else "audio"
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     rows = []
     for k in sorted(set(f) | set(w)):
@@ -42,7 +50,7 @@ def main():
         sel = [r for r in rows if any(n in r[0] for n in names)]
         if sel:
             groups[g] = sum(r[1] + r[2] for r in sel if r[1] + r[2] > 0.01 * max(x[1] + x[2] for x in sel))
-    json.dump({"config": config, "bytes_per_launch": groups,
+    json.dump({"config": config, "kernel_sources_sha16": kernel_hash(family), "bytes_per_launch": groups,
                "per_kernel": {r[0][:120]: {"fetch_bytes_x2": r[1], "write_bytes": r[2], "dispatches": r[3]} for r in rows}}, open(out_json, "w"), indent=1)
     with open(out_md, "w") as fh:
         fh.write("| kernel | dispatches | FETCH_SIZE x 2 (B / dispatch) | WRITE_SIZE (B / dispatch) | sum |\n|---|---|---|---|---|\n")

@@ -1,32 +1,56 @@
 #!/bin/bash
-# Collect what profiles/rNN/ holds, on the GPU box:  gpurun -- 'bash tools/profile_round.sh r02'
-# Every rocprofv3 pass is wrapped in its own `timeout`; PMC passes use --kernel-trace only (never the hip/hsa trace domains).
+# Collect what profiles/rNN/ holds, on the GPU box:  gpurun -- 'bash tools/profile_round.sh r03'
+# Every rocprofv3 pass is wrapped in its own `timeout`; PMC passes use --kernel-trace only (never the hip/hsa trace domains),
+# FETCH_SIZE and WRITE_SIZE in separate runs (MI355X_MICROARCH.md).  profiles/rNN/README.md is generated from these outputs
+# (tools/profile_readme.py), not written by hand.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-realtime --no-t-sweep --no-north-star --no-held-leg --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 320"
+COMMON="--no-cpu-baseline --no-realtime --no-t-sweep --no-north-star --no-held-leg --no-material-leg --no-scaling-probe --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 0"
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
+pmc() {   # pmc <tag> <counters...> -- <command...>: one counter pass, summary into $OUT/<tag>.txt, raw csv path echoed
+  local tag=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rm -rf /tmp/p_$tag
+  timeout 900 rocprofv3 --kernel-trace --pmc "${ctr[@]}" --output-format csv -d /tmp/p_$tag -- "$@" > /dev/null 2>&1
+  local f=$(find /tmp/p_$tag -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python $REPO/tools/pmc_summary.py $f > $OUT/$tag.txt
+  echo $f
+}
 # 1. the default command, as the driver runs it
 timeout 900 python $REPO/bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 # 2. the same command under the kernel trace
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py > $OUT/bench_line_under_rocprof.json 2>/dev/null
+rm -rf /tmp/kt; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py > $OUT/bench_line_under_rocprof.json 2>/dev/null
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_default_bench.csv
-# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md), headline configuration, fewer steps
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python $REPO/bench.py $COMMON > /dev/null 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python $REPO/bench.py $COMMON > /dev/null 2>&1
-python $REPO/tools/pmc_traffic.py $(find /tmp/pf -name "*counter_collection.csv" | head -1) $(find /tmp/pw -name "*counter_collection.csv" | head -1) \
-    $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.md '{"strips": 1024, "ticks_per_step": 2048, "sample_rate": 48000, "fused": true, "eq_fast": false, "n_gpus": 1, "gates_toggle": true}'
+# 3. HBM traffic of the headline configuration
+FCSV=$(pmc pmc_fetch FETCH_SIZE -- python $REPO/bench.py $COMMON)
+WCSV=$(pmc pmc_write WRITE_SIZE -- python $REPO/bench.py $COMMON)
+python $REPO/tools/pmc_traffic.py $FCSV $WCSV $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.md \
+    '{"strips": 1024, "ticks_per_step": 2048, "sample_rate": 48000, "fused": true, "eq_fast": false, "n_gpus": 1, "gates_toggle": true}' audio
 # 4. SQ counters of the headline kernels, gates toggling and held
-for mode in "" "--hold-gates"; do
-  tag=toggle; [ -n "$mode" ] && tag=held
-  timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d /tmp/sq$tag -- python $REPO/bench.py $COMMON $mode > /dev/null 2>&1
-  python $REPO/tools/pmc_summary.py $(find /tmp/sq$tag -name "*counter_collection.csv" | head -1) > $OUT/pmc_sq_$tag.txt
-done
-# 5. the clock the chip sustains under the headline kernel: busy cycles per SE / duration (GRBM_GUI_ACTIVE: per XCD)
-timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d /tmp/clk -- python $REPO/bench.py $COMMON > /dev/null 2>&1
-python $REPO/tools/pmc_summary.py $(find /tmp/clk -name "*counter_collection.csv" | head -1) > $OUT/pmc_clock.txt
-cp $(find /tmp/clk -name "*kernel_trace.csv" | head -1) $OUT/pmc_clock_kernel_trace.csv 2>/dev/null
+pmc pmc_sq_toggle $SQ1 -- python $REPO/bench.py $COMMON > /dev/null
+pmc pmc_sq_held $SQ1 -- python $REPO/bench.py $COMMON --hold-gates > /dev/null
+# 5. the clock the chip sustains under the headline kernels: GRBM_GUI_ACTIVE (per XCD) / duration of the same dispatches
+CCSV=$(pmc pmc_clock GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -- python $REPO/bench.py $COMMON)
+cp $(find /tmp/p_pmc_clock -name "*kernel_trace.csv" | head -1) $OUT/pmc_clock_kernel_trace.csv 2>/dev/null
+python $REPO/tools/pmc_clock.py $CCSV $OUT/pmc_clock_kernel_trace.csv $OUT/clock.json
+# 6. config 4 (video leg alone): kernel times, SQ counters, traffic
+rm -rf /tmp/vk; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vk -- python $REPO/tools/vleg.py 3840 > $OUT/video_leg_line.json 2>/dev/null
+cp $(find /tmp/vk -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_video_leg.csv
+pmc video_sq $SQ1 -- python $REPO/tools/vleg.py 1280 > /dev/null
+VF=$(pmc video_fetch FETCH_SIZE -- python $REPO/tools/vleg.py 1280)
+VW=$(pmc video_write WRITE_SIZE -- python $REPO/tools/vleg.py 1280)
+python $REPO/tools/pmc_traffic.py $VF $VW $OUT/video_pmc_traffic.json $OUT/video_pmc_hbm_traffic.md '{"leg": "video", "frames_per_launch": 16}' video
+# 7. config 3 (FIR + resampler leg alone)
+rm -rf /tmp/fk; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fk -- python $REPO/tools/fleg.py 128 10 > $OUT/fir_leg_line.json 2>/dev/null
+cp $(find /tmp/fk -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_fir_leg.csv
+pmc fir_sq $SQ1 -- python $REPO/tools/fleg.py 128 6 > /dev/null
+pmc fir_sq2 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY -- python $REPO/tools/fleg.py 128 6 > /dev/null
+FF=$(pmc fir_fetch FETCH_SIZE -- python $REPO/tools/fleg.py 128 6)
+FW=$(pmc fir_write WRITE_SIZE -- python $REPO/tools/fleg.py 128 6)
+python $REPO/tools/pmc_traffic.py $FF $FW $OUT/fir_pmc_traffic.json $OUT/fir_pmc_hbm_traffic.md '{"leg": "fir_resample", "ticks_per_step": 128}' fir
+python $REPO/tools/profile_readme.py $OUT $R > $OUT/README.md
 ls -la $OUT
