@@ -617,7 +617,7 @@ __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* b
 }
 
 template <int SB, int KMODE, int KSTEREO>
-__global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+__global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                                 uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][TILE]
     constexpr int EQ_SB = SB, EQ_TILE = EqTileGeo<SB>::TILE;
@@ -654,46 +654,59 @@ __global__ __launch_bounds__(64, 3) void k_eq_three_spec_tiled(const EqDesc* __r
     uint32_t xmin = 0xffffffffu, xmax = 0u;
     const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
     EnvTick cur{}; EnvLane el{};
-    int envk = 0;
     const bool nice = env_params_nice(d.env);
     EqChunkRec* rec = recs + (size_t)inst * plan.n_chunks + (active ? j : 0);
 
-    int next_tick = 0;   // chunk-relative index of the next tick's first sample (chunks are whole ticks, ticks whole super-blocks)
+    // One loop per PHASE, not one loop that picks its phase every step: the warm-up, and then -- per tick -- the one epilogue form the tick
+    // needs.  With a single loop over the super-blocks that dispatched to the four compute variants, the compiler gave each variant its
+    // own register assignment for the carried state (eight f64 poles, the delay line, min / max) and moved it back to a common one at the
+    // back edge: 44 v_mov_b64 per super-block, 3 instructions per sample that no sample needed (ISA; PMC 79 -> 77 per output sample with
+    // the index arithmetic of the DMA, see DESIGN.md 5.2 ledger).  Here a variant's loop keeps the state where it is; moves happen once per tick.
     eq_tile_issue<SB>(c, eq_tiles, -(int)plan.warm);
-    for (int g = 0; g < total; ++g) {
-        float* buf = eq_tiles + (g & 1) * EQ_TILE;
+    auto begin_sb = [&](int g) -> float* {
         const int so = (g - n_warm) * EQ_SB;
         if (g + 1 < total) eq_tile_issue<SB>(c, eq_tiles + ((g + 1) & 1) * EQ_TILE, so + EQ_SB);   // its previous tenant was stored one step ago
         // everything but the DMA just issued has landed: this super-block's tile, and the stores of the one before
         if (g + 1 < total) { if (SB == 32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (g < n_warm) {
-            eq_tile_compute<SB, EQM_PLAIN, 0, true>(K, buf, c.lane, so, warm_from, cur, el, s, xmin, xmax);
-            continue;
-        }
-        if (g == n_warm) {   // first sample of my chunk: record where the warm-up took me (chunks that started at the stream's start: the exact state)
-            if (active) {
+        return eq_tiles + (g & 1) * EQ_TILE;
+    };
+    int g = 0;
+    for (; g < n_warm; ++g) {
+        float* buf = begin_sb(g);
+        eq_tile_compute<SB, EQM_PLAIN, 0, true>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
+    }
+    if (active) {   // first sample of my chunk: record where the warm-up took me (chunks that started at the stream's start: the exact state)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
+        for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
+    }
+    if constexpr (KMODE == EQM_AMP_ENV) {
+        const int sb_per_tick = (int)(r.fpc / EQ_SB);   // chunks are whole ticks, ticks whole super-blocks (launcher)
+        while (g < total) {
+            // a new tick (wave-uniform): its Envelope state, per lane
+            const int so0 = (g - n_warm) * EQ_SB;
+            const size_t tk = ((size_t)begin + (size_t)so0) / r.fpc;
+            cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
+            const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so0;
+            el = env_lane_coeffs(K.env, cur, t, r.fpc, nice);
+            el.k0 = (uint32_t)so0; el.t_chunk = r.t0 + (uint64_t)begin;
+            const int envk = __ballot(active && so0 < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so0 < len && el.flat == 0u) == 0ull ? 1 : 2);
+            const int g_end = g + sb_per_tick < total ? g + sb_per_tick : total;
+            if (envk == 1) {
+                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 1, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
+            } else if (envk == 2) {
+                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 2, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
+            } else {
+                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 3, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
             }
         }
-        if constexpr (KMODE == EQM_AMP_ENV) {
-            if (so == next_tick) {   // a new tick (wave-uniform: chunks are whole ticks): its Envelope state, per lane
-                next_tick += (int)r.fpc;
-                const size_t tk = ((size_t)begin + (size_t)so) / r.fpc;
-                cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
-                const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so;
-                el = env_lane_coeffs(K.env, cur, t, r.fpc, nice);
-                el.k0 = (uint32_t)so; el.t_chunk = r.t0 + (uint64_t)begin;
-                envk = __ballot(active && so < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so < len && el.flat == 0u) == 0ull ? 1 : 2);
-            }
-            if (envk == 1) eq_tile_compute<SB, KMODE, 1, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-            else if (envk == 2) eq_tile_compute<SB, KMODE, 2, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-            else eq_tile_compute<SB, KMODE, 3, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
-        } else {
+    } else {
+        for (; g < total; ++g) {
+            float* buf = begin_sb(g);
+            const int so = (g - n_warm) * EQ_SB;
             eq_tile_compute<SB, KMODE, 0, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            eq_tile_store<SB, KSTEREO != 0>(c, buf, so);
         }
-        eq_tile_store<SB, KSTEREO != 0>(c, buf, so);
     }
     if (active) {
 #pragma unroll
@@ -1014,15 +1027,16 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     size_t best;
     if (force_c > 1) best = std::min<size_t>((size_t)force_c, nc_max);
     else {
-        // Cost of a plan with nc chunks per instance: the samples every lane walks, warm-ups included, over how full the chip is --
-        // the VALU pipes saturate at about 3 waves per SIMD (measured: 1 wave 5.8 ms, 2 waves 4.7, 3 waves 4.3, 4 - 7 waves 4.4 - 4.7 for
-        // 1024 strips x 2048 ticks); a wave is 64 chunks of one instance.  Few instances => more, shorter chunks, down to one warm-up
-        // (the rank of an 8-GPU job: 128 strips run 1024 chunks of two ticks).  Below one wave per SIMD a wave runs at its own
-        // pace whether 1 or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
+        // Cost of a plan with nc chunks per instance: the samples every lane walks, warm-ups included, over how full the chip is.  A wave
+        // is 64 chunks of one instance; every tiled variant of the kernel now fits FOUR waves per SIMD (the Envelope variant went from 141
+        // to 109 VGPRs when its loop was split per phase) and the fourth pays: 1024 strips x 2048 ticks, 192 chunks (3 waves per SIMD)
+        // 5.83 ms, 256 chunks (4 waves) 4.55 ms.  Waves beyond one round of 4 per SIMD wait for a second round.  Few instances => more,
+        // shorter chunks, down to one warm-up (the rank of an 8-GPU job).  Below one wave per SIMD a wave runs at its own pace whether 1
+        // or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
         auto cost = [&](size_t nc) {
             const double waves = (double)n * (double)((nc + 63) / 64);
-            const double rounds = std::ceil(waves / 3072.0);            // waves beyond one round of 3 per SIMD wait for a second one
-            const double occ = waves / (rounds * 3072.0);
+            const double rounds = std::ceil(waves / 4096.0);
+            const double occ = waves / (rounds * 4096.0);
             return ((double)nc * (double)(chunk_of(nc) + W)) / occ;     // ~ frames + nc * W, with the chunk rounding
         };
         best = std::min<size_t>(64, nc_max);
@@ -1064,7 +1078,8 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
                        r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
     if (tiled) {
-        const size_t lds = 2 * 64 * (size_t)sb * sizeof(float);
+        static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
+        const size_t lds = std::max<size_t>(2 * 64 * (size_t)sb * sizeof(float), (size_t)lds_pad);
 #define MX_GT(M, S) { if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
         switch (um) {
