@@ -1418,7 +1418,7 @@ void Graph::run_video_tick(uint64_t t) {
             n.rgba_cur = (n.rgba_cur + 1u) % K;
             uint8_t* const out = (uint8_t*)n.rgba[n.rgba_cur].p;
             if (d->lazy) {   // the composite only exists as a cross-fade chain: evaluate it straight into RGBA
-                ChainRgbaArgs c;
+                ChainRgbaArgs c{};
                 fill_chain_rgba_sources(*d->lazy, c, stream_);   // layers that are unevaluated scaler outputs are resampled inside the kernel
                 c.rgba = out; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
                 c.use_matrix = p.use_matrix;

@@ -5,7 +5,9 @@
 // (stride % 64 == 0), so a lane moves 16 pixels (one dwordx4) and a wave 1 KiB per instruction.
 #include <algorithm>
 #include <cstddef>
+#include <cstring>
 #include <map>
+#include <vector>
 #include <mutex>
 
 #include "mx_dev.hpp"
@@ -896,14 +898,19 @@ static bool plan_scale_job(const ScaleArgs& a, ScaleJob& j) {
     j.tile_start[3] = total; j.variant = out.variant; j.s_rows = out.s_rows;
     return true;
 }
-// descriptor slots per stream: page-locked staging + its device copy; a slot is rewritten only after the launch that read it has finished
+// Descriptor slots per (device, stream): page-locked staging + its device copy + the bytes it holds.  A stream of pictures cycles through rings of
+// frames (a decoder's pool, a Scaler's 2K output frames, the sink's K RGBA buffers), so the descriptor of a launch is, byte for byte, one that was
+// uploaded a few launches ago: a launch whose descriptor equals a slot's content uses that slot as it is -- no copy, no event, nothing between two
+// launches but the launch itself (the upload + cross-stream wait cost ~11 us per launch: 0.7 us per frame at sixteen frames per launch).  A miss
+// takes the least recently used slot: it is rewritten only after the last launch that read it has finished.
 namespace {
-struct DescSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; hipEvent_t done = nullptr, copied = nullptr; bool used = false; };
-struct DescRing { DescSlot slot[4]; uint32_t next = 0; hipStream_t copy = nullptr; };   // `copy`: the uploads' own stream -- they run beside the previous launch, not behind it
+struct DescSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t bytes = 0; uint64_t hash = 0, used_at = 0; hipEvent_t done = nullptr, copied = nullptr; bool used = false; };
+struct DescRing { DescSlot slot[16]; uint64_t clock = 0; hipStream_t copy = nullptr; std::vector<uint8_t> build; };   // `copy`: the uploads' own stream -- they run beside the previous launch
 std::mutex g_desc_mu;
 std::map<std::pair<int, hipStream_t>, DescRing> g_desc;
 constexpr size_t VB_HEADER = offsetof(VideoBatchDesc, c);
 constexpr size_t VB_BYTES = sizeof(VideoBatchDesc);
+uint64_t fnv1a(const uint8_t* p, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; }
 }  // namespace
 static void launch_separately(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
     for (int i = 0; i < n_jobs; i += 4) {
@@ -926,45 +933,56 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
         mm = m;
     }
     if (!one) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }
-    // the descriptor, built in a page-locked slot
+    // the descriptor: built in host memory, then looked up among the slots already on the device
     int dev = 0;
     hip_check(hipGetDevice(&dev), "hipGetDevice");
-    DescSlot* sl; hipStream_t copy_stream;
-    {
-        std::lock_guard<std::mutex> lk(g_desc_mu);
-        DescRing& r = g_desc[{dev, s}];
-        if (!r.copy) hip_check(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking), "hipStreamCreate(descriptor uploads)");
-        sl = &r.slot[r.next]; r.next = (r.next + 1) & 3u; copy_stream = r.copy;
-    }
-    if (!sl->host) {
-        hip_check(hipEventCreateWithFlags(&sl->copied, hipEventDisableTiming), "hipEventCreate");
-        hip_check(hipHostMalloc((void**)&sl->host, VB_BYTES, hipHostMallocDefault), "hipHostMalloc(video batch descriptor)");
-        hip_check(hipMalloc((void**)&sl->dev, VB_BYTES), "hipMalloc(video batch descriptor)");
-        hip_check(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming), "hipEventCreate");
-    }
-    if (sl->used) hip_check(hipEventSynchronize(sl->done), "hipEventSynchronize(video batch descriptor)");
-    VideoBatchDesc* d = reinterpret_cast<VideoBatchDesc*>(sl->host);
+    std::lock_guard<std::mutex> lk(g_desc_mu);   // (a ring belongs to one stream, i.e. to one engine thread: the lock is uncontended)
+    DescRing& ring = g_desc[{dev, s}];
+    if (!ring.copy) hip_check(hipStreamCreateWithFlags(&ring.copy, hipStreamNonBlocking), "hipStreamCreate(descriptor uploads)");
+    if (ring.build.size() < VB_BYTES) ring.build.assign(VB_BYTES, 0);
+    VideoBatchDesc* d = reinterpret_cast<VideoBatchDesc*>(ring.build.data());
     uint32_t gx = 0, variant_max = 0; bool any_job = false;
+    std::memset(d, 0, VB_HEADER);
     d->n_chains = (uint32_t)n_chains; d->n_jobs = (uint32_t)n_jobs; d->jobs_off = (uint32_t)(VB_HEADER + (size_t)n_chains * sizeof(ChainRgbaArgs)); d->_pad = 0;
     for (int k = 0; k < n_chains; ++k) {
         ChainRgbaArgs& c = d->c[k];
+        std::memset(&c, 0, sizeof c);             // padding bytes take part in the comparison
         c = chains[k];
         chain_matrix_mode(c); chain_blank_planes(c);
         d->chain_tx[k] = (c.width + 127) / 128;
         d->chain_tiles[k] = d->chain_tx[k] * ((c.height + 31) / 32);
         gx = std::max(gx, d->chain_tiles[k]);
     }
-    ScaleJob* dj = reinterpret_cast<ScaleJob*>(sl->host + d->jobs_off);
+    ScaleJob* dj = reinterpret_cast<ScaleJob*>(ring.build.data() + d->jobs_off);
     for (int k = 0; k < n_jobs; ++k) {
-        if (!plan_scale_job(jobs[k], dj[k])) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }   // (the slot stays free: nothing was launched from it)
+        std::memset(&dj[k], 0, sizeof dj[k]);
+        if (!plan_scale_job(jobs[k], dj[k])) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }
         gx = std::max(gx, dj[k].tile_start[3]); variant_max = std::max(variant_max, dj[k].variant); any_job = true;
     }
     const size_t bytes = d->jobs_off + (size_t)n_jobs * sizeof(ScaleJob);
-    // the upload goes on its own stream (the host runs ahead of the device: it executes while the previous launch still runs); the
-    // launch stream only waits for its event
-    hip_check(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, copy_stream), "hipMemcpyAsync(video batch descriptor)");
-    hip_check(hipEventRecord(sl->copied, copy_stream), "hipEventRecord");
-    hip_check(hipStreamWaitEvent(s, sl->copied, 0), "hipStreamWaitEvent");
+    const uint64_t h = fnv1a(ring.build.data(), bytes);
+    DescSlot* sl = nullptr;
+    for (DescSlot& c : ring.slot) if (c.used && c.bytes == bytes && c.hash == h && std::memcmp(c.host, ring.build.data(), bytes) == 0) { sl = &c; break; }
+    const bool hit = sl != nullptr;
+    if (!hit) {
+        sl = &ring.slot[0];
+        for (DescSlot& c : ring.slot) { if (!c.used) { sl = &c; break; } if (c.used_at < sl->used_at) sl = &c; }
+        if (!sl->host) {
+            hip_check(hipHostMalloc((void**)&sl->host, VB_BYTES, hipHostMallocDefault), "hipHostMalloc(video batch descriptor)");
+            hip_check(hipMalloc((void**)&sl->dev, VB_BYTES), "hipMalloc(video batch descriptor)");
+            hip_check(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&sl->copied, hipEventDisableTiming), "hipEventCreate");
+        }
+        if (sl->used) hip_check(hipEventSynchronize(sl->done), "hipEventSynchronize(video batch descriptor)");   // the last launch that read it
+        std::memcpy(sl->host, ring.build.data(), bytes);
+        sl->bytes = bytes; sl->hash = h;
+        // the upload goes on its own stream (the host runs ahead of the device: it executes while the previous launch still runs); the
+        // launch stream only waits for its event
+        hip_check(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, ring.copy), "hipMemcpyAsync(video batch descriptor)");
+        hip_check(hipEventRecord(sl->copied, ring.copy), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(s, sl->copied, 0), "hipStreamWaitEvent");
+    }
+    sl->used_at = ++ring.clock;
     const dim3 grid((gx + 7u) & ~7u, (uint32_t)(n_chains + n_jobs));
     const size_t lds = any_job ? scale_tile_lds(variant_max) : 0;
     const VideoBatchDesc* dd = reinterpret_cast<const VideoBatchDesc*>(sl->dev);

@@ -503,7 +503,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
 
 void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp, const FrameRef& target, int32_t* const tmp_plane[3], hipStream_t s) {
     const ScaleTables& t = *tp;
-    ScaleArgs a;
+    ScaleArgs a{};
     for (int p = 0; p < 3; ++p) {
         const int c = p ? 1 : 0;
         ScalePlane& sp = a.p[p];
