@@ -800,17 +800,17 @@ typedef const __attribute__((address_space(4))) VideoBatchDesc* VbDescPtr;
 template <int MM>
 __global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc) {
     VbDescPtr d = (VbDescPtr)desc;
-    const uint32_t y = blockIdx.y, x = blockIdx.x;
-    const uint32_t n_chains = d->n_chains;
-    if (y < n_chains) {
-        const uint32_t n = d->chain_tiles[y];
+    const uint32_t x = blockIdx.x;
+    const uint32_t row = d->row_of[blockIdx.y];
+    if (row < 128u) {
+        const uint32_t n = d->chain_tiles[row];
         if (x >= n) return;
-        const uint32_t t = xcd_run(x, n), tx = d->chain_tx[y];
-        chain_rgba_tile<MM, false>(d->c[y], (int)(t % tx), (int)(t / tx));
+        const uint32_t t = xcd_run(x, n), tx = d->chain_tx[row];
+        chain_rgba_tile<MM, false>(d->c[row], (int)(t % tx), (int)(t / tx));
         return;
     }
     typedef const __attribute__((address_space(4))) ScaleJob* JobPtr;
-    const auto& j = ((JobPtr)((const __attribute__((address_space(4))) uint8_t*)d + d->jobs_off))[y - n_chains];
+    const auto& j = ((JobPtr)((const __attribute__((address_space(4))) uint8_t*)d + d->jobs_off))[row - 128u];
     const uint32_t n = j.tile_start[3];
     if (x >= n) return;
     const uint32_t t = xcd_run(x, n);
@@ -958,6 +958,19 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
         std::memset(&dj[k], 0, sizeof dj[k]);
         if (!plan_scale_job(jobs[k], dj[k])) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }
         gx = std::max(gx, dj[k].tile_start[3]); variant_max = std::max(variant_max, dj[k].variant); any_job = true;
+    }
+    // row order (MX_VIDEO_ORDER): 0 the chains' rows first, the jobs' behind them; 1 interleaved in proportion; 2 the jobs' first
+    {
+        static const int order = env_int("MX_VIDEO_ORDER", 0);
+        const int nr = n_chains + n_jobs;
+        int ci = 0, ji = 0;
+        for (int r = 0; r < nr; ++r) {
+            bool take_chain;
+            if (order == 2) take_chain = ji >= n_jobs;
+            else if (order == 1) take_chain = ci < n_chains && (ji >= n_jobs || (int64_t)ci * n_jobs <= (int64_t)ji * n_chains);
+            else take_chain = ci < n_chains;
+            d->row_of[r] = take_chain ? (uint8_t)ci++ : (uint8_t)(128 + ji++);
+        }
     }
     const size_t bytes = d->jobs_off + (size_t)n_jobs * sizeof(ScaleJob);
     const uint64_t h = fnv1a(ring.build.data(), bytes);

@@ -99,6 +99,7 @@ struct ScaleJob { ScalePlane p[3]; uint32_t tile_start[4]; uint32_t tiles_x[3]; 
 struct VideoBatchDesc {   // header | c[n_chains] | ScaleJob[n_jobs] at byte jobs_off: only the used part is uploaded
     uint32_t n_chains, n_jobs, jobs_off, _pad;
     uint32_t chain_tiles[MX_VB_MAX_CHAINS], chain_tx[MX_VB_MAX_CHAINS];
+    uint8_t row_of[MX_VB_MAX_CHAINS + MX_VB_MAX_JOBS];   // blockIdx.y -> chain k (value k) or scale job j (value 128 + j): the order rows are dispatched in
     ChainRgbaArgs c[MX_VB_MAX_CHAINS];
     ScaleJob j[MX_VB_MAX_JOBS];   // capacity only: the jobs follow the chains actually present
 };
