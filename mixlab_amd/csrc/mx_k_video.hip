@@ -191,7 +191,32 @@ __device__ __forceinline__ uint32_t pack_rgba(int r, int g, int b, int sh) {
     const uint32_t ba = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(b, 255 << sh, sh);
     return rg | (ba << 16);
 }
-template <int MM>   // matrix mode: 0 none, 1 full 32-bit products, 2 24-bit products
+// Matrix mode 3: the 3 x 4 matrix in f32, two pixels per v_pk_fma_f32.  EXACT, not approximate: R, G, B are integers 0 .. 255, the
+// coefficients are m / 4096 (a power-of-two scaling: no rounding) and the launcher takes this mode only when, per row,
+// 2 * 255 * (|m0| + |m1| + |m2|) + |2 (m3 + 2048) - 4095| < 2^24 -- every partial sum is then an integer multiple of 2^-13 below 2^11
+// in magnitude, representable in f32's 24 bits, so each fused multiply-add returns its exact result.  The constant term is
+// (m3 + 2048) / 4096 - 1/2 + 2^-13: v_cvt_pk_u8_f32 rounds to nearest-even and saturates to 0 .. 255 (probed on the chip), and a
+// multiple of 2^-12 minus 1/2 plus 2^-13 is never a tie and rounds to the floor -- the integer path's clip8(sum >> 12).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void yuv_px_pair_f32(const float* mf, int Y0, int Y1, int U, int V, uint32_t& p0, uint32_t& p1) {
+    const int D = U - 128, E = V - 128;
+    const int cr = 459 * E + 128, cg = -55 * D - 136 * E + 128, cb = 541 * D + 128;
+    const int y0 = 298 * (Y0 - 16), y1 = 298 * (Y1 - 16);
+    const uint32_t rg0 = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(y0 + cr, y0 + cg, 8);
+    const uint32_t rg1 = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(y1 + cr, y1 + cg, 8);
+    const uint32_t bb = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(y0 + cb, y1 + cb, 8);
+    const f32x2 R = {(float)(rg0 & 0xffu), (float)(rg1 & 0xffu)}, G = {(float)((rg0 >> 8) & 0xffu), (float)((rg1 >> 8) & 0xffu)};
+    const f32x2 B = {(float)(bb & 0xffu), (float)((bb >> 8) & 0xffu)};
+    f32x2 o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f32x2 c = {mf[4 * i + 3], mf[4 * i + 3]}, m0 = {mf[4 * i], mf[4 * i]}, m1 = {mf[4 * i + 1], mf[4 * i + 1]}, m2 = {mf[4 * i + 2], mf[4 * i + 2]};
+        o[i] = __builtin_elementwise_fma(m0, R, __builtin_elementwise_fma(m1, G, __builtin_elementwise_fma(m2, B, c)));
+    }
+    p0 = __builtin_amdgcn_cvt_pk_u8_f32(o[2].x, 2u, __builtin_amdgcn_cvt_pk_u8_f32(o[1].x, 1u, __builtin_amdgcn_cvt_pk_u8_f32(o[0].x, 0u, 0xff000000u)));
+    p1 = __builtin_amdgcn_cvt_pk_u8_f32(o[2].y, 2u, __builtin_amdgcn_cvt_pk_u8_f32(o[1].y, 1u, __builtin_amdgcn_cvt_pk_u8_f32(o[0].y, 0u, 0xff000000u)));
+}
+template <int MM>   // matrix mode: 0 none, 1 full 32-bit products, 2 24-bit products (3: yuv_px_pair_f32)
 __device__ __forceinline__ uint32_t yuv_px(const int* m, int Y, int U, int V) {
     const int C = Y - 16, D = U - 128, E = V - 128;
     const int rs = 298 * C + 459 * E + 128, gs = 298 * C - 55 * D - 136 * E + 128, bs = 298 * C + 541 * D + 128;
@@ -360,12 +385,24 @@ __device__ __forceinline__ uint32_t cs_mask_quad(uint32_t quad, uint32_t blank, 
 
 template <int MM, bool SC, class ArgsRef>   // ArgsRef: ChainRgbaArgs in kernel arguments, or in the constant address space (k_video_batch)
 __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const int by) {
-    // tile of 128 x 32 luma pixels; a lane owns 8 pixels x 2 rows and their 4 + 4 chroma samples
+    // a lane owns a UNIT of 8 pixels x 2 rows and their 4 + 4 chroma samples.  With inline-scaled layers (SC) a block is a tile of
+    // 128 x 32 luma pixels (the scaler windows in LDS are per tile).  Without them nothing ties a block to a rectangle, and a block
+    // takes 256 CONSECUTIVE units in row-major order (bx = the block's index, by unused): a wave's loads are 512 contiguous bytes of
+    // one luma row (256 of a chroma row) instead of 128 (64) bytes of four rows each -- whole DRAM bursts and cache lines per request,
+    // no half-used chroma lines, and no idle lanes at the right edge whatever the width.
     const int tid = threadIdx.x;
     const int cb = tid & 15, rp = tid >> 4;
-    const int X0 = bx * 128, Y0 = by * 32;
-    const uint32_t xb = (uint32_t)(X0 / 8 + cb);     // 8-pixel column block
-    const uint32_t yb = (uint32_t)(Y0 / 2 + rp);     // row pair
+    const int X0 = SC ? bx * 128 : 0, Y0 = SC ? by * 32 : 0;
+    uint32_t xb, yb;
+    if constexpr (SC) {
+        xb = (uint32_t)(X0 / 8 + cb);     // 8-pixel column block
+        yb = (uint32_t)(Y0 / 2 + rp);     // row pair
+    } else {
+        const uint32_t upr = (a.width + 7u) >> 3, idx = (uint32_t)bx * 256u + (uint32_t)tid;
+        uint32_t q = __umulhi(idx, a.upr_magic);      // idx / upr or one less (upr_magic = floor(2^32 / upr), idx < 2^32 / upr)
+        q += (idx - q * upr >= upr) ? 1u : 0u;
+        yb = q; xb = idx - q * upr;
+    }
     const bool valid = xb * 8 < a.width && yb * 2 < a.height;
     // per source: 2 dwords of Y for each of the two rows, one dword of U, one of V  (6 dwords)
     uint32_t L[MX_CHAIN_MAX_SRC][6];
@@ -492,11 +529,11 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
         }
     }
     uint32_t v[6];
-    uint32_t fa[MX_CHAIN_MAX_SRC - 1], fb[MX_CHAIN_MAX_SRC - 1]; int mtx[12];   // wave-uniform copies: SGPRs
+    uint32_t fa[MX_CHAIN_MAX_SRC - 1], fb[MX_CHAIN_MAX_SRC - 1]; int mtx[12]; float mtf[12];   // wave-uniform copies: SGPRs
 #pragma unroll
     for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) { fa[k] = a.fa_pk[k]; fb[k] = a.fb_pk[k]; }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) mtx[k] = a.m[k];
+    for (int k = 0; k < 12; ++k) { if (MM == 3) mtf[k] = a.mf[k]; else mtx[k] = a.m[k]; }
     chain_eval_pk<6>(v, L, a.n_src, fa, fb);
     if (!valid) return;
 #pragma unroll
@@ -509,9 +546,15 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
             const uint32_t yw = v[2 * r + g4];
             const uint32_t cu = (v[4] >> (16 * g4)) & 0xffffu, cv = (v[5] >> (16 * g4)) & 0xffffu;
             uint32_t px[4];
+            if constexpr (MM == 3) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                px[k] = yuv_px<MM>(mtx, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
+                for (int k = 0; k < 4; k += 2)
+                    yuv_px_pair_f32(mtf, (int)((yw >> (8 * k)) & 0xff), (int)((yw >> (8 * k + 8)) & 0xff), (int)((cu >> (4 * k)) & 0xff), (int)((cv >> (4 * k)) & 0xff), px[k], px[k + 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    px[k] = yuv_px<MM>(mtx, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
+            }
             const uint32_t x = xb * 8 + g4 * 4;
             if (x + 4 <= a.width) *reinterpret_cast<uint4*>(o + g4 * 16) = make_uint4(px[0], px[1], px[2], px[3]);
             else for (uint32_t k = 0; x + k < a.width; ++k) reinterpret_cast<uint32_t*>(o + g4 * 16)[k] = px[k];
@@ -521,7 +564,8 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
 template <int MM, bool SC>
 __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a, uint32_t tx, uint32_t n_tiles) {
     const uint32_t t = xcd_run(blockIdx.x, n_tiles);
-    chain_rgba_tile<MM, SC>(a, (int)(t % tx), (int)(t / tx));
+    if constexpr (SC) chain_rgba_tile<MM, SC>(a, (int)(t % tx), (int)(t / tx));
+    else chain_rgba_tile<MM, SC>(a, (int)t, 0);
 }
 
 // A blank row per device (Y = 0x00, U = V = 0x80: what AvFrame::blank writes, frame.rs:128-132), 32 KB each, read with stride 0 by the
@@ -550,7 +594,12 @@ static void chain_blank_planes(ChainRgbaArgs& a) {   // kernels without inline-s
 }
 // what the launcher derives from the arguments once per launch: the matrix mode (24-bit products when every entry fits) and the
 // per-step cross-fade factors as packed u16 pairs (chain_eval_pk)
+static uint32_t chain_strip_blocks(const ChainRgbaArgs& a) {   // blocks of 256 units (8 pixels x 2 rows) in row-major order
+    const uint64_t units = (uint64_t)((a.width + 7u) >> 3) * ((a.height + 1u) >> 1);
+    return (uint32_t)((units + 255u) / 256u);
+}
 static int chain_matrix_mode(ChainRgbaArgs& a) {
+    { const uint32_t upr = std::max(1u, (a.width + 7u) >> 3); a.upr_magic = (uint32_t)std::min<uint64_t>(0xffffffffull, (1ull << 32) / upr); a._pad0 = 0; }
     // A step whose factor for the running composite is 255 returns it unchanged -- (255 v + 0 o) / 255 = v exactly -- and one whose factor
     // is 0 returns the other layer exactly: a fader at either end of its travel (where a fader usually rests).  Such steps are dropped
     // here, bit for bit the same picture: the first kind leaves its layer unread, the second restarts the chain at its layer.
@@ -577,6 +626,20 @@ static int chain_matrix_mode(ChainRgbaArgs& a) {
     bool fits = true;
     for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] < -(1 << 23) || a.m[k] >= (1 << 23))) fits = false;
     a.use_matrix = fits ? 2 : 1;
+    static const int no_f32 = env_int("MX_VIDEO_NO_F32_MATRIX", 0);
+    bool small = fits && !no_f32;
+    for (int i = 0; i < 3 && small; ++i) {
+        const int64_t mag = 2 * 255 * (std::llabs((long long)a.m[4 * i]) + std::llabs((long long)a.m[4 * i + 1]) + std::llabs((long long)a.m[4 * i + 2]))
+                            + std::llabs(2 * ((long long)a.m[4 * i + 3] + 2048) - 4095);
+        if (mag >= (1ll << 24)) small = false;
+    }
+    if (small) {
+        for (int i = 0; i < 3; ++i) {
+            for (int k = 0; k < 3; ++k) a.mf[4 * i + k] = (float)a.m[4 * i + k] / 4096.0f;
+            a.mf[4 * i + 3] = (float)(2 * ((long long)a.m[4 * i + 3] + 2048) - 4095) / 8192.0f;
+        }
+        a.use_matrix = 3;
+    }
     return a.use_matrix;
 }
 void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
@@ -588,15 +651,18 @@ void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
     const dim3 grid(n_tiles);
     if (a.n_scaled) {
         const size_t lds = CS_T_BYTES + (size_t)a.n_scaled * CS_S_BYTES;
-        if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
+        if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
+        else if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
         else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
         else hipLaunchKernelGGL((k_fade_chain_rgba<0, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
         return;
     }
     chain_blank_planes(a);
-    if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), grid, dim3(256), 0, s, a, tx, n_tiles);
-    else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), grid, dim3(256), 0, s, a, tx, n_tiles);
-    else hipLaunchKernelGGL((k_fade_chain_rgba<0, false>), grid, dim3(256), 0, s, a, tx, n_tiles);
+    const uint32_t nb = chain_strip_blocks(a);   // the strip form: tx = 0 marks it for the kernel
+    if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+    else if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+    else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+    else hipLaunchKernelGGL((k_fade_chain_rgba<0, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
 }
 
 // Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
@@ -697,18 +763,20 @@ __device__ __forceinline__ void sc_hcol_fixed(const uint8_t* S, int hf /* first 
 // 256), Q = staging passes of 256 / CPR rows each.  Interior tiles (the whole window inside the source row, 16-byte aligned planes)
 // stage with ONE predicated dwordx4 load per lane and pass -- nothing is fetched that the tile does not filter; tiles at the picture's
 // left / right edge, unaligned or interleaved (nv12 chroma) sources take sc_stage's general path into the same window.
-template <int CPR, int Q, int HR, class PlaneRef>
+// TH = output rows per tile (a multiple of 8): 32, or 40 where 40 output rows still need no more than 32 window rows (upscales by >= ~1.45):
+// the H pass filters a fixed 2 HR rows whatever the window holds, so more output rows per tile mean fewer H values per output.
+template <int CPR, int Q, int HR, int TH, class PlaneRef>
 __device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile, const uint32_t tiles_x, const int s_rows) {
     constexpr int SS = CPR * 16, RPP = 256 / CPR;
     constexpr int ROWS = 2 * HR;               // T2 rows in LDS (the launcher's s_rows <= ROWS); the window has one row more
     const int ty = (int)(tile / tiles_x), tx = (int)(tile - (uint32_t)ty * tiles_x);
-    const int ox0 = tx * SC_TW, oy0 = ty * SC_TH;
+    const int ox0 = tx * SC_TW, oy0 = ty * TH;
     extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
     uint32_t* const T2 = reinterpret_cast<uint32_t*>(sc_smem);                 // [ROWS][SC_TW] pairs (p, p + 1) of H-filtered rows
     uint8_t* const S = sc_smem + (size_t)ROWS * SC_TW * 4;                     // [ROWS + 1][SS] source window, signed bytes
     const int tid = threadIdx.x;
     const int dw = (int)p.dw, dh = (int)p.dh, sw = (int)p.sw, sh = (int)p.sh;
-    const int oxe = min(ox0 + SC_TW, dw), oye = min(oy0 + SC_TH, dh);
+    const int oxe = min(ox0 + SC_TW, dw), oye = min(oy0 + TH, dh);
     // source window of the tile: wave-uniform integer arithmetic
     const uint32_t dhf = p.dh_full ? p.dh_full : p.dh;
     const int cx0 = sc_first_tap_m((uint32_t)ox0, p.sw, p.dw, p.mh), cxl = sc_first_tap_m((uint32_t)(oxe - 1), p.sw, p.dw, p.mh);
@@ -719,9 +787,9 @@ __device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile
     const int oxi = tid & (SC_TW - 1);
     const uint4 hx = p.hx[min(ox0 + oxi, dw - 1)];
     const int cg = tid & 31, oyr = tid >> 5;                  // V pass: pixel group (4 columns) and first row; rows oyr + 8k
-    uint4 vx[4];
+    uint4 vx[TH / 8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) vx[k] = p.vx[min(oy0 + oyr + 8 * k, dh - 1)];
+    for (int k = 0; k < TH / 8; ++k) vx[k] = p.vx[min(oy0 + oyr + 8 * k, dh - 1)];
     // ---- stage ----
     const int row_lo = max(0, (int)p.h_row0), row_hi = min(sh - 1, (int)(p.h_row0 + p.h_rows) - 1);
     const int n_chunks = (w.nc4 + 3) >> 2;
@@ -756,7 +824,7 @@ __device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile
         const uint32_t off0 = (uint32_t)(oy0 + oyr) * p.dst_stride + (uint32_t)(ox0 + oxg);   // 32-bit offsets from the (scalar) plane base
         const bool whole = ox0 + oxg + 4 <= dw && ((reinterpret_cast<uintptr_t>(p.dst) | p.dst_stride) & 3u) == 0;   // ox0 + oxg is a multiple of 4
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < TH / 8; ++k) {
             if (oy0 + oyr + 8 * k >= dh) break;
             const uint32_t quad = sc_vquad(T2, SC_TW, (int)vx[k].z - ry0, oxg, make_uint2(vx[k].x, vx[k].y));
             uint8_t* o = p.dst + (size_t)(off0 + (uint32_t)(8 * k) * p.dst_stride);
@@ -765,12 +833,14 @@ __device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile
         }
     }
 }
-// variant (launcher-chosen, wave-uniform): 0 = windows <= 128 bytes x 32 rows (the 720p -> 1080p class), 1 = 128 x 48, 2 = 256 x 48
+// variant (launcher-chosen, wave-uniform): 0 = windows <= 128 bytes x 32 rows, 1 = 128 x 48, 2 = 256 x 48 (tiles of 128 x 32 outputs);
+// 3 = 128 bytes x 32 rows under tiles of 128 x 40 outputs (the 720p -> 1080p class)
 template <class PlaneRef>
 __device__ __forceinline__ void scale_tile_variant(const uint32_t variant, PlaneRef& p, const uint32_t tile, const uint32_t tiles_x, const int s_rows) {
-    if (variant == 0u) scale_tile_body<8, 1, 16>(p, tile, tiles_x, s_rows);
-    else if (variant == 1u) scale_tile_body<8, 2, 24>(p, tile, tiles_x, s_rows);
-    else scale_tile_body<16, 3, 24>(p, tile, tiles_x, s_rows);
+    if (variant == 3u) scale_tile_body<8, 1, 16, 40>(p, tile, tiles_x, s_rows);
+    else if (variant == 0u) scale_tile_body<8, 1, 16, 32>(p, tile, tiles_x, s_rows);
+    else if (variant == 1u) scale_tile_body<8, 2, 24, 32>(p, tile, tiles_x, s_rows);
+    else scale_tile_body<16, 3, 24, 32>(p, tile, tiles_x, s_rows);
 }
 __device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32_t block) {
     int plane = 0;
@@ -780,7 +850,7 @@ __device__ __forceinline__ void scale_tile(const ScaleBatchArgs& a, const uint32
 }
 // LDS of a tile body: [2 HR][128] row pairs + [2 HR + 1][SS] window
 static size_t scale_tile_lds(uint32_t variant) {
-    const size_t hr = variant == 0u ? 16 : 24, ss = variant == 2u ? 256 : 128;
+    const size_t hr = (variant == 0u || variant == 3u) ? 16 : 24, ss = variant == 2u ? 256 : 128;
     return 2 * hr * SC_TW * 4 + (2 * hr + 1) * ss;
 }
 
@@ -805,8 +875,7 @@ __global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc)
     if (row < 128u) {
         const uint32_t n = d->chain_tiles[row];
         if (x >= n) return;
-        const uint32_t t = xcd_run(x, n), tx = d->chain_tx[row];
-        chain_rgba_tile<MM, false>(d->c[row], (int)(t % tx), (int)(t / tx));
+        chain_rgba_tile<MM, false>(d->c[row], (int)xcd_run(x, n), 0);
         return;
     }
     typedef const __attribute__((address_space(4))) ScaleJob* JobPtr;
@@ -866,11 +935,28 @@ static bool plan_scale_tiles(const ScaleBatchArgs& a, ScaleBatchArgs& b, uint32_
     // staging shape of the tile body (scale_tile2): windows up to 128 bytes wide stage 8 chunks per row, 32 rows per pass
     b.variant = s_stride <= 128 ? (s_rows <= 32 ? 0u : 1u) : 2u;
     s_stride = s_stride <= 128 ? 128u : 256u;
+    // tiles of 40 output rows where their windows (exactly, from the tap spec) still fit the 32 rows one staging pass holds
+    static const int no_th40 = env_int("MX_SCALE_NO_TH40", 0);
+    uint32_t th = SC_TH;
+    if (b.variant == 0u && !no_th40) {
+        bool fits = true;
+        for (uint32_t i = 0; i < a.n && fits; ++i) {
+            const ScalePlane& p = a.p[i];
+            if (!p.dw || !p.dh) continue;
+            const uint32_t dhf = p.dh_full ? p.dh_full : p.dh;
+            for (uint32_t oy0 = 0; oy0 < p.dh && fits; oy0 += 40u) {
+                const uint32_t oye = std::min(oy0 + 40u, p.dh);
+                const int ry0 = sc_first_tap_m(oy0 + p.oy_base, p.sh, dhf, p.mv), ryl = sc_first_tap_m(oye - 1u + p.oy_base, p.sh, dhf, p.mv);
+                if (ryl + 4 - ry0 > 32) fits = false;
+            }
+        }
+        if (fits) { b.variant = 3u; th = 40u; s_rows = 32u; }
+    }
     lds = scale_tile_lds(b.variant);
     for (uint32_t i = 0; i < a.n; ++i) {
         b.tile_start[i] = total;
         b.tiles_x[i] = (a.p[i].dw + SC_TW - 1) / SC_TW;
-        total += b.tiles_x[i] * ((a.p[i].dh + SC_TH - 1) / SC_TH);
+        total += b.tiles_x[i] * ((a.p[i].dh + th - 1) / th);
     }
     for (uint32_t i = a.n; i <= MX_SCALE_BATCH_PLANES; ++i) { b.tile_start[i] = total; if (i < MX_SCALE_BATCH_PLANES) b.tiles_x[i] = 1; }
     b.s_rows = s_rows; b.s_stride = s_stride;
@@ -941,7 +1027,7 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     if (!ring.copy) hip_check(hipStreamCreateWithFlags(&ring.copy, hipStreamNonBlocking), "hipStreamCreate(descriptor uploads)");
     if (ring.build.size() < VB_BYTES) ring.build.assign(VB_BYTES, 0);
     VideoBatchDesc* d = reinterpret_cast<VideoBatchDesc*>(ring.build.data());
-    uint32_t gx = 0, variant_max = 0; bool any_job = false;
+    uint32_t gx = 0; size_t lds = 0;
     std::memset(d, 0, VB_HEADER);
     d->n_chains = (uint32_t)n_chains; d->n_jobs = (uint32_t)n_jobs; d->jobs_off = (uint32_t)(VB_HEADER + (size_t)n_chains * sizeof(ChainRgbaArgs)); d->_pad = 0;
     for (int k = 0; k < n_chains; ++k) {
@@ -949,15 +1035,15 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
         std::memset(&c, 0, sizeof c);             // padding bytes take part in the comparison
         c = chains[k];
         chain_matrix_mode(c); chain_blank_planes(c);
-        d->chain_tx[k] = (c.width + 127) / 128;
-        d->chain_tiles[k] = d->chain_tx[k] * ((c.height + 31) / 32);
+        d->chain_tx[k] = 0;
+        d->chain_tiles[k] = chain_strip_blocks(c);
         gx = std::max(gx, d->chain_tiles[k]);
     }
     ScaleJob* dj = reinterpret_cast<ScaleJob*>(ring.build.data() + d->jobs_off);
     for (int k = 0; k < n_jobs; ++k) {
         std::memset(&dj[k], 0, sizeof dj[k]);
         if (!plan_scale_job(jobs[k], dj[k])) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }
-        gx = std::max(gx, dj[k].tile_start[3]); variant_max = std::max(variant_max, dj[k].variant); any_job = true;
+        gx = std::max(gx, dj[k].tile_start[3]); lds = std::max(lds, scale_tile_lds(dj[k].variant));
     }
     // row order (MX_VIDEO_ORDER): 0 the chains' rows first, the jobs' behind them; 1 interleaved in proportion; 2 the jobs' first
     {
@@ -997,9 +1083,9 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     }
     sl->used_at = ++ring.clock;
     const dim3 grid((gx + 7u) & ~7u, (uint32_t)(n_chains + n_jobs));
-    const size_t lds = any_job ? scale_tile_lds(variant_max) : 0;
     const VideoBatchDesc* dd = reinterpret_cast<const VideoBatchDesc*>(sl->dev);
-    if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd);
+    if (mm == 3) hipLaunchKernelGGL(k_video_batch<3>, grid, dim3(256), lds, s, dd);
+    else if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd);
     else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd);
     else hipLaunchKernelGGL(k_video_batch<0>, grid, dim3(256), lds, s, dd);
     hip_check(hipEventRecord(sl->done, s), "hipEventRecord");

@@ -52,6 +52,7 @@ struct RgbaArgs {
     const uint8_t* y; const uint8_t* u; const uint8_t* v; uint8_t* rgba;
     uint32_t y_stride, u_stride, v_stride, rgba_stride, width, height;
     int32_t use_matrix; int32_t m[12];
+    float mf[12];   // launcher-filled when every row of m is small enough for exact f32 sums (use_matrix == 3): m / 4096, the constant carrying the rounding
 };
 
 void launch_crossfade(const FadeArgs& a, hipStream_t s);
@@ -88,7 +89,9 @@ struct ChainRgbaArgs {   // the same chain feeding the build-specified YUV420P -
     uint32_t fade[MX_CHAIN_MAX_SRC - 1]; uint32_t v_is_a[MX_CHAIN_MAX_SRC - 1];
     uint32_t fa_pk[MX_CHAIN_MAX_SRC - 1], fb_pk[MX_CHAIN_MAX_SRC - 1];   // launcher-filled from fade / v_is_a: the step's two factors as u16 x 2
     uint8_t* rgba; uint32_t rgba_stride, width, height;
+    uint32_t upr_magic, _pad0;   // launcher-filled: floor(2^32 / units per row pair), units of 8 pixels (the strip form of the tile walks units in row-major order)
     int32_t use_matrix; int32_t m[12];
+    float mf[12];   // launcher-filled when every row of m is small enough for exact f32 sums (use_matrix == 3): m / 4096, the constant carrying the rounding
     uint32_t n_scaled; uint32_t scaled_src[MX_CHAIN_MAX_SCALED];   // chain position of each inline-scaled layer (its ChainSrc planes are nullptr)
     ChainScale sc[MX_CHAIN_MAX_SCALED];
 };

@@ -60,6 +60,8 @@ def test_crossfade_missing_channel_reads_blank(which):
 
 @pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((640, 480), (1920, 1080)), ((1920, 1080), (560, 350)),
                                   ((1000, 300), (640, 640)), ((64, 64), (64, 64)), ((322, 182), (1120, 700)),
+                                  # tiles of 40 output rows (upscales whose 40-row windows fit one staging pass) and ratios either side of that class
+                                  ((640, 360), (960, 540)), ((660, 372), (960, 542)), ((400, 300), (800, 600)), ((500, 282), (730, 412)), ((96, 54), (134, 76)),
                                   # downscales (widened kernel): monitor sizes, a 12.8x shrink, a ratio just above 1, awkward sizes
                                   ((1920, 1080), (1120, 700)), ((4096, 2160), (320, 180)), ((1922, 1082), (1920, 1080)), ((1002, 564), (400, 226))])
 def test_dynamic_scale_letterbox_bit_exact_vs_build_spec(geom):
@@ -154,7 +156,14 @@ def test_scale_geometry_examples():
 
 
 @pytest.mark.parametrize("matrix", [None, [4096, 0, 0, 0, 0, 4096, 0, 0, 0, 0, 4096, 0],
-                                     [3000, 800, 296, 40960, -200, 4500, -204, 0, 100, -300, 4296, -8192]])
+                                     [3000, 800, 296, 40960, -200, 4500, -204, 0, 100, -300, 4296, -8192],
+                                     # the f32 form of the matrix (exact while the row sums stay below 2^24 in units of 2^-13): negative sums, sums past 255,
+                                     # a row at the edge of the bound; then rows beyond it (24-bit integer products) and beyond 24 bits (32-bit products)
+                                     [-4096, 0, 0, 1044480, 0, -4096, 0, 1044480, 0, 0, -4096, 1044480],
+                                     [8192, 8192, 8192, -1000000, -3000, -3000, -3000, 4095, 1, 1, 1, 2047],
+                                     [10922, 10922, 10922, 30000, 4096, 0, 0, -2048, 0, 0, 4097, -2049],
+                                     [20000, 20000, 20000, -7000000, 0, 4096, 0, 0, -20000, 0, 0, 2000000],
+                                     [8400000, 0, 0, 0, 0, 4096, 0, 0, 0, 0, -8400000, 0]])
 @pytest.mark.parametrize("size", [(1920, 1080), (66, 34), (130, 70)])
 def test_yuv_to_rgba_bit_exact_vs_build_spec(size, matrix):
     w, h = size
