@@ -823,13 +823,18 @@ __device__ __forceinline__ void scale_tile_body(PlaneRef& p, const uint32_t tile
     if (ox0 + oxg < dw) {
         const uint32_t off0 = (uint32_t)(oy0 + oyr) * p.dst_stride + (uint32_t)(ox0 + oxg);   // 32-bit offsets from the (scalar) plane base
         const bool whole = ox0 + oxg + 4 <= dw && ((reinterpret_cast<uintptr_t>(p.dst) | p.dst_stride) & 3u) == 0;   // ox0 + oxg is a multiple of 4
+        // every row's quad is computed (rows below the picture use the last row's entry: their reads stay inside T2), only the stores are
+        // conditional: the TH / 4 LDS reads go out in one burst instead of one round trip per row
+        uint32_t quad[TH / 8];
+#pragma unroll
+        for (int k = 0; k < TH / 8; ++k) quad[k] = sc_vquad(T2, SC_TW, (int)vx[k].z - ry0, oxg, make_uint2(vx[k].x, vx[k].y));
 #pragma unroll
         for (int k = 0; k < TH / 8; ++k) {
-            if (oy0 + oyr + 8 * k >= dh) break;
-            const uint32_t quad = sc_vquad(T2, SC_TW, (int)vx[k].z - ry0, oxg, make_uint2(vx[k].x, vx[k].y));
-            uint8_t* o = p.dst + (size_t)(off0 + (uint32_t)(8 * k) * p.dst_stride);
-            if (whole) *reinterpret_cast<uint32_t*>(o) = quad;
-            else for (int j = 0; j < 4 && ox0 + oxg + j < dw; ++j) o[j] = (uint8_t)(quad >> (8 * j));
+            if (oy0 + oyr + 8 * k < dh) {
+                uint8_t* o = p.dst + (size_t)(off0 + (uint32_t)(8 * k) * p.dst_stride);
+                if (whole) *reinterpret_cast<uint32_t*>(o) = quad[k];
+                else for (int j = 0; j < 4 && ox0 + oxg + j < dw; ++j) o[j] = (uint8_t)(quad[k] >> (8 * j));
+            }
         }
     }
 }
