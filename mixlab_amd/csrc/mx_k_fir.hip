@@ -130,41 +130,70 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict
     const uint32_t up = d.up, down = d.down;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);                       // [P][up]
-    double2* win = reinterpret_cast<double2*>(tab + (size_t)P * up);     // [win_cap] widened once while staging
+    // The window as TWO planes of doubles (left, right), widened once while staging.  As interleaved double2 a tap step is one
+    // ds_read_b128 per lane, and that instruction serves the wave in the lane groups {0-3, 12-15, 20-27}, ...: with lanes on
+    // (nearly) consecutive frames two lanes of a group meet on a bank and every read costs twice (profiles/r03: SQ_LDS_BANK_CONFLICT
+    // 2x the LDS-active cycles).  ds_read_b64 serves lanes 0-31 and 32-63 as they are: 32 (nearly) consecutive doubles cover the 64
+    // banks at most once -- two conflict-free 2-cycle reads instead of one 8-cycle one.
+    const uint32_t cap = (win_cap + 1u) & ~1u;
+    double* xl = tab + (size_t)P * up;                                   // [cap]
+    double* xr = xl + cap;                                               // [cap]
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < (uint32_t)P * up; i += 256) {
         const uint32_t ph = i / (uint32_t)P, k = i - ph * (uint32_t)P;
         tab[(size_t)k * up + ph] = d.taps[i];
     }
     const bool small = (uint64_t)255 * down + up < (1ull << 32);          // lane offsets fit 32 bits (always, for audio ratios)
-    for (size_t blk = (size_t)blockIdx.x * 256; blk < out_frames; blk += (size_t)gridDim.x * 256) {
+    // geometry of the group of 256 outputs from `blk` on: the window's first input frame, its length, the first output's remainder
+    struct Grp { long long f0; uint32_t cnt, r0; };
+    auto group_of = [&](size_t blk) {
+        Grp g;
         const uint64_t num0 = (out_base + blk) * down;
         const uint64_t n0_abs = num0 / up;                                // block-uniform
-        const uint32_t r0 = (uint32_t)(num0 - n0_abs * up);
+        g.r0 = (uint32_t)(num0 - n0_abs * up);
         const uint32_t last = (uint32_t)min((size_t)255, out_frames - 1 - blk);
-        const uint32_t span = (uint32_t)((r0 + (uint64_t)last * down) / up);   // n of the last output relative to n0
-        const long long f0 = (long long)(n0_abs - in_base) - H;           // input index of win[0]
-        const uint32_t cnt = min(span + 1u + (uint32_t)H, win_cap);
-        for (uint32_t w = tid; w < cnt; w += 256) {
-            const long long f = f0 + w;
-            float2 v = make_float2(0.f, 0.f);
+        const uint32_t span = (uint32_t)((g.r0 + (uint64_t)last * down) / up);   // n of the last output relative to n0
+        g.f0 = (long long)(n0_abs - in_base) - H;                         // input index of window frame 0
+        g.cnt = min(span + 1u + (uint32_t)H, win_cap);
+        return g;
+    };
+    // a window is at most 256 * down / up + P frames: up to `per` frames per lane (1 for upsampling ratios and P <= 256 * (1 - down / up))
+    auto fetch = [&](const Grp& g, uint32_t w) {
+        const long long f = g.f0 + w;
+        float2 v = make_float2(0.f, 0.f);
+        if (w < g.cnt) {
             if (f >= 0) { if (d.in) v = reinterpret_cast<const float2*>(d.in)[f]; }
             else { const long long hh = (long long)H + f; if (hh >= 0) v = d.hist[hh]; }
-            win[w] = make_double2((double)v.x, (double)v.y);
         }
+        return v;
+    };
+    const bool one = win_cap <= 256u;                                     // the whole window is one frame per lane: prefetched in a register
+    size_t blk = (size_t)blockIdx.x * 256;
+    Grp g = blk < out_frames ? group_of(blk) : Grp{0, 0u, 0u};
+    float2 pre = (one && blk < out_frames) ? fetch(g, tid) : make_float2(0.f, 0.f);
+    for (; blk < out_frames; blk += (size_t)gridDim.x * 256) {
+        if (one) { if ((uint32_t)tid < g.cnt) { xl[tid] = (double)pre.x; xr[tid] = (double)pre.y; } }
+        else for (uint32_t w = tid; w < g.cnt; w += 256) { const float2 v = fetch(g, w); xl[w] = (double)v.x; xr[w] = (double)v.y; }
         __syncthreads();
+        const uint32_t r0 = g.r0;
+        // the next group's frames are requested now and arrive while this group's taps run: a block pays the round trip to memory once, not per group
+        const size_t nxt = blk + (size_t)gridDim.x * 256;
+        if (nxt < out_frames) { g = group_of(nxt); if (one) pre = fetch(g, tid); }
         if (blk + tid < out_frames) {
             uint32_t dn, phase;
             if (small) { const uint32_t q = r0 + (uint32_t)tid * down; dn = q / up; phase = q - dn * up; }
             else { const uint64_t q = r0 + (uint64_t)tid * down; dn = (uint32_t)(q / up); phase = (uint32_t)(q - (uint64_t)dn * up); }
-            const double2* x = win + H + dn;                              // x[0] = frame n of this output
-            const double* h = tab + phase;
+            // volatile: each read stays a ds_read_b64 of its own (merged into ds_read2_b64 pairs they are served 16 lanes at a time)
+            typedef const volatile __attribute__((address_space(3))) double* LdsD;
+            const LdsD l = (LdsD)(xl + H + dn);                           // l[0] = frame n of this output
+            const LdsD r = (LdsD)(xr + H + dn);
+            const LdsD h = (LdsD)(tab + phase);
             double al = 0.0, ar = 0.0;
             for (int k = 0; k < P; ++k) {
                 const double c = h[(size_t)k * up];
-                const double2 v = x[-k];
-                al = al + c * v.x;
-                ar = ar + c * v.y;
+                const double vl = l[-k], vr = r[-k];
+                al = al + c * vl;
+                ar = ar + c * vr;
             }
             reinterpret_cast<float2*>(d.out)[blk + tid] = make_float2((float)al, (float)ar);
         }
@@ -212,10 +241,13 @@ __global__ __launch_bounds__(256) void k_resample_history(const ResampleDesc* __
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles, uint32_t win_frames,
                      size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s) {
     if (!n || !out_frames) return;
-    const size_t lds = (size_t)tab_doubles * sizeof(double) + (size_t)win_frames * sizeof(double2);
+    const size_t lds = (size_t)tab_doubles * sizeof(double) + (size_t)((win_frames + 1u) & ~1u) * 2 * sizeof(double);
     if (lds <= 60 * 1024) {
-        // few blocks per channel, each walking many 256-output groups: the table is loaded once per block
-        const uint32_t per_ch = (uint32_t)std::max<size_t>(1, std::min<size_t>((out_frames + 255) / 256, std::max<uint32_t>(1u, 4096u / n)));
+        // few blocks per channel, each walking many 256-output groups (the table is loaded once per block): as many blocks as the chip
+        // holds at once, so they all start together, do the same work and end together -- no partly filled last round
+        static const uint32_t cus = [] { int dev = 0, n_cu = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256; return (uint32_t)std::max(n_cu, 1); }();
+        const uint32_t resident = cus * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+        const uint32_t per_ch = (uint32_t)std::max<size_t>(1, std::min<size_t>((out_frames + 255) / 256, std::max<uint32_t>(1u, resident / n)));
         hipLaunchKernelGGL(k_resample, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
     } else {
         hipLaunchKernelGGL(k_resample_gather, dim3(grid_x(out_frames, 256, 1024), n), dim3(256), 0, s, d, out_frames, out_base, in_base);
