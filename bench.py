@@ -855,15 +855,21 @@ def main():
                     if evs[i] is not None:
                         g.schedule_params_batch(evs[i][0], evs[i][1])
                     g.run_ticks(tick0 + i * Ts, Ts)
-                for i in range(3):
+                sub(0)
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                for i in range(1, 3):
                     sub(i)
+                host_free_s = (time.perf_counter() - th) / 2     # two submissions into an idle queue: what the host needs when nothing makes it wait
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(3, n_sub + 3):
                     sub(i)
+                host_s = time.perf_counter() - t0        # the host's share: scheduling + enqueueing, before the device is waited for
                 torch.cuda.synchronize()
                 dts = time.perf_counter() - t0
-                t_sweep[str(Ts)] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub}
+                t_sweep[str(Ts)] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub,
+                                    "host_ms_per_step": round(host_s / n_sub * 1e3, 4), "host_ms_per_step_idle_queue": round(host_free_s * 1e3, 4)}
                 tick0 += (n_sub + 3) * Ts
             # T = 64 again on a graph built with MX_FLAG_OVERLAP_TAIL: the Mixer bank of submission k on a second stream beside submission
             # k + 1's EqThree group.  At T = 2048 that loses (the EqThree launch is exactly one round of three waves per SIMD and Mixer waves
