@@ -318,3 +318,9 @@ def test_crossfade_division_identity_the_packed_kernel_relies_on():
     x1 = x + 1
     assert np.array_equal((x1 + (x1 >> 8)) >> 8, x // 255)
     assert int((x1 + (x1 >> 8)).max()) < 65536
+
+
+def test_graft_entry_build_is_what_the_driver_calls_and_it_passes():
+    """build() compiles (here: finds up to date) the library and the oracle and checks the loaded library against the header's ABI version."""
+    import __graft_entry__ as entry
+    entry.build()
