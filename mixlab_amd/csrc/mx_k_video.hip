@@ -872,24 +872,41 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a, u
 // XCD in every row and xcd_run hands each XCD a contiguous run of a row's tiles.  The descriptor lives in device memory (it is far
 // beyond the 4 KB of kernel arguments) and is read through the constant address space: scalar loads.
 typedef const __attribute__((address_space(4))) VideoBatchDesc* VbDescPtr;
+__device__ __forceinline__ uint32_t pin_s32(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
+template <class T> __device__ __forceinline__ T* pin_sptr(T* v) { uint64_t u = (uint64_t)(uintptr_t)v; asm volatile("" : "+s"(u)); return (T*)(uintptr_t)u; }
 template <int MM>
-__global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc) {
-    VbDescPtr d = (VbDescPtr)desc;
+__global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc, const VbRows rows) {
+    typedef const __attribute__((address_space(4))) uint8_t* BytePtr;
     const uint32_t x = blockIdx.x;
-    const uint32_t row = d->row_of[blockIdx.y];
-    if (row < 128u) {
-        const uint32_t n = d->chain_tiles[row];
-        if (x >= n) return;
-        chain_rgba_tile<MM, false>(d->c[row], (int)xcd_run(x, n), 0);
+    VbRow r = rows.r[blockIdx.y];                        // kernel arguments: the whole record requested at once, waited for once
+    asm volatile("" : "+s"(r.is_job), "+s"(r.n_tiles), "+s"(r.off), "+s"(r.ts1), "+s"(r.ts2), "+s"(r.tx0), "+s"(r.tx1), "+s"(r.tx2), "+s"(r.variant), "+s"(r.s_rows));
+    const uint32_t n = r.n_tiles;
+    if (x >= n) return;
+    if (!r.is_job) {
+        typedef const __attribute__((address_space(4))) ChainRgbaArgs* ChainPtr;
+        chain_rgba_tile<MM, false>(*(ChainPtr)((BytePtr)desc + r.off), (int)xcd_run(x, n), 0);
         return;
     }
-    typedef const __attribute__((address_space(4))) ScaleJob* JobPtr;
-    const auto& j = ((JobPtr)((const __attribute__((address_space(4))) uint8_t*)d + d->jobs_off))[row - 128u];
-    const uint32_t n = j.tile_start[3];
-    if (x >= n) return;
     const uint32_t t = xcd_run(x, n);
-    const int plane = t >= j.tile_start[2] ? 2 : (t >= j.tile_start[1] ? 1 : 0);
-    scale_tile_variant(j.variant, j.p[plane], t - j.tile_start[plane], j.tiles_x[plane], (int)j.s_rows);
+    const int plane = t >= r.ts2 ? 2 : (t >= r.ts1 ? 1 : 0);
+    const uint32_t ts = plane == 2 ? r.ts2 : (plane == 1 ? r.ts1 : 0u), tiles_x = plane == 2 ? r.tx2 : (plane == 1 ? r.tx1 : r.tx0);
+    typedef const __attribute__((address_space(4))) ScaleJob* JobPtr;
+    const auto& src = ((JobPtr)((BytePtr)desc + r.off))->p[plane];
+    // the plane's record in one go: every field the tile body reads is requested here, together (read field by field where it is used, the loads
+    // sat behind one another's waits), and waited for once
+    ScalePlane pl;
+    pl.src = src.src; pl.dst = src.dst; pl.src_stride = src.src_stride; pl.dst_stride = src.dst_stride;
+    pl.sw = src.sw; pl.sh = src.sh; pl.dw = src.dw; pl.dh = src.dh;
+    pl.hfirst = nullptr; pl.hcoef = nullptr; pl.vfirst = nullptr; pl.vcoef = nullptr; pl.hn = 0; pl.vn = 0; pl.tmp = nullptr; pl.hpk = nullptr; pl.vpk = nullptr;
+    pl.h_row0 = src.h_row0; pl.h_rows = src.h_rows; pl.sxs = src.sxs; pl.sxo = src.sxo; pl.oy_base = src.oy_base; pl.dh_full = src.dh_full;
+    pl.hx = src.hx; pl.vx = src.vx; pl.mh = src.mh; pl.mv = src.mv;
+    {   // ONE statement that needs them all: the loads above are issued together and waited for once
+        uint64_t p0 = (uint64_t)(uintptr_t)pl.src, p1 = (uint64_t)(uintptr_t)pl.dst, p2 = (uint64_t)(uintptr_t)pl.hx, p3 = (uint64_t)(uintptr_t)pl.vx;
+        asm volatile("" : "+s"(p0), "+s"(p1), "+s"(p2), "+s"(p3), "+s"(pl.src_stride), "+s"(pl.dst_stride), "+s"(pl.sw), "+s"(pl.sh), "+s"(pl.dw), "+s"(pl.dh),
+                     "+s"(pl.h_row0), "+s"(pl.h_rows), "+s"(pl.sxs), "+s"(pl.sxo), "+s"(pl.oy_base), "+s"(pl.dh_full), "+s"(pl.mh), "+s"(pl.mv));
+        pl.src = (const uint8_t*)(uintptr_t)p0; pl.dst = (uint8_t*)(uintptr_t)p1; pl.hx = (const uint4*)(uintptr_t)p2; pl.vx = (const uint4*)(uintptr_t)p3;
+    }
+    scale_tile_variant(r.variant, pl, t - ts, tiles_x, (int)r.s_rows);
 }
 
 __global__ __launch_bounds__(256) void k_scale_bicubic_batch(ScaleBatchArgs a) {   // simple gather form, any ratio
@@ -1089,10 +1106,23 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     sl->used_at = ++ring.clock;
     const dim3 grid((gx + 7u) & ~7u, (uint32_t)(n_chains + n_jobs));
     const VideoBatchDesc* dd = reinterpret_cast<const VideoBatchDesc*>(sl->dev);
-    if (mm == 3) hipLaunchKernelGGL(k_video_batch<3>, grid, dim3(256), lds, s, dd);
-    else if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd);
-    else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd);
-    else hipLaunchKernelGGL(k_video_batch<0>, grid, dim3(256), lds, s, dd);
+    VbRows rows;
+    std::memset(&rows, 0, sizeof rows);
+    for (int y = 0; y < n_chains + n_jobs; ++y) {
+        VbRow& r = rows.r[y];
+        const uint32_t ro = d->row_of[y];
+        if (ro < 128u) { r.is_job = 0u; r.n_tiles = d->chain_tiles[ro]; r.off = (uint32_t)(VB_HEADER + (size_t)ro * sizeof(ChainRgbaArgs)); }
+        else {
+            const ScaleJob& jb = dj[ro - 128u];
+            r.is_job = 1u; r.n_tiles = jb.tile_start[3]; r.off = d->jobs_off + (uint32_t)((size_t)(ro - 128u) * sizeof(ScaleJob));
+            r.ts1 = jb.tile_start[1]; r.ts2 = jb.tile_start[2]; r.tx0 = jb.tiles_x[0]; r.tx1 = jb.tiles_x[1]; r.tx2 = jb.tiles_x[2];
+            r.variant = jb.variant; r.s_rows = jb.s_rows;
+        }
+    }
+    if (mm == 3) hipLaunchKernelGGL(k_video_batch<3>, grid, dim3(256), lds, s, dd, rows);
+    else if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd, rows);
+    else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd, rows);
+    else hipLaunchKernelGGL(k_video_batch<0>, grid, dim3(256), lds, s, dd, rows);
     hip_check(hipEventRecord(sl->done, s), "hipEventRecord");
     sl->used = true;
 }

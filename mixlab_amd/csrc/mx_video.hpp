@@ -106,6 +106,17 @@ struct VideoBatchDesc {   // header | c[n_chains] | ScaleJob[n_jobs] at byte job
     ChainRgbaArgs c[MX_VB_MAX_CHAINS];
     ScaleJob j[MX_VB_MAX_JOBS];   // capacity only: the jobs follow the chains actually present
 };
+// What a block needs to find its work, per grid row, passed in the KERNEL ARGUMENTS (one scalar load off the kernarg pointer; read out of the descriptor in
+// device memory it was a chain of dependent loads -- row_of[y] (a byte: a VECTOR load and a readfirstlane), then the row's tile count, then the job's
+// tile_start[3], [2], [1] one after the other, then tiles_x and the variant -- eight round trips before a scaler block requested its first pixel).
+struct VbRow {
+    uint32_t is_job, n_tiles;         // chain row or scale-job row; blocks of the row that have work
+    uint32_t off;                     // byte offset in the descriptor of the row's ChainRgbaArgs / of its ScaleJob
+    uint32_t ts1, ts2;                // jobs: first tile of planes 1 and 2 (plane 0 starts at 0)
+    uint32_t tx0, tx1, tx2;           // jobs: tiles per tile row of each plane
+    uint32_t variant, s_rows;         // jobs: tile body variant and window rows
+};
+struct VbRows { VbRow r[MX_VB_MAX_CHAINS + MX_VB_MAX_JOBS]; };
 void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
 // K: how many ticks' RGBA chains (and the scale jobs of the K ticks after them) share one launch inside a batched run (MX_VIDEO_BATCH, default 16, 1..16)
 uint32_t video_batch_ticks();
