@@ -338,6 +338,7 @@ Graph::~Graph() {
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
     for (Stage& st : stage_) { if (st.done) (void)hipEventDestroy(st.done); if (st.host) (void)hipHostFree(st.host); }
+    if (stream_) video_stream_retired(stream_);   // (also for a caller's stream: this graph will not launch on it again, the next one starts an empty ring)
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 

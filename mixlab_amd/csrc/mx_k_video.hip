@@ -1020,6 +1020,23 @@ constexpr size_t VB_HEADER = offsetof(VideoBatchDesc, c);
 constexpr size_t VB_BYTES = sizeof(VideoBatchDesc);
 uint64_t fnv1a(const uint8_t* p, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; }
 }  // namespace
+// A stream is about to be destroyed (Graph::~Graph, after it synchronised): its descriptor slots -- page-locked staging, device copies, events, the
+// upload stream -- go with it.  (A later stream may get the same handle value; it starts with an empty ring.)
+void video_stream_retired(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_desc_mu);
+    for (auto it = g_desc.begin(); it != g_desc.end();) {
+        if (it->first.second != s) { ++it; continue; }
+        DescRing& ring = it->second;
+        for (DescSlot& c : ring.slot) {
+            if (c.host) (void)hipHostFree(c.host);
+            if (c.dev) (void)hipFree(c.dev);
+            if (c.done) (void)hipEventDestroy(c.done);
+            if (c.copied) (void)hipEventDestroy(c.copied);
+        }
+        if (ring.copy) { (void)hipStreamSynchronize(ring.copy); (void)hipStreamDestroy(ring.copy); }
+        it = g_desc.erase(it);
+    }
+}
 static void launch_separately(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s) {
     for (int i = 0; i < n_jobs; i += 4) {
         ScaleBatchArgs b{};

@@ -118,6 +118,7 @@ struct VbRow {
 };
 struct VbRows { VbRow r[MX_VB_MAX_CHAINS + MX_VB_MAX_JOBS]; };
 void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
+void video_stream_retired(hipStream_t s);   // the stream is going away: free what launch_video_batch keeps for it
 // K: how many ticks' RGBA chains (and the scale jobs of the K ticks after them) share one launch inside a batched run (MX_VIDEO_BATCH, default 16, 1..16)
 uint32_t video_batch_ticks();
 void launch_fade_chain(const ChainArgs& a, hipStream_t s);
