@@ -1013,12 +1013,19 @@ static bool plan_scale_job(const ScaleArgs& a, ScaleJob& j) {
 // takes the least recently used slot: it is rewritten only after the last launch that read it has finished.
 namespace {
 struct DescSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t bytes = 0; uint64_t hash = 0, used_at = 0; hipEvent_t done = nullptr, copied = nullptr; bool used = false; };
-struct DescRing { DescSlot slot[16]; uint64_t clock = 0; hipStream_t copy = nullptr; std::vector<uint8_t> build; };   // `copy`: the uploads' own stream -- they run beside the previous launch
+struct DescRing { DescSlot slot[16]; uint64_t clock = 0; hipStream_t copy = nullptr; std::vector<uint8_t> build; std::mutex mu; };   // `copy`: the uploads' own stream -- they run beside the previous launch
 std::mutex g_desc_mu;
 std::map<std::pair<int, hipStream_t>, DescRing> g_desc;
 constexpr size_t VB_HEADER = offsetof(VideoBatchDesc, c);
 constexpr size_t VB_BYTES = sizeof(VideoBatchDesc);
-uint64_t fnv1a(const uint8_t* p, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; }
+// (a filter in front of the memcmp, eight bytes per step: a descriptor is ~30 KB and a launch must not cost the host tens of microseconds)
+uint64_t desc_hash(const uint8_t* p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+    for (; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
 }  // namespace
 // A stream is about to be destroyed (Graph::~Graph, after it synchronised): its descriptor slots -- page-locked staging, device copies, events, the
 // upload stream -- go with it.  (A later stream may get the same handle value; it starts with an empty ring.)
@@ -1061,8 +1068,10 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     // the descriptor: built in host memory, then looked up among the slots already on the device
     int dev = 0;
     hip_check(hipGetDevice(&dev), "hipGetDevice");
-    std::lock_guard<std::mutex> lk(g_desc_mu);   // (a ring belongs to one stream, i.e. to one engine thread: the lock is uncontended)
-    DescRing& ring = g_desc[{dev, s}];
+    DescRing* ring_p;
+    { std::lock_guard<std::mutex> lk(g_desc_mu); ring_p = &g_desc[{dev, s}]; }   // map nodes stay where they are; a ring is erased only when its stream is retired
+    DescRing& ring = *ring_p;
+    std::lock_guard<std::mutex> lk(ring.mu);     // a ring belongs to one stream, i.e. to one engine thread: uncontended, and other streams' launches do not wait here
     if (!ring.copy) hip_check(hipStreamCreateWithFlags(&ring.copy, hipStreamNonBlocking), "hipStreamCreate(descriptor uploads)");
     if (ring.build.size() < VB_BYTES) ring.build.assign(VB_BYTES, 0);
     VideoBatchDesc* d = reinterpret_cast<VideoBatchDesc*>(ring.build.data());
@@ -1098,7 +1107,7 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
         }
     }
     const size_t bytes = d->jobs_off + (size_t)n_jobs * sizeof(ScaleJob);
-    const uint64_t h = fnv1a(ring.build.data(), bytes);
+    const uint64_t h = desc_hash(ring.build.data(), bytes);
     DescSlot* sl = nullptr;
     for (DescSlot& c : ring.slot) if (c.used && c.bytes == bytes && c.hash == h && std::memcmp(c.host, ring.build.data(), bytes) == 0) { sl = &c; break; }
     const bool hit = sl != nullptr;
