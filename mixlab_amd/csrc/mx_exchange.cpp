@@ -40,6 +40,7 @@ static hipEvent_t make_event(bool timing) {
 
 Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint32_t world, const void* uid, LoopbackGroup* lb, uint32_t mode)
     : lb_(lb), rank_(rank), world_(world), T_(n_ticks) {
+  try {
     if (world == 0 || rank >= world) throw Error(MX_ERR_INVALID, "rank must be below world");
     if (n_ticks == 0) throw Error(MX_ERR_INVALID, "n_ticks is 0");
     if (mode > MX_EXCHANGE_ALLREDUCE) throw Error(MX_ERR_INVALID, "unknown exchange mode");
@@ -92,23 +93,30 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
         lb->members[rank] = this;
         lb->arrived[rank] = lb->completed;
     }
+  } catch (...) {      // a constructor that throws runs no destructor: the stream, the events and a half-made communicator are released here
+    joined_ = false;   // (never entered in the loopback group's member list)
+    destroy();
+    throw;
+  }
 }
 
-Exchange::~Exchange() {
+void Exchange::destroy() noexcept {
     (void)hipSetDevice(device_);
     if (cs_) (void)hipStreamSynchronize(cs_);
-    if (lb_) {
+    if (lb_ && joined_ && rank_ < lb_->members.size() && lb_->members[rank_] == this) {
         // peers may still be reading this member's buffers
         for (Exchange* q : lb_->members) if (q && q != this && q->cs_) (void)hipStreamSynchronize(q->cs_);
         lb_->members[rank_] = nullptr;
     }
-    if (comm_) (void)ncclCommDestroy(comm_);
+    if (comm_) { (void)ncclCommDestroy(comm_); comm_ = nullptr; }
     for (Slot& sl : slots_) {
         sl.cg.reset();
-        for (hipEvent_t e : {sl.packed, sl.begin, sl.fin, sl.done, sl.consumed}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t* e : {&sl.packed, &sl.begin, &sl.fin, &sl.done, &sl.consumed}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     }
-    if (cs_) (void)hipStreamDestroy(cs_);
+    if (cs_) { (void)hipStreamDestroy(cs_); cs_ = nullptr; }
 }
+
+Exchange::~Exchange() { destroy(); }
 
 // Mixer(world, unity) for Master and for Cue over bound device buffers: partial r's master at base + r * peer_stride, its cue
 // cue_off floats further.  Unity = 0 dB, fader 1.0: each term is (x as f64 * 1.0) as f32 = x, so an output sample is the f32 sum

@@ -69,6 +69,8 @@ private:
     void build_combine(Slot& sl, uint32_t ticks, const float* base, size_t peer_stride, size_t cue_off);
     void collective_rccl(Slot& sl);
     static void loopback_round(LoopbackGroup& grp, uint64_t step);
+    void destroy() noexcept;           // what the destructor does; also the constructor's exit by exception
+    bool joined_ = true;
 
     LoopbackGroup* lb_ = nullptr;
     ncclComm* comm_ = nullptr;
