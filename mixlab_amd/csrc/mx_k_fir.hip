@@ -123,11 +123,17 @@ void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, 
 // rows of one 128-byte-strided column); the 64-bit division M * down / up is done once per block, each lane only
 // divides a 32-bit offset.  A block walks many 256-output groups so the table is loaded once per ~50 groups.
 // k_resample_gather is the plain form for tables that do not fit LDS.
+// UPC: the interpolation factor when the launcher knows every channel of the launch has that one (160: the 44.1 -> 48 kHz ratio), else 0.  With it the
+// table's row stride is a constant and a tap's coefficient read carries its row as an instruction immediate; at run-time stride every tap costs an
+// address add per lane (16 of a lane's ~124 VALU instructions per output).
+template <int UPC>
 __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict__ descs, size_t out_frames,
                                                   uint64_t out_base, uint64_t in_base, uint32_t win_cap) {
     const ResampleDesc d = descs[blockIdx.y];
     const int P = (int)d.taps_per_phase, H = P - 1;
-    const uint32_t up = d.up, down = d.down;
+    const uint32_t up = UPC ? (uint32_t)UPC : d.up, down = d.down;
+    // floor(q / up) for the lanes' 32-bit offsets by a reciprocal made once per block: mulhi gives the quotient or one less (q M / 2^32 > q / up - 1)
+    const uint32_t up_magic = up > 1u ? (uint32_t)((1ull << 32) / up) : 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);                       // [P][up]
     // The window as TWO planes of doubles (left, right), widened once while staging.  As interleaved double2 a tap step is one
@@ -181,7 +187,11 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict
         if (nxt < out_frames) { g = group_of(nxt); if (one) pre = fetch(g, tid); }
         if (blk + tid < out_frames) {
             uint32_t dn, phase;
-            if (small) { const uint32_t q = r0 + (uint32_t)tid * down; dn = q / up; phase = q - dn * up; }
+            if (small) {
+                const uint32_t q = r0 + (uint32_t)tid * down;
+                dn = __umulhi(q, up_magic); phase = q - dn * up;
+                if (phase >= up) { ++dn; phase -= up; }
+            }
             else { const uint64_t q = r0 + (uint64_t)tid * down; dn = (uint32_t)(q / up); phase = (uint32_t)(q - (uint64_t)dn * up); }
             // volatile: each read stays a ds_read_b64 of its own (merged into ds_read2_b64 pairs they are served 16 lanes at a time)
             typedef const volatile __attribute__((address_space(3))) double* LdsD;
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict
             const LdsD h = (LdsD)(tab + phase);
             double al = 0.0, ar = 0.0;
             for (int k = 0; k < P; ++k) {
-                const double c = h[(size_t)k * up];
+                const double c = UPC ? h[(size_t)k * UPC] : h[(size_t)k * up];
                 const double vl = l[-k], vr = r[-k];
                 al = al + c * vl;
                 ar = ar + c * vr;
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256) void k_resample_history(const ResampleDesc* __
     for (int j = threadIdx.x; j < H; j += 256) d.hist[j] = tmp[j];
 }
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles, uint32_t win_frames,
-                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s) {
+                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up) {
     if (!n || !out_frames) return;
     const size_t lds = (size_t)tab_doubles * sizeof(double) + (size_t)((win_frames + 1u) & ~1u) * 2 * sizeof(double);
     if (lds <= 60 * 1024) {
@@ -248,7 +258,8 @@ void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint3
         static const uint32_t cus = [] { int dev = 0, n_cu = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256; return (uint32_t)std::max(n_cu, 1); }();
         const uint32_t resident = cus * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
         const uint32_t per_ch = (uint32_t)std::max<size_t>(1, std::min<size_t>((out_frames + 255) / 256, std::max<uint32_t>(1u, resident / n)));
-        hipLaunchKernelGGL(k_resample, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
+        if (common_up == 160u) hipLaunchKernelGGL(k_resample<160>, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
+        else hipLaunchKernelGGL(k_resample<0>, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
     } else {
         hipLaunchKernelGGL(k_resample_gather, dim3(grid_x(out_frames, 256, 1024), n), dim3(256), 0, s, d, out_frames, out_base, in_base);
     }
