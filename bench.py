@@ -469,7 +469,7 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup):
             sec = k_ms[k] * 1e-3
             roof[k] = {"ms": round(k_ms[k], 5), "f64_ops_per_launch": ops[k], "f64_tops": round(ops[k] / sec / 1e12, 2), "f64_frac": round(ops[k] / sec / 1e12 / F64_VALU_PEAK_TOPS, 3),
                        "moved_bytes_per_launch": moved[k], "hbm_frac": round(moved[k] / sec / 1e9 / HBM_PEAK_GBS, 4),
-                       "traffic": traffic.get(k), "bound": "f64 VALU (prescribed mul + add, no FMA by spec)" if k == "fir" else "LDS bandwidth (24 B of LDS per tap step and lane against four f64 operations)"}
+                       "traffic": traffic.get(k), "bound": "f64 VALU (prescribed mul + add, no FMA by spec)" if k == "fir" else "on-chip: LDS issue (three 8-byte reads per tap step and lane against four f64 operations) and the latency between a group's barriers; neither the f64 rate nor HBM"}
     out["roofline"] = {"per_kernel": roof, "f64_peak_tops": F64_VALU_PEAK_TOPS, "hbm_peak_gbs": HBM_PEAK_GBS,
                        "traffic_source": "profiles/r03/fir_pmc_traffic.json" if traffic else None}
     if "fir" in k_ms:

@@ -19,7 +19,7 @@ GROUPS = {   # bench.py's launch groups (what its hipEvents bracket)
     "video_chain": ("k_fade_chain",),
     "video_batch": ("k_video_batch<2>",),
     "fir": ("k_fir(",),
-    "resample": ("k_resample(",),
+    "resample": ("k_resample(", "k_resample<"),
 }
 
 
