@@ -405,7 +405,7 @@ def north_star_realtime_leg(torch, stream, local_rank, abi, Workspace, synth, n_
     return out
 
 
-def fir_leg(torch, stream, local_rank, T, steps, warmup):
+def fir_leg(torch, stream, local_rank, T, steps, warmup, flags=0, with_contract=True):
     """BASELINE.json configs[2] (build-specified): 256 stereo channels @44.1 kHz ->
     128-tap FIR reverb -> 160/147 polyphase resampler (16 taps per phase) -> 48 kHz-domain Mixer(256).
     f64 accumulation in ascending tap order with separate multiply and add, one rounding to f32."""
@@ -428,7 +428,7 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup):
     mix = ws.mixer([(0.0, 1.0, k % 2 == 0) for k in range(n_ch)])
     for k, r in enumerate(rs):
         ws.connect(r, 0, mix, k)
-    g = ws.build(max_ticks_per_run=T, device=local_rank, stream=stream.cuda_stream)
+    g = ws.build(max_ticks_per_run=T, flags=flags, device=local_rank, stream=stream.cuda_stream)
     for k, s in enumerate(srcs):
         blk = synth.noise(60 + k, 2 * SPT * min(T, 64))
         g.write_source(s, np.tile(blk, (T + 63) // 64)[: 2 * SPT * T], T)
@@ -477,6 +477,16 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup):
                                "frac": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12 / 39.3, 3), "note": "prescribed f64 mul + add only (no FMA by spec)"}
     if "resample" in k_ms:
         out["resample_f64_tops"] = round(rs_ops / (k_ms["resample"] * 1e-3) / 1e12, 2)
+    if with_contract:
+        # the same leg in the contracted order (MX_FLAG_FP_CONTRACT: acc = fma(h[k], x, acc), half the f64 instructions; <= 1 ULP of the spec)
+        from mixlab_amd import abi
+        g.close()
+        fc = fir_leg(torch, stream, local_rank, T, steps, warmup, flags=abi.FLAG_FP_CONTRACT, with_contract=False)
+        out["fp_contract"] = {"flag": "MX_FLAG_FP_CONTRACT", "parity": "<= 1 ULP of the separate multiply-and-add spec; bit-exact vs the oracle's contract mode (tests/test_gpu_fp_contract.py)",
+                              "value": fc["value"], "unit": fc["unit"], "ms_per_step": fc["ms_per_step"], "kernel_ms_per_step": fc["kernel_ms_per_step"],
+                              "roofline": {k: {kk: v[kk] for kk in ("ms", "f64_ops_per_launch", "f64_tops", "f64_frac", "moved_bytes_per_launch", "hbm_frac")}
+                                           for k, v in fc["roofline"]["per_kernel"].items()},
+                              "note": "f64_ops counts the spec's mul and add separately (an fma does two of them): f64_frac can approach 2 x the instruction-rate roof"}
     return out
 
 
@@ -667,6 +677,9 @@ def main():
     ap.add_argument("--no-t-sweep", action="store_true", help="skip the shorter-submission legs (T = 64 and 1024 ticks, SURVEY 8d)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the one-tick-per-submission leg (hundreds of tiny dispatches: slow under a counter-collecting profiler)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 240-strip + 8-layer real-time leg")
+    ap.add_argument("--no-contract-leg", action="store_true", help="skip the MX_FLAG_FP_CONTRACT leg (the same graph in the contracted order, <= 1 ULP)")
+    ap.add_argument("--fp-contract", action="store_true", help="run the HEADLINE in the contracted order (MX_FLAG_FP_CONTRACT: <= 1 ULP, NOT the reference's bits); "
+                    "the default line reports it as the `fp_contract` leg beside the exact headline")
     ap.add_argument("--no-material-leg", action="store_true", help="skip the realistic-material (muted strips, silences) and poisoned-strip legs")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
@@ -703,7 +716,7 @@ def main():
     toggling = not args.hold_gates
 
     stream = torch.cuda.Stream()
-    flags = (abi.FLAG_EQ_FAST if args.eq_fast else 0) | (abi.FLAG_NO_FUSE if args.no_fuse else 0)
+    flags = (abi.FLAG_EQ_FAST if args.eq_fast else 0) | (abi.FLAG_NO_FUSE if args.no_fuse else 0) | (abi.FLAG_FP_CONTRACT if args.fp_contract else 0)
     overlap = args.overlap_tail and not (world > 1 or args.force_combine)   # the exchange packs the buses on the compute stream: one stream there
     if overlap:
         flags |= abi.FLAG_OVERLAP_TAIL
@@ -794,6 +807,41 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # The same job in the CONTRACTED order (MX_FLAG_FP_CONTRACT): a second graph over the SAME resident sources (bound, not copied), own
+    # state; every f32 within 1 ULP of the exact order, bit-exact vs the oracle's contract mode (tests/test_gpu_fp_contract.py).  Not `value`.
+    contract = None
+    if not use_dist and not args.no_contract_leg and not args.eq_fast and not args.fp_contract:
+        with torch.cuda.stream(stream):
+            g_fc = ws.build(max_ticks_per_run=T, flags=(flags & ~abi.FLAG_OVERLAP_TAIL) | abi.FLAG_FP_CONTRACT, device=local_rank, stream=stream.cuda_stream)
+            for sn in srcs:
+                g_fc.bind_source_device(sn, g.output_device_ptr(sn, 0)[0])
+            n_c = min(args.steps, 10)
+            evs = [gate_events(abi, trigs, first, i * T, T) if toggling else None for i in range(2 + n_c)]
+
+            def step_fc(i):
+                if evs[i] is not None:
+                    g_fc.schedule_params_batch(evs[i][0], evs[i][1])
+                g_fc.run_ticks(i * T, T)
+            for i in range(2):
+                step_fc(i)
+            torch.cuda.synchronize()
+            g_fc.profile_enable(not args.no_profile)
+            t0 = time.perf_counter()
+            for i in range(n_c):
+                step_fc(2 + i)
+            torch.cuda.synchronize()
+            dt_c = time.perf_counter() - t0
+            g_fc.profile_enable(False)
+            ck, _ct, cn = g_fc.profile_collect()
+            c_ran, c_rep = g_fc.eq_spec_stats()
+            contract = {"flag": "MX_FLAG_FP_CONTRACT", "ms_per_step": dt_c / n_c * 1e3, "value": args.strips * T * n_c / dt_c, "unit": "channel-ticks/s", "steps": n_c,
+                        "kernel_ms_per_step": {k: v / max(1, cn) for k, v in sorted(ck.items()) if v > 0},
+                        "eq_spec": {"chunks_run": c_ran, "chunks_repaired": c_rep},
+                        "parity": "every f32 output within 1 ULP of the reference's order (NOT its bits); bit-exact vs the oracle's contract mode (tests/test_gpu_fp_contract.py)",
+                        "what": "the reference's f64 expressions with each multiply fused into the add that consumes it: EqThree 26 instead of 36 f64 instructions per sample "
+                                "(eq_three.rs:76-88,117-124), Envelope decay and Amplifier depth() one fma each"}
+            g_fc.close()
 
     exch = None
     if ex is not None:
@@ -1025,6 +1073,20 @@ def main():
                     roof["f64_valu"]["sustained_clock"] = {"ghz": ghz, "peak_tops_at_that_clock": round(F64_VALU_PEAK_TOPS * ghz / 2.4, 1),
                                                            "frac_at_that_clock": round(f64_ops / (avg_ms * 1e-3) / 1e12 / (F64_VALU_PEAK_TOPS * ghz / 2.4), 3),
                                                            "source": "profiles/r03/clock.json: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled; a committed measurement of these kernel sources, not read live"}
+        if contract is not None:
+            ck_ms = contract["kernel_ms_per_step"]
+            if "eq_three" in ck_ms:
+                alg = moved_bytes("eq_three")
+                sec = ck_ms["eq_three"] * 1e-3
+                ops_fc = 26.0 + 5.0 + (12.0 * 0.7 if toggling else 0.0)      # f64 INSTRUCTIONS of the contracted order per strip-sample (an fma counts once)
+                contract["roofline"] = {"kernel": "eq_three launch group, contracted order (k_env_ticks<true> + k_eq_three_spec_tiled<16, ., ., true> + k_eq_three_repair<true>)",
+                                        "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                        "traffic": None, "avg_launch_ms": round(ck_ms["eq_three"], 5), "algorithmic_bytes_per_launch": alg,
+                                        "f64_valu": {"instructions_per_sample_contracted": ops_fc, "achieved_tops": round(ops_fc * local_strips * frames / sec / 1e12, 2), "peak_tops": F64_VALU_PEAK_TOPS,
+                                                     "frac": round(ops_fc * local_strips * frames / sec / 1e12 / F64_VALU_PEAK_TOPS, 3)},
+                                        "limiter": "f64 VALU issue, as the exact order: 51.5 VALU instructions per sample in the hot loop (exact: 63), 20 per warm-up sample (28)"}
+            contract["kernel_ms_per_step"] = {k: round(v, 5) for k, v in ck_ms.items()}
+            contract["speedup_vs_exact"] = round((dt / args.steps * 1e3) / contract["ms_per_step"], 3)
         moved = sum(moved_bytes(k) for k in k_ms)
         rep_sorted = sorted(rep_ms)
         out = {
@@ -1035,7 +1097,8 @@ def main():
             "config": {"workload": f"{args.strips}-channel Mixer + EqThree + Envelope chain (Trigger->Envelope; noise->EqThree->StereoPanner->Amplifier->Mixer), {SR} Hz f32",
                        "strips": args.strips, "ticks_per_step": T, "samples_per_tick": spt,
                        "gates": "toggle every 30 ticks, phase k mod 60, applied between ticks inside the batch (mx_graph_schedule_params_batch)" if toggling else "held for the whole run",
-                       "eq_mode": "time-parallel scan (<= 1 ULP, MX_FLAG_EQ_FAST)" if args.eq_fast else "exact order (default): speculative time-parallel kernel, verified bit-exact",
+                       "eq_mode": "time-parallel scan (<= 1 ULP, MX_FLAG_EQ_FAST)" if args.eq_fast else ("CONTRACTED order (MX_FLAG_FP_CONTRACT): <= 1 ULP of the reference, NOT its bits" if args.fp_contract
+                                   else "exact order (default): speculative time-parallel kernel, verified bit-exact"),
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
                        "overlap": "MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k runs on a second stream beside step k + 1's EqThree group (strip ports double-buffered)" if overlap else "off",
                        "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else "") + (", ticks per step scaled with N (--scale-ticks)" if args.scale_ticks else ""),
@@ -1048,6 +1111,7 @@ def main():
                         "median": round(rep_sorted[len(rep_sorted) // 2], 4), "min": round(rep_sorted[0], 4), "max": round(rep_sorted[-1], 4),
                         "spread_pct": round((rep_sorted[-1] - rep_sorted[0]) / rep_sorted[len(rep_sorted) // 2] * 100.0, 2)},
             "held_gates": held,
+            "fp_contract": contract,
             "exchange": exch,
             "realtime": realtime,
             "t_sweep": t_sweep,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MX_ABI_VERSION 2u   /* 2: mx_exchange_*, mx_monitor_tick.dropped, mx_monitor_params_ex, packed RGB pixel formats */
+#define MX_ABI_VERSION 3u   /* 2: mx_exchange_*, mx_monitor_tick.dropped, mx_monitor_params_ex, packed RGB pixel formats; 3: MX_FLAG_FP_CONTRACT */
 
 /* ---- status codes (0 ok, <0 error; cf. MIXLAB_IOCTX_ERROR / MIXLAB_IOCTX_PANIC) ---- */
 enum {
@@ -108,6 +108,16 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
  * name, kept as a no-op; it wins if both are given. */
 #define MX_FLAG_EQ_EXACT 1u
 #define MX_FLAG_EQ_FAST 4u
+/* MX_FLAG_FP_CONTRACT: the CONTRACTED order -- the reference's f64 expressions with every multiply fused into the add that consumes
+ * it (what -ffp-contract=fast makes of the same source; Rust itself never contracts).  It applies to EqThree
+ * (p += f * (in - p) as fma(f, in - p, p), pole 0's + VSA as fma(f, in - p, VSA), the band mix as fma(hi, g_hi, fma(mid, g_mid, lo * g_lo)),
+ * eq_three.rs:76-88,117-124), Envelope (sustain + (1 - sustain) * decay as one fma, envelope.rs:46-47), Amplifier (depth() as one fma,
+ * amplifier.rs:71-73) and the build-specified Fir / Resample (acc = fma(h[k], x, acc), ascending k).  NOT bit-exact with the
+ * reference: every f32 output is within 1 ULP of the exact order's (26 instead of 36 f64 instructions per EqThree sample).  The
+ * contracted order is as deterministic as the exact one -- speculation, proof and repair work on it unchanged -- and the oracle's
+ * contract mode (orc_set_fp_contract) restates it, so it is tested bit for bit.  Not with MX_FLAG_EQ_FAST (the scan has its own
+ * arithmetic): mx_graph_build fails with MX_ERR_INVALID. */
+#define MX_FLAG_FP_CONTRACT 16u
 
 #define MX_FLAG_OVERLAP_TAIL 8u /* throughput mode for batched runs: the LAST launch group, when it is a Mixer bank, runs on a second
                                   stream beside the NEXT run's earlier groups (an HBM-bound kernel beside a VALU-bound one); the ports it

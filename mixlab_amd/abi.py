@@ -32,6 +32,7 @@ WAVE_ON, WAVE_OFF, WAVE_SINE, WAVE_SQUARE, WAVE_TRIANGLE, WAVE_SAW = range(6)
 FLAG_EQ_EXACT = 1   # the default (kept as a no-op name)
 FLAG_NO_FUSE = 2
 FLAG_EQ_FAST = 4    # time-parallel EqThree: <= 1 ULP, not bit-exact
+FLAG_FP_CONTRACT = 16   # the contracted order (mul+add fused): <= 1 ULP of the exact order, equal to the oracle's contract mode
 FLAG_OVERLAP_TAIL = 8   # the last Mixer bank runs on a second stream beside the next run's earlier groups
 
 

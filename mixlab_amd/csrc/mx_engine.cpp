@@ -100,6 +100,8 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     const uint32_t max_ticks = o.max_ticks_per_run ? o.max_ticks_per_run : 1u;
     cap_frames_ = cap_frames_override ? cap_frames_override : spt_ * (size_t)max_ticks;
     flags_ = o.flags;
+    if ((flags_ & MX_FLAG_FP_CONTRACT) && (flags_ & MX_FLAG_EQ_FAST) && !(flags_ & MX_FLAG_EQ_EXACT))
+        throw Error(MX_ERR_INVALID, "MX_FLAG_FP_CONTRACT is a mode of the exact-order kernels: not with MX_FLAG_EQ_FAST");
 
     if (o.device >= 0) { hip_check(hipSetDevice(o.device), "hipSetDevice"); device_ = o.device; }
     else hip_check(hipGetDevice(&device_), "hipGetDevice");
@@ -986,14 +988,14 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         const size_t gfpc = fpc * g.dom_num / g.dom_den;    // ... per tick
         const GateBits gates{(const uint32_t*)g.gates.p, g.gate_words, call_off};
         switch (g.kind) {
-        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)desc_of(g), n, gf, stream_); break;
-        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)desc_of(g), (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_); break;
+        case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)desc_of(g), n, gf, stream_, fp_contract()); break;
+        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)desc_of(g), (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_, fp_contract()); break;
         case MX_KIND_EQ_THREE: {
-            EqRun r{gf, gfpc, n_calls, 0u, t0, sample_rate_, 1.0 / sample_rate_, lo_f_, hi_f_, nullptr};
+            EqRun r{gf, gfpc, n_calls, fp_contract() ? 1u : 0u, t0, sample_rate_, 1.0 / sample_rate_, lo_f_, hi_f_, nullptr};
             if (g.state2.p) {   // Envelopes folded into the epilogue: their state entering every tick of this span
                 const size_t need = (size_t)n * n_calls * sizeof(EnvTick);
                 if (g.env_ticks.bytes < need || !g.env_ticks.p) { sync(); g.env_ticks.alloc(need); }
-                launch_env_ticks((const EnvTickDesc*)g.tick_desc.p, n, gates, n_calls, gfpc, t0, sample_rate_, (EnvTick*)g.env_ticks.p, stream_);
+                launch_env_ticks((const EnvTickDesc*)g.tick_desc.p, n, gates, n_calls, gfpc, t0, sample_rate_, (EnvTick*)g.env_ticks.p, stream_, fp_contract());
                 r.ticks = (const EnvTick*)g.env_ticks.p;
             }
             if (eq_exact()) {
@@ -1046,10 +1048,10 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)desc_of(g), n, gf, stream_); break;
         case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)desc_of(g), n, gf, stream_); break;
         case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)desc_of(g), n, gf, gfpc, &gates, stream_); break;
-        case MX_KIND_FIR: launch_fir((const FirDesc*)desc_of(g), n, g.max_taps, gf, stream_); break;
+        case MX_KIND_FIR: launch_fir((const FirDesc*)desc_of(g), n, g.max_taps, gf, stream_, fp_contract()); break;
         case MX_KIND_RESAMPLE:
             launch_resample((const ResampleDesc*)desc_of(g), n, g.max_taps, g.rs_tab_doubles, g.rs_win_frames, frames * g.in_dom_num / g.in_dom_den, gf,
-                            t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_, g.rs_common_up);
+                            t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_, g.rs_common_up, fp_contract());
             break;
         case MX_KIND_PLOTTER: {
             jobs.clear();

@@ -114,6 +114,7 @@ public:
     hipStream_t tail_stream() const { return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL
     size_t n_nodes() const { return nodes_.size(); }
     bool eq_exact() const { return (flags_ & MX_FLAG_EQ_EXACT) || !(flags_ & MX_FLAG_EQ_FAST); }   // the default is the reference's order
+    bool fp_contract() const { return (flags_ & MX_FLAG_FP_CONTRACT) != 0; }                       // the contracted order (mixlab_gpu.h)
     const Node& node(uint32_t i) const { return nodes_.at(i); }
 
     void update_params(uint32_t node, const void* params, size_t len);

@@ -23,11 +23,20 @@ __device__ __forceinline__ double seq_ms(uint64_t first, uint64_t last, double s
     return ms_of_u32((uint32_t)dt, sr, rsr);
 }
 __device__ __forceinline__ double clamp01(double x) { return x > 1.0 ? 1.0 : (x < 0.0 ? 0.0 : x); }  // envelope.rs:20-28
+
+// FC (MX_FLAG_FP_CONTRACT, mixlab_gpu.h): the same expressions with every multiply whose only consumer is an add fused into it
+// -- what `-ffp-contract=fast` would make of the reference's source; one rounding instead of two, results within 1 ULP of the
+// f32 the exact order stores.  The fusions are spelled out (never left to the compiler) and restated by the oracle's contract
+// mode, so the contracted order is as reproducible as the exact one.  mul_add<FC>(a, b, c) = a * b + c.
+template <bool FC> __device__ __forceinline__ double mul_add(double a, double b, double c) {
+    if constexpr (FC) return __builtin_fma(a, b, c); else return a * b + c;
+}
+template <bool FC = false>
 __device__ __forceinline__ double amp_on_ms(const EnvParams& p, double ms) {                          // envelope.rs:37-49
     const double attack = p.inv_attack * ms;
     const double since_decay = ms - p.attack_ms;
     const double decay_amplitude = 1.0 - clamp01(p.inv_decay * since_decay);
-    const double decay = p.sustain + (p.one_minus_sustain * decay_amplitude);
+    const double decay = mul_add<FC>(p.one_minus_sustain, decay_amplitude, p.sustain);
     return ms < p.attack_ms ? attack : decay;
 }
 __device__ __forceinline__ double amp_off_ms(const EnvParams& p, double off_amp, double ms) {         // envelope.rs:51-56
@@ -37,17 +46,19 @@ __device__ __forceinline__ double amp_off_ms(const EnvParams& p, double off_amp,
 
 // One Envelope::run_tick step of the state machine for a CONSTANT gate over a whole run starting at
 // t0 (envelope.rs:99-115): only the first sample can change the state.
+template <bool FC = false>
 __device__ __forceinline__ void env_const_gate_step(const EnvParams& p, float gate, uint64_t t0, double sr, double rsr,
                                                     uint32_t& tag, uint64_t& seq, double& off_amp) {
     if (tag != 1u) { if (gate == 1.0f) { tag = 1u; seq = t0; } }
-    else if (gate == 0.0f) { off_amp = amp_on_ms(p, seq_ms(seq, t0, sr, rsr)); tag = 2u; seq = t0; }
+    else if (gate == 0.0f) { off_amp = amp_on_ms<FC>(p, seq_ms(seq, t0, sr, rsr)); tag = 2u; seq = t0; }
 }
 // amplitude at absolute sample time t for a state that no longer changes during the run
+template <bool FC = false>
 __device__ __forceinline__ double env_amplitude(const EnvParams& p, uint32_t tag, uint64_t seq, double off_amp,
                                                 uint64_t t, double sr, double rsr) {
     if (tag == 0u) return 0.0;                                   // envelope.rs:36
     const double ms = seq_ms(seq, t, sr, rsr);
-    return tag == 1u ? amp_on_ms(p, ms) : amp_off_ms(p, off_amp, ms);
+    return tag == 1u ? amp_on_ms<FC>(p, ms) : amp_off_ms(p, off_amp, ms);
 }
 
 // Has the amplitude stopped changing at time t (and therefore for every later t of the run)?  ms is

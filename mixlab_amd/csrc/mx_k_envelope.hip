@@ -29,7 +29,7 @@ __device__ __forceinline__ double read_lane_f64(double v, int l) {
     return __longlong_as_double((long long)read_lane_u64((uint64_t)__double_as_longlong(v), l));
 }
 
-template <int K>
+template <int K, bool FC>   // FC: the contracted order (MX_FLAG_FP_CONTRACT): amp_on_ms's decay as one fma
 __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ descs, EnvState* __restrict__ states,
                                                    uint32_t n_inst, size_t frames, size_t fpc, GateBits gates, uint64_t t0, double sr, double rsr) {
     const int lane = threadIdx.x & 63;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
                 double a = 0.0;                                                   // envelope.rs:36
                 if (tag != 0u) {                                                  // uniform
                     const double ms = ms_of_u32(d0 + (uint32_t)(64 * k + lane), sr, rsr);
-                    a = (tag == 1u) ? amp_on_ms(p.p, ms) : amp_off_ms(p.p, off_amp, ms);
+                    a = (tag == 1u) ? amp_on_ms<FC>(p.p, ms) : amp_off_ms(p.p, off_amp, ms);
                 }
                 if (i < frames) p.out[i] = (float)a;
             }
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
                 const uint64_t Rb = R & ((1ull << fl) - 1ull);
                 const uint64_t on = Rb ? tb + (uint64_t)top_bit(Rb) : seq;
                 my_tag = 2u; my_seq = off;
-                my_off = amp_on_ms(p.p, seq_ms(on, off, sr, rsr));      // envelope.rs:108-111
+                my_off = amp_on_ms<FC>(p.p, seq_ms(on, off, sr, rsr));      // envelope.rs:108-111
             }
             const double ms = seq_ms(my_seq, tb + (uint64_t)lane, sr, rsr);
-            const double a_on = amp_on_ms(p.p, ms);
+            const double a_on = amp_on_ms<FC>(p.p, ms);
             const double a_off = amp_off_ms(p.p, my_off, ms);
             const double a = my_tag == 1u ? a_on : (my_tag == 2u ? a_off : 0.0);   // envelope.rs:36
             if (valid) p.out[i] = (float)a;
@@ -131,12 +131,14 @@ __global__ __launch_bounds__(256) void k_envelope(const EnvDesc* __restrict__ de
     if (lane == 0) { states[inst].tag = tag; states[inst].seq = seq; states[inst].off_amplitude = off_amp; }
 }
 
-void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s) {
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s, bool fc) {
     if (!n || !frames) return;
     const double rsr = 1.0 / sample_rate;
     if (!fpc) fpc = frames;
-    if (frames > 64 * 4) hipLaunchKernelGGL(k_envelope<8>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, fpc, gates, t0, sample_rate, rsr);
-    else hipLaunchKernelGGL(k_envelope<2>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, fpc, gates, t0, sample_rate, rsr);
+#define MX_ENV_GO(K, F) hipLaunchKernelGGL((k_envelope<K, F>), dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, fpc, gates, t0, sample_rate, rsr)
+    if (frames > 64 * 4) { if (fc) MX_ENV_GO(8, true); else MX_ENV_GO(8, false); }
+    else { if (fc) MX_ENV_GO(2, true); else MX_ENV_GO(2, false); }
+#undef MX_ENV_GO
 }
 
 }  // namespace mx

@@ -41,6 +41,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // One wave per instance, 64 ticks per step: the gate of tick c is bit c, so "state after the first sample of tick c" follows
 // from the last rising / falling edge at or before c exactly as in k_envelope (envelope.rs:99-115 with one marker per tick).
+template <bool FC>
 __global__ __launch_bounds__(256) void k_env_ticks(const EnvTickDesc* __restrict__ descs, uint32_t n_inst, GateBits gates, uint32_t n_calls,
                                                     size_t fpc, uint64_t t0, double sr, double rsr, EnvTick* __restrict__ ticks) {
     const int lane = threadIdx.x & 63;
@@ -73,15 +74,15 @@ __global__ __launch_bounds__(256) void k_env_ticks(const EnvTickDesc* __restrict
             const uint64_t Rb = R & ((1ull << fl) - 1ull);
             const uint64_t on = Rb ? t_of(top_bit64(Rb)) : seq;
             my_tag = 2u; my_seq = off;
-            my_off = amp_on_ms(d.p, seq_ms(on, off, sr, rsr));       // envelope.rs:108-111
+            my_off = amp_on_ms<FC>(d.p, seq_ms(on, off, sr, rsr));   // envelope.rs:108-111
         }
         if (valid) {
             const uint64_t t = t_of(lane);
             EnvTick k;
             k.seq = my_seq; k.off_amp = my_off; k.tag = my_tag;
             k.flat = env_saturated(d.p, my_tag, my_seq, t, sr, rsr) ? 1u : 0u;
-            const float cc = (float)env_amplitude(d.p, my_tag, my_seq, my_off, t, sr, rsr);
-            k.depth = d.amp_one_minus + d.amp_mod_depth * (double)cc;
+            const float cc = (float)env_amplitude<FC>(d.p, my_tag, my_seq, my_off, t, sr, rsr);
+            k.depth = amp_depth<FC>(d.amp_one_minus, d.amp_mod_depth, (double)cc);
             ticks[(size_t)inst * n_calls + c] = k;
         }
         const int last = n_calls - c0 >= 64u ? 63 : (int)(n_calls - c0) - 1;
@@ -91,9 +92,10 @@ __global__ __launch_bounds__(256) void k_env_ticks(const EnvTickDesc* __restrict
     }
     if (lane == 0) { d.state->tag = tag; d.state->seq = seq; d.state->off_amplitude = off_amp; }
 }
-void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s) {
+void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s, bool fc) {
     if (!n || !n_calls) return;
-    hipLaunchKernelGGL(k_env_ticks, dim3((n + 3) / 4), dim3(256), 0, s, d, n, gates, n_calls, fpc, t0, sample_rate, 1.0 / sample_rate, ticks);
+    if (fc) hipLaunchKernelGGL(k_env_ticks<true>, dim3((n + 3) / 4), dim3(256), 0, s, d, n, gates, n_calls, fpc, t0, sample_rate, 1.0 / sample_rate, ticks);
+    else hipLaunchKernelGGL(k_env_ticks<false>, dim3((n + 3) / 4), dim3(256), 0, s, d, n, gates, n_calls, fpc, t0, sample_rate, 1.0 / sample_rate, ticks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -151,15 +153,16 @@ __device__ __forceinline__ EnvLane env_lane_coeffs(const EnvParams& p, const Env
     return e;
 }
 // amplifier depth() for sample k of the span (branch-free form; `e.general` lanes are handled by the caller)
+template <bool FC>
 __device__ __forceinline__ double env_lane_depth(const EnvParams& p, const EnvLane& e, uint32_t k, double one_minus, double mod_depth, double sr, double rsr) {
     const double ms = ms_of_u32(e.dt0 + k, sr, rsr);
     const double tt = e.k * (ms - e.m0);
     const double c = __builtin_fmin(tt, 1.0);                  // clamp()'s upper bound (envelope.rs:21-22); no NaN here, see above
-    const double val = e.A + e.B * (1.0 - c);
+    const double val = mul_add<FC>(e.B, 1.0 - c, e.A);
     const double att = p.inv_attack * ms;
     const double a = (e.on && ms < p.attack_ms) ? att : val;
     const float cc = (float)a;                                 // Envelope stores f32 (envelope.rs:117)
-    return one_minus + mod_depth * (double)cc;                 // amplifier.rs:71-73
+    return amp_depth<FC>(one_minus, mod_depth, (double)cc);    // amplifier.rs:71-73
 }
 
 // A run of `n` consecutive samples of one chunk through the recurrence and the epilogue: blocks of EQ_BLK samples with the next
@@ -167,7 +170,7 @@ __device__ __forceinline__ double env_lane_depth(const EnvParams& p, const EnvLa
 // load sits inside a per-sample condition (its join would cost an s_waitcnt vmcnt(0), i.e. the prefetch).
 // ENVK: 0 no inline Envelope; 1 every lane of the wave is flat this tick (constant depth); 2 branch-free closed form;
 //       3 general form (env_depth: 64-bit distances, negative off_amplitude).
-template <int MODE, bool STEREO, int ENVK>
+template <int MODE, bool STEREO, int ENVK, bool FC>
 __device__ __forceinline__ void eq_spec_span(const EqDesc& d, const EqRun& r, const float* __restrict__ in, float* __restrict__ outm,
                                              const float* __restrict__ ctl, const size_t n, const EnvTick& cur, const EnvLane& el, uint64_t t,
                                              EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
@@ -180,10 +183,10 @@ __device__ __forceinline__ void eq_spec_span(const EqDesc& d, const EqRun& r, co
         if (MODE == EQM_PLAIN) return y;
         double depth;
         if (MODE == EQM_AMP_CONST) depth = depth_const;
-        else if (MODE == EQM_AMP_CTL) depth = one_minus + mod_depth * (double)c;   // amplifier.rs:71-73
+        else if (MODE == EQM_AMP_CTL) depth = amp_depth<FC>(one_minus, mod_depth, (double)c);   // amplifier.rs:71-73
         else if (ENVK == 1) depth = el.depth;
-        else if (ENVK == 2) { depth = env_lane_depth(d.env, el, kk, one_minus, mod_depth, r.sr, rsr); ++kk; }
-        else { depth = env_depth(d.env, cur, one_minus, mod_depth, t, r.sr, rsr); ++t; }
+        else if (ENVK == 2) { depth = env_lane_depth<FC>(d.env, el, kk, one_minus, mod_depth, r.sr, rsr); ++kk; }
+        else { depth = env_depth<FC>(d.env, cur, one_minus, mod_depth, t, r.sr, rsr); ++t; }
         return amp_apply(y, depth, amplitude);
     };
     auto track = [&](float x) { const uint32_t b = __float_as_uint(x); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax; };
@@ -215,7 +218,7 @@ __device__ __forceinline__ void eq_spec_span(const EqDesc& d, const EqRun& r, co
             for (int e = 0; e < 4; ++e) {
                 const float x = xa[q][e];
                 track(x);
-                v[e] = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ca[q][e] : 0.f);
+                v[e] = fold(eq_step<FC>(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ca[q][e] : 0.f);
             }
             put4(b * EQ_BLK + 4 * q, v);
             __builtin_amdgcn_sched_barrier(0);   // four samples at a time: interleaving all sixteen epilogues costs more registers than it hides latency
@@ -232,21 +235,21 @@ __device__ __forceinline__ void eq_spec_span(const EqDesc& d, const EqRun& r, co
         if (MODE == EQM_AMP_CTL) c4 = ld_stream4(ctl + i);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { track(x4[e]); v[e] = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x4[e]), c4[e]); }
+        for (int e = 0; e < 4; ++e) { track(x4[e]); v[e] = fold(eq_step<FC>(s, lo_f, hi_f, g_lo, g_mid, g_hi, x4[e]), c4[e]); }
         put4(i, v);
     }
 #pragma unroll 1
     for (; i < n; ++i) {
         const float x = in[i];
         track(x);
-        const float v = fold(eq_step(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ctl[i] : 0.f);
+        const float v = fold(eq_step<FC>(s, lo_f, hi_f, g_lo, g_mid, g_hi, x), MODE == EQM_AMP_CTL ? ctl[i] : 0.f);
         if (STEREO) reinterpret_cast<float2*>(outm)[i] = make_float2(v, v); else outm[i] = v;
     }
 }
 
 // my chunk: [begin, begin + len) of the instance's stream.  With an inline Envelope the chunk is a whole number of ticks
 // (eq_plan_spec) and is walked tick by tick: the tick's Envelope state is loaded once per tick and turned into per-lane coefficients.
-template <int MODE, bool STEREO>
+template <int MODE, bool STEREO, bool FC>
 __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, const EnvTick* __restrict__ ticks, const size_t begin, const size_t len,
                                               EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     const float* __restrict__ in = d.in + begin;
@@ -254,7 +257,7 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
     const float* __restrict__ ctl = MODE == EQM_AMP_CTL ? d.ctl + begin : nullptr;
     if (MODE != EQM_AMP_ENV) {
         const EnvTick none{}; const EnvLane nl{};
-        eq_spec_span<MODE, STEREO, 0>(d, r, in, outm, ctl, len, none, nl, 0, s, xmin, xmax);
+        eq_spec_span<MODE, STEREO, 0, FC>(d, r, in, outm, ctl, len, none, nl, 0, s, xmin, xmax);
         return;
     }
     const size_t fpc = r.fpc;
@@ -268,9 +271,9 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
         const EnvLane el = env_lane_coeffs(d.env, cur, t, n, nice);
         float* const o = outm + (STEREO ? 2 * i : i);
         // wave-level choice of the span's form (lanes that left the loop already do not vote)
-        if (__ballot(el.general != 0u) != 0ull) eq_spec_span<MODE, STEREO, 3>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
-        else if (__ballot(el.flat == 0u) == 0ull) eq_spec_span<MODE, STEREO, 1>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
-        else eq_spec_span<MODE, STEREO, 2>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
+        if (__ballot(el.general != 0u) != 0ull) eq_spec_span<MODE, STEREO, 3, FC>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
+        else if (__ballot(el.flat == 0u) == 0ull) eq_spec_span<MODE, STEREO, 1, FC>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
+        else eq_spec_span<MODE, STEREO, 2, FC>(d, r, in + i, o, nullptr, n, cur, el, t, s, xmin, xmax);
         i += n; off = 0; ++call;
     }
 }
@@ -280,6 +283,7 @@ __device__ __forceinline__ void eq_spec_chunk(const EqDesc& d, const EqRun& r, c
 // with the chunk loop above -- sixteen samples of loads in flight while the previous sixteen are computed, outputs stored four at
 // a time; lanes of a wave may belong to instances with different epilogues (the switch is per lane).
 // ---------------------------------------------------------------------------------------------
+template <bool FC>
 __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r) {
     const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= n_inst) return;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
     const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
     const bool stereo = !(d.epi == 0u || (d.flags & MX_EQF_MONO_DUP));
     const int mode = d.epi != 2u ? EQM_PLAIN : ((d.flags & MX_EQF_ENV) ? EQM_AMP_ENV : (d.ctl ? EQM_AMP_CTL : EQM_AMP_CONST));
-#define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true>(d, r, ticks, 0, r.frames, s, xmin, xmax); else eq_spec_chunk<M, false>(d, r, ticks, 0, r.frames, s, xmin, xmax); break
+#define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true, FC>(d, r, ticks, 0, r.frames, s, xmin, xmax); else eq_spec_chunk<M, false, FC>(d, r, ticks, 0, r.frames, s, xmin, xmax); break
     switch (mode) { MX_EQ_CASE(EQM_PLAIN); MX_EQ_CASE(EQM_AMP_CONST); MX_EQ_CASE(EQM_AMP_CTL); default: MX_EQ_CASE(EQM_AMP_ENV); }
 #undef MX_EQ_CASE
 #pragma unroll
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(64) void k_eq_three_exact(const EqDesc* __restrict_
 // one lane per instance: its step is a chain of five dependent f64 instructions plus LDS round trips.  Removed.)
 // ---------------------------------------------------------------------------------------------
 struct EqPolesScratch { double* p3; double* hist_old; };   // [n][2][frames] last pole per cascade and sample; [n][3] the delay line before the run
+template <bool FC>
 __global__ __launch_bounds__(64) void k_eq_three_poles(const EqDesc* __restrict__ descs, EqState* __restrict__ states, uint32_t n_inst, EqRun r, EqPolesScratch sc) {
     const uint32_t id = blockIdx.x * 64 + threadIdx.x;
     if (id >= 2u * n_inst) return;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64) void k_eq_three_poles(const EqDesc* __restrict_
         for (int q = 0; q < 4; ++q) {
             double o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pump(f, p, (double)xa[q][e]);
+            for (int e = 0; e < 4; ++e) o[e] = pump<FC>(f, p, (double)xa[q][e]);
             typedef double __attribute__((ext_vector_type(2))) d2v;
             __builtin_nontemporal_store(d2v{o[0], o[1]}, reinterpret_cast<d2v*>(out + i + 4 * q));
             __builtin_nontemporal_store(d2v{o[2], o[3]}, reinterpret_cast<d2v*>(out + i + 4 * q + 2));
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(64) void k_eq_three_poles(const EqDesc* __restrict_
 #pragma unroll
         for (int q = 0; q < 4; ++q) xa[q] = xb[q];
     }
-    for (; i < N; ++i) out[i] = pump(f, p, (double)in[i]);
+    for (; i < N; ++i) out[i] = pump<FC>(f, p, (double)in[i]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { if (c) st.hi[k] = p[k]; else st.lo[k] = p[k]; }
     if (c == 0) {
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(64) void k_eq_three_poles(const EqDesc* __restrict_
     }
 }
 // sample-parallel: the band mix and the folded modules for sample i of instance blockIdx.y
+template <bool FC>
 __global__ __launch_bounds__(256) void k_eq_three_emit(const EqDesc* __restrict__ descs, uint32_t n_inst, EqRun r, EqPolesScratch sc) {
     const uint32_t inst = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(256) void k_eq_three_emit(const EqDesc* __restrict_
     const double h0 = i >= 3 ? (double)d.in[i - 3] : sc.hist_old[(size_t)inst * 3 + i];   // eq_three.rs:66,80-83: the input three samples back
     const double h = h0 - hp;
     const double mid = h0 - (h + l);
-    const float y = (float)(l * d.gain_lo + mid * d.gain_mid + h * d.gain_hi);          // eq_three.rs:76-88
-    EqSeqEmit em;
+    const float y = band_mix<FC>(l, mid, h, d.gain_lo, d.gain_mid, d.gain_hi);          // eq_three.rs:76-88
+    EqSeqEmit<FC> em;
     em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
     em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
     if ((em.E.flags & MX_EQF_ENV) && em.E.epi == 2u) {   // EqSeqEmit::seek with 32-bit arithmetic (the launcher keeps frames below 2^31: a 64-bit division per sample costs more than the sample)
@@ -391,16 +397,22 @@ void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun
     if (!n || !r.frames) return;
     if (scratch) {
         EqPolesScratch sc{(double*)scratch, (double*)scratch + (size_t)n * 2 * r.frames};
-        hipLaunchKernelGGL(k_eq_three_poles, dim3((2 * n + 63) / 64), dim3(64), 0, s, d, st, n, r, sc);
-        hipLaunchKernelGGL(k_eq_three_emit, dim3((unsigned)((r.frames + 255) / 256), n), dim3(256), 0, s, d, n, r, sc);
+        if (r.fc) {
+            hipLaunchKernelGGL(k_eq_three_poles<true>, dim3((2 * n + 63) / 64), dim3(64), 0, s, d, st, n, r, sc);
+            hipLaunchKernelGGL(k_eq_three_emit<true>, dim3((unsigned)((r.frames + 255) / 256), n), dim3(256), 0, s, d, n, r, sc);
+        } else {
+            hipLaunchKernelGGL(k_eq_three_poles<false>, dim3((2 * n + 63) / 64), dim3(64), 0, s, d, st, n, r, sc);
+            hipLaunchKernelGGL(k_eq_three_emit<false>, dim3((unsigned)((r.frames + 255) / 256), n), dim3(256), 0, s, d, n, r, sc);
+        }
         return;
     }
-    hipLaunchKernelGGL(k_eq_three_exact, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
+    if (r.fc) hipLaunchKernelGGL(k_eq_three_exact<true>, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
+    else hipLaunchKernelGGL(k_eq_three_exact<false>, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
 }
 
 // KMODE / KSTEREO >= 0: every instance of the launch has that epilogue (the usual case: a bank of equal strips) and the kernel is
 // compiled for it alone -- its own register budget, no dead variants; -1: decided per wave.
-template <int KMODE, int KSTEREO>
+template <int KMODE, int KSTEREO, bool FC>
 __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) void k_eq_three_spec(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                        uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
     const uint32_t inst = blockIdx.x / waves_per_inst;                         // wave-uniform: one instance per wave, descriptor in SGPRs
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
 #pragma unroll
             for (int q = 0; q < EQ_BLK / 4; ++q) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const double x = (double)xa[q][e]; pump(r.lo_f, s.lo, x); pump(r.hi_f, s.hi, x); }
+                for (int e = 0; e < 4; ++e) { const double x = (double)xa[q][e]; pump<FC>(r.lo_f, s.lo, x); pump<FC>(r.hi_f, s.hi, x); }
             }
 #pragma unroll
             for (int q = 0; q < EQ_BLK / 4; ++q) xa[q] = xb[q];
@@ -455,9 +467,9 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
     const bool stereo = !(d.epi == 0u || (d.flags & MX_EQF_MONO_DUP));
     const int mode = d.epi != 2u ? EQM_PLAIN : ((d.flags & MX_EQF_ENV) ? EQM_AMP_ENV : (d.ctl ? EQM_AMP_CTL : EQM_AMP_CONST));
     if constexpr (KMODE >= 0) {
-        eq_spec_chunk<KMODE, KSTEREO != 0>(d, r, ticks, begin, len, s, xmin, xmax);
+        eq_spec_chunk<KMODE, KSTEREO != 0, FC>(d, r, ticks, begin, len, s, xmin, xmax);
     } else {
-#define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true>(d, r, ticks, begin, len, s, xmin, xmax); else eq_spec_chunk<M, false>(d, r, ticks, begin, len, s, xmin, xmax); break
+#define MX_EQ_CASE(M) case M: if (stereo) eq_spec_chunk<M, true, FC>(d, r, ticks, begin, len, s, xmin, xmax); else eq_spec_chunk<M, false, FC>(d, r, ticks, begin, len, s, xmin, xmax); break
         switch (mode) { MX_EQ_CASE(EQM_PLAIN); MX_EQ_CASE(EQM_AMP_CONST); MX_EQ_CASE(EQM_AMP_CTL); default: MX_EQ_CASE(EQM_AMP_ENV); }
 #undef MX_EQ_CASE
     }
@@ -549,7 +561,7 @@ __device__ __forceinline__ EqK eq_constants(const EqDesc& d, const EqRun& r) {
 }
 
 // compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
-template <int SB, int MODE, int ENVK, bool WARM>   // WARM: `len` is the (negative) chunk-relative index of the lane's first warm-up sample
+template <int SB, int MODE, int ENVK, bool WARM, bool FC>   // WARM: `len` is the (negative) chunk-relative index of the lane's first warm-up sample
 __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const int lane, const int so, const int len,
                                                 const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     const double g_lo = K.g_lo, g_mid = K.g_mid, g_hi = K.g_hi, lo_f = K.lo_f, hi_f = K.hi_f;
@@ -568,22 +580,22 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
             const double dx[4] = {(double)x4[0], (double)x4[1], (double)x4[2], (double)x4[3]};
             if (WARM) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { pump(lo_f, s.lo, dx[e]); pump(hi_f, s.hi, dx[e]); }
+                for (int e = 0; e < 4; ++e) { pump<FC>(lo_f, s.lo, dx[e]); pump<FC>(hi_f, s.hi, dx[e]); }
             } else {
                 const double hh[4] = {s.h0, s.h1, s.h2, dx[0]};
                 f4v v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t b = __float_as_uint(x4[e]); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
-                    const float y = eq_step_h(s, lo_f, hi_f, g_lo, g_mid, g_hi, dx[e], hh[e]);
+                    const float y = eq_step_h<FC>(s, lo_f, hi_f, g_lo, g_mid, g_hi, dx[e], hh[e]);
                     if (MODE == EQM_PLAIN) v[e] = y;
                     else {
                         double depth;
                         const uint32_t kk = (uint32_t)(so + 4 * pce + e);      // sample index inside the chunk; el.dt0 counts from the tick's first sample
                         if (MODE == EQM_AMP_CONST) depth = depth_const;
                         else if (ENVK == 1) depth = el.depth;
-                        else if (ENVK == 2) depth = env_lane_depth(K.env, el, kk - el.k0, one_minus, mod_depth, K.sr, K.rsr);
-                        else depth = env_depth(K.env, cur, one_minus, mod_depth, el.t_chunk + kk, K.sr, K.rsr);
+                        else if (ENVK == 2) depth = env_lane_depth<FC>(K.env, el, kk - el.k0, one_minus, mod_depth, K.sr, K.rsr);
+                        else depth = env_depth<FC>(K.env, cur, one_minus, mod_depth, el.t_chunk + kk, K.sr, K.rsr);
                         v[e] = amp_apply(y, depth, amplitude);
                     }
                 }
@@ -616,7 +628,7 @@ __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* b
     }
 }
 
-template <int SB, int KMODE, int KSTEREO>
+template <int SB, int KMODE, int KSTEREO, bool FC>
 __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                                 uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][TILE]
@@ -674,7 +686,7 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
     int g = 0;
     for (; g < n_warm; ++g) {
         float* buf = begin_sb(g);
-        eq_tile_compute<SB, EQM_PLAIN, 0, true>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
+        eq_tile_compute<SB, EQM_PLAIN, 0, true, FC>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
     }
     if (active) {   // first sample of my chunk: record where the warm-up took me (chunks that started at the stream's start: the exact state)
 #pragma unroll
@@ -693,18 +705,18 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
             const int envk = __ballot(active && so0 < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so0 < len && el.flat == 0u) == 0ull ? 1 : 2);
             const int g_end = g + sb_per_tick < total ? g + sb_per_tick : total;
             if (envk == 1) {
-                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 1, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
+                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 1, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
             } else if (envk == 2) {
-                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 2, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
+                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 2, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
             } else {
-                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 3, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
+                for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 3, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0>(c, buf, so); }
             }
         }
     } else {
         for (; g < total; ++g) {
             float* buf = begin_sb(g);
             const int so = (g - n_warm) * EQ_SB;
-            eq_tile_compute<SB, KMODE, 0, false>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            eq_tile_compute<SB, KMODE, 0, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
             eq_tile_store<SB, KSTEREO != 0>(c, buf, so);
         }
     }
@@ -734,17 +746,19 @@ __device__ __forceinline__ bool dual_same(const Dual& a, const Dual& b) {
     return eq;
 }
 // does one sample of input x leave the state where it is?  (then every further sample of the same x does, too)
+template <bool FC>
 __device__ __forceinline__ bool dual_stuck(const Dual& s, double lo_f, double hi_f, double x) {
     Dual n = s;
-    pump(lo_f, n.lo, x); pump(hi_f, n.hi, x);
+    pump<FC>(lo_f, n.lo, x); pump<FC>(hi_f, n.hi, x);
     return dual_same(n, s);
 }
 // the EQ's f32 for a state that one more sample of the input has ALREADY been pumped into (eq_three.rs:70-85)
+template <bool FC>
 __device__ __forceinline__ float eq_out_of(const Dual& s, double h0, double g_lo, double g_mid, double g_hi) {
     const double l = s.lo[3];
     const double h = h0 - s.hi[3];
     const double mid = h0 - (h + l);
-    return (float)(l * g_lo + mid * g_mid + h * g_hi);
+    return band_mix<FC>(l, mid, h, g_lo, g_mid, g_hi);
 }
 
 // ---- the walk: chunks [j0, j_limit) in order with the TRUE state E at the start of chunk j0 in hand ----
@@ -771,6 +785,7 @@ __device__ __forceinline__ bool eq_all_nan(const double (&E)[8]) {
     for (int k = 0; k < 8; ++k) a = a && (E[k] != E[k]);
     return a;
 }
+template <bool FC>
 __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r, const EqSpecPlan& plan, const EqChunkRec* __restrict__ rc, uint32_t inst,
                                                  uint32_t j0, uint32_t j_limit, uint32_t force_until, double (&E)[8]) {
     const size_t C = plan.chunk;
@@ -795,17 +810,17 @@ __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r
             // chunk's f32 outputs are a function of (state, delay-line value) only -- compare them for the four delay-line values
             // the chunk sees; equal => what the lane wrote is the sequential order's, and the true state stays where it is
             const double xc = (double)__uint_as_float(R.xmin);
-            if (dual_stuck(A, r.lo_f, r.hi_f, xc) && dual_stuck(B, r.lo_f, r.hi_f, xc)) {
+            if (dual_stuck<FC>(A, r.lo_f, r.hi_f, xc) && dual_stuck<FC>(B, r.lo_f, r.hi_f, xc)) {
                 bool same = true;
                 const double hv[4] = {h0, h1, h2, xc};
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    same = same && __float_as_uint(eq_out_of(A, hv[q], d.gain_lo, d.gain_mid, d.gain_hi)) == __float_as_uint(eq_out_of(B, hv[q], d.gain_lo, d.gain_mid, d.gain_hi));
+                    same = same && __float_as_uint(eq_out_of<FC>(A, hv[q], d.gain_lo, d.gain_mid, d.gain_hi)) == __float_as_uint(eq_out_of<FC>(B, hv[q], d.gain_lo, d.gain_mid, d.gain_hi));
                 if (same) continue;                // E unchanged: the state stands still through the chunk
             }
         }
         // general case: both trajectories sample by sample; rewrite the outputs whose f32 differs; stop when they coalesce
-        EqSeqEmit em;
+        EqSeqEmit<FC> em;
         em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
         em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
         bool coalesced = false, stuckA = false, stuckB = false;
@@ -827,9 +842,9 @@ __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r
                     const double x = (double)xf;
                     const bool rep = have_prev && __float_as_uint(xf) == prev_bits;     // same input as the previous sample
                     prev_bits = __float_as_uint(xf); have_prev = true;
-                    if (!(rep && stuckA)) { const Dual o = A; pump(r.lo_f, A.lo, x); pump(r.hi_f, A.hi, x); stuckA = rep && dual_same(o, A); }
-                    if (!(rep && stuckB)) { const Dual o = B; pump(r.lo_f, B.lo, x); pump(r.hi_f, B.hi, x); stuckB = rep && dual_same(o, B); }
-                    const float ya = eq_out_of(A, h0, d.gain_lo, d.gain_mid, d.gain_hi), yb = eq_out_of(B, h0, d.gain_lo, d.gain_mid, d.gain_hi);
+                    if (!(rep && stuckA)) { const Dual o = A; pump<FC>(r.lo_f, A.lo, x); pump<FC>(r.hi_f, A.hi, x); stuckA = rep && dual_same(o, A); }
+                    if (!(rep && stuckB)) { const Dual o = B; pump<FC>(r.lo_f, B.lo, x); pump<FC>(r.hi_f, B.hi, x); stuckB = rep && dual_same(o, B); }
+                    const float ya = eq_out_of<FC>(A, h0, d.gain_lo, d.gain_mid, d.gain_hi), yb = eq_out_of<FC>(B, h0, d.gain_lo, d.gain_mid, d.gain_hi);
                     h0 = h1; h1 = h2; h2 = x;
                     if (force || __float_as_uint(ya) != __float_as_uint(yb)) { em.seek(begin + i); em.emit(begin + i, ya); }
                     if (!force && dual_same(A, B)) coalesced = true;            // from here on the lane's run IS the sequential order
@@ -850,6 +865,7 @@ __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r
 }
 // the rest of the stream from chunk j on under an absorbing (all-NaN) state, all 64 lanes: every output is the EQ's f32 for (that
 // state pumped once with the sample's input, the sample's delay-line value) through the folded epilogue, sample by sample independently
+template <bool FC>
 __device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, const EqSpecPlan& plan, uint32_t inst, uint32_t j, const double (&E)[8], int lane) {
     const size_t begin = (size_t)j * plan.chunk;
     Dual A0; dual_load(A0, E);
@@ -857,7 +873,7 @@ __device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, con
     const size_t n_units = (r.frames - begin + unit - 1) / unit;   // begin is a multiple of a tick when an Envelope is folded in (eq_plan_spec)
     for (size_t u = (size_t)lane; u < n_units; u += 64) {
         const size_t a = begin + u * unit, b = a + unit < r.frames ? a + unit : r.frames;
-        EqSeqEmit em;
+        EqSeqEmit<FC> em;
         em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
         em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
         em.seek(a);
@@ -872,8 +888,8 @@ __device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, con
                 if (i < b) {
                     const double x = (double)xv[e >> 2][e & 3];
                     Dual A = A0;
-                    pump(r.lo_f, A.lo, x); pump(r.hi_f, A.hi, x);
-                    em.emit(i, eq_out_of(A, h0, d.gain_lo, d.gain_mid, d.gain_hi));
+                    pump<FC>(r.lo_f, A.lo, x); pump<FC>(r.hi_f, A.hi, x);
+                    em.emit(i, eq_out_of<FC>(A, h0, d.gain_lo, d.gain_mid, d.gain_hi));
                     h0 = h1; h1 = h2; h2 = x;
                 }
             }
@@ -898,6 +914,7 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
 // i - 1 ended on the recorded end of its last chunk.  Where one did not, everything from there to the end of the round is walked again
 // in order from the true state, rewriting every sample (memory there may hold a wrong island's rewrites).  An absorbing all-NaN state
 // is never walked: the rest of the stream is filled by the whole wave (eq_nan_fill).
+template <bool FC>
 __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                          const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats) {
     const uint32_t inst = blockIdx.x;
@@ -920,12 +937,12 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
     unsigned long long repaired = 0;
     while (pos < NC) {
         if (have_E) {
-            if (eq_all_nan(E)) { repaired += NC - pos; eq_nan_fill(d, r, plan, inst, pos, E, lane); pos = NC; break; }
+            if (eq_all_nan(E)) { repaired += NC - pos; eq_nan_fill<FC>(d, r, plan, inst, pos, E, lane); pos = NC; break; }
             // in order from the true state, by one lane: to the end of the round that went wrong (rewriting everything), else one chunk at a
             // time -- as soon as a chunk ends on its recorded end the islands behind it are searched (and walked side by side) again
             const uint32_t lim = force_until > pos ? force_until : pos + 1;
             EqWalk w{lim, 0ull};
-            if (lane == 0) w = eq_repair_walk(d, r, plan, rc, inst, pos, lim, force_until, E);
+            if (lane == 0) w = eq_repair_walk<FC>(d, r, plan, rc, inst, pos, lim, force_until, E);
             w.j_end = (uint32_t)__shfl((int)w.j_end, 0, 64);
             repaired += (unsigned long long)(uint32_t)__shfl((int)(uint32_t)w.repaired, 0, 64);
 #pragma unroll
@@ -957,7 +974,7 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
             const uint32_t h = heads[lane], lim = heads[lane + 1];
 #pragma unroll
             for (int k = 0; k < 8; ++k) El[k] = rc[h - 1].end[k];
-            w = eq_repair_walk(d, r, plan, rc, inst, h, lim, 0u, El);
+            w = eq_repair_walk<FC>(d, r, plan, rc, inst, h, lim, 0u, El);
             in_sync = w.j_end == lim && same8(El, rc[lim - 1].end);
         }
         // the assumptions, in stream order
@@ -1074,33 +1091,37 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     EqChunkRec* recs = (EqChunkRec*)scratch;
     static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
     const int um = uniform_mode;
-    const int sb = env_int("MX_EQ_SPEC_SB", 16) == 32 ? 32 : 16;   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
+    const int sb = (!r.fc && env_int("MX_EQ_SPEC_SB", 16) == 32) ? 32 : 16;   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
     const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
                        r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
     if (tiled) {
         static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
         const size_t lds = std::max<size_t>(2 * 64 * (size_t)sb * sizeof(float), (size_t)lds_pad);
-#define MX_GT(M, S) { if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
-                      else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
+        // the contracted order (MX_FLAG_FP_CONTRACT) is compiled for the 16-sample super-block only (the faster of the two)
+#define MX_GT(M, S) { if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
+                      else if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
+                      else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
         switch (um) {
         case 0: MX_GT(EQM_PLAIN, 0); break;     case 1: MX_GT(EQM_PLAIN, 1); break;
         case 2: MX_GT(EQM_AMP_CONST, 0); break; case 3: MX_GT(EQM_AMP_CONST, 1); break;
         case 6: MX_GT(EQM_AMP_ENV, 0); break;   default: MX_GT(EQM_AMP_ENV, 1); break;
         }
 #undef MX_GT
-        hipLaunchKernelGGL(k_eq_three_repair, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
-        return;
-    }
-#define MX_GO(M, S) hipLaunchKernelGGL((k_eq_three_spec<M, S>), dim3(n * wpi), dim3(64), 0, s, d, (const EqState*)st, r, plan, wpi, recs)
-    switch (uniform_mode) {
-    case 0: MX_GO(EQM_PLAIN, 0); break;     case 1: MX_GO(EQM_PLAIN, 1); break;
-    case 2: MX_GO(EQM_AMP_CONST, 0); break; case 3: MX_GO(EQM_AMP_CONST, 1); break;
-    case 4: MX_GO(EQM_AMP_CTL, 0); break;   case 5: MX_GO(EQM_AMP_CTL, 1); break;
-    case 6: MX_GO(EQM_AMP_ENV, 0); break;   case 7: MX_GO(EQM_AMP_ENV, 1); break;
-    default: MX_GO(-1, -1); break;
-    }
+    } else {
+#define MX_GO(M, S) { if (r.fc) hipLaunchKernelGGL((k_eq_three_spec<M, S, true>), dim3(n * wpi), dim3(64), 0, s, d, (const EqState*)st, r, plan, wpi, recs); \
+                      else hipLaunchKernelGGL((k_eq_three_spec<M, S, false>), dim3(n * wpi), dim3(64), 0, s, d, (const EqState*)st, r, plan, wpi, recs); }
+        switch (uniform_mode) {
+        case 0: MX_GO(EQM_PLAIN, 0); break;     case 1: MX_GO(EQM_PLAIN, 1); break;
+        case 2: MX_GO(EQM_AMP_CONST, 0); break; case 3: MX_GO(EQM_AMP_CONST, 1); break;
+        case 4: MX_GO(EQM_AMP_CTL, 0); break;   case 5: MX_GO(EQM_AMP_CTL, 1); break;
+        case 6: MX_GO(EQM_AMP_ENV, 0); break;   case 7: MX_GO(EQM_AMP_ENV, 1); break;
+        default: MX_GO(-1, -1); break;
+        }
 #undef MX_GO
-    hipLaunchKernelGGL(k_eq_three_repair, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
+    }
+    // the proof (and, where a boundary fails, the repair) runs the same order the chunks ran
+    if (r.fc) hipLaunchKernelGGL(k_eq_three_repair<true>, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
+    else hipLaunchKernelGGL(k_eq_three_repair<false>, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
 }
 
 }  // namespace mx

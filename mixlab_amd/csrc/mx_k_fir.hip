@@ -5,12 +5,15 @@
 // Arithmetic follows the reference's own convention for audio (mixer.rs:62, eq_three.rs:85,
 // amplifier.rs:56): widen f32 to f64, accumulate in f64 in ASCENDING tap index with separate
 // multiply and add (no FMA), round once to f32.  Bit-exact against the oracle; parity unpinned.
+// FC (MX_FLAG_FP_CONTRACT): the accumulation as acc = fma(h[k], x, acc) in the same ascending order -- half the f64 instructions;
+// equal to the oracle's contract mode bit for bit, within 1 ULP of the separate multiply-and-add spec.
 //
 // Every output sample is independent given the input history, so both kernels are plain
 // data-parallel: a 256-lane block stages its input window in LDS (coalesced), taps are wave-uniform.
 #include <algorithm>
 
 #include "mx_dev.hpp"
+#include "mx_env_math.hpp"   // mul_add<FC>
 
 namespace mx {
 
@@ -27,6 +30,7 @@ namespace mx {
 // 5 frames = 20 banks, and the 16 lanes a ds_read_b128 serves per pass cover all 64 banks exactly once.
 // Frames are widened to f64 once while staging (exact); taps sit in LDS (uniform reads broadcast).
 __device__ __forceinline__ int fir_pad(int f) { return f + (f >> 2); }
+template <bool FC>
 __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const FirDesc* __restrict__ descs, size_t frames) {
     const FirDesc d = descs[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const FirDesc* __restrict__ d
 #pragma unroll
                     for (int j = 0; j < FIR_PER; ++j) {
                         const double2 x = w[(j - u + FIR_PER) % FIR_PER];
-                        al[j] = al[j] + h * x.x;
-                        ar[j] = ar[j] + h * x.y;
+                        al[j] = mul_add<FC>(h, x.x, al[j]);
+                        ar[j] = mul_add<FC>(h, x.y, ar[j]);
                     }
                     // frame x[o - 1 - (k + u)] enters; it replaces the slot of x[o + 3 - (k + u)], which no later tap needs
                     w[(FIR_PER - 1 - u + FIR_PER) % FIR_PER] = rd((K - 1) - 1 - (k + u) + FIR_PER);
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const FirDesc* __restrict__ d
             for (; k < K; ++k) {                                          // K not a multiple of 4: rotate by moving
                 const double h = tapl[k];
 #pragma unroll
-                for (int j = 0; j < FIR_PER; ++j) { al[j] = al[j] + h * w[j].x; ar[j] = ar[j] + h * w[j].y; }
+                for (int j = 0; j < FIR_PER; ++j) { al[j] = mul_add<FC>(h, w[j].x, al[j]); ar[j] = mul_add<FC>(h, w[j].y, ar[j]); }
 #pragma unroll
                 for (int j = FIR_PER - 1; j > 0; --j) w[j] = w[j - 1];
                 w[0] = rd((K - 1) - 1 - k + FIR_PER);
@@ -104,12 +108,13 @@ __global__ __launch_bounds__(256) void k_fir_history(const FirDesc* __restrict__
     __syncthreads();
     for (int j = threadIdx.x; j < H; j += 256) d.hist[j] = tmp[j];
 }
-void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s) {
+void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s, bool fc) {
     if (!n || !frames) return;
     const size_t wn = (size_t)FIR_TILE + max_taps + FIR_PER;
     const size_t lds = (size_t)((max_taps + 1) & ~1u) * sizeof(double) + (wn + wn / 4 + 2) * sizeof(double2);
     dim3 grid(grid_x(frames, FIR_TILE, 1024), n);
-    hipLaunchKernelGGL(k_fir, grid, dim3(FIR_BLOCK), lds, s, d, frames);
+    if (fc) hipLaunchKernelGGL(k_fir<true>, grid, dim3(FIR_BLOCK), lds, s, d, frames);
+    else hipLaunchKernelGGL(k_fir<false>, grid, dim3(FIR_BLOCK), lds, s, d, frames);
     hipLaunchKernelGGL(k_fir_history, dim3(n), dim3(256), max_taps * sizeof(float2), s, d, frames);
 }
 
@@ -126,7 +131,7 @@ void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, 
 // UPC: the interpolation factor when the launcher knows every channel of the launch has that one (160: the 44.1 -> 48 kHz ratio), else 0.  With it the
 // table's row stride is a constant and a tap's coefficient read carries its row as an instruction immediate; at run-time stride every tap costs an
 // address add per lane (16 of a lane's ~124 VALU instructions per output).
-template <int UPC>
+template <int UPC, bool FC>
 __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict__ descs, size_t out_frames,
                                                   uint64_t out_base, uint64_t in_base, uint32_t win_cap) {
     const ResampleDesc d = descs[blockIdx.y];
@@ -202,14 +207,15 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict
             for (int k = 0; k < P; ++k) {
                 const double c = UPC ? h[(size_t)k * UPC] : h[(size_t)k * up];
                 const double vl = l[-k], vr = r[-k];
-                al = al + c * vl;
-                ar = ar + c * vr;
+                al = mul_add<FC>(c, vl, al);
+                ar = mul_add<FC>(c, vr, ar);
             }
             reinterpret_cast<float2*>(d.out)[blk + tid] = make_float2((float)al, (float)ar);
         }
         __syncthreads();
     }
 }
+template <bool FC>
 __global__ __launch_bounds__(256) void k_resample_gather(const ResampleDesc* __restrict__ descs, size_t out_frames,
                                                          uint64_t out_base, uint64_t in_base) {
     const ResampleDesc d = descs[blockIdx.y];
@@ -227,8 +233,8 @@ __global__ __launch_bounds__(256) void k_resample_gather(const ResampleDesc* __r
             float2 v = make_float2(0.f, 0.f);
             if (f >= 0) { if (d.in) v = reinterpret_cast<const float2*>(d.in)[f]; }
             else { const long long hh = (long long)H + f; if (hh >= 0) v = d.hist[hh]; }
-            al = al + h[k] * (double)v.x;
-            ar = ar + h[k] * (double)v.y;
+            al = mul_add<FC>(h[k], (double)v.x, al);
+            ar = mul_add<FC>(h[k], (double)v.y, ar);
         }
         reinterpret_cast<float2*>(d.out)[m] = make_float2((float)al, (float)ar);
     }
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(256) void k_resample_history(const ResampleDesc* __
     for (int j = threadIdx.x; j < H; j += 256) d.hist[j] = tmp[j];
 }
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles, uint32_t win_frames,
-                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up) {
+                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up, bool fc) {
     if (!n || !out_frames) return;
     const size_t lds = (size_t)tab_doubles * sizeof(double) + (size_t)((win_frames + 1u) & ~1u) * 2 * sizeof(double);
     if (lds <= 60 * 1024) {
@@ -258,10 +264,13 @@ void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint3
         static const uint32_t cus = [] { int dev = 0, n_cu = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256; return (uint32_t)std::max(n_cu, 1); }();
         const uint32_t resident = cus * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
         const uint32_t per_ch = (uint32_t)std::max<size_t>(1, std::min<size_t>((out_frames + 255) / 256, std::max<uint32_t>(1u, resident / n)));
-        if (common_up == 160u) hipLaunchKernelGGL(k_resample<160>, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
-        else hipLaunchKernelGGL(k_resample<0>, dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames);
+#define MX_RS_GO(U, F) hipLaunchKernelGGL((k_resample<U, F>), dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames)
+        if (common_up == 160u) { if (fc) MX_RS_GO(160, true); else MX_RS_GO(160, false); }
+        else { if (fc) MX_RS_GO(0, true); else MX_RS_GO(0, false); }
+#undef MX_RS_GO
     } else {
-        hipLaunchKernelGGL(k_resample_gather, dim3(grid_x(out_frames, 256, 1024), n), dim3(256), 0, s, d, out_frames, out_base, in_base);
+        if (fc) hipLaunchKernelGGL(k_resample_gather<true>, dim3(grid_x(out_frames, 256, 1024), n), dim3(256), 0, s, d, out_frames, out_base, in_base);
+        else hipLaunchKernelGGL(k_resample_gather<false>, dim3(grid_x(out_frames, 256, 1024), n), dim3(256), 0, s, d, out_frames, out_base, in_base);
     }
     hipLaunchKernelGGL(k_resample_history, dim3(n), dim3(256), (max_taps + 1) * sizeof(float2), s, d, in_frames);
 }

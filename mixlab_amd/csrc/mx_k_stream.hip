@@ -7,6 +7,7 @@
 // L,R) -- n_ticks consecutive 735/800-sample tick buffers back to back -- 256-byte aligned.
 // Instances of one module kind are batched into one launch.
 #include "mx_dev.hpp"
+#include "mx_env_math.hpp"
 
 namespace mx {
 
@@ -15,6 +16,7 @@ namespace mx {
 //   out[i] = (in[i] as f64 * (1.0 - d + d * mod[i/2]) * amplitude) as f32
 // algorithmic bytes per frame: 8 (in) + 4 (ctl) + 8 (out) = 20
 // ---------------------------------------------------------------------------------------------
+template <bool FC>   // FC: depth() as one fma (MX_FLAG_FP_CONTRACT, mul_add<> in mx_env_math.hpp)
 __global__ __launch_bounds__(256) void k_amplifier(const AmpDesc* __restrict__ descs, size_t n /* stereo floats */) {
     const AmpDesc d = descs[blockIdx.y];
     const size_t nq = (n + 3) >> 2;
@@ -27,8 +29,8 @@ __global__ __launch_bounds__(256) void k_amplifier(const AmpDesc* __restrict__ d
             const float2 c = ld2(d.ctl, q, n >> 1);   // stereo floats 4q..4q+3 <-> mono 2q, 2q+1
             m0 = (double)c.x; m1 = (double)c.y;
         }
-        const double dep0 = one_minus + md * m0;      // depth(), amplifier.rs:71-73
-        const double dep1 = one_minus + md * m1;
+        const double dep0 = mul_add<FC>(md, m0, one_minus);   // depth(), amplifier.rs:71-73
+        const double dep1 = mul_add<FC>(md, m1, one_minus);
         float4 o;
         o.x = (float)((double)v.x * dep0 * amp);
         o.y = (float)((double)v.y * dep0 * amp);
@@ -37,11 +39,12 @@ __global__ __launch_bounds__(256) void k_amplifier(const AmpDesc* __restrict__ d
         st4(d.out, q, n, o);
     }
 }
-void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s) {
+void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s, bool fc) {
     if (!n || !frames) return;
     const size_t ns = frames * 2;
     dim3 grid(grid_x((ns + 3) / 4, 256, 4096), n);
-    hipLaunchKernelGGL(k_amplifier, grid, dim3(256), 0, s, d, ns);
+    if (fc) hipLaunchKernelGGL(k_amplifier<true>, grid, dim3(256), 0, s, d, ns);
+    else hipLaunchKernelGGL(k_amplifier<false>, grid, dim3(256), 0, s, d, ns);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -97,12 +97,13 @@ struct ResampleDesc { const float* in; float* out; const double* taps /* [up][ta
                       uint32_t up, down, taps_per_phase, pad; };
 
 // Launchers.  `frames` = mono samples in this run (= n_ticks * SPT); stereo buffers hold 2*frames.
-void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s);
-void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s);
+// fc (here and below): MX_FLAG_FP_CONTRACT -- the kernel instantiated for the contracted order (mul_add<true>, mx_env_math.hpp)
+void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s, bool fc = false);
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s, bool fc = false);
 // per-tick Envelope states of the folded Envelopes of an EqThree group: ticks[inst][call], `n_calls` ticks of `fpc` samples from t0
-void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s);
+void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s, bool fc = false);
 // what every EqThree launch needs beyond the descriptors: the per-tick Envelope table (null when no instance folds one)
-struct EqRun { size_t frames; size_t fpc /* samples per tick (call) */; uint32_t n_calls; uint32_t pad; uint64_t t0; double sr, rsr /* RN(1 / sr), host */, lo_f, hi_f; const EnvTick* ticks /* [n][n_calls] */; };
+struct EqRun { size_t frames; size_t fpc /* samples per tick (call) */; uint32_t n_calls; uint32_t fc /* MX_FLAG_FP_CONTRACT: the contracted order */; uint64_t t0; double sr, rsr /* RN(1 / sr), host */, lo_f, hi_f; const EnvTick* ticks /* [n][n_calls] */; };
 // scratch != nullptr: the split-cascade form for few instances (eq_use_poles_split; eq_poles_scratch_bytes of scratch); else one lane per instance
 void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, void* scratch, hipStream_t s);
 bool eq_use_poles_split(uint32_t n, size_t frames);
@@ -130,9 +131,9 @@ void launch_f32_to_i16(const float* in, int16_t* out, size_t n, int dup, hipStre
 void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s);
 struct CopyJob { void* dst; const void* src; size_t bytes; };
 void launch_copy_jobs(const CopyJob* device_jobs, uint32_t n, hipStream_t s);   // one block per job
-void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s);
+void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s, bool fc = false);
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles /* max up * taps_per_phase */,
                      uint32_t win_frames /* max 255 * down / up + 2 + taps_per_phase */, size_t in_frames, size_t out_frames,
-                     uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up = 0 /* every channel's `up` when they all agree, else 0 */);
+                     uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up = 0 /* every channel's `up` when they all agree, else 0 */, bool fc = false);
 
 }  // namespace mx

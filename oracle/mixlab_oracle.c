@@ -12,6 +12,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ------------------------------------------------------------------------------------------ */
+/* CONTRACT MODE (test infrastructure for MX_FLAG_FP_CONTRACT, include/mixlab_gpu.h).  Off (the default) every expression is
+ * evaluated as the reference writes it, never fused.  On, the SAME expressions are evaluated with each multiply fused into the add
+ * that consumes it -- spelled out with fma(), never left to the compiler (this file is built with -ffp-contract=off either way):
+ *   eq_three.rs:117-124  p0 += fma(f, x - p0, VSA);  p_k = fma(f, p_{k-1} - p_k, p_k)
+ *   eq_three.rs:76-88    out = fma(hi, g_hi, fma(mid, g_mid, lo * g_lo))
+ *   envelope.rs:46-47    sustain + (1 - sustain) * decay  = fma(1 - sustain, decay, sustain)
+ *   amplifier.rs:71-73   (1 - d) + d * mod                = fma(d, mod, 1 - d)
+ *   Fir / Resample       acc = fma(h[k], x, acc), ascending k
+ * It is what the device's contracted kernels must reproduce bit for bit; tests bound its distance from the exact mode (<= 1 ULP
+ * of every f32 output).  The flag is process-global and read once per call. */
+static int g_fp_contract = 0;
+void orc_set_fp_contract(int on) { g_fp_contract = on ? 1 : 0; }
+int orc_get_fp_contract(void) { return g_fp_contract; }
+#define ORC_INLINE static inline __attribute__((always_inline))
+ORC_INLINE double orc_mul_add(const int fc, double a, double b, double c) { return fc ? fma(a, b, c) : a * b + c; }
+
 /* std::f64::consts::PI */
 #define ORC_PI 3.14159265358979323846264338327950288
 
@@ -55,7 +72,14 @@ void orc_eq_three_init(orc_eq_three* s, double sample_rate) {
 }
 
 /* LowPass::pump, eq_three.rs:117-124 */
-static inline double orc_pump(double f, double* p, double sample) {
+ORC_INLINE double orc_pump(const int fc, double f, double* p, double sample) {
+    if (fc) {
+        p[0] += fma(f, sample - p[0], ORC_VSA);
+        p[1] = fma(f, p[0] - p[1], p[1]);
+        p[2] = fma(f, p[1] - p[2], p[2]);
+        p[3] = fma(f, p[2] - p[3], p[3]);
+        return p[3];
+    }
     p[0] += f * (sample - p[0]) + ORC_VSA;
     p[1] += f * (p[0] - p[1]);
     p[2] += f * (p[1] - p[2]);
@@ -64,23 +88,27 @@ static inline double orc_pump(double f, double* p, double sample) {
 }
 
 /* EqThree::run_tick, eq_three.rs:58-89 */
-void orc_eq_three_run(orc_eq_three* s, const orc_eq_three_params* p, const float* in, float* out, size_t n) {
+ORC_INLINE void eq_three_run_impl(const int fc, orc_eq_three* s, const orc_eq_three_params* p, const float* in, float* out, size_t n) {
     double gain_lo = orc_decibel_to_linear(p->gain_lo_db);
     double gain_mid = orc_decibel_to_linear(p->gain_mid_db);
     double gain_hi = orc_decibel_to_linear(p->gain_hi_db);
     for (size_t i = 0; i < n; i++) {
         double sample = (double)(in ? in[i] : 0.0f);
-        double lo = orc_pump(s->lo_f, s->lo, sample);
-        double hi = s->history[0] - orc_pump(s->hi_f, s->hi, sample);
+        double lo = orc_pump(fc, s->lo_f, s->lo, sample);
+        double hi = s->history[0] - orc_pump(fc, s->hi_f, s->hi, sample);
         double mid = s->history[0] - (hi + lo);
         s->history[0] = s->history[1];
         s->history[1] = s->history[2];
         s->history[2] = sample;
+        if (fc) { out[i] = (float)fma(hi, gain_hi, fma(mid, gain_mid, lo * gain_lo)); continue; }
         lo = lo * gain_lo;
         mid = mid * gain_mid;
         hi = hi * gain_hi;
         out[i] = (float)(lo + mid + hi);
     }
+}
+void orc_eq_three_run(orc_eq_three* s, const orc_eq_three_params* p, const float* in, float* out, size_t n) {
+    if (g_fp_contract) eq_three_run_impl(1, s, p, in, out, n); else eq_three_run_impl(0, s, p, in, out, n);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -106,7 +134,7 @@ static double orc_env_amplitude(const orc_envelope_params* p, const orc_envelope
         } else {
             double ms_since_decay_started = ms_since_on - p->attack_ms;
             double decay_amplitude = 1.0 - orc_clamp01(1.0 / p->decay_ms * ms_since_decay_started);
-            return p->sustain_amplitude + ((1.0 - p->sustain_amplitude) * decay_amplitude);
+            return orc_mul_add(g_fp_contract, 1.0 - p->sustain_amplitude, decay_amplitude, p->sustain_amplitude);
         }
     }
     case 2: {
@@ -140,9 +168,10 @@ void orc_envelope_run(orc_envelope* s, const orc_envelope_params* p, double samp
 void orc_amplifier_run(const orc_amplifier_params* p, const float* in_stereo, const float* control,
                        float* out_stereo, size_t stereo_len) {
     double mod_depth = p->mod_depth, amplitude = p->amplitude;
+    const int fc = g_fp_contract;
     for (size_t i = 0; i < stereo_len; i++) {
         double mod_value = control ? (double)control[i / 2] : 1.0; /* amplifier.rs:54 */
-        double depth = 1.0 - mod_depth + mod_depth * mod_value;    /* amplifier.rs:71-73 */
+        double depth = orc_mul_add(fc, mod_depth, mod_value, 1.0 - mod_depth);    /* amplifier.rs:71-73: 1.0 - mod_depth + mod_depth * mod_value */
         float x = in_stereo ? in_stereo[i] : 0.0f;
         out_stereo[i] = (float)((double)x * depth * amplitude);    /* amplifier.rs:56 */
     }
@@ -260,11 +289,12 @@ static void update_hist(float* hist, uint32_t H, const float* in, size_t frames)
 }
 void orc_fir_run(const double* taps, uint32_t n_taps, float* hist, const float* in, float* out, size_t frames) {
     const uint32_t H = n_taps - 1;
+    const int fc = g_fp_contract;
     for (size_t n = 0; n < frames; n++) {
         double al = 0.0, ar = 0.0;
         for (uint32_t k = 0; k < n_taps; k++) {
-            al = al + taps[k] * (double)fir_x(hist, H, in, (long long)n - k, 0);
-            ar = ar + taps[k] * (double)fir_x(hist, H, in, (long long)n - k, 1);
+            al = orc_mul_add(fc, taps[k], (double)fir_x(hist, H, in, (long long)n - k, 0), al);
+            ar = orc_mul_add(fc, taps[k], (double)fir_x(hist, H, in, (long long)n - k, 1), ar);
         }
         out[2 * n] = (float)al; out[2 * n + 1] = (float)ar;
     }
@@ -274,6 +304,7 @@ void orc_fir_run(const double* taps, uint32_t n_taps, float* hist, const float* 
 void orc_resample_run(const double* taps, uint32_t up, uint32_t down, uint32_t P, float* hist,
                       uint64_t in_base, uint64_t out_base, const float* in, size_t in_frames, float* out, size_t out_frames) {
     const uint32_t H = P - 1;
+    const int fc = g_fp_contract;
     for (size_t m = 0; m < out_frames; m++) {
         uint64_t num = (out_base + m) * (uint64_t)down;
         uint64_t n_abs = num / up;
@@ -282,8 +313,8 @@ void orc_resample_run(const double* taps, uint32_t up, uint32_t down, uint32_t P
         const double* h = taps + (size_t)phase * P;
         double al = 0.0, ar = 0.0;
         for (uint32_t k = 0; k < P; k++) {
-            al = al + h[k] * (double)fir_x(hist, H, in, n - k, 0);
-            ar = ar + h[k] * (double)fir_x(hist, H, in, n - k, 1);
+            al = orc_mul_add(fc, h[k], (double)fir_x(hist, H, in, n - k, 0), al);
+            ar = orc_mul_add(fc, h[k], (double)fir_x(hist, H, in, n - k, 1), ar);
         }
         out[2 * m] = (float)al; out[2 * m + 1] = (float)ar;
     }

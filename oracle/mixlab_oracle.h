@@ -63,6 +63,11 @@ typedef struct { double freq; uint32_t waveform; uint32_t _pad; } orc_oscillator
 typedef struct { double freq_lo, freq_hi; } orc_fm_sine_params;                                        /* :292-296 */
 typedef struct { uint32_t gate_open; } orc_trigger_params;                                             /* :304-308 */
 
+/* ---- contract mode: the checker for MX_FLAG_FP_CONTRACT (see mixlab_oracle.c).  0 (default): the reference's order, never fused;
+ * 1: the same expressions with every multiply fused into the add that consumes it, as explicit fma().  Process-global. ---- */
+void orc_set_fp_contract(int on);
+int orc_get_fp_contract(void);
+
 /* ---- stateless helpers ---- */
 double orc_decibel_to_linear(double db);                  /* protocol/src/lib.rs:469-471 */
 double orc_lowpass_coeff(double freq, double sample_rate); /* src/module/eq_three.rs:113-115 */

@@ -86,6 +86,27 @@ lib.orc_rational_cmp.restype = C.c_int
 lib.orc_rational_cmp.argtypes = [Rational, Rational]
 
 
+lib.orc_set_fp_contract.argtypes = [C.c_int]
+lib.orc_get_fp_contract.restype = C.c_int
+
+
+class fp_contract:
+    """`with oracle.fp_contract():` -- the oracle evaluates EqThree / Envelope / Amplifier / Fir / Resample in the CONTRACTED order
+    (explicit fma, oracle/mixlab_oracle.c "CONTRACT MODE"): the checker for graphs built with MX_FLAG_FP_CONTRACT."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = lib.orc_get_fp_contract()
+        lib.orc_set_fp_contract(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        lib.orc_set_fp_contract(self.prev)
+        return False
+
+
 def _p(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
