@@ -446,7 +446,10 @@ int mx_graph_rgba_output(mx_graph* g, uint32_t node, void** device_rgba, int32_t
  * a frame: *frame = that picture through the node's DynamicScaler (the input itself when it already has the encoder's size,
  * encode.rs:342-345; one reference for the caller, still on the device: download it or hand it to a device encoder), frame_ts = ts +
  * tick_offset (monitor.rs:229), dur = its duration hint; else video_present = 0 and *frame = NULL.  The reference DROPS a tick when its
- * codec thread lags (try_send on a channel of two, monitor.rs:163-177); nothing is dropped here. */
+ * codec thread lags (try_send on a channel of two, monitor.rs:163-177): a node built with mx_monitor_params_ex.queue_depth > 0 does the same
+ * (`dropped`, below: nothing is scaled for such a tick, until mx_graph_monitor_consume frees slots); the short parameter form keeps every tick.
+ * Device memory inside a batched run (MX_VIDEO_BATCH = K ticks per launch, default 16): every scaled layer's Scaler holds a ring of 2K output
+ * frames (1080p yuv420p: 32 x 3.1 MB = 100 MB per scaled layer) and every VIDEO_TO_RGBA node K RGBA buffers (16 x 8.3 MB = 133 MB). */
 typedef struct { int32_t video_present; int64_t ts_num, ts_den, frame_ts_num, frame_ts_den, dur_num, dur_den;
                  int32_t dropped; /* mx_monitor_params_ex.queue_depth > 0: the queue was full, the codec thread never gets this tick (nor its audio) */ int32_t _pad; } mx_monitor_tick;
 int mx_graph_read_monitor_tick(mx_graph* g, uint32_t node, uint32_t tick_in_run, mx_monitor_tick* info, mx_dframe** frame);

@@ -74,8 +74,9 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
         for f in [ex.submit(_compile_one, hipcc, s, o, verbose) for (s, o) in jobs]:
             f.result()
     tmp = LIB.with_suffix(".so.tmp")
-    # librccl is linked directly: the bus exchange (mx_exchange_*) calls ncclAllGather / ncclSend / ncclRecv itself
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *[str(o) for o in objs], "-lrccl"]
+    # librccl is NOT a link-time dependency: the bus exchange (mx_exchange_*) calls ncclAllGather / ncclSend / ncclRecv itself through
+    # entry points it binds with dlopen on first use (mx_exchange.cpp), so hosts without RCCL can build and load the library
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *[str(o) for o in objs], "-ldl"]
     if verbose:
         print("[mixlab_amd.build]", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=str(PKG))

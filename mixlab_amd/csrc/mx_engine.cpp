@@ -340,8 +340,9 @@ Graph::~Graph() {
     for (auto& v : prof_runs_) for (auto& e : v) (void)hipEventDestroy(e);
     for (auto& v : prof_pool_) for (auto& e : v) (void)hipEventDestroy(e);
     for (Stage& st : stage_) { if (st.done) (void)hipEventDestroy(st.done); if (st.host) (void)hipHostFree(st.host); }
-    if (stream_) video_stream_retired(stream_);   // (also for a caller's stream: this graph will not launch on it again, the next one starts an empty ring)
-    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    // the descriptor ring launch_video_batch keeps per stream goes with a stream this graph OWNS; a caller's stream may be shared with other
+    // graphs / scalers that are launching on it right now (their ring must not be freed under them): its ring lives as long as the process
+    if (own_stream_ && stream_) { video_stream_retired(stream_); (void)hipStreamDestroy(stream_); }
 }
 
 // Graph-compiler fusion.  A port buffer is a per-tick temporary of Engine::run_tick
@@ -1427,7 +1428,7 @@ void Graph::run_video_tick(uint64_t t) {
                 c.rgba = out; c.rgba_stride = (uint32_t)stride; c.width = d->width; c.height = d->height;
                 c.use_matrix = p.use_matrix;
                 for (int k = 0; k < 12; ++k) c.m[k] = p.matrix_q12[k];
-                // Inside a batched run the sink runs LATE and K ticks at a time (K = video_batch_ticks(), 8): the chains of ticks k .. k + K - 1
+                // Inside a batched run the sink runs LATE and K ticks at a time (K = video_batch_ticks(), default 16): the chains of ticks k .. k + K - 1
                 // leave in ONE launch together with the scaler tiles ticks k + K .. k + 2K - 1 queued (mx_k_video.hip k_video_batch) -- the
                 // chip then holds waves of several frames in every phase at once instead of marching through load / compute / store in step.
                 // Every K-th sink call is an event: it takes ALL queued scales along (so the scales a chain needs left at its own event

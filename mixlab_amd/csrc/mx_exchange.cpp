@@ -12,21 +12,57 @@
 //               ring's order differs per chunk): explicitly non-parity, RCCL only.
 #include "mx_exchange.hpp"
 
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on first use (below)
 
 #include <cstring>
+#include <mutex>
 #include <string>
 
 namespace mx {
 
+// RCCL is bound LAZILY (dlopen on the first RCCL exchange / mx_exchange_unique_id): single-GPU audio and video use and the loopback
+// transport never call it, so a host without librccl can still build and load libmixlab_gpu.so; asking for the RCCL transport there
+// fails with MX_ERR_DEVICE and a message that names the library.  The collectives of the data path are still this library's own calls.
+namespace {
+struct Rccl {
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    std::string error;   // why it is not available (empty: loaded)
+};
+const Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { const char* e = dlerror(); r.error = std::string("librccl.so could not be loaded (") + (e ? e : "?") + "): the RCCL transport is not available on this host"; return; }
+        auto sym = [&](auto& fp, const char* n) { fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(h, n)); if (!fp && r.error.empty()) r.error = std::string("librccl.so has no ") + n; };
+        sym(r.GetErrorString, "ncclGetErrorString"); sym(r.GetUniqueId, "ncclGetUniqueId"); sym(r.CommInitRank, "ncclCommInitRank");
+        sym(r.CommDestroy, "ncclCommDestroy"); sym(r.AllGather, "ncclAllGather"); sym(r.AllReduce, "ncclAllReduce");
+        sym(r.Send, "ncclSend"); sym(r.Recv, "ncclRecv"); sym(r.GroupStart, "ncclGroupStart"); sym(r.GroupEnd, "ncclGroupEnd");
+    });
+    if (!r.error.empty()) throw Error(MX_ERR_DEVICE, r.error);
+    return r;
+}
+}  // namespace
+
 static void nccl_check(ncclResult_t r, const char* what) {
-    if (r != ncclSuccess) throw Error(MX_ERR_DEVICE, std::string(what) + ": " + ncclGetErrorString(r));
+    if (r != ncclSuccess) throw Error(MX_ERR_DEVICE, std::string(what) + ": " + rccl().GetErrorString(r));
 }
 
 void exchange_unique_id(void* out128) {
     static_assert(sizeof(ncclUniqueId) == MX_EXCHANGE_ID_BYTES, "ncclUniqueId size");
     ncclUniqueId id;
-    nccl_check(ncclGetUniqueId(&id), "ncclGetUniqueId");
+    nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
     std::memcpy(out128, &id, sizeof id);
 }
 
@@ -87,7 +123,7 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
         ncclUniqueId id;
         std::memcpy(&id, uid, sizeof id);
         ncclComm_t c = nullptr;
-        nccl_check(ncclCommInitRank(&c, (int)world, id, (int)rank), "ncclCommInitRank");
+        nccl_check(rccl().CommInitRank(&c, (int)world, id, (int)rank), "ncclCommInitRank");
         comm_ = c;
     } else {
         lb->members[rank] = this;
@@ -108,7 +144,7 @@ void Exchange::destroy() noexcept {
         for (Exchange* q : lb_->members) if (q && q != this && q->cs_) (void)hipStreamSynchronize(q->cs_);
         lb_->members[rank_] = nullptr;
     }
-    if (comm_) { (void)ncclCommDestroy(comm_); comm_ = nullptr; }
+    if (comm_) { try { (void)rccl().CommDestroy(comm_); } catch (...) {} comm_ = nullptr; }
     for (Slot& sl : slots_) {
         sl.cg.reset();
         for (hipEvent_t* e : {&sl.packed, &sl.begin, &sl.fin, &sl.done, &sl.consumed}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -168,15 +204,21 @@ Exchange::Slot& Exchange::slot_of(uint64_t step, const char* what) {
 void Exchange::submit(uint64_t step) {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     Slot& sl = slots_[step & 1];
-    if (lb_) {
+    if (lb_) {   // everything that can be refused is refused BEFORE the slot or the group's bookkeeping is touched: a refused submit leaves the group usable
         if (lb_->arrived[rank_] != lb_->completed) throw Error(MX_ERR_INVALID, "loopback: this rank already submitted a step the other ranks have not submitted yet");
         for (Exchange* q : lb_->members) if (!q) throw Error(MX_ERR_INVALID, "loopback: not every rank of the group has been created");
+        for (uint32_t r = 0; r < world_; ++r)
+            if (r != rank_ && lb_->arrived[r] != lb_->completed && lb_->arrived[r] != (int64_t)step)
+                throw Error(MX_ERR_INVALID, "loopback: the ranks of a group submit the same step numbers in the same order");
     }
     // the exchange that last used this slot has finished with the packed partials (loopback: every peer that read them, too)
     if (sl.used) {
         if (lb_) { for (Exchange* q : lb_->members) hip_check(hipStreamWaitEvent(compute_, q->slots_[step & 1].done, 0), "hipStreamWaitEvent"); }
         else hip_check(hipStreamWaitEvent(compute_, sl.done, 0), "hipStreamWaitEvent");
     }
+    // all-reduce runs in place: its RESULT is `part`, which the pack below overwrites -- on the compute stream, so the consumer's
+    // release (an event on ITS stream) has to order the pack, not only the next exchange (the other modes' results are written on cs_)
+    if (mode_ == MX_EXCHANGE_ALLREDUCE && sl.consumed_pending) hip_check(hipStreamWaitEvent(compute_, sl.consumed, 0), "hipStreamWaitEvent");
     float* part = (float*)sl.part.p;
     if (c_ptr_ == m_ptr_ + n_fl_ && n_flp_ == n_fl_) {   // Master and Cue are neighbours in the graph's slab: one copy packs both
         hip_check(hipMemcpyAsync(part, m_ptr_, 2 * n_fl_ * sizeof(float), hipMemcpyDeviceToDevice, compute_), "hipMemcpyAsync(pack)");
@@ -201,35 +243,34 @@ void Exchange::submit(uint64_t step) {
     for (int64_t a : lb_->arrived) all = all && a == (int64_t)step;
     for (Exchange* q : lb_->members) all = all && q->slots_[step & 1].step == (int64_t)step;
     if (all) loopback_round(*lb_, step);
-    else for (uint32_t r = 0; r < world_; ++r)
-        if (lb_->arrived[r] != lb_->completed && lb_->arrived[r] != (int64_t)step) throw Error(MX_ERR_INVALID, "loopback: the ranks of a group submit the same step numbers in the same order");
 }
 
 void Exchange::collective_rccl(Slot& sl) {
     ncclComm_t comm = comm_;
+    const Rccl& R = rccl();
     float* part = (float*)sl.part.p;
     const int W = (int)world_;
     if (mode_ == MX_EXCHANGE_ALLGATHER) {
-        nccl_check(ncclAllGather(part, sl.gathered.p, 2 * n_flp_, ncclFloat, comm, cs_), "ncclAllGather");   // ONE all-gather per step
+        nccl_check(R.AllGather(part, sl.gathered.p, 2 * n_flp_, ncclFloat, comm, cs_), "ncclAllGather");   // ONE all-gather per step
         sl.cg->run(0, fpt_ / 2, T_);                                                                          // rank-ordered f32 sum
     } else if (mode_ == MX_EXCHANGE_SLICES) {
         float* recv = (float*)sl.recv.p;
-        nccl_check(ncclGroupStart(), "ncclGroupStart");                  // slice j of every rank's partial buses -> rank j
+        nccl_check(R.GroupStart(), "ncclGroupStart");                  // slice j of every rank's partial buses -> rank j
         for (int q = 0; q < W; ++q) {
-            nccl_check(ncclSend(part + (size_t)q * L_, L_, ncclFloat, q, comm, cs_), "ncclSend");
-            nccl_check(ncclSend(part + n_flp_ + (size_t)q * L_, L_, ncclFloat, q, comm, cs_), "ncclSend");
-            nccl_check(ncclRecv(recv + (size_t)q * 2 * Lp_, L_, ncclFloat, q, comm, cs_), "ncclRecv");
-            nccl_check(ncclRecv(recv + (size_t)q * 2 * Lp_ + Lp_, L_, ncclFloat, q, comm, cs_), "ncclRecv");
+            nccl_check(R.Send(part + (size_t)q * L_, L_, ncclFloat, q, comm, cs_), "ncclSend");
+            nccl_check(R.Send(part + n_flp_ + (size_t)q * L_, L_, ncclFloat, q, comm, cs_), "ncclSend");
+            nccl_check(R.Recv(recv + (size_t)q * 2 * Lp_, L_, ncclFloat, q, comm, cs_), "ncclRecv");
+            nccl_check(R.Recv(recv + (size_t)q * 2 * Lp_ + Lp_, L_, ncclFloat, q, comm, cs_), "ncclRecv");
         }
-        nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+        nccl_check(R.GroupEnd(), "ncclGroupEnd");
         sl.cg->run(0, fpt_ / 2, t_slice_);                              // rank-ordered f32 sum of my slice
         float* fin = (float*)sl.final_.p;
-        nccl_check(ncclGroupStart(), "ncclGroupStart");                  // every rank ends with the whole Master and Cue
-        nccl_check(ncclAllGather(sl.fm_out, fin, L_, ncclFloat, comm, cs_), "ncclAllGather");
-        nccl_check(ncclAllGather(sl.fc_out, fin + n_flp_, L_, ncclFloat, comm, cs_), "ncclAllGather");
-        nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+        nccl_check(R.GroupStart(), "ncclGroupStart");                  // every rank ends with the whole Master and Cue
+        nccl_check(R.AllGather(sl.fm_out, fin, L_, ncclFloat, comm, cs_), "ncclAllGather");
+        nccl_check(R.AllGather(sl.fc_out, fin + n_flp_, L_, ncclFloat, comm, cs_), "ncclAllGather");
+        nccl_check(R.GroupEnd(), "ncclGroupEnd");
     } else {
-        nccl_check(ncclAllReduce(part, part, 2 * n_flp_, ncclFloat, ncclSum, comm, cs_), "ncclAllReduce");   // non-parity: the ring decides the order
+        nccl_check(R.AllReduce(part, part, 2 * n_flp_, ncclFloat, ncclSum, comm, cs_), "ncclAllReduce");   // non-parity: the ring decides the order
     }
 }
 

@@ -1,6 +1,6 @@
 """mx_exchange_* on the GPU over a single-rank RCCL communicator (what one rank of the 8-GPU job runs, collectives included:
-ncclCommInitRank, ncclAllGather, grouped ncclSend / ncclRecv, ncclAllReduce -- all called by libmixlab_gpu.so itself, which links
-librccl): the combined bus of every exchange mode must be the local Mixer's output bit for bit (Mixer(1, unity) of one partial is
+ncclCommInitRank, ncclAllGather, grouped ncclSend / ncclRecv, ncclAllReduce -- all called by libmixlab_gpu.so itself, which binds
+librccl on first use): the combined bus of every exchange mode must be the local Mixer's output bit for bit (Mixer(1, unity) of one partial is
 that partial), across pipelined steps that reuse the two slots.  world > 1 runs through the same code on the loopback transport:
 tests/test_gpu_config5_sharded.py; the 2-rank layouts and the rank-ordered combine on CPU: tests/test_distributed_gloo.py.
 
@@ -33,6 +33,16 @@ def strips(n, sr=48000):
 
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
+
+def rccl_mapped():
+    return any("librccl" in line for line in open("/proc/self/maps"))
+
+# the library is loaded, a graph has run -- and RCCL is not in the process yet: it is bound on the first RCCL exchange
+_ws, _mix = strips(2); _g = _ws.build(max_ticks_per_run=2, device=0); _g.run_ticks(0, 2); _g.sync()
+assert not rccl_mapped(), "librccl was loaded before anything asked for the RCCL transport"
+unique_id()
+assert rccl_mapped(), "mx_exchange_unique_id did not bind librccl"
+print("ok lazy-rccl", flush=True)
 
 for sr, T, n in ((48000, 8, 6), (44100, 3, 5)):          # 44.1 kHz x an odd tick count: bus lengths that are not multiples of a cache line
     for mode in ("allgather", "slices", "allreduce"):
@@ -85,12 +95,53 @@ def test_single_rank_rccl_exchange_through_the_c_abi_returns_the_local_bus_over_
     for sr in (48000, 44100):
         for mode in ("allgather", "slices", "allreduce"):
             assert f"ok {sr} {mode}" in res.stdout, res.stdout[-2000:]
-    assert "ok bogus-mode" in res.stdout
+    assert "ok bogus-mode" in res.stdout and "ok lazy-rccl" in res.stdout
 
 
-def test_library_links_rccl_and_exports_the_exchange():
-    out = subprocess.run(["readelf", "-d", str(ROOT / "mixlab_amd" / "libmixlab_gpu.so")], capture_output=True, text=True).stdout
-    assert "librccl.so" in out
+def test_a_refused_loopback_submit_leaves_the_group_usable():
+    """Ranks of a loopback group must submit the same step numbers; a submit that breaks the rule is refused BEFORE anything is packed or
+    recorded, so the group carries on (the refusal used to come after the state was changed and wedged the group)."""
+    import numpy as np
+    from mixlab_amd import abi
+    from mixlab_amd.exchange import BusExchange, LoopbackGroup
+    from mixlab_amd.workspace import Workspace
+    T = 4
+    graphs, mixes = [], []
+    for r in range(2):
+        ws = Workspace(48000, 60)
+        mix = ws.mixer([(0.0, 1.0, True)])
+        osc = ws.oscillator(220.0 * (r + 1), abi.WAVE_SAW); ws.connect(osc, 1, mix, 0)
+        graphs.append(ws.build(max_ticks_per_run=T)); mixes.append(mix)
+    grp = LoopbackGroup(2)
+    ex = [BusExchange(graphs[r], mixes[r], T, r, 2, mode="allgather", loopback=grp) for r in range(2)]
+    for g in graphs:
+        g.run_ticks(0, T)
+    ex[0].submit(0)
+    with pytest.raises(abi.MxError):
+        ex[1].submit(1)                      # rank 0 is waiting with step 0
+    with pytest.raises(abi.MxError):
+        ex[0].submit(0)                      # rank 0 already submitted
+    ex[1].submit(0)                          # the group is intact: the round completes
+    want_m = graphs[0].read_output(mixes[0], 0, T, True) + graphs[1].read_output(mixes[1], 0, T, True)
+    for r in range(2):
+        m, _c = ex[r].result(0)
+        assert np.array_equal(m.view(np.uint32), want_m.view(np.uint32))
+    for g in graphs:
+        g.run_ticks(T, T)
+    ex[1].submit(1); ex[0].submit(1)
+    assert np.array_equal(ex[0].result(1)[0], ex[1].result(1)[0])
+    for e in ex:
+        e.close()
+    grp.close()
+
+
+def test_library_binds_rccl_lazily_and_exports_the_exchange():
+    lib = str(ROOT / "mixlab_amd" / "libmixlab_gpu.so")
+    out = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "librccl" not in out, "librccl is a load-time dependency again: hosts without RCCL could not load the library"
+    blob = open(lib, "rb").read()
+    for name in (b"librccl.so", b"ncclAllGather", b"ncclSend", b"ncclRecv", b"ncclAllReduce", b"ncclCommInitRank"):
+        assert name in blob, f"{name!r}: the library no longer binds that RCCL entry point"
     syms = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "mixlab_amd" / "libmixlab_gpu.so")], capture_output=True, text=True).stdout
     for name in ("mx_exchange_create", "mx_exchange_submit", "mx_exchange_wait", "mx_exchange_result", "mx_exchange_unique_id", "mx_loopback_group_create"):
         assert f" T {name}" in syms
