@@ -975,19 +975,25 @@ def main():
                     continue
                 g.write_source(sn, buf, T)
             ran0, rep0 = g.eq_spec_stats()
+            rs0 = g.eq_repair_stats()
             base_i = nxt + 200
             n_m = min(args.steps, 10)
             for i in list(range(base_i, base_i + 2 + n_m)) + list(range(base_i + 20, base_i + 22 + n_m)):   # the schedules, before any clock starts
                 events[i] = gate_events(abi, trigs, first, i * T, T) if toggling else None
             for i in range(2):
                 step(base_i + i)
+            g.profile_enable(not args.no_profile)
             dt_m = timed_region(base_i + 2, n_m)
+            g.profile_enable(False)
+            mk, _mt, mn = g.profile_collect()
             ran1, rep1 = g.eq_spec_stats()
             material["daw"] = {"what": f"{n_muted} strips muted (exact zeros), {n_gaps} with 3 s programme / 2 s digital silence alternating, the rest noise; gates toggling as in the headline",
                                "ms_per_step": round(dt_m / n_m * 1e3, 4), "value": args.strips * T * n_m / dt_m, "unit": "channel-ticks/s",
-                               "eq_spec": {"chunks_run": ran1 - ran0, "chunks_repaired": rep1 - rep0}}
-            # one strip poisoned: a NaN in its source.  Its poles are NaN from then on (the state is carried from step to step), no chunk
-            # after the NaN can prove itself, and the repair pass fills the strip's remaining outputs with all 64 lanes of its wave
+                               "kernel_ms_per_step": {k: round(v / max(1, mn), 5) for k, v in sorted(mk.items()) if v > 0},
+                               "eq_spec": {"chunks_run": ran1 - ran0, "chunks_repaired": rep1 - rep0},
+                               "repair_pass": {k: v - rs0[k] for k, v in g.eq_repair_stats().items()}}
+            # one strip poisoned: a NaN in its source.  Its poles are NaN from then on (the state is carried from step to step); in the step the NaN
+            # arrives no chunk after it can prove itself and the repair pass fills the strip's remaining outputs with all 64 lanes of its wave
             bad = np.array(synth.noise(first + 2, min(T, 256) * spt), dtype=np.float32)
             bad = np.tile(bad, (T + min(T, 256) - 1) // min(T, 256))[: T * spt].copy()
             bad[(T * spt) // 3] = np.float32("nan")
@@ -999,7 +1005,7 @@ def main():
             ran3, rep3 = g.eq_spec_stats()
             material["one_strip_poisoned_by_a_nan"] = {"ms_per_step": round(dt_p / n_m * 1e3, 4), "value": args.strips * T * n_m / dt_p, "unit": "channel-ticks/s",
                                                        "eq_spec": {"chunks_run": ran3 - ran2, "chunks_repaired": rep3 - rep2},
-                                                       "note": "on top of the daw material; the poisoned strip's whole stream is re-emitted by its repair wave (parallel fill) every step"}
+                                                       "note": "on top of the daw material; from the second step on the poisoned strip CARRIES an all-NaN state, which stands still under any input: its speculative lanes start from it and prove themselves (the step the NaN arrives in is finished by the repair wave's parallel fill)"}
 
     scaling = None
     if not use_dist and not args.no_scaling_probe and not args.no_fuse and args.strips % 8 == 0:

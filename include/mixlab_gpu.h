@@ -182,6 +182,11 @@ int mx_graph_schedule_params_batch(mx_graph* g, const mx_param_event* events, si
  * verification pass found different from the sequential order's and re-ran (exactly-constant input after a signal).
  * Synchronises the graph's stream. */
 int mx_graph_eq_spec_stats(mx_graph* g, uint64_t* chunks_run, uint64_t* chunks_repaired);
+/* The same counters with what the proof / repair pass did about them: out[0] chunks run, [1] chunks not proven by their recorded start
+ * state, [2] of those settled by comparing outputs under a constant input (O(1)), [3] walk steps of 16 samples (both trajectories re-run
+ * side by side, outputs rewritten), [4] fill steps of 16 samples (constant input, standing state, outputs differ), [5] rounds of islands
+ * walked side by side, [6] in-order walks after an island that ended apart from the speculative run, [7] streams finished by the NaN fill. */
+int mx_graph_eq_repair_stats(mx_graph* g, uint64_t out[8]);
 
 /* Feed a SOURCE_* node: n_ticks consecutive tick buffers (SPT mono / 2*SPT interleaved stereo f32). */
 int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks);

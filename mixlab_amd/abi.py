@@ -113,6 +113,7 @@ class ParamEvent(C.Structure):
 _proto("mx_graph_schedule_params", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_schedule_params_batch", C.c_int, C.c_void_p, C.POINTER(ParamEvent), C.c_size_t)
 _proto("mx_graph_eq_spec_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+_proto("mx_graph_eq_repair_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64))
 _proto("mx_graph_write_source", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_bind_source_device", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p)
 _proto("mx_graph_run_ticks", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32)
@@ -224,6 +225,13 @@ class Graph:
     def schedule_params_batch(self, events: "C.Array", n: int | None = None):
         """events: a ctypes array of ParamEvent whose `params` pointers the caller keeps alive for the call."""
         check(lib.mx_graph_schedule_params_batch(self._h, events, len(events) if n is None else n))
+
+    def eq_repair_stats(self) -> dict:
+        """mx_graph_eq_repair_stats: what the proof / repair pass of the speculative EqThree did (counters since the graph was built)"""
+        v = (C.c_uint64 * 8)()
+        check(lib.mx_graph_eq_repair_stats(self._h, v))
+        keys = ("chunks_run", "chunks_repaired", "settled_by_comparison", "walk_steps_16", "fill_steps_16", "island_rounds", "in_order_walks", "nan_fills")
+        return {k: int(x) for k, x in zip(keys, v)}
 
     def eq_spec_stats(self):
         """-> (chunks run, chunks repaired) of the speculative exact EqThree path since the graph was built."""

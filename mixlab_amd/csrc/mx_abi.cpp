@@ -117,10 +117,18 @@ int mx_graph_schedule_params_batch(mx_graph* g, const mx_param_event* events, si
 int mx_graph_eq_spec_stats(mx_graph* g, uint64_t* chunks_run, uint64_t* chunks_repaired) {
     return guard([&] {
         REQUIRE(g, "graph is NULL");
-        uint64_t v[2];
+        uint64_t v[8];
         g->g->eq_spec_stats(v);
         if (chunks_run) *chunks_run = v[0];
         if (chunks_repaired) *chunks_repaired = v[1];
+    });
+}
+
+int mx_graph_eq_repair_stats(mx_graph* g, uint64_t out[8]) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        REQUIRE(out, "out is NULL");
+        g->g->eq_spec_stats(out);
     });
 }
 

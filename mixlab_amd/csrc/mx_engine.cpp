@@ -802,11 +802,11 @@ void Graph::refresh_gates(Group& g, uint32_t run_calls) {
     g.gate_words = words; g.gates_version = gates_version_; g.gates_calls = run_calls;
 }
 
-void Graph::eq_spec_stats(uint64_t out[2]) {
-    out[0] = out[1] = 0;
+void Graph::eq_spec_stats(uint64_t out[8]) {
+    for (int k = 0; k < 8; ++k) out[k] = 0;
     if (!eq_stats_.p) return;
     sync();
-    hip_check(hipMemcpy(out, eq_stats_.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(eq stats)");
+    hip_check(hipMemcpy(out, eq_stats_.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(eq stats)");
 }
 
 void Graph::write_source(uint32_t node, const float* host, size_t frames) {
@@ -1004,7 +1004,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                 if (eq_plan_spec(n, gf, gfpc, lo_f_, hi_f_, plan)) {   // long streams: speculative time-parallel form, verified bit-exact
                     const size_t need = eq_spec_scratch_bytes(n, plan);
                     if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
-                    if (!eq_stats_.p) { eq_stats_.alloc(2 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 2 * sizeof(uint64_t)), "hipMemset"); }
+                    if (!eq_stats_.p) { eq_stats_.alloc(8 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 8 * sizeof(uint64_t)), "hipMemset"); }
                     launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
                 } else {
                     void* scratch = nullptr;

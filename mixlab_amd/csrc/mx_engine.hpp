@@ -123,7 +123,7 @@ public:
     void check_schedule(uint32_t node, const void* params, size_t len) const;   // schedule_params' validation alone
     void drop_schedules();                                                      // forget every queued update (a run that failed must not leave them for the next)
     // counters of the speculative exact EqThree kernel since the graph was built: [0] chunks run, [1] chunks the repair pass had to re-run
-    void eq_spec_stats(uint64_t out[2]);
+    void eq_spec_stats(uint64_t out[8]);   // see k_eq_three_repair
     void write_source(uint32_t node, const float* host, size_t frames);
     void bind_source(uint32_t node, const void* dev);
     // n_calls ModuleT::run_tick calls of frames_per_call mono samples each, back to back
@@ -211,7 +211,7 @@ private:
     const void* desc_of(const Group& g) const { return (parity_ && g.desc_alt.p) ? g.desc_alt.p : g.desc.p; }
     size_t run_off_frames_ = 0;   // base-rate frames before the span being launched (a run cut at scheduled parameter updates)
     uint64_t gates_version_ = 0;  // bumped whenever a Trigger's params or schedule change
-    DevBuf eq_stats_;             // [2] u64 counters of the speculative EqThree kernel
+    DevBuf eq_stats_;             // [8] u64 counters of the speculative EqThree kernel's proof / repair pass
     struct Stage { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
     Stage stage_[4]; uint32_t stage_next_ = 0;
     uint32_t prof_runs_count_ = 0;

@@ -410,6 +410,27 @@ void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun
     else hipLaunchKernelGGL(k_eq_three_exact<false>, dim3((n + 63) / 64), dim3(64), 0, s, d, st, n, r);
 }
 
+// Where a speculative lane's warm-up starts from.  Zeros are as good as any bounded guess on live input (the warm-up forgets it).  The one
+// input class the speculation fails on is a CONSTANT one (a muted strip, DC): the true state stands still a few ulps from the fixed point,
+// on the side it came from, and no warm-up from zeros ever arrives there -- every chunk of a muted strip failed its proof and went through
+// the repair pass (691 200 of 3 145 728 chunks of bench.py's `material.daw`).  But the state such a strip CARRIES into the run is that very
+// standing state: if one more sample of the value my warm-up window begins with leaves the carried state where it is, the lane starts from
+// it -- exact as long as the input stays that constant up to my chunk, and a guess like any other if it does not (the proof decides).
+template <bool FC>
+__device__ __forceinline__ void eq_spec_guess(const EqState& st, const double lo_f, const double hi_f, const float x_first, EqPoles& s) {
+    double lo[4], hi[4], nlo[4], nhi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lo[k] = nlo[k] = st.lo[k]; hi[k] = nhi[k] = st.hi[k]; }
+    pump<FC>(lo_f, nlo, (double)x_first); pump<FC>(hi_f, nhi, (double)x_first);
+    bool still = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) still = still && __double_as_longlong(nlo[k]) == __double_as_longlong(lo[k]) && __double_as_longlong(nhi[k]) == __double_as_longlong(hi[k]);
+    if (still) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s.lo[k] = lo[k]; s.hi[k] = hi[k]; }
+    }
+}
+
 // KMODE / KSTEREO >= 0: every instance of the launch has that epilogue (the usual case: a bank of equal strips) and the kernel is
 // compiled for it alone -- its own register budget, no dead variants; -1: decided per wave.
 template <int KMODE, int KSTEREO, bool FC>
@@ -435,6 +456,7 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s.lo[k] = 0.0; s.hi[k] = 0.0; }
+        eq_spec_guess<FC>(states[inst], r.lo_f, r.hi_f, d.in[begin - W], s);
     }
     if (wlen) {
         // the exact recurrence over the wlen samples before my chunk (a multiple of EQ_BLK: chunks are multiples of 32 samples)
@@ -662,6 +684,8 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s.lo[k] = st.lo[k]; s.hi[k] = st.hi[k]; }
         s.h0 = st.history[0]; s.h1 = st.history[1]; s.h2 = st.history[2];
+    } else if (active) {
+        eq_spec_guess<FC>(states[inst], K.lo_f, K.hi_f, d.in[begin - (long long)plan.warm], s);
     }
     uint32_t xmin = 0xffffffffu, xmax = 0u;
     const EnvTick* ticks = r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr;
@@ -728,48 +752,54 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
 }
 
 // ---- repair ----
+// The repair pass works in GROUPS of four consecutive lanes.  A walk runs two trajectories side by side -- A from the true state (the
+// sequential order) and B, the one the chunk's speculative lane ran -- and each is two independent cascades of the same input
+// (eq_three.rs:68-74): four recurrences of identical code, one per lane (role 0: A low, 1: A high, 2: B low, 3: B high), thirteen dependent
+// f64 instructions per sample instead of the ~110 one lane needed for all of it (the wave pays an instruction's issue slot whether one lane
+// or sixty-four run it).  What has no recurrence -- the band mix, the folded Panner / Amplifier / Envelope, the stores -- is done by the
+// four lanes together, sixteen samples at a time, from the last poles the A lanes leave in LDS.  Every lane of a group takes the same
+// branches: decisions are made on values shared through ballots and shuffles inside the group.  Groups are independent of each other
+// (up to sixteen islands of a stream side by side).
+__device__ __forceinline__ bool same4(const double (&a)[4], const double* b) {
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) eq = eq && (__double_as_longlong(a[k]) == __double_as_longlong(b[k]));
+    return eq;
+}
 __device__ __forceinline__ bool same8(const double (&a)[8], const double* b) {
     bool eq = true;
 #pragma unroll
     for (int k = 0; k < 8; ++k) eq = eq && (__double_as_longlong(a[k]) == __double_as_longlong(b[k]));
     return eq;
 }
-struct Dual { double lo[4], hi[4]; };
-__device__ __forceinline__ void dual_load(Dual& s, const double* p) {
+__device__ __forceinline__ bool all_nan4(const double (&a)[4]) { return a[0] != a[0] && a[1] != a[1] && a[2] != a[2] && a[3] != a[3]; }
+__device__ __forceinline__ bool eq_all_nan(const double (&E)[8]) {
+    bool a = true;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { s.lo[k] = p[k]; s.hi[k] = p[4 + k]; }
+    for (int k = 0; k < 8; ++k) a = a && (E[k] != E[k]);
+    return a;
 }
-__device__ __forceinline__ bool dual_same(const Dual& a, const Dual& b) {
-    bool eq = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) eq = eq && __double_as_longlong(a.lo[k]) == __double_as_longlong(b.lo[k]) && __double_as_longlong(a.hi[k]) == __double_as_longlong(b.hi[k]);
-    return eq;
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(u >> 32), src, 64);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
-// does one sample of input x leave the state where it is?  (then every further sample of the same x does, too)
+// true when the condition holds in all four lanes of the group that starts at lane g0 (all four execute this together)
+__device__ __forceinline__ bool grp_all(bool c, int g0) { return ((__ballot(c) >> g0) & 0xFull) == 0xFull; }
+// LDS executes a wave's own accesses in order, so what one lane wrote is there for another lane's later read without any wait; this only
+// keeps the compiler from moving either across the hand-over (a fence would also drain the wave's global loads: the input prefetch)
+__device__ __forceinline__ void lds_handover() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+// the EQ's f32 (eq_three.rs:70-85) from the two cascades' last poles AFTER the sample was pumped in, and the input three samples back
 template <bool FC>
-__device__ __forceinline__ bool dual_stuck(const Dual& s, double lo_f, double hi_f, double x) {
-    Dual n = s;
-    pump<FC>(lo_f, n.lo, x); pump<FC>(hi_f, n.hi, x);
-    return dual_same(n, s);
-}
-// the EQ's f32 for a state that one more sample of the input has ALREADY been pumped into (eq_three.rs:70-85)
-template <bool FC>
-__device__ __forceinline__ float eq_out_of(const Dual& s, double h0, double g_lo, double g_mid, double g_hi) {
-    const double l = s.lo[3];
-    const double h = h0 - s.hi[3];
+__device__ __forceinline__ float eq_out_of(double l, double hp, double h0, double g_lo, double g_mid, double g_hi) {
+    const double h = h0 - hp;
     const double mid = h0 - (h + l);
     return band_mix<FC>(l, mid, h, g_lo, g_mid, g_hi);
 }
-
-// ---- the walk: chunks [j0, j_limit) in order with the TRUE state E at the start of chunk j0 in hand ----
-// A chunk whose recorded start equals the true state is exact as the speculative lane left it (E moves to its recorded end); any
-// other is re-run from the true state beside the speculative trajectory: output samples whose f32 differs are rewritten, and the
-// two meet again as soon as the trajectories coalesce.  On return E is the true state at the start of chunk j_end; j_end = j_limit
-// unless the walk stopped in front of an ABSORBING state (all eight poles NaN: no later chunk can ever match -- the caller fills the
-// rest of the stream with the whole wave instead of walking it).  Chunks below `force_until` are rewritten sample for sample
-// whatever is recorded about them (a fallback after an island that started from a wrong assumption: memory there may hold that
-// island's rewrites, not the speculative outputs).
-struct EqWalk { uint32_t j_end; unsigned long long repaired; };
 // four samples from index i of a stream of n: one 16-byte load where all four exist, the ragged tail element by element
 __device__ __forceinline__ f4v eq_ld4(const float* __restrict__ p, size_t i, size_t n) {
     if (i + 4 <= n) return *reinterpret_cast<const f4v*>(p + i);
@@ -779,88 +809,212 @@ __device__ __forceinline__ f4v eq_ld4(const float* __restrict__ p, size_t i, siz
     if (i + 2 < n) v[2] = p[i + 2];
     return v;
 }
-__device__ __forceinline__ bool eq_all_nan(const double (&E)[8]) {
-    bool a = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a = a && (E[k] != E[k]);
-    return a;
-}
+
+// The folded epilogue for a lane that emits four consecutive samples out of every sixteen (EqSeqEmit's arithmetic, with a tick cursor that
+// can step over the samples its neighbours emit): `call` is the tick of the cursor's sample, `left` what remains of that tick counting it.
+template <bool FC>
+struct EqBlkEmit {
+    EqEpi E; double sr, rsr; uint64_t t0; size_t fpc;
+    size_t left = 1; uint32_t call = 0, cur_call = 0xffffffffu; EnvTick cur{}; bool env = false;
+    __device__ __forceinline__ void init(const EqDesc& d, const EqRun& r, uint32_t inst) {
+        E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
+        sr = r.sr; rsr = r.rsr; t0 = r.t0; fpc = r.fpc ? r.fpc : 1;
+        env = (E.flags & MX_EQF_ENV) && E.epi == 2u && E.ticks;
+    }
+    __device__ __forceinline__ void seek(size_t i) { if (env) { call = (uint32_t)(i / fpc); left = fpc - i % fpc; } }
+    __device__ __forceinline__ void skip(size_t n) {
+        if (!env) return;
+        while (n >= left) { n -= left; ++call; left = fpc; }
+        left -= n;
+    }
+    __device__ __forceinline__ void emit(size_t i, float y) {   // the cursor is on sample i; it moves to i + 1
+        float v = y;
+        if (E.epi == 2u) {
+            double depth;
+            if (env) {
+                if (call != cur_call) { cur = E.ticks[call]; cur_call = call; }
+                depth = env_depth<FC>(E.env, cur, E.amp_one_minus, E.amp_mod_depth, t0 + i, sr, rsr);
+                if (--left == 0) { ++call; left = fpc; }
+            } else {
+                const double m = E.ctl ? (double)E.ctl[i] : 1.0;                       // amplifier.rs:54
+                depth = amp_depth<FC>(E.amp_one_minus, E.amp_mod_depth, m);           // amplifier.rs:71-73
+            }
+            v = amp_apply(y, depth, E.amp_amplitude);
+        }
+        if (eq_mono_out(E)) E.out[i] = v;                                             // one float per frame
+        else reinterpret_cast<float2*>(E.out)[i] = make_float2(v, v);                 // stereo_panner.rs:35-38
+    }
+};
+
+// ---- the walk: chunks [j0, j_limit) in order with the TRUE state E at the start of chunk j0 in hand; called by the four lanes of a group ----
+// A chunk whose recorded start equals the true state is exact as the speculative lane left it (E moves to its recorded end).  Any other:
+//   * as long as the input stays what the chunk's first sample is and both trajectories stand still under it, the f32 outputs are a
+//     function of (state, delay-line value) only -- compared for the delay-line values in question; equal => what the lane wrote there is
+//     the sequential order's and the true state stays where it is.  A chunk whose whole input is that constant (record: min == max; every
+//     chunk deep inside a silence) is settled by that comparison alone, O(1); otherwise the input is scanned for its first change (the chunk
+//     in which programme returns after a silence) and the walk starts there;
+//   * from there both trajectories are re-run, EQ_RB samples per step, and every output whose f32 differs from what the lane wrote is
+//     replaced, until
+//       - the trajectories coalesce: from there on the lane's run IS the sequential order (E = its recorded end), or
+//       - the input is constant to the chunk's end and both stand still: the rest is compared as above and, if it differs, filled from A, or
+//       - the chunk ends (E = A).
+// On return E is the true state at the start of chunk j_end; j_end = j_limit unless the walk stopped in front of an ABSORBING state (all eight
+// poles NaN: no later chunk can ever match -- the caller fills the rest of the stream with the whole wave instead of walking it).  Chunks
+// below `force_until` are rewritten sample for sample whatever is recorded about them (a fallback after an island that started from a wrong
+// assumption: memory there may hold that island's rewrites, not the speculative outputs).
+struct EqWalk { uint32_t j_end; uint32_t repaired; uint32_t settled /* chunks the O(1) comparison settled */, steps /* walk steps of EQ_RB samples */, fills /* fill steps */; };
+constexpr int EQ_RB = 16;   // samples per step of a walk
 template <bool FC>
 __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r, const EqSpecPlan& plan, const EqChunkRec* __restrict__ rc, uint32_t inst,
-                                                 uint32_t j0, uint32_t j_limit, uint32_t force_until, double (&E)[8]) {
+                                                 uint32_t j0, uint32_t j_limit, uint32_t force_until, double (&E)[8], const int lane,
+                                                 double* __restrict__ p3g /* this group's [4][EQ_RB]: the four cascades' last poles of a step */) {
+    const int role = lane & 3, g0 = lane & ~3, half = role & 1;
+    const bool is_a = role < 2;
+    const double f = half ? r.hi_f : r.lo_f;
+    const double g_lo = d.gain_lo, g_mid = d.gain_mid, g_hi = d.gain_hi;
     const size_t C = plan.chunk;
-    EqWalk w{j_limit, 0ull};
+    EqWalk w{j_limit, 0u, 0u, 0u, 0u};
+    double Q[4];                                   // the cascade this lane runs: A's (roles 0, 1: always the true state's half), B's inside a walk
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Q[k] = E[4 * half + k];
+    EqBlkEmit<FC> em; em.init(d, r, inst);
+    // the four last poles of the group after one more sample: A low, A high, B low, B high
+    auto outs_differ = [&](const double q3, const double hv) {
+        const double a_lo = shfl_f64(q3, g0), a_hi = shfl_f64(q3, g0 + 1), b_lo = shfl_f64(q3, g0 + 2), b_hi = shfl_f64(q3, g0 + 3);
+        return __float_as_uint(eq_out_of<FC>(a_lo, a_hi, hv, g_lo, g_mid, g_hi)) != __float_as_uint(eq_out_of<FC>(b_lo, b_hi, hv, g_lo, g_mid, g_hi));
+    };
     for (uint32_t j = j0; j < j_limit; ++j) {
         const EqChunkRec& R = rc[j];
+        const double* rs = R.start + 4 * half; const double* re = R.end + 4 * half;
         const bool force = j < force_until;
-        if (!force && same8(E, R.start)) {          // the speculative chunk started from the true state: everything it wrote is exact
+        if (!force && grp_all(!is_a || same4(Q, rs), g0)) {   // the speculative chunk started from the true state: everything it wrote is exact
+            if (is_a) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) E[k] = R.end[k];
+                for (int k = 0; k < 4; ++k) Q[k] = re[k];
+            }
             continue;
         }
-        if (eq_all_nan(E)) { w.j_end = j; return w; }
+        if (grp_all(!is_a || all_nan4(Q), g0)) { w.j_end = j; break; }
         ++w.repaired;
         const size_t begin = (size_t)j * C;
         const size_t len = r.frames - begin < C ? r.frames - begin : C;
-        Dual A, B;                                 // A: from the true state (the sequential order); B: the trajectory the chunk's lane ran
-        dual_load(A, E); dual_load(B, R.start);
-        double h0 = (double)d.in[begin - 3], h1 = (double)d.in[begin - 2], h2 = (double)d.in[begin - 1];
-        if (R.xmin == R.xmax && !force) {
-            // constant input over the whole chunk (digital silence, DC): if both trajectories already stand still under it, the
-            // chunk's f32 outputs are a function of (state, delay-line value) only -- compare them for the four delay-line values
-            // the chunk sees; equal => what the lane wrote is the sequential order's, and the true state stays where it is
-            const double xc = (double)__uint_as_float(R.xmin);
-            if (dual_stuck<FC>(A, r.lo_f, r.hi_f, xc) && dual_stuck<FC>(B, r.lo_f, r.hi_f, xc)) {
-                bool same = true;
-                const double hv[4] = {h0, h1, h2, xc};
+        const float* __restrict__ xin = d.in + begin;     // begin >= one chunk: xin[-3 .. -1] exist (chunk 0 is never repaired)
+        if (!is_a) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    same = same && __float_as_uint(eq_out_of<FC>(A, hv[q], d.gain_lo, d.gain_mid, d.gain_hi)) == __float_as_uint(eq_out_of<FC>(B, hv[q], d.gain_lo, d.gain_mid, d.gain_hi));
-                if (same) continue;                // E unchanged: the state stands still through the chunk
+            for (int k = 0; k < 4; ++k) Q[k] = rs[k];     // B: the trajectory the chunk's lane ran
+        }
+        const bool konst = R.xmin == R.xmax;
+        // does one more sample of x leave my cascade where it is?  (then every further sample of x does, too)
+        auto stands_still = [&](const double x, double& q3_after) {
+            double n[4] = {Q[0], Q[1], Q[2], Q[3]};
+            pump<FC>(f, n, x);
+            q3_after = n[3];
+            return same4(n, Q);
+        };
+        size_t i0 = 0;
+        if (!force) {
+            const float x0f = konst ? __uint_as_float(R.xmin) : xin[0];
+            const double x0 = (double)x0f;
+            double q3;
+            if (grp_all(stands_still(x0, q3), g0)) {
+                const double hv = role < 3 ? (double)xin[role - 3] : x0;          // the four delay-line values in question: x[-3], x[-2], x[-1], x0
+                if (grp_all(!outs_differ(q3, hv), g0)) {
+                    if (konst) { ++w.settled; continue; }                         // E unchanged: the state stands still through the chunk
+                    // where does the input change?  128 samples per round trip to memory: the four lanes take four samples each of eight steps
+                    const uint32_t b0 = __float_as_uint(x0f);
+                    size_t is = 0;
+                    int first = 8;
+                    for (; is < len; is += 8 * EQ_RB) {
+                        f4v v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = eq_ld4(xin, is + (size_t)(EQ_RB * u + 4 * role), len);
+                        first = 8;
+#pragma unroll
+                        for (int u = 7; u >= 0; --u) {
+                            bool df = false;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) df = df || (is + (size_t)(EQ_RB * u + 4 * role + e) < len && __float_as_uint(v[u][e]) != b0);
+                            if (df) first = u;
+                        }
+                        first = min(first, __shfl_xor(first, 1, 64)); first = min(first, __shfl_xor(first, 2, 64));
+                        if (first < 8) break;
+                    }
+                    if (first >= 8) { ++w.settled; continue; }                    // (the record said the input changes; it does not: settled like a constant chunk)
+                    i0 = is + (size_t)(EQ_RB * first);                            // nothing moves and nothing differs before the step the change is in
+                }
             }
         }
-        // general case: both trajectories sample by sample; rewrite the outputs whose f32 differs; stop when they coalesce
-        EqSeqEmit<FC> em;
-        em.E = eq_epi_of(d, r.ticks ? r.ticks + (size_t)inst * r.n_calls : nullptr);
-        em.sr = r.sr; em.rsr = r.rsr; em.t0 = r.t0; em.fpc = r.fpc;
-        bool coalesced = false, stuckA = false, stuckB = false;
-        uint32_t prev_bits = 0; bool have_prev = false;
-        // the input travels sixteen samples at a time, the next sixteen requested before these are walked: a load per sample would put a
-        // memory round trip (hundreds of ns) into every step of a walk that is already one dependent chain (chunks start on 64-byte lines)
-        const float* xin = d.in + begin;
+        // both trajectories, EQ_RB samples per step; the input travels a step ahead of the walk
+        em.seek(begin + i0 + (size_t)(4 * role));
+        bool coalesced = false;
+        const double xc = (double)__uint_as_float(R.xmin);
         f4v xa[4], xb[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xa[q] = eq_ld4(xin, (size_t)(4 * q), len);
-        for (size_t i0 = 0; i0 < len && !coalesced; i0 += 16) {
+        for (int q = 0; q < 4; ++q) xa[q] = eq_ld4(xin, i0 + (size_t)(4 * q), len);
+        for (; i0 < len; i0 += EQ_RB) {
+            ++w.steps;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xb[q] = eq_ld4(xin, i0 + 16 + (size_t)(4 * q), len);
+            for (int q = 0; q < 4; ++q) xb[q] = eq_ld4(xin, i0 + EQ_RB + (size_t)(4 * q), len);
+            float xh[4];                               // the inputs three samples back of the four samples this lane emits
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const size_t i = i0 + (size_t)e;
-                if (i < len && !coalesced) {
-                    const float xf = xa[e >> 2][e & 3];
-                    const double x = (double)xf;
-                    const bool rep = have_prev && __float_as_uint(xf) == prev_bits;     // same input as the previous sample
-                    prev_bits = __float_as_uint(xf); have_prev = true;
-                    if (!(rep && stuckA)) { const Dual o = A; pump<FC>(r.lo_f, A.lo, x); pump<FC>(r.hi_f, A.hi, x); stuckA = rep && dual_same(o, A); }
-                    if (!(rep && stuckB)) { const Dual o = B; pump<FC>(r.lo_f, B.lo, x); pump<FC>(r.hi_f, B.hi, x); stuckB = rep && dual_same(o, B); }
-                    const float ya = eq_out_of<FC>(A, h0, d.gain_lo, d.gain_mid, d.gain_hi), yb = eq_out_of<FC>(B, h0, d.gain_lo, d.gain_mid, d.gain_hi);
-                    h0 = h1; h1 = h2; h2 = x;
-                    if (force || __float_as_uint(ya) != __float_as_uint(yb)) { em.seek(begin + i); em.emit(begin + i, ya); }
-                    if (!force && dual_same(A, B)) coalesced = true;            // from here on the lane's run IS the sequential order
+            for (int k = 0; k < 4; ++k) { const size_t i = i0 + (size_t)(4 * role + k); xh[k] = i < len ? xin[(long long)i - 3] : 0.f; }
+            const int nb = len - i0 < (size_t)EQ_RB ? (int)(len - i0) : EQ_RB;
+            if (nb == EQ_RB) {
+#pragma unroll
+                for (int e = 0; e < EQ_RB; ++e) { pump<FC>(f, Q, (double)xa[e >> 2][e & 3]); p3g[role * EQ_RB + e] = Q[3]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EQ_RB; ++e) if (e < nb) { pump<FC>(f, Q, (double)xa[e >> 2][e & 3]); p3g[role * EQ_RB + e] = Q[3]; }
+            }
+            lds_handover();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 4 * role + k;
+                if (e < nb) {
+                    const float ya = eq_out_of<FC>(p3g[e], p3g[EQ_RB + e], (double)xh[k], g_lo, g_mid, g_hi);
+                    // what the chunk's lane wrote here went through the same epilogue: only an EQ sample that differs has to be emitted again
+                    if (force || __float_as_uint(ya) != __float_as_uint(eq_out_of<FC>(p3g[2 * EQ_RB + e], p3g[3 * EQ_RB + e], (double)xh[k], g_lo, g_mid, g_hi)))
+                        em.emit(begin + i0 + (size_t)e, ya);
+                    else em.skip(1);
+                }
+            }
+            lds_handover();
+            if (nb < EQ_RB) { i0 = len; break; }       // the stream's ragged end
+            em.skip(EQ_RB - 4);
+            if (!force) {
+                double P2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) P2[k] = shfl_f64(Q[k], lane ^ 2);
+                if (grp_all(same4(Q, P2), g0)) { coalesced = true; break; }               // from here on the lane's run IS the sequential order
+                if (konst) {
+                    double q3;
+                    if (grp_all(stands_still(xc, q3), g0)) {                              // neither trajectory moves again in this chunk
+                        i0 += EQ_RB;
+                        if (outs_differ(q3, xc)) {                                        // the same in all four lanes (every delay-line value from here on is xc)
+                            const double a_lo = shfl_f64(q3, g0), a_hi = shfl_f64(q3, g0 + 1);
+                            const float yc = eq_out_of<FC>(a_lo, a_hi, xc, g_lo, g_mid, g_hi);
+                            for (; i0 < len; i0 += EQ_RB) {
+                                ++w.fills;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { const size_t i = i0 + (size_t)(4 * role + k); if (i < len) em.emit(begin + i, yc); }
+                                em.skip(EQ_RB - 4);
+                            }
+                        }
+                        break;
+                    }
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) xa[q] = xb[q];
         }
-        if (coalesced) {
+        if (coalesced && is_a) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) E[k] = R.end[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { E[k] = A.lo[k]; E[4 + k] = A.hi[k]; }
+            for (int k = 0; k < 4; ++k) Q[k] = re[k];
         }
+        // else: roles 0, 1 hold A's state at the chunk's end (walked to the end, or standing still until it)
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { E[k] = shfl_f64(Q[k], g0); E[4 + k] = shfl_f64(Q[k], g0 + 1); }
     return w;
 }
 // the rest of the stream from chunk j on under an absorbing (all-NaN) state, all 64 lanes: every output is the EQ's f32 for (that
@@ -868,7 +1022,6 @@ __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r
 template <bool FC>
 __device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, const EqSpecPlan& plan, uint32_t inst, uint32_t j, const double (&E)[8], int lane) {
     const size_t begin = (size_t)j * plan.chunk;
-    Dual A0; dual_load(A0, E);
     const size_t unit = r.fpc ? r.fpc : 1024;                      // a lane takes whole ticks: its Envelope cursor starts at a tick's first sample
     const size_t n_units = (r.frames - begin + unit - 1) / unit;   // begin is a multiple of a tick when an Envelope is folded in (eq_plan_spec)
     for (size_t u = (size_t)lane; u < n_units; u += 64) {
@@ -887,19 +1040,14 @@ __device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, con
                 const size_t i = i0 + (size_t)e;
                 if (i < b) {
                     const double x = (double)xv[e >> 2][e & 3];
-                    Dual A = A0;
-                    pump<FC>(r.lo_f, A.lo, x); pump<FC>(r.hi_f, A.hi, x);
-                    em.emit(i, eq_out_of<FC>(A, h0, d.gain_lo, d.gain_mid, d.gain_hi));
+                    double lo[4] = {E[0], E[1], E[2], E[3]}, hi[4] = {E[4], E[5], E[6], E[7]};
+                    pump<FC>(r.lo_f, lo, x); pump<FC>(r.hi_f, hi, x);
+                    em.emit(i, eq_out_of<FC>(lo[3], hi[3], h0, d.gain_lo, d.gain_mid, d.gain_hi));
                     h0 = h1; h1 = h2; h2 = x;
                 }
             }
         }
     }
-}
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(u >> 32), src, 64);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 // One wave per instance.  First every boundary is checked in parallel against the SPECULATIVE end state of the chunk before
@@ -909,20 +1057,23 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
 // or a NaN) the stream is walked on from there with the true state in hand (eq_repair_walk).
 // ISLANDS.  Programme that falls silent and comes back -- a desk's normal material -- fails a few boundaries after every onset of
 // silence, seconds apart.  Each run of failures starts at a HEAD: a failing boundary whose predecessor matched.  If the chunk before a
-// head is exact, the true state at the head is that chunk's recorded end -- which every island can ASSUME and walk at once, one LANE per
-// head (up to 64 per round), each up to the next head.  The assumptions are then checked in stream order: island i held if island
-// i - 1 ended on the recorded end of its last chunk.  Where one did not, everything from there to the end of the round is walked again
-// in order from the true state, rewriting every sample (memory there may hold a wrong island's rewrites).  An absorbing all-NaN state
-// is never walked: the rest of the stream is filled by the whole wave (eq_nan_fill).
+// head is exact, the true state at the head is that chunk's recorded end -- which every island can ASSUME and walk at once, one GROUP of
+// four lanes per head (up to 16 per round), each up to the next head.  The assumptions are then checked in stream order: island i held if
+// island i - 1 ended on the recorded end of its last chunk.  Where one did not, everything from there to the end of the round is walked
+// again in order from the true state, rewriting every sample (memory there may hold a wrong island's rewrites).  An absorbing all-NaN
+// state is never walked: the rest of the stream is filled by the whole wave (eq_nan_fill).
+constexpr int EQ_ISLANDS = 16;
 template <bool FC>
 __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                          const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats) {
     const uint32_t inst = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, grp = lane >> 2;
     const EqDesc& d = descs[inst];
     const EqChunkRec* rc = recs + (size_t)inst * plan.n_chunks;
     const uint32_t NC = plan.n_chunks;
-    __shared__ uint32_t heads[65];
+    __shared__ uint32_t heads[EQ_ISLANDS + 1];
+    __shared__ double p3s[EQ_ISLANDS * 4 * EQ_RB];
+    double* p3g = p3s + grp * 4 * EQ_RB;
     auto fails = [&](uint32_t j) {                 // boundary j (1 <= j < NC): chunk j's recorded start differs from chunk j - 1's recorded end
         bool ok = true;
 #pragma unroll
@@ -934,17 +1085,20 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
     for (int k = 0; k < 8; ++k) E[k] = 0.0;
     bool have_E = false;
     uint32_t pos = 1, force_until = 0;             // every chunk before `pos` is proven
-    unsigned long long repaired = 0;
+    unsigned long long repaired = 0, settled = 0, steps = 0, fills = 0, rounds = 0, in_order = 0, nan_fills = 0;
     while (pos < NC) {
         if (have_E) {
-            if (eq_all_nan(E)) { repaired += NC - pos; eq_nan_fill<FC>(d, r, plan, inst, pos, E, lane); pos = NC; break; }
-            // in order from the true state, by one lane: to the end of the round that went wrong (rewriting everything), else one chunk at a
-            // time -- as soon as a chunk ends on its recorded end the islands behind it are searched (and walked side by side) again
+            if (eq_all_nan(E)) { repaired += NC - pos; ++nan_fills; eq_nan_fill<FC>(d, r, plan, inst, pos, E, lane); pos = NC; break; }
+            // in order from the true state, by the first group: to the end of the round that went wrong (rewriting everything), else one chunk
+            // at a time -- as soon as a chunk ends on its recorded end the islands behind it are searched (and walked side by side) again
             const uint32_t lim = force_until > pos ? force_until : pos + 1;
-            EqWalk w{lim, 0ull};
-            if (lane == 0) w = eq_repair_walk<FC>(d, r, plan, rc, inst, pos, lim, force_until, E);
+            EqWalk w{lim, 0u, 0u, 0u, 0u};
+            ++in_order;
+            if (lane < 4) w = eq_repair_walk<FC>(d, r, plan, rc, inst, pos, lim, force_until, E, lane, p3g);
             w.j_end = (uint32_t)__shfl((int)w.j_end, 0, 64);
-            repaired += (unsigned long long)(uint32_t)__shfl((int)(uint32_t)w.repaired, 0, 64);
+            repaired += (unsigned long long)(uint32_t)__shfl((int)w.repaired, 0, 64);
+            settled += (unsigned long long)(uint32_t)__shfl((int)w.settled, 0, 64); steps += (unsigned long long)(uint32_t)__shfl((int)w.steps, 0, 64);
+            fills += (unsigned long long)(uint32_t)__shfl((int)w.fills, 0, 64);
 #pragma unroll
             for (int k = 0; k < 8; ++k) E[k] = shfl_f64(E[k], 0);
             pos = w.j_end;
@@ -952,44 +1106,47 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
             if (pos >= NC) { have_E = true; break; }
             continue;
         }
-        // the next (up to 64) heads at or after pos
+        // the next (up to EQ_ISLANDS) heads at or after pos
         uint32_t n_heads = 0, scan_end = NC;
         for (uint32_t j0 = pos; j0 < NC; j0 += 64) {
             const uint32_t j = j0 + (uint32_t)lane;
             const bool head = j < NC && fails(j) && (j == pos || !fails(j - 1));
             uint64_t m = __ballot(head);
-            while (m && n_heads < 64) { const int b = __builtin_ctzll(m); if (lane == 0) heads[n_heads] = j0 + (uint32_t)b; ++n_heads; m &= m - 1; }
-            if (m) { scan_end = j0 + (uint32_t)__builtin_ctzll(m); break; }   // a 65th head: this round ends in front of it
+            while (m && n_heads < (uint32_t)EQ_ISLANDS) { const int b = __builtin_ctzll(m); if (lane == 0) heads[n_heads] = j0 + (uint32_t)b; ++n_heads; m &= m - 1; }
+            if (m) { scan_end = j0 + (uint32_t)__builtin_ctzll(m); break; }   // one head too many: this round ends in front of it
         }
         if (n_heads == 0) { pos = NC; break; }     // every boundary from pos on matches: proven to the end
         if (lane == 0) heads[n_heads] = scan_end;
         __syncthreads();
-        // one lane per island, all at once, each from its predecessor chunk's recorded end, each up to the next head
+        // one group per island, all at once, each from its predecessor chunk's recorded end, each up to the next head
         double El[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) El[k] = 0.0;
-        EqWalk w{0u, 0ull};
+        EqWalk w{0u, 0u, 0u, 0u, 0u};
+        ++rounds;
         bool in_sync = true;
-        if ((uint32_t)lane < n_heads) {
-            const uint32_t h = heads[lane], lim = heads[lane + 1];
+        if ((uint32_t)grp < n_heads) {
+            const uint32_t h = heads[grp], lim = heads[grp + 1];
 #pragma unroll
             for (int k = 0; k < 8; ++k) El[k] = rc[h - 1].end[k];
-            w = eq_repair_walk<FC>(d, r, plan, rc, inst, h, lim, 0u, El);
+            w = eq_repair_walk<FC>(d, r, plan, rc, inst, h, lim, 0u, El, lane, p3g);
             in_sync = w.j_end == lim && same8(El, rc[lim - 1].end);
         }
         // the assumptions, in stream order
         uint32_t i = 0;
         bool apart = false;
         for (; i < n_heads; ++i) {
-            repaired += (unsigned long long)(uint32_t)__shfl((int)(uint32_t)w.repaired, (int)i, 64);
-            if (!__shfl((int)in_sync, (int)i, 64)) { apart = true; break; }
+            repaired += (unsigned long long)(uint32_t)__shfl((int)w.repaired, (int)(4 * i), 64);
+            settled += (unsigned long long)(uint32_t)__shfl((int)w.settled, (int)(4 * i), 64); steps += (unsigned long long)(uint32_t)__shfl((int)w.steps, (int)(4 * i), 64);
+            fills += (unsigned long long)(uint32_t)__shfl((int)w.fills, (int)(4 * i), 64);
+            if (!__shfl((int)in_sync, (int)(4 * i), 64)) { apart = true; break; }
         }
         __syncthreads();                           // heads[] is rewritten by the next round
         if (!apart) { pos = scan_end; continue; }
-        // island i ended apart, at chunk j_end with the true state in its lane: go on from there in order
-        pos = (uint32_t)__shfl((int)w.j_end, (int)i, 64);
+        // island i ended apart, at chunk j_end with the true state in its group: go on from there in order
+        pos = (uint32_t)__shfl((int)w.j_end, (int)(4 * i), 64);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) E[k] = shfl_f64(El[k], (int)i);
+        for (int k = 0; k < 8; ++k) E[k] = shfl_f64(El[k], (int)(4 * i));
         have_E = true;
         force_until = i + 1 < n_heads ? scan_end : pos;   // the islands behind it in this round started from an assumption that did not hold
     }
@@ -1005,7 +1162,14 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
     const size_t F = r.frames;
     st.history[0] = (double)d.in[F - 3]; st.history[1] = (double)d.in[F - 2]; st.history[2] = (double)d.in[F - 1];   // F >= 2 warm-ups >= 3 samples
     states[inst] = st;
-    if (stats) { atomicAdd(&stats[0], (unsigned long long)NC); if (repaired) atomicAdd(&stats[1], repaired); }
+    if (stats) {   // [0] chunks run, [1] not proven by their recorded start, [2] of those settled by the O(1) comparison, [3] walk steps (EQ_RB samples), [4] fill steps,
+                   // [5] rounds of islands, [6] in-order walks after an island that ended apart, [7] streams finished by the NaN fill
+        atomicAdd(&stats[0], (unsigned long long)NC);
+        if (repaired) {
+            atomicAdd(&stats[1], repaired); atomicAdd(&stats[2], settled); atomicAdd(&stats[3], steps); atomicAdd(&stats[4], fills);
+            atomicAdd(&stats[5], rounds); atomicAdd(&stats[6], in_order); atomicAdd(&stats[7], nan_fills);
+        }
+    }
 }
 
 // warm-up length: the 4-pole cascade's response to a unit difference k samples back is at most C(k+3,3) p^k (p = 1 - f); W is

@@ -26,9 +26,9 @@ for kind in sys.argv[1:] or ["noise", "muted", "gaps", "onegap"]:
     g.write_source(s, synth.noise(5, L) if kind == "muted" else material(kind), T)
     g.run_ticks(0, T)                      # a first run on programme, so that a muted strip has a state to decay from
     g.write_source(s, material(kind), T)
-    r0 = g.eq_spec_stats()
+    r0 = g.eq_repair_stats()
     for i in range(3):
         g.run_ticks((i + 1) * T, T)
     g.sync()
-    r1 = g.eq_spec_stats()
-    print(kind, "chunks run / repaired over 3 runs:", r1[0] - r0[0], r1[1] - r0[1], flush=True)
+    r1 = g.eq_repair_stats()
+    print(kind, "over 3 runs:", {k: r1[k] - r0[k] for k in r1}, flush=True)
