@@ -650,7 +650,7 @@ __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* b
     }
 }
 
-template <int SB, int KMODE, int KSTEREO, bool FC>
+template <int SB, int KMODE, int KSTEREO, bool FC, int NBUF = 2>
 __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                                 uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][TILE]
@@ -698,9 +698,20 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
     // own register assignment for the carried state (eight f64 poles, the delay line, min / max) and moved it back to a common one at the
     // back edge: 44 v_mov_b64 per super-block, 3 instructions per sample that no sample needed (ISA; PMC 79 -> 77 per output sample with
     // the index arithmetic of the DMA, see DESIGN.md 5.2 ledger).  Here a variant's loop keeps the state where it is; moves happen once per tick.
-    eq_tile_issue<SB>(c, eq_tiles, -(int)plan.warm);
+    // NBUF == 1 (with SB = 32): ONE tile of WHOLE 128-byte lines.  Half lines (SB = 16) cost the memory system: the L2 fetches whole lines, the
+    // other half is asked for a super-block of compute later, and by then 44 % of the lines have left the 4 MiB L2 that 512 such waves stream
+    // through (tools/fetch_probe.hip: 1.44x the bytes on the fabric; this kernel's FETCH_SIZE said the same).  Whole lines need 8 KiB per tile
+    // and a second tile would halve the waves a CU holds -- so there is none: a super-block's lines are asked for when the one before is
+    // stored, and the round trip is hidden by the other three waves of the SIMD instead of by a buffer.
+    if constexpr (NBUF == 2) eq_tile_issue<SB>(c, eq_tiles, -(int)plan.warm);
     auto begin_sb = [&](int g) -> float* {
         const int so = (g - n_warm) * EQ_SB;
+        if constexpr (NBUF == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage-out's reads of the tile are done before the DMA may land on it
+            eq_tile_issue<SB>(c, eq_tiles, so);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return eq_tiles;
+        }
         if (g + 1 < total) eq_tile_issue<SB>(c, eq_tiles + ((g + 1) & 1) * EQ_TILE, so + EQ_SB);   // its previous tenant was stored one step ago
         // everything but the DMA just issued has landed: this super-block's tile, and the stores of the one before
         if (g + 1 < total) { if (SB == 32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
@@ -1255,14 +1266,20 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     EqChunkRec* recs = (EqChunkRec*)scratch;
     static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
     const int um = uniform_mode;
-    const int sb = (!r.fc && env_int("MX_EQ_SPEC_SB", 16) == 32) ? 32 : 16;   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
+    // 321 (default): whole 128-byte lines, ONE tile of 32 samples per row (8 KiB of LDS per wave); 16: half lines, two tiles (round 3's default:
+    // 1.44x the source bytes on the fabric, tools/fetch_probe.hip); 32: whole lines, two tiles (16 KiB: ten waves per CU).  Measured, 1024 strips x
+    // 2048 ticks: 4.46 / 4.56 ms exact, 3.85 / 4.09 ms contracted (321 / 16).  A/B knob; the contracted order is compiled for 321 and 16.
+    const int sb_env = env_int("MX_EQ_SPEC_SB", 321);
+    const int sb = (!r.fc && sb_env == 32) ? 32 : (sb_env == 16 ? 16 : 321);   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
     const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
                        r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
     if (tiled) {
         static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
-        const size_t lds = std::max<size_t>(2 * 64 * (size_t)sb * sizeof(float), (size_t)lds_pad);
+        const size_t lds = std::max<size_t>((sb == 321 ? 1 : 2) * 64 * (size_t)(sb == 321 ? 32 : sb) * sizeof(float), (size_t)lds_pad);
         // the contracted order (MX_FLAG_FP_CONTRACT) is compiled for the 16-sample super-block only (the faster of the two)
-#define MX_GT(M, S) { if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
+#define MX_GT(M, S) { if (sb == 321 && r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, true, 1>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
+                      else if (sb == 321) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false, 1>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
+                      else if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
         switch (um) {

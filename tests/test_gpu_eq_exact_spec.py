@@ -315,6 +315,15 @@ def test_spec_eq_inline_envelope_with_unusual_parameters_matches_the_oracle(env_
     assert g.eq_spec_stats()[0] > 0
 
 
+@pytest.mark.parametrize("sb", ["16", "32"])
+def test_spec_eq_other_tile_shapes_stay_bit_exact(sb, monkeypatch):
+    """The tiled kernel's default moves WHOLE 128-byte lines through ONE tile per wave (MX_EQ_SPEC_SB=321); the two-tile shapes -- half lines
+    (16, round 3's default) and whole lines (32) -- stay compiled as A/B knobs and stay bit-exact."""
+    monkeypatch.setenv("MX_EQ_SPEC_SB", sb)
+    test_spec_eq_every_fused_epilogue_matches_the_oracle_graph((48000, 800))
+    test_spec_eq_bit_exact_on_live_and_stalling_inputs_state_carried((48000, 800), 0, monkeypatch)
+
+
 def test_one_lane_per_instance_kernel_still_matches_the_oracle():
     """Short streams of FEW instances now take the split-cascade path (k_eq_three_poles + k_eq_three_emit); k_eq_three_exact -- one lane
     per instance -- remains the path of short streams with thousands of instances (bench.py's 10 240-strip real-time graph).  The
