@@ -640,6 +640,79 @@ def scaling_probe(torch, stream, local_rank, abi, Workspace, synth, strips, T, S
     return out
 
 
+def exchange_parity(torch, dist, np, g, ex, mix, T, step, world):
+    """Is the exchange's combined bus the rank-ordered f32 sum of the partial buses (the graph N x Mixer(strips / N) -> Mixer(N, unity),
+    src/module/mixer.rs:57-68: master starts at +0.0 and adds channel after channel)?  Checked without any of the exchange's own code: every
+    rank's raw partial Master / Cue (read back from its graph) travels through ONE plain all_gather of torch.distributed (ncclAllGather), the
+    sum is made on the host in rank order with numpy f32 adds, and compared bit for bit with mx_exchange_read_result.  Collective: every
+    rank calls it; returns this rank's verdict."""
+    part = np.concatenate([g.read_output(mix, 0, T, True), g.read_output(mix, 1, T, True)])
+    mine = torch.from_numpy(part).cuda()
+    if world > 1:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        parts = [q.cpu().numpy() for q in parts]
+    else:
+        parts = [part]
+    acc = np.zeros_like(part)                      # util::zero, then `master[i] += ...` per channel in order (mixer.rs:54-68); x * 1.0 is x
+    for q in parts:
+        acc = acc + q
+    got_m, got_c = ex.result(step)
+    got = np.concatenate([got_m, got_c])
+    bad = np.flatnonzero(got.view(np.uint32) != acc.view(np.uint32))
+    if bad.size == 0:
+        return {"verdict": "bit-exact", "samples_compared": int(got.size), "against": f"host sum in rank order of {len(parts)} partial buses gathered by a plain ncclAllGather"}
+    i = int(bad[0])
+    return {"verdict": "MISMATCH", "samples_compared": int(got.size), "mismatching": int(bad.size), "first_index": i,
+            "got": float(got[i]), "want": float(acc[i])}
+
+
+def scaled_ticks_leg(torch, dist, np, synth, abi, shard, Workspace, args, rank, world, local_rank, stream, nccl_id_fn, toggling):
+    """N > 1: the OTHER tick policy beside the one the headline ran -- T x N ticks per step, so that a rank's chunk length (and the share of
+    warm-up samples its speculative EqThree runs) is what it is on one GPU.  Own graph, own exchange; barrier + max over ranks like the headline."""
+    from mixlab_amd.exchange import BusExchange
+    T, SR = args.ticks_per_step * world, args.sample_rate
+    spt = SR // 60
+    first, local_strips = shard.strip_range(rank, world, args.strips)
+    ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, local_strips, first, SR, want_trigs=True)
+    g = ws.build(max_ticks_per_run=T, flags=(abi.FLAG_EQ_FAST if args.eq_fast else 0) | (abi.FLAG_FP_CONTRACT if args.fp_contract else 0), device=local_rank, stream=stream.cuda_stream)
+    base_ticks = min(T, 256)
+    for j, sn in enumerate(srcs):
+        blk = synth.noise(first + j, base_ticks * spt)
+        g.write_source(sn, np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt], T)
+    ex = BusExchange(g, mix, T, rank, world, mode=args.exchange, nccl_id=nccl_id_fn())
+    steps, warm = min(args.steps, 6), 2
+    events = [gate_events(abi, trigs, first, i * T, T) if toggling else None for i in range(warm + steps + 1)]
+
+    def step(i):
+        if events[i] is not None:
+            g.schedule_params_batch(events[i][0], events[i][1])
+        g.run_ticks(i * T, T)
+        ex.submit(i)
+    with torch.cuda.stream(stream):
+        for i in range(warm):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warm + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        parity = exchange_parity(torch, dist, np, g, ex, mix, T, warm + steps - 1, world) if ex.mode != "allreduce" else None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    out = {"policy": "ticks per step scaled with N (a rank's chunks keep their one-GPU length)", "ticks_per_step": T, "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "value": args.strips * T * steps / dt, "unit": "channel-ticks/s", "exchange_mode": ex.mode, "parity": parity}
+    ex.close(); g.close()
+    return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -671,6 +744,7 @@ def main():
     ap.add_argument("--force-combine", action="store_true", help="run the N > 1 exchange path at N = 1 (single-rank RCCL group)")
     ap.add_argument("--scale-ticks", action="store_true", help="N > 1: T = --ticks-per-step x N ticks per step, so that a rank's chunk length (and with it the share of "
                     "warm-up samples its speculative EqThree runs) stays what it is on one GPU; the model line shows both policies")
+    ap.add_argument("--no-scaled-leg", action="store_true", help="N > 1: skip the second tick policy (T x N ticks per step) that the line carries beside the headline's")
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the one-GPU measurement of what a rank of a 2 / 4 / 8-GPU job computes per step (scaling_model)")
     ap.add_argument("--no-profile", action="store_true", help="debug: no per-kernel hipEvents in the timed region (roofline omitted)")
     ap.add_argument("--repeats", type=int, default=4, help="further repetitions of the K timed steps after the headline region (spread of the clock)")
@@ -855,10 +929,20 @@ def main():
                     ex_ms_all = []
                 ex_ms_all.append(ex.elapsed_ms(nxt + i))
         ex_ms = sorted(ex_ms_all)[len(ex_ms_all) // 2]
+        if ex.world != world:
+            raise SystemExit(f"the exchange's communicator has {ex.world} ranks, the job {world}")
         exch = {"mode": ex.mode, "rccl_ranks": ex.world, "transport": "RCCL, called by libmixlab_gpu.so (mx_exchange_*)",
                 "bytes_received_per_rank_per_step": ex.bytes_received_per_step(),
                 "exchange_ms_per_step": round(ex_ms, 4), "parity": "rank-ordered f32 sum (the graph N x Mixer(strips/N) -> Mixer(N))" if ex.mode != "allreduce"
                 else "NONE: ncclAllReduce order is not a reference graph's"}
+        if ex.mode != "allreduce":
+            # parity evidence that needs none of the exchange's own code (collective: every rank takes part; rank 0 reports)
+            with torch.cuda.stream(stream):
+                exch["parity_check"] = exchange_parity(torch, dist, np, g, ex, mix, T, nxt + 3, world)
+            if world > 1:
+                ok = torch.tensor([1 if exch["parity_check"]["verdict"] == "bit-exact" else 0], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                exch["parity_check"]["all_ranks"] = "bit-exact" if int(ok.item()) == 1 else "MISMATCH on some rank"
         if ex.mode == "allreduce" and world > 1:
             # measured deviation of the all-reduce from the ordered sum of the same partial buses
             box = [unique_id() if rank == 0 else None]
@@ -869,6 +953,15 @@ def main():
                 torch.cuda.synchronize()
             exch["max_ulp_vs_ordered_sum"] = ex.max_ulp_vs(nxt + 8, *ordered.result(0))
             ordered.close()
+
+    other_policy = None
+    if use_dist and not args.scale_ticks and not args.no_scaled_leg and (world > 1 or args.force_combine):
+        def fresh_id():
+            box = [unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            return box[0]
+        other_policy = scaled_ticks_leg(torch, dist, np, synth, abi, shard, Workspace, args, rank, world, local_rank, stream, fresh_id, toggling)
 
     # real-time regime: one 60 Hz tick per submission, synchronised every tick like a live engine
     realtime = None
@@ -1119,6 +1212,7 @@ def main():
             "held_gates": held,
             "fp_contract": contract,
             "exchange": exch,
+            "scaled_ticks": other_policy,
             "realtime": realtime,
             "t_sweep": t_sweep,
             "material": material,
