@@ -639,13 +639,14 @@ void Graph::upload_group_one(Group& g) {
     }
     case MX_KIND_RESAMPLE: {
         size_t tt = 0, th = 0; g.max_taps = 0;
-        g.rs_tab_doubles = 0; g.rs_win_frames = 0; g.rs_common_up = 0; bool rs_first = true;
+        g.rs_tab_doubles = 0; g.rs_win_frames = 0; g.rs_common_up = 0; g.rs_common_taps = 0; g.rs_common_down = 0; bool rs_first = true;
         for (uint32_t id : g.nodes) {
             mx_resample_params h; std::memcpy(&h, nodes_[id].params.data(), sizeof h);
             tt += (size_t)h.up * h.taps_per_phase; th += h.taps_per_phase; g.max_taps = std::max(g.max_taps, h.taps_per_phase);
             g.rs_tab_doubles = (uint32_t)std::min<uint64_t>(0xffffffffu, std::max<uint64_t>(g.rs_tab_doubles, (uint64_t)h.up * h.taps_per_phase));
             g.rs_win_frames = (uint32_t)std::min<uint64_t>(0xffffffffu, std::max<uint64_t>(g.rs_win_frames, (uint64_t)255 * h.down / h.up + 2 + h.taps_per_phase));
-            if (rs_first) { g.rs_common_up = h.up; rs_first = false; } else if (g.rs_common_up != h.up) g.rs_common_up = 0;   // every node's interpolation factor, if they agree
+            if (rs_first) { g.rs_common_up = h.up; g.rs_common_taps = h.taps_per_phase; g.rs_common_down = h.down; rs_first = false; }   // every node's ratio and taps per phase, where they agree
+            else { if (g.rs_common_up != h.up) g.rs_common_up = 0; if (g.rs_common_taps != h.taps_per_phase) g.rs_common_taps = 0; if (g.rs_common_down != h.down) g.rs_common_down = 0; }
         }
         std::vector<double> taps(tt);
         if (g.extra.bytes < tt * sizeof(double) || !g.extra.p) g.extra.alloc(tt * sizeof(double));
@@ -1052,7 +1053,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         case MX_KIND_FIR: launch_fir((const FirDesc*)desc_of(g), n, g.max_taps, gf, stream_, fp_contract()); break;
         case MX_KIND_RESAMPLE:
             launch_resample((const ResampleDesc*)desc_of(g), n, g.max_taps, g.rs_tab_doubles, g.rs_win_frames, frames * g.in_dom_num / g.in_dom_den, gf,
-                            t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_, g.rs_common_up, fp_contract());
+                            t0 * g.in_dom_num / g.in_dom_den, t0 * g.dom_num / g.dom_den, stream_, g.rs_common_up, fp_contract(), g.rs_common_taps, g.rs_common_down);
             break;
         case MX_KIND_PLOTTER: {
             jobs.clear();

@@ -79,6 +79,7 @@ struct Group {
     uint32_t kind = 0;
     uint32_t dom_num = 1, dom_den = 1, in_dom_num = 1, in_dom_den = 1;   // every node of a group shares one rate domain
     uint32_t max_taps = 0;   // Fir / Resample: most taps; Mixer: most channels
+    uint32_t rs_common_taps = 0, rs_common_down = 0;   // ... and their taps per phase / decimation factor, likewise
     uint32_t rs_common_up = 0;   // Resample: the nodes' interpolation factor when they all have the same (the staged kernel's table stride becomes a constant)
     uint32_t rs_tab_doubles = 0, rs_win_frames = 0;   // Resample: LDS plan of the staged kernel (largest table / input window of the group)
     std::vector<uint32_t> nodes;

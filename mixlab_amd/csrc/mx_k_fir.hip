@@ -18,76 +18,76 @@
 namespace mx {
 
 #define FIR_BLOCK 256
-#define FIR_PER 4                          // consecutive outputs per lane
-#define FIR_TILE (FIR_BLOCK * FIR_PER)     // outputs per block step
 // out[n] = (f32) sum_k h[k] * (f64) x[n-k] per channel; x[m<0] comes from the carried history.
 //
 // The prescribed work is 4 f64 operations per tap and stereo frame (2 mul + 2 add, no FMA by spec).  With one output
 // per lane every tap step also needs 16 B of LDS per lane, and LDS (128 B/clk/CU) feeds only half of what the four
-// SIMDs can multiply -- measured 0.475 of the f64 rate, exactly that roof.  So a lane owns FOUR consecutive outputs:
-// their inputs are a sliding window in registers, one new frame per tap step serves all four, LDS traffic drops 4x.
-// Lanes then read frames 4 apart; the window is stored with one pad frame after every 4 (p = f + f/4): a stride of
-// 5 frames = 20 banks, and the 16 lanes a ds_read_b128 serves per pass cover all 64 banks exactly once.
+// SIMDs can multiply -- measured 0.475 of the f64 rate, exactly that roof.  So a lane owns PER consecutive outputs (4, or 8:
+// launch_fir): their inputs are a sliding window in registers, one new frame per tap step serves all of them, LDS traffic drops
+// PER-fold, and the loop's own instructions (a tap's coefficient read, the LDS offsets) are shared by PER x 4 f64 operations.
+// Lanes then read frames PER apart; the window is stored with one pad frame after every PER (p = f + f / PER): a stride of
+// PER + 1 frames = 20 (36) banks, and the 16 lanes a ds_read_b128 serves per pass cover all 64 banks exactly once.
 // Frames are widened to f64 once while staging (exact); taps sit in LDS (uniform reads broadcast).
-__device__ __forceinline__ int fir_pad(int f) { return f + (f >> 2); }
-template <bool FC>
+template <int PER> __device__ __forceinline__ int fir_pad(int f) { return f + (f / PER); }   // f >= 0; PER a power of two: a shift
+template <int PER, bool FC>
 __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const FirDesc* __restrict__ descs, size_t frames) {
+    constexpr int TILE = FIR_BLOCK * PER;                                 // outputs per block step
     const FirDesc d = descs[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = (int)d.n_taps;
     double* tapl = reinterpret_cast<double*>(smem);                       // [K rounded up to even]
-    double2* win = reinterpret_cast<double2*>(tapl + ((K + 1) & ~1));     // padded window of FIR_TILE + K - 1 frames
+    double2* win = reinterpret_cast<double2*>(tapl + ((K + 1) & ~1));     // padded window of TILE + K - 1 frames
     for (int k = threadIdx.x; k < K; k += FIR_BLOCK) tapl[k] = d.taps[k];
-    // FIR_PER zero frames in front of the window: the frame that "enters" after the last tap of the first output is
+    // PER zero frames in front of the window: the frame that "enters" after the last tap of the first output is
     // never used, and with the pad its read needs no guard -- the tap loop is branch-free
-    if (threadIdx.x < FIR_PER) win[fir_pad((int)threadIdx.x)] = make_double2(0.0, 0.0);
-    const int WN = FIR_TILE + K - 1;
-    for (size_t blk = (size_t)blockIdx.x * FIR_TILE; blk < frames; blk += (size_t)gridDim.x * FIR_TILE) {
+    if ((int)threadIdx.x < PER) win[fir_pad<PER>((int)threadIdx.x)] = make_double2(0.0, 0.0);
+    const int WN = TILE + K - 1;
+    for (size_t blk = (size_t)blockIdx.x * TILE; blk < frames; blk += (size_t)gridDim.x * TILE) {
         // window frame w <-> stream frame blk - (K-1) + w
         for (int w = threadIdx.x; w < WN; w += FIR_BLOCK) {
             const long long f = (long long)blk + w - (K - 1);
             float2 v = make_float2(0.f, 0.f);
             if (f >= 0) { if ((size_t)f < frames && d.in) v = reinterpret_cast<const float2*>(d.in)[f]; }
             else { const long long h = (long long)(K - 1) + f; if (h >= 0) v = d.hist[h]; }   // hist[j] = x[j - (K-1)]
-            win[fir_pad(w + FIR_PER)] = make_double2((double)v.x, (double)v.y);
+            win[fir_pad<PER>(w + PER)] = make_double2((double)v.x, (double)v.y);
         }
         __syncthreads();
-        const int o = FIR_PER * (int)threadIdx.x;                         // my first output inside the tile
+        const int o = PER * (int)threadIdx.x;                             // my first output inside the tile
         if (blk + o < frames) {
-            double al[FIR_PER], ar[FIR_PER];
-            double2 w[FIR_PER];                                           // w[j] = x[o + j - k] for the current tap k
-            // o is a multiple of 4, so fir_pad(o + m) = fir_pad(o) + fir_pad(m): one per-lane base, wave-uniform (scalar) offsets
-            const char* lane_base = reinterpret_cast<const char*>(win) + (size_t)fir_pad(o) * sizeof(double2);
-            auto rd = [&](int m) { return *reinterpret_cast<const double2*>(lane_base + (size_t)fir_pad(m) * sizeof(double2)); };
+            double al[PER], ar[PER];
+            double2 w[PER];                                               // w[j] = x[o + j - k] for the current tap k
+            // o is a multiple of PER, so fir_pad(o + m) = fir_pad(o) + fir_pad(m): one per-lane base, wave-uniform (scalar) offsets
+            const char* lane_base = reinterpret_cast<const char*>(win) + (size_t)fir_pad<PER>(o) * sizeof(double2);
+            auto rd = [&](int m) { return *reinterpret_cast<const double2*>(lane_base + (size_t)fir_pad<PER>(m) * sizeof(double2)); };
 #pragma unroll
-            for (int j = 0; j < FIR_PER; ++j) { al[j] = 0.0; ar[j] = 0.0; w[j] = rd(j + (K - 1) + FIR_PER); }
+            for (int j = 0; j < PER; ++j) { al[j] = 0.0; ar[j] = 0.0; w[j] = rd(j + (K - 1) + PER); }
             int k = 0;
 #pragma unroll 2
-            for (; k + FIR_PER <= K; k += FIR_PER) {
+            for (; k + PER <= K; k += PER) {
 #pragma unroll
-                for (int u = 0; u < FIR_PER; ++u) {                       // tap k + u: the window has slid u frames; slot names rotate, nothing moves
+                for (int u = 0; u < PER; ++u) {                           // tap k + u: the window has slid u frames; slot names rotate, nothing moves
                     const double h = tapl[k + u];
 #pragma unroll
-                    for (int j = 0; j < FIR_PER; ++j) {
-                        const double2 x = w[(j - u + FIR_PER) % FIR_PER];
+                    for (int j = 0; j < PER; ++j) {
+                        const double2 x = w[(j - u + PER) % PER];
                         al[j] = mul_add<FC>(h, x.x, al[j]);
                         ar[j] = mul_add<FC>(h, x.y, ar[j]);
                     }
-                    // frame x[o - 1 - (k + u)] enters; it replaces the slot of x[o + 3 - (k + u)], which no later tap needs
-                    w[(FIR_PER - 1 - u + FIR_PER) % FIR_PER] = rd((K - 1) - 1 - (k + u) + FIR_PER);
+                    // frame x[o - 1 - (k + u)] enters; it replaces the slot of x[o + PER - 1 - (k + u)], which no later tap needs
+                    w[(PER - 1 - u + PER) % PER] = rd((K - 1) - 1 - (k + u) + PER);
                 }
             }
-            for (; k < K; ++k) {                                          // K not a multiple of 4: rotate by moving
+            for (; k < K; ++k) {                                          // K not a multiple of PER: rotate by moving
                 const double h = tapl[k];
 #pragma unroll
-                for (int j = 0; j < FIR_PER; ++j) { al[j] = mul_add<FC>(h, w[j].x, al[j]); ar[j] = mul_add<FC>(h, w[j].y, ar[j]); }
+                for (int j = 0; j < PER; ++j) { al[j] = mul_add<FC>(h, w[j].x, al[j]); ar[j] = mul_add<FC>(h, w[j].y, ar[j]); }
 #pragma unroll
-                for (int j = FIR_PER - 1; j > 0; --j) w[j] = w[j - 1];
-                w[0] = rd((K - 1) - 1 - k + FIR_PER);
+                for (int j = PER - 1; j > 0; --j) w[j] = w[j - 1];
+                w[0] = rd((K - 1) - 1 - k + PER);
             }
             float2* out = reinterpret_cast<float2*>(d.out) + blk + o;
 #pragma unroll
-            for (int j = 0; j < FIR_PER; ++j) if (blk + o + j < frames) out[j] = make_float2((float)al[j], (float)ar[j]);
+            for (int j = 0; j < PER; ++j) if (blk + o + j < frames) out[j] = make_float2((float)al[j], (float)ar[j]);
         }
         __syncthreads();
     }
@@ -110,11 +110,17 @@ __global__ __launch_bounds__(256) void k_fir_history(const FirDesc* __restrict__
 }
 void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s, bool fc) {
     if (!n || !frames) return;
-    const size_t wn = (size_t)FIR_TILE + max_taps + FIR_PER;
-    const size_t lds = (size_t)((max_taps + 1) & ~1u) * sizeof(double) + (wn + wn / 4 + 2) * sizeof(double2);
-    dim3 grid(grid_x(frames, FIR_TILE, 1024), n);
-    if (fc) hipLaunchKernelGGL(k_fir<true>, grid, dim3(FIR_BLOCK), lds, s, d, frames);
-    else hipLaunchKernelGGL(k_fir<false>, grid, dim3(FIR_BLOCK), lds, s, d, frames);
+    // outputs per lane: 8 where the streams are long enough to fill the chip with tiles of 2048 outputs (and the window fits LDS), else 4
+    static const int force_per = env_int("MX_FIR_PER", 0);
+    const int per = force_per == 4 || force_per == 8 ? force_per : ((frames >= 8192 && max_taps <= 1024) ? 8 : 4);
+    const size_t tile = (size_t)FIR_BLOCK * per;
+    const size_t wn = tile + max_taps + per;
+    const size_t lds = (size_t)((max_taps + 1) & ~1u) * sizeof(double) + (wn + wn / per + 2) * sizeof(double2);
+    dim3 grid(grid_x(frames, (unsigned)tile, 1024), n);
+#define MX_FIR_GO(P, F) hipLaunchKernelGGL((k_fir<P, F>), grid, dim3(FIR_BLOCK), lds, s, d, frames)
+    if (per == 8) { if (fc) MX_FIR_GO(8, true); else MX_FIR_GO(8, false); }
+    else { if (fc) MX_FIR_GO(4, true); else MX_FIR_GO(4, false); }
+#undef MX_FIR_GO
     hipLaunchKernelGGL(k_fir_history, dim3(n), dim3(256), max_taps * sizeof(float2), s, d, frames);
 }
 
@@ -215,6 +221,78 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleDesc* __restrict
         __syncthreads();
     }
 }
+// k_resample_ps ("phase-stationary"): the form for a launch whose channels all share the ratio UP / down and P taps per phase (config 3: 160 / 147,
+// 16 taps).  Output M + UP has the phase of output M, so when a block's groups of 256 outputs are a multiple of UP outputs apart (the launcher
+// makes the blocks per channel a multiple of UP / gcd(UP, 256)) every lane keeps ONE phase for the whole launch: its P coefficients are loaded
+// into registers once -- no table in LDS (20 KiB per block in k_resample) and no coefficient read per tap: two 8-byte LDS reads per four f64
+// operations instead of three (profiles/r03: the kernel waited on LDS issue and latency, at 0.245 of the f64 rate and 0.29 of HBM).  The offset of a
+// lane's first input frame inside the window is loop-invariant for the same reason.  With 8 KiB of LDS per block the window is double-buffered:
+// one barrier per group instead of two, the next group's frames in flight while this group's taps run.
+template <int UP, int P, bool FC>
+__global__ __launch_bounds__(256) void k_resample_ps(const ResampleDesc* __restrict__ descs, size_t out_frames, uint64_t out_base, uint64_t in_base) {
+    const ResampleDesc d = descs[blockIdx.y];
+    constexpr int H = P - 1;
+    constexpr uint32_t CAP = 256;                                         // window frames per group: 255 * down / UP + 2 + P <= 256 (launcher)
+    const uint32_t down = d.down;
+    __shared__ double win[2][2][CAP];                                     // [buffer][left, right][frame], widened once while staging
+    const int tid = threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;                        // a multiple of UP outputs: phases and offsets repeat
+    size_t blk = (size_t)blockIdx.x * 256;
+    if (blk >= out_frames) return;
+    // the block's first output: n0 = floor(M0 * down / UP), r0 = (M0 * down) mod UP -- r0 is the same for every group of this block
+    const uint64_t num0 = (out_base + blk) * down;
+    const uint64_t n0_abs = num0 / UP;
+    const uint32_t r0 = (uint32_t)(num0 - n0_abs * UP);
+    const uint32_t q = r0 + (uint32_t)tid * down;                         // < UP + 255 * down: 32 bits for every audio ratio (launcher)
+    const uint32_t dn = q / UP, phase = q - dn * UP;                      // my input frame relative to the group's first, my phase: loop-invariant
+    double c[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) c[k] = d.taps[(size_t)phase * P + k];
+    const uint64_t in_step = (uint64_t)(stride / UP) * down;              // input frames between two groups of this block (exact: stride % UP == 0)
+    long long f0 = (long long)(n0_abs - in_base) - H;                    // input index of window frame 0 of the current group
+    const uint32_t cnt_full = min((uint32_t)((r0 + 255ull * down) / UP) + 1u + (uint32_t)H, CAP);   // window frames of a full group (loop-invariant)
+    const float2* __restrict__ in2 = reinterpret_cast<const float2*>(d.in);
+    auto fetch = [&](long long base_f, size_t g_blk) {
+        // an interior group (block-uniform test): every frame of its window exists in this run's input -- one guarded load, no geometry
+        if (base_f >= 0 && out_frames - g_blk >= 256 && in2) return (uint32_t)tid < cnt_full ? (in2 + base_f)[tid] : make_float2(0.f, 0.f);
+        uint32_t cnt = cnt_full;
+        if (out_frames - g_blk < 256) cnt = min((uint32_t)((r0 + (uint64_t)(out_frames - 1 - g_blk) * down) / UP) + 1u + (uint32_t)H, CAP);   // the stream's last, partial group
+        const long long f = base_f + tid;
+        float2 v = make_float2(0.f, 0.f);
+        if ((uint32_t)tid < cnt) {
+            if (f >= 0) { if (in2) v = in2[f]; }
+            else { const long long hh = (long long)H + f; if (hh >= 0) v = d.hist[hh]; }
+        }
+        return v;
+    };
+    // the frames of the next TWO groups are in flight while this group's taps run: one group's taps (a few hundred cycles) do not cover a round trip to memory
+    float2 pre = fetch(f0, blk), pre2 = make_float2(0.f, 0.f);
+    if (blk + stride < out_frames) pre2 = fetch(f0 + (long long)in_step, blk + stride);
+    f0 += 2 * (long long)in_step;                                         // window start of the group two ahead
+    int buf = 0;
+    for (; blk < out_frames; blk += stride, buf ^= 1) {
+        win[buf][0][tid] = (double)pre.x; win[buf][1][tid] = (double)pre.y;
+        __syncthreads();      // (the one barrier: a wave writes buffer b again two groups later, after every wave has passed the barrier in between)
+        pre = pre2;
+        const size_t nxt2 = blk + 2 * stride;
+        if (nxt2 < out_frames) pre2 = fetch(f0, nxt2);
+        f0 += (long long)in_step;
+        if (blk + tid < out_frames) {
+            // volatile: each read stays a ds_read_b64 of its own (merged into ds_read2_b64 pairs they are served 16 lanes at a time)
+            typedef const volatile __attribute__((address_space(3))) double* LdsD;
+            const LdsD l = (LdsD)(&win[buf][0][H + dn]);                  // l[0] = frame n of this output
+            const LdsD r = (LdsD)(&win[buf][1][H + dn]);
+            double al = 0.0, ar = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const double vl = l[-k], vr = r[-k];
+                al = mul_add<FC>(c[k], vl, al);
+                ar = mul_add<FC>(c[k], vr, ar);
+            }
+            reinterpret_cast<float2*>(d.out)[blk + tid] = make_float2((float)al, (float)ar);
+        }
+    }
+}
 template <bool FC>
 __global__ __launch_bounds__(256) void k_resample_gather(const ResampleDesc* __restrict__ descs, size_t out_frames,
                                                          uint64_t out_base, uint64_t in_base) {
@@ -255,13 +333,27 @@ __global__ __launch_bounds__(256) void k_resample_history(const ResampleDesc* __
     for (int j = threadIdx.x; j < H; j += 256) d.hist[j] = tmp[j];
 }
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles, uint32_t win_frames,
-                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up, bool fc) {
+                     size_t in_frames, size_t out_frames, uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up, bool fc, uint32_t common_taps, uint32_t common_down) {
     if (!n || !out_frames) return;
+    static const uint32_t cus = [] { int dev = 0, n_cu = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256; return (uint32_t)std::max(n_cu, 1); }();
+    static const int no_ps = env_int("MX_RESAMPLE_PS", 1) == 0;           // A/B: the staged kernel everywhere
+    // every channel 160 / down with 16 taps per phase, a window that fits 256 frames: lanes keep their phase (k_resample_ps)
+    if (!no_ps && common_up == 160u && common_taps == 16u && common_down && (uint64_t)255 * common_down / 160u + 2u + 16u <= 256u && (uint64_t)160u + 255ull * common_down < (1ull << 32)) {
+        const uint32_t m = 5;                                             // 160 / gcd(160, 256): blocks per channel come in multiples of it
+        const size_t groups = (out_frames + 255) / 256;
+        const uint32_t resident = cus * 8u;                               // 8 KiB of LDS and 4 waves per block: the 32-wave limit decides
+        uint32_t per_ch = std::max<uint32_t>(1u, resident / n) / m * m;
+        if (per_ch == 0) per_ch = m;
+        per_ch = (uint32_t)std::min<size_t>(per_ch, (groups + m - 1) / m * m);
+        if (fc) hipLaunchKernelGGL((k_resample_ps<160, 16, true>), dim3(per_ch, n), dim3(256), 0, s, d, out_frames, out_base, in_base);
+        else hipLaunchKernelGGL((k_resample_ps<160, 16, false>), dim3(per_ch, n), dim3(256), 0, s, d, out_frames, out_base, in_base);
+        hipLaunchKernelGGL(k_resample_history, dim3(n), dim3(256), (max_taps + 1) * sizeof(float2), s, d, in_frames);
+        return;
+    }
     const size_t lds = (size_t)tab_doubles * sizeof(double) + (size_t)((win_frames + 1u) & ~1u) * 2 * sizeof(double);
     if (lds <= 60 * 1024) {
         // few blocks per channel, each walking many 256-output groups (the table is loaded once per block): as many blocks as the chip
         // holds at once, so they all start together, do the same work and end together -- no partly filled last round
-        static const uint32_t cus = [] { int dev = 0, n_cu = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256; return (uint32_t)std::max(n_cu, 1); }();
         const uint32_t resident = cus * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
         const uint32_t per_ch = (uint32_t)std::max<size_t>(1, std::min<size_t>((out_frames + 255) / 256, std::max<uint32_t>(1u, resident / n)));
 #define MX_RS_GO(U, F) hipLaunchKernelGGL((k_resample<U, F>), dim3(per_ch, n), dim3(256), lds, s, d, out_frames, out_base, in_base, win_frames)

@@ -134,6 +134,7 @@ void launch_copy_jobs(const CopyJob* device_jobs, uint32_t n, hipStream_t s);   
 void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s, bool fc = false);
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles /* max up * taps_per_phase */,
                      uint32_t win_frames /* max 255 * down / up + 2 + taps_per_phase */, size_t in_frames, size_t out_frames,
-                     uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up = 0 /* every channel's `up` when they all agree, else 0 */, bool fc = false);
+                     uint64_t in_base, uint64_t out_base, hipStream_t s, uint32_t common_up = 0 /* every channel's `up` when they all agree, else 0 */, bool fc = false,
+                     uint32_t common_taps = 0, uint32_t common_down = 0 /* likewise taps_per_phase and `down` */);
 
 }  // namespace mx
