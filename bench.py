@@ -322,7 +322,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
                                    "layers_read_by_the_chain": layers_read,
                                    "launches": "k_video_batch: the chains of 16 ticks and the scaler tiles of the 16 ticks after them in ONE launch (MX_VIDEO_BATCH; DESIGN.md 5.3)",
                                    "ticks_per_submission": T,
-                                   "note": "per-kernel durations and PMC traffic: profiles/r03 (the hipEvents here bracket the whole per-tick video section)"},
+                                   "note": "per-kernel durations and PMC traffic: profiles/r04 (the hipEvents here bracket the whole per-tick video section)"},
     }
 
 
@@ -453,7 +453,7 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup, flags=0, with_contract=
            "ticks_per_step": T, "ms_per_step": dt / steps * 1e3, "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
            "realtime_stereo_channels_equiv": n_ch * T * steps / dt / 60.0}
     # per-kernel roofs: the f64 operations the spec prescribes against the f64 VALU rate, the bytes a kernel has to move against HBM, and the
-    # HBM traffic of the committed PMC passes (profiles/r03/fir_pmc_traffic.json) while the kernel sources are the ones it was collected on
+    # HBM traffic of the committed PMC passes (profiles/r04/fir_pmc_traffic.json) while the kernel sources are the ones it was collected on
     traffic = {}
     try:
         rec = json.load(open(PROFILE_DIR / "fir_pmc_traffic.json"))
@@ -471,7 +471,7 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup, flags=0, with_contract=
                        "moved_bytes_per_launch": moved[k], "hbm_frac": round(moved[k] / sec / 1e9 / HBM_PEAK_GBS, 4),
                        "traffic": traffic.get(k), "bound": "f64 VALU (prescribed mul + add, no FMA by spec)" if k == "fir" else "on-chip: LDS issue (three 8-byte reads per tap step and lane against four f64 operations) and the latency between a group's barriers; neither the f64 rate nor HBM"}
     out["roofline"] = {"per_kernel": roof, "f64_peak_tops": F64_VALU_PEAK_TOPS, "hbm_peak_gbs": HBM_PEAK_GBS,
-                       "traffic_source": "profiles/r03/fir_pmc_traffic.json" if traffic else None}
+                       "traffic_source": "profiles/r04/fir_pmc_traffic.json" if traffic else None}
     if "fir" in k_ms:
         out["fir_f64_valu"] = {"ops_per_launch": fir_ops, "achieved_tops": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12, 2), "peak_tops": 39.3,
                                "frac": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12 / 39.3, 3), "note": "prescribed f64 mul + add only (no FMA by spec)"}
@@ -552,7 +552,7 @@ def fir_cpu_baseline(T_ref_ticks=8, n_ch=8):
             "sample": f"{n_ch} of the 256 stereo channels x {n_ticks} ticks, single thread, {dt:.1f} s"}
 
 
-PROFILE_DIR = ROOT / "profiles" / "r03"
+PROFILE_DIR = ROOT / "profiles" / "r04"
 
 
 def _kernel_hash(family):
@@ -561,32 +561,52 @@ def _kernel_hash(family):
     return kernel_hash(family)
 
 
-def pmc_traffic(kernel, args, world, toggling):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r03/pmc_traffic.json, collected
+def pmc_traffic(kernel, args, world, toggling, fc=None):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r04/pmc_traffic.json, collected
     with this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide streaming reads); None when the run's configuration differs from the profiled one
     OR the kernel sources have changed since the profile was collected (their hash is recorded in the JSON) -- counters cannot be
     read from inside the process, and a stale figure is worse than none."""
+    fc = bool(args.fp_contract) if fc is None else fc
+    name = "pmc_traffic_fc.json" if fc else "pmc_traffic.json"
     try:
-        rec = json.load(open(PROFILE_DIR / "pmc_traffic.json"))
+        rec = json.load(open(PROFILE_DIR / name))
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_sources_sha16") != _kernel_hash("audio"):
-        return None, "profiles/r03/pmc_traffic.json is STALE (kernel sources changed since it was collected): not copied"
+        return None, f"profiles/r04/{name} is STALE (kernel sources changed since it was collected): not copied"
     c = rec.get("config", {})
     same = (c.get("strips") == args.strips and c.get("ticks_per_step") == args.ticks_per_step and c.get("sample_rate") == args.sample_rate
             and c.get("fused") == (not args.no_fuse) and c.get("eq_fast") == bool(args.eq_fast) and c.get("n_gpus") == world
-            and c.get("gates_toggle") == bool(toggling))
+            and c.get("gates_toggle") == bool(toggling) and bool(c.get("fp_contract", False)) == fc)
     if not same or kernel not in rec.get("bytes_per_launch", {}):
         return None, None
-    return rec["bytes_per_launch"][kernel], "profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; kernel sources unchanged since)"
+    return rec["bytes_per_launch"][kernel], f"profiles/r04/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; the x2 confirmed on this kernel's whole-line reads by tools/fetch_probe.hip; kernel sources unchanged since)"
 
 
-def sustained_clock_ghz(kernel_substr):
-    """The clock the chip held under a kernel in the committed counter pass (profiles/r03/clock.json), or None when that profile was
+def sq_profile(kernel_substr, fc, samples):
+    """What the committed SQ counter pass (profiles/r04/pmc_sq_toggle.json / pmc_sq_fc.json: means per dispatch) says about the dominant kernel, per
+    OUTPUT sample of the launch: VALU wave-instructions x 64 lanes / samples.  None when the profile was collected on other kernel sources."""
+    try:
+        rec = json.load(open(PROFILE_DIR / ("pmc_sq_fc.json" if fc else "pmc_sq_toggle.json")))
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernel_sources_sha16") != _kernel_hash("audio"):
+        return None
+    for k, v in rec.get("mean_per_dispatch", {}).items():
+        if kernel_substr in k and v.get("SQ_INSTS_VALU", 0) > 1e6:
+            out = {"kernel": k[-70:], "valu_instructions_per_output_sample": round(v["SQ_INSTS_VALU"] * 64.0 / samples, 2)}
+            if v.get("SQ_ACTIVE_INST_VALU"):
+                out["valu_active_quad_cycles_per_dispatch"] = v["SQ_ACTIVE_INST_VALU"]   # x 4 cycles / (1024 SIMDs x the dispatch's cycles) = the share of time the VALU pipes are busy
+            return out
+    return None
+
+
+def sustained_clock_ghz(kernel_substr, fc=False):
+    """The clock the chip held under a kernel in the committed counter pass (profiles/r04/clock.json, clock_fc.json), or None when that profile was
     collected on other kernel sources."""
     try:
-        rec = json.load(open(PROFILE_DIR / "clock.json"))
+        rec = json.load(open(PROFILE_DIR / ("clock_fc.json" if fc else "clock.json")))
     except (OSError, ValueError):
         return None
     if rec.get("kernel_sources_sha16") != _kernel_hash("audio"):
@@ -1153,10 +1173,19 @@ def main():
                     "algorithmic_bytes_per_unit": "2M = 8 B per sample per strip (SURVEY 8d: EqThree channel-tick; source read + strip written as one float per frame)",
                     "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
-                    "limiter": ("f64 VALU issue (profiles/r03, DESIGN.md 5.2 ledger): the hot loop is 63.5 VALU instructions per sample of which 59 are the reference's own operations in the reference's order, "
-                                "the warm-up of every chunk adds 14.5 % more lane-samples; the VALU pipes are busy most of the kernel at the clock the chip sustains under f64 issue; "
-                                "HBM traffic = 1.16x algorithmic (the warm-up re-read): HBM is the roof only nominally" if dom == "eq_three" else "HBM"),
                     "per_kernel": per_kernel}
+            if dom == "eq_three":
+                sq = sq_profile("k_eq_three_spec_tiled", bool(args.fp_contract), local_strips * frames)
+                mand = (26.0 + 5.0 + 12.0 * 0.7) if args.fp_contract else (36.0 + 8.0 + 15.0)
+                roof["limiter"] = ("f64 VALU issue, not HBM: " + (f"{sq['valu_instructions_per_output_sample']} VALU instructions per output sample (PMC SQ_INSTS_VALU, profiles/r04), " if sq else "") +
+                                   f"{mand:.0f} of them the reference's own operations" + (" with each multiply fused into its add" if args.fp_contract else " in the reference's order") +
+                                   "; every chunk re-runs a warm-up of 1 280 samples per 6 400; " +
+                                   (f"HBM traffic {traffic / alg:.2f}x the algorithmic bytes (PMC; the warm-up re-read is 1.10x of that by construction)" if traffic else "HBM traffic: no current PMC pass") +
+                                   "; the board's power limit holds the clock below 2.4 GHz under this kernel (f64_valu.sustained_clock)")
+                if sq:
+                    roof["sq_profile"] = sq
+            else:
+                roof["limiter"] = "HBM"
             if dom == "eq_three":
                 # the bound that applies: f64 VALU.  Reference arithmetic per strip-sample: EqThree 36 f64 operations (2 x 4 poles x (sub, mul, add)
                 # + VSA adds + band split + gains + 2 conversions), Amplifier 6 (conversions, depth, 2 products), Envelope closed form ~13 on the
@@ -1167,20 +1196,23 @@ def main():
                                     "peak_tops": F64_VALU_PEAK_TOPS, "frac": round(f64_ops / (avg_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TOPS, 3),
                                     "note": "f64 operations of the reference's arithmetic per second against the f64 VALU instruction rate at the 2.4 GHz peak clock (an FMA would count once; none is allowed here)",
                                     }
-                ghz = sustained_clock_ghz("k_eq_three_spec_tiled")
+                ghz = sustained_clock_ghz("k_eq_three_spec_tiled", bool(args.fp_contract))
                 if ghz:
                     roof["f64_valu"]["sustained_clock"] = {"ghz": ghz, "peak_tops_at_that_clock": round(F64_VALU_PEAK_TOPS * ghz / 2.4, 1),
                                                            "frac_at_that_clock": round(f64_ops / (avg_ms * 1e-3) / 1e12 / (F64_VALU_PEAK_TOPS * ghz / 2.4), 3),
-                                                           "source": "profiles/r03/clock.json: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled; a committed measurement of these kernel sources, not read live"}
+                                                           "source": "profiles/r04/clock.json: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled; a committed measurement of these kernel sources, not read live"}
         if contract is not None:
             ck_ms = contract["kernel_ms_per_step"]
             if "eq_three" in ck_ms:
                 alg = moved_bytes("eq_three")
                 sec = ck_ms["eq_three"] * 1e-3
                 ops_fc = 26.0 + 5.0 + (12.0 * 0.7 if toggling else 0.0)      # f64 INSTRUCTIONS of the contracted order per strip-sample (an fma counts once)
-                contract["roofline"] = {"kernel": "eq_three launch group, contracted order (k_env_ticks<true> + k_eq_three_spec_tiled<16, ., ., true> + k_eq_three_repair<true>)",
+                contract["roofline"] = {"kernel": "eq_three launch group, contracted order (k_env_ticks<true> + k_eq_three_spec_tiled<32, ., ., true, 1> + k_eq_three_repair<true>)",
                                         "bound": "hbm", "achieved": round(alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                        "traffic": None, "avg_launch_ms": round(ck_ms["eq_three"], 5), "algorithmic_bytes_per_launch": alg,
+                                        "traffic": pmc_traffic("eq_three", args, world, toggling, fc=True)[0], "traffic_source": pmc_traffic("eq_three", args, world, toggling, fc=True)[1],
+                                        "avg_launch_ms": round(ck_ms["eq_three"], 5), "algorithmic_bytes_per_launch": alg,
+                                        "sq_profile": sq_profile("k_eq_three_spec_tiled", True, local_strips * frames),
+                                        "sustained_clock_ghz": sustained_clock_ghz("k_eq_three_spec_tiled", True),
                                         "f64_valu": {"instructions_per_sample_contracted": ops_fc, "achieved_tops": round(ops_fc * local_strips * frames / sec / 1e12, 2), "peak_tops": F64_VALU_PEAK_TOPS,
                                                      "frac": round(ops_fc * local_strips * frames / sec / 1e12 / F64_VALU_PEAK_TOPS, 3)},
                                         "limiter": "f64 VALU issue, as the exact order: 51.5 VALU instructions per sample in the hot loop (exact: 63), 20 per warm-up sample (28)"}

@@ -6,9 +6,9 @@ import pathlib
 
 CSRC = pathlib.Path(__file__).resolve().parent.parent / "mixlab_amd" / "csrc"
 FAMILIES = {
-    "audio": ["mx_k_eq_exact.hip", "mx_k_eq_common.hpp", "mx_k_eq_three.hip", "mx_k_mixer.hip", "mx_k_envelope.hip", "mx_kernels.hpp"],
+    "audio": ["mx_k_eq_exact.hip", "mx_k_eq_common.hpp", "mx_env_math.hpp", "mx_k_eq_three.hip", "mx_k_mixer.hip", "mx_k_envelope.hip", "mx_kernels.hpp"],
     "video": ["mx_k_video.hip", "mx_video.hpp"],
-    "fir": ["mx_k_fir.hip"],
+    "fir": ["mx_k_fir.hip", "mx_env_math.hpp"],
 }
 
 

@@ -17,9 +17,9 @@ GROUPS = {   # bench.py's launch groups (what its hipEvents bracket)
     "mixer": ("k_mixer",),
     "video_scaler": ("k_scale_bicubic",),
     "video_chain": ("k_fade_chain",),
-    "video_batch": ("k_video_batch<2>",),
-    "fir": ("k_fir(",),
-    "resample": ("k_resample(", "k_resample<"),
+    "video_batch": ("k_video_batch<",),
+    "fir": ("k_fir(", "k_fir<"),
+    "resample": ("k_resample(", "k_resample<", "k_resample_ps<"),
 }
 
 

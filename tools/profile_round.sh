@@ -1,16 +1,16 @@
 #!/bin/bash
-# Collect what profiles/rNN/ holds, on the GPU box:  gpurun -- 'bash tools/profile_round.sh r03'
+# Collect what profiles/rNN/ holds, on the GPU box:  gpurun -- 'bash tools/profile_round.sh r04'
 # Every rocprofv3 pass is wrapped in its own `timeout`; PMC passes use --kernel-trace only (never the hip/hsa trace domains),
 # FETCH_SIZE and WRITE_SIZE in separate runs (MI355X_MICROARCH.md).  profiles/rNN/README.md is generated from these outputs
 # (tools/profile_readme.py), not written by hand.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-realtime --no-t-sweep --no-north-star --no-held-leg --no-material-leg --no-scaling-probe --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 0"
+COMMON="--no-cpu-baseline --no-realtime --no-t-sweep --no-north-star --no-held-leg --no-material-leg --no-contract-leg --no-scaling-probe --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 0"
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
 pmc() {   # pmc <tag> <counters...> -- <command...>: one counter pass, summary into $OUT/<tag>.txt, raw csv path echoed
   local tag=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
@@ -30,13 +30,23 @@ FCSV=$(pmc pmc_fetch FETCH_SIZE -- python $REPO/bench.py $COMMON)
 WCSV=$(pmc pmc_write WRITE_SIZE -- python $REPO/bench.py $COMMON)
 python $REPO/tools/pmc_traffic.py $FCSV $WCSV $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.md \
     '{"strips": 1024, "ticks_per_step": 2048, "sample_rate": 48000, "fused": true, "eq_fast": false, "n_gpus": 1, "gates_toggle": true}' audio
-# 4. SQ counters of the headline kernels, gates toggling and held
-pmc pmc_sq_toggle $SQ1 -- python $REPO/bench.py $COMMON > /dev/null
+# 3b. the same in the contracted order (MX_FLAG_FP_CONTRACT as the headline: --fp-contract)
+FCSV=$(pmc pmc_fetch_fc FETCH_SIZE -- python $REPO/bench.py $COMMON --fp-contract)
+WCSV=$(pmc pmc_write_fc WRITE_SIZE -- python $REPO/bench.py $COMMON --fp-contract)
+python $REPO/tools/pmc_traffic.py $FCSV $WCSV $OUT/pmc_traffic_fc.json $OUT/pmc_hbm_traffic_fc.md \
+    '{"strips": 1024, "ticks_per_step": 2048, "sample_rate": 48000, "fused": true, "eq_fast": false, "fp_contract": true, "n_gpus": 1, "gates_toggle": true}' audio
+# 3c. what FETCH_SIZE says on KNOWN byte counts in the EqThree kernel's read pattern (half lines vs whole lines; tools/fetch_probe.hip)
+( cd $REPO && bash tools/fetch_probe.sh 250 > /dev/null 2>&1 ); cp $REPO/gpurun_out/fetch_probe/times.txt $OUT/fetch_probe_times.txt; cp $REPO/gpurun_out/fetch_probe/counters.txt $OUT/fetch_probe_counters.txt
+# 4. SQ counters of the headline kernels, gates toggling and held, and in the contracted order
+SQCSV=$(pmc pmc_sq_toggle $SQ1 -- python $REPO/bench.py $COMMON); python $REPO/tools/pmc_sq_json.py $SQCSV $OUT/pmc_sq_toggle.json audio
 pmc pmc_sq_held $SQ1 -- python $REPO/bench.py $COMMON --hold-gates > /dev/null
+SQCSV=$(pmc pmc_sq_fc $SQ1 -- python $REPO/bench.py $COMMON --fp-contract); python $REPO/tools/pmc_sq_json.py $SQCSV $OUT/pmc_sq_fc.json audio
 # 5. the clock the chip sustains under the headline kernels: GRBM_GUI_ACTIVE (per XCD) / duration of the same dispatches
 CCSV=$(pmc pmc_clock GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -- python $REPO/bench.py $COMMON)
 cp $(find /tmp/p_pmc_clock -name "*kernel_trace.csv" | head -1) $OUT/pmc_clock_kernel_trace.csv 2>/dev/null
 python $REPO/tools/pmc_clock.py $CCSV $OUT/pmc_clock_kernel_trace.csv $OUT/clock.json
+CCSV=$(pmc pmc_clock_fc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -- python $REPO/bench.py $COMMON --fp-contract)
+python $REPO/tools/pmc_clock.py $CCSV $(find /tmp/p_pmc_clock_fc -name "*kernel_trace.csv" | head -1) $OUT/clock_fc.json
 # 6. config 4 (video leg alone): kernel times, SQ counters, traffic
 rm -rf /tmp/vk; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vk -- python $REPO/tools/vleg.py 3840 > $OUT/video_leg_line.json 2>/dev/null
 cp $(find /tmp/vk -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_video_leg.csv
