@@ -929,7 +929,7 @@ __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r
             double q3;
             if (grp_all(stands_still(x0, q3), g0)) {
                 const double hv = role < 3 ? (double)xin[role - 3] : x0;          // the four delay-line values in question: x[-3], x[-2], x[-1], x0
-                if (grp_all(!outs_differ(q3, hv), g0)) {
+                if (grp_all(!outs_differ(q3, hv), g0) && !(plan.pad & 1u)) {   // (plan.pad: MX_EQ_REPAIR_TEST, see launch_eq_three_spec)
                     if (konst) { ++w.settled; continue; }                         // E unchanged: the state stands still through the chunk
                     // where does the input change?  128 samples per round trip to memory: the four lanes take four samples each of eight steps
                     const uint32_t b0 = __float_as_uint(x0f);
@@ -1001,7 +1001,7 @@ __device__ __forceinline__ EqWalk eq_repair_walk(const EqDesc& d, const EqRun& r
                     double q3;
                     if (grp_all(stands_still(xc, q3), g0)) {                              // neither trajectory moves again in this chunk
                         i0 += EQ_RB;
-                        if (outs_differ(q3, xc)) {                                        // the same in all four lanes (every delay-line value from here on is xc)
+                        if (outs_differ(q3, xc) || (plan.pad & 1u)) {                     // the same in all four lanes (every delay-line value from here on is xc)
                             const double a_lo = shfl_f64(q3, g0), a_hi = shfl_f64(q3, g0 + 1);
                             const float yc = eq_out_of<FC>(a_lo, a_hi, xc, g_lo, g_mid, g_hi);
                             for (; i0 < len; i0 += EQ_RB) {
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
 #pragma unroll
             for (int k = 0; k < 8; ++k) El[k] = rc[h - 1].end[k];
             w = eq_repair_walk<FC>(d, r, plan, rc, inst, h, lim, 0u, El, lane, p3g);
-            in_sync = w.j_end == lim && same8(El, rc[lim - 1].end);
+            in_sync = w.j_end == lim && same8(El, rc[lim - 1].end) && !(plan.pad & 2u);
         }
         // the assumptions, in stream order
         uint32_t i = 0;
@@ -1264,6 +1264,11 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     if (!n || !r.frames) return;
     const uint32_t wpi = (plan.n_chunks + 63) / 64;
     EqChunkRec* recs = (EqChunkRec*)scratch;
+    // MX_EQ_REPAIR_TEST (tests only; never changes a result bit, only which path produces it): 1 = a standing pair of trajectories is treated as if its
+    // outputs differed (the comparison that settles a constant chunk is skipped, the rest of the chunk is FILLED from the true state); 2 = every island is
+    // treated as having ended apart from the speculative run (the in-order fallback that rewrites everything behind it).  Both paths are otherwise reached
+    // only by inputs whose f32 outputs differ between two states a few f64 ulps apart.
+    EqSpecPlan plan_t = plan; plan_t.pad = (uint32_t)env_int("MX_EQ_REPAIR_TEST", 0);
     static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
     const int um = uniform_mode;
     // 321 (default): whole 128-byte lines, ONE tile of 32 samples per row (8 KiB of LDS per wave); 16: half lines, two tiles (round 3's default:
@@ -1301,8 +1306,8 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
 #undef MX_GO
     }
     // the proof (and, where a boundary fails, the repair) runs the same order the chunks ran
-    if (r.fc) hipLaunchKernelGGL(k_eq_three_repair<true>, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
-    else hipLaunchKernelGGL(k_eq_three_repair<false>, dim3(n), dim3(64), 0, s, d, st, r, plan, (const EqChunkRec*)recs, (unsigned long long*)stats);
+    if (r.fc) hipLaunchKernelGGL(k_eq_three_repair<true>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats);
+    else hipLaunchKernelGGL(k_eq_three_repair<false>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats);
 }
 
 }  // namespace mx

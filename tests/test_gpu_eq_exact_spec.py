@@ -315,6 +315,45 @@ def test_spec_eq_inline_envelope_with_unusual_parameters_matches_the_oracle(env_
     assert g.eq_spec_stats()[0] > 0
 
 
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+def test_spec_eq_repair_paths_that_live_signals_never_take_still_give_the_sequential_order(mode, monkeypatch):
+    """Two paths of the repair pass are reached only when the f32 outputs of two standing states a few f64 ulps apart differ -- the FILL of a
+    constant chunk from the true state, and the in-order fallback (rewrite everything) behind an island that ended apart from the speculative
+    run.  MX_EQ_REPAIR_TEST forces them (1: fill, 2: every island ends apart, 3: both): they may only cost time, never a bit.  Programme with
+    silences, DC plateaus and a strip muted to the end, state carried over two runs, plain EQs and the folded Envelope + Amplifier."""
+    monkeypatch.setenv("MX_EQ_REPAIR_TEST", mode)
+    monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", "96")
+    test_spec_eq_programme_with_many_silences_islands_repaired_side_by_side("96", monkeypatch)
+    SR, SPT, T = 48000, 800, 240
+    ws = Workspace(SR, 60)
+    src = ws.source_mono(); eq = ws.eq_three(2.0, -1.0, 3.0); pan = ws.stereo_panner()
+    trig = ws.trigger(True); env = ws.envelope(5.0, 80.0, 0.6, 40.0); amp = ws.amplifier(0.9, 0.8)
+    ws.connect(src, 0, eq, 0); ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1); ws.connect(pan, 0, amp, 0); ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp, 1)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    # programme with a positive offset: both cascades reach every silence from ABOVE, where a lane that warmed up from zeros stands BELOW (two
+    # trajectories from the same side stall on the same value and prove themselves -- half of all silences of zero-mean programme do)
+    x = (np.float32(0.5) + np.float32(0.3) * synth.noise(950, 2 * T * SPT)).astype(np.float32)
+    x[20000:60000] = 0.0; x[120000:150000] = 0.0; x[150000:170000] = np.float32(0.25); x[180000:180003] = 0.0; x[250000:] = 0.0   # two islands far apart in run 0, one to the end in run 1
+    for run in range(2):
+        sl = slice(run * T * SPT, (run + 1) * T * SPT)
+        g.write_source(src, x[sl], T)
+        g.schedule_params(trig, 50, abi.TriggerParams(0)); g.schedule_params(trig, 130, abi.TriggerParams(1))
+        g.run_ticks(run * T, T)
+        got = g.read_output(amp, 0, T, True)
+        for t in range(T):
+            if t == 50: og.update_params(trig, abi.TriggerParams(0))
+            if t == 130: og.update_params(trig, abi.TriggerParams(1))
+            og.set_source(src, x[run * T * SPT + t * SPT: run * T * SPT + (t + 1) * SPT])
+            og.run_tick(run * T + t)
+            assert_bit_exact(got[t * 2 * SPT:(t + 1) * 2 * SPT], og.output(amp, 0), f"run {run} tick {t} (MX_EQ_REPAIR_TEST={mode})")
+    st = g.eq_repair_stats()
+    if mode in ("1", "3"):
+        assert st["fill_steps_16"] > 0, st
+    if mode in ("2", "3"):
+        assert st["in_order_walks"] > 0, st
+
+
 @pytest.mark.parametrize("sb", ["16", "32"])
 def test_spec_eq_other_tile_shapes_stay_bit_exact(sb, monkeypatch):
     """The tiled kernel's default moves WHOLE 128-byte lines through ONE tile per wave (MX_EQ_SPEC_SB=321); the two-tile shapes -- half lines

@@ -9,8 +9,9 @@ import oracle, synth
 from mixlab_amd import abi
 from test_gpu_audio_parity import strips
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+first = int(_pos[0]) if len(_pos) > 0 else 0
+count = int(_pos[1]) if len(_pos) > 1 else 100
 
 
 def run(seed):
@@ -25,6 +26,9 @@ def run(seed):
     flags = int(rng.choice([0, 0, abi.FLAG_NO_FUSE]))
     if "--fast" in sys.argv:
         flags |= abi.FLAG_EQ_FAST
+    if "--contract" in sys.argv:      # MX_FLAG_FP_CONTRACT against the oracle's contract mode: bit for bit, like the exact order
+        flags |= abi.FLAG_FP_CONTRACT
+        oracle.lib.orc_set_fp_contract(1)
     desc = f"seed {seed}: {SR} Hz, {n_strips} strips, batch {batch} x {n_runs}, gate period {period}, chunks {os.environ['MX_EQ_SPEC_CHUNKS']}, warm {os.environ['MX_EQ_SPEC_WARM']}, flags {flags}"
     ws, mix, srcs, trigs = strips(n_strips, SR)
     og = oracle.OracleGraph(ws)
