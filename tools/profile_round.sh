@@ -20,8 +20,6 @@ pmc() {   # pmc <tag> <counters...> -- <command...>: one counter pass, summary i
   [ -n "$f" ] && python $REPO/tools/pmc_summary.py $f > $OUT/$tag.txt
   echo $f
 }
-# 1. the default command, as the driver runs it
-timeout 900 python $REPO/bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 # 2. the same command under the kernel trace
 rm -rf /tmp/kt; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py > $OUT/bench_line_under_rocprof.json 2>/dev/null
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_default_bench.csv
@@ -62,5 +60,9 @@ pmc fir_sq2 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VM
 FF=$(pmc fir_fetch FETCH_SIZE -- python $REPO/tools/fleg.py 128 6)
 FW=$(pmc fir_write WRITE_SIZE -- python $REPO/tools/fleg.py 128 6)
 python $REPO/tools/pmc_traffic.py $FF $FW $OUT/fir_pmc_traffic.json $OUT/fir_pmc_hbm_traffic.md '{"leg": "fir_resample", "ticks_per_step": 128}' fir
+# 8. LAST: the default command, as the driver runs it -- with this round's counter summaries in place, so that the line's roofline.traffic / limiter /
+#    sustained clock are the ones just collected on these kernel sources (bench.py copies them only while the recorded source hash matches)
+mkdir -p $REPO/profiles/$R && cp $OUT/*.json $REPO/profiles/$R/ 2>/dev/null
+timeout 900 python $REPO/bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 python $REPO/tools/profile_readme.py $OUT $R > $OUT/README.md
 ls -la $OUT
