@@ -583,7 +583,7 @@ __device__ __forceinline__ EqK eq_constants(const EqDesc& d, const EqRun& r) {
 }
 
 // compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
-template <int SB, int MODE, int ENVK, bool WARM, bool FC>   // WARM: `len` is the (negative) chunk-relative index of the lane's first warm-up sample
+template <int SB, int MODE, int ENVK, bool WARM, bool FC, bool LO_ONLY = false>   // WARM: `len` is the (negative) chunk-relative index of the lane's first warm-up sample; LO_ONLY: the early part of a warm-up, where only the slow cascade runs
 __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const int lane, const int so, const int len,
                                                 const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     const double g_lo = K.g_lo, g_mid = K.g_mid, g_hi = K.g_hi, lo_f = K.lo_f, hi_f = K.hi_f;
@@ -602,7 +602,7 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
             const double dx[4] = {(double)x4[0], (double)x4[1], (double)x4[2], (double)x4[3]};
             if (WARM) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { pump<FC>(lo_f, s.lo, dx[e]); pump<FC>(hi_f, s.hi, dx[e]); }
+                for (int e = 0; e < 4; ++e) { pump<FC>(lo_f, s.lo, dx[e]); if (!LO_ONLY) pump<FC>(hi_f, s.hi, dx[e]); }
             } else {
                 const double hh[4] = {s.h0, s.h1, s.h2, dx[0]};
                 f4v v;
@@ -718,7 +718,20 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return eq_tiles + (g & 1) * EQ_TILE;
     };
+    // The two cascades are independent filters of one input (eq_three.rs:68-74) and forget at their own rates: the high one (2 700 Hz, p = 0.65 at 48 kHz) has
+    // coalesced after plan.warm_hi samples (eq_warm_len(hi_f): 256 where the low one, 420 Hz, needs 1 280), so a lane that speculates runs it over the LAST warm_hi
+    // samples of its window only -- 13 of the warm-up's 26 f64 operations per sample saved over four fifths of it.  A lane that warms up from the stream's start
+    // runs both from there (it starts from the exact carried state: nothing may be skipped); the wave's early, low-only super-blocks end where its first lane needs both.
+    const int hi_from = (active && from_start) ? warm_from : -(int)plan.warm_hi;
+    int hi_min = hi_from;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) hi_min = min(hi_min, __shfl_xor(hi_min, m, 64));
+    const int n_lo = max(0, min(n_warm, n_warm + (hi_min - (EQ_SB - 1)) / EQ_SB));   // super-blocks that end at or before hi_min (hi_min <= 0: C division rounds towards zero, hence the bias)
     int g = 0;
+    for (; g < n_lo; ++g) {
+        float* buf = begin_sb(g);
+        eq_tile_compute<SB, EQM_PLAIN, 0, true, FC, true>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
+    }
     for (; g < n_warm; ++g) {
         float* buf = begin_sb(g);
         eq_tile_compute<SB, EQM_PLAIN, 0, true, FC>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
@@ -1199,11 +1212,13 @@ static size_t eq_warm_len(double f) {
 }
 
 bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan) {
-    plan = EqSpecPlan{1u, 0u, 0u, 0u};
+    plan = EqSpecPlan{1u, 0u, 0u, 0u, 0u};
     if (!n || !frames) return false;
     size_t W = std::max(eq_warm_len(lo_f), eq_warm_len(hi_f));
+    size_t W_hi = eq_warm_len(hi_f) == (size_t)-1 ? W : (eq_warm_len(hi_f) + 31) / 32 * 32;   // the high cascade's own forgetting length (whole super-blocks)
     const int force_w = env_int("MX_EQ_SPEC_WARM", 0);       // tests: a short warm-up makes every boundary fail and the repair pass do all the work
-    if (force_w > 0) W = ((size_t)force_w + 15) / 16 * 16;
+    if (force_w > 0) { W = ((size_t)force_w + 15) / 16 * 16; W_hi = W; }
+    if (env_int("MX_EQ_SPEC_WARM_HI_FULL", 0)) W_hi = W;      // A/B: both cascades over the whole window (rounds 2 - 3)
     if (W == (size_t)-1) return false;
     const int force_c = env_int("MX_EQ_SPEC_CHUNKS", 0);     // tuning / tests: chunks per instance (1 = never speculate)
     if (force_c == 1) return false;
@@ -1247,7 +1262,7 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     if (best < 2) return false;
     size_t C = chunk_of(best);
     if (C < c_min) C = (c_min + unit - 1) / unit * unit;
-    plan.chunk = (uint32_t)C; plan.warm = (uint32_t)W;
+    plan.chunk = (uint32_t)C; plan.warm = (uint32_t)W; plan.warm_hi = (uint32_t)std::min(W, W_hi);
     plan.n_chunks = (uint32_t)((frames + C - 1) / C);
     return plan.n_chunks >= 2;
 }
