@@ -280,7 +280,11 @@ typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P =
                /* packed RGB, one plane (data[0]; data[1], data[2] NULL): scaler INPUTS only (a screen capture, an image file).  BUILD-SPECIFIED: the
                 * frame stands for the yuv444p frame of its per-pixel BT.709 limited-range conversion (DESIGN.md "Pixel formats"), which is then
                 * resampled like any 4:4:4 input -- libswscale's own RGB path is unknown here: parity unpinned, like the scaler */
-               MX_PIXFMT_RGB24 = 4 /* R, G, B bytes */, MX_PIXFMT_BGRA = 5 /* B, G, R, A bytes; alpha ignored */ } mx_pixfmt;
+               MX_PIXFMT_RGB24 = 4 /* R, G, B bytes */, MX_PIXFMT_BGRA = 5 /* B, G, R, A bytes; alpha ignored */,
+               /* the other planar 8-bit YUV layouts an AVPixelFormat descriptor can carry (pixfmt.rs:97-111: log2_chroma_w / log2_chroma_h of 0, 1 or 2): scaler
+                * inputs like yuv422p / yuv444p -- every plane resampled from its own size; width / height multiples of the subsampling */
+               MX_PIXFMT_YUV410P = 6 /* chroma 1/4 x 1/4 */, MX_PIXFMT_YUV411P = 7 /* chroma 1/4 x 1 */, MX_PIXFMT_YUV440P = 8 /* chroma 1 x 1/2 */,
+               MX_PIXFMT_GRAY8 = 9 /* one plane of luma: stands for the yuv444p frame with U = V = 0x80 (scaler input only, like packed RGB) */ } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer

@@ -69,7 +69,7 @@ int mx_dframe_create_fmt(uint32_t width, uint32_t height, mx_pixfmt fmt, void* s
     return guard([&] {
         REQUIRE(out, "out is NULL");
         *out = nullptr;
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_BGRA, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_GRAY8, "unknown pixel format");
         *out = H(DFrame::create(width, height, S(stream), (uint8_t)fmt));
     });
 }

@@ -100,7 +100,7 @@ static void alloc_planes(DFrame* f) {
 }
 
 DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
-    if (fmt > MX_PIXFMT_BGRA) throw Error(MX_ERR_INVALID, "unknown pixel format");
+    if (fmt > MX_PIXFMT_GRAY8) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
     f->fmt = fmt;
     if (w == 0 || h == 0 || (w & ((1u << f->cw()) - 1u)) || (h & ((1u << f->chs()) - 1u)))
@@ -441,7 +441,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     in_w_ = in_w; in_h_ = in_h; in_fmt_ = in_fmt;
     auto t = std::make_shared<ScaleTables>();
     t->in_w = in_w; t->in_h = in_h; t->out_w = out_w_; t->out_h = out_h_;
-    t->in_cw = in_fmt == MX_PIXFMT_YUV444P ? 0u : 1u; t->in_ch = (in_fmt == MX_PIXFMT_YUV420P || in_fmt == MX_PIXFMT_NV12) ? 1u : 0u;
+    t->in_cw = DFrame::fmt_cw(in_fmt); t->in_ch = DFrame::fmt_ch(in_fmt);
     const uint32_t src_w[2] = {in_w, in_w >> t->in_cw}, src_h[2] = {in_h, in_h >> t->in_ch};   // the planes of the input format
     t->geo = scaler_geometry(in_w, in_h, out_w_, out_h_);
     const ScaleGeometry& geo = t->geo;
@@ -526,15 +526,20 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
     queue_scale(a, s, in, target, tp);      // leaves with the other scales of this tick as one launch
 }
 
-// a packed RGB input is first turned into the yuv444p frame it stands for (build-specified conversion), into a frame nobody else holds
+// a packed RGB (or gray8) input is first turned into the yuv444p frame it stands for (build-specified conversion), into a frame nobody else holds
 FrameRef Scaler::planar_of(const FrameRef& in) {
     if (!in->packed()) return in;
     FrameRef out;
     for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
     if (!out) {
         if (rgb_pool_.size() >= 2 * (size_t)video_batch_ticks() + 2) rgb_pool_.erase(rgb_pool_.begin());
-        rgb_pool_.push_back(FrameRef(DFrame::create_unfilled(in->width, in->height, MX_PIXFMT_YUV444P), false));
+        // (created BLANK: a gray8 input only ever writes the luma plane, its chroma stays 0x80)
+        rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, MX_PIXFMT_YUV444P), false));
         out = rgb_pool_.back();
+    }
+    if (in->fmt == MX_PIXFMT_GRAY8) {   // luma as it is, U = V = 0x80 (what swscale's gray -> yuv gives; build-specified like the RGB matrix)
+        hip_check(hipMemcpy2DAsync(out->data[0], out->stride[0], in->data[0], in->stride[0], in->width, in->height, hipMemcpyDeviceToDevice, stream_), "hipMemcpy2DAsync(gray8)");
+        return out;
     }
     launch_rgb_to_yuv444(in->data[0], in->stride[0], in->width, in->height, in->bpp(), in->fmt == MX_PIXFMT_BGRA ? 2u : 0u, out->data, out->stride, stream_);
     return out;

@@ -207,10 +207,12 @@ struct DFrame {
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
-    bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA; }   // one plane of 3 / 4 bytes per pixel: a scaler input only
+    bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA || fmt == MX_PIXFMT_GRAY8; }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
     uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : 1u); }
-    uint32_t cw() const { return (fmt == MX_PIXFMT_YUV444P || packed()) ? 0u : 1u; }    // log2_chroma_w, pixfmt.rs:97-100
-    uint32_t chs() const { return (fmt == MX_PIXFMT_YUV420P || fmt == MX_PIXFMT_NV12) ? 1u : 0u; }   // log2_chroma_h, pixfmt.rs:102-105
+    static uint32_t fmt_cw(uint8_t f) { return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
+    static uint32_t fmt_ch(uint8_t f) { return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
+    uint32_t cw() const { return fmt_cw(fmt); }
+    uint32_t chs() const { return fmt_ch(fmt); }
     // nv12: the two chroma "planes" are the even / odd bytes of ONE stored plane (data[1]; data[2] aliases it): samples xstep bytes apart from xoff
     bool semi() const { return fmt == MX_PIXFMT_NV12; }
     uint32_t xstep(int p) const { return (semi() && p) ? 2u : 1u; }

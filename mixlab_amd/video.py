@@ -122,6 +122,7 @@ def _host_frame(planes, w, h):
 
 PIXFMT_YUV420P, PIXFMT_YUV422P, PIXFMT_YUV444P, PIXFMT_NV12 = 0, 1, 2, 3   # mx_pixfmt (nv12: plane 1 = interleaved U,V, no plane 2)
 PIXFMT_RGB24, PIXFMT_BGRA = 4, 5                                            # packed RGB, one plane: scaler inputs only
+PIXFMT_YUV410P, PIXFMT_YUV411P, PIXFMT_YUV440P, PIXFMT_GRAY8 = 6, 7, 8, 9    # chroma 1/4 x 1/4, 1/4 x 1, 1 x 1/2; one luma plane (stands for yuv444p with U = V = 0x80)
 
 
 class DFrame:
@@ -137,7 +138,8 @@ class DFrame:
         f = C.c_int()
         check(lib.mx_dframe_format(self._h, C.byref(f)))
         self.fmt = f.value
-        self.cw, self.ch = (0 if self.fmt == PIXFMT_YUV444P else 1), (1 if self.fmt in (PIXFMT_YUV420P, PIXFMT_NV12) else 0)
+        self.cw = 0 if self.fmt in (PIXFMT_YUV444P, PIXFMT_YUV440P) else (2 if self.fmt in (PIXFMT_YUV410P, PIXFMT_YUV411P) else 1)
+        self.ch = 1 if self.fmt in (PIXFMT_YUV420P, PIXFMT_NV12, PIXFMT_YUV440P) else (2 if self.fmt == PIXFMT_YUV410P else 0)
         w, h = C.c_uint32(), C.c_uint32()
         self._data = (C.c_void_p * 3)()
         self._stride = (C.c_int32 * 3)()
@@ -169,15 +171,17 @@ class DFrame:
     def upload_packed(self, pix):
         """packed RGB formats: pix (height, width, 3) rgb24 / (height, width, 4) bgra"""
         a = np.ascontiguousarray(pix, dtype=np.uint8)
-        assert self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA) and a.shape == (self.height, self.width, 3 if self.fmt == PIXFMT_RGB24 else 4)
+        if self.fmt == PIXFMT_GRAY8:
+            a = a.reshape(self.height, self.width, 1)
+        assert self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA, PIXFMT_GRAY8) and a.shape == (self.height, self.width, {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1}[self.fmt])
         plane = a.reshape(self.height, -1)
         hf = _host_frame([plane], self.width, self.height)
         check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
         return self
 
     def download(self):
-        if self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA):
-            bpp = 3 if self.fmt == PIXFMT_RGB24 else 4
+        if self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA, PIXFMT_GRAY8):
+            bpp = {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1}[self.fmt]
             plane = np.empty((self.height, self.width * bpp), np.uint8)
             hf = _host_frame([plane], self.width, self.height)
             check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))

@@ -162,8 +162,9 @@ typedef struct {
                                    formats a scaler INPUT may have (codec/src/ffmpeg/scale.rs:16-39 carries the input pixel format) */
 } orc_frame;
 /* chroma subsampling of a format (codec/src/ffmpeg/pixfmt.rs:97-105) */
-static inline uint32_t orc_fmt_cw(uint32_t fmt) { return fmt == 2 ? 0u : 1u; }
-static inline uint32_t orc_fmt_ch(uint32_t fmt) { return (fmt == 0 || fmt == 3) ? 1u : 0u; }
+/* fmt: 0 yuv420p, 1 yuv422p, 2 yuv444p, 3 nv12, (4, 5: packed RGB -- orc_packed_rgb_to_yuv444), 6 yuv410p, 7 yuv411p, 8 yuv440p */
+static inline uint32_t orc_fmt_cw(uint32_t fmt) { return (fmt == 2 || fmt == 8) ? 0u : ((fmt == 6 || fmt == 7) ? 2u : 1u); }
+static inline uint32_t orc_fmt_ch(uint32_t fmt) { return (fmt == 0 || fmt == 3 || fmt == 8) ? 1u : (fmt == 6 ? 2u : 0u); }
 
 /* codec/src/ffmpeg/frame.rs:76-138: Y=0x00, U=V=0x80 over stride*(h-1)+w bytes of each plane */
 void orc_frame_blank(orc_frame* f);

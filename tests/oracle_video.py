@@ -42,7 +42,7 @@ class HostFrame:
 
     def __init__(self, w, h, fmt=0):
         self.w, self.h, self.fmt = w, h, fmt
-        self.cw, self.ch = (0 if fmt == 2 else 1), (1 if fmt in (0, 3) else 0)
+        self.cw, self.ch = (0 if fmt in (2, 8) else (2 if fmt in (6, 7) else 1)), (1 if fmt in (0, 3, 8) else (2 if fmt == 6 else 0))
         if fmt == 3:
             self.planes = [np.zeros((h, align(w, 64)), np.uint8), np.zeros((h >> 1, align(w, 64)), np.uint8)]
         else:

@@ -39,7 +39,7 @@ def yuv_pattern(w: int, h: int, layer: int, seed: int = 0, fmt: int = 0):
     """SURVEY.md section 8d config 4 pattern, planar YUV (fmt 0 yuv420p, 1 yuv422p, 2 yuv444p): Y(x,y) = (x + 2y + 31*layer + LCG
     noise) mod 256, U/V alike at the format's chroma resolution.  Pure numpy -- bench.py and the tests' HostFrame.fill share it."""
     planes = []
-    cw, ch = (0 if fmt == 2 else 1), (1 if fmt == 0 else 0)
+    cw, ch = (0 if fmt in (2, 8) else (2 if fmt in (6, 7) else 1)), (1 if fmt in (0, 8) else (2 if fmt == 6 else 0))   # 6 yuv410p, 7 yuv411p, 8 yuv440p
     for p in range(3):
         hh, ww = h >> (ch if p else 0), w >> (cw if p else 0)
         yy, xx = np.mgrid[0:hh, 0:ww].astype(np.uint32)

@@ -104,6 +104,61 @@ def test_scaler_input_of_another_pixel_format_is_converted_plane_by_plane(geom, 
     assert_frame_equal(res, want, f"persistent scaler {geom} fmt {fmt}")
 
 
+@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV410P, video.PIXFMT_YUV411P, video.PIXFMT_YUV440P], ids=["yuv410p", "yuv411p", "yuv440p"])
+@pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((320, 180), (320, 180)), ((640, 480), (1920, 1080)), ((1920, 1080), (560, 350)), ((68, 36), (640, 640))])
+def test_scaler_inputs_with_quarter_and_vertical_only_chroma_subsampling(geom, fmt):
+    """The other planar 8-bit layouts an AVPixelFormat descriptor can describe (pixfmt.rs:97-111: log2_chroma_w / log2_chroma_h up to 2): yuv410p,
+    yuv411p, yuv440p as scaler inputs -- every plane resampled from ITS size into the yuv420p output (chroma upscaled up to 4x: the gather form
+    where the tiled one's window would not fit), stateless and through the persistent scaler, also at the output's own size."""
+    (iw, ih), (ow, oh) = geom
+    src = ov.HostFrame(iw, ih, fmt).fill(4, seed=2)
+    want = ov.HostFrame(ow, oh); ov.dynamic_scale(src, want)
+    dsrc = video.DFrame(iw, ih, fmt=fmt).upload(*src.visible())
+    for a, b in zip(dsrc.download(), src.visible()):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    out = video.DFrame(ow, oh)
+    video.scale(dsrc, out)
+    assert_frame_equal(out, want, f"scale {geom} fmt {fmt}")
+    res = video.Scaler(ow, oh).scale(dsrc)
+    assert res.device_planes()[0] != dsrc.device_planes()[0]
+    assert_frame_equal(res, want, f"persistent scaler {geom} fmt {fmt}")
+    with pytest.raises(abi.MxError):
+        video.DFrame(iw + 2, ih, fmt=video.PIXFMT_YUV410P)      # a quarter-width chroma plane needs a width that is a multiple of 4
+
+
+@pytest.mark.parametrize("src,dst", [((320, 180), (480, 270)), ((64, 64), (320, 180)), ((1280, 720), (560, 350)), ((320, 180), (320, 180)), ((321, 181), (320, 180))],
+                         ids=["up-1.5x", "pillarbox", "monitor-downscale", "same-size", "odd-size"])
+def test_gray8_scaler_input_stands_for_the_yuv444_frame_with_neutral_chroma(src, dst):
+    """gray8 (one luma plane, any size): BUILD-SPECIFIED as the yuv444p frame with U = V = 0x80, resampled like any 4:4:4 input -- the luma as the
+    oracle scales it, the chroma planes neutral wherever the picture is (flat stays flat: the taps sum to exactly 1) -- stateless, persistent
+    scaler (twice: its pooled 4:4:4 frame is reused) and as a VideoMixer input."""
+    rng = np.random.default_rng(src[0] * 11 + dst[0])
+    w, h = src
+    gray = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    d = video.DFrame(w, h, fmt=video.PIXFMT_GRAY8).upload_packed(gray)
+    assert np.array_equal(d.download()[0][..., 0], gray)
+    as444 = ov.HostFrame(w, h, 2)
+    as444.planes[0][:, :w] = gray; as444.planes[1][:, :w] = 0x80; as444.planes[2][:, :w] = 0x80
+    want = ov.HostFrame(*dst); ov.blank(want); ov.dynamic_scale(as444, want)
+    out = video.DFrame(*dst)
+    video.scale(d, out)
+    for p, (x, y) in enumerate(zip(out.download(), want.visible())):
+        assert np.array_equal(x, y), f"stateless scale, plane {p}"
+    assert (out.download()[1] == 0x80).all() and (out.download()[2] == 0x80).all()
+    sc = video.Scaler(*dst)
+    for _ in range(2):
+        res = sc.scale(d)
+        for p, (x, y) in enumerate(zip(res.download(), want.visible())):
+            assert np.array_equal(x, y), f"persistent scaler, plane {p}"
+    other = ov.HostFrame(*dst).fill(3, seed=5)
+    m = video.VideoMixer(a=0, b=1, fader=0.4)
+    om = ov.OracleVideoMixer(a=0, b=1, fader=0.4)
+    prog, _a, _b = m.run_tick(0, [(d, (1, 30), (0, 1)), (video.DFrame(*dst).upload(*other.visible()), (1, 30), (0, 1)), None, None])
+    want_prog = om.run_tick(0, [(as444, (1, 30), (0, 1)), (other, (1, 30), (0, 1)), None, None])
+    for p, (x, y) in enumerate(zip(prog.download(), want_prog.visible())):
+        assert np.array_equal(x, y), f"VideoMixer program, plane {p}"
+
+
 @pytest.mark.parametrize("geom", [((128, 6), (2, 220)), ((6, 128), (220, 2)), ((1920, 2), (64, 64))])
 def test_scaled_size_without_rows_or_columns_is_the_blank_letterbox(geom):
     """A picture so thin that its aligned scaled size is zero rows or columns: the reference would panic (sws_getContext returns NULL for a
