@@ -19,6 +19,8 @@ def size(rng, fmt, big):
         w = int(rng.choice([2, 4, 6, 64, 128, 130, 1920, 1280]))
     if rng.random() < 0.15:
         h = int(rng.choice([2, 4, 6, 64, 72, 1080, 720]))
+    if fmt in (6, 7, 8):                      # yuv410p / yuv411p / yuv440p: multiples of the quarter subsampling
+        w, h = max(4, w & ~3), max(4, h & ~3)
     return w, h
 
 
@@ -33,7 +35,7 @@ bad = 0
 scalers = {}
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    fmt = int(rng.choice([0, 0, 1, 2, 3]))
+    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8]))
     big = rng.random() < 0.15
     (iw, ih), (ow, oh) = size(rng, fmt, big), size(rng, 0, big)
     what = f"seed {seed}: {iw}x{ih} fmt {fmt} -> {ow}x{oh}"
