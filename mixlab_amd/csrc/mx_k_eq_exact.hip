@@ -1286,11 +1286,14 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     EqSpecPlan plan_t = plan; plan_t.pad = (uint32_t)env_int("MX_EQ_REPAIR_TEST", 0);
     static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
     const int um = uniform_mode;
-    // 321 (default): whole 128-byte lines, ONE tile of 32 samples per row (8 KiB of LDS per wave); 16: half lines, two tiles (round 3's default:
+    // 321: whole 128-byte lines, ONE tile of 32 samples per row (8 KiB of LDS per wave); 16: half lines, two tiles (round 3's default:
     // 1.44x the source bytes on the fabric, tools/fetch_probe.hip); 32: whole lines, two tiles (16 KiB: ten waves per CU).  Measured, 1024 strips x
     // 2048 ticks: 4.46 / 4.56 ms exact, 3.85 / 4.09 ms contracted (321 / 16).  A/B knob; the contracted order is compiled for 321 and 16.
-    const int sb_env = env_int("MX_EQ_SPEC_SB", 321);
-    const int sb = (!r.fc && sb_env == 32) ? 32 : (sb_env == 16 ? 16 : 321);   // samples per lane per super-block (16: 8 KiB of LDS per wave; measured 3 - 12 % faster than 32)
+    // Unset: ONE tile while three or four waves share a SIMD (they hide each other's tile round trips and a second tile would cost a wave), TWO where at most two do
+    // (short submissions: a wave alone on its SIMD waits out every round trip itself; 1024 strips x 64 ticks 0.294 -> 0.276 ms, x 128 ticks 0.470 -> 0.458 ms).
+    const int sb_env = env_int("MX_EQ_SPEC_SB", 0);
+    const int sb_auto = (size_t)n * wpi <= 2048 ? (r.fc ? 16 : 32) : 321;
+    const int sb = sb_env == 0 ? sb_auto : (!r.fc && sb_env == 32) ? 32 : (sb_env == 16 ? 16 : 321);   // samples per lane per super-block
     const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
                        r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
     if (tiled) {

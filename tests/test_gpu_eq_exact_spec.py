@@ -354,10 +354,11 @@ def test_spec_eq_repair_paths_that_live_signals_never_take_still_give_the_sequen
         assert st["in_order_walks"] > 0, st
 
 
-@pytest.mark.parametrize("sb", ["16", "32"])
-def test_spec_eq_other_tile_shapes_stay_bit_exact(sb, monkeypatch):
-    """The tiled kernel's default moves WHOLE 128-byte lines through ONE tile per wave (MX_EQ_SPEC_SB=321); the two-tile shapes -- half lines
-    (16, round 3's default) and whole lines (32) -- stay compiled as A/B knobs and stay bit-exact."""
+@pytest.mark.parametrize("sb", ["16", "32", "321"])
+def test_spec_eq_every_tile_shape_is_bit_exact(sb, monkeypatch):
+    """The tiled kernel moves WHOLE 128-byte lines through ONE tile per wave (MX_EQ_SPEC_SB=321) where three or four waves share a SIMD -- the
+    benchmarked shape, test_gpu_full_size.py -- and through TWO tiles (32) where at most two do, which is every small graph of this suite; half
+    lines through two tiles (16, round 3's default) is the contracted order's two-tile shape.  Each forced here over the same graphs."""
     monkeypatch.setenv("MX_EQ_SPEC_SB", sb)
     test_spec_eq_every_fused_epilogue_matches_the_oracle_graph((48000, 800))
     test_spec_eq_bit_exact_on_live_and_stalling_inputs_state_carried((48000, 800), 0, monkeypatch)
