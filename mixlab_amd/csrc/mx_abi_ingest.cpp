@@ -226,14 +226,14 @@ int mx_frame_stager_upload(mx_frame_stager* st, const mx_frame* host, mx_pixfmt 
     return guard([&] {
         REQUIRE(st && host && out, "NULL argument");
         *out = nullptr;
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_GRAY8, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)mx::DFrame::kLastFmt, "unknown pixel format");
         *out = H(st->st.upload(host->width, host->height, (uint8_t)fmt, host->data, host->stride));
     });
 }
 int mx_frame_stager_acquire(mx_frame_stager* st, uint32_t width, uint32_t height, mx_pixfmt fmt, mx_frame* host, uint32_t* ticket) {
     return guard([&] {
         REQUIRE(st && host && ticket, "NULL argument");
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_GRAY8, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)mx::DFrame::kLastFmt, "unknown pixel format");
         *ticket = 0;
         std::memset(host, 0, sizeof *host);
         host->dur_den = 1; host->off_den = 1;

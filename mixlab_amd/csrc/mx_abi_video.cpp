@@ -69,7 +69,7 @@ int mx_dframe_create_fmt(uint32_t width, uint32_t height, mx_pixfmt fmt, void* s
     return guard([&] {
         REQUIRE(out, "out is NULL");
         *out = nullptr;
-        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)MX_PIXFMT_GRAY8, "unknown pixel format");
+        REQUIRE((int)fmt >= 0 && (int)fmt <= (int)mx::DFrame::kLastFmt, "unknown pixel format");
         *out = H(DFrame::create(width, height, S(stream), (uint8_t)fmt));
     });
 }
@@ -129,7 +129,7 @@ int mx_video_blank(mx_dframe* f, void* stream) {
     return guard([&] {
         REQUIRE(f, "frame is NULL");
         DFrame* d = D(f);
-        mx::launch_blank(d->data[0], d->plane_bytes[0], d->data[1], d->plane_bytes[1], d->data[2], d->plane_bytes[2], S(stream));
+        mx::launch_blank(d->data[0], d->plane_bytes[0], d->data[1], d->plane_bytes[1], d->data[2], d->plane_bytes[2], S(stream), d->blank_chroma());
         mx::hip_check(hipGetLastError(), "blank launch");
     });
 }

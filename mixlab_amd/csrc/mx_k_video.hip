@@ -666,20 +666,20 @@ void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
 }
 
 // Blank fill (codec/src/ffmpeg/frame.rs:76-138): Y = 0, U = V = 0x80 over the whole allocation of each plane.
-__global__ __launch_bounds__(256) void k_blank(uint8_t* y, size_t y_bytes, uint8_t* u, size_t u_bytes, uint8_t* v, size_t v_bytes) {
+__global__ __launch_bounds__(256) void k_blank(uint8_t* y, size_t y_bytes, uint8_t* u, size_t u_bytes, uint8_t* v, size_t v_bytes, uint32_t cfill) {
     const size_t yq = y_bytes / 16, uq = u_bytes / 16, vq = v_bytes / 16;
-    const uint4 zy = make_uint4(0, 0, 0, 0), zc = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    const uint4 zy = make_uint4(0, 0, 0, 0), zc = make_uint4(cfill, cfill, cfill, cfill);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < yq + uq + vq; i += (size_t)gridDim.x * 256) {
         if (i < yq) reinterpret_cast<uint4*>(y)[i] = zy;
         else if (i < yq + uq) reinterpret_cast<uint4*>(u)[i - yq] = zc;
         else reinterpret_cast<uint4*>(v)[i - yq - uq] = zc;
     }
 }
-void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s) {
+void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s, uint32_t cfill) {
     flush_scales(s);
     const size_t q = (yb + ub + vb) / 16;
     if (!q) return;
-    hipLaunchKernelGGL(k_blank, dim3(grid_x(q, 256, 2048)), dim3(256), 0, s, y, yb, u, ub, v, vb);
+    hipLaunchKernelGGL(k_blank, dim3(grid_x(q, 256, 2048)), dim3(256), 0, s, y, yb, u, ub, v, vb, cfill);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1264,6 +1264,27 @@ void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, u
     flush_scales(s);
     if (!w || !h) return;
     hipLaunchKernelGGL(k_rgb_to_yuv444, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w, h, bpp, r_off, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2]);
+}
+// 10-bit samples in 16-bit words -> the 8-bit frame of the same layout (BUILD-SPECIFIED, include/mixlab_gpu.h mx_pixfmt): min(255, (v + 2) >> 2) with
+// v = (word >> shift) & 1023.  Four samples per lane, all three planes in one launch (blockIdx.z); an ingest format conversion like the RGB one.
+__global__ __launch_bounds__(256) void k_deep_to_8(DeepArgs a) {
+    const uint32_t p = blockIdx.z;
+    const uint32_t x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= a.w[p] || y >= a.h[p]) return;
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(a.src[p] + (size_t)y * a.src_stride[p]) + a.xoff[p];
+    uint8_t* out = a.dst[p] + (size_t)y * a.dst_stride[p] + x4;
+    const uint32_t n = min(4u, a.w[p] - x4);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t v = ((uint32_t)row[(size_t)(x4 + k) * a.xstep[p]] >> a.shift) & 1023u;
+        out[k] = (uint8_t)min(255u, (v + 2u) >> 2);
+    }
+}
+void launch_deep_to_8(const DeepArgs& a, hipStream_t s) {
+    flush_scales(s);
+    uint32_t w = 0, h = 0;
+    for (int p = 0; p < 3; ++p) { w = std::max(w, a.w[p]); h = std::max(h, a.h[p]); }
+    if (!w || !h) return;
+    hipLaunchKernelGGL(k_deep_to_8, dim3((w + 255) / 256, (h + 3) / 4, 3), dim3(256), 0, s, a);
 }
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s) {
     flush_scales(s);

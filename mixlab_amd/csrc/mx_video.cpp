@@ -100,7 +100,7 @@ static void alloc_planes(DFrame* f) {
 }
 
 DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
-    if (fmt > MX_PIXFMT_GRAY8) throw Error(MX_ERR_INVALID, "unknown pixel format");
+    if (fmt > DFrame::kLastFmt) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
     f->fmt = fmt;
     if (w == 0 || h == 0 || (w & ((1u << f->cw()) - 1u)) || (h & ((1u << f->chs()) - 1u)))
@@ -113,7 +113,7 @@ DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
 
 DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
     std::unique_ptr<DFrame> f(create_unfilled(w, h, fmt));
-    launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s);
+    launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s, f->blank_chroma());
     return f.release();
 }
 
@@ -526,16 +526,28 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
     queue_scale(a, s, in, target, tp);      // leaves with the other scales of this tick as one launch
 }
 
-// a packed RGB (or gray8) input is first turned into the yuv444p frame it stands for (build-specified conversion), into a frame nobody else holds
+// a packed RGB (or gray8) input is first turned into the yuv444p frame it stands for, a 10-bit one into the 8-bit frame of its layout (build-specified
+// conversions), into a frame nobody else holds
 FrameRef Scaler::planar_of(const FrameRef& in) {
-    if (!in->packed()) return in;
+    if (!in->packed() && !in->deep()) return in;
+    const uint8_t as_fmt = in->deep() ? DFrame::shallow_of(in->fmt) : (uint8_t)MX_PIXFMT_YUV444P;
     FrameRef out;
-    for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
+    for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->fmt == as_fmt && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
     if (!out) {
         if (rgb_pool_.size() >= 2 * (size_t)video_batch_ticks() + 2) rgb_pool_.erase(rgb_pool_.begin());
         // (created BLANK: a gray8 input only ever writes the luma plane, its chroma stays 0x80)
-        rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, MX_PIXFMT_YUV444P), false));
+        rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, as_fmt), false));
         out = rgb_pool_.back();
+    }
+    if (in->deep()) {
+        DeepArgs a{};
+        for (int p = 0; p < 3; ++p) {
+            a.src[p] = in->data[p]; a.dst[p] = out->data[p]; a.src_stride[p] = in->stride[p]; a.dst_stride[p] = out->stride[p];
+            a.w[p] = out->pw(p); a.h[p] = out->ph(p); a.xstep[p] = in->xstep(p); a.xoff[p] = in->xoff(p);
+        }
+        a.shift = in->fmt == MX_PIXFMT_P010 ? 6u : 0u;
+        launch_deep_to_8(a, stream_);
+        return out;
     }
     if (in->fmt == MX_PIXFMT_GRAY8) {   // luma as it is, U = V = 0x80 (what swscale's gray -> yuv gives; build-specified like the RGB matrix)
         hip_check(hipMemcpy2DAsync(out->data[0], out->stride[0], in->data[0], in->stride[0], in->width, in->height, hipMemcpyDeviceToDevice, stream_), "hipMemcpy2DAsync(gray8)");
@@ -549,6 +561,7 @@ FrameRef Scaler::scale(const FrameRef& in0, bool may_defer) {
     if (in0->width == out_w_ && in0->height == out_h_ && in0->fmt == MX_PIXFMT_YUV420P) return in0;   // equal picture settings, encode.rs:342-345
     in0->ensure_pixels(stream_);                                                 // a symbolic frame must exist before it can be resampled
     const FrameRef in = planar_of(in0);
+    if (in.f != in0.f && in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;   // a 10-bit 4:2:0 picture of the output's size: its 8-bit frame is the result
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);   // encode.rs:347-384
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
     ring_pos_ = (ring_pos_ + 1) % (uint32_t)ring_.size(); frame_ = ring_[ring_pos_];   // not a frame the last 2K - 1 calls wrote: the RGBA chains that read those may be launched AFTER this scale (Graph defers them)
@@ -565,6 +578,7 @@ FrameRef Scaler::scale_keep(const FrameRef& in0) {
     if (in0->width == out_w_ && in0->height == out_h_ && in0->fmt == MX_PIXFMT_YUV420P) { in0->ensure_pixels(stream_); return in0; }
     in0->ensure_pixels(stream_);
     const FrameRef in = planar_of(in0);
+    if (in.f != in0.f && in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);
     FrameRef out;
     for (auto& f : keep_pool_) if (f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }   // only the pool holds it

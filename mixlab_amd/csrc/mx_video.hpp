@@ -123,7 +123,7 @@ void video_stream_retired(hipStream_t s);   // the stream is going away: free wh
 uint32_t video_batch_ticks();
 void launch_fade_chain(const ChainArgs& a, hipStream_t s);
 void launch_fade_chain_rgba(const ChainRgbaArgs& a, hipStream_t s);
-void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s);
+void launch_blank(uint8_t* y, size_t yb, uint8_t* u, size_t ub, uint8_t* v, size_t vb, hipStream_t s, uint32_t cfill = 0x80808080u);   // cfill: the chroma planes' 32-bit fill pattern
 void launch_scale_bicubic(const ScaleArgs& a, hipStream_t s);
 void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s);
 // deferred scaling: Scaler::scale queues its planes per stream; every reader of frame pixels flushes first
@@ -138,6 +138,10 @@ struct GatherArgs { const uint4* src[224]; uint4* dst; uint32_t q_per_frame, n; 
 void launch_gather_frames(const GatherArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
 // packed RGB (rgb24: bpp 3, r_off 0; bgra: bpp 4, r_off 2) -> yuv444p planes, BUILD-SPECIFIED BT.709 limited range (DESIGN.md "Pixel formats")
+struct DeepArgs {   // per plane: source words xstep apart from word xoff of a row, w x h samples
+    const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], w[3], h[3], xstep[3], xoff[3]; uint32_t shift;
+};
+void launch_deep_to_8(const DeepArgs& a, hipStream_t s);
 void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
 
 // ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----
@@ -207,18 +211,24 @@ struct DFrame {
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
+    static constexpr uint8_t kLastFmt = MX_PIXFMT_P010;
+    // 10-bit samples in 16-bit words: a scaler input only, turned into the 8-bit frame of the same layout it stands for (Scaler::planar_of)
+    bool deep() const { return fmt >= MX_PIXFMT_YUV420P10 && fmt <= MX_PIXFMT_P010; }
+    uint32_t bps() const { return deep() ? 2u : 1u; }                       // bytes per stored sample
+    uint32_t blank_chroma() const { return !deep() ? 0x80808080u : (fmt == MX_PIXFMT_P010 ? 0x80008000u : 0x02000200u); }   // mid-scale chroma as the format stores it
+    static uint8_t shallow_of(uint8_t f) { return f == MX_PIXFMT_YUV422P10 ? MX_PIXFMT_YUV422P : (f == MX_PIXFMT_YUV444P10 ? MX_PIXFMT_YUV444P : MX_PIXFMT_YUV420P); }
     bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA || fmt == MX_PIXFMT_GRAY8; }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
     uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : 1u); }
-    static uint32_t fmt_cw(uint8_t f) { return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
-    static uint32_t fmt_ch(uint8_t f) { return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
+    static uint32_t fmt_cw(uint8_t f) { return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV444P10 || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
+    static uint32_t fmt_ch(uint8_t f) { return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_YUV420P10 || f == MX_PIXFMT_P010) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
     uint32_t cw() const { return fmt_cw(fmt); }
     uint32_t chs() const { return fmt_ch(fmt); }
     // nv12: the two chroma "planes" are the even / odd bytes of ONE stored plane (data[1]; data[2] aliases it): samples xstep bytes apart from xoff
-    bool semi() const { return fmt == MX_PIXFMT_NV12; }
+    bool semi() const { return fmt == MX_PIXFMT_NV12 || fmt == MX_PIXFMT_P010; }
     uint32_t xstep(int p) const { return (semi() && p) ? 2u : 1u; }
     uint32_t xoff(int p) const { return (semi() && p == 2) ? 1u : 0u; }
     int stored_planes() const { return packed() ? 1 : (semi() ? 2 : 3); }
-    uint32_t stored_row_bytes(int p) const { return packed() ? width * bpp() : ((semi() && p == 1) ? width : pw(p)); }
+    uint32_t stored_row_bytes(int p) const { return packed() ? width * bpp() : ((semi() && p == 1) ? width : pw(p)) * bps(); }
     uint8_t* data[3] = {nullptr, nullptr, nullptr};
     uint32_t stride[3] = {0, 0, 0};
     size_t plane_bytes[3] = {0, 0, 0};

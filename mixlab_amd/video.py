@@ -125,6 +125,10 @@ PIXFMT_RGB24, PIXFMT_BGRA = 4, 5                                            # pa
 PIXFMT_YUV410P, PIXFMT_YUV411P, PIXFMT_YUV440P, PIXFMT_GRAY8 = 6, 7, 8, 9    # chroma 1/4 x 1/4, 1/4 x 1, 1 x 1/2; one luma plane (stands for yuv444p with U = V = 0x80)
 
 
+PIXFMT_YUV420P10, PIXFMT_YUV422P10, PIXFMT_YUV444P10, PIXFMT_P010 = 10, 11, 12, 13   # 10-bit samples in 16-bit LE words (p010: semi-planar, value in the high bits): scaler inputs only
+_DEEP = (PIXFMT_YUV420P10, PIXFMT_YUV422P10, PIXFMT_YUV444P10, PIXFMT_P010)
+
+
 class DFrame:
     """Device-resident planar YUV frame (one reference owned by this object); yuv420p unless `fmt` says otherwise."""
 
@@ -138,8 +142,8 @@ class DFrame:
         f = C.c_int()
         check(lib.mx_dframe_format(self._h, C.byref(f)))
         self.fmt = f.value
-        self.cw = 0 if self.fmt in (PIXFMT_YUV444P, PIXFMT_YUV440P) else (2 if self.fmt in (PIXFMT_YUV410P, PIXFMT_YUV411P) else 1)
-        self.ch = 1 if self.fmt in (PIXFMT_YUV420P, PIXFMT_NV12, PIXFMT_YUV440P) else (2 if self.fmt == PIXFMT_YUV410P else 0)
+        self.cw = 0 if self.fmt in (PIXFMT_YUV444P, PIXFMT_YUV440P, PIXFMT_YUV444P10) else (2 if self.fmt in (PIXFMT_YUV410P, PIXFMT_YUV411P) else 1)
+        self.ch = 1 if self.fmt in (PIXFMT_YUV420P, PIXFMT_NV12, PIXFMT_YUV440P, PIXFMT_YUV420P10, PIXFMT_P010) else (2 if self.fmt == PIXFMT_YUV410P else 0)
         w, h = C.c_uint32(), C.c_uint32()
         self._data = (C.c_void_p * 3)()
         self._stride = (C.c_int32 * 3)()
@@ -163,7 +167,11 @@ class DFrame:
 
     def upload(self, y, u, v=None):
         """planar formats: (y, u, v); nv12: (y, uv) with uv the interleaved chroma rows of `width` bytes"""
-        planes = [np.ascontiguousarray(a, dtype=np.uint8) for a in ((y, u) if self.fmt == PIXFMT_NV12 else (y, u, v))]
+        semi = self.fmt in (PIXFMT_NV12, PIXFMT_P010)
+        if self.fmt in _DEEP:   # 16-bit little-endian words, handed over as rows of bytes
+            planes = [np.ascontiguousarray(a, dtype="<u2").view(np.uint8) for a in ((y, u) if semi else (y, u, v))]
+        else:
+            planes = [np.ascontiguousarray(a, dtype=np.uint8) for a in ((y, u) if semi else (y, u, v))]
         hf = _host_frame(planes, self.width, self.height)
         check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
         return self
@@ -186,13 +194,14 @@ class DFrame:
             hf = _host_frame([plane], self.width, self.height)
             check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
             return [plane.reshape(self.height, self.width, bpp)]
-        if self.fmt == PIXFMT_NV12:
-            planes = [np.empty((self.height, self.width), np.uint8), np.empty((self.height >> 1, self.width), np.uint8)]
+        bps = 2 if self.fmt in _DEEP else 1
+        if self.fmt in (PIXFMT_NV12, PIXFMT_P010):
+            planes = [np.empty((self.height, self.width * bps), np.uint8), np.empty((self.height >> 1, self.width * bps), np.uint8)]
         else:
-            planes = [np.empty((self.height >> (self.ch if p else 0), self.width >> (self.cw if p else 0)), np.uint8) for p in range(3)]
+            planes = [np.empty((self.height >> (self.ch if p else 0), (self.width >> (self.cw if p else 0)) * bps), np.uint8) for p in range(3)]
         hf = _host_frame(planes, self.width, self.height)
         check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
-        return planes
+        return [a.view("<u2") for a in planes] if bps == 2 else planes
 
     def device_planes(self):
         return [self._data[p] for p in range(3)], [self._stride[p] for p in range(3)]

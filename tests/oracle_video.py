@@ -27,6 +27,7 @@ lib.orc_dynamic_scale.argtypes = [C.POINTER(OFrame), C.POINTER(OFrame)]
 lib.orc_scaler_geometry.argtypes = [C.c_uint32] * 4 + [C.POINTER(ScaleGeometry)]
 lib.orc_unify_picture_settings.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
 lib.orc_yuv420_to_rgba.argtypes = [C.POINTER(OFrame), C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+lib.orc_deep_to_8.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OFrame)]
 lib.orc_packed_rgb_to_yuv444.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OFrame)]
 lib.orc_bicubic_tap_count.argtypes = [C.c_uint32, C.c_uint32]
 lib.orc_bicubic_tap_count.restype = C.c_uint32
@@ -91,6 +92,17 @@ def packed_rgb_to_yuv444(pix: np.ndarray, fmt: int) -> HostFrame:
     h, w, bpp = a.shape
     out = HostFrame(w, h, 2)
     lib.orc_packed_rgb_to_yuv444(a.ctypes.data_as(C.c_void_p), w * bpp, w, h, fmt, C.byref(out.c))
+    return out
+
+
+def deep_to_8(planes, w: int, h: int, fmt: int) -> HostFrame:
+    """planes: uint16 arrays (little-endian words) of a 10-bit frame -- fmt 10 / 11 / 12: (y, u, v); 13 (p010): (y, uv) with uv rows of `w` words --
+    -> the 8-bit frame (fmt 0 / 1 / 2 / 0) a scaler input of that format stands for"""
+    arrs = [np.ascontiguousarray(a, dtype="<u2") for a in planes]
+    out = HostFrame(w, h, {10: 0, 11: 1, 12: 2, 13: 0}[fmt])
+    ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs], *([None] * (3 - len(arrs))))
+    strides = (C.c_int32 * 3)(*[a.strides[0] for a in arrs], *([0] * (3 - len(arrs))))
+    lib.orc_deep_to_8(ptrs, strides, w, h, fmt, C.byref(out.c))
     return out
 
 

@@ -314,6 +314,30 @@ def test_product_scaler_taps_equal_the_exact_rational_spec():
         assert got == g["coef"], f"product coefficients {g['src']} -> {g['dst']}"
 
 
+def test_oracle_ten_bit_conversion_is_round_to_nearest_with_the_ignored_bits_ignored():
+    """orc_deep_to_8 against the rule stated in include/mixlab_gpu.h, on every 10-bit value: min(255, floor(v / 4 + 1/2)) in exact integers, the same
+    whatever sits in the six bits a format ignores, p010's chroma de-interleaved."""
+    import oracle_video as ov
+    vals = np.arange(1024, dtype=np.uint16)
+    want = np.minimum(255, (2 * vals.astype(np.int64) + 4) // 8).astype(np.uint8)       # floor(v/4 + 1/2)
+    assert want[1] == 0 and want[2] == 1 and want[1021] == 255 and want[1018] == 255 and want[1017] == 254
+    w, h = 64, 32
+    y = np.resize(vals, (h, w))
+    for fmt, cw, ch in ((10, 1, 1), (11, 1, 0), (12, 0, 0)):
+        u = np.resize(vals[::-1], (h >> ch, w >> cw)); v = np.resize(vals[3:], (h >> ch, w >> cw))
+        for junk in (0, 0xFC00, 0x5400):
+            f = ov.deep_to_8([y | junk, u | junk, v | junk], w, h, fmt)
+            for got, src in zip(f.visible(), (y, u, v)):
+                assert np.array_equal(got, want[src])
+    u = np.resize(vals[::-1], (h // 2, w // 2)); v = np.resize(vals[5:], (h // 2, w // 2))
+    uv = np.empty((h // 2, w), np.uint16); uv[:, 0::2] = u; uv[:, 1::2] = v
+    for junk in (0, 0x3F, 0x2A):
+        f = ov.deep_to_8([(y << 6) | junk, (uv << 6) | junk], w, h, 13)
+        assert f.fmt == 0
+        for got, src in zip(f.visible(), (y, u, v)):
+            assert np.array_equal(got, want[src])
+
+
 def test_oracle_packed_rgb_conversion_equals_the_exact_rational_matrix():
     """The build-specified packed RGB -> yuv444 conversion (what an rgb24 / bgra scaler input stands for): the oracle's hard-coded integers
     against tests/golden/rgb_matrix_bt709.json, which make_rgb_matrix.py derives from the BT.709 primaries with exact rationals."""

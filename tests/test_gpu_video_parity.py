@@ -126,6 +126,61 @@ def test_scaler_inputs_with_quarter_and_vertical_only_chroma_subsampling(geom, f
         video.DFrame(iw + 2, ih, fmt=video.PIXFMT_YUV410P)      # a quarter-width chroma plane needs a width that is a multiple of 4
 
 
+def _ten_bit_planes(rng, w, h, fmt):
+    """random 10-bit planes with the edge values in, and garbage in the bits the format says are ignored"""
+    cw = 0 if fmt == video.PIXFMT_YUV444P10 else 1
+    ch = 1 if fmt in (video.PIXFMT_YUV420P10, video.PIXFMT_P010) else 0
+    def plane(ph, pw):
+        v = rng.integers(0, 1024, size=(ph, pw), dtype=np.uint16)
+        v.flat[:12] = [0, 1, 2, 3, 5, 6, 1018, 1019, 1020, 1021, 1022, 1023]
+        junk = rng.integers(0, 64, size=(ph, pw), dtype=np.uint16)
+        return ((v << 6) | junk) if fmt == video.PIXFMT_P010 else (v | (junk << 10))
+    y, u, v = plane(h, w), plane(h >> ch, w >> cw), plane(h >> ch, w >> cw)
+    if fmt == video.PIXFMT_P010:
+        uv = np.empty((h >> 1, w), np.uint16); uv[:, 0::2] = u; uv[:, 1::2] = v
+        return [y, uv]
+    return [y, u, v]
+
+
+@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV420P10, video.PIXFMT_YUV422P10, video.PIXFMT_YUV444P10, video.PIXFMT_P010], ids=["yuv420p10", "yuv422p10", "yuv444p10", "p010"])
+@pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((320, 180), (320, 180)), ((1920, 1080), (560, 350)), ((66, 38), (640, 640)), ((3840, 2160), (1920, 1080))],
+                         ids=["720p-up", "same-size", "monitor-downscale", "tiny-pillarbox", "2160p-down"])
+def test_ten_bit_scaler_inputs_stand_for_the_8_bit_frame_of_their_layout(geom, fmt):
+    """10-bit YUV in 16-bit little-endian words (what a decoder of a 10-bit stream delivers; pixfmt.rs:107-111 reads the depth off the descriptor):
+    BUILD-SPECIFIED as the 8-bit frame of the same layout with samples min(255, (v + 2) >> 2) -- the ignored bits of a word really ignored, 1022 and 1023
+    clipped, p010's value in the high bits and its chroma de-interleaved -- which is then resampled like any 8-bit input: stateless, through the persistent
+    scaler (twice: its pooled 8-bit frame is reused), at the output's own size (4:2:0: the converted frame IS the result) and as a VideoMixer input."""
+    (iw, ih), (ow, oh) = geom
+    rng = np.random.default_rng(iw * 7 + ow + fmt)
+    planes = _ten_bit_planes(rng, iw, ih, fmt)
+    d = video.DFrame(iw, ih, fmt=fmt).upload(*planes)
+    for a, b in zip(d.download(), planes):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    as8 = ov.deep_to_8(planes, iw, ih, fmt)
+    want = ov.HostFrame(ow, oh); ov.blank(want); ov.dynamic_scale(as8, want)
+    out = video.DFrame(ow, oh)
+    video.scale(d, out)
+    assert_frame_equal(out, want, f"scale {geom} fmt {fmt}")
+    sc = video.Scaler(ow, oh)
+    for _ in range(2):
+        res = sc.scale(d)
+        assert res.device_planes()[0] != d.device_planes()[0]
+        assert_frame_equal(res, want, f"persistent scaler {geom} fmt {fmt}")
+    if (iw, ih) == (ow, oh) and as8.fmt == 0:
+        for x, y in zip(out.download(), as8.visible()):
+            assert np.array_equal(x, y)
+    if iw <= 1920:
+        other = ov.HostFrame(ow, oh).fill(2, seed=9)
+        m = video.VideoMixer(a=1, b=0, fader=0.7)
+        om = ov.OracleVideoMixer(a=1, b=0, fader=0.7)
+        prog, _a, _b = m.run_tick(0, [(d, (1, 30), (0, 1)), (video.DFrame(ow, oh).upload(*other.visible()), (1, 30), (0, 1)), None, None])
+        want_prog = om.run_tick(0, [(as8, (1, 30), (0, 1)), (other, (1, 30), (0, 1)), None, None])
+        for p, (x, y) in enumerate(zip(prog.download(), want_prog.visible())):
+            assert np.array_equal(x, y), f"VideoMixer program, plane {p}"
+    with pytest.raises(abi.MxError):
+        video.DFrame(iw + 1, ih, fmt=video.PIXFMT_P010)          # 4:2:0: even sizes
+
+
 @pytest.mark.parametrize("src,dst", [((320, 180), (480, 270)), ((64, 64), (320, 180)), ((1280, 720), (560, 350)), ((320, 180), (320, 180)), ((321, 181), (320, 180))],
                          ids=["up-1.5x", "pillarbox", "monitor-downscale", "same-size", "odd-size"])
 def test_gray8_scaler_input_stands_for_the_yuv444_frame_with_neutral_chroma(src, dst):

@@ -35,7 +35,7 @@ bad = 0
 scalers = {}
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8]))
+    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8, 10, 11, 12, 13]))
     big = rng.random() < 0.15
     (iw, ih), (ow, oh) = size(rng, fmt, big), size(rng, 0, big)
     what = f"seed {seed}: {iw}x{ih} fmt {fmt} -> {ow}x{oh}"
@@ -43,9 +43,20 @@ for seed in range(first, first + count):
         print(what, flush=True)
     try:
         assert video.scale_geometry(iw, ih, ow, oh) == ov.scaler_geometry(iw, ih, ow, oh), what + " geometry"
-        src = ov.HostFrame(iw, ih, fmt).fill(seed % 50, seed=seed)
+        if fmt >= 10:      # 10-bit words (random samples, junk in the ignored bits): the 8-bit frame they stand for goes through the oracle's scaler
+            cw, ch = (0 if fmt == 12 else 1), (1 if fmt in (10, 13) else 0)
+            def plane(ph, pw):
+                v, junk = rng.integers(0, 1024, size=(ph, pw), dtype=np.uint16), rng.integers(0, 64, size=(ph, pw), dtype=np.uint16)
+                return ((v << 6) | junk) if fmt == 13 else (v | (junk << 10))
+            planes = [plane(ih, iw), plane(ih >> ch, iw >> cw), plane(ih >> ch, iw >> cw)]
+            if fmt == 13:
+                uv = np.empty((ih >> 1, iw), np.uint16); uv[:, 0::2] = planes[1]; uv[:, 1::2] = planes[2]; planes = [planes[0], uv]
+            src = ov.deep_to_8(planes, iw, ih, fmt)
+            dsrc = video.DFrame(iw, ih, fmt=fmt).upload(*planes)
+        else:
+            src = ov.HostFrame(iw, ih, fmt).fill(seed % 50, seed=seed)
+            dsrc = video.DFrame(iw, ih, fmt=fmt).upload(*src.visible())
         want = ov.HostFrame(ow, oh); ov.dynamic_scale(src, want)
-        dsrc = video.DFrame(iw, ih, fmt=fmt).upload(*src.visible())
         out = video.DFrame(ow, oh)
         video.scale(dsrc, out)
         check(out, want, what)
@@ -54,7 +65,7 @@ for seed in range(first, first + count):
             scalers[key] = video.Scaler(*key)
         w2 = ov.HostFrame(*key); ov.dynamic_scale(src, w2)
         res = scalers[key].scale(dsrc)
-        check(res, w2 if (iw, ih, fmt) != (key[0], key[1], 0) else src, what + f" persistent {key}")
+        check(res, w2 if (iw, ih, src.fmt) != (key[0], key[1], 0) else src, what + f" persistent {key}")
         if len(scalers) > 40:
             scalers.clear()
     except Exception:
