@@ -131,6 +131,37 @@ def test_frame_stager_round_trip_and_reuse(fmt):
                 assert np.array_equal(a, b), f"frame {k}: plane {p} differs"
 
 
+@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV420P10, video.PIXFMT_P010], ids=["yuv420p10", "p010"])
+def test_frame_stager_takes_ten_bit_pictures(fmt):
+    """What a 10-bit decoder hands over -- 16-bit words, strides in bytes -- through the staging ring: the device frame holds the words as they came, and a
+    scaler makes of it what the oracle makes of the 8-bit frame it stands for (include/mixlab_gpu.h mx_pixfmt)."""
+    rng = np.random.default_rng(fmt)
+    st = ingest.FrameStager(slots=2)
+    st.fence(None)
+    for k in range(5):
+        w, h = [(322, 182), (1280, 720)][k % 2]
+        y = rng.integers(0, 1024, (h, w), dtype=np.uint16); u = rng.integers(0, 1024, (h // 2, w // 2), dtype=np.uint16); v = rng.integers(0, 1024, (h // 2, w // 2), dtype=np.uint16)
+        if fmt == video.PIXFMT_P010:
+            uv = np.empty((h // 2, w), np.uint16); uv[:, 0::2] = u; uv[:, 1::2] = v
+            planes = [y << 6, uv << 6]
+        else:
+            planes = [y, u, v]
+        wide = []
+        for a in planes:                # a host stride wider than the row
+            b = rng.integers(0, 65536, (a.shape[0], a.shape[1] + 2 * int(rng.integers(0, 20))), dtype=np.uint16)
+            b[:, : a.shape[1]] = a
+            wide.append(b)
+        d = st.upload(wide, w, h, fmt)
+        st.sync()
+        for got, want in zip(d.download(), planes):
+            assert np.array_equal(got, want)
+        out = video.DFrame(640, 360)
+        video.scale(d, out)
+        ref = ov.HostFrame(640, 360); ov.blank(ref); ov.dynamic_scale(ov.deep_to_8(planes, w, h, fmt), ref)
+        for p, (a, b) in enumerate(zip(out.download(), ref.visible())):
+            assert np.array_equal(a, b), f"frame {k}: plane {p}"
+
+
 def test_frame_stager_acquire_commit_is_copy_free_and_bounded():
     """A decoder writing straight into the slots: three pictures held at once (reference pictures), committed out of order; a fourth
     acquire while all three slots are held is MX_ERR_FULL."""
