@@ -285,12 +285,15 @@ typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P =
                 * inputs like yuv422p / yuv444p -- every plane resampled from its own size; width / height multiples of the subsampling */
                MX_PIXFMT_YUV410P = 6 /* chroma 1/4 x 1/4 */, MX_PIXFMT_YUV411P = 7 /* chroma 1/4 x 1 */, MX_PIXFMT_YUV440P = 8 /* chroma 1 x 1/2 */,
                MX_PIXFMT_GRAY8 = 9 /* one plane of luma: stands for the yuv444p frame with U = V = 0x80 (scaler input only, like packed RGB) */,
-               /* 10-bit YUV as decoders of 10-bit streams deliver it (pixfmt.rs:107-111: bits per component from the descriptor): samples are 16-bit little-endian words,
-                * mx_frame strides in BYTES as ever.  Scaler INPUTS only.  BUILD-SPECIFIED: the frame stands for the 8-bit frame of the same layout whose samples are
-                * min(255, (v + 2) >> 2), v the 10-bit value -- rounded to nearest, ties up -- which is then resampled like any 8-bit input (libswscale keeps the two
-                * extra bits through its filters and dithers on the way out: unknown here, parity unpinned like the scaler) */
+               /* YUV deeper than 8 bits, as decoders of 10- / 12-bit streams deliver it (pixfmt.rs:107-111: bits per component from the descriptor): samples are 16-bit
+                * little-endian words, mx_frame strides in BYTES as ever.  Scaler INPUTS only.  BUILD-SPECIFIED: the frame stands for the 8-bit frame of the same layout
+                * whose samples are min(255, (v + 2^(b-9)) >> (b - 8)), v the b-bit value -- rounded to nearest, ties up: (v + 2) >> 2 for ten bits -- which is then
+                * resampled like any 8-bit input (libswscale keeps the extra bits through its filters and dithers on the way out: unknown here, parity unpinned like the scaler) */
                MX_PIXFMT_YUV420P10 = 10, MX_PIXFMT_YUV422P10 = 11, MX_PIXFMT_YUV444P10 = 12 /* three planes, the value in the LOW ten bits of a word (the upper six ignored) */,
-               MX_PIXFMT_P010 = 13 /* semi-planar 4:2:0 like nv12: luma plane + one plane of interleaved U,V words, the value in the HIGH ten bits of a word (the lower six ignored) */ } mx_pixfmt;
+               MX_PIXFMT_P010 = 13 /* semi-planar 4:2:0 like nv12: luma plane + one plane of interleaved U,V words, the value in the HIGH ten bits of a word (the lower six ignored) */,
+               MX_PIXFMT_YUV420P12 = 14, MX_PIXFMT_YUV422P12 = 15, MX_PIXFMT_YUV444P12 = 16 /* the value in the low twelve bits (the upper four ignored) */,
+               MX_PIXFMT_YUV420P16 = 17, MX_PIXFMT_YUV422P16 = 18, MX_PIXFMT_YUV444P16 = 19 /* all sixteen bits */,
+               MX_PIXFMT_P016 = 20 /* semi-planar 4:2:0, all sixteen bits (p012 is this layout with the low four bits zero: the same rounding applies) */ } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer

@@ -1265,8 +1265,9 @@ void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, u
     if (!w || !h) return;
     hipLaunchKernelGGL(k_rgb_to_yuv444, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w, h, bpp, r_off, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2]);
 }
-// 10-bit samples in 16-bit words -> the 8-bit frame of the same layout (BUILD-SPECIFIED, include/mixlab_gpu.h mx_pixfmt): min(255, (v + 2) >> 2) with
-// v = (word >> shift) & 1023.  Four samples per lane, all three planes in one launch (blockIdx.z); an ingest format conversion like the RGB one.
+// b-bit samples (10, 12, 16) in 16-bit words -> the 8-bit frame of the same layout (BUILD-SPECIFIED, include/mixlab_gpu.h mx_pixfmt):
+// min(255, (v + 2^(b-9)) >> (b - 8)) with v = (word >> shift) & (2^b - 1).  Four samples per lane, all three planes in one launch (blockIdx.z); an ingest
+// format conversion like the RGB one.
 __global__ __launch_bounds__(256) void k_deep_to_8(DeepArgs a) {
     const uint32_t p = blockIdx.z;
     const uint32_t x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1275,8 +1276,8 @@ __global__ __launch_bounds__(256) void k_deep_to_8(DeepArgs a) {
     uint8_t* out = a.dst[p] + (size_t)y * a.dst_stride[p] + x4;
     const uint32_t n = min(4u, a.w[p] - x4);
     for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t v = ((uint32_t)row[(size_t)(x4 + k) * a.xstep[p]] >> a.shift) & 1023u;
-        out[k] = (uint8_t)min(255u, (v + 2u) >> 2);
+        const uint32_t v = ((uint32_t)row[(size_t)(x4 + k) * a.xstep[p]] >> a.shift) & ((1u << a.bits) - 1u);
+        out[k] = (uint8_t)min(255u, (v + (1u << (a.bits - 9u))) >> (a.bits - 8u));
     }
 }
 void launch_deep_to_8(const DeepArgs& a, hipStream_t s) {

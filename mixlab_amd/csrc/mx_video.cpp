@@ -530,7 +530,8 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
 // conversions), into a frame nobody else holds
 FrameRef Scaler::planar_of(const FrameRef& in) {
     if (!in->packed() && !in->deep()) return in;
-    const uint8_t as_fmt = in->deep() ? DFrame::shallow_of(in->fmt) : (uint8_t)MX_PIXFMT_YUV444P;
+    const DFrame::Deep* deep = DFrame::deep_of(in->fmt);
+    const uint8_t as_fmt = deep ? deep->layout : (uint8_t)MX_PIXFMT_YUV444P;
     FrameRef out;
     for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->fmt == as_fmt && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
     if (!out) {
@@ -539,13 +540,13 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
         rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, as_fmt), false));
         out = rgb_pool_.back();
     }
-    if (in->deep()) {
+    if (deep) {
         DeepArgs a{};
         for (int p = 0; p < 3; ++p) {
             a.src[p] = in->data[p]; a.dst[p] = out->data[p]; a.src_stride[p] = in->stride[p]; a.dst_stride[p] = out->stride[p];
             a.w[p] = out->pw(p); a.h[p] = out->ph(p); a.xstep[p] = in->xstep(p); a.xoff[p] = in->xoff(p);
         }
-        a.shift = in->fmt == MX_PIXFMT_P010 ? 6u : 0u;
+        a.shift = deep->shift; a.bits = deep->bits;
         launch_deep_to_8(a, stream_);
         return out;
     }

@@ -139,7 +139,7 @@ void launch_gather_frames(const GatherArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
 // packed RGB (rgb24: bpp 3, r_off 0; bgra: bpp 4, r_off 2) -> yuv444p planes, BUILD-SPECIFIED BT.709 limited range (DESIGN.md "Pixel formats")
 struct DeepArgs {   // per plane: source words xstep apart from word xoff of a row, w x h samples
-    const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], w[3], h[3], xstep[3], xoff[3]; uint32_t shift;
+    const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], w[3], h[3], xstep[3], xoff[3]; uint32_t shift, bits;
 };
 void launch_deep_to_8(const DeepArgs& a, hipStream_t s);
 void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
@@ -211,20 +211,32 @@ struct DFrame {
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
-    static constexpr uint8_t kLastFmt = MX_PIXFMT_P010;
-    // 10-bit samples in 16-bit words: a scaler input only, turned into the 8-bit frame of the same layout it stands for (Scaler::planar_of)
-    bool deep() const { return fmt >= MX_PIXFMT_YUV420P10 && fmt <= MX_PIXFMT_P010; }
+    static constexpr uint8_t kLastFmt = MX_PIXFMT_P016;
+    // samples deeper than 8 bits in 16-bit words: a scaler input only, turned into the 8-bit frame of the same layout it stands for (Scaler::planar_of)
+    struct Deep { uint8_t layout /* the 8-bit format of the layout */, bits, shift /* of the value inside a word */, semi; };
+    static const Deep* deep_of(uint8_t f) {
+        static constexpr Deep k[] = {
+            {MX_PIXFMT_YUV420P, 10, 0, 0}, {MX_PIXFMT_YUV422P, 10, 0, 0}, {MX_PIXFMT_YUV444P, 10, 0, 0}, {MX_PIXFMT_YUV420P, 10, 6, 1},   // 10 .. 13
+            {MX_PIXFMT_YUV420P, 12, 0, 0}, {MX_PIXFMT_YUV422P, 12, 0, 0}, {MX_PIXFMT_YUV444P, 12, 0, 0},                                  // 14 .. 16
+            {MX_PIXFMT_YUV420P, 16, 0, 0}, {MX_PIXFMT_YUV422P, 16, 0, 0}, {MX_PIXFMT_YUV444P, 16, 0, 0}, {MX_PIXFMT_YUV420P, 16, 0, 1}};  // 17 .. 20
+        return (f >= MX_PIXFMT_YUV420P10 && f <= MX_PIXFMT_P016) ? &k[f - MX_PIXFMT_YUV420P10] : nullptr;
+    }
+    bool deep() const { return deep_of(fmt) != nullptr; }
     uint32_t bps() const { return deep() ? 2u : 1u; }                       // bytes per stored sample
-    uint32_t blank_chroma() const { return !deep() ? 0x80808080u : (fmt == MX_PIXFMT_P010 ? 0x80008000u : 0x02000200u); }   // mid-scale chroma as the format stores it
-    static uint8_t shallow_of(uint8_t f) { return f == MX_PIXFMT_YUV422P10 ? MX_PIXFMT_YUV422P : (f == MX_PIXFMT_YUV444P10 ? MX_PIXFMT_YUV444P : MX_PIXFMT_YUV420P); }
+    uint32_t blank_chroma() const {                                         // mid-scale chroma as the format stores it, two words
+        const Deep* d = deep_of(fmt);
+        if (!d) return 0x80808080u;
+        const uint32_t w = (1u << (d->bits - 1)) << d->shift;
+        return w | (w << 16);
+    }
     bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA || fmt == MX_PIXFMT_GRAY8; }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
     uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : 1u); }
-    static uint32_t fmt_cw(uint8_t f) { return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV444P10 || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
-    static uint32_t fmt_ch(uint8_t f) { return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_YUV420P10 || f == MX_PIXFMT_P010) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
+    static uint32_t fmt_cw(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
+    static uint32_t fmt_ch(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
     uint32_t cw() const { return fmt_cw(fmt); }
     uint32_t chs() const { return fmt_ch(fmt); }
     // nv12: the two chroma "planes" are the even / odd bytes of ONE stored plane (data[1]; data[2] aliases it): samples xstep bytes apart from xoff
-    bool semi() const { return fmt == MX_PIXFMT_NV12 || fmt == MX_PIXFMT_P010; }
+    bool semi() const { const Deep* d = deep_of(fmt); return fmt == MX_PIXFMT_NV12 || (d && d->semi); }
     uint32_t xstep(int p) const { return (semi() && p) ? 2u : 1u; }
     uint32_t xoff(int p) const { return (semi() && p == 2) ? 1u : 0u; }
     int stored_planes() const { return packed() ? 1 : (semi() ? 2 : 3); }

@@ -248,7 +248,7 @@ class FrameStager(_Handle):
     def upload(self, planes, width, height, fmt=PIXFMT_YUV420P) -> DFrame:
         # 10-bit formats: uint16 planes (little-endian words) travel as rows of bytes
         ps = [np.ascontiguousarray(a, dtype="<u2").view(np.uint8) if np.asarray(a).dtype.itemsize == 2 else np.ascontiguousarray(a, dtype=np.uint8) for a in planes]
-        assert len(ps) == (2 if fmt in (PIXFMT_NV12, 13) else 3)
+        assert len(ps) == (2 if fmt in (PIXFMT_NV12, 13, 20) else 3)
         hf = _host_frame(ps, width, height)
         h = C.c_void_p()
         check(lib.mx_frame_stager_upload(self._h, C.byref(hf), fmt, C.byref(h)))
@@ -258,9 +258,9 @@ class FrameStager(_Handle):
         """-> (ticket, [numpy views of the slot's planes, rows x stride bytes]): write the picture into them, then commit(ticket)"""
         hf, ticket = abi.Frame(), C.c_uint32()
         check(lib.mx_frame_stager_acquire(self._h, width, height, fmt, C.byref(hf), C.byref(ticket)))
-        cw, ch = (0 if fmt in (2, 8, 12) else (2 if fmt in (6, 7) else 1)), (1 if fmt in (0, 3, 8, 10, 13) else (2 if fmt == 6 else 0))
+        cw, ch = (0 if fmt in (2, 8, 12, 16, 19) else (2 if fmt in (6, 7) else 1)), (1 if fmt in (0, 3, 8, 10, 13, 14, 17, 20) else (2 if fmt == 6 else 0))
         views = []
-        for p in range(2 if fmt in (PIXFMT_NV12, 13) else 3):
+        for p in range(2 if fmt in (PIXFMT_NV12, 13, 20) else 3):
             rows = height if p == 0 else height >> ch
             buf = (C.c_uint8 * (rows * hf.stride[p])).from_address(hf.data[p])
             views.append(np.frombuffer(buf, np.uint8).reshape(rows, hf.stride[p]))

@@ -126,7 +126,12 @@ PIXFMT_YUV410P, PIXFMT_YUV411P, PIXFMT_YUV440P, PIXFMT_GRAY8 = 6, 7, 8, 9    # c
 
 
 PIXFMT_YUV420P10, PIXFMT_YUV422P10, PIXFMT_YUV444P10, PIXFMT_P010 = 10, 11, 12, 13   # 10-bit samples in 16-bit LE words (p010: semi-planar, value in the high bits): scaler inputs only
-_DEEP = (PIXFMT_YUV420P10, PIXFMT_YUV422P10, PIXFMT_YUV444P10, PIXFMT_P010)
+PIXFMT_YUV420P12, PIXFMT_YUV422P12, PIXFMT_YUV444P12 = 14, 15, 16                    # 12 bits, low-aligned
+PIXFMT_YUV420P16, PIXFMT_YUV422P16, PIXFMT_YUV444P16, PIXFMT_P016 = 17, 18, 19, 20   # all 16 bits (p016: semi-planar)
+# deep format -> (8-bit format of the layout, bits, shift of the value inside a word)
+DEEP = {10: (0, 10, 0), 11: (1, 10, 0), 12: (2, 10, 0), 13: (0, 10, 6), 14: (0, 12, 0), 15: (1, 12, 0), 16: (2, 12, 0), 17: (0, 16, 0), 18: (1, 16, 0), 19: (2, 16, 0), 20: (0, 16, 0)}
+_DEEP = tuple(DEEP)
+_SEMI = (PIXFMT_NV12, PIXFMT_P010, PIXFMT_P016)
 
 
 class DFrame:
@@ -142,8 +147,9 @@ class DFrame:
         f = C.c_int()
         check(lib.mx_dframe_format(self._h, C.byref(f)))
         self.fmt = f.value
-        self.cw = 0 if self.fmt in (PIXFMT_YUV444P, PIXFMT_YUV440P, PIXFMT_YUV444P10) else (2 if self.fmt in (PIXFMT_YUV410P, PIXFMT_YUV411P) else 1)
-        self.ch = 1 if self.fmt in (PIXFMT_YUV420P, PIXFMT_NV12, PIXFMT_YUV440P, PIXFMT_YUV420P10, PIXFMT_P010) else (2 if self.fmt == PIXFMT_YUV410P else 0)
+        lay = DEEP[self.fmt][0] if self.fmt in DEEP else self.fmt
+        self.cw = 0 if lay in (PIXFMT_YUV444P, PIXFMT_YUV440P) else (2 if lay in (PIXFMT_YUV410P, PIXFMT_YUV411P) else 1)
+        self.ch = 1 if lay in (PIXFMT_YUV420P, PIXFMT_NV12, PIXFMT_YUV440P) else (2 if lay == PIXFMT_YUV410P else 0)
         w, h = C.c_uint32(), C.c_uint32()
         self._data = (C.c_void_p * 3)()
         self._stride = (C.c_int32 * 3)()
@@ -167,7 +173,7 @@ class DFrame:
 
     def upload(self, y, u, v=None):
         """planar formats: (y, u, v); nv12: (y, uv) with uv the interleaved chroma rows of `width` bytes"""
-        semi = self.fmt in (PIXFMT_NV12, PIXFMT_P010)
+        semi = self.fmt in _SEMI
         if self.fmt in _DEEP:   # 16-bit little-endian words, handed over as rows of bytes
             planes = [np.ascontiguousarray(a, dtype="<u2").view(np.uint8) for a in ((y, u) if semi else (y, u, v))]
         else:
@@ -195,7 +201,7 @@ class DFrame:
             check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
             return [plane.reshape(self.height, self.width, bpp)]
         bps = 2 if self.fmt in _DEEP else 1
-        if self.fmt in (PIXFMT_NV12, PIXFMT_P010):
+        if self.fmt in _SEMI:
             planes = [np.empty((self.height, self.width * bps), np.uint8), np.empty((self.height >> 1, self.width * bps), np.uint8)]
         else:
             planes = [np.empty((self.height >> (self.ch if p else 0), (self.width >> (self.cw if p else 0)) * bps), np.uint8) for p in range(3)]

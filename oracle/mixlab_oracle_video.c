@@ -327,24 +327,27 @@ void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w
     }
 }
 
-/* BUILD-SPECIFIED (include/mixlab_gpu.h mx_pixfmt 10 - 13; the reference hands any AVPixelFormat to libswscale, scale.rs:16-39, and reads the bit depth off the
- * descriptor, pixfmt.rs:107-111 -- what libswscale does with the two extra bits is unknown here: parity unpinned).  A 10-bit scaler input stands for the 8-bit frame
- * of the same layout: sample = min(255, (v + 2) >> 2), v = (word >> shift) & 1023 -- shift 0 for yuv4xxp10le (upper six bits ignored), 6 for p010le.
- * planes[p]: 16-bit little-endian words, stride in BYTES; fmt 10 / 11 / 12 = yuv420p10 / 422p10 / 444p10 (three planes), 13 = p010 (plane 1 = interleaved U, V
- * words, planes[2] ignored).  dst: a frame of fmt 0 / 1 / 2 / 0 and the same size. */
+/* BUILD-SPECIFIED (include/mixlab_gpu.h mx_pixfmt 10 - 20; the reference hands any AVPixelFormat to libswscale, scale.rs:16-39, and reads the bit depth off the
+ * descriptor, pixfmt.rs:107-111 -- what libswscale does with the extra bits is unknown here: parity unpinned).  A scaler input deeper than 8 bits stands for the
+ * 8-bit frame of the same layout: sample = min(255, (v + 2^(b-9)) >> (b - 8)), v = (word >> shift) & (2^b - 1).
+ * fmt: 10 / 11 / 12 yuv420p10 / 422p10 / 444p10 (b 10, shift 0), 13 p010 (b 10, shift 6), 14 / 15 / 16 the 12-bit planar ones, 17 / 18 / 19 the 16-bit ones, 20 p016.
+ * planes[p]: 16-bit little-endian words, stride in BYTES; p010 / p016: plane 1 = interleaved U, V words, planes[2] ignored.
+ * dst: the 8-bit frame of the layout (fmt 0 / 1 / 2) and the same size. */
 void orc_deep_to_8(const uint8_t* const planes[3], const int32_t strides[3], uint32_t w, uint32_t h, int fmt, orc_frame* dst) {
+    const uint32_t bits = fmt <= 13 ? 10u : (fmt <= 16 ? 12u : 16u);
     const uint32_t shift = fmt == 13 ? 6u : 0u;
+    const int is_semi = fmt == 13 || fmt == 20;
     for (int p = 0; p < 3; p++) {
         const uint32_t pw = p ? w >> orc_fmt_cw(dst->fmt) : w, ph = p ? h >> orc_fmt_ch(dst->fmt) : h;
-        const int semi = fmt == 13 && p;
+        const int semi = is_semi && p;
         const uint8_t* base = semi ? planes[1] : planes[p];
         const int32_t stride = semi ? strides[1] : strides[p];
         for (uint32_t y = 0; y < ph; y++) {
             const uint8_t* row = base + (size_t)y * stride;
             for (uint32_t x = 0; x < pw; x++) {
                 const size_t word = semi ? 2u * (size_t)x + (p == 2 ? 1u : 0u) : (size_t)x;
-                const uint32_t v = (((uint32_t)row[2 * word] | ((uint32_t)row[2 * word + 1] << 8)) >> shift) & 1023u;
-                const uint32_t o = (v + 2u) >> 2;
+                const uint32_t v = (((uint32_t)row[2 * word] | ((uint32_t)row[2 * word + 1] << 8)) >> shift) & ((1u << bits) - 1u);
+                const uint32_t o = (v + (1u << (bits - 9u))) >> (bits - 8u);
                 dst->data[p][(size_t)y * dst->stride[p] + x] = (uint8_t)(o > 255u ? 255u : o);
             }
         }

@@ -96,10 +96,10 @@ def packed_rgb_to_yuv444(pix: np.ndarray, fmt: int) -> HostFrame:
 
 
 def deep_to_8(planes, w: int, h: int, fmt: int) -> HostFrame:
-    """planes: uint16 arrays (little-endian words) of a 10-bit frame -- fmt 10 / 11 / 12: (y, u, v); 13 (p010): (y, uv) with uv rows of `w` words --
-    -> the 8-bit frame (fmt 0 / 1 / 2 / 0) a scaler input of that format stands for"""
+    """planes: uint16 arrays (little-endian words) of a frame deeper than 8 bits -- planar formats (10 .. 12, 14 .. 19): (y, u, v); p010 / p016 (13, 20): (y, uv)
+    with uv rows of `w` words -- -> the 8-bit frame of the layout (fmt 0 / 1 / 2) a scaler input of that format stands for"""
     arrs = [np.ascontiguousarray(a, dtype="<u2") for a in planes]
-    out = HostFrame(w, h, {10: 0, 11: 1, 12: 2, 13: 0}[fmt])
+    out = HostFrame(w, h, {10: 0, 11: 1, 12: 2, 13: 0, 14: 0, 15: 1, 16: 2, 17: 0, 18: 1, 19: 2, 20: 0}[fmt])
     ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs], *([None] * (3 - len(arrs))))
     strides = (C.c_int32 * 3)(*[a.strides[0] for a in arrs], *([0] * (3 - len(arrs))))
     lib.orc_deep_to_8(ptrs, strides, w, h, fmt, C.byref(out.c))

@@ -314,28 +314,31 @@ def test_product_scaler_taps_equal_the_exact_rational_spec():
         assert got == g["coef"], f"product coefficients {g['src']} -> {g['dst']}"
 
 
-def test_oracle_ten_bit_conversion_is_round_to_nearest_with_the_ignored_bits_ignored():
-    """orc_deep_to_8 against the rule stated in include/mixlab_gpu.h, on every 10-bit value: min(255, floor(v / 4 + 1/2)) in exact integers, the same
-    whatever sits in the six bits a format ignores, p010's chroma de-interleaved."""
+def test_oracle_deep_conversion_is_round_to_nearest_with_the_ignored_bits_ignored():
+    """orc_deep_to_8 against the rule stated in include/mixlab_gpu.h, on every value of every depth: min(255, floor(v / 2^(b-8) + 1/2)) in exact integers, the
+    same whatever sits in the bits a format ignores, the semi-planar chroma de-interleaved."""
     import oracle_video as ov
-    vals = np.arange(1024, dtype=np.uint16)
-    want = np.minimum(255, (2 * vals.astype(np.int64) + 4) // 8).astype(np.uint8)       # floor(v/4 + 1/2)
-    assert want[1] == 0 and want[2] == 1 and want[1021] == 255 and want[1018] == 255 and want[1017] == 254
-    w, h = 64, 32
-    y = np.resize(vals, (h, w))
-    for fmt, cw, ch in ((10, 1, 1), (11, 1, 0), (12, 0, 0)):
-        u = np.resize(vals[::-1], (h >> ch, w >> cw)); v = np.resize(vals[3:], (h >> ch, w >> cw))
-        for junk in (0, 0xFC00, 0x5400):
-            f = ov.deep_to_8([y | junk, u | junk, v | junk], w, h, fmt)
+    for fmt, (lay, bits, shift) in {10: (0, 10, 0), 11: (1, 10, 0), 12: (2, 10, 0), 13: (0, 10, 6), 14: (0, 12, 0), 15: (1, 12, 0), 16: (2, 12, 0),
+                                    17: (0, 16, 0), 18: (1, 16, 0), 19: (2, 16, 0), 20: (0, 16, 0)}.items():
+        n = 1 << bits
+        vals = np.arange(n, dtype=np.int64)
+        want = np.minimum(255, (2 * vals + (1 << (bits - 8))) >> (bits - 7)).astype(np.uint8)       # floor(v / 2^(b-8) + 1/2)
+        if bits == 10:
+            assert want[1] == 0 and want[2] == 1 and want[1021] == 255 and want[1018] == 255 and want[1017] == 254
+        w, h = 256, max(4, 2 * n // 256)                     # every value in the luma plane, twice
+        cw, ch = (0 if lay == 2 else 1), (1 if lay == 0 else 0)
+        y = np.resize(vals, (h, w)); u = np.resize(vals[::-1], (h >> ch, w >> cw)); v = np.resize(vals[3:], (h >> ch, w >> cw))
+        for junk in (0, (1 << (16 - bits)) - 1, 0x2A & ((1 << (16 - bits)) - 1)):
+            pack = (lambda a: ((a << shift) | junk)) if shift else (lambda a: (a | (junk << bits)))
+            if fmt in (13, 20):
+                uv = np.empty((h // 2, w), np.int64); uv[:, 0::2] = u; uv[:, 1::2] = v
+                planes = [pack(y).astype(np.uint16), pack(uv).astype(np.uint16)]
+            else:
+                planes = [pack(y).astype(np.uint16), pack(u).astype(np.uint16), pack(v).astype(np.uint16)]
+            f = ov.deep_to_8(planes, w, h, fmt)
+            assert f.fmt == lay
             for got, src in zip(f.visible(), (y, u, v)):
-                assert np.array_equal(got, want[src])
-    u = np.resize(vals[::-1], (h // 2, w // 2)); v = np.resize(vals[5:], (h // 2, w // 2))
-    uv = np.empty((h // 2, w), np.uint16); uv[:, 0::2] = u; uv[:, 1::2] = v
-    for junk in (0, 0x3F, 0x2A):
-        f = ov.deep_to_8([(y << 6) | junk, (uv << 6) | junk], w, h, 13)
-        assert f.fmt == 0
-        for got, src in zip(f.visible(), (y, u, v)):
-            assert np.array_equal(got, want[src])
+                assert np.array_equal(got, want[src]), (fmt, junk)
 
 
 def test_oracle_packed_rgb_conversion_equals_the_exact_rational_matrix():

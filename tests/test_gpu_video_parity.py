@@ -126,33 +126,34 @@ def test_scaler_inputs_with_quarter_and_vertical_only_chroma_subsampling(geom, f
         video.DFrame(iw + 2, ih, fmt=video.PIXFMT_YUV410P)      # a quarter-width chroma plane needs a width that is a multiple of 4
 
 
-def _ten_bit_planes(rng, w, h, fmt):
-    """random 10-bit planes with the edge values in, and garbage in the bits the format says are ignored"""
-    cw = 0 if fmt == video.PIXFMT_YUV444P10 else 1
-    ch = 1 if fmt in (video.PIXFMT_YUV420P10, video.PIXFMT_P010) else 0
+def _deep_planes(rng, w, h, fmt):
+    """random planes of a format deeper than 8 bits with the edge values in, and garbage in the bits the format says are ignored"""
+    lay, bits, shift = video.DEEP[fmt]
+    cw, ch = (0 if lay == 2 else 1), (1 if lay == 0 else 0)
+    top = (1 << bits) - 1
     def plane(ph, pw):
-        v = rng.integers(0, 1024, size=(ph, pw), dtype=np.uint16)
-        v.flat[:12] = [0, 1, 2, 3, 5, 6, 1018, 1019, 1020, 1021, 1022, 1023]
-        junk = rng.integers(0, 64, size=(ph, pw), dtype=np.uint16)
-        return ((v << 6) | junk) if fmt == video.PIXFMT_P010 else (v | (junk << 10))
+        v = rng.integers(0, top + 1, size=(ph, pw), dtype=np.uint32)
+        v.flat[:12] = [0, 1, (1 << (bits - 9)) - 1, 1 << (bits - 9), (1 << (bits - 8)) + 1, 3 << (bits - 9), top - (5 << (bits - 10)), top - (1 << (bits - 8)), top - (3 << (bits - 9)) + 1, top - 2, top - 1, top]
+        junk = rng.integers(0, 1 << (16 - bits), size=(ph, pw), dtype=np.uint32) if bits < 16 else 0
+        return (((v << shift) | junk) if shift else (v | (junk << bits))).astype(np.uint16)
     y, u, v = plane(h, w), plane(h >> ch, w >> cw), plane(h >> ch, w >> cw)
-    if fmt == video.PIXFMT_P010:
+    if fmt in (video.PIXFMT_P010, video.PIXFMT_P016):
         uv = np.empty((h >> 1, w), np.uint16); uv[:, 0::2] = u; uv[:, 1::2] = v
         return [y, uv]
     return [y, u, v]
 
 
-@pytest.mark.parametrize("fmt", [video.PIXFMT_YUV420P10, video.PIXFMT_YUV422P10, video.PIXFMT_YUV444P10, video.PIXFMT_P010], ids=["yuv420p10", "yuv422p10", "yuv444p10", "p010"])
+@pytest.mark.parametrize("fmt", sorted(video.DEEP), ids=["yuv420p10", "yuv422p10", "yuv444p10", "p010", "yuv420p12", "yuv422p12", "yuv444p12", "yuv420p16", "yuv422p16", "yuv444p16", "p016"])
 @pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((320, 180), (320, 180)), ((1920, 1080), (560, 350)), ((66, 38), (640, 640)), ((3840, 2160), (1920, 1080))],
                          ids=["720p-up", "same-size", "monitor-downscale", "tiny-pillarbox", "2160p-down"])
-def test_ten_bit_scaler_inputs_stand_for_the_8_bit_frame_of_their_layout(geom, fmt):
-    """10-bit YUV in 16-bit little-endian words (what a decoder of a 10-bit stream delivers; pixfmt.rs:107-111 reads the depth off the descriptor):
-    BUILD-SPECIFIED as the 8-bit frame of the same layout with samples min(255, (v + 2) >> 2) -- the ignored bits of a word really ignored, 1022 and 1023
-    clipped, p010's value in the high bits and its chroma de-interleaved -- which is then resampled like any 8-bit input: stateless, through the persistent
+def test_deep_scaler_inputs_stand_for_the_8_bit_frame_of_their_layout(geom, fmt):
+    """10- / 12- / 16-bit YUV in 16-bit little-endian words (what a decoder of a deep stream delivers; pixfmt.rs:107-111 reads the depth off the descriptor):
+    BUILD-SPECIFIED as the 8-bit frame of the same layout with samples min(255, (v + 2^(b-9)) >> (b - 8)) -- the ignored bits of a word really ignored, the top
+    values clipped, p010's value in the high bits, the semi-planar chroma de-interleaved -- which is then resampled like any 8-bit input: stateless, through the persistent
     scaler (twice: its pooled 8-bit frame is reused), at the output's own size (4:2:0: the converted frame IS the result) and as a VideoMixer input."""
     (iw, ih), (ow, oh) = geom
     rng = np.random.default_rng(iw * 7 + ow + fmt)
-    planes = _ten_bit_planes(rng, iw, ih, fmt)
+    planes = _deep_planes(rng, iw, ih, fmt)
     d = video.DFrame(iw, ih, fmt=fmt).upload(*planes)
     for a, b in zip(d.download(), planes):
         assert a.shape == b.shape and np.array_equal(a, b)

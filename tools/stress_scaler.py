@@ -35,7 +35,7 @@ bad = 0
 scalers = {}
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8, 10, 11, 12, 13]))
+    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8] + list(range(10, 21))))
     big = rng.random() < 0.15
     (iw, ih), (ow, oh) = size(rng, fmt, big), size(rng, 0, big)
     what = f"seed {seed}: {iw}x{ih} fmt {fmt} -> {ow}x{oh}"
@@ -43,13 +43,15 @@ for seed in range(first, first + count):
         print(what, flush=True)
     try:
         assert video.scale_geometry(iw, ih, ow, oh) == ov.scaler_geometry(iw, ih, ow, oh), what + " geometry"
-        if fmt >= 10:      # 10-bit words (random samples, junk in the ignored bits): the 8-bit frame they stand for goes through the oracle's scaler
-            cw, ch = (0 if fmt == 12 else 1), (1 if fmt in (10, 13) else 0)
+        if fmt >= 10:      # words deeper than 8 bits (random samples, junk in the ignored bits): the 8-bit frame they stand for goes through the oracle's scaler
+            lay, bits, shift = video.DEEP[fmt]
+            cw, ch = (0 if lay == 2 else 1), (1 if lay == 0 else 0)
             def plane(ph, pw):
-                v, junk = rng.integers(0, 1024, size=(ph, pw), dtype=np.uint16), rng.integers(0, 64, size=(ph, pw), dtype=np.uint16)
-                return ((v << 6) | junk) if fmt == 13 else (v | (junk << 10))
+                v = rng.integers(0, 1 << bits, size=(ph, pw), dtype=np.uint32)
+                junk = rng.integers(0, 1 << (16 - bits), size=(ph, pw), dtype=np.uint32) if bits < 16 else 0
+                return (((v << shift) | junk) if shift else (v | (junk << bits))).astype(np.uint16)
             planes = [plane(ih, iw), plane(ih >> ch, iw >> cw), plane(ih >> ch, iw >> cw)]
-            if fmt == 13:
+            if fmt in (13, 20):
                 uv = np.empty((ih >> 1, iw), np.uint16); uv[:, 0::2] = planes[1]; uv[:, 1::2] = planes[2]; planes = [planes[0], uv]
             src = ov.deep_to_8(planes, iw, ih, fmt)
             dsrc = video.DFrame(iw, ih, fmt=fmt).upload(*planes)
