@@ -341,6 +341,41 @@ def test_oracle_deep_conversion_is_round_to_nearest_with_the_ignored_bits_ignore
                 assert np.array_equal(got, want[src]), (fmt, junk)
 
 
+def ulp_distance_f32(a, b):
+    """distance in units in the last place between two float32 arrays (monotone integer mapping of the bit patterns)"""
+    def key(x):
+        i = np.ascontiguousarray(x, dtype=np.float32).view(np.int32).astype(np.int64)
+        return np.where(i < 0, -(i & 0x7FFFFFFF), i)
+    return np.abs(key(a) - key(b))
+
+
+def test_oracle_fir_and_resampler_agree_with_scipy_within_one_ulp():
+    """The two build-specified audio modules have no reference counterpart, so their oracle and kernels come from one paragraph of DESIGN.md.  This pins the
+    MATH independently: tests/golden/fir_resample_scipy.npz holds scipy.signal.lfilter / upfirdn outputs (f64, scipy's own summation order) for seeded input,
+    a 128-tap FIR and three resampling ratios (160/147, 2/3, 3/1); the oracle's f32 outputs are within 1 ULP of them everywhere (or within 2^-40 absolute at a
+    zero crossing), and equal in all but a few samples per thousand."""
+    import pathlib
+    import oracle as o
+    z = np.load(pathlib.Path(__file__).parent / "golden" / "fir_resample_scipy.npz")
+    x = np.ascontiguousarray(z["x"]).reshape(-1)
+    frames = z["x"].shape[0]
+    def close(got, want, what):
+        got, want = np.asarray(got, np.float32).reshape(-1), np.asarray(want, np.float32).reshape(-1)
+        d = ulp_distance_f32(got, want)
+        bad = (d > 1) & (np.abs(got.astype(np.float64) - want.astype(np.float64)) > 2.0 ** -40)
+        assert not bad.any(), f"{what}: {int(bad.sum())} samples beyond 1 ULP, first {int(np.flatnonzero(bad)[0])}"
+        assert (d != 0).mean() < 5e-3, f"{what}: {(d != 0).mean():.4f} of the samples differ"
+    taps = z["fir_taps"]
+    close(o.fir_run(taps, np.zeros(2 * (taps.size - 1), np.float32), x), z["y_fir"], "FIR vs scipy.signal.lfilter")
+    for name in "abc":
+        up, down, tpp = (int(v) for v in z[f"rs_{name}_ratio"])
+        table = z[f"rs_{name}_table"]
+        want = z[f"rs_{name}_y"]
+        got = o.resample_run(table, up, down, np.zeros(2 * max(1, tpp - 1), np.float32), 0, 0, x, want.shape[0])
+        close(got, want, f"resampler {up}/{down} vs scipy.signal.upfirdn")
+    assert frames == 735 * 8
+
+
 def test_oracle_packed_rgb_conversion_equals_the_exact_rational_matrix():
     """The build-specified packed RGB -> yuv444 conversion (what an rgb24 / bgra scaler input stands for): the oracle's hard-coded integers
     against tests/golden/rgb_matrix_bt709.json, which make_rgb_matrix.py derives from the BT.709 primaries with exact rationals."""

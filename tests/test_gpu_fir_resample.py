@@ -163,6 +163,40 @@ def test_random_resampler_and_fir_chains_match_oracle_graph(seed):
                 assert_bit_exact(got, w, f"seed {seed} run {run} node {n}")
 
 
+@pytest.mark.parametrize("flags", [0, abi.FLAG_FP_CONTRACT], ids=["exact", "contracted"])
+def test_device_fir_and_resamplers_agree_with_scipy_within_one_ulp(flags):
+    """The independent pin of the two build-specified modules (tests/golden/make_fir_resample_scipy.py: scipy.signal.lfilter / upfirdn in f64 on seeded
+    input), through the graph path in one eight-tick submission: every f32 the device produces is within 1 ULP of scipy's (2^-40 absolute at a zero
+    crossing) -- in the spec's order and in the contracted one."""
+    import pathlib
+    from test_cpu_oracle_and_abi import ulp_distance_f32
+    z = np.load(pathlib.Path(__file__).parent / "golden" / "fir_resample_scipy.npz")
+    x = np.ascontiguousarray(z["x"]).reshape(-1)
+    T = z["x"].shape[0] // 735
+    ws = Workspace(44100, 60)
+    src = ws.source_stereo()
+    fir = ws.fir(z["fir_taps"]); ws.connect(src, 0, fir, 0)
+    rs = {}
+    for name in "abc":
+        up, down, _tpp = (int(v) for v in z[f"rs_{name}_ratio"])
+        rs[name] = ws.resample(up, down, z[f"rs_{name}_table"]); ws.connect(src, 0, rs[name], 0)
+    g = ws.build(max_ticks_per_run=T, flags=flags)
+    g.write_source(src, x, T)
+    g.run_ticks(0, T)
+    def close(got, want, what):
+        got, want = np.asarray(got, np.float32).reshape(-1), np.asarray(want, np.float32).reshape(-1)
+        assert got.size == want.size, what
+        d = ulp_distance_f32(got, want)
+        bad = (d > 1) & (np.abs(got.astype(np.float64) - want.astype(np.float64)) > 2.0 ** -40)
+        assert not bad.any(), f"{what}: {int(bad.sum())} samples beyond 1 ULP, first {int(np.flatnonzero(bad)[0])}"
+        assert (d != 0).mean() < 5e-3, f"{what}: {(d != 0).mean():.4f} of the samples differ"
+    close(g.read_output(fir, 0, T, True), z["y_fir"], "FIR vs scipy.signal.lfilter")
+    for name in "abc":
+        want = z[f"rs_{name}_y"]
+        close(g.read_output(rs[name], 0, T, True, rate=(want.size, 2 * 735 * T)), want, f"resampler {name} vs scipy.signal.upfirdn")
+    g.close()
+
+
 def test_disconnected_input_of_a_mixer_behind_the_resampler_reads_silence_at_full_capacity():
     """A Mixer in the 48 kHz domain (behind a 160/147 Resample) with one Disconnected channel, run at n_ticks ==
     max_ticks_per_run: the zero buffer (src/engine/io.rs:8-9) must cover the UPSAMPLED length -- the disconnected channel
