@@ -293,7 +293,10 @@ typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P =
                MX_PIXFMT_P010 = 13 /* semi-planar 4:2:0 like nv12: luma plane + one plane of interleaved U,V words, the value in the HIGH ten bits of a word (the lower six ignored) */,
                MX_PIXFMT_YUV420P12 = 14, MX_PIXFMT_YUV422P12 = 15, MX_PIXFMT_YUV444P12 = 16 /* the value in the low twelve bits (the upper four ignored) */,
                MX_PIXFMT_YUV420P16 = 17, MX_PIXFMT_YUV422P16 = 18, MX_PIXFMT_YUV444P16 = 19 /* all sixteen bits */,
-               MX_PIXFMT_P016 = 20 /* semi-planar 4:2:0, all sixteen bits (p012 is this layout with the low four bits zero: the same rounding applies) */ } mx_pixfmt;
+               MX_PIXFMT_P016 = 20 /* semi-planar 4:2:0, all sixteen bits (p012 is this layout with the low four bits zero: the same rounding applies) */,
+               /* packed 4:2:2, one plane of 2 bytes per pixel (what capture devices deliver): scaler INPUTS only; the frame stands for the yuv422p frame with the same
+                * samples (a byte shuffle, nothing to specify), which is then resampled like any yuv422p input; width even */
+               MX_PIXFMT_YUYV422 = 21 /* Y0 U Y1 V */, MX_PIXFMT_UYVY422 = 22 /* U Y0 V Y1 */ } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer

@@ -1287,6 +1287,22 @@ void launch_deep_to_8(const DeepArgs& a, hipStream_t s) {
     if (!w || !h) return;
     hipLaunchKernelGGL(k_deep_to_8, dim3((w + 255) / 256, (h + 3) / 4, 3), dim3(256), 0, s, a);
 }
+// packed 4:2:2 -> yuv422p: one lane per pixel PAIR (4 source bytes -> 2 luma, 1 U, 1 V); an ingest format conversion
+__global__ __launch_bounds__(256) void k_yuyv_to_422p(const uint8_t* __restrict__ src, uint32_t src_stride, uint32_t w2 /* pixel pairs per row */, uint32_t h, uint32_t y_first,
+                                                      uint8_t* __restrict__ dy, uint8_t* __restrict__ du, uint8_t* __restrict__ dv, uint32_t sy, uint32_t su, uint32_t sv) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w2 || y >= h) return;
+    const uint32_t q = *reinterpret_cast<const uint32_t*>(src + (size_t)y * src_stride + 4 * (size_t)x);   // rows are 64-byte aligned (alloc_planes)
+    const uint32_t b0 = q & 0xffu, b1 = (q >> 8) & 0xffu, b2 = (q >> 16) & 0xffu, b3 = q >> 24;
+    const uint32_t y0 = y_first ? b0 : b1, u = y_first ? b1 : b0, y1 = y_first ? b2 : b3, v = y_first ? b3 : b2;
+    *reinterpret_cast<uint16_t*>(dy + (size_t)y * sy + 2 * (size_t)x) = (uint16_t)(y0 | (y1 << 8));
+    du[(size_t)y * su + x] = (uint8_t)u; dv[(size_t)y * sv + x] = (uint8_t)v;
+}
+void launch_yuyv_to_422p(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t y_first, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s) {
+    flush_scales(s);
+    if (!w || !h) return;
+    hipLaunchKernelGGL(k_yuyv_to_422p, dim3((w / 2 + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w / 2, h, y_first, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2]);
+}
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s) {
     flush_scales(s);
     if (!a.width || !a.height) return;

@@ -531,7 +531,7 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
 FrameRef Scaler::planar_of(const FrameRef& in) {
     if (!in->packed() && !in->deep()) return in;
     const DFrame::Deep* deep = DFrame::deep_of(in->fmt);
-    const uint8_t as_fmt = deep ? deep->layout : (uint8_t)MX_PIXFMT_YUV444P;
+    const uint8_t as_fmt = deep ? deep->layout : (in->yuyv() ? (uint8_t)MX_PIXFMT_YUV422P : (uint8_t)MX_PIXFMT_YUV444P);
     FrameRef out;
     for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->fmt == as_fmt && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
     if (!out) {
@@ -548,6 +548,10 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
         }
         a.shift = deep->shift; a.bits = deep->bits;
         launch_deep_to_8(a, stream_);
+        return out;
+    }
+    if (in->yuyv()) {
+        launch_yuyv_to_422p(in->data[0], in->stride[0], in->width, in->height, in->fmt == MX_PIXFMT_YUYV422 ? 1u : 0u, out->data, out->stride, stream_);
         return out;
     }
     if (in->fmt == MX_PIXFMT_GRAY8) {   // luma as it is, U = V = 0x80 (what swscale's gray -> yuv gives; build-specified like the RGB matrix)

@@ -142,6 +142,8 @@ struct DeepArgs {   // per plane: source words xstep apart from word xoff of a r
     const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], w[3], h[3], xstep[3], xoff[3]; uint32_t shift, bits;
 };
 void launch_deep_to_8(const DeepArgs& a, hipStream_t s);
+// packed 4:2:2 (yuyv: y_first 1, uyvy: 0) -> yuv422p planes: a byte shuffle
+void launch_yuyv_to_422p(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t y_first, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
 void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
 
 // ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----
@@ -211,7 +213,8 @@ struct DFrame {
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
-    static constexpr uint8_t kLastFmt = MX_PIXFMT_P016;
+    static constexpr uint8_t kLastFmt = MX_PIXFMT_UYVY422;
+    bool yuyv() const { return fmt == MX_PIXFMT_YUYV422 || fmt == MX_PIXFMT_UYVY422; }   // packed 4:2:2: a scaler input only, de-interleaved into the yuv422p frame it stands for
     // samples deeper than 8 bits in 16-bit words: a scaler input only, turned into the 8-bit frame of the same layout it stands for (Scaler::planar_of)
     struct Deep { uint8_t layout /* the 8-bit format of the layout */, bits, shift /* of the value inside a word */, semi; };
     static const Deep* deep_of(uint8_t f) {
@@ -229,8 +232,8 @@ struct DFrame {
         const uint32_t w = (1u << (d->bits - 1)) << d->shift;
         return w | (w << 16);
     }
-    bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA || fmt == MX_PIXFMT_GRAY8; }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
-    uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : 1u); }
+    bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA || fmt == MX_PIXFMT_GRAY8 || yuyv(); }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
+    uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : (yuyv() ? 2u : 1u)); }
     static uint32_t fmt_cw(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
     static uint32_t fmt_ch(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
     uint32_t cw() const { return fmt_cw(fmt); }

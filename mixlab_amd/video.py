@@ -130,7 +130,9 @@ PIXFMT_YUV420P12, PIXFMT_YUV422P12, PIXFMT_YUV444P12 = 14, 15, 16               
 PIXFMT_YUV420P16, PIXFMT_YUV422P16, PIXFMT_YUV444P16, PIXFMT_P016 = 17, 18, 19, 20   # all 16 bits (p016: semi-planar)
 # deep format -> (8-bit format of the layout, bits, shift of the value inside a word)
 DEEP = {10: (0, 10, 0), 11: (1, 10, 0), 12: (2, 10, 0), 13: (0, 10, 6), 14: (0, 12, 0), 15: (1, 12, 0), 16: (2, 12, 0), 17: (0, 16, 0), 18: (1, 16, 0), 19: (2, 16, 0), 20: (0, 16, 0)}
+PIXFMT_YUYV422, PIXFMT_UYVY422 = 21, 22                                              # packed 4:2:2, one plane of 2 bytes per pixel: scaler inputs only
 _DEEP = tuple(DEEP)
+_PACKED_BPP = {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1, PIXFMT_YUYV422: 2, PIXFMT_UYVY422: 2}
 _SEMI = (PIXFMT_NV12, PIXFMT_P010, PIXFMT_P016)
 
 
@@ -187,15 +189,17 @@ class DFrame:
         a = np.ascontiguousarray(pix, dtype=np.uint8)
         if self.fmt == PIXFMT_GRAY8:
             a = a.reshape(self.height, self.width, 1)
-        assert self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA, PIXFMT_GRAY8) and a.shape == (self.height, self.width, {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1}[self.fmt])
+        if self.fmt in (PIXFMT_YUYV422, PIXFMT_UYVY422):
+            a = a.reshape(self.height, self.width, 2)
+        assert self.fmt in _PACKED_BPP and a.shape == (self.height, self.width, _PACKED_BPP[self.fmt])
         plane = a.reshape(self.height, -1)
         hf = _host_frame([plane], self.width, self.height)
         check(lib.mx_dframe_upload(self._h, C.byref(hf), self.stream))
         return self
 
     def download(self):
-        if self.fmt in (PIXFMT_RGB24, PIXFMT_BGRA, PIXFMT_GRAY8):
-            bpp = {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1}[self.fmt]
+        if self.fmt in _PACKED_BPP:
+            bpp = _PACKED_BPP[self.fmt]
             plane = np.empty((self.height, self.width * bpp), np.uint8)
             hf = _host_frame([plane], self.width, self.height)
             check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))

@@ -354,6 +354,19 @@ void orc_deep_to_8(const uint8_t* const planes[3], const int32_t strides[3], uin
     }
 }
 
+/* Packed 4:2:2 (include/mixlab_gpu.h mx_pixfmt 21 yuyv422: Y0 U Y1 V; 22 uyvy422: U Y0 V Y1) -> the yuv422p frame with the same samples: a byte shuffle. */
+void orc_yuyv_to_422p(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt, orc_frame* dst) {
+    const int yo = fmt == 21 ? 0 : 1, co = 1 - yo;
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t* row = src + (size_t)y * src_stride;
+        for (uint32_t x = 0; x < w; x++) dst->data[0][(size_t)y * dst->stride[0] + x] = row[2 * x + yo];
+        for (uint32_t x = 0; x < w / 2; x++) {
+            dst->data[1][(size_t)y * dst->stride[1] + x] = row[4 * x + co];
+            dst->data[2][(size_t)y * dst->stride[2] + x] = row[4 * x + co + 2];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Rational64 arithmetic as used by MediaTime / MediaDuration (util/src/time.rs:9-75): always kept
  * reduced with a positive denominator, like num_rational::Ratio::new. */

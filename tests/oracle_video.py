@@ -28,6 +28,7 @@ lib.orc_scaler_geometry.argtypes = [C.c_uint32] * 4 + [C.POINTER(ScaleGeometry)]
 lib.orc_unify_picture_settings.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
 lib.orc_yuv420_to_rgba.argtypes = [C.POINTER(OFrame), C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
 lib.orc_deep_to_8.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OFrame)]
+lib.orc_yuyv_to_422p.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OFrame)]
 lib.orc_packed_rgb_to_yuv444.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OFrame)]
 lib.orc_bicubic_tap_count.argtypes = [C.c_uint32, C.c_uint32]
 lib.orc_bicubic_tap_count.restype = C.c_uint32
@@ -103,6 +104,15 @@ def deep_to_8(planes, w: int, h: int, fmt: int) -> HostFrame:
     ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs], *([None] * (3 - len(arrs))))
     strides = (C.c_int32 * 3)(*[a.strides[0] for a in arrs], *([0] * (3 - len(arrs))))
     lib.orc_deep_to_8(ptrs, strides, w, h, fmt, C.byref(out.c))
+    return out
+
+
+def yuyv_to_422p(pix: np.ndarray, fmt: int) -> HostFrame:
+    """pix: (h, 2 * w) uint8 rows of packed 4:2:2 (fmt 21 yuyv422 / 22 uyvy422) -> the yuv422p frame with the same samples"""
+    a = np.ascontiguousarray(pix, dtype=np.uint8)
+    h, w2 = a.shape
+    out = HostFrame(w2 // 2, h, 1)
+    lib.orc_yuyv_to_422p(a.ctypes.data_as(C.c_void_p), w2, w2 // 2, h, fmt, C.byref(out.c))
     return out
 
 

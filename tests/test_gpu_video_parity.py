@@ -126,6 +126,37 @@ def test_scaler_inputs_with_quarter_and_vertical_only_chroma_subsampling(geom, f
         video.DFrame(iw + 2, ih, fmt=video.PIXFMT_YUV410P)      # a quarter-width chroma plane needs a width that is a multiple of 4
 
 
+@pytest.mark.parametrize("fmt", [video.PIXFMT_YUYV422, video.PIXFMT_UYVY422], ids=["yuyv422", "uyvy422"])
+@pytest.mark.parametrize("geom", [((1280, 720), (1920, 1080)), ((640, 480), (640, 480)), ((1920, 1080), (560, 350)), ((70, 37), (640, 640))], ids=["720p-up", "same-size", "monitor-downscale", "tiny"])
+def test_packed_422_scaler_inputs_are_the_yuv422p_frame_with_the_same_samples(geom, fmt):
+    """yuyv422 / uyvy422 (what capture devices deliver; one plane, 2 bytes per pixel): the frame stands for the yuv422p frame with the same samples -- a byte
+    shuffle, nothing to specify -- and is resampled like it: stateless, persistent scaler (twice: the pooled frame is reused), VideoMixer input."""
+    (iw, ih), (ow, oh) = geom
+    rng = np.random.default_rng(iw + 3 * ow + fmt)
+    pix = rng.integers(0, 256, size=(ih, 2 * iw), dtype=np.uint8)
+    d = video.DFrame(iw, ih, fmt=fmt).upload_packed(pix)
+    assert np.array_equal(d.download()[0].reshape(ih, 2 * iw), pix)
+    as422 = ov.yuyv_to_422p(pix, fmt)
+    yo = 0 if fmt == video.PIXFMT_YUYV422 else 1
+    assert np.array_equal(as422.visible()[0], pix[:, yo::2]) and np.array_equal(as422.visible()[1], pix[:, 1 - yo::4]) and np.array_equal(as422.visible()[2], pix[:, 3 - yo::4])
+    want = ov.HostFrame(ow, oh); ov.blank(want); ov.dynamic_scale(as422, want)
+    out = video.DFrame(ow, oh)
+    video.scale(d, out)
+    assert_frame_equal(out, want, f"scale {geom} fmt {fmt}")
+    sc = video.Scaler(ow, oh)
+    for _ in range(2):
+        assert_frame_equal(sc.scale(d), want, f"persistent scaler {geom} fmt {fmt}")
+    other = ov.HostFrame(ow, oh).fill(1, seed=3)
+    m = video.VideoMixer(a=0, b=1, fader=0.25)
+    om = ov.OracleVideoMixer(a=0, b=1, fader=0.25)
+    prog, _a, _b = m.run_tick(0, [(d, (1, 30), (0, 1)), (video.DFrame(ow, oh).upload(*other.visible()), (1, 30), (0, 1)), None, None])
+    want_prog = om.run_tick(0, [(as422, (1, 30), (0, 1)), (other, (1, 30), (0, 1)), None, None])
+    for p, (x, y) in enumerate(zip(prog.download(), want_prog.visible())):
+        assert np.array_equal(x, y), f"VideoMixer program, plane {p}"
+    with pytest.raises(abi.MxError):
+        video.DFrame(iw + 1, ih, fmt=fmt)
+
+
 def _deep_planes(rng, w, h, fmt):
     """random planes of a format deeper than 8 bits with the edge values in, and garbage in the bits the format says are ignored"""
     lay, bits, shift = video.DEEP[fmt]

@@ -35,7 +35,7 @@ bad = 0
 scalers = {}
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8] + list(range(10, 21))))
+    fmt = int(rng.choice([0, 0, 1, 2, 3, 6, 7, 8] + list(range(10, 23))))
     big = rng.random() < 0.15
     (iw, ih), (ow, oh) = size(rng, fmt, big), size(rng, 0, big)
     what = f"seed {seed}: {iw}x{ih} fmt {fmt} -> {ow}x{oh}"
@@ -43,7 +43,11 @@ for seed in range(first, first + count):
         print(what, flush=True)
     try:
         assert video.scale_geometry(iw, ih, ow, oh) == ov.scaler_geometry(iw, ih, ow, oh), what + " geometry"
-        if fmt >= 10:      # words deeper than 8 bits (random samples, junk in the ignored bits): the 8-bit frame they stand for goes through the oracle's scaler
+        if fmt in (21, 22):      # packed 4:2:2: random bytes; the yuv422p frame with the same samples goes through the oracle's scaler
+            pix = rng.integers(0, 256, size=(ih, 2 * iw), dtype=np.uint8)
+            src = ov.yuyv_to_422p(pix, fmt)
+            dsrc = video.DFrame(iw, ih, fmt=fmt).upload_packed(pix)
+        elif fmt >= 10:      # words deeper than 8 bits (random samples, junk in the ignored bits): the 8-bit frame they stand for goes through the oracle's scaler
             lay, bits, shift = video.DEEP[fmt]
             cw, ch = (0 if lay == 2 else 1), (1 if lay == 0 else 0)
             def plane(ph, pw):
