@@ -296,7 +296,9 @@ typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P =
                MX_PIXFMT_P016 = 20 /* semi-planar 4:2:0, all sixteen bits (p012 is this layout with the low four bits zero: the same rounding applies) */,
                /* packed 4:2:2, one plane of 2 bytes per pixel (what capture devices deliver): scaler INPUTS only; the frame stands for the yuv422p frame with the same
                 * samples (a byte shuffle, nothing to specify), which is then resampled like any yuv422p input; width even */
-               MX_PIXFMT_YUYV422 = 21 /* Y0 U Y1 V */, MX_PIXFMT_UYVY422 = 22 /* U Y0 V Y1 */ } mx_pixfmt;
+               MX_PIXFMT_YUYV422 = 21 /* Y0 U Y1 V */, MX_PIXFMT_UYVY422 = 22 /* U Y0 V Y1 */,
+               /* the other byte orders of packed 8-bit RGB: the same build-specified conversion as rgb24 / bgra */
+               MX_PIXFMT_BGR24 = 23 /* B, G, R */, MX_PIXFMT_RGBA = 24 /* R, G, B, A; alpha ignored */, MX_PIXFMT_ARGB = 25 /* A, R, G, B */, MX_PIXFMT_ABGR = 26 /* A, B, G, R */ } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer

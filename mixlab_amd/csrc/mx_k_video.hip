@@ -1250,20 +1250,20 @@ __global__ __launch_bounds__(256) void k_yuv420_to_rgba(RgbaArgs a) {
 }
 // packed RGB -> yuv444p (BUILD-SPECIFIED, DESIGN.md "Pixel formats"): what a packed scaler input stands for.  One lane per pixel; an ingest
 // format conversion, not a hot path.
-__global__ __launch_bounds__(256) void k_rgb_to_yuv444(const uint8_t* __restrict__ src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off,
+__global__ __launch_bounds__(256) void k_rgb_to_yuv444(const uint8_t* __restrict__ src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi,
                                                        uint8_t* __restrict__ dy, uint8_t* __restrict__ du, uint8_t* __restrict__ dv, uint32_t sy, uint32_t su, uint32_t sv) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const uint8_t* px = src + (size_t)y * src_stride + (size_t)x * bpp;
-    const int R = px[r_off], G = px[1], B = px[2u - r_off];
+    const int R = px[ri], G = px[gi], B = px[bi];
     dy[(size_t)y * sy + x] = (uint8_t)(((47 * R + 157 * G + 16 * B + 128) >> 8) + 16);
     du[(size_t)y * su + x] = (uint8_t)(((-26 * R - 87 * G + 112 * B + 128) >> 8) + 128);
     dv[(size_t)y * sv + x] = (uint8_t)(((112 * R - 102 * G - 10 * B + 128) >> 8) + 128);
 }
-void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s) {
+void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s) {
     flush_scales(s);
     if (!w || !h) return;
-    hipLaunchKernelGGL(k_rgb_to_yuv444, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w, h, bpp, r_off, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2]);
+    hipLaunchKernelGGL(k_rgb_to_yuv444, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w, h, bpp, ri, gi, bi, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2]);
 }
 // b-bit samples (10, 12, 16) in 16-bit words -> the 8-bit frame of the same layout (BUILD-SPECIFIED, include/mixlab_gpu.h mx_pixfmt):
 // min(255, (v + 2^(b-9)) >> (b - 8)) with v = (word >> shift) & (2^b - 1).  Four samples per lane, all three planes in one launch (blockIdx.z); an ingest

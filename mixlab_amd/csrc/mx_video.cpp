@@ -558,7 +558,8 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
         hip_check(hipMemcpy2DAsync(out->data[0], out->stride[0], in->data[0], in->stride[0], in->width, in->height, hipMemcpyDeviceToDevice, stream_), "hipMemcpy2DAsync(gray8)");
         return out;
     }
-    launch_rgb_to_yuv444(in->data[0], in->stride[0], in->width, in->height, in->bpp(), in->fmt == MX_PIXFMT_BGRA ? 2u : 0u, out->data, out->stride, stream_);
+    const DFrame::Rgb rgb = DFrame::rgb_of(in->fmt);
+    launch_rgb_to_yuv444(in->data[0], in->stride[0], in->width, in->height, rgb.bpp, rgb.r, rgb.g, rgb.b, out->data, out->stride, stream_);
     return out;
 }
 

@@ -137,14 +137,14 @@ void launch_copy_planes(const CopyArgs& a, hipStream_t s);
 struct GatherArgs { const uint4* src[224]; uint4* dst; uint32_t q_per_frame, n; };
 void launch_gather_frames(const GatherArgs& a, hipStream_t s);
 void launch_yuv420_to_rgba(const RgbaArgs& a, hipStream_t s);
-// packed RGB (rgb24: bpp 3, r_off 0; bgra: bpp 4, r_off 2) -> yuv444p planes, BUILD-SPECIFIED BT.709 limited range (DESIGN.md "Pixel formats")
+// packed RGB (bpp bytes per pixel; R, G, B at byte ri, gi, bi of a pixel) -> yuv444p planes, BUILD-SPECIFIED BT.709 limited range (DESIGN.md "Pixel formats")
 struct DeepArgs {   // per plane: source words xstep apart from word xoff of a row, w x h samples
     const uint8_t* src[3]; uint8_t* dst[3]; uint32_t src_stride[3], dst_stride[3], w[3], h[3], xstep[3], xoff[3]; uint32_t shift, bits;
 };
 void launch_deep_to_8(const DeepArgs& a, hipStream_t s);
 // packed 4:2:2 (yuyv: y_first 1, uyvy: 0) -> yuv422p planes: a byte shuffle
 void launch_yuyv_to_422p(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t y_first, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
-void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t r_off, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
+void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
 
 // ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----
 struct Rational {
@@ -213,7 +213,17 @@ struct DFrame {
     void ensure_pixels(hipStream_t s);   // materialise a lazy frame (one fused launch)
     uint32_t width = 0, height = 0;      // luma size (a multiple of the chroma subsampling)
     uint8_t fmt = MX_PIXFMT_YUV420P;     // mx_pixfmt
-    static constexpr uint8_t kLastFmt = MX_PIXFMT_UYVY422;
+    static constexpr uint8_t kLastFmt = MX_PIXFMT_ABGR;
+    // packed 8-bit RGB: bytes per pixel and the byte index of R, G, B inside a pixel (0 bytes per pixel: not an RGB format)
+    struct Rgb { uint8_t bpp, r, g, b; };
+    static Rgb rgb_of(uint8_t f) {
+        switch (f) {
+        case MX_PIXFMT_RGB24: return {3, 0, 1, 2}; case MX_PIXFMT_BGR24: return {3, 2, 1, 0};
+        case MX_PIXFMT_BGRA: return {4, 2, 1, 0};  case MX_PIXFMT_RGBA: return {4, 0, 1, 2};
+        case MX_PIXFMT_ARGB: return {4, 1, 2, 3};  case MX_PIXFMT_ABGR: return {4, 3, 2, 1};
+        default: return {0, 0, 0, 0};
+        }
+    }
     bool yuyv() const { return fmt == MX_PIXFMT_YUYV422 || fmt == MX_PIXFMT_UYVY422; }   // packed 4:2:2: a scaler input only, de-interleaved into the yuv422p frame it stands for
     // samples deeper than 8 bits in 16-bit words: a scaler input only, turned into the 8-bit frame of the same layout it stands for (Scaler::planar_of)
     struct Deep { uint8_t layout /* the 8-bit format of the layout */, bits, shift /* of the value inside a word */, semi; };
@@ -232,9 +242,9 @@ struct DFrame {
         const uint32_t w = (1u << (d->bits - 1)) << d->shift;
         return w | (w << 16);
     }
-    bool packed() const { return fmt == MX_PIXFMT_RGB24 || fmt == MX_PIXFMT_BGRA || fmt == MX_PIXFMT_GRAY8 || yuyv(); }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
-    uint32_t bpp() const { return fmt == MX_PIXFMT_BGRA ? 4u : (fmt == MX_PIXFMT_RGB24 ? 3u : (yuyv() ? 2u : 1u)); }
-    static uint32_t fmt_cw(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV440P || f == MX_PIXFMT_RGB24 || f == MX_PIXFMT_BGRA || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
+    bool packed() const { return rgb_of(fmt).bpp != 0 || fmt == MX_PIXFMT_GRAY8 || yuyv(); }   // ONE stored plane (3 / 4 / 1 bytes per pixel): a scaler input only, turned into the yuv444p frame it stands for
+    uint32_t bpp() const { return rgb_of(fmt).bpp ? rgb_of(fmt).bpp : (yuyv() ? 2u : 1u); }
+    static uint32_t fmt_cw(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV444P || f == MX_PIXFMT_YUV440P || rgb_of(f).bpp != 0 || f == MX_PIXFMT_GRAY8) ? 0u : ((f == MX_PIXFMT_YUV410P || f == MX_PIXFMT_YUV411P) ? 2u : 1u); }   // log2_chroma_w, pixfmt.rs:97-100
     static uint32_t fmt_ch(uint8_t f) { if (const Deep* d = deep_of(f)) f = d->layout; return (f == MX_PIXFMT_YUV420P || f == MX_PIXFMT_NV12 || f == MX_PIXFMT_YUV440P) ? 1u : (f == MX_PIXFMT_YUV410P ? 2u : 0u); }   // log2_chroma_h, pixfmt.rs:102-105
     uint32_t cw() const { return fmt_cw(fmt); }
     uint32_t chs() const { return fmt_ch(fmt); }

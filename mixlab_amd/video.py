@@ -132,7 +132,8 @@ PIXFMT_YUV420P16, PIXFMT_YUV422P16, PIXFMT_YUV444P16, PIXFMT_P016 = 17, 18, 19, 
 DEEP = {10: (0, 10, 0), 11: (1, 10, 0), 12: (2, 10, 0), 13: (0, 10, 6), 14: (0, 12, 0), 15: (1, 12, 0), 16: (2, 12, 0), 17: (0, 16, 0), 18: (1, 16, 0), 19: (2, 16, 0), 20: (0, 16, 0)}
 PIXFMT_YUYV422, PIXFMT_UYVY422 = 21, 22                                              # packed 4:2:2, one plane of 2 bytes per pixel: scaler inputs only
 _DEEP = tuple(DEEP)
-_PACKED_BPP = {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1, PIXFMT_YUYV422: 2, PIXFMT_UYVY422: 2}
+PIXFMT_BGR24, PIXFMT_RGBA, PIXFMT_ARGB, PIXFMT_ABGR = 23, 24, 25, 26                  # the other byte orders of packed RGB
+_PACKED_BPP = {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1, PIXFMT_YUYV422: 2, PIXFMT_UYVY422: 2, PIXFMT_BGR24: 3, PIXFMT_RGBA: 4, PIXFMT_ARGB: 4, PIXFMT_ABGR: 4}
 _SEMI = (PIXFMT_NV12, PIXFMT_P010, PIXFMT_P016)
 
 

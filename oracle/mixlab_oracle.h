@@ -193,7 +193,7 @@ int orc_scale_plane_bicubic_rows(const uint8_t* slice, int32_t src_stride, uint3
                                  uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh, uint32_t row0, uint32_t rows);
 void orc_deep_to_8(const uint8_t* const planes[3], const int32_t strides[3], uint32_t w, uint32_t h, int fmt /* 10 - 20 */, orc_frame* dst);   /* build-specified: 10- / 12- / 16-bit words -> the 8-bit frame of the layout */
 void orc_yuyv_to_422p(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt /* 21 yuyv422, 22 uyvy422 */, orc_frame* dst);   /* a byte shuffle into yuv422p */
-void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt /* 4 rgb24, 5 bgra */, orc_frame* dst);   /* build-specified */
+void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt /* 4 rgb24, 5 bgra, 23 bgr24, 24 rgba, 25 argb, 26 abgr */, orc_frame* dst);   /* build-specified */
 int orc_dynamic_scale_band(const orc_frame* in_slice, uint32_t in_full_h, uint32_t src_row0, orc_frame* out, uint32_t full_w, uint32_t full_h, uint32_t row0);
 /* src/video/encode.rs:338-397: identity when sizes match (copies), else blank + scale into letterbox */
 void orc_dynamic_scale(const orc_frame* in, orc_frame* out);

@@ -313,13 +313,17 @@ void orc_yuv420_to_rgba(const orc_frame* in, uint8_t* rgba, int32_t rgba_stride,
  * yuv444p frame of its per-pixel conversion, BT.709 limited range with the usual 8-bit integer coefficients (round(219/255 K 256),
  * round(224/255 K' 256): tests/golden/make_rgb_matrix.py derives them from exact rationals):
  *   Y = ((47 R + 157 G + 16 B + 128) >> 8) + 16,  U = ((-26 R - 87 G + 112 B + 128) >> 8) + 128,  V = ((112 R - 102 G - 10 B + 128) >> 8) + 128
- * fmt 4 = rgb24 (R, G, B bytes), 5 = bgra (B, G, R, A bytes; alpha ignored).  dst: a yuv444p frame of the same size. */
+ * fmt 4 = rgb24 (R, G, B bytes), 5 = bgra (B, G, R, A bytes; alpha ignored), 23 bgr24, 24 rgba, 25 argb, 26 abgr.  dst: a yuv444p frame of the same size. */
 void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt, orc_frame* dst) {
-    const int bpp = fmt == 5 ? 4 : 3, ri = fmt == 5 ? 2 : 0, bi = fmt == 5 ? 0 : 2;
+    /* 4 rgb24, 5 bgra, 23 bgr24, 24 rgba, 25 argb, 26 abgr (include/mixlab_gpu.h mx_pixfmt) */
+    const int bpp = (fmt == 4 || fmt == 23) ? 3 : 4;
+    const int ri = fmt == 4 || fmt == 24 ? 0 : (fmt == 25 ? 1 : (fmt == 26 ? 3 : 2));
+    const int gi = fmt == 25 || fmt == 26 ? 2 : 1;
+    const int bi = fmt == 4 || fmt == 24 ? 2 : (fmt == 25 ? 3 : (fmt == 26 ? 1 : 0));
     for (uint32_t y = 0; y < h; y++) {
         const uint8_t* row = src + (size_t)y * src_stride;
         for (uint32_t x = 0; x < w; x++) {
-            const int32_t R = row[bpp * x + ri], G = row[bpp * x + 1], B = row[bpp * x + bi];
+            const int32_t R = row[bpp * x + ri], G = row[bpp * x + gi], B = row[bpp * x + bi];
             dst->data[0][(size_t)y * dst->stride[0] + x] = (uint8_t)(((47 * R + 157 * G + 16 * B + 128) >> 8) + 16);
             dst->data[1][(size_t)y * dst->stride[1] + x] = (uint8_t)(((-26 * R - 87 * G + 112 * B + 128) >> 8) + 128);
             dst->data[2][(size_t)y * dst->stride[2] + x] = (uint8_t)(((112 * R - 102 * G - 10 * B + 128) >> 8) + 128);

@@ -88,7 +88,7 @@ def dynamic_scale(src: HostFrame, dst: HostFrame):
 
 
 def packed_rgb_to_yuv444(pix: np.ndarray, fmt: int) -> HostFrame:
-    """pix: (h, w, 3) rgb24 (fmt 4) or (h, w, 4) bgra (fmt 5) uint8 -> the yuv444p frame a scaler input of that format stands for"""
+    """pix: (h, w, 3) rgb24 / bgr24 (fmt 4 / 23) or (h, w, 4) bgra / rgba / argb / abgr (5 / 24 / 25 / 26) uint8 -> the yuv444p frame a scaler input of that format stands for"""
     a = np.ascontiguousarray(pix, dtype=np.uint8)
     h, w, bpp = a.shape
     out = HostFrame(w, h, 2)

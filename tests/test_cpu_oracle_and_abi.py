@@ -396,6 +396,10 @@ def test_oracle_packed_rgb_conversion_equals_the_exact_rational_matrix():
     got2 = ov.packed_rgb_to_yuv444(bgra, 5).visible()
     for p in range(3):
         assert np.array_equal(got2[p], got[p])
+    alpha = rng.integers(0, 256, size=(6, 10, 1), dtype=np.uint8)
+    for fmt, pix in ((23, rgb[..., ::-1]), (24, np.concatenate([rgb, alpha], axis=2)), (25, np.concatenate([alpha, rgb], axis=2)), (26, np.concatenate([alpha, rgb[..., ::-1]], axis=2))):
+        for p, plane in enumerate(ov.packed_rgb_to_yuv444(pix, fmt).visible()):       # bgr24, rgba, argb, abgr: the same pixels in another byte order
+            assert np.array_equal(plane, got[p]), (fmt, p)
     assert int(want[0].min()) >= 16 and int(want[0].max()) <= 235
 
 

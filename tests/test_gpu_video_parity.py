@@ -462,7 +462,7 @@ def test_video_mixer_random_scenarios_match_oracle(seed):
     assert shown > 5
 
 
-@pytest.mark.parametrize("fmt", [video.PIXFMT_RGB24, video.PIXFMT_BGRA], ids=["rgb24", "bgra"])
+@pytest.mark.parametrize("fmt", [video.PIXFMT_RGB24, video.PIXFMT_BGRA, video.PIXFMT_BGR24, video.PIXFMT_RGBA, video.PIXFMT_ARGB, video.PIXFMT_ABGR], ids=["rgb24", "bgra", "bgr24", "rgba", "argb", "abgr"])
 @pytest.mark.parametrize("src,dst", [((320, 180), (480, 270)), ((322, 182), (320, 180)), ((64, 64), (320, 180)), ((1280, 720), (560, 350)), ((320, 180), (320, 180))],
                          ids=["up-1.5x", "down-slightly", "pillarbox", "monitor-downscale", "same-size"])
 def test_packed_rgb_scaler_inputs_equal_the_oracle_composition(fmt, src, dst):
@@ -471,7 +471,7 @@ def test_packed_rgb_scaler_inputs_equal_the_oracle_composition(fmt, src, dst):
     settings differ by the format, encode.rs:342-352).  Stateless call, persistent scaler and a VideoMixer input."""
     rng = np.random.default_rng(src[0] * 7 + dst[0] + fmt)
     w, h = src
-    bpp = 3 if fmt == video.PIXFMT_RGB24 else 4
+    bpp = 3 if fmt in (video.PIXFMT_RGB24, video.PIXFMT_BGR24) else 4
     pix = rng.integers(0, 256, size=(h, w, bpp), dtype=np.uint8)
     pix[: h // 3] = (np.add.outer(np.arange(h // 3), np.arange(w))[..., None] * np.array([1, 2, 3, 1][:bpp])).astype(np.uint8)   # a smooth part too
     d = video.DFrame(w, h, fmt=fmt).upload_packed(pix)
