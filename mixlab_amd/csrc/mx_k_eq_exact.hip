@@ -629,16 +629,52 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
     }
 }
 
+// The samples [i_lo, i_hi) (chunk-relative) of a super-block, one at a time, in the general Envelope form: the super-block in which a tick ends when ticks are not
+// whole super-blocks (735 samples at 44.1 kHz).  Every lane of the wave crosses the boundary at the same sample (chunks are whole ticks), so the range is
+// wave-uniform; the caller runs the part before the boundary with the old tick's state, loads the new one, and runs the rest.  Samples outside the range keep what
+// the tile holds: outputs already made, or inputs still to come.  One super-block in 23 takes this path.
+template <int SB, int MODE, bool FC>
+__device__ __forceinline__ void eq_tile_compute_range(const EqK& K, float* buf, const int lane, const int so, const int len, const int i_lo, const int i_hi,
+                                                      const EnvTick& cur, const uint64_t t_chunk, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
+    typedef EqTileGeo<SB> G;
+    const int sw = G::sw(lane);
+    f4v* row = reinterpret_cast<f4v*>(buf + lane * SB);
+#pragma unroll 1
+    for (int pce = 0; pce < G::S; ++pce) {
+        const int base = so + 4 * pce;
+        if (base + 4 <= i_lo || base >= i_hi) continue;               // wave-uniform
+        if (base < len) {                                             // len is a multiple of 4
+            f4v v = row[pce ^ sw];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (base + e >= i_lo && base + e < i_hi) {            // wave-uniform
+                    const uint32_t b = __float_as_uint(v[e]); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
+                    const float y = eq_step<FC>(s, K.lo_f, K.hi_f, K.g_lo, K.g_mid, K.g_hi, v[e]);
+                    const double depth = env_depth<FC>(K.env, cur, K.one_minus, K.mod_depth, t_chunk + (uint64_t)(base + e), K.sr, K.rsr);
+                    v[e] = MODE == EQM_AMP_ENV ? amp_apply(y, depth, K.amplitude) : y;
+                }
+            }
+            row[pce ^ sw] = v;
+        }
+    }
+}
+
 // stage-out of a computed tile: whole lines, eight lanes per chunk line
-template <int SB, bool STEREO>
+// RAGGED: chunks that are not whole super-blocks (whole ticks of 735 samples at 44.1 kHz: 5 880 = 183.75 of them) end inside their last one, and the pieces beyond
+// the end are the NEXT chunk's first samples -- that chunk's lane writes them, this one must not (`pieces`: how many of the row's pieces are the chunk's, wave-uniform)
+template <int SB, bool STEREO, bool RAGGED = false>
 __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* buf, int so) {
     typedef EqTileGeo<SB> G;
+    const int pieces = RAGGED ? ((int)c.C - so) >> 2 : G::S;
 #pragma unroll
     for (int k = 0; k < G::N_INSTR; ++k) {
         const f4v o = *reinterpret_cast<const f4v*>(buf + k * 256 + c.lane * 4);
-        const uint32_t chunk = c.chunk0 + (uint32_t)(G::ROWS * k + c.lane / G::S);
+        const int cj = G::ROWS * k + c.lane / G::S;
+        const uint32_t chunk = c.chunk0 + (uint32_t)cj;
         const int idx = c.base[k] + so;                               // so >= 0 here (stage-out only happens in the chunk proper)
-        if (chunk < c.n_chunks && idx + 4 <= (int)c.F) {
+        bool mine = true;
+        if (RAGGED) mine = ((c.lane % G::S) ^ G::sw(cj)) < pieces;
+        if (mine && chunk < c.n_chunks && idx + 4 <= (int)c.F) {
             if (STEREO) {
                 f4v a = {o[0], o[0], o[1], o[1]}, b = {o[2], o[2], o[3], o[3]};   // stereo_panner.rs:35-38
                 __builtin_nontemporal_store(a, reinterpret_cast<f4v*>(c.out + 2 * idx));
@@ -650,7 +686,9 @@ __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* b
     }
 }
 
-template <int SB, int KMODE, int KSTEREO, bool FC, int NBUF = 2>
+// RT ("ragged ticks", inline Envelope only): ticks that are not whole super-blocks -- 735 samples at 44.1 kHz, the reference's own rate -- in chunks of whole ticks that
+// are multiples of 4 samples (2 940 = 4 ticks).  An instantiation of its own: the 48 kHz kernels keep their code and their registers.
+template <int SB, int KMODE, int KSTEREO, bool FC, int NBUF = 2, bool RT = false>
 __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
                                                                 uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][TILE]
@@ -740,7 +778,47 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
     }
-    if constexpr (KMODE == EQM_AMP_ENV) {
+    if constexpr (KMODE == EQM_AMP_ENV && RT) {
+        // Chunks are whole ticks (launcher), so every lane is at the same place inside its tick.  Where ticks are whole super-blocks too (48 kHz: 800 = 25 x 32) a tick
+        // is a run of super-blocks in one form; where they are not (44.1 kHz: 735) the super-block that holds a tick's end is walked sample by sample in the general
+        // form, the old tick's state before the boundary and the new one's behind it (eq_tile_compute_range), and the super-blocks between two boundaries as before.
+        const int fpc = (int)r.fpc;
+        int tick_i = 0;                              // tick index inside the chunk
+        int so0 = 0;
+        auto load_tick = [&]() {                     // the Envelope state entering tick tick_i of every lane's chunk, per lane
+            so0 = tick_i * fpc;
+            const size_t tk = ((size_t)begin + (size_t)so0) / r.fpc;
+            cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
+            const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so0;
+            el = env_lane_coeffs(K.env, cur, t, r.fpc, nice);
+            el.k0 = (uint32_t)so0; el.t_chunk = r.t0 + (uint64_t)begin;
+        };
+        load_tick();
+        while (g < total) {
+            const int so_g = (g - n_warm) * EQ_SB;
+            const int t_end = so0 + fpc;             // first sample of the next tick
+            if (so_g + EQ_SB <= t_end) {
+                const int envk = __ballot(active && so0 < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so0 < len && el.flat == 0u) == 0ull ? 1 : 2);
+                const int g_int = n_warm + t_end / EQ_SB;                      // super-blocks that end at or before t_end
+                const int g_end = g_int < total ? g_int : total;
+                if (envk == 1) {
+                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 1, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
+                } else if (envk == 2) {
+                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 2, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
+                } else {
+                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 3, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
+                }
+                if (t_end % EQ_SB == 0) { ++tick_i; load_tick(); }             // the tick ended with its last super-block
+            } else {
+                float* buf = begin_sb(g);
+                eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, so_g, len, so_g, t_end, cur, el.t_chunk, s, xmin, xmax);
+                ++tick_i; load_tick();
+                eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, so_g, len, t_end, so_g + EQ_SB, cur, el.t_chunk, s, xmin, xmax);
+                eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so_g);
+                ++g;
+            }
+        }
+    } else if constexpr (KMODE == EQM_AMP_ENV) {
         const int sb_per_tick = (int)(r.fpc / EQ_SB);   // chunks are whole ticks, ticks whole super-blocks (launcher)
         while (g < total) {
             // a new tick (wave-uniform): its Envelope state, per lane
@@ -1211,7 +1289,7 @@ static size_t eq_warm_len(double f) {
     return (size_t)-1;
 }
 
-bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan) {
+bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan, bool whole_ticks) {
     plan = EqSpecPlan{1u, 0u, 0u, 0u, 0u};
     if (!n || !frames) return false;
     size_t W = std::max(eq_warm_len(lo_f), eq_warm_len(hi_f));
@@ -1225,7 +1303,12 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     if (frames < 2 * W || frames < 64) return false;          // a stream shorter than two warm-ups: one lane per instance
     // Chunk lengths are whole ticks when that is a multiple of 16 samples (an inline Envelope's state is read once per tick and every
     // lane of a wave crosses its tick boundaries at the same step), else multiples of 32 samples.
-    const size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
+    // With an inline Envelope (whole_ticks) chunks are whole ticks at ANY rate, in multiples that keep them multiples of 4 samples: 735 -> 2 940 (44.1 kHz), 800 -> 800.
+    size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
+    if (whole_ticks && fpc >= 32 && fpc % 16 != 0) {
+        size_t u = fpc; while (u % 4) u += fpc;
+        if (u <= frames / 2) unit = u;
+    }
     auto chunk_of = [&](size_t nc) { return ((frames + nc - 1) / nc + unit - 1) / unit * unit; };
     // Chunks may be SHORTER than the warm-up (a chunk whose window would reach the stream's start warms up from there, from the carried
     // state): short submissions get a wave of 64 chunks per strip where C >= W allowed 40.  Not below 256 samples.
@@ -1294,8 +1377,11 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     const int sb_env = env_int("MX_EQ_SPEC_SB", 0);
     const int sb_auto = (size_t)n * wpi <= 2048 ? (r.fc ? 16 : 32) : 321;
     const int sb = sb_env == 0 ? sb_auto : (!r.fc && sb_env == 32) ? 32 : (sb_env == 16 ? 16 : 321);   // samples per lane per super-block
-    const bool tiled = !no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
-                       r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0));
+    // ragged ticks (RT instantiations): an inline Envelope at a rate whose tick is not whole super-blocks (44.1 kHz: 735) -- chunks of whole ticks, multiples of 4 samples
+    const bool rt = !no_tiles && (um == 6 || um == 7) && r.fpc >= 32 && r.fpc % 32 != 0 && plan.chunk % r.fpc == 0 && plan.chunk % 4 == 0 && r.frames % 4 == 0 &&
+                    plan.warm % 32 == 0 && r.frames < (1ull << 30) && r.frames >= 4;
+    const bool tiled = rt || (!no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
+                       r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0)));
     if (tiled) {
         static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
         const size_t lds = std::max<size_t>((sb == 321 ? 1 : 2) * 64 * (size_t)(sb == 321 ? 32 : sb) * sizeof(float), (size_t)lds_pad);
@@ -1305,6 +1391,12 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
                       else if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
+        if (rt) {   // one tile of whole 16-byte rows (the rows of such chunks are not line-aligned either way)
+            const size_t lds1 = (size_t)64 * 32 * sizeof(float);
+#define MX_GRT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_ENV, S, F, 1, true>), dim3(n * wpi), dim3(64), lds1, s, d, (const EqState*)st, r, plan, wpi, recs)
+            if (um == 6) { if (r.fc) MX_GRT(0, true); else MX_GRT(0, false); } else { if (r.fc) MX_GRT(1, true); else MX_GRT(1, false); }
+#undef MX_GRT
+        } else
         switch (um) {
         case 0: MX_GT(EQM_PLAIN, 0); break;     case 1: MX_GT(EQM_PLAIN, 1); break;
         case 2: MX_GT(EQM_AMP_CONST, 0); break; case 3: MX_GT(EQM_AMP_CONST, 1); break;

@@ -78,8 +78,9 @@ def test_contracted_spec_eq_every_fused_epilogue(rate, contracted):
 
 
 @pytest.mark.parametrize("env_p", [(25.0, 500.0, 0.8, 200.0), (0.0, 100.0, 0.5, 50.0), (10.0, 40.0, 1.5, 30.0), (3.0, 20.0, -0.25, 15.0)])
-def test_contracted_spec_eq_inline_envelope_with_unusual_parameters(env_p, contracted):
-    spec.test_spec_eq_inline_envelope_with_unusual_parameters_matches_the_oracle(env_p)
+@pytest.mark.parametrize("rate", RATES)
+def test_contracted_spec_eq_inline_envelope_with_unusual_parameters(env_p, rate, contracted):
+    spec.test_spec_eq_inline_envelope_with_unusual_parameters_matches_the_oracle(env_p, rate)
 
 
 def _run_config2(n_strips, sr, spt, T, runs, flags, batch, noise):
@@ -195,6 +196,12 @@ def test_contracted_eq_three_on_the_reference_golden_pair_within_one_ulp():
         d = synth.ulp_diff(got, want[:got.size])
         assert d.max() <= 1, f"{d.max()} ULP from the reference's golden output"
         assert np.count_nonzero(d) <= got.size // 100000, f"{np.count_nonzero(d)} of {got.size} samples differ from the golden output"
+
+
+def test_contracted_config2_at_2048_ticks_of_44k1_bit_exact_vs_the_contract_oracle(contracted):
+    """The benchmark shape at the reference's own rate in the contracted order: the RT instantiations of the tiled kernel (ticks of 735 samples)."""
+    import test_gpu_full_size as fs
+    fs.test_config2_at_the_benchmarked_batch_length_2048_ticks_bit_exact((44100, 735))
 
 
 def test_contracted_config2_full_size_every_strip_within_one_ulp_of_the_exact_order():
