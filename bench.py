@@ -687,6 +687,43 @@ def exchange_parity(torch, dist, np, g, ex, mix, T, step, world):
             "got": float(got[i]), "want": float(acc[i])}
 
 
+def other_rate_leg(torch, np, synth, abi, Workspace, args, local_rank, stream, sample_rate, T, steps=5):
+    """The headline job at ANOTHER sample rate on a graph of its own -- 44.1 kHz is the reference's own rate (src/engine.rs SAMPLE_RATE),
+    48 kHz the one config 2 is written for.  Same strips, same gate schedule, same T; not part of `value`."""
+    ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, args.strips, 0, sample_rate, want_trigs=True)
+    spt = ws.spt
+    flags = abi.FLAG_FP_CONTRACT if args.fp_contract else 0
+    with torch.cuda.stream(stream):
+        g = ws.build(max_ticks_per_run=T, flags=flags, device=local_rank, stream=stream.cuda_stream)
+        base_ticks = min(T, 256)
+        for j, sn in enumerate(srcs):
+            blk = synth.noise(j, base_ticks * spt)
+            g.write_source(sn, np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt], T)
+        evs = [gate_events(abi, trigs, 0, i * T, T) for i in range(steps + 1)]
+
+        def step(i):
+            if evs[i] is not None:
+                g.schedule_params_batch(evs[i][0], evs[i][1])
+            g.run_ticks(i * T, T)
+        step(0)
+        torch.cuda.synchronize()
+        g.profile_enable(not args.no_profile)
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        g.profile_enable(False)
+        by_kind, _tot, n_prof = g.profile_collect()
+        ran, repaired = g.eq_spec_stats()
+        g.close()
+    return {"sample_rate": sample_rate, "samples_per_tick": spt, "ticks_per_step": T, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "value": args.strips * T * steps / dt, "unit": "channel-ticks/s",
+            "kernel_ms_per_step": {k: round(v / max(1, n_prof), 5) for k, v in sorted(by_kind.items()) if v > 0},
+            "eq_spec": {"chunks_run": int(ran), "chunks_repaired": int(repaired)},
+            "note": "a channel-tick at 44.1 kHz is 735 samples against 800: per SAMPLE this is value x 735 / 800 of the headline's"}
+
+
 def scaled_ticks_leg(torch, dist, np, synth, abi, shard, Workspace, args, rank, world, local_rank, stream, nccl_id_fn, toggling):
     """N > 1: the OTHER tick policy beside the one the headline ran -- T x N ticks per step, so that a rank's chunk length (and the share of
     warm-up samples its speculative EqThree runs) is what it is on one GPU.  Own graph, own exchange; barrier + max over ranks like the headline."""
@@ -774,6 +811,7 @@ def main():
     ap.add_argument("--no-contract-leg", action="store_true", help="skip the MX_FLAG_FP_CONTRACT leg (the same graph in the contracted order, <= 1 ULP)")
     ap.add_argument("--fp-contract", action="store_true", help="run the HEADLINE in the contracted order (MX_FLAG_FP_CONTRACT: <= 1 ULP, NOT the reference's bits); "
                     "the default line reports it as the `fp_contract` leg beside the exact headline")
+    ap.add_argument("--no-rate-leg", action="store_true", help="skip the 44.1 kHz leg (the headline job at the reference's own sample rate)")
     ap.add_argument("--no-material-leg", action="store_true", help="skip the realistic-material (muted strips, silences) and poisoned-strip legs")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
@@ -1059,6 +1097,11 @@ def main():
                                               "flag": "MX_FLAG_OVERLAP_TAIL (the last Mixer bank on a second stream beside the next submission's EqThree group; bit-identical results)"}
                 g2.close()
 
+    # the same job at the reference's own sample rate (config 2 is written for 48 kHz; the reference runs at 44.1 kHz)
+    rate_leg = None
+    if not use_dist and not args.no_rate_leg and toggling and args.sample_rate != 44100:
+        rate_leg = other_rate_leg(torch, np, synth, abi, Workspace, args, local_rank, stream, 44100, T)
+
     # Realistic material and the repair pass's worst case, on the same graph (LAST: the poisoned strip's state stays NaN for ever).
     # The headline's sources are seeded noise, on which every chunk boundary of the speculative EqThree proves itself; a desk also carries
     # muted strips (exact zeros) and programme that falls silent and comes back -- the one input class the proof fails on (poles stall a few
@@ -1247,6 +1290,7 @@ def main():
             "scaled_ticks": other_policy,
             "realtime": realtime,
             "t_sweep": t_sweep,
+            "rate_44100": rate_leg,
             "material": material,
             "scaling_model": scaling,
             "north_star_realtime": north,
