@@ -1002,7 +1002,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
             }
             if (eq_exact()) {
                 EqSpecPlan plan;
-                if (eq_plan_spec(n, gf, gfpc, lo_f_, hi_f_, plan, g.eq_mode == 6 || g.eq_mode == 7)) {   // long streams: speculative time-parallel form, verified bit-exact
+                if (eq_plan_spec(n, gf, gfpc, lo_f_, hi_f_, plan, g.eq_mode == 6 || g.eq_mode == 7, g.eq_mode == 4 || g.eq_mode == 5)) {   // long streams: speculative time-parallel form, verified bit-exact
                     const size_t need = eq_spec_scratch_bytes(n, plan);
                     if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
                     if (!eq_stats_.p) { eq_stats_.alloc(8 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 8 * sizeof(uint64_t)), "hipMemset"); }

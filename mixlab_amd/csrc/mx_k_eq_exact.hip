@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64, (KMODE == EQM_AMP_ENV || KMODE < 0) ? 3 : 4) vo
 //   stage-out  the tile is read back linearly (lane l of step k holds slot l & 7 of chunk 8k + (l >> 3)) and stored with eight
 //              lanes per line: whole lines again.
 // The wave needs no barrier (a wave per workgroup; its own vmcnt orders the DMA before its ds_reads).  16 KiB of LDS per wave.
-// Conditions (launch_eq_three_spec): frames % 4 == 0, chunk % 32 == 0, frames < 2^30, no control BUFFER (EQM_AMP_CTL keeps the
+// Conditions (launch_eq_three_spec): frames % 4 == 0, chunk % 32 == 0, frames < 2^30 (a control BUFFER, EQM_AMP_CTL, takes a second tile; before round 4 it kept the
 // direct form), and with an inline Envelope samples-per-tick % 32 == 0 (48 kHz: 800).
 // ---------------------------------------------------------------------------------------------
 typedef const float __attribute__((address_space(1)))* mx_gfp1;
@@ -557,13 +557,14 @@ __device__ __forceinline__ void eq_tile_bases(EqTileCtx& c) {
     }
 }
 template <int SB>
-__device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, int so) {
+__device__ __forceinline__ void eq_tile_issue(const EqTileCtx& c, float* buf, int so, const float* src = nullptr /* another stream of the instance with the input's indexing: the Amplifier's control */) {
     typedef EqTileGeo<SB> G;
+    const float* from = src ? src : c.in;
 #pragma unroll
     for (int k = 0; k < G::N_INSTR; ++k) {
         // before the stream (chunk 0's warm-up) / past it (lanes beyond the last chunk): never used, keep the address legal
         const int idx = min(max(c.base[k] + so, 0), (int)c.F - 4);    // one v_med3_i32
-        __builtin_amdgcn_global_load_lds((mx_gfp1)(c.in + (size_t)(uint32_t)idx), (mx_lfp3)(buf + k * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((mx_gfp1)(from + (size_t)(uint32_t)idx), (mx_lfp3)(buf + k * 256), 16, 0, 0);
     }
 }
 
@@ -585,7 +586,7 @@ __device__ __forceinline__ EqK eq_constants(const EqDesc& d, const EqRun& r) {
 // compute phase over my row of the tile: ENVK as in eq_spec_span (0: no inline Envelope)
 template <int SB, int MODE, int ENVK, bool WARM, bool FC, bool LO_ONLY = false>   // WARM: `len` is the (negative) chunk-relative index of the lane's first warm-up sample; LO_ONLY: the early part of a warm-up, where only the slow cascade runs
 __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const int lane, const int so, const int len,
-                                                const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
+                                                const EnvTick& cur, const EnvLane& el, EqPoles& s, uint32_t& xmin, uint32_t& xmax, const float* cbuf = nullptr /* EQM_AMP_CTL: the control's tile */) {
     const double g_lo = K.g_lo, g_mid = K.g_mid, g_hi = K.g_hi, lo_f = K.lo_f, hi_f = K.hi_f;
     const double one_minus = K.one_minus, mod_depth = K.mod_depth, amplitude = K.amplitude;
     const double depth_const = one_minus + mod_depth * 1.0;           // Disconnected control: mod value 1.0 (amplifier.rs:54)
@@ -605,7 +606,8 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
                 for (int e = 0; e < 4; ++e) { pump<FC>(lo_f, s.lo, dx[e]); if (!LO_ONLY) pump<FC>(hi_f, s.hi, dx[e]); }
             } else {
                 const double hh[4] = {s.h0, s.h1, s.h2, dx[0]};
-                f4v v;
+                f4v v, c4 = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == EQM_AMP_CTL) c4 = reinterpret_cast<const f4v*>(cbuf + lane * SB)[pce ^ sw];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t b = __float_as_uint(x4[e]); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
@@ -615,6 +617,7 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
                         double depth;
                         const uint32_t kk = (uint32_t)(so + 4 * pce + e);      // sample index inside the chunk; el.dt0 counts from the tick's first sample
                         if (MODE == EQM_AMP_CONST) depth = depth_const;
+                        else if (MODE == EQM_AMP_CTL) depth = amp_depth<FC>(one_minus, mod_depth, (double)c4[e]);   // amplifier.rs:54,71-73
                         else if (ENVK == 1) depth = el.depth;
                         else if (ENVK == 2) depth = env_lane_depth<FC>(K.env, el, kk - el.k0, one_minus, mod_depth, K.sr, K.rsr);
                         else depth = env_depth<FC>(K.env, cur, one_minus, mod_depth, el.t_chunk + kk, K.sr, K.rsr);
@@ -747,6 +750,7 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
         if constexpr (NBUF == 1) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage-out's reads of the tile are done before the DMA may land on it
             eq_tile_issue<SB>(c, eq_tiles, so);
+            if constexpr (KMODE == EQM_AMP_CTL) { if (so >= 0) eq_tile_issue<SB>(c, eq_tiles + EQ_TILE, so, d.ctl); }   // the control of the same samples, into a tile of its own
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return eq_tiles;
         }
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
         for (; g < total; ++g) {
             float* buf = begin_sb(g);
             const int so = (g - n_warm) * EQ_SB;
-            eq_tile_compute<SB, KMODE, 0, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax);
+            eq_tile_compute<SB, KMODE, 0, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax, KMODE == EQM_AMP_CTL ? buf + EQ_TILE : nullptr);
             eq_tile_store<SB, KSTEREO != 0>(c, buf, so);
         }
     }
@@ -1289,7 +1293,7 @@ static size_t eq_warm_len(double f) {
     return (size_t)-1;
 }
 
-bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan, bool whole_ticks) {
+bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan, bool whole_ticks, bool two_tiles) {
     plan = EqSpecPlan{1u, 0u, 0u, 0u, 0u};
     if (!n || !frames) return false;
     size_t W = std::max(eq_warm_len(lo_f), eq_warm_len(hi_f));
@@ -1325,9 +1329,12 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
         // or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
         auto cost = [&](size_t nc) {
             const double waves = (double)n * (double)((nc + 63) / 64);
-            const double rounds = std::ceil(waves / 4096.0);
-            const double occ = waves / (rounds * 4096.0);
-            return ((double)nc * (double)(chunk_of(nc) + W)) / occ;     // ~ frames + nc * W, with the chunk rounding
+            const double resident = two_tiles ? 2560.0 : 4096.0;      // 16 KiB of LDS per wave (input + control tile): ten waves per CU instead of sixteen
+            const double rounds = std::ceil(waves / resident);
+            const double occ = waves / (rounds * resident);
+            // (a second round does not start until slots of the first free up wave by wave, and its tail runs on a half-empty chip: measured with the control tile,
+            // 293 chunks in two rounds 6.75 ms against 128 in one 5.96 ms where this model without the factor called them equal)
+            return ((double)nc * (double)(chunk_of(nc) + W)) / occ * (two_tiles ? 1.0 + 0.15 * (rounds - 1.0) : 1.0);     // ~ frames + nc * W, with the chunk rounding
         };
         best = std::min<size_t>(64, nc_max);
         double best_cost = cost(best);
@@ -1380,7 +1387,10 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     // ragged ticks (RT instantiations): an inline Envelope at a rate whose tick is not whole super-blocks (44.1 kHz: 735) -- chunks of whole ticks, multiples of 4 samples
     const bool rt = !no_tiles && (um == 6 || um == 7) && r.fpc >= 32 && r.fpc % 32 != 0 && plan.chunk % r.fpc == 0 && plan.chunk % 4 == 0 && r.frames % 4 == 0 &&
                     plan.warm % 32 == 0 && r.frames < (1ull << 30) && r.frames >= 4;
-    const bool tiled = rt || (!no_tiles && um >= 0 && um != 4 && um != 5 && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
+    // a control BUFFER (um 4 / 5: an Amplifier modulated by another module's output -- an LFO, an Envelope that is not folded in): the control of a super-block travels
+    // through a second tile beside the input's (one tile each, 16 KiB per wave: ten waves per CU); the direct form it had until round 4: 33 ms per step where this takes 6
+    const bool ctl_tiled = env_int("MX_EQ_CTL_DIRECT", 0) == 0;
+    const bool tiled = rt || (!no_tiles && um >= 0 && (ctl_tiled || (um != 4 && um != 5)) && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
                        r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0)));
     if (tiled) {
         static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
@@ -1391,6 +1401,12 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
                       else if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
                       else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
+        if (um == 4 || um == 5) {
+            const size_t lds2 = (size_t)2 * 64 * 32 * sizeof(float);
+#define MX_GCT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_CTL, S, F, 1>), dim3(n * wpi), dim3(64), lds2, s, d, (const EqState*)st, r, plan, wpi, recs)
+            if (um == 4) { if (r.fc) MX_GCT(0, true); else MX_GCT(0, false); } else { if (r.fc) MX_GCT(1, true); else MX_GCT(1, false); }
+#undef MX_GCT
+        } else
         if (rt) {   // one tile of whole 16-byte rows (the rows of such chunks are not line-aligned either way)
             const size_t lds1 = (size_t)64 * 32 * sizeof(float);
 #define MX_GRT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_ENV, S, F, 1, true>), dim3(n * wpi), dim3(64), lds1, s, d, (const EqState*)st, r, plan, wpi, recs)

@@ -113,7 +113,8 @@ void launch_eq_three_scan(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
                           const EqScanTab* tabs /* 4 tables: L = 4, 8, 16, 32 */, const EqSplit& split, const EqSpanPow& pp, hipStream_t s);
 // speculative time-parallel EXACT mode (k_eq_three_spec + k_eq_three_repair): see mx_k_eq_three.hip
 struct EqSpecPlan { uint32_t n_chunks; uint32_t chunk; uint32_t warm; uint32_t pad; uint32_t warm_hi /* the high cascade runs over the last warm_hi samples of a warm-up only (tiled kernel) */; };
-bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan, bool whole_ticks = false /* an inline Envelope: chunks of whole ticks at any rate */);   // false: one lane per instance (launch_eq_three_exact)
+bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan, bool whole_ticks = false /* an inline Envelope: chunks of whole ticks at any rate */,
+                  bool two_tiles = false /* a control buffer: input and control tile per wave, ten waves per CU */);   // false: one lane per instance (launch_eq_three_exact)
 size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan);
 int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl);   // 0..7: (epilogue kind) * 2 + (stereo store); the specialisation key
 void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode /* 0..7, or -1: mixed */,

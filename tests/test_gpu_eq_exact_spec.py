@@ -284,6 +284,54 @@ def test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate):
     assert ran > 0
 
 
+@pytest.mark.parametrize("rate", RATES)
+@pytest.mark.parametrize("chunks", ["0", "130"])
+def test_spec_eq_amplifier_modulated_by_a_buffer_takes_the_control_through_its_own_tile(rate, chunks, monkeypatch):
+    """EqThree -> StereoPanner -> Amplifier whose control is another module's OUTPUT (an oscillator as LFO shared by several strips, a source per strip, an
+    Envelope that cannot be folded in because two Amplifiers read it): the tiled speculative kernel stages the control of every super-block in a second
+    tile beside the input's (until round 4 this mode kept the direct-load kernel: 7x slower).  Long runs, state carried, stereo and Mixer-only (one float per
+    frame) stores, the planner's chunking and a forced one whose last chunk is ragged; MX_EQ_CTL_DIRECT=1 (the old form) gives the same bits."""
+    SR, SPT = rate
+    T = 160
+    monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", chunks)
+    ws = Workspace(SR, 60)
+    lfo = ws.oscillator(3.0, abi.WAVE_TRIANGLE)
+    trig = ws.trigger(True); env = ws.envelope(5.0, 60.0, 0.5, 30.0); ws.connect(trig, 0, env, 0)
+    src, ctl_src, outs = [], ws.source_mono(), []
+    mix = ws.mixer([(0.0, 1.0, k % 2 == 0) for k in range(3)])
+    for k in range(6):
+        s = ws.source_mono(); e = ws.eq_three(2.0 - k, 0.5 * k, -1.0 + k); p = ws.stereo_panner(); a = ws.amplifier(0.8 + 0.1 * k, 0.2 + 0.15 * k)
+        ws.connect(s, 0, e, 0); ws.connect(e, 0, p, 0); ws.connect(e, 0, p, 1); ws.connect(p, 0, a, 0)
+        ws.connect([lfo, lfo, ctl_src, env, env, lfo][k], 0, a, 1)         # env feeds two Amplifiers: not folded, a buffer like the others
+        if k < 3:
+            ws.connect(a, 0, mix, k)                                        # read by a Mixer only: stored as one float per frame
+        else:
+            outs.append(a)                                                  # a terminal: stored as stereo
+        src.append(s)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    for run in range(2):
+        x = [synth.noise(900 + 7 * run + k, T * SPT) for k in range(6)]
+        cx = synth.noise(950 + run, T * SPT)
+        for s_, v in zip(src, x):
+            g.write_source(s_, v, T)
+        g.write_source(ctl_src, cx, T)
+        g.schedule_params(trig, 40, abi.TriggerParams(run)); g.schedule_params(trig, 90, abi.TriggerParams(1 - run))
+        g.run_ticks(run * T, T)
+        got = [g.read_output(mix, 0, T, True), g.read_output(mix, 1, T, True)] + [g.read_output(a, 0, T, True) for a in outs]
+        for t in range(T):
+            if t == 40: og.update_params(trig, abi.TriggerParams(run))
+            if t == 90: og.update_params(trig, abi.TriggerParams(1 - run))
+            for s_, v in zip(src, x):
+                og.set_source(s_, v[t * SPT:(t + 1) * SPT])
+            og.set_source(ctl_src, cx[t * SPT:(t + 1) * SPT])
+            og.run_tick(run * T + t)
+            want = [og.output(mix, 0), og.output(mix, 1)] + [og.output(a, 0) for a in outs]
+            for k, (gv, w) in enumerate(zip(got, want)):
+                assert_bit_exact(gv[t * w.size:(t + 1) * w.size], w, f"run {run} output {k} tick {t}")
+    assert g.eq_spec_stats()[0] > 0
+
+
 @pytest.mark.parametrize("env_p", [(25.0, 500.0, 0.8, 200.0), (0.0, 100.0, 0.5, 50.0), (5.0, 0.0, 0.7, 0.0), (10.0, 40.0, 1.5, 30.0),
                                    (3.0, 20.0, -0.25, 15.0), (1e-3, 1e-3, 0.0, 1e-3), (400.0, 3000.0, 0.3, 2500.0)])
 @pytest.mark.parametrize("rate", RATES)

@@ -77,6 +77,11 @@ def test_contracted_spec_eq_every_fused_epilogue(rate, contracted):
     spec.test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate)
 
 
+@pytest.mark.parametrize("rate", RATES)
+def test_contracted_spec_eq_amplifier_modulated_by_a_buffer(rate, contracted, monkeypatch):
+    spec.test_spec_eq_amplifier_modulated_by_a_buffer_takes_the_control_through_its_own_tile(rate, "0", monkeypatch)
+
+
 @pytest.mark.parametrize("env_p", [(25.0, 500.0, 0.8, 200.0), (0.0, 100.0, 0.5, 50.0), (10.0, 40.0, 1.5, 30.0), (3.0, 20.0, -0.25, 15.0)])
 @pytest.mark.parametrize("rate", RATES)
 def test_contracted_spec_eq_inline_envelope_with_unusual_parameters(env_p, rate, contracted):

@@ -1,0 +1,38 @@
+"""What a strip costs whose Amplifier is modulated by a BUFFER (an oscillator as LFO) instead of an inline Envelope: 1024 strips x T ticks.  usage: python tools/ctl_probe.py [T] [flags]"""
+import pathlib, sys, time
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
+import synth
+from mixlab_amd import abi
+from mixlab_amd.workspace import Workspace
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+n = 1024
+for kind in ("env", "lfo", "none"):
+    ws = Workspace(48000, 60)
+    mix = ws.mixer([(0.0, 0.5, False)] * n)
+    srcs = []
+    lfo = ws.oscillator(2.0, abi.WAVE_TRIANGLE) if kind == "lfo" else None
+    for k in range(n):
+        s = ws.source_mono(); e = ws.eq_three(1.0, -2.0, 3.0); p = ws.stereo_panner(); a = ws.amplifier(1.0, 0.5)
+        ws.connect(s, 0, e, 0); ws.connect(e, 0, p, 0); ws.connect(e, 0, p, 1); ws.connect(p, 0, a, 0)
+        if kind == "env":
+            tr = ws.trigger(True); en = ws.envelope(); ws.connect(tr, 0, en, 0); ws.connect(en, 0, a, 1)
+        elif kind == "lfo":
+            ws.connect(lfo, 0, a, 1)
+        ws.connect(a, 0, mix, k); srcs.append(s)
+    g = ws.build(max_ticks_per_run=T, flags=flags)
+    blk = synth.noise(1, 256 * ws.spt)
+    x = np.tile(blk, (T + 255) // 256)[: T * ws.spt]
+    for s in srcs:
+        g.write_source(s, x, T)
+    g.run_ticks(0, T); g.sync()
+    t0 = time.perf_counter()
+    for i in range(1, 4):
+        g.run_ticks(i * T, T)
+    g.sync()
+    dt = (time.perf_counter() - t0) / 3
+    print(kind, f"{dt * 1e3:.2f} ms per step, {n * T / dt / 1e6:.1f} M channel-ticks/s", g.eq_spec_stats(), flush=True)
+    g.close()
