@@ -213,21 +213,34 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     }
     for (Node& n : nodes_) { n.out_elided.assign(n.out_type.size(), 0); n.out_dup.assign(n.out_type.size(), 0); }
     if (!(flags_ & MX_FLAG_NO_FUSE)) plan_fusion();
-    // groups: (level, kind); nodes folded into another node's kernel are never launched
+    // groups: (level, kind); nodes folded into another node's kernel are never launched.  EqThree nodes also by the epilogue the compiler gave them (plain, -> Panner,
+    // -> Amplifier with a constant / a buffer / an inline Envelope as control; stereo or one float per frame): a launch group of ONE mode takes the kernel
+    // specialised for it -- sixteen strips of another mode among a thousand put the whole group on the general direct-load form (29 ms against 5, tools/ctl_probe.py)
+    auto eq_key = [&](const Node& nd) -> int {
+        if (nd.kind != MX_KIND_EQ_THREE) return 0;
+        const uint32_t epi = nd.fuse_amp >= 0 ? 2u : (nd.fuse_pan >= 0 ? 1u : 0u);
+        uint32_t fl = 0;
+        if (nd.fuse_amp >= 0 ? nodes_[nd.fuse_amp].out_dup[0] : (nd.fuse_pan >= 0 && nodes_[nd.fuse_pan].out_dup[0])) fl |= MX_EQF_MONO_DUP;
+        if (nd.fuse_env >= 0) fl |= MX_EQF_ENV;
+        const bool has_ctl = nd.fuse_amp >= 0 && nd.fuse_env < 0 && nodes_[nd.fuse_amp].in_src[1].node >= 0;
+        return 1 + eq_epilogue_mode(epi, fl, has_ctl);
+    };
+    for (Node& n : nodes_) n.sub_key = eq_key(n);
     std::vector<uint32_t> sorted;
     for (uint32_t id : order_) if (!nodes_[id].elided) sorted.push_back(id);
     std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
         if (nodes_[a].level != nodes_[b].level) return nodes_[a].level < nodes_[b].level;
         if (nodes_[a].kind != nodes_[b].kind) return nodes_[a].kind < nodes_[b].kind;
+        if (nodes_[a].sub_key != nodes_[b].sub_key) return nodes_[a].sub_key < nodes_[b].sub_key;
         const uint64_t da = ((uint64_t)nodes_[a].dom_num << 32) | nodes_[a].dom_den, db = ((uint64_t)nodes_[b].dom_num << 32) | nodes_[b].dom_den;
         return da < db;
     });
     for (uint32_t id : sorted) {
         Node& n = nodes_[id];
-        if (groups_.empty() || groups_.back().level != n.level || groups_.back().kind != n.kind ||
+        if (groups_.empty() || groups_.back().level != n.level || groups_.back().kind != n.kind || groups_.back().sub_key != n.sub_key ||
             groups_.back().dom_num != n.dom_num || groups_.back().dom_den != n.dom_den ||
             groups_.back().in_dom_num != n.in_dom_num || groups_.back().in_dom_den != n.in_dom_den) {
-            Group g; g.level = n.level; g.kind = n.kind;
+            Group g; g.level = n.level; g.kind = n.kind; g.sub_key = n.sub_key;
             g.dom_num = n.dom_num; g.dom_den = n.dom_den; g.in_dom_num = n.in_dom_num; g.in_dom_den = n.in_dom_den;
             groups_.push_back(std::move(g));
         }

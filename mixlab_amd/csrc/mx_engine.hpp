@@ -35,6 +35,7 @@ struct Node {
     uint32_t in_dom_num = 1, in_dom_den = 1;  // ... of the input ports
     uint32_t slot = 0;                        // index inside its (level, kind) group
     int group = -1;
+    int sub_key = 0;                          // EQ_THREE: 1 + the epilogue mode the graph compiler gave the node (launch groups are of one mode); 0 otherwise
     // parameter updates queued for ticks inside the next run (Engine::client_update between two ticks, src/engine.rs:192-214)
     struct SchedEv { uint32_t tick; std::vector<uint8_t> params; };
     std::vector<SchedEv> sched;
@@ -77,6 +78,7 @@ struct Node {
 struct Group {
     int level = 0;
     uint32_t kind = 0;
+    int sub_key = 0;
     uint32_t dom_num = 1, dom_den = 1, in_dom_num = 1, in_dom_den = 1;   // every node of a group shares one rate domain
     uint32_t max_taps = 0;   // Fir / Resample: most taps; Mixer: most channels
     uint32_t rs_common_taps = 0, rs_common_down = 0;   // ... and their taps per phase / decimation factor, likewise
