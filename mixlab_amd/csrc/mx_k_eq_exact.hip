@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void eq_nan_fill(const EqDesc& d, const EqRun& r, con
 constexpr int EQ_ISLANDS = 16;
 template <bool FC>
 __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict__ descs, EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
-                                                         const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats) {
+                                                         const EqChunkRec* __restrict__ recs, unsigned long long* __restrict__ stats, uint32_t tail) {
     const uint32_t inst = blockIdx.x;
     const int lane = threadIdx.x, grp = lane >> 2;
     const EqDesc& d = descs[inst];
@@ -1265,7 +1265,19 @@ __global__ __launch_bounds__(64) void k_eq_three_repair(const EqDesc* __restrict
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { st.lo[k] = E[k]; st.hi[k] = E[4 + k]; }
-    const size_t F = r.frames;
+    size_t F = r.frames;
+    if (tail) {   // the one to three samples behind the last whole piece (launcher), from the exact state, through the same epilogue
+        EqBlkEmit<FC> em; em.init(d, r, inst); em.seek(F);
+        double lo[4] = {E[0], E[1], E[2], E[3]}, hi[4] = {E[4], E[5], E[6], E[7]};
+        for (uint32_t k = 0; k < tail; ++k) {
+            const double x = (double)d.in[F + k];
+            pump<FC>(r.lo_f, lo, x); pump<FC>(r.hi_f, hi, x);
+            em.emit(F + k, eq_out_of<FC>(lo[3], hi[3], (double)d.in[F + k - 3], d.gain_lo, d.gain_mid, d.gain_hi));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { st.lo[k] = lo[k]; st.hi[k] = hi[k]; }
+        F += tail;
+    }
     st.history[0] = (double)d.in[F - 3]; st.history[1] = (double)d.in[F - 2]; st.history[2] = (double)d.in[F - 1];   // F >= 2 warm-ups >= 3 samples
     states[inst] = st;
     if (stats) {   // [0] chunks run, [1] not proven by their recorded start, [2] of those settled by the O(1) comparison, [3] walk steps (EQ_RB samples), [4] fill steps,
@@ -1365,9 +1377,18 @@ int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl) {
     return mode * 2 + stereo;
 }
 
-void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode, void* scratch, uint64_t* stats, hipStream_t s) {
-    if (!n || !r.frames) return;
-    const uint32_t wpi = (plan.n_chunks + 63) / 64;
+void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r_in, const EqSpecPlan& plan_in, int uniform_mode, void* scratch, uint64_t* stats, hipStream_t s) {
+    if (!n || !r_in.frames) return;
+    // A stream that is not whole pieces of four samples (735 t frames at 44.1 kHz with t not a multiple of 4): the tiled kernel runs the frames up to the last
+    // multiple of four, and the proof / repair kernel -- which ends up holding the exact state there -- walks the one to three samples left (`tail`).
+    EqRun r = r_in; EqSpecPlan plan = plan_in;
+    uint32_t tail = (uint32_t)(r_in.frames & 3u);
+    if (tail) {
+        r.frames = r_in.frames - tail;
+        plan.n_chunks = (uint32_t)((r.frames + plan.chunk - 1) / plan.chunk);
+        if (plan.n_chunks < 2) { r = r_in; plan = plan_in; tail = 0; }
+    }
+    uint32_t wpi = (plan.n_chunks + 63) / 64;
     EqChunkRec* recs = (EqChunkRec*)scratch;
     // MX_EQ_REPAIR_TEST (tests only; never changes a result bit, only which path produces it): 1 = a standing pair of trajectories is treated as if its
     // outputs differed (the comparison that settles a constant chunk is skipped, the rest of the chunk is FILLED from the true state); 2 = every island is
@@ -1392,6 +1413,7 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     const bool ctl_tiled = env_int("MX_EQ_CTL_DIRECT", 0) == 0;
     const bool tiled = rt || (!no_tiles && um >= 0 && (ctl_tiled || (um != 4 && um != 5)) && r.frames % 4 == 0 && plan.chunk % 32 == 0 && plan.warm % 32 == 0 &&
                        r.frames < (1ull << 30) && r.frames >= 4 && ((um != 6 && um != 7) || (r.fpc % 32 == 0 && plan.chunk % r.fpc == 0)));
+    if (!tiled && tail) { r = r_in; plan = plan_in; tail = 0; wpi = (plan.n_chunks + 63) / 64; }   // the direct form takes any length itself
     if (tiled) {
         static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
         const size_t lds = std::max<size_t>((sb == 321 ? 1 : 2) * 64 * (size_t)(sb == 321 ? 32 : sb) * sizeof(float), (size_t)lds_pad);
@@ -1432,8 +1454,9 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
 #undef MX_GO
     }
     // the proof (and, where a boundary fails, the repair) runs the same order the chunks ran
-    if (r.fc) hipLaunchKernelGGL(k_eq_three_repair<true>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats);
-    else hipLaunchKernelGGL(k_eq_three_repair<false>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats);
+    plan_t.n_chunks = plan.n_chunks;
+    if (r.fc) hipLaunchKernelGGL(k_eq_three_repair<true>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats, tail);
+    else hipLaunchKernelGGL(k_eq_three_repair<false>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats, tail);
 }
 
 }  // namespace mx

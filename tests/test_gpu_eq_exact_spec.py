@@ -284,6 +284,48 @@ def test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate):
     assert ran > 0
 
 
+@pytest.mark.parametrize("T", [30, 50, 101, 33])
+def test_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(T):
+    """735 T frames at 44.1 kHz are a multiple of four only when T is: the tiled kernel takes the frames up to the last multiple of four and the proof / repair
+    kernel walks the one to three samples left from the exact state it ends up with, through the same epilogue (until round 4 such a submission fell back to the
+    direct-load kernel).  Plain EQ, EQ -> Panner -> Amplifier with an inline Envelope (ragged ticks) and with a control buffer; three runs, state carried."""
+    SR, SPT = 44100, 735
+    ws = Workspace(SR, 60)
+    src = [ws.source_mono() for _ in range(3)]; ctl_src = ws.source_mono()
+    eq = [ws.eq_three(1.0 + k, -2.0 * k, 0.5 * k) for k in range(3)]
+    for s_, e in zip(src, eq):
+        ws.connect(s_, 0, e, 0)
+    pan = [ws.stereo_panner() for _ in range(2)]
+    for k in range(2):
+        ws.connect(eq[k + 1], 0, pan[k], 0); ws.connect(eq[k + 1], 0, pan[k], 1)
+    trig = ws.trigger(True); env = ws.envelope(5.0, 80.0, 0.6, 40.0); amp_env = ws.amplifier(1.1, 0.7)
+    ws.connect(pan[0], 0, amp_env, 0); ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp_env, 1)
+    amp_buf = ws.amplifier(0.9, 0.4); ws.connect(pan[1], 0, amp_buf, 0); ws.connect(ctl_src, 0, amp_buf, 1)
+    g = ws.build(max_ticks_per_run=T)
+    og = oracle.OracleGraph(ws)
+    outs = [(eq[0], False), (amp_env, True), (amp_buf, True)]
+    for run in range(3):
+        x = [synth.noise(1200 + 5 * run + k, T * SPT) for k in range(3)]
+        cx = np.abs(synth.noise(1250 + run, T * SPT))
+        for s_, v in zip(src, x):
+            g.write_source(s_, v, T)
+        g.write_source(ctl_src, cx, T)
+        g.schedule_params(trig, T // 3, abi.TriggerParams(run % 2)); g.schedule_params(trig, 2 * T // 3, abi.TriggerParams(1 - run % 2))
+        g.run_ticks(run * T, T)
+        got = [g.read_output(nd, 0, T, st) for nd, st in outs]
+        for t in range(T):
+            if t == T // 3: og.update_params(trig, abi.TriggerParams(run % 2))
+            if t == 2 * T // 3: og.update_params(trig, abi.TriggerParams(1 - run % 2))
+            for s_, v in zip(src, x):
+                og.set_source(s_, v[t * SPT:(t + 1) * SPT])
+            og.set_source(ctl_src, cx[t * SPT:(t + 1) * SPT])
+            og.run_tick(run * T + t)
+            for k, (nd, _st) in enumerate(outs):
+                w = og.output(nd, 0)
+                assert_bit_exact(got[k][t * w.size:(t + 1) * w.size], w, f"T {T} run {run} output {k} tick {t}")
+    assert g.eq_spec_stats()[0] > 0
+
+
 @pytest.mark.parametrize("rate", RATES)
 @pytest.mark.parametrize("chunks", ["0", "130"])
 def test_spec_eq_amplifier_modulated_by_a_buffer_takes_the_control_through_its_own_tile(rate, chunks, monkeypatch):

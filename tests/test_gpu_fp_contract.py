@@ -77,6 +77,10 @@ def test_contracted_spec_eq_every_fused_epilogue(rate, contracted):
     spec.test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate)
 
 
+def test_contracted_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(contracted):
+    spec.test_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(50)
+
+
 @pytest.mark.parametrize("rate", RATES)
 def test_contracted_spec_eq_amplifier_modulated_by_a_buffer(rate, contracted, monkeypatch):
     spec.test_spec_eq_amplifier_modulated_by_a_buffer_takes_the_control_through_its_own_tile(rate, "0", monkeypatch)

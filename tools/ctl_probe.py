@@ -10,16 +10,18 @@ from mixlab_amd.workspace import Workspace
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = 1024
-for kind in ("env", "lfo", "none", "mixed", "mixed2"):
+for kind in ("env", "lfo", "none", "mixed", "mixed2", "envgate"):
     ws = Workspace(48000, 60)
     mix = ws.mixer([(0.0, 0.5, False)] * n)
     srcs = []
-    lfo = ws.oscillator(2.0, abi.WAVE_TRIANGLE) if kind == "lfo" else None
+    lfo = ws.oscillator(2.0, abi.WAVE_TRIANGLE) if kind == "lfo" else (ws.oscillator(1.5, abi.WAVE_SQUARE) if kind == "envgate" else None)
     for k in range(n):
         s = ws.source_mono(); e = ws.eq_three(1.0, -2.0, 3.0); p = ws.stereo_panner(); a = ws.amplifier(1.0, 0.5)
         ws.connect(s, 0, e, 0); ws.connect(e, 0, p, 0); ws.connect(e, 0, p, 1); ws.connect(p, 0, a, 0)
         if kind == "env" or (kind == "mixed" and k % 64 != 0):      # mixed: one strip in 64 has no Envelope on its Amplifier -- another epilogue mode in the same launch group
             tr = ws.trigger(True); en = ws.envelope(); ws.connect(tr, 0, en, 0); ws.connect(en, 0, a, 1)
+        elif kind == "envgate":                    # an Envelope per strip whose gate is a module's OUTPUT (a square LFO), not a Trigger: a state machine over the samples
+            en = ws.envelope(); ws.connect(lfo, 0, en, 0); ws.connect(en, 0, a, 1)
         elif kind == "lfo":
             ws.connect(lfo, 0, a, 1)
         if kind == "mixed2" and k % 64 == 0:      # one strip in 64 goes from its StereoPanner straight to the Mixer: epilogue "panner" among 63 "amplifier, constant depth"
@@ -38,5 +40,6 @@ for kind in ("env", "lfo", "none", "mixed", "mixed2"):
         g.run_ticks(i * T, T)
     g.sync()
     dt = (time.perf_counter() - t0) / 3
+    prof = ""
     print(kind, f"{dt * 1e3:.2f} ms per step, {n * T / dt / 1e6:.1f} M channel-ticks/s", g.eq_spec_stats(), flush=True)
     g.close()
