@@ -1321,6 +1321,7 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     // lane of a wave crosses its tick boundaries at the same step), else multiples of 32 samples.
     // With an inline Envelope (whole_ticks) chunks are whole ticks at ANY rate, in multiples that keep them multiples of 4 samples: 735 -> 2 940 (44.1 kHz), 800 -> 800.
     size_t unit = (fpc && fpc % 16 == 0 && fpc <= frames / 2) ? fpc : 32;
+    if (!whole_ticks && unit % 32) unit = 32;                 // (ticks of 16 (mod 32) samples: only the inline Envelope needs whole ticks, everybody else whole lines)
     if (whole_ticks && fpc >= 32 && fpc % 16 != 0) {
         size_t u = fpc; while (u % 4) u += fpc;
         if (u <= frames / 2) unit = u;
