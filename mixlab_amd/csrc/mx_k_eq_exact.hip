@@ -543,8 +543,15 @@ struct EqTileCtx {
     int base[8];
 };
 
+// ALIGNED ROWS (the RT instantiations).  A chunk of 5 880 samples (eight ticks of 735) begins 0 / 96 / 64 / 32 bytes into a 128-byte line: a row of the tile that
+// starts AT the chunk's begin straddles two lines in every super-block, and the other half of each is wanted one super-block later, when the L2 has turned over --
+// 12.9 GB fetched per launch for 7.4 needed (PMC).  So a row's grid starts at the LINE its chunk begins in: the chunk's sample i sits at tile position i + shift,
+// shift = (chunk * C) mod 32 samples (a multiple of 4: whole pieces); every DMA row is a whole line again, and what differs per lane is only where its chunk starts and
+// ends inside the first and the last super-block, and where inside a super-block its ticks end (tile positions differ by the shifts: multiples of 4 up to 28 -- 0 / 24 / 16 / 8 for chunks of 5 880 samples).
+__device__ __forceinline__ int eq_row_shift(uint32_t chunk, uint32_t C) { return (int)(((chunk & 31u) * (C & 31u)) & 31u); }
+
 // stage-in of the super-block whose first sample sits `so` samples from each chunk's begin (negative during the warm-up)
-template <int SB>
+template <int SB, bool ALIGN_ROWS = false>
 __device__ __forceinline__ void eq_tile_bases(EqTileCtx& c) {
     typedef EqTileGeo<SB> G;
     const int s = c.lane % G::S;
@@ -552,7 +559,7 @@ __device__ __forceinline__ void eq_tile_bases(EqTileCtx& c) {
     for (int k = 0; k < G::N_INSTR; ++k) {
         const int cj = G::ROWS * k + c.lane / G::S;
         const int pce = s ^ G::sw(cj);                                // the piece that belongs in slot s of row cj
-        const long long b = (long long)(c.chunk0 + (uint32_t)cj) * (long long)c.C + 4 * pce;
+        const long long b = (long long)(c.chunk0 + (uint32_t)cj) * (long long)c.C + 4 * pce - (ALIGN_ROWS ? eq_row_shift(c.chunk0 + (uint32_t)cj, c.C) : 0);
         c.base[k] = (int)(b > 0x3fffffffLL ? 0x3fffffffLL : b);       // lanes beyond the stream: any legal value (clamped again below, never used)
     }
 }
@@ -632,11 +639,11 @@ __device__ __forceinline__ void eq_tile_compute(const EqK& K, float* buf, const 
     }
 }
 
-// The samples [i_lo, i_hi) (chunk-relative) of a super-block, one at a time, in the general Envelope form: the super-block in which a tick ends when ticks are not
-// whole super-blocks (735 samples at 44.1 kHz).  Every lane of the wave crosses the boundary at the same sample (chunks are whole ticks), so the range is
-// wave-uniform; the caller runs the part before the boundary with the old tick's state, loads the new one, and runs the rest.  Samples outside the range keep what
-// the tile holds: outputs already made, or inputs still to come.  One super-block in 23 takes this path.
-template <int SB, int MODE, bool FC>
+// The samples of a super-block whose chunk-relative index lies in [i_lo, i_hi), one at a time, in the general Envelope form: the first super-block of a chunk (the
+// samples before index 0 are still warm-up: OUT = false, the recurrence only), and the one or two super-blocks in which a tick ends (the samples before the boundary
+// with the old tick's state, the rest with the new one's).  `so` is the chunk-relative index of the lane's first tile sample -- per lane with aligned rows; the bounds
+// are wave-uniform.  Samples outside the range keep what the tile holds: outputs already made, or inputs still to come.
+template <int SB, int MODE, bool FC, bool OUT = true>
 __device__ __forceinline__ void eq_tile_compute_range(const EqK& K, float* buf, const int lane, const int so, const int len, const int i_lo, const int i_hi,
                                                       const EnvTick& cur, const uint64_t t_chunk, EqPoles& s, uint32_t& xmin, uint32_t& xmax) {
     typedef EqTileGeo<SB> G;
@@ -645,38 +652,45 @@ __device__ __forceinline__ void eq_tile_compute_range(const EqK& K, float* buf, 
 #pragma unroll 1
     for (int pce = 0; pce < G::S; ++pce) {
         const int base = so + 4 * pce;
-        if (base + 4 <= i_lo || base >= i_hi) continue;               // wave-uniform
-        if (base < len) {                                             // len is a multiple of 4
+        if (base + 4 > i_lo && base < i_hi && base < len) {           // len is a multiple of 4
             f4v v = row[pce ^ sw];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (base + e >= i_lo && base + e < i_hi) {            // wave-uniform
-                    const uint32_t b = __float_as_uint(v[e]); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
-                    const float y = eq_step<FC>(s, K.lo_f, K.hi_f, K.g_lo, K.g_mid, K.g_hi, v[e]);
-                    const double depth = env_depth<FC>(K.env, cur, K.one_minus, K.mod_depth, t_chunk + (uint64_t)(base + e), K.sr, K.rsr);
-                    v[e] = MODE == EQM_AMP_ENV ? amp_apply(y, depth, K.amplitude) : y;
+                if (base + e >= i_lo && base + e < i_hi) {
+                    if (OUT) {
+                        const uint32_t b = __float_as_uint(v[e]); xmin = b < xmin ? b : xmin; xmax = b > xmax ? b : xmax;
+                        const float y = eq_step<FC>(s, K.lo_f, K.hi_f, K.g_lo, K.g_mid, K.g_hi, v[e]);
+                        const double depth = env_depth<FC>(K.env, cur, K.one_minus, K.mod_depth, t_chunk + (uint64_t)(base + e), K.sr, K.rsr);
+                        v[e] = MODE == EQM_AMP_ENV ? amp_apply(y, depth, K.amplitude) : y;
+                    } else {
+                        const double x = (double)v[e];
+                        pump<FC>(K.lo_f, s.lo, x); pump<FC>(K.hi_f, s.hi, x);
+                        s.h0 = s.h1; s.h1 = s.h2; s.h2 = x;
+                    }
                 }
             }
-            row[pce ^ sw] = v;
+            if (OUT) row[pce ^ sw] = v;
         }
     }
 }
 
 // stage-out of a computed tile: whole lines, eight lanes per chunk line
-// RAGGED: chunks that are not whole super-blocks (whole ticks of 735 samples at 44.1 kHz: 5 880 = 183.75 of them) end inside their last one, and the pieces beyond
-// the end are the NEXT chunk's first samples -- that chunk's lane writes them, this one must not (`pieces`: how many of the row's pieces are the chunk's, wave-uniform)
+// RAGGED (aligned rows, eq_row_shift): a row holds its chunk's samples at tile positions shift .. shift + C - 1; what lies before and behind them in the first and the
+// last super-block is the neighbouring chunks', whose lanes write it
 template <int SB, bool STEREO, bool RAGGED = false>
 __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* buf, int so) {
     typedef EqTileGeo<SB> G;
-    const int pieces = RAGGED ? ((int)c.C - so) >> 2 : G::S;
 #pragma unroll
     for (int k = 0; k < G::N_INSTR; ++k) {
         const f4v o = *reinterpret_cast<const f4v*>(buf + k * 256 + c.lane * 4);
         const int cj = G::ROWS * k + c.lane / G::S;
         const uint32_t chunk = c.chunk0 + (uint32_t)cj;
-        const int idx = c.base[k] + so;                               // so >= 0 here (stage-out only happens in the chunk proper)
+        const int idx = c.base[k] + so;                               // >= 0: stage-out only happens from the chunk's first super-block on
         bool mine = true;
-        if (RAGGED) mine = ((c.lane % G::S) ^ G::sw(cj)) < pieces;
+        if (RAGGED) {
+            const int i = so + 4 * ((c.lane % G::S) ^ G::sw(cj)) - eq_row_shift(chunk, c.C);   // chunk-relative index of this piece
+            mine = i >= 0 && i + 4 <= (int)c.C;
+        }
         if (mine && chunk < c.n_chunks && idx + 4 <= (int)c.F) {
             if (STEREO) {
                 f4v a = {o[0], o[0], o[1], o[1]}, b = {o[2], o[2], o[3], o[3]};   // stereo_panner.rs:35-38
@@ -703,13 +717,14 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
     c.in = d.in; c.out = d.out;
     c.chunk0 = (blockIdx.x % waves_per_inst) * 64u; c.n_chunks = plan.n_chunks; c.C = plan.chunk; c.F = (uint32_t)r.frames;
     c.lane = threadIdx.x;
-    eq_tile_bases<SB>(c);
+    eq_tile_bases<SB, RT>(c);
     const uint32_t j = c.chunk0 + threadIdx.x;
     const bool active = j < plan.n_chunks;
     const long long begin = (long long)j * c.C;
     const int len = active ? (int)((long long)c.F - begin < (long long)c.C ? (long long)c.F - begin : (long long)c.C) : 0;
     const int len0 = (int)((long long)c.F - (long long)c.chunk0 * c.C < (long long)c.C ? (long long)c.F - (long long)c.chunk0 * c.C : (long long)c.C);   // the wave's longest chunk (wave-uniform)
-    const int n_warm = (int)(plan.warm / EQ_SB), n_main = (len0 + EQ_SB - 1) / EQ_SB;
+    const int row_shift = RT ? eq_row_shift(j, c.C) : 0;   // aligned rows: my chunk's sample i sits at tile position i + row_shift
+    const int n_warm = (int)(plan.warm / EQ_SB), n_main = (len0 + (RT ? EQ_SB - 4 : 0) + EQ_SB - 1) / EQ_SB;
     const int total = n_warm + n_main;
 
     EqPoles s;
@@ -772,54 +787,70 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
     int g = 0;
     for (; g < n_lo; ++g) {
         float* buf = begin_sb(g);
-        eq_tile_compute<SB, EQM_PLAIN, 0, true, FC, true>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
+        eq_tile_compute<SB, EQM_PLAIN, 0, true, FC, true>(K, buf, c.lane, (g - n_warm) * EQ_SB - row_shift, warm_from, cur, el, s, xmin, xmax);
     }
     for (; g < n_warm; ++g) {
         float* buf = begin_sb(g);
-        eq_tile_compute<SB, EQM_PLAIN, 0, true, FC>(K, buf, c.lane, (g - n_warm) * EQ_SB, warm_from, cur, el, s, xmin, xmax);
+        eq_tile_compute<SB, EQM_PLAIN, 0, true, FC>(K, buf, c.lane, (g - n_warm) * EQ_SB - row_shift, warm_from, cur, el, s, xmin, xmax);
     }
-    if (active) {   // first sample of my chunk: record where the warm-up took me (chunks that started at the stream's start: the exact state)
+    if (!RT && active) {   // first sample of my chunk: record where the warm-up took me (chunks that started at the stream's start: the exact state)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
     }
     if constexpr (KMODE == EQM_AMP_ENV && RT) {
-        // Chunks are whole ticks (launcher), so every lane is at the same place inside its tick.  Where ticks are whole super-blocks too (48 kHz: 800 = 25 x 32) a tick
-        // is a run of super-blocks in one form; where they are not (44.1 kHz: 735) the super-block that holds a tick's end is walked sample by sample in the general
-        // form, the old tick's state before the boundary and the new one's behind it (eq_tile_compute_range), and the super-blocks between two boundaries as before.
+        // Chunks are whole ticks (launcher), so every lane is at the same place inside its tick -- in chunk-relative samples; its tile position is that plus its row's
+        // shift (aligned rows, eq_row_shift: 0 .. 28).  A super-block whose samples are one tick's for every lane runs in that tick's form as at 48 kHz; the first
+        // super-block of the chunk (the samples before the chunk's begin are the end of the warm-up) and the one or two in which a tick ends for some lane are walked
+        // sample by sample in the general form (eq_tile_compute_range), the old tick's state before the boundary and the new one's behind it.
         const int fpc = (int)r.fpc;
-        int tick_i = 0;                              // tick index inside the chunk
-        int so0 = 0;
-        auto load_tick = [&]() {                     // the Envelope state entering tick tick_i of every lane's chunk, per lane
+        int tick_i = 0, so0 = 0;
+        auto tick_at = [&](int ti) { const size_t tk = ((size_t)begin + (size_t)ti * (size_t)fpc) / r.fpc; return ticks[tk < r.n_calls ? tk : r.n_calls - 1]; };
+        // (a tick's EnvTick is fetched where it is used, not carried: eight registers that the per-sample loops of the other forms would have to leave alone)
+        const uint64_t t_chunk = r.t0 + (uint64_t)begin;
+        auto load_tick = [&]() {                     // the coefficients of tick tick_i of every lane's chunk, per lane
             so0 = tick_i * fpc;
-            const size_t tk = ((size_t)begin + (size_t)so0) / r.fpc;
-            cur = ticks[tk < r.n_calls ? tk : r.n_calls - 1];
-            const uint64_t t = r.t0 + (uint64_t)begin + (uint64_t)so0;
-            el = env_lane_coeffs(K.env, cur, t, r.fpc, nice);
-            el.k0 = (uint32_t)so0; el.t_chunk = r.t0 + (uint64_t)begin;
+            const EnvTick ct = tick_at(tick_i);
+            el = env_lane_coeffs(K.env, ct, t_chunk + (uint64_t)so0, r.fpc, nice);
+            el.k0 = (uint32_t)so0; el.t_chunk = t_chunk;
         };
         load_tick();
+        {   // the chunk's first super-block
+            float* buf = begin_sb(g);
+            const EnvTick cur0 = tick_at(0);
+            eq_tile_compute_range<SB, KMODE, FC, false>(K, buf, c.lane, -row_shift, len > 0 ? len : 4, -EQ_SB, 0, cur0, t_chunk, s, xmin, xmax);
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rec->start[k] = s.lo[k]; rec->start[4 + k] = s.hi[k]; }
+            }
+            eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, -row_shift, len, 0, 0x3fffffff, cur0, t_chunk, s, xmin, xmax);
+            eq_tile_store<SB, KSTEREO != 0, true>(c, buf, 0);
+            ++g;
+        }
         while (g < total) {
-            const int so_g = (g - n_warm) * EQ_SB;
-            const int t_end = so0 + fpc;             // first sample of the next tick
+            int so_g = (g - n_warm) * EQ_SB;
+            const int t_end = so0 + fpc;             // chunk-relative index of the next tick's first sample
             if (so_g + EQ_SB <= t_end) {
                 const int envk = __ballot(active && so0 < len && el.general != 0u) != 0ull ? 3 : (__ballot(active && so0 < len && el.flat == 0u) == 0ull ? 1 : 2);
-                const int g_int = n_warm + t_end / EQ_SB;                      // super-blocks that end at or before t_end
+                const int g_int = n_warm + t_end / EQ_SB;                      // super-blocks that end at or before t_end for the unshifted rows (the shifted ones end earlier)
                 const int g_end = g_int < total ? g_int : total;
                 if (envk == 1) {
-                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 1, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
+                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 1, false, FC>(K, buf, c.lane, so - row_shift, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
                 } else if (envk == 2) {
-                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 2, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
+                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 2, false, FC>(K, buf, c.lane, so - row_shift, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
                 } else {
-                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 3, false, FC>(K, buf, c.lane, so, len, cur, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
+                    const EnvTick cur3 = tick_at(tick_i);
+                    for (; g < g_end; ++g) { float* buf = begin_sb(g); const int so = (g - n_warm) * EQ_SB; eq_tile_compute<SB, KMODE, 3, false, FC>(K, buf, c.lane, so - row_shift, len, cur3, el, s, xmin, xmax); eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so); }
                 }
-                if (t_end % EQ_SB == 0) { ++tick_i; load_tick(); }             // the tick ended with its last super-block
             } else {
-                float* buf = begin_sb(g);
-                eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, so_g, len, so_g, t_end, cur, el.t_chunk, s, xmin, xmax);
+                // the tick ends inside this super-block for the rows with the smallest shift, up to 28 samples later for the others
+                const EnvTick now = tick_at(tick_i), nxt = tick_at(tick_i + 1);
+                for (; g < total && so_g - (EQ_SB - 4) < t_end; ++g, so_g += EQ_SB) {
+                    float* buf = begin_sb(g);
+                    eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, so_g - row_shift, len, -0x3fffffff, t_end, now, t_chunk, s, xmin, xmax);
+                    eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, so_g - row_shift, len, t_end, 0x3fffffff, nxt, t_chunk, s, xmin, xmax);
+                    eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so_g);
+                }
                 ++tick_i; load_tick();
-                eq_tile_compute_range<SB, KMODE, FC>(K, buf, c.lane, so_g, len, t_end, so_g + EQ_SB, cur, el.t_chunk, s, xmin, xmax);
-                eq_tile_store<SB, KSTEREO != 0, true>(c, buf, so_g);
-                ++g;
             }
         }
     } else if constexpr (KMODE == EQM_AMP_ENV) {

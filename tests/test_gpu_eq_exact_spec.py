@@ -284,11 +284,14 @@ def test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate):
     assert ran > 0
 
 
-@pytest.mark.parametrize("T", [30, 50, 101, 33])
-def test_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(T):
+@pytest.mark.parametrize("T,chunks", [(30, "0"), (50, "0"), (101, "0"), (33, "0"), (257, "8"), (257, "2"), (148, "3")])
+def test_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(T, chunks, monkeypatch):
     """735 T frames at 44.1 kHz are a multiple of four only when T is: the tiled kernel takes the frames up to the last multiple of four and the proof / repair
     kernel walks the one to three samples left from the exact state it ends up with, through the same epilogue (until round 4 such a submission fell back to the
-    direct-load kernel).  Plain EQ, EQ -> Panner -> Amplifier with an inline Envelope (ragged ticks) and with a control buffer; three runs, state carried."""
+    direct-load kernel).  Plain EQ, EQ -> Panner -> Amplifier with an inline Envelope (ragged ticks) and with a control buffer; three runs, state carried.
+    Forced chunk counts give chunks of 36 and 132 ticks, whose rows sit 28 samples into their lines: the largest shift of the aligned-row grid (a first version
+    assumed 24, the largest one the planner's own chunks have -- tools/stress_eq_shapes.py found it)."""
+    monkeypatch.setenv("MX_EQ_SPEC_CHUNKS", chunks)
     SR, SPT = 44100, 735
     ws = Workspace(SR, 60)
     src = [ws.source_mono() for _ in range(3)]; ctl_src = ws.source_mono()

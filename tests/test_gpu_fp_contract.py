@@ -77,8 +77,9 @@ def test_contracted_spec_eq_every_fused_epilogue(rate, contracted):
     spec.test_spec_eq_every_fused_epilogue_matches_the_oracle_graph(rate)
 
 
-def test_contracted_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(contracted):
-    spec.test_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(50)
+@pytest.mark.parametrize("T,chunks", [(50, "0"), (257, "8")])
+def test_contracted_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(T, chunks, contracted, monkeypatch):
+    spec.test_spec_eq_streams_that_are_not_whole_pieces_of_four_samples(T, chunks, monkeypatch)
 
 
 @pytest.mark.parametrize("rate", RATES)
