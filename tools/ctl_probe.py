@@ -35,11 +35,14 @@ for kind in ("env", "lfo", "none", "mixed", "mixed2", "envgate"):
     for s in srcs:
         g.write_source(s, x, T)
     g.run_ticks(0, T); g.sync()
+    g.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(1, 4):
         g.run_ticks(i * T, T)
     g.sync()
     dt = (time.perf_counter() - t0) / 3
-    prof = ""
-    print(kind, f"{dt * 1e3:.2f} ms per step, {n * T / dt / 1e6:.1f} M channel-ticks/s", g.eq_spec_stats(), flush=True)
+    g.profile_enable(False)
+    by_kind, _tot, n_prof = g.profile_collect()
+    prof = {k: round(v / max(1, n_prof), 3) for k, v in sorted(by_kind.items()) if v > 0}
+    print(kind, f"{dt * 1e3:.2f} ms per step, {n * T / dt / 1e6:.1f} M channel-ticks/s", g.eq_spec_stats(), prof, flush=True)
     g.close()
