@@ -1004,7 +1004,12 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         const GateBits gates{(const uint32_t*)g.gates.p, g.gate_words, call_off};
         switch (g.kind) {
         case MX_KIND_AMPLIFIER: launch_amplifier((const AmpDesc*)desc_of(g), n, gf, stream_, fp_contract()); break;
-        case MX_KIND_ENVELOPE: launch_envelope((const EnvDesc*)desc_of(g), (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_, fp_contract()); break;
+        case MX_KIND_ENVELOPE: {
+            const size_t need = envelope_scratch_bytes(n, gf);       // long streams: marker bitmaps and per-segment states (mx_k_envelope.hip)
+            if (need && (g.spec.bytes < need || !g.spec.p)) { sync(); g.spec.alloc(need); }
+            launch_envelope((const EnvDesc*)desc_of(g), (EnvState*)g.state.p, n, gf, gfpc, gates, t0, sample_rate_, stream_, fp_contract(), need ? g.spec.p : nullptr, need ? g.spec.bytes : 0);
+            break;
+        }
         case MX_KIND_EQ_THREE: {
             EqRun r{gf, gfpc, n_calls, fp_contract() ? 1u : 0u, t0, sample_rate_, 1.0 / sample_rate_, lo_f_, hi_f_, nullptr};
             if (g.state2.p) {   // Envelopes folded into the epilogue: their state entering every tick of this span

@@ -99,7 +99,9 @@ struct ResampleDesc { const float* in; float* out; const double* taps /* [up][ta
 // Launchers.  `frames` = mono samples in this run (= n_ticks * SPT); stereo buffers hold 2*frames.
 // fc (here and below): MX_FLAG_FP_CONTRACT -- the kernel instantiated for the contracted order (mul_add<true>, mx_env_math.hpp)
 void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s, bool fc = false);
-void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s, bool fc = false);
+void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, size_t fpc, const GateBits& gates, uint64_t t0, double sample_rate, hipStream_t s, bool fc = false,
+                     void* scratch = nullptr, size_t scratch_bytes = 0 /* envelope_scratch_bytes(): segments of long streams (mx_k_envelope.hip); without it one wave per instance */);
+size_t envelope_scratch_bytes(uint32_t n, size_t frames);
 // per-tick Envelope states of the folded Envelopes of an EqThree group: ticks[inst][call], `n_calls` ticks of `fpc` samples from t0
 void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s, bool fc = false);
 // what every EqThree launch needs beyond the descriptors: the per-tick Envelope table (null when no instance folds one)

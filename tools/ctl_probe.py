@@ -10,7 +10,8 @@ from mixlab_amd.workspace import Workspace
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = 1024
-for kind in ("env", "lfo", "none", "mixed", "mixed2", "envgate"):
+import os
+for kind in (os.environ.get("PROBE_KINDS", "env,lfo,none,mixed,mixed2,envgate").split(",")):
     ws = Workspace(48000, 60)
     mix = ws.mixer([(0.0, 0.5, False)] * n)
     srcs = []
