@@ -1387,10 +1387,11 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
             if (c < best_cost * 0.98) { best_cost = c; best = nc; }
         }
         // one lane per instance (no speculation) costs `frames` dependent steps of ~110 cycles, 64 instances per wave; a chunk lane
-        // (C + W) steps of ~460 cycles when its wave has a SIMD to itself, ~190 per resident wave when the pipes are shared
+        // (C + W) steps of ~260 cycles when its wave has a SIMD to itself, ~190 per resident wave when the pipes are shared
         const double seq = (double)frames * 110.0 * std::ceil((double)((n + 63) / 64) / 1024.0);
         const double per_simd = std::max(1.0, (double)n * (double)((best + 63) / 64) / 1024.0);
-        const double spec = (double)(chunk_of(best) + W) * (per_simd <= 1.0 ? 460.0 : 190.0 * per_simd);
+        // (260: 1024 strips x 16 ticks, one wave per SIMD walking 800 + 1 280 samples, 1 024 of them low cascade only: 0.244 ms; it was 460 before the warm-up split)
+        const double spec = (double)(chunk_of(best) + W) * (per_simd <= 1.0 ? 260.0 : 190.0 * per_simd);
         if (best < 2 || spec >= seq) return false;
     }
     if (best < 2) return false;
