@@ -60,6 +60,11 @@ pmc fir_sq2 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VM
 FF=$(pmc fir_fetch FETCH_SIZE -- python $REPO/tools/fleg.py 128 6)
 FW=$(pmc fir_write WRITE_SIZE -- python $REPO/tools/fleg.py 128 6)
 python $REPO/tools/pmc_traffic.py $FF $FW $OUT/fir_pmc_traffic.json $OUT/fir_pmc_hbm_traffic.md '{"leg": "fir_resample", "ticks_per_step": 128}' fir
+# 7b. graph shapes beside the headline's (an Amplifier modulated by a buffer, launch groups of mixed epilogue modes, Envelopes gated by a module's output) and the
+#     headline job at 44.1 kHz under the counters
+( cd $REPO && timeout 600 python tools/ctl_probe.py 2048 > $OUT/graph_shapes_probe.txt 2>&1 )
+( cd $REPO && timeout 900 bash tools/pmc_44k1.sh > $OUT/pmc_44k1.txt 2>&1 )
+cd /tmp
 # 8. LAST: the default command, as the driver runs it -- with this round's counter summaries in place, so that the line's roofline.traffic / limiter /
 #    sustained clock are the ones just collected on these kernel sources (bench.py copies them only while the recorded source hash matches)
 mkdir -p $REPO/profiles/$R && cp $OUT/*.json $REPO/profiles/$R/ 2>/dev/null
