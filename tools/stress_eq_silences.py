@@ -75,24 +75,39 @@ def run(seed):
     T = int(rng.choice([60, 128, 300, 700]))
     runs = int(rng.choice([2, 3]))
     fused = bool(rng.integers(0, 2))
+    ctl_kind = int(rng.integers(0, 4)) if fused else 0     # 0 inline Envelope; 1 a shared triangle LFO, 2 a source per strip, 3 ONE Envelope for all strips (not folded): control BUFFERS
     os.environ["MX_EQ_SPEC_CHUNKS"] = str(int(rng.choice([0, 0, 7, 24, 64, 130, 300, 700])))
     os.environ["MX_EQ_SPEC_WARM"] = str(int(rng.choice([0, 0, 0, 64, 512])))
     os.environ["MX_EQ_SPEC_SB"] = str(int(rng.choice([321, 321, 16])))
     desc = (f"seed {seed}: {SR} Hz, {n} strips, {runs} runs of {T} ticks, fused {fused}, chunks {os.environ['MX_EQ_SPEC_CHUNKS']}, warm {os.environ['MX_EQ_SPEC_WARM']}, "
-            f"sb {os.environ['MX_EQ_SPEC_SB']}, contract {CONTRACT}")
+            f"sb {os.environ['MX_EQ_SPEC_SB']}, ctl {ctl_kind}, contract {CONTRACT}")
     flags = abi.FLAG_FP_CONTRACT if CONTRACT else 0
     L = runs * T * SPT
     sig = [material(rng, seed, k, L) for k in range(n)]
+    csig = [np.abs(material(rng, seed, 500 + k, L)) for k in range(n)] if ctl_kind == 2 else []
     ws = Workspace(SR, 60)
-    srcs, outs, trigs = [], [], []
+    srcs, outs, trigs, ctl_srcs = [], [], [], []
+    lfo = ws.oscillator(float(rng.uniform(0.2, 9.0)), abi.WAVE_TRIANGLE) if ctl_kind == 1 else None
+    shared_env = None
+    if ctl_kind == 3:
+        st = ws.trigger(bool(rng.integers(0, 2))); shared_env = ws.envelope(5.0, 80.0, 0.6, 40.0); ws.connect(st, 0, shared_env, 0); trigs.append(st)
+        sink = ws.amplifier(1.0, 1.0); ws.connect(shared_env, 0, sink, 1)      # a second consumer keeps it a module of its own even with one strip
     for k in range(n):
         s = ws.source_mono(); e = ws.eq_three(*(float(v) for v in rng.uniform(-24.0, 6.0, 3)))
         ws.connect(s, 0, e, 0); srcs.append(s)
         if fused:
             pan = ws.stereo_panner(); amp = ws.amplifier(float(rng.uniform(0.5, 1.2)), float(rng.uniform(0.0, 1.0)))
-            trig = ws.trigger(bool(rng.integers(0, 2))); env = ws.envelope(5.0, 80.0, 0.6, 40.0)
-            ws.connect(e, 0, pan, 0); ws.connect(e, 0, pan, 1); ws.connect(pan, 0, amp, 0); ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp, 1)
-            outs.append((amp, True)); trigs.append(trig)
+            ws.connect(e, 0, pan, 0); ws.connect(e, 0, pan, 1); ws.connect(pan, 0, amp, 0)
+            if ctl_kind == 0:
+                trig = ws.trigger(bool(rng.integers(0, 2))); env = ws.envelope(5.0, 80.0, 0.6, 40.0)
+                ws.connect(trig, 0, env, 0); ws.connect(env, 0, amp, 1); trigs.append(trig)
+            elif ctl_kind == 1:
+                ws.connect(lfo, 0, amp, 1)
+            elif ctl_kind == 2:
+                cs = ws.source_mono(); ws.connect(cs, 0, amp, 1); ctl_srcs.append(cs)
+            else:
+                ws.connect(shared_env, 0, amp, 1)
+            outs.append((amp, True))
         else:
             outs.append((e, False))
     g = ws.build(max_ticks_per_run=T, flags=flags)
@@ -109,6 +124,8 @@ def run(seed):
                     g.schedule_params(tr, t, abi.TriggerParams(v))
             for k, s in enumerate(srcs):
                 g.write_source(s, sig[k][sl], T)
+            for k, s in enumerate(ctl_srcs):
+                g.write_source(s, csig[k][sl], T)
             g.run_ticks(r * T, T)
             got = [g.read_output(nd, 0, T, st) for nd, st in outs]
             for t in range(T):
@@ -116,6 +133,8 @@ def run(seed):
                     og.update_params(tr, abi.TriggerParams(v))
                 for k, s in enumerate(srcs):
                     og.set_source(s, sig[k][r * T * SPT + t * SPT: r * T * SPT + (t + 1) * SPT])
+                for k, s in enumerate(ctl_srcs):
+                    og.set_source(s, csig[k][r * T * SPT + t * SPT: r * T * SPT + (t + 1) * SPT])
                 og.run_tick(r * T + t)
                 for k, (nd, st) in enumerate(outs):
                     w = og.output(nd, 0)
