@@ -97,7 +97,7 @@ struct Group {
     DevBuf gates; uint32_t gate_words = 0; uint64_t gates_version = ~0ull; uint32_t gates_calls = 0;
     DevBuf tick_desc;   // EqThree: EnvTickDesc[] of the folded Envelopes
     DevBuf env_ticks;   // EqThree: EnvTick[n][n_calls] of the current launch
-    DevBuf spec;        // EqThree: chunk records of the speculative exact kernel
+    DevBuf spec;        // EqThree: chunk records of the speculative exact kernel; Envelope: marker bitmaps and per-segment states of a long stream (mx_k_envelope.hip)
     int eq_mode = -1;   // EqThree: the one epilogue every instance has (eq_epilogue_mode), or -1 when they differ
 };
 

@@ -817,6 +817,7 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
         {   // the chunk's first super-block
             float* buf = begin_sb(g);
             const EnvTick cur0 = tick_at(0);
+            // (the warm-up part has no upper bound of its own: `len` only has to admit the negative indices -- a lane without a chunk walks them too, harmlessly)
             eq_tile_compute_range<SB, KMODE, FC, false>(K, buf, c.lane, -row_shift, len > 0 ? len : 4, -EQ_SB, 0, cur0, t_chunk, s, xmin, xmax);
             if (active) {
 #pragma unroll
