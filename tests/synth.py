@@ -43,6 +43,6 @@ def yuv_pattern(w: int, h: int, layer: int, seed: int = 0, fmt: int = 0):
     for p in range(3):
         hh, ww = h >> (ch if p else 0), w >> (cw if p else 0)
         yy, xx = np.mgrid[0:hh, 0:ww].astype(np.uint32)
-        lcg = ((xx * np.uint32(1664525) + yy * np.uint32(1013904223) + np.uint32(seed * 7919 + layer * 104729 + p * 31337)) >> np.uint32(13)) & np.uint32(15)
+        lcg = ((xx * np.uint32(1664525) + yy * np.uint32(1013904223) + np.uint32((seed * 7919 + layer * 104729 + p * 31337) & 0xffffffff)) >> np.uint32(13)) & np.uint32(15)
         planes.append(((xx + 2 * yy + 31 * layer + 57 * p + lcg) & np.uint32(255)).astype(np.uint8))
     return planes
