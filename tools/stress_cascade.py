@@ -26,7 +26,7 @@ def rsize(rng):
 def run(seed):
     rng = np.random.default_rng(seed)
     os.environ["MX_SCALE_INLINE"] = str(int(rng.integers(0, 2)))
-    n_layers = int(rng.integers(2, 6)); n_ticks = int(rng.integers(6, 26)); with_monitor = rng.random() < 0.5
+    n_layers = int(rng.integers(2, 6)) if rng.random() < 0.8 else int(rng.integers(6, 15)); n_ticks = int(rng.integers(6, 26)); with_monitor = rng.random() < 0.5
     faders = [float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])) for _ in range(n_layers - 1)]
     matrix = None if rng.random() < 0.5 else [int(v) for v in rng.integers(-600, 4600, 12)]
     ws = Workspace(SR, 60)
