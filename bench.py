@@ -108,6 +108,30 @@ def build_strips(abi, Workspace, synth, n_strips, first_strip, sample_rate, ws=N
     return ws, mix, srcs
 
 
+def headline_parity(g, abi, Workspace, synth, args, sample_rate, T, n_steps_run, first, local_strips, mix, toggling, contract, src_of):
+    """The timed submissions' outputs against the CPU oracle at the job's own shape (tests/headline_replay.py): a sample of strips replayed from
+    tick 0 and compared bit for bit with the last submission's fused strip outputs; Master / Cue of sampled ticks against the oracle Mixer over the
+    device's own strips.  Runs AFTER a timed region, outside every clock.  `src_of(j)`: the T-tick source buffer of local strip j as uploaded."""
+    import headline_replay as hr    # test infrastructure: the checker
+
+    total = max(1024, args.strips)
+    ids = hr.sample_strips(local_strips, args.parity_strips)
+    mg = synth.uniform(11, total, -24.0, 6.0)
+    mf = synth.uniform(12, total, 0.0, 1.0)
+
+    def one(k):
+        ws1, mix1, srcs1, trigs1 = build_strips(abi, Workspace, synth, 1, k, sample_rate, total=total, want_trigs=True)
+        return ws1, (mix1, srcs1[0], trigs1[0], mix1 + 6)
+
+    t0 = time.perf_counter()
+    rec = hr.replay_and_compare(g, one, ids, first, {j: src_of(j) for j in ids}, T, n_steps_run, mix, lambda j: mix + 6 * j + 6, toggling=toggling,
+                                contract=contract, check_ticks=6, all_amp_nodes=[mix + 6 * j + 6 for j in range(local_strips)],
+                                mixer_channels=[(float(mg[k]), float(mf[k]), k % 8 == 0) for k in range(first, first + local_strips)])
+    rec["shape"] = f"{local_strips} strips x {T} ticks per submission @ {sample_rate} Hz, submission {n_steps_run - 1} (the last one timed)"
+    rec["seconds"] = round(time.perf_counter() - t0, 2)
+    return rec
+
+
 def native_oracle():
     """Build the CPU oracle ON THIS HOST with -O3 -march=native (same sources, same -ffp-contract=off -fno-fast-math: same
     results) for the timed baselines; falls back to the library shipped with the repo.  Must run before `import oracle`."""
@@ -716,8 +740,14 @@ def other_rate_leg(torch, np, synth, abi, Workspace, args, local_rank, stream, s
         g.profile_enable(False)
         by_kind, _tot, n_prof = g.profile_collect()
         ran, repaired = g.eq_spec_stats()
+        r_parity = None
+        if not args.no_headline_parity and not args.eq_fast and not args.no_fuse:
+            def src_of(j):
+                blk = synth.noise(j, base_ticks * spt)
+                return np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt]
+            r_parity = headline_parity(g, abi, Workspace, synth, args, sample_rate, T, 1 + steps, 0, args.strips, mix, True, bool(args.fp_contract), src_of)
         g.close()
-    return {"sample_rate": sample_rate, "samples_per_tick": spt, "ticks_per_step": T, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+    return {"sample_rate": sample_rate, "headline_parity": r_parity, "samples_per_tick": spt, "ticks_per_step": T, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
             "value": args.strips * T * steps / dt, "unit": "channel-ticks/s",
             "kernel_ms_per_step": {k: round(v / max(1, n_prof), 5) for k, v in sorted(by_kind.items()) if v > 0},
             "eq_spec": {"chunks_run": int(ran), "chunks_repaired": int(repaired)},
@@ -812,6 +842,8 @@ def main():
     ap.add_argument("--fp-contract", action="store_true", help="run the HEADLINE in the contracted order (MX_FLAG_FP_CONTRACT: <= 1 ULP, NOT the reference's bits); "
                     "the default line reports it as the `fp_contract` leg beside the exact headline")
     ap.add_argument("--no-rate-leg", action="store_true", help="skip the 44.1 kHz leg (the headline job at the reference's own sample rate)")
+    ap.add_argument("--no-headline-parity", action="store_true", help="skip the oracle replay of the timed submissions at their own shape (headline_parity)")
+    ap.add_argument("--parity-strips", type=int, default=16, help="strips replayed through the CPU oracle from tick 0 for headline_parity")
     ap.add_argument("--no-material-leg", action="store_true", help="skip the realistic-material (muted strips, silences) and poisoned-strip legs")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
     ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
@@ -919,6 +951,14 @@ def main():
         g.profile_enable(False)
         by_kind, prof_total_ms, n_prof = g.profile_collect()
         spec_ran, spec_repaired = g.eq_spec_stats()
+        # the timed submissions against the oracle at their own shape (outside every clock; before anything else overwrites the last step's outputs)
+        parity = None
+        if not args.no_headline_parity and not args.eq_fast and not args.no_fuse and rank == 0:
+            def src_of(j):
+                blk = synth.noise(first + j, base_ticks * spt)
+                return np.tile(blk, (T + base_ticks - 1) // base_ticks)[: T * spt]
+            parity = headline_parity(g, abi, Workspace, synth, args, SR, T, args.warmup + args.steps, first, local_strips, mix, toggling,
+                                     bool(args.fp_contract), src_of)
         # the spread of the clock: the same K steps again, a few times (not part of `value`)
         rep_ms = [dt / args.steps * 1e3]
         if not use_dist:
@@ -967,9 +1007,13 @@ def main():
             g_fc.profile_enable(False)
             ck, _ct, cn = g_fc.profile_collect()
             c_ran, c_rep = g_fc.eq_spec_stats()
+            c_parity = None
+            if parity is not None:
+                c_parity = headline_parity(g_fc, abi, Workspace, synth, args, SR, T, 2 + n_c, first, local_strips, mix, toggling, True, src_of)
             contract = {"flag": "MX_FLAG_FP_CONTRACT", "ms_per_step": dt_c / n_c * 1e3, "value": args.strips * T * n_c / dt_c, "unit": "channel-ticks/s", "steps": n_c,
                         "kernel_ms_per_step": {k: v / max(1, cn) for k, v in sorted(ck.items()) if v > 0},
                         "eq_spec": {"chunks_run": c_ran, "chunks_repaired": c_rep},
+                        "headline_parity": c_parity,
                         "parity": "every f32 output within 1 ULP of the reference's order (NOT its bits); bit-exact vs the oracle's contract mode (tests/test_gpu_fp_contract.py)",
                         "what": "the reference's f64 expressions with each multiply fused into the add that consumes it: EqThree 26 instead of 36 f64 instructions per sample "
                                 "(eq_three.rs:76-88,117-124), Envelope decay and Amplifier depth() one fma each"}
@@ -1280,6 +1324,7 @@ def main():
             "realtime_channels_equiv": value / 60.0,
             "graph_hbm_frac_moved_bytes": round(moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "eq_spec": {"chunks_run": spec_ran, "chunks_repaired": spec_repaired},
+            "headline_parity": parity,
             "roofline": roof,
             "repeats": {"what": f"ms per step of {len(rep_ms)} consecutive regions of {args.steps} steps (the first is the timed region)", "ms_per_step": [round(v, 4) for v in rep_ms],
                         "median": round(rep_sorted[len(rep_sorted) // 2], 4), "min": round(rep_sorted[0], 4), "max": round(rep_sorted[-1], 4),

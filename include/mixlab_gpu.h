@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MX_ABI_VERSION 3u   /* 2: mx_exchange_*, mx_monitor_tick.dropped, mx_monitor_params_ex, packed RGB pixel formats; 3: MX_FLAG_FP_CONTRACT */
+#define MX_ABI_VERSION 4u   /* 2: mx_exchange_*, mx_monitor_tick.dropped, mx_monitor_params_ex, packed RGB pixel formats; 3: MX_FLAG_FP_CONTRACT;
+                              * 4: mx_graph_read_output_window, per-pixel alpha (MX_PIXFMT_YUVA420P, mx_video_mixer_params.flags) */
 
 /* ---- status codes (0 ok, <0 error; cf. MIXLAB_IOCTX_ERROR / MIXLAB_IOCTX_PANIC) ---- */
 enum {
@@ -201,6 +202,9 @@ int mx_graph_sync(mx_graph* g);
 
 /* Copy an output port's buffers of the last run to the host (synchronises the stream). */
 int mx_graph_read_output(mx_graph* g, uint32_t node, uint32_t port, float* host_samples, size_t n_ticks);
+/* The same for ticks [first_tick_in_run, first_tick_in_run + n_ticks) of the last run only: a consumer that wants the tail of a long
+ * submission (or a checker that samples it) does not pay PCIe for the rest. */
+int mx_graph_read_output_window(mx_graph* g, uint32_t node, uint32_t port, float* host_samples, size_t first_tick_in_run, size_t n_ticks);
 /* The data formats either side of the path, converted on the device so PCIe carries 2 bytes per sample:
  *   sinks (Monitor / StreamOutput, src/video/encode.rs:183-195): clamp to [-1, 1], * 32767.0, `as i16` (saturating, truncating);
  *   ingest (StreamInput, src/module/stream_input.rs:167-173):    sample as f32 / 32768.0. */

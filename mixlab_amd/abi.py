@@ -119,6 +119,7 @@ _proto("mx_graph_bind_source_device", C.c_int, C.c_void_p, C.c_uint32, C.c_void_
 _proto("mx_graph_run_ticks", C.c_int, C.c_void_p, C.c_uint64, C.c_uint32)
 _proto("mx_graph_sync", C.c_int, C.c_void_p)
 _proto("mx_graph_read_output", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
+_proto("mx_graph_read_output_window", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t)
 _proto("mx_graph_read_output_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_write_source_i16", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_output_device_ptr", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
@@ -256,6 +257,12 @@ class Graph:
         """rate = (up, down) of the port's sample-rate domain (a Resample node's output is not at the graph's rate)."""
         out = np.empty(n_ticks * (self.spt * rate[0] // rate[1]) * (2 if stereo else 1), dtype=np.float32)
         check(lib.mx_graph_read_output(self._h, node, port, out.ctypes.data_as(C.c_void_p), n_ticks))
+        return out
+
+    def read_output_window(self, node, port, first_tick: int, n_ticks: int, stereo: bool) -> np.ndarray:
+        """ticks [first_tick, first_tick + n_ticks) of the last run (ports in the graph's own rate domain)"""
+        out = np.empty(n_ticks * self.spt * (2 if stereo else 1), dtype=np.float32)
+        check(lib.mx_graph_read_output_window(self._h, node, port, out.ctypes.data_as(C.c_void_p), first_tick, n_ticks))
         return out
 
     def read_output_i16(self, node, port, n_ticks: int, stereo: bool, rate=(1, 1)) -> np.ndarray:

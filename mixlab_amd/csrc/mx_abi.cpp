@@ -160,6 +160,13 @@ int mx_graph_read_output(mx_graph* g, uint32_t node, uint32_t port, float* host_
     return guard([&] { REQUIRE(g, "graph is NULL"); g->g->read_output(node, port, host_samples, n_ticks * g->g->spt()); });
 }
 
+int mx_graph_read_output_window(mx_graph* g, uint32_t node, uint32_t port, float* host_samples, size_t first_tick_in_run, size_t n_ticks) {
+    return guard([&] {
+        REQUIRE(g, "graph is NULL");
+        g->g->read_output(node, port, host_samples, n_ticks * g->g->spt(), first_tick_in_run * g->g->spt());
+    });
+}
+
 int mx_graph_read_output_i16(mx_graph* g, uint32_t node, uint32_t port, int16_t* host_samples, size_t n_ticks) {
     return guard([&] { REQUIRE(g, "graph is NULL"); g->g->read_output_i16(node, port, host_samples, n_ticks * g->g->spt()); });
 }

@@ -1266,23 +1266,25 @@ Graph::Perf Graph::performance_info(uint64_t* module_us, size_t cap) {
     return pf;
 }
 
-void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames) {
+void Graph::read_output(uint32_t node, uint32_t port, float* host, size_t frames, size_t first_frame) {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     wait_tail(-1);
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
-    if (frames > cap_frames_) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
+    if (first_frame > cap_frames_ || frames > cap_frames_ - first_frame) throw Error(MX_ERR_INVALID, "more ticks than max_ticks_per_run");
     if (frames && !host) throw Error(MX_ERR_INVALID, "host_samples is NULL");
     const Node& n = nodes_[node];
     if (n.out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
-    frames = frames * n.dom_num / n.dom_den;   // the port's own sample-rate domain
+    // the port's own sample-rate domain; a window starts and ends where whole ticks do
+    const size_t f0 = first_frame * n.dom_num / n.dom_den;
+    frames = (first_frame + frames) * n.dom_num / n.dom_den - f0;
     if (n.out_dup[port]) {   // stored as one float per frame (L == R): expand for the caller
-        hip_check(hipMemcpyAsync(host, out_ptr(n, port), frames * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+        hip_check(hipMemcpyAsync(host, out_ptr(n, port) + f0, frames * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
         sync();
         for (size_t i = frames; i-- > 0;) { const float v = host[i]; host[2 * i] = v; host[2 * i + 1] = v; }
         return;
     }
-    const size_t fl = floats_per_frame(n.out_type[port]) * frames;
-    hip_check(hipMemcpyAsync(host, out_ptr(n, port), fl * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
+    const size_t fpf = floats_per_frame(n.out_type[port]);
+    hip_check(hipMemcpyAsync(host, out_ptr(n, port) + fpf * f0, fpf * frames * sizeof(float), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(D2H)");
     sync();
 }
 

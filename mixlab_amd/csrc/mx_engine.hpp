@@ -135,7 +135,7 @@ public:
     // accumulate per-group hipEvent timings across runs without synchronising (bench: kernel time over the timed region)
     void profile_enable(bool on);
     uint32_t profile_collect(float* ms_by_kind, float* ms_total);   // syncs; returns number of runs collected
-    void read_output(uint32_t node, uint32_t port, float* host, size_t frames);
+    void read_output(uint32_t node, uint32_t port, float* host, size_t frames, size_t first_frame = 0);   // frames [first_frame, first_frame + frames) of the last run
     void read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t frames);   // sink hand-off format
     void write_source_i16(uint32_t node, const int16_t* host, size_t frames);            // ingest format
     float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_tick);

@@ -536,7 +536,6 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
     for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->fmt == as_fmt && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
     if (!out) {
         if (rgb_pool_.size() >= 2 * (size_t)video_batch_ticks() + 2) rgb_pool_.erase(rgb_pool_.begin());
-        // (created BLANK: a gray8 input only ever writes the luma plane, its chroma stays 0x80)
         rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, as_fmt), false));
         out = rgb_pool_.back();
     }
@@ -556,6 +555,9 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
     }
     if (in->fmt == MX_PIXFMT_GRAY8) {   // luma as it is, U = V = 0x80 (what swscale's gray -> yuv gives; build-specified like the RGB matrix)
         hip_check(hipMemcpy2DAsync(out->data[0], out->stride[0], in->data[0], in->stride[0], in->width, in->height, hipMemcpyDeviceToDevice, stream_), "hipMemcpy2DAsync(gray8)");
+        // the pool frame may last have held a packed-RGB picture of this size (same yuv444p class): its chroma planes are that picture's, not 0x80
+        for (int p = 1; p < 3; ++p)
+            hip_check(hipMemset2DAsync(out->data[p], out->stride[p], 0x80, out->pw(p), out->ph(p), stream_), "hipMemset2DAsync(gray8 chroma)");
         return out;
     }
     const DFrame::Rgb rgb = DFrame::rgb_of(in->fmt);

@@ -343,6 +343,7 @@ typedef struct {
     int plot_fired;
     float* plot_l; float* plot_r;
     const float* source;   /* host-fed */
+    uint32_t source_ring;  /* 0: `source` is this tick's block; R > 0: `source` holds R ticks and tick t reads block t mod R */
     uint32_t dom_num, dom_den, in_dom_num, in_dom_den;   /* sample-rate domain (Resample changes it) */
     float* hist;           /* Fir / Resample carried input frames */
     int ran;               /* produced output this tick (back-edges read Disconnected) */
@@ -491,6 +492,16 @@ int orc_graph_set_source(orc_graph* g, uint32_t node, const float* samples) {
     onode* n = &g->nodes[node];
     if (n->kind != ORC_KIND_SOURCE_MONO && n->kind != ORC_KIND_SOURCE_STEREO) return -1;
     n->source = samples;
+    n->source_ring = 0;
+    return 0;
+}
+
+/* A source that replays a resident buffer of `ring_ticks` ticks: tick t reads block (t mod ring_ticks).  This is what a device-resident
+ * synthetic source re-read by every submission looks like to the modules behind it (bench.py's sources; nothing in the reference: its
+ * sources are live, src/source.rs). */
+int orc_graph_set_source_ring(orc_graph* g, uint32_t node, const float* samples, uint32_t ring_ticks) {
+    if (orc_graph_set_source(g, node, samples) != 0 || ring_ticks == 0) return -1;
+    g->nodes[node].source_ring = ring_ticks;
     return 0;
 }
 
@@ -562,10 +573,10 @@ int orc_graph_run_tick(orc_graph* g, uint64_t tick) {
             break;
         }
         case ORC_KIND_SOURCE_MONO:
-            if (n->source) memcpy(n->out_buf[0], n->source, spt * sizeof(float));
+            if (n->source) memcpy(n->out_buf[0], n->source + (n->source_ring ? (tick % n->source_ring) * spt : 0), spt * sizeof(float));
             break;
         case ORC_KIND_SOURCE_STEREO:
-            if (n->source) memcpy(n->out_buf[0], n->source, 2 * spt * sizeof(float));
+            if (n->source) memcpy(n->out_buf[0], n->source + (n->source_ring ? (tick % n->source_ring) * 2 * spt : 0), 2 * spt * sizeof(float));
             break;
         default: return -1;
         }

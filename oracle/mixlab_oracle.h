@@ -139,6 +139,8 @@ size_t orc_graph_samples_per_tick(const orc_graph* g);
 int orc_graph_update_params(orc_graph* g, uint32_t node, const void* params, uint32_t params_len);
 /* host-fed source ports: pointer is read during run_tick (SPT mono / 2*SPT stereo floats) */
 int orc_graph_set_source(orc_graph* g, uint32_t node, const float* samples);
+/* the source replays a resident buffer of ring_ticks ticks: tick t reads block (t mod ring_ticks) */
+int orc_graph_set_source_ring(orc_graph* g, uint32_t node, const float* samples, uint32_t ring_ticks);
 /* one Engine::run_tick: fresh zeroed outputs, topological order, t = tick * SPT */
 int orc_graph_run_tick(orc_graph* g, uint64_t tick);
 /* n consecutive ticks with the sources left as they are (one foreign call: lets a threaded timing harness run free of the caller's interpreter lock) */

@@ -68,6 +68,7 @@ lib.orc_graph_destroy.argtypes = [C.c_void_p]
 lib.orc_graph_samples_per_tick.restype = C.c_size_t
 lib.orc_graph_samples_per_tick.argtypes = [C.c_void_p]
 lib.orc_graph_set_source.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+lib.orc_graph_set_source_ring.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
 lib.orc_graph_update_params.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
 lib.orc_graph_run_tick.argtypes = [C.c_void_p, C.c_uint64]
 lib.orc_graph_run_ticks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
@@ -206,6 +207,12 @@ class OracleGraph:
         a = f32(samples)
         self._src[node] = a
         assert lib.orc_graph_set_source(self._h, node, _p(a)) == 0
+
+    def set_source_ring(self, node, samples: np.ndarray, ring_ticks: int):
+        """the source replays `samples` (ring_ticks ticks): tick t reads block t mod ring_ticks"""
+        a = f32(samples)
+        self._src[node] = a
+        assert lib.orc_graph_set_source_ring(self._h, node, _p(a), ring_ticks) == 0
 
     def update_params(self, node, params):
         from mixlab_amd.abi import params_bytes

@@ -200,7 +200,7 @@ def test_abi_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_error_channel_without_gpu():
-    assert abi.lib.mx_abi_version() == 3
+    assert abi.lib.mx_abi_version() == 4
     n = abi.lib.mx_device_count()
     if n <= 0:   # CPU box: the call must fail cleanly and say why, not crash or fall back
         assert n == abi.MX_ERR_DEVICE and b"hip" in abi.lib.mx_last_error().lower()

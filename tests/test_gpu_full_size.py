@@ -207,3 +207,46 @@ def test_config2_at_the_benchmarked_batch_length_2048_ticks_bit_exact(rate):
         sl = slice(tick * 2 * SPT, (tick + 1) * 2 * SPT)
         assert np.array_equal(got_m[sl].view(np.uint32), og.output(mix, 0).view(np.uint32)), f"master differs in tick {tick}"
         assert np.array_equal(got_c[sl].view(np.uint32), og.output(mix, 1).view(np.uint32)), f"cue differs in tick {tick}"
+
+
+@pytest.mark.parametrize("mode", ["exact", "contract"])
+def test_headline_shape_1024_strips_x_2048_ticks_with_the_planners_own_plan_against_the_oracle(mode):
+    """bench.py's headline job AT ITS OWN SHAPE -- 1024 strips x 2048 ticks per submission @48 kHz, gates toggling inside the submissions through
+    mx_graph_schedule_params_batch, no environment forcing: the kernel instantiation, chunk plan and launch geometry are the ones the timed region
+    runs -- over two submissions (state carried from the first into the second).  16 sampled strips are replayed through the oracle from tick 0
+    and compared bit for bit with the second submission's fused strip outputs; Master / Cue of sampled ticks against the oracle Mixer over the
+    device's own 1024 strips (tests/headline_replay.py -- the same checker bench.py runs after its timed region)."""
+    import bench
+    import headline_replay as hr
+    from mixlab_amd.workspace import Workspace
+
+    T, n_steps = 2048, 2
+    flags = abi.FLAG_FP_CONTRACT if mode == "contract" else 0
+    ws, mix, srcs, trigs = bench.build_strips(abi, Workspace, synth, N, 0, SR48, want_trigs=True)
+    g = ws.build(max_ticks_per_run=T, flags=flags)
+    base_ticks = 256
+
+    def src_of(j):
+        return np.tile(synth.noise(j, base_ticks * SPT48), T // base_ticks)
+
+    for j, s in enumerate(srcs):
+        g.write_source(s, src_of(j), T)
+    for i in range(n_steps):
+        ev = bench.gate_events(abi, trigs, 0, i * T, T)
+        g.schedule_params_batch(ev[0], ev[1])
+        g.run_ticks(i * T, T)
+    ran, repaired = g.eq_spec_stats()
+    assert ran >= n_steps * 16 * N                  # the speculative time-parallel kernel ran (not the short-stream path)
+    ids = hr.sample_strips(N, 16)
+    mg, mf = synth.uniform(11, N, -24.0, 6.0), synth.uniform(12, N, 0.0, 1.0)
+
+    def one(k):
+        ws1, mix1, srcs1, trigs1 = bench.build_strips(abi, Workspace, synth, 1, k, SR48, total=N, want_trigs=True)
+        return ws1, (mix1, srcs1[0], trigs1[0], mix1 + 6)
+
+    rec = hr.replay_and_compare(g, one, ids, 0, {j: src_of(j) for j in ids}, T, n_steps, mix, lambda j: mix + 6 * j + 6, toggling=True,
+                                contract=mode == "contract", check_ticks=6, all_amp_nodes=[mix + 6 * j + 6 for j in range(N)],
+                                mixer_channels=[(float(mg[k]), float(mf[k]), k % 8 == 0) for k in range(N)])
+    assert rec["verdict"] == "bit-exact", rec
+    assert rec["strips_checked"] == 16 and rec["samples_compared"] == 16 * T * 2 * SPT48
+    assert rec["buses"]["verdict"] == "bit-exact", rec

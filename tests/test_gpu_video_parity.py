@@ -495,3 +495,31 @@ def test_packed_rgb_scaler_inputs_equal_the_oracle_composition(fmt, src, dst):
     want_prog = om.run_tick(0, [(as444, (1, 30), (0, 1)), (other, (1, 30), (0, 1)), None, None])
     for p, (x, y) in enumerate(zip(prog.download(), want_prog.visible())):
         assert np.array_equal(x, y), f"VideoMixer program, plane {p}"
+
+
+def test_one_scaler_fed_rgb24_then_gray8_of_the_same_size_keeps_gray_chroma_neutral():
+    """A persistent scaler converts packed RGB and gray8 inputs into pooled yuv444p frames of the input's size.  A gray8 picture that follows an RGB
+    one of the same size reuses the RGB picture's pool frame: its chroma planes must be re-blanked to 0x80 (gray8 IS the frame with U = V = 0x80),
+    not keep the colour of the picture before."""
+    rng = np.random.default_rng(77)
+    (w, h), dst = (320, 180), (480, 270)
+    pix = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    gray = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    d_rgb = video.DFrame(w, h, fmt=video.PIXFMT_RGB24).upload_packed(pix)
+    d_gray = video.DFrame(w, h, fmt=video.PIXFMT_GRAY8).upload_packed(gray)
+    as444 = ov.HostFrame(w, h, 2)
+    as444.planes[0][:, :w] = gray; as444.planes[1][:, :w] = 0x80; as444.planes[2][:, :w] = 0x80
+    want_gray = ov.HostFrame(*dst); ov.blank(want_gray); ov.dynamic_scale(as444, want_gray)
+    want_rgb = ov.HostFrame(*dst); ov.blank(want_rgb); ov.dynamic_scale(ov.packed_rgb_to_yuv444(pix, video.PIXFMT_RGB24), want_rgb)
+    sc = video.Scaler(*dst)
+    for rnd in range(3):
+        res = sc.scale(d_rgb)
+        for p, (x, y) in enumerate(zip(res.download(), want_rgb.visible())):
+            assert np.array_equal(x, y), f"round {rnd}: rgb24, plane {p}"
+        del res
+        res = sc.scale(d_gray)
+        got = res.download()
+        for p, (x, y) in enumerate(zip(got, want_gray.visible())):
+            assert np.array_equal(x, y), f"round {rnd}: gray8 after rgb24, plane {p}"
+        assert (got[1] == 0x80).all() and (got[2] == 0x80).all()
+        del res
