@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define MX_ABI_VERSION 4u   /* 2: mx_exchange_*, mx_monitor_tick.dropped, mx_monitor_params_ex, packed RGB pixel formats; 3: MX_FLAG_FP_CONTRACT;
-                              * 4: mx_graph_read_output_window, per-pixel alpha (MX_PIXFMT_YUVA420P, mx_video_mixer_params.flags) */
+                              * 4: mx_graph_read_output_window, per-pixel alpha (MX_PIXFMT_YUVA420P, mx_dframe_*_alpha; the A byte of packed RGBA honoured) */
 
 /* ---- status codes (0 ok, <0 error; cf. MIXLAB_IOCTX_ERROR / MIXLAB_IOCTX_PANIC) ---- */
 enum {
@@ -284,7 +284,7 @@ typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P =
                /* packed RGB, one plane (data[0]; data[1], data[2] NULL): scaler INPUTS only (a screen capture, an image file).  BUILD-SPECIFIED: the
                 * frame stands for the yuv444p frame of its per-pixel BT.709 limited-range conversion (DESIGN.md "Pixel formats"), which is then
                 * resampled like any 4:4:4 input -- libswscale's own RGB path is unknown here: parity unpinned, like the scaler */
-               MX_PIXFMT_RGB24 = 4 /* R, G, B bytes */, MX_PIXFMT_BGRA = 5 /* B, G, R, A bytes; alpha ignored */,
+               MX_PIXFMT_RGB24 = 4 /* R, G, B bytes */, MX_PIXFMT_BGRA = 5 /* B, G, R, A bytes; A = the pixel's coverage, see MX_PIXFMT_YUVA420P */,
                /* the other planar 8-bit YUV layouts an AVPixelFormat descriptor can carry (pixfmt.rs:97-111: log2_chroma_w / log2_chroma_h of 0, 1 or 2): scaler
                 * inputs like yuv422p / yuv444p -- every plane resampled from its own size; width / height multiples of the subsampling */
                MX_PIXFMT_YUV410P = 6 /* chroma 1/4 x 1/4 */, MX_PIXFMT_YUV411P = 7 /* chroma 1/4 x 1 */, MX_PIXFMT_YUV440P = 8 /* chroma 1 x 1/2 */,
@@ -302,7 +302,15 @@ typedef enum { MX_PIXFMT_YUV420P = 0, MX_PIXFMT_YUV422P = 1, MX_PIXFMT_YUV444P =
                 * samples (a byte shuffle, nothing to specify), which is then resampled like any yuv422p input; width even */
                MX_PIXFMT_YUYV422 = 21 /* Y0 U Y1 V */, MX_PIXFMT_UYVY422 = 22 /* U Y0 V Y1 */,
                /* the other byte orders of packed 8-bit RGB: the same build-specified conversion as rgb24 / bgra */
-               MX_PIXFMT_BGR24 = 23 /* B, G, R */, MX_PIXFMT_RGBA = 24 /* R, G, B, A; alpha ignored */, MX_PIXFMT_ARGB = 25 /* A, R, G, B */, MX_PIXFMT_ABGR = 26 /* A, B, G, R */ } mx_pixfmt;
+               MX_PIXFMT_BGR24 = 23 /* B, G, R */, MX_PIXFMT_RGBA = 24 /* R, G, B, A */, MX_PIXFMT_ARGB = 25 /* A, R, G, B */, MX_PIXFMT_ABGR = 26 /* A, B, G, R */,
+               /* PER-PIXEL ALPHA (BUILD-SPECIFIED: the reference's only "alpha" is the VideoMixer's global fader, video_mixer.rs:168).  A layer may carry a COVERAGE
+                * plane -- yuva420p: yuv420p plus a fourth plane of width x height bytes, 255 = opaque (mx_frame holds the three YUV planes; the fourth travels through
+                * mx_dframe_upload_alpha / _download_alpha) -- and the A byte of a four-byte packed RGB input IS that plane (straight, not premultiplied).  The scaler
+                * resamples it like luma (letterbox bars opaque).  A VideoMixer step then weighs its layers per sample, in fade_line's own u16 arithmetic
+                * (video_mixer.rs:211-235), aA / aB = the coverage of A / B there (255 where a layer carries none; chroma samples use the co-sited luma sample's):
+                *     wa = (aA * fade) / 255;   wb = (aB * (255 - wa)) / 255;   out = (A * (255 - wb) + B * wb) / 255
+                * Opaque layers give wa = fade, wb = 255 - fade: the reference's cross-fade bit for bit.  The composite itself is opaque yuv420p (DESIGN.md "Per-pixel alpha"). */
+               MX_PIXFMT_YUVA420P = 27 } mx_pixfmt;
 
 /* Device frame: the AvFrame<Video> stand-in.  Reference-counted like an AVFrame (clone =
  * av_frame_clone, codec/src/ffmpeg/frame.rs:351-361): create returns one reference; the VideoMixer
@@ -319,6 +327,11 @@ void mx_dframe_release(mx_dframe* f);
 int mx_dframe_upload(mx_dframe* f, const mx_frame* host, void* stream);       /* visible area; synchronous */
 int mx_dframe_download(const mx_dframe* f, mx_frame* host, void* stream);     /* visible area; synchronous */
 int mx_dframe_planes(const mx_dframe* f, uint32_t* width, uint32_t* height, void* device_data[3], int32_t stride[3]);
+/* The coverage plane of a yuva420p frame (MX_PIXFMT_YUVA420P): width x height bytes, `stride` bytes per host row.  Synchronous.  MX_ERR_INVALID for a frame
+ * without one.  alpha_plane: its device address (NULL: none) for producers that write it on the device. */
+int mx_dframe_upload_alpha(mx_dframe* f, const uint8_t* host_alpha, int32_t stride, void* stream);
+int mx_dframe_download_alpha(const mx_dframe* f, uint8_t* host_alpha, int32_t stride, void* stream);
+int mx_dframe_alpha_plane(const mx_dframe* f, void** device_alpha, int32_t* stride);
 
 /* AvFrame::blank (frame.rs:76-138) */
 int mx_video_blank(mx_dframe* f, void* stream);

@@ -69,12 +69,51 @@ int mx_dframe_create_fmt(uint32_t width, uint32_t height, mx_pixfmt fmt, void* s
     return guard([&] {
         REQUIRE(out, "out is NULL");
         *out = nullptr;
+        if (fmt == MX_PIXFMT_YUVA420P) { *out = H(DFrame::create(width, height, S(stream), MX_PIXFMT_YUV420P, true)); return; }   // yuv420p + a coverage plane (opaque until uploaded)
         REQUIRE((int)fmt >= 0 && (int)fmt <= (int)mx::DFrame::kLastFmt, "unknown pixel format");
         *out = H(DFrame::create(width, height, S(stream), (uint8_t)fmt));
     });
 }
 int mx_dframe_format(const mx_dframe* f, mx_pixfmt* fmt) {
-    return guard([&] { REQUIRE(f && fmt, "NULL argument"); *fmt = (mx_pixfmt)D(f)->fmt; });
+    return guard([&] {
+        REQUIRE(f && fmt, "NULL argument");
+        *fmt = (D(f)->fmt == MX_PIXFMT_YUV420P && D(f)->with_alpha) ? MX_PIXFMT_YUVA420P : (mx_pixfmt)D(f)->fmt;
+    });
+}
+static DFrame* alpha_frame(const mx_dframe* f) {
+    REQUIRE(f, "frame is NULL");
+    DFrame* d = const_cast<DFrame*>(D(f));
+    if (!d->with_alpha) throw Error(MX_ERR_INVALID, "the frame has no coverage plane (create it as MX_PIXFMT_YUVA420P; packed RGBA carries its alpha in the pixels)");
+    return d;
+}
+int mx_dframe_upload_alpha(mx_dframe* f, const uint8_t* host_alpha, int32_t stride, void* stream) {
+    return guard([&] {
+        DFrame* d = alpha_frame(f);
+        REQUIRE(host_alpha && stride >= (int32_t)d->width, "host alpha plane is NULL or its stride smaller than the width");
+        hipStream_t s = S(stream);
+        d->ensure_pixels(s);
+        mx::hip_check(hipMemcpy2DAsync(d->alpha, d->alpha_stride, host_alpha, (size_t)stride, d->width, d->height, hipMemcpyHostToDevice, s), "hipMemcpy2DAsync(H2D alpha)");
+        mx::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+int mx_dframe_download_alpha(const mx_dframe* f, uint8_t* host_alpha, int32_t stride, void* stream) {
+    return guard([&] {
+        DFrame* d = alpha_frame(f);
+        REQUIRE(host_alpha && stride >= (int32_t)d->width, "host alpha plane is NULL or its stride smaller than the width");
+        hipStream_t s = S(stream);
+        d->ensure_pixels(s);
+        mx::flush_scales(s);
+        mx::hip_check(hipMemcpy2DAsync(host_alpha, (size_t)stride, d->alpha, d->alpha_stride, d->width, d->height, hipMemcpyDeviceToHost, s), "hipMemcpy2DAsync(D2H alpha)");
+        mx::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+int mx_dframe_alpha_plane(const mx_dframe* f, void** device_alpha, int32_t* stride) {
+    return guard([&] {
+        REQUIRE(f && device_alpha, "NULL argument");
+        const DFrame* d = D(f);
+        *device_alpha = d->alpha;                       // NULL: the frame carries none (or has no pixels yet)
+        if (stride) *stride = (int32_t)d->alpha_stride;
+    });
 }
 int mx_dframe_retain(mx_dframe* f) {
     return guard([&] { REQUIRE(f, "frame is NULL"); D(f)->retain(); });
@@ -148,7 +187,8 @@ int mx_video_crossfade(mx_dframe* out, const mx_dframe* a, const mx_dframe* b, d
         if (rb) rb->ensure_pixels(S(stream));
         auto chain = mx::make_chain(ra, rb, mx::crossfade_factor(fader), S(stream));
         mx::ChainArgs ar;
-        mx::fill_chain_sources(*chain, ar.src, ar.n_src, ar.fade, ar.v_is_a);
+        mx::fill_chain_sources(*chain, ar.src, ar.n_src, ar.fade, ar.v_is_a, ar.al, ar.alpha_mask);
+        ar._pad1 = 0;
         for (int p = 0; p < 3; ++p) {
             ar.out[p] = o->data[p]; ar.out_stride[p] = o->stride[p];
             ar.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;
@@ -187,6 +227,10 @@ int mx_video_scale(const mx_dframe* in, mx_dframe* out, void* stream) {
             c.rows[p] = o->ph(p); c.row_bytes[p] = o->pw(p);
         }
         mx::launch_copy_planes(c, s);
+        if (o->alpha) {   // the output asked for the coverage plane too: the scaled one, or opaque when the input carries none
+            if (res->alpha) mx::hip_check(hipMemcpy2DAsync(o->alpha, o->alpha_stride, res->alpha, res->alpha_stride, o->width, o->height, hipMemcpyDeviceToDevice, s), "hipMemcpy2DAsync(alpha)");
+            else mx::hip_check(hipMemsetAsync(o->alpha, 0xff, o->alpha_bytes, s), "hipMemsetAsync(alpha)");
+        }
         mx::hip_check(hipGetLastError(), "scale launch");
         mx::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");   // the temporary scaler's frame dies here
     });

@@ -145,6 +145,71 @@ __device__ __forceinline__ void chain_eval_pk(uint32_t (&v)[NW], const uint32_t 
     for (int w = 0; w < NW; ++w) v[w] = px4_pack(acc[w]);
 }
 
+// ---- per-pixel alpha (BUILD-SPECIFIED, mx_video.hpp ChainAlpha): the same steps with a per-sample factor pair ----
+// x / 255 for x <= 255 * 255 in packed u16 (the identity fade_pk uses, tests/test_fastdiv.py)
+__device__ __forceinline__ u16x2 div255_pk(u16x2 x) {
+    const u16x2 one = {1, 1};
+    const u16x2 x1 = x + one;
+    return (u16x2)((x1 + (x1 >> 8)) >> 8);
+}
+// One step with coverage.  v: the running composite (opaque unless it is still the bare base layer: av != nullptr), o / ao: the other layer and its coverage
+// (ao == nullptr: opaque), F = (fader * 255) as u8, via: the running composite sits on input A.
+//   wa = (aA F) / 255;  wb = (aB (255 - wa)) / 255;  out = (A (255 - wb) + B wb) / 255
+template <int NW>
+__device__ __forceinline__ void chain_step_alpha(Px4 (&acc)[NW], const uint32_t (&o)[NW], const uint32_t* ao, const uint32_t* av, const uint32_t F, const bool via) {
+    const u16x2 k255 = {255, 255};
+    const unsigned short f = (unsigned short)(via ? F : 255u - F), g = (unsigned short)(255u - f);   // nominal factors of the running composite and of the other layer
+    const u16x2 gp = {g, g}, Fp = {(unsigned short)F, (unsigned short)F};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        u16x2 wo_e, wo_o;
+        if (!av) {   // opaque running composite: the other layer's factor is its nominal one scaled by its coverage, the composite takes the rest
+            const Px4 a = px4_unpack(ao[w]);
+            wo_e = div255_pk(a.e * gp); wo_o = div255_pk(a.o * gp);
+        } else {
+            const Px4 a_v = px4_unpack(av[w]);
+            Px4 a_o; a_o.e = k255; a_o.o = k255;
+            if (ao) a_o = px4_unpack(ao[w]);
+            if (via) {   // A = running composite, B = other
+                const u16x2 wa_e = div255_pk(a_v.e * Fp), wa_o = div255_pk(a_v.o * Fp);
+                wo_e = div255_pk(a_o.e * (k255 - wa_e)); wo_o = div255_pk(a_o.o * (k255 - wa_o));
+            } else {     // A = other, B = running composite
+                const u16x2 wa_e = div255_pk(a_o.e * Fp), wa_o = div255_pk(a_o.o * Fp);
+                wo_e = k255 - div255_pk(a_v.e * (k255 - wa_e)); wo_o = k255 - div255_pk(a_v.o * (k255 - wa_o));
+            }
+        }
+        const Px4 ov = px4_unpack(o[w]);
+        acc[w].e = fade_pk(acc[w].e, ov.e, k255 - wo_e, wo_e);
+        acc[w].o = fade_pk(acc[w].o, ov.o, k255 - wo_o, wo_o);
+    }
+}
+// the chain with coverage planes: A[k] holds layer k's coverage in the layout of L[k] (only for layers whose bit is set in `mask`)
+template <int NW>
+__device__ __forceinline__ void chain_eval_alpha(uint32_t (&v)[NW], const uint32_t (*L)[NW], const uint32_t (*A)[NW], uint32_t n_src,
+                                                 const uint32_t* fade, const uint32_t* v_is_a, const uint32_t mask) {
+    Px4 acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = px4_unpack(L[0][w]);
+#pragma unroll
+    for (int k = 1; k < MX_CHAIN_MAX_SRC; ++k) {
+        if (k < (int)n_src) {
+            const uint32_t F = fade[k - 1] & 0xffu; const bool via = v_is_a[k - 1] != 0u;
+            const bool oa = (mask >> k) & 1u, va = k == 1 && (mask & 1u);     // wave-uniform: the mask is a kernel argument
+            if (!oa && !va) {
+                const unsigned short f = (unsigned short)(via ? F : 255u - F), g = (unsigned short)(255u - f);
+                const u16x2 fa = {f, f}, fb = {g, g};
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc[w] = fade_px4(acc[w], px4_unpack(L[k][w]), fa, fb);
+            } else {
+                chain_step_alpha<NW>(acc, L[k], oa ? A[k] : nullptr, va ? A[0] : nullptr, F, via);
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = px4_pack(acc[w]);
+}
+
+template <bool AL>
 __global__ __launch_bounds__(256) void k_fade_chain(ChainArgs args) {
     uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     int plane = 0;
@@ -162,14 +227,36 @@ __global__ __launch_bounds__(256) void k_fade_chain(ChainArgs args) {
         L[k][0] = t.x; L[k][1] = t.y; L[k][2] = t.z; L[k][3] = t.w;
     }
     uint32_t v[4];
-    chain_eval<4>(v, L, args.n_src, args.fade, args.v_is_a);
+    if constexpr (!AL) {
+        chain_eval<4>(v, L, args.n_src, args.fade, args.v_is_a);
+    } else {
+        // the coverage of this chunk's 16 samples: luma -- 16 bytes of the plane's row; chroma -- the co-sited luma samples (2x, 2y): the even bytes of 32
+        uint32_t A[MX_CHAIN_MAX_SRC][4];
+#pragma unroll
+        for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
+            A[k][0] = A[k][1] = A[k][2] = A[k][3] = 0xffffffffu;
+            if (k < (int)args.n_src && ((args.alpha_mask >> k) & 1u)) {
+                if (plane == 0) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(args.al[k].p + (size_t)row * args.al[k].stride + col);
+                    A[k][0] = t.x; A[k][1] = t.y; A[k][2] = t.z; A[k][3] = t.w;
+                } else {
+                    const uint8_t* ar = args.al[k].p + (size_t)(2u * row) * args.al[k].stride + 2u * col;
+                    const uint4 a = *reinterpret_cast<const uint4*>(ar), b = *reinterpret_cast<const uint4*>(ar + 16);
+                    A[k][0] = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u); A[k][1] = __builtin_amdgcn_perm(a.w, a.z, 0x06040200u);
+                    A[k][2] = __builtin_amdgcn_perm(b.y, b.x, 0x06040200u); A[k][3] = __builtin_amdgcn_perm(b.w, b.z, 0x06040200u);
+                }
+            }
+        }
+        chain_eval_alpha<4>(v, L, A, args.n_src, args.fade, args.v_is_a, args.alpha_mask);
+    }
     *reinterpret_cast<uint4*>(args.out[plane] + (size_t)row * args.out_stride[plane] + col) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 void launch_fade_chain(const ChainArgs& a, hipStream_t s) {
     flush_scales(s);   // queued scaler output may be among the layers
     const uint32_t total = a.chunks[0] + a.chunks[1] + a.chunks[2];
     if (!total) return;
-    hipLaunchKernelGGL(k_fade_chain, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    if (a.alpha_mask) hipLaunchKernelGGL(k_fade_chain<true>, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_fade_chain<false>, dim3((total + 255) / 256), dim3(256), 0, s, a);
 }
 
 // the same chain feeding YUV420P -> RGBA (+ matrix): one lane owns 16 luma pixels x 2 rows and their
@@ -383,8 +470,9 @@ __device__ __forceinline__ uint32_t cs_mask_quad(uint32_t quad, uint32_t blank, 
     return (quad & m) | (blank & ~m);
 }
 
-template <int MM, bool SC, class ArgsRef>   // ArgsRef: ChainRgbaArgs in kernel arguments, or in the constant address space (k_video_batch)
+template <int MM, bool SC, bool AL, class ArgsRef>   // ArgsRef: ChainRgbaArgs in kernel arguments, or in the constant address space (k_video_batch); AL: layers with coverage planes
 __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const int by) {
+    static_assert(!(SC && AL), "a chain with coverage planes takes its scaled layers materialised");
     // a lane owns a UNIT of 8 pixels x 2 rows and their 4 + 4 chroma samples.  With inline-scaled layers (SC) a block is a tile of
     // 128 x 32 luma pixels (the scaler windows in LDS are per tile).  Without them nothing ties a block to a rectangle, and a block
     // takes 256 CONSECUTIVE units in row-major order (bx = the block's index, by unused): a wave's loads are 512 contiguous bytes of
@@ -534,7 +622,32 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
     for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) { fa[k] = a.fa_pk[k]; fb[k] = a.fb_pk[k]; }
 #pragma unroll
     for (int k = 0; k < 12; ++k) { if (MM == 3) mtf[k] = a.mf[k]; else mtx[k] = a.m[k]; }
-    chain_eval_pk<6>(v, L, a.n_src, fa, fb);
+    if constexpr (AL) {
+        // coverage of the unit's 8 x 2 luma samples (the layout of L[k][0..3]) and of its 4 chroma samples -- the co-sited luma samples (2x, 2y): the even
+        // bytes of the upper row -- for U and V alike.  Only layers that carry a plane are read (the mask is wave-uniform).
+        const uint32_t mask = a.alpha_mask;
+        const uint32_t xc = min(xb, (a.width - 1u) >> 3), yc = min(yb, (a.height - 1u) >> 1);
+        uint32_t A[MX_CHAIN_MAX_SRC][6];
+#pragma unroll
+        for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
+#pragma unroll
+            for (int w = 0; w < 6; ++w) A[k][w] = 0xffffffffu;
+            if ((mask >> k) & 1u) {
+                const auto& al = a.al[k];
+                const uint32_t o0 = __umul24(2u * yc, al.stride) + xc * 8u;
+                const uint2 r0 = *reinterpret_cast<const uint2*>(al.p + (size_t)o0);
+                const uint2 r1 = *reinterpret_cast<const uint2*>(al.p + (size_t)(o0 + al.stride));
+                A[k][0] = r0.x; A[k][1] = r0.y; A[k][2] = r1.x; A[k][3] = r1.y;
+                A[k][4] = A[k][5] = __builtin_amdgcn_perm(r0.y, r0.x, 0x06040200u);
+            }
+        }
+        uint32_t fd[MX_CHAIN_MAX_SRC - 1], via[MX_CHAIN_MAX_SRC - 1];
+#pragma unroll
+        for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) { fd[k] = a.fade[k]; via[k] = a.v_is_a[k]; }
+        chain_eval_alpha<6>(v, L, A, a.n_src, fd, via, mask);
+    } else {
+        chain_eval_pk<6>(v, L, a.n_src, fa, fb);
+    }
     if (!valid) return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -561,11 +674,11 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
         }
     }
 }
-template <int MM, bool SC>
+template <int MM, bool SC, bool AL = false>
 __global__ __launch_bounds__(256) void k_fade_chain_rgba(ChainRgbaArgs a, uint32_t tx, uint32_t n_tiles) {
     const uint32_t t = xcd_run(blockIdx.x, n_tiles);
-    if constexpr (SC) chain_rgba_tile<MM, SC>(a, (int)(t % tx), (int)(t / tx));
-    else chain_rgba_tile<MM, SC>(a, (int)t, 0);
+    if constexpr (SC) chain_rgba_tile<MM, SC, false>(a, (int)(t % tx), (int)(t / tx));
+    else chain_rgba_tile<MM, SC, AL>(a, (int)t, 0);
 }
 
 // A blank row per device (Y = 0x00, U = V = 0x80: what AvFrame::blank writes, frame.rs:128-132), 32 KB each, read with stride 0 by the
@@ -591,6 +704,7 @@ static void chain_blank_planes(ChainRgbaArgs& a) {   // kernels without inline-s
     for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k)
         for (int p = 0; p < 3; ++p)
             if (k >= (int)a.n_src || !a.src[k].p[p]) { a.src[k].p[p] = blank_row(p); a.src[k].stride[p] = 0; }
+    for (int k = (int)a.n_src; k < MX_CHAIN_MAX_SRC; ++k) { a.al[k].p = nullptr; a.al[k].stride = 0; a.al[k]._pad = 0; a.alpha_mask &= ~(1u << k); }
 }
 // what the launcher derives from the arguments once per launch: the matrix mode (24-bit products when every entry fits) and the
 // per-step cross-fade factors as packed u16 pairs (chain_eval_pk)
@@ -603,18 +717,23 @@ static int chain_matrix_mode(ChainRgbaArgs& a) {
     // A step whose factor for the running composite is 255 returns it unchanged -- (255 v + 0 o) / 255 = v exactly -- and one whose factor
     // is 0 returns the other layer exactly: a fader at either end of its travel (where a fader usually rests).  Such steps are dropped
     // here, bit for bit the same picture: the first kind leaves its layer unread, the second restarts the chain at its layer.
+    // With coverage planes (ChainAlpha): a step whose nominal factor for the OTHER layer is 0 still leaves the running composite unchanged (w_other = (a 0) / 255
+    // = 0) unless the composite is the bare base layer WITH coverage (its own coverage then decides); a step whose nominal factor for the other layer is 255
+    // returns that layer exactly only when the layer is opaque.
     if (!a.n_scaled && a.n_src >= 2) {
-        ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t fade[MX_CHAIN_MAX_SRC - 1], via[MX_CHAIN_MAX_SRC - 1]; uint32_t n = 1;
-        src[0] = a.src[0];
+        ChainSrc src[MX_CHAIN_MAX_SRC]; ChainAlpha al[MX_CHAIN_MAX_SRC]; uint32_t fade[MX_CHAIN_MAX_SRC - 1], via[MX_CHAIN_MAX_SRC - 1]; uint32_t n = 1;
+        src[0] = a.src[0]; al[0] = (a.alpha_mask & 1u) ? a.al[0] : ChainAlpha{nullptr, 0, 0};
         for (uint32_t k = 1; k < a.n_src; ++k) {
             const uint32_t f = (a.v_is_a[k - 1] ? a.fade[k - 1] : 255u - a.fade[k - 1]) & 0xffu;   // the running composite's factor
-            if (f == 255u) continue;
-            if (f == 0u) { src[0] = a.src[k]; n = 1; continue; }
-            src[n] = a.src[k]; fade[n - 1] = a.fade[k - 1]; via[n - 1] = a.v_is_a[k - 1]; ++n;
+            const bool other_alpha = ((a.alpha_mask >> k) & 1u) != 0, base_alpha = n == 1 && al[0].p != nullptr;
+            if (f == 255u && !base_alpha) continue;
+            if (f == 0u && !other_alpha) { src[0] = a.src[k]; al[0] = ChainAlpha{nullptr, 0, 0}; n = 1; continue; }
+            src[n] = a.src[k]; al[n] = other_alpha ? a.al[k] : ChainAlpha{nullptr, 0, 0}; fade[n - 1] = a.fade[k - 1]; via[n - 1] = a.v_is_a[k - 1]; ++n;
         }
-        for (uint32_t k = 0; k < n; ++k) a.src[k] = src[k];
+        a.alpha_mask = 0;
+        for (uint32_t k = 0; k < n; ++k) { a.src[k] = src[k]; a.al[k] = al[k]; if (al[k].p) a.alpha_mask |= 1u << k; }
         for (uint32_t k = 0; k + 1 < n; ++k) { a.fade[k] = fade[k]; a.v_is_a[k] = via[k]; }
-        for (uint32_t k = n; k < MX_CHAIN_MAX_SRC; ++k) { for (int pl = 0; pl < 3; ++pl) { a.src[k].p[pl] = nullptr; a.src[k].stride[pl] = 0; } }
+        for (uint32_t k = n; k < MX_CHAIN_MAX_SRC; ++k) { for (int pl = 0; pl < 3; ++pl) { a.src[k].p[pl] = nullptr; a.src[k].stride[pl] = 0; } a.al[k] = ChainAlpha{nullptr, 0, 0}; }
         for (uint32_t k = n - 1; k < MX_CHAIN_MAX_SRC - 1; ++k) { a.fade[k] = 0; a.v_is_a[k] = 1; }
         a.n_src = n;
     }
@@ -650,6 +769,7 @@ void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
     const uint32_t tx = (a.width + 127) / 128, n_tiles = tx * ((a.height + 31) / 32);
     const dim3 grid(n_tiles);
     if (a.n_scaled) {
+        if (a.alpha_mask) throw Error(MX_ERR_INTERNAL, "a chain with coverage planes reached the inline-scaling kernel");
         const size_t lds = CS_T_BYTES + (size_t)a.n_scaled * CS_S_BYTES;
         if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
         else if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, true>), grid, dim3(256), lds, s, a, tx, n_tiles);
@@ -659,6 +779,13 @@ void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
     }
     chain_blank_planes(a);
     const uint32_t nb = chain_strip_blocks(a);   // the strip form: tx = 0 marks it for the kernel
+    if (a.alpha_mask) {
+        if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, false, true>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+        else if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false, true>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+        else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false, true>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+        else hipLaunchKernelGGL((k_fade_chain_rgba<0, false, true>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+        return;
+    }
     if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
     else if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
     else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
@@ -874,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_scale_bicubic_tiled(ScaleBatchArgs a, u
 typedef const __attribute__((address_space(4))) VideoBatchDesc* VbDescPtr;
 __device__ __forceinline__ uint32_t pin_s32(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
 template <class T> __device__ __forceinline__ T* pin_sptr(T* v) { uint64_t u = (uint64_t)(uintptr_t)v; asm volatile("" : "+s"(u)); return (T*)(uintptr_t)u; }
-template <int MM>
+template <int MM, bool AL = false>
 __global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc, const VbRows rows) {
     typedef const __attribute__((address_space(4))) uint8_t* BytePtr;
     const uint32_t x = blockIdx.x;
@@ -884,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc,
     if (x >= n) return;
     if (!r.is_job) {
         typedef const __attribute__((address_space(4))) ChainRgbaArgs* ChainPtr;
-        chain_rgba_tile<MM, false>(*(ChainPtr)((BytePtr)desc + r.off), (int)xcd_run(x, n), 0);
+        chain_rgba_tile<MM, false, AL>(*(ChainPtr)((BytePtr)desc + r.off), (int)xcd_run(x, n), 0);
         return;
     }
     const uint32_t t = xcd_run(x, n);
@@ -1057,12 +1184,14 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     static const int no_fuse = env_int("MX_VIDEO_NO_LAUNCH_FUSION", 0);
     bool one = !no_fuse && n_jobs <= MX_VB_MAX_JOBS && n_chains <= MX_VB_MAX_CHAINS;
     int mm = -1;
+    bool any_alpha = false;   // a launch whose chains include one with coverage planes runs the kernel that knows them (the others take its plain steps: the mask is per chain)
     for (int k = 0; k < n_chains && one; ++k) {
         ChainRgbaArgs c = chains[k];
         if (c.n_scaled || !c.width || !c.height) one = false;
         const int m = chain_matrix_mode(c);
         if (mm >= 0 && m != mm) one = false;
         mm = m;
+        any_alpha = any_alpha || c.alpha_mask != 0;
     }
     if (!one) { launch_separately(jobs, n_jobs, chains, n_chains, s); return; }
     // the descriptor: built in host memory, then looked up among the slots already on the device
@@ -1145,6 +1274,12 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
             r.variant = jb.variant; r.s_rows = jb.s_rows;
         }
     }
+    if (any_alpha) {
+        if (mm == 3) hipLaunchKernelGGL((k_video_batch<3, true>), grid, dim3(256), lds, s, dd, rows);
+        else if (mm == 2) hipLaunchKernelGGL((k_video_batch<2, true>), grid, dim3(256), lds, s, dd, rows);
+        else if (mm == 1) hipLaunchKernelGGL((k_video_batch<1, true>), grid, dim3(256), lds, s, dd, rows);
+        else hipLaunchKernelGGL((k_video_batch<0, true>), grid, dim3(256), lds, s, dd, rows);
+    } else
     if (mm == 3) hipLaunchKernelGGL(k_video_batch<3>, grid, dim3(256), lds, s, dd, rows);
     else if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd, rows);
     else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd, rows);
@@ -1251,19 +1386,24 @@ __global__ __launch_bounds__(256) void k_yuv420_to_rgba(RgbaArgs a) {
 // packed RGB -> yuv444p (BUILD-SPECIFIED, DESIGN.md "Pixel formats"): what a packed scaler input stands for.  One lane per pixel; an ingest
 // format conversion, not a hot path.
 __global__ __launch_bounds__(256) void k_rgb_to_yuv444(const uint8_t* __restrict__ src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi,
-                                                       uint8_t* __restrict__ dy, uint8_t* __restrict__ du, uint8_t* __restrict__ dv, uint32_t sy, uint32_t su, uint32_t sv) {
+                                                       uint8_t* __restrict__ dy, uint8_t* __restrict__ du, uint8_t* __restrict__ dv, uint32_t sy, uint32_t su, uint32_t sv,
+                                                       uint8_t* __restrict__ da, uint32_t sa, uint32_t ai) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const uint8_t* px = src + (size_t)y * src_stride + (size_t)x * bpp;
     const int R = px[ri], G = px[gi], B = px[bi];
+    if (da) da[(size_t)y * sa + x] = px[ai];   // the A byte: the pixel's coverage (straight alpha), as it is
     dy[(size_t)y * sy + x] = (uint8_t)(((47 * R + 157 * G + 16 * B + 128) >> 8) + 16);
     du[(size_t)y * su + x] = (uint8_t)(((-26 * R - 87 * G + 112 * B + 128) >> 8) + 128);
     dv[(size_t)y * sv + x] = (uint8_t)(((112 * R - 102 * G - 10 * B + 128) >> 8) + 128);
 }
-void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s) {
+void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s,
+                          uint8_t* alpha_dst, uint32_t alpha_stride, uint32_t ai) {
     flush_scales(s);
     if (!w || !h) return;
-    hipLaunchKernelGGL(k_rgb_to_yuv444, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w, h, bpp, ri, gi, bi, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2]);
+    if (bpp != 4) alpha_dst = nullptr;
+    hipLaunchKernelGGL(k_rgb_to_yuv444, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, src_stride, w, h, bpp, ri, gi, bi, dst[0], dst[1], dst[2], dst_stride[0], dst_stride[1], dst_stride[2],
+                       alpha_dst, alpha_stride, ai);
 }
 // b-bit samples (10, 12, 16) in 16-bit words -> the 8-bit frame of the same layout (BUILD-SPECIFIED, include/mixlab_gpu.h mx_pixfmt):
 // min(255, (v + 2^(b-9)) >> (b - 8)) with v = (word >> shift) & (2^b - 1).  Four samples per lane, all three planes in one launch (blockIdx.z); an ingest

@@ -54,11 +54,11 @@ void flush_locked(hipStream_t s, PendingScales& q) {
     q.keep.clear(); q.keep_tabs.clear();
 }
 }  // namespace
-void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs) {
+void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs, bool companion) {
     std::lock_guard<std::mutex> lk(g_scale_mu);
     PendingScales& q = g_scale_q[s];
     bool conflict = q.jobs.size() >= MX_VB_MAX_JOBS;
-    for (const FrameRef& k : q.keep) if (k.f == src.f || k.f == dst.f) conflict = true;   // no ordering inside one launch
+    if (!companion) for (const FrameRef& k : q.keep) if (k.f == src.f || k.f == dst.f) conflict = true;   // no ordering inside one launch
     if (conflict) flush_locked(s, q);
     q.jobs.push_back(a);
     q.keep.push_back(src); q.keep.push_back(dst);
@@ -94,15 +94,25 @@ static void alloc_planes(DFrame* f) {
         off[p] = total;
         total += (f->plane_bytes[p] + 255) & ~(size_t)255;
     }
+    size_t alpha_off = 0;
+    if (f->with_alpha) {   // the coverage plane: one byte per luma sample, rows 64-byte aligned like the others
+        f->alpha_stride = (f->width + 63u) & ~63u;
+        f->alpha_bytes = (size_t)f->alpha_stride * f->height;
+        alpha_off = total;
+        total += (f->alpha_bytes + 255) & ~(size_t)255;
+    }
     f->mem.alloc(total);
     for (int p = 0; p < np; ++p) f->data[p] = (uint8_t*)f->mem.p + off[p];
+    if (f->with_alpha) f->alpha = (uint8_t*)f->mem.p + alpha_off;
     if (np == 2) { f->data[2] = f->data[1]; f->stride[2] = f->stride[1]; f->plane_bytes[2] = 0; }   // nv12: V = the odd bytes of the UV plane
 }
 
-DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
+DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt, bool alpha) {
     if (fmt > DFrame::kLastFmt) throw Error(MX_ERR_INVALID, "unknown pixel format");
     std::unique_ptr<DFrame> f(new DFrame());
     f->fmt = fmt;
+    f->with_alpha = alpha;
+    if (alpha && (f->packed() || f->deep() || f->semi())) throw Error(MX_ERR_INVALID, "a coverage plane goes with planar 8-bit YUV (yuva420p); four-byte packed RGB carries its own");
     if (w == 0 || h == 0 || (w & ((1u << f->cw()) - 1u)) || (h & ((1u << f->chs()) - 1u)))
         throw Error(MX_ERR_INVALID, "frame size must be non-zero and a multiple of the chroma subsampling (yuv420p: even)");
     if (w > 16384 || h > 16384) throw Error(MX_ERR_INVALID, "frame too large");
@@ -111,9 +121,10 @@ DFrame* DFrame::create_unfilled(uint32_t w, uint32_t h, uint8_t fmt) {
     return f.release();
 }
 
-DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt) {
-    std::unique_ptr<DFrame> f(create_unfilled(w, h, fmt));
+DFrame* DFrame::create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt, bool alpha) {
+    std::unique_ptr<DFrame> f(create_unfilled(w, h, fmt, alpha));
     launch_blank(f->data[0], f->plane_bytes[0], f->data[1], f->plane_bytes[1], f->data[2], f->plane_bytes[2], s, f->blank_chroma());
+    if (f->alpha) hip_check(hipMemsetAsync(f->alpha, 0xff, f->alpha_bytes, s), "hipMemsetAsync(alpha)");   // a blank frame is opaque
     return f.release();
 }
 
@@ -125,9 +136,14 @@ DFrame* DFrame::create_lazy(uint32_t w, uint32_t h, std::shared_ptr<LazyChain> c
 }
 
 void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], uint32_t& n_src,
-                        uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1]) {
+                        uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1],
+                        ChainAlpha (&al)[MX_CHAIN_MAX_SRC], uint32_t& alpha_mask) {
+    alpha_mask = 0;
     auto put = [&](int k, const FrameRef& f) {
         for (int p = 0; p < 3; ++p) { src[k].p[p] = f ? f->data[p] : nullptr; src[k].stride[p] = f ? f->stride[p] : 0; }
+        al[k].p = (f && f->alpha) ? f->alpha : nullptr; al[k].stride = al[k].p ? f->alpha_stride : 0; al[k]._pad = 0;
+        if (f && f->with_alpha && !f->alpha) throw Error(MX_ERR_INTERNAL, "a frame with coverage reached a chain without its pixels");
+        if (al[k].p) alpha_mask |= 1u << k;
     };
     if (c.steps.size() + 1 > MX_CHAIN_MAX_SRC) throw Error(MX_ERR_INTERNAL, "cross-fade chain too long");
     for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) put(k, FrameRef());
@@ -143,6 +159,7 @@ void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], u
 DFrame* DFrame::create_lazy_scale(uint32_t w, uint32_t h, std::shared_ptr<LazyScale> sc) {
     std::unique_ptr<DFrame> f(new DFrame());
     f->width = w; f->height = h;
+    f->with_alpha = sc->src && sc->src->carries_alpha() && sc->target && sc->target->alpha;   // known before the pixels exist
     f->lazy_scale = std::move(sc);
     return f.release();
 }
@@ -155,7 +172,8 @@ static void chain_layers_need_pixels(const LazyChain& c, hipStream_t s) {   // k
 static void launch_chain_into(const LazyChain& c, DFrame* o, hipStream_t s) {
     chain_layers_need_pixels(c, s);
     ChainArgs a;
-    fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a);
+    fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a, a.al, a.alpha_mask);
+    a._pad1 = 0;
     for (int p = 0; p < 3; ++p) {
         a.out[p] = o->data[p]; a.out_stride[p] = o->stride[p];
         a.chunks_per_row[p] = ((o->pw(p) + 31u) / 32u) * 2u;     // fade_line's 32-byte blocks (video_mixer.rs:219-234)
@@ -172,6 +190,7 @@ void DFrame::ensure_pixels(hipStream_t s) {
         scale_into(sc->src, sc->t, sc->target, nullptr, s);
         alias = sc->target;
         for (int p = 0; p < 3; ++p) { data[p] = alias->data[p]; stride[p] = alias->stride[p]; plane_bytes[p] = alias->plane_bytes[p]; }
+        if (with_alpha) { alpha = alias->alpha; alpha_stride = alias->alpha_stride; alpha_bytes = alias->alpha_bytes; }
         return;
     }
     if (!lazy) return;
@@ -199,15 +218,18 @@ void fill_chain_rgba_sources(const LazyChain& c, ChainRgbaArgs& a, hipStream_t s
     // as an opt-in (MX_SCALE_INLINE=1, read per call so tests can switch it), bit-exact either way.
     const char* const inl = getenv("MX_SCALE_INLINE");
     const bool no_inline = !(inl && atoi(inl) != 0);
+    bool any_alpha = c.base && c.base->with_alpha;
+    for (const auto& st : c.steps) any_alpha = any_alpha || (st.other && st.other->with_alpha);
     auto take = [&](const FrameRef& f, uint32_t k) {
         if (!f || !f->lazy_scale) return;
-        if (no_inline || a.n_scaled == MX_CHAIN_MAX_SCALED || !f->lazy_scale->t->four_tap || !f->lazy_scale->src->data[0] || f->lazy_scale->src->semi()) { f->ensure_pixels(s); return; }
+        if (no_inline || any_alpha || a.n_scaled == MX_CHAIN_MAX_SCALED || !f->lazy_scale->t->four_tap || !f->lazy_scale->src->data[0] || f->lazy_scale->src->semi()) { f->ensure_pixels(s); return; }
         chain_scale_of(*f->lazy_scale, a.sc[a.n_scaled]);
         a.scaled_src[a.n_scaled++] = k;
     };
     take(c.base, 0);
     for (size_t k = 0; k < c.steps.size(); ++k) take(c.steps[k].other, (uint32_t)k + 1);
-    fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a);   // an inline-scaled layer has no planes: nullptr here, as a blank one
+    fill_chain_sources(c, a.src, a.n_src, a.fade, a.v_is_a, a.al, a.alpha_mask);   // an inline-scaled layer has no planes: nullptr here, as a blank one
+    a._pad1 = 0;
 }
 
 // (a, b, fade) -> chain; a lazy operand's own chain is extended instead of being evaluated
@@ -405,6 +427,7 @@ BandScaler::BandScaler(uint32_t in_w, uint32_t in_full_h, uint32_t src_row0, uin
 void BandScaler::run(const DFrame* slice, DFrame* out, hipStream_t s) {
     if (!slice || !out) throw Error(MX_ERR_INVALID, "NULL frame");
     if (slice->fmt != MX_PIXFMT_YUV420P || out->fmt != MX_PIXFMT_YUV420P) throw Error(MX_ERR_INVALID, "row bands are cut from yuv420p pictures");
+    if (slice->with_alpha) throw Error(MX_ERR_INVALID, "a band-scaled layer cannot carry a coverage plane (feed layers with alpha at the picture's own size, cut to the band)");
     if (slice->width != in_w_ || slice->height != slice_rows_ || out->width != full_w_ || out->height != band_rows_ || !slice->data[0] || !out->data[0])
         throw Error(MX_ERR_INVALID, "frames do not have the sizes this band scaler was planned for");
     if (needs_blank_ || !any_) launch_blank(out->data[0], out->plane_bytes[0], out->data[1], out->plane_bytes[1], out->data[2], out->plane_bytes[2], s);   // AvFrame::blank: the letterbox bars
@@ -437,8 +460,8 @@ void scale_band(const DFrame* slice, uint32_t in_full_h, uint32_t src_row0, DFra
     hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");   // the tables and the row buffer die here
 }
 
-void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
-    in_w_ = in_w; in_h_ = in_h; in_fmt_ = in_fmt;
+void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt, bool in_alpha) {
+    in_w_ = in_w; in_h_ = in_h; in_fmt_ = in_fmt; in_alpha_ = in_alpha;
     auto t = std::make_shared<ScaleTables>();
     t->in_w = in_w; t->in_h = in_h; t->out_w = out_w_; t->out_h = out_h_;
     t->in_cw = DFrame::fmt_cw(in_fmt); t->in_ch = DFrame::fmt_ch(in_fmt);
@@ -447,7 +470,7 @@ void Scaler::retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt) {
     const ScaleGeometry& geo = t->geo;
     flush_scales(stream_);             // queued jobs write the old output frames
     ring_.assign(2 * (size_t)video_batch_ticks(), FrameRef());
-    for (auto& f : ring_) f = FrameRef(DFrame::create(out_w_, out_h_, stream_), false);   // AvFrame::blank(output_picture), encode.rs:382
+    for (auto& f : ring_) f = FrameRef(DFrame::create(out_w_, out_h_, stream_, MX_PIXFMT_YUV420P, in_alpha), false);   // AvFrame::blank(output_picture), encode.rs:382 (a coverage plane goes along with the picture)
     ring_pos_ = 0; frame_ = ring_[0];
     keep_pool_.clear();                // their borders belong to the old letterbox
     if (geo.scaled_w == 0 || geo.scaled_h == 0) {   // a picture so thin that its aligned scaled size has no rows or columns: scale() hands out the blank frame
@@ -518,12 +541,24 @@ void scale_into(const FrameRef& in, const std::shared_ptr<const ScaleTables>& tp
         sp.hx = t.hx[c]; sp.vx = t.vx[c]; sp.mh = t.mh[c]; sp.mv = t.mv[c];
         sp.sxs = in->xstep(p) - 1u; sp.sxo = in->xoff(p);
     }
+    // BUILD-SPECIFIED: the coverage plane is resampled like the luma plane (its tables, its passes) into the same letterboxed rectangle; the bars keep the
+    // 255 the blank target was created with.  A companion job whose chroma slots are empty.
+    ScaleArgs al{};
+    const bool with_alpha = in->alpha && target->alpha;
+    if (with_alpha) {
+        al.p[0] = a.p[0];
+        al.p[0].src = in->alpha; al.p[0].src_stride = in->alpha_stride;
+        al.p[0].dst = target->alpha + (size_t)t.geo.letterbox_y * target->alpha_stride + t.geo.letterbox_x; al.p[0].dst_stride = target->alpha_stride;
+        al.p[0].sxs = 0; al.p[0].sxo = 0;
+    }
     if (tmp_plane && tmp_plane[0]) {        // widened kernel (downscale): two passes, launched in stream order
         flush_scales(s);
         launch_scale_wide(a, s);
+        if (with_alpha) launch_scale_wide(al, s);   // after the luma passes in stream order: the row buffer is free again
         return;
     }
     queue_scale(a, s, in, target, tp);      // leaves with the other scales of this tick as one launch
+    if (with_alpha) queue_scale(al, s, in, target, tp, true);
 }
 
 // a packed RGB (or gray8) input is first turned into the yuv444p frame it stands for, a 10-bit one into the 8-bit frame of its layout (build-specified
@@ -532,11 +567,12 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
     if (!in->packed() && !in->deep()) return in;
     const DFrame::Deep* deep = DFrame::deep_of(in->fmt);
     const uint8_t as_fmt = deep ? deep->layout : (in->yuyv() ? (uint8_t)MX_PIXFMT_YUV422P : (uint8_t)MX_PIXFMT_YUV444P);
+    const bool want_alpha = DFrame::rgb_of(in->fmt).bpp == 4;   // the A byte is the pixel's coverage (straight alpha): it travels as the planar frame's coverage plane
     FrameRef out;
-    for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->fmt == as_fmt && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
+    for (auto& f : rgb_pool_) if (f->width == in->width && f->height == in->height && f->fmt == as_fmt && f->with_alpha == want_alpha && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }
     if (!out) {
         if (rgb_pool_.size() >= 2 * (size_t)video_batch_ticks() + 2) rgb_pool_.erase(rgb_pool_.begin());
-        rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, as_fmt), false));
+        rgb_pool_.push_back(FrameRef(DFrame::create(in->width, in->height, stream_, as_fmt, want_alpha), false));
         out = rgb_pool_.back();
     }
     if (deep) {
@@ -561,7 +597,8 @@ FrameRef Scaler::planar_of(const FrameRef& in) {
         return out;
     }
     const DFrame::Rgb rgb = DFrame::rgb_of(in->fmt);
-    launch_rgb_to_yuv444(in->data[0], in->stride[0], in->width, in->height, rgb.bpp, rgb.r, rgb.g, rgb.b, out->data, out->stride, stream_);
+    launch_rgb_to_yuv444(in->data[0], in->stride[0], in->width, in->height, rgb.bpp, rgb.r, rgb.g, rgb.b, out->data, out->stride, stream_,
+                         out->alpha, out->alpha_stride, 6u - rgb.r - rgb.g - rgb.b);   // the byte of a four-byte pixel that is none of R, G, B
     return out;
 }
 
@@ -570,7 +607,7 @@ FrameRef Scaler::scale(const FrameRef& in0, bool may_defer) {
     in0->ensure_pixels(stream_);                                                 // a symbolic frame must exist before it can be resampled
     const FrameRef in = planar_of(in0);
     if (in.f != in0.f && in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;   // a 10-bit 4:2:0 picture of the output's size: its 8-bit frame is the result
-    if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);   // encode.rs:347-384
+    if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt || in_alpha_ != in->with_alpha) retarget(in->width, in->height, in->fmt, in->with_alpha);   // encode.rs:347-384
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return frame_;
     ring_pos_ = (ring_pos_ + 1) % (uint32_t)ring_.size(); frame_ = ring_[ring_pos_];   // not a frame the last 2K - 1 calls wrote: the RGBA chains that read those may be launched AFTER this scale (Graph defers them)
     if (may_defer && t_->four_tap) {
@@ -587,7 +624,7 @@ FrameRef Scaler::scale_keep(const FrameRef& in0) {
     in0->ensure_pixels(stream_);
     const FrameRef in = planar_of(in0);
     if (in.f != in0.f && in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;
-    if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt) retarget(in->width, in->height, in->fmt);
+    if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt || in_alpha_ != in->with_alpha) retarget(in->width, in->height, in->fmt, in->with_alpha);
     FrameRef out;
     for (auto& f : keep_pool_) if (f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }   // only the pool holds it
     if (!out) { keep_pool_.push_back(FrameRef(DFrame::create(out_w_, out_h_, stream_), false)); out = keep_pool_.back(); }

@@ -68,11 +68,19 @@ bool scale_tile_origins_match_m(uint32_t src, uint32_t dst, const int32_t* first
 // nullptr (the blank constant, video_mixer.rs:180-188).
 enum { MX_CHAIN_MAX_SRC = 8 };
 struct ChainSrc { const uint8_t* p[3]; uint32_t stride[3]; };
+// BUILD-SPECIFIED per-pixel alpha (DESIGN.md "Per-pixel alpha"; the reference's only alpha is the global fader, video_mixer.rs:168): a layer may carry a
+// coverage plane, one byte per LUMA sample (p = nullptr: opaque).  A step then weighs its two layers per sample:
+//   wa = (aA * fade) / 255;  wb = (aB * (255 - wa)) / 255;  out = (A * (255 - wb) + B * wb) / 255     (u16, truncating -- fade_line's form)
+// with aA / aB = 255 where a layer carries none -- then wa = fade, wb = 255 - fade: the reference's cross-fade bit for bit.  A chroma sample uses
+// the coverage of its co-sited luma sample (2x, 2y).  The running composite of a chain is opaque (a VideoMixer produces yuv420p without alpha), so
+// from the second step on only the OTHER layer's plane matters: w_other = (a_other * g) / 255, g its nominal factor.
+struct ChainAlpha { const uint8_t* p; uint32_t stride, _pad; };
 struct ChainArgs {
     ChainSrc src[MX_CHAIN_MAX_SRC]; uint32_t n_src;
     uint32_t fade[MX_CHAIN_MAX_SRC - 1]; uint32_t v_is_a[MX_CHAIN_MAX_SRC - 1];
     uint8_t* out[3]; uint32_t out_stride[3];
     uint32_t chunks[3], chunks_per_row[3];
+    ChainAlpha al[MX_CHAIN_MAX_SRC]; uint32_t alpha_mask, _pad1;   // bit k: src[k] carries a coverage plane
 };
 // A chain layer that is the DynamicScaler's letterboxed output of a smaller (or equal-sized) picture, resampled INSIDE the chain kernel
 // (4-tap axes only): the scaled frame is never written.  Index [0] = luma, [1] = both chroma planes.
@@ -94,6 +102,7 @@ struct ChainRgbaArgs {   // the same chain feeding the build-specified YUV420P -
     float mf[12];   // launcher-filled when every row of m is small enough for exact f32 sums (use_matrix == 3): m / 4096, the constant carrying the rounding
     uint32_t n_scaled; uint32_t scaled_src[MX_CHAIN_MAX_SCALED];   // chain position of each inline-scaled layer (its ChainSrc planes are nullptr)
     ChainScale sc[MX_CHAIN_MAX_SCALED];
+    ChainAlpha al[MX_CHAIN_MAX_SRC]; uint32_t alpha_mask, _pad1;   // coverage planes (ChainArgs); never together with inline-scaled layers
 };
 // Several ticks' video work as ONE launch (mx_k_video.hip k_video_batch): up to MX_VB_MAX_CHAINS RGBA chains and MX_VB_MAX_JOBS scale jobs
 // (a job = the three planes of one scaled frame).  The descriptor is uploaded to device memory per launch.
@@ -129,7 +138,8 @@ void launch_scale_batch(const ScaleBatchArgs& a, hipStream_t s);
 // deferred scaling: Scaler::scale queues its planes per stream; every reader of frame pixels flushes first
 struct FrameRef;
 struct ScaleTables;
-void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs = nullptr);
+void queue_scale(const ScaleArgs& a, hipStream_t s, const FrameRef& src, const FrameRef& dst, std::shared_ptr<const ScaleTables> tabs = nullptr,
+                 bool companion = false);   // companion: the coverage-plane job of the frame pair just queued (other planes of the same frames: no hazard, no flush)
 void flush_scales(hipStream_t s);
 void launch_chains_rgba_after_queued_scales(const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
 void launch_copy_planes(const CopyArgs& a, hipStream_t s);
@@ -144,7 +154,8 @@ struct DeepArgs {   // per plane: source words xstep apart from word xoff of a r
 void launch_deep_to_8(const DeepArgs& a, hipStream_t s);
 // packed 4:2:2 (yuyv: y_first 1, uyvy: 0) -> yuv422p planes: a byte shuffle
 void launch_yuyv_to_422p(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t y_first, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
-void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s);
+void launch_rgb_to_yuv444(const uint8_t* src, uint32_t src_stride, uint32_t w, uint32_t h, uint32_t bpp, uint32_t ri, uint32_t gi, uint32_t bi, uint8_t* const dst[3], const uint32_t dst_stride[3], hipStream_t s,
+                          uint8_t* alpha_dst = nullptr, uint32_t alpha_stride = 0, uint32_t ai = 0);   // alpha_dst: the A byte (byte ai of a four-byte pixel) goes to that plane
 
 // ---- exact rationals: MediaTime / MediaDuration (util/src/time.rs:9-75, num_rational::Ratio<i64>) ----
 struct Rational {
@@ -257,9 +268,16 @@ struct DFrame {
     uint8_t* data[3] = {nullptr, nullptr, nullptr};
     uint32_t stride[3] = {0, 0, 0};
     size_t plane_bytes[3] = {0, 0, 0};
+    // BUILD-SPECIFIED coverage plane (MX_PIXFMT_YUVA420P; the planar frame a four-byte packed RGB input stands for): width x height bytes, 255 = opaque.
+    // The public format YUVA420P is (fmt = YUV420P, with_alpha); a frame without pixels yet (lazy scale) knows with_alpha before `alpha` exists.
+    bool with_alpha = false;
+    uint8_t* alpha = nullptr;
+    uint32_t alpha_stride = 0;
+    size_t alpha_bytes = 0;
+    bool carries_alpha() const { return with_alpha || rgb_of(fmt).bpp == 4; }
     DevBuf mem;
-    static DFrame* create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt = MX_PIXFMT_YUV420P);   // blank-filled (frame.rs:76-138)
-    static DFrame* create_unfilled(uint32_t w, uint32_t h, uint8_t fmt);   // planes allocated, contents undefined: for a caller that overwrites every byte (FrameStager)
+    static DFrame* create(uint32_t w, uint32_t h, hipStream_t s, uint8_t fmt = MX_PIXFMT_YUV420P, bool alpha = false);   // blank-filled (frame.rs:76-138); alpha: opaque
+    static DFrame* create_unfilled(uint32_t w, uint32_t h, uint8_t fmt, bool alpha = false);   // planes allocated, contents undefined: for a caller that overwrites every byte (FrameStager)
     size_t plane_offset(int p) const { return (size_t)(data[p] - (uint8_t*)mem.p); }
     void retain() { rc.fetch_add(1, std::memory_order_relaxed); }
     void release() { if (rc.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
@@ -273,7 +291,8 @@ inline FrameRef::~FrameRef() { if (f) f->release(); }
 // flatten (a, b, fade) into a chain: extends a's (or b's) chain when that side is lazy
 std::shared_ptr<LazyChain> make_chain(const FrameRef& a, const FrameRef& b, uint8_t fade, hipStream_t s);
 void fill_chain_sources(const LazyChain& c, ChainSrc (&src)[MX_CHAIN_MAX_SRC], uint32_t& n_src,
-                        uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1]);
+                        uint32_t (&fade)[MX_CHAIN_MAX_SRC - 1], uint32_t (&v_is_a)[MX_CHAIN_MAX_SRC - 1],
+                        ChainAlpha (&al)[MX_CHAIN_MAX_SRC], uint32_t& alpha_mask);
 // the RGBA sink's form: layers that are unevaluated scaler outputs are handed over as ChainScale (up to MX_CHAIN_MAX_SCALED; the rest
 // and every layer the inline resampler cannot take are materialised on `s` first)
 void fill_chain_rgba_sources(const LazyChain& c, ChainRgbaArgs& a, hipStream_t s);
@@ -320,11 +339,12 @@ public:
     // a topology edit moved the owning VideoMixer to another graph: queued work leaves on the old stream first
     void rebind(hipStream_t s) { flush_scales(stream_); stream_ = s; }
 private:
-    void retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt);
+    void retarget(uint32_t in_w, uint32_t in_h, uint8_t in_fmt, bool in_alpha);
     uint32_t out_w_, out_h_;
     hipStream_t stream_;
     uint32_t in_w_ = 0, in_h_ = 0;   // settings the cached context was built for (encode.rs:347-352)
     uint8_t in_fmt_ = MX_PIXFMT_YUV420P;
+    bool in_alpha_ = false;          // the input carries a coverage plane: so do the output frames
     FrameRef frame_;                 // cached blank output frame (encode.rs:382) -- the one the latest scale() wrote
     std::vector<FrameRef> keep_pool_; // scale_keep's outputs: blank frames of this context's letterbox geometry, reused once released
     std::vector<FrameRef> rgb_pool_; // yuv444p frames a packed RGB input is converted into before it is resampled

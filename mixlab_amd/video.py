@@ -31,6 +31,9 @@ _proto("mx_dframe_release", None, C.c_void_p)
 _proto("mx_dframe_upload", C.c_int, C.c_void_p, C.POINTER(abi.Frame), C.c_void_p)
 _proto("mx_dframe_download", C.c_int, C.c_void_p, C.POINTER(abi.Frame), C.c_void_p)
 _proto("mx_dframe_planes", C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p * 3), C.POINTER(C.c_int32 * 3))
+_proto("mx_dframe_upload_alpha", C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+_proto("mx_dframe_download_alpha", C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+_proto("mx_dframe_alpha_plane", C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32))
 _proto("mx_video_blank", C.c_int, C.c_void_p, C.c_void_p)
 _proto("mx_video_crossfade", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p)
 _proto("mx_video_scale", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
@@ -135,6 +138,7 @@ _DEEP = tuple(DEEP)
 PIXFMT_BGR24, PIXFMT_RGBA, PIXFMT_ARGB, PIXFMT_ABGR = 23, 24, 25, 26                  # the other byte orders of packed RGB
 _PACKED_BPP = {PIXFMT_RGB24: 3, PIXFMT_BGRA: 4, PIXFMT_GRAY8: 1, PIXFMT_YUYV422: 2, PIXFMT_UYVY422: 2, PIXFMT_BGR24: 3, PIXFMT_RGBA: 4, PIXFMT_ARGB: 4, PIXFMT_ABGR: 4}
 _SEMI = (PIXFMT_NV12, PIXFMT_P010, PIXFMT_P016)
+PIXFMT_YUVA420P = 27   # yuv420p + a coverage plane (per-pixel alpha, build-specified): upload() takes the three YUV planes, upload_alpha() the fourth
 
 
 class DFrame:
@@ -150,7 +154,7 @@ class DFrame:
         f = C.c_int()
         check(lib.mx_dframe_format(self._h, C.byref(f)))
         self.fmt = f.value
-        lay = DEEP[self.fmt][0] if self.fmt in DEEP else self.fmt
+        lay = DEEP[self.fmt][0] if self.fmt in DEEP else (PIXFMT_YUV420P if self.fmt == PIXFMT_YUVA420P else self.fmt)
         self.cw = 0 if lay in (PIXFMT_YUV444P, PIXFMT_YUV440P) else (2 if lay in (PIXFMT_YUV410P, PIXFMT_YUV411P) else 1)
         self.ch = 1 if lay in (PIXFMT_YUV420P, PIXFMT_NV12, PIXFMT_YUV440P) else (2 if lay == PIXFMT_YUV410P else 0)
         w, h = C.c_uint32(), C.c_uint32()
@@ -213,6 +217,23 @@ class DFrame:
         hf = _host_frame(planes, self.width, self.height)
         check(lib.mx_dframe_download(self._h, C.byref(hf), self.stream))
         return [a.view("<u2") for a in planes] if bps == 2 else planes
+
+    def has_alpha(self) -> bool:
+        p, st = C.c_void_p(), C.c_int32()
+        check(lib.mx_dframe_alpha_plane(self._h, C.byref(p), C.byref(st)))
+        return bool(p.value)
+
+    def upload_alpha(self, alpha):
+        """yuva420p: the coverage plane, (height, width) uint8, 255 = opaque"""
+        a = np.ascontiguousarray(alpha, dtype=np.uint8)
+        assert a.shape == (self.height, self.width)
+        check(lib.mx_dframe_upload_alpha(self._h, a.ctypes.data_as(C.c_void_p), self.width, self.stream))
+        return self
+
+    def download_alpha(self):
+        a = np.empty((self.height, self.width), np.uint8)
+        check(lib.mx_dframe_download_alpha(self._h, a.ctypes.data_as(C.c_void_p), self.width, self.stream))
+        return a
 
     def device_planes(self):
         return [self._data[p] for p in range(3)], [self._stride[p] for p in range(3)]

@@ -162,6 +162,10 @@ typedef struct {
     int32_t stride[3];          /* bytes per row, multiple of 32 (video_mixer.rs:196-201) */
     uint32_t fmt;               /* 0 = yuv420p (everything the VideoMixer produces, video_mixer.rs:282-283), 1 = yuv422p, 2 = yuv444p, 3 = nv12 (data[1] = interleaved UV, data[2] unused):
                                    formats a scaler INPUT may have (codec/src/ffmpeg/scale.rs:16-39 carries the input pixel format) */
+    /* BUILD-SPECIFIED per-pixel coverage (no reference counterpart: the reference's only "alpha" is the global fader, video_mixer.rs:168): one byte per
+     * LUMA sample, 255 = opaque; NULL = the layer carries none (opaque everywhere).  See orc_video_crossfade. */
+    uint8_t* alpha;
+    int32_t alpha_stride;
 } orc_frame;
 /* chroma subsampling of a format (codec/src/ffmpeg/pixfmt.rs:97-105) */
 /* fmt: 0 yuv420p, 1 yuv422p, 2 yuv444p, 3 nv12, (4, 5: packed RGB -- orc_packed_rgb_to_yuv444), 6 yuv410p, 7 yuv411p, 8 yuv440p */
@@ -172,7 +176,14 @@ static inline uint32_t orc_fmt_ch(uint32_t fmt) { return (fmt == 0 || fmt == 3 |
 void orc_frame_blank(orc_frame* f);
 /* src/module/video_mixer.rs:168 */
 uint8_t orc_crossfade_factor(double fader);
-/* src/module/video_mixer.rs:151-239: a/b NULL => read the (blank) output plane itself */
+/* src/module/video_mixer.rs:151-239: a/b NULL => read the (blank) output plane itself.
+ * BUILD-SPECIFIED when a or b carries an alpha plane (per-pixel alpha composite, DESIGN.md "Per-pixel alpha"): per sample of every plane, with
+ * aA / aB the layers' coverage there (255 where a layer carries none; a chroma sample takes the coverage of its co-sited luma sample,
+ * (x << log2_chroma_w, y << log2_chroma_h)) and all arithmetic in u16 with truncating division, as fade_line's:
+ *     wa  = (aA * fade) / 255                 -- the fader scales A's coverage by the reference's own truncation rule
+ *     wb  = (aB * (255 - wa)) / 255           -- B takes what A leaves, as far as B covers the sample
+ *     out = (A * (255 - wb) + B * wb) / 255   -- fade_line's form with the per-sample pair (255 - wb, wb)
+ * aA = aB = 255 gives wa = fade, wb = 255 - fade: fade_line bit for bit.  The output carries no alpha (the VideoMixer produces opaque yuv420p). */
 void orc_video_crossfade(orc_frame* out, const orc_frame* a, const orc_frame* b, uint8_t fade);
 /* src/module/video_mixer.rs:276-297 */
 void orc_unify_picture_settings(uint32_t aw, uint32_t ah, uint32_t bw, uint32_t bh, uint32_t* w, uint32_t* h);
@@ -195,7 +206,7 @@ int orc_scale_plane_bicubic_rows(const uint8_t* slice, int32_t src_stride, uint3
                                  uint8_t* dst, int32_t dst_stride, uint32_t dw, uint32_t dh, uint32_t row0, uint32_t rows);
 void orc_deep_to_8(const uint8_t* const planes[3], const int32_t strides[3], uint32_t w, uint32_t h, int fmt /* 10 - 20 */, orc_frame* dst);   /* build-specified: 10- / 12- / 16-bit words -> the 8-bit frame of the layout */
 void orc_yuyv_to_422p(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt /* 21 yuyv422, 22 uyvy422 */, orc_frame* dst);   /* a byte shuffle into yuv422p */
-void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt /* 4 rgb24, 5 bgra, 23 bgr24, 24 rgba, 25 argb, 26 abgr */, orc_frame* dst);   /* build-specified */
+void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w, uint32_t h, int fmt /* 4 rgb24, 5 bgra, 23 bgr24, 24 rgba, 25 argb, 26 abgr */, orc_frame* dst);   /* build-specified; dst->alpha (when not NULL) receives the A byte of the four-byte formats, 255 for the three-byte ones */
 int orc_dynamic_scale_band(const orc_frame* in_slice, uint32_t in_full_h, uint32_t src_row0, orc_frame* out, uint32_t full_w, uint32_t full_h, uint32_t row0);
 /* src/video/encode.rs:338-397: identity when sizes match (copies), else blank + scale into letterbox */
 void orc_dynamic_scale(const orc_frame* in, orc_frame* out);

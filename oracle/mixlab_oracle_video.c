@@ -51,8 +51,43 @@ static void orc_fade_line(uint8_t* out, const uint8_t* a, const uint8_t* b, size
     }
 }
 
+/* BUILD-SPECIFIED per-pixel alpha (mixlab_oracle.h orc_video_crossfade): fade_line with a per-sample factor pair.  aa / ab: the coverage of A / B
+ * at each sample of this row, `astep` bytes apart (1 for luma, 1 << log2_chroma_w for chroma: the co-sited luma sample); NULL = 255 everywhere.
+ * Same 32-sample blocks, same u16 lanes, same truncating divisions as orc_fade_line. */
+static void orc_fade_line_alpha(uint8_t* out, const uint8_t* a, const uint8_t* b, size_t len, uint8_t fade, const uint8_t* aa, const uint8_t* ab, size_t astep, size_t alen) {
+    uint8_t* end = out + len;
+    size_t x = 0;
+    while (out < end) {
+        for (int k = 0; k < 32; k++, x++) {
+            /* samples of the block beyond the picture's width (fade_line runs to the end of its 32-byte block) have no coverage sample: opaque */
+            const uint16_t al_a = (aa && x * astep < alen) ? aa[x * astep] : 255, al_b = (ab && x * astep < alen) ? ab[x * astep] : 255;
+            const uint16_t wa = (uint16_t)((uint16_t)(al_a * (uint16_t)fade) / 255);
+            const uint16_t wb = (uint16_t)((uint16_t)(al_b * (uint16_t)(255 - wa)) / 255);
+            const uint16_t a_comp = (uint16_t)((uint16_t)a[k] * (uint16_t)(255 - wb));
+            const uint16_t b_comp = (uint16_t)((uint16_t)b[k] * wb);
+            out[k] = (uint8_t)((uint16_t)(a_comp + b_comp) / 255);
+        }
+        a += 32; b += 32; out += 32;
+    }
+}
+
 /* src/module/video_mixer.rs:151-239 */
 void orc_video_crossfade(orc_frame* out, const orc_frame* a, const orc_frame* b, uint8_t fade) {
+    if ((a && a->alpha) || (b && b->alpha)) {   /* BUILD-SPECIFIED: a layer with a coverage plane */
+        for (int plane = 0; plane < 3; plane++) {
+            const uint32_t cw = plane ? 1u : 0u, chs = plane ? 1u : 0u;   /* the composite is yuv420p (video_mixer.rs:282-283) */
+            size_t width = out->width >> cw, height = out->height >> chs;
+            const uint8_t* a_ptr = a ? a->data[plane] : out->data[plane];
+            size_t a_ls = a ? (size_t)a->stride[plane] : (size_t)out->stride[plane];
+            const uint8_t* b_ptr = b ? b->data[plane] : out->data[plane];
+            size_t b_ls = b ? (size_t)b->stride[plane] : (size_t)out->stride[plane];
+            for (size_t y = 0; y < height; y++)
+                orc_fade_line_alpha(out->data[plane] + y * (size_t)out->stride[plane], a_ptr + y * a_ls, b_ptr + y * b_ls, width, fade,
+                                    (a && a->alpha) ? a->alpha + (y << chs) * (size_t)a->alpha_stride : NULL,
+                                    (b && b->alpha) ? b->alpha + (y << chs) * (size_t)b->alpha_stride : NULL, (size_t)1 << cw, out->width);
+        }
+        return;
+    }
     for (int plane = 0; plane < 3; plane++) {
         size_t width = plane ? (out->width >> 1) : out->width;     /* video_mixer.rs:176 */
         size_t height = plane ? (out->height >> 1) : out->height;  /* video_mixer.rs:177 */
@@ -261,11 +296,24 @@ void orc_dynamic_scale(const orc_frame* in, orc_frame* out) {
             for (uint32_t y = 0; y < h; y++)
                 memcpy(out->data[p] + (size_t)y * out->stride[p], in->data[p] + (size_t)y * in->stride[p], w);
         }
+        if (out->alpha)
+            for (uint32_t y = 0; y < in->height; y++) {
+                if (in->alpha) memcpy(out->alpha + (size_t)y * out->alpha_stride, in->alpha + (size_t)y * in->alpha_stride, in->width);
+                else memset(out->alpha + (size_t)y * out->alpha_stride, 255, in->width);
+            }
         return;
     }
     orc_scale_geometry g;
     orc_scaler_geometry(in->width, in->height, out->width, out->height, &g);
     orc_frame_blank(out);
+    /* BUILD-SPECIFIED: the coverage plane is resampled like the luma plane (same taps, same passes); the letterbox bars are opaque (the blank
+     * frame they come from is, encode.rs:382) */
+    if (out->alpha) {
+        for (uint32_t y = 0; y < out->height; y++) memset(out->alpha + (size_t)y * out->alpha_stride, 255, out->width);
+        if (in->alpha && g.scaled_w && g.scaled_h)
+            orc_scale_plane_bicubic(in->alpha, in->alpha_stride, in->width, in->height,
+                                    out->alpha + (size_t)g.letterbox_y * out->alpha_stride + g.letterbox_x, out->alpha_stride, g.scaled_w, g.scaled_h);
+    }
     /* A picture so thin that its aligned scaled size has no rows or columns: the reference hands sws_getContext a zero dimension, gets
      * NULL and panics (codec/src/ffmpeg/scale.rs:22-33).  BUILD-SPECIFIED instead of a panic: the blank letterbox frame. */
     if (g.scaled_w == 0 || g.scaled_h == 0) return;
@@ -320,6 +368,7 @@ void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w
     const int ri = fmt == 4 || fmt == 24 ? 0 : (fmt == 25 ? 1 : (fmt == 26 ? 3 : 2));
     const int gi = fmt == 25 || fmt == 26 ? 2 : 1;
     const int bi = fmt == 4 || fmt == 24 ? 2 : (fmt == 25 ? 3 : (fmt == 26 ? 1 : 0));
+    const int ai = (fmt == 25 || fmt == 26) ? 0 : 3;
     for (uint32_t y = 0; y < h; y++) {
         const uint8_t* row = src + (size_t)y * src_stride;
         for (uint32_t x = 0; x < w; x++) {
@@ -327,6 +376,7 @@ void orc_packed_rgb_to_yuv444(const uint8_t* src, int32_t src_stride, uint32_t w
             dst->data[0][(size_t)y * dst->stride[0] + x] = (uint8_t)(((47 * R + 157 * G + 16 * B + 128) >> 8) + 16);
             dst->data[1][(size_t)y * dst->stride[1] + x] = (uint8_t)(((-26 * R - 87 * G + 112 * B + 128) >> 8) + 128);
             dst->data[2][(size_t)y * dst->stride[2] + x] = (uint8_t)(((112 * R - 102 * G - 10 * B + 128) >> 8) + 128);
+            if (dst->alpha) dst->alpha[(size_t)y * dst->alpha_stride + x] = bpp == 4 ? row[bpp * x + ai] : 255;   /* the A byte is the pixel's coverage (straight, not premultiplied) */
         }
     }
 }
@@ -394,15 +444,17 @@ int orc_rational_cmp(orc_rational a, orc_rational b) {
 /* ------------------------------------------------------------------------------------------ */
 /* VideoMixer::run_tick, src/module/video_mixer.rs:70-250, as a plain state machine over owned
  * frame copies (an AVFrame refcount clone of an immutable frame is observationally a copy). */
-static void vm_frame_alloc(orc_frame* f, uint32_t w, uint32_t h) {
+static void vm_frame_alloc(orc_frame* f, uint32_t w, uint32_t h, int with_alpha) {
     f->width = w; f->height = h; f->fmt = 0;   /* yuv420p, video_mixer.rs:282-283 */
     for (int p = 0; p < 3; ++p) {
         uint32_t pw = p ? w >> 1 : w, ph = p ? h >> 1 : h;
         f->stride[p] = (int32_t)((pw + 63u) & ~63u);
         f->data[p] = (uint8_t*)malloc((size_t)f->stride[p] * (ph ? ph : 1));
     }
+    f->alpha = NULL; f->alpha_stride = 0;
+    if (with_alpha) { f->alpha_stride = (int32_t)((w + 63u) & ~63u); f->alpha = (uint8_t*)malloc((size_t)f->alpha_stride * (h ? h : 1)); }   /* build-specified: the layer's coverage travels with it */
 }
-static void vm_frame_free(orc_frame* f) { for (int p = 0; p < 3; ++p) { free(f->data[p]); f->data[p] = NULL; } f->width = f->height = 0; }
+static void vm_frame_free(orc_frame* f) { for (int p = 0; p < 3; ++p) { free(f->data[p]); f->data[p] = NULL; } free(f->alpha); f->alpha = NULL; f->width = f->height = 0; }
 static void vm_frame_copy_from(orc_frame* dst, const orc_frame* src) {   /* dst freshly allocated with src's size */
     for (int p = 0; p < 3; ++p) {
         uint32_t pw = p ? src->width >> 1 : src->width, ph = p ? src->height >> 1 : src->height;
@@ -423,7 +475,7 @@ static void vm_rescale(orc_video_mixer* m, int i, uint32_t tw, uint32_t th) {
     if (!m->has_scaler[i] || m->scaler_w[i] != tw || m->scaler_h[i] != th) {
         m->has_scaler[i] = 1; m->scaler_w[i] = tw; m->scaler_h[i] = th;
         if (m->has_stored[i]) {
-            orc_frame scaled; vm_frame_alloc(&scaled, tw, th);
+            orc_frame scaled; vm_frame_alloc(&scaled, tw, th, m->stored[i].alpha != NULL);
             orc_dynamic_scale(&m->stored[i], &scaled);
             vm_frame_free(&m->stored[i]);
             m->stored[i] = scaled;
@@ -449,7 +501,7 @@ int orc_video_mixer_run_tick(orc_video_mixer* m, uint64_t t, const orc_video_inp
         if (in[i].frame) {
             if (m->has_stored[i]) { vm_frame_free(&m->stored[i]); m->has_stored[i] = 0; }
             vm_rescale(m, i, tw, th);
-            vm_frame_alloc(&m->stored[i], tw, th);
+            vm_frame_alloc(&m->stored[i], tw, th, in[i].frame->alpha != NULL);
             orc_dynamic_scale(in[i].frame, &m->stored[i]);
             m->active_until[i] = orc_rational_add(orc_rational_add(now, in[i].tick_offset), in[i].duration_hint);
             m->has_stored[i] = 1;

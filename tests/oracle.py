@@ -47,7 +47,8 @@ class OEdge(C.Structure):
 
 class OFrame(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("data", C.c_void_p * 3), ("stride", C.c_int32 * 3),
-                ("fmt", C.c_uint32)]   # 0 yuv420p, 1 yuv422p, 2 yuv444p
+                ("fmt", C.c_uint32),   # 0 yuv420p, 1 yuv422p, 2 yuv444p
+                ("alpha", C.c_void_p), ("alpha_stride", C.c_int32)]   # build-specified coverage plane (one byte per luma sample), NULL = opaque
 
 
 class ScaleGeometry(C.Structure):

@@ -55,6 +55,18 @@ class HostFrame:
             self.c.data[p] = self.planes[p].ctypes.data
             self.c.stride[p] = self.planes[p].shape[1]
 
+    def set_alpha(self, alpha=None):
+        """attach a coverage plane (build-specified per-pixel alpha): (h, w) uint8, default opaque"""
+        self.alpha = np.full((self.h, align(self.w, 64)), 255, np.uint8)
+        if alpha is not None:
+            self.alpha[:, : self.w] = alpha
+        self.c.alpha = self.alpha.ctypes.data
+        self.c.alpha_stride = self.alpha.shape[1]
+        return self
+
+    def visible_alpha(self):
+        return self.alpha[:, : self.w]
+
     def visible(self):
         if self.fmt == 3:
             return [self.planes[0][:, : self.w], self.planes[1][:, : self.w]]
@@ -92,6 +104,8 @@ def packed_rgb_to_yuv444(pix: np.ndarray, fmt: int) -> HostFrame:
     a = np.ascontiguousarray(pix, dtype=np.uint8)
     h, w, bpp = a.shape
     out = HostFrame(w, h, 2)
+    if bpp == 4:
+        out.set_alpha()       # the A byte is the pixel's coverage: it travels as the planar frame's coverage plane
     lib.orc_packed_rgb_to_yuv444(a.ctypes.data_as(C.c_void_p), w * bpp, w, h, fmt, C.byref(out.c))
     return out
 
