@@ -155,8 +155,9 @@ __device__ __forceinline__ u16x2 div255_pk(u16x2 x) {
 // One step with coverage.  v: the running composite (opaque unless it is still the bare base layer: av != nullptr), o / ao: the other layer and its coverage
 // (ao == nullptr: opaque), F = (fader * 255) as u8, via: the running composite sits on input A.
 //   wa = (aA F) / 255;  wb = (aB (255 - wa)) / 255;  out = (A (255 - wb) + B wb) / 255
-template <int NW>
-__device__ __forceinline__ void chain_step_alpha(Px4 (&acc)[NW], const uint32_t (&o)[NW], const uint32_t* ao, const uint32_t* av, const uint32_t F, const bool via) {
+template <int NW>   // (arrays by reference and flags, never pointers: a register array whose address is taken lives in scratch memory)
+__device__ __forceinline__ void chain_step_alpha(Px4 (&acc)[NW], const uint32_t (&o)[NW], const uint32_t (&ao_)[NW], const bool ao, const uint32_t (&av_)[NW], const bool av,
+                                                 const uint32_t F, const bool via) {
     const u16x2 k255 = {255, 255};
     const unsigned short f = (unsigned short)(via ? F : 255u - F), g = (unsigned short)(255u - f);   // nominal factors of the running composite and of the other layer
     const u16x2 gp = {g, g}, Fp = {(unsigned short)F, (unsigned short)F};
@@ -164,12 +165,12 @@ __device__ __forceinline__ void chain_step_alpha(Px4 (&acc)[NW], const uint32_t 
     for (int w = 0; w < NW; ++w) {
         u16x2 wo_e, wo_o;
         if (!av) {   // opaque running composite: the other layer's factor is its nominal one scaled by its coverage, the composite takes the rest
-            const Px4 a = px4_unpack(ao[w]);
-            wo_e = div255_pk(a.e * gp); wo_o = div255_pk(a.o * gp);
+            const Px4 a = px4_unpack(ao_[w]);
+            wo_e = div255_pk(a.e * gp); wo_o = div255_pk(a.o * gp);   // (x + 1 rides on the multiply: one v_pk_mad_u16)
         } else {
-            const Px4 a_v = px4_unpack(av[w]);
+            const Px4 a_v = px4_unpack(av_[w]);
             Px4 a_o; a_o.e = k255; a_o.o = k255;
-            if (ao) a_o = px4_unpack(ao[w]);
+            if (ao) a_o = px4_unpack(ao_[w]);
             if (via) {   // A = running composite, B = other
                 const u16x2 wa_e = div255_pk(a_v.e * Fp), wa_o = div255_pk(a_v.o * Fp);
                 wo_e = div255_pk(a_o.e * (k255 - wa_e)); wo_o = div255_pk(a_o.o * (k255 - wa_o));
@@ -201,7 +202,7 @@ __device__ __forceinline__ void chain_eval_alpha(uint32_t (&v)[NW], const uint32
 #pragma unroll
                 for (int w = 0; w < NW; ++w) acc[w] = fade_px4(acc[w], px4_unpack(L[k][w]), fa, fb);
             } else {
-                chain_step_alpha<NW>(acc, L[k], oa ? A[k] : nullptr, va ? A[0] : nullptr, F, via);
+                chain_step_alpha<NW>(acc, L[k], A[k], oa, A[0], va, F, via);
             }
         }
     }
@@ -303,7 +304,32 @@ __device__ __forceinline__ void yuv_px_pair_f32(const float* mf, int Y0, int Y1,
     p0 = __builtin_amdgcn_cvt_pk_u8_f32(o[2].x, 2u, __builtin_amdgcn_cvt_pk_u8_f32(o[1].x, 1u, __builtin_amdgcn_cvt_pk_u8_f32(o[0].x, 0u, 0xff000000u)));
     p1 = __builtin_amdgcn_cvt_pk_u8_f32(o[2].y, 2u, __builtin_amdgcn_cvt_pk_u8_f32(o[1].y, 1u, __builtin_amdgcn_cvt_pk_u8_f32(o[0].y, 0u, 0xff000000u)));
 }
-template <int MM>   // matrix mode: 0 none, 1 full 32-bit products, 2 24-bit products (3: yuv_px_pair_f32)
+// Matrix mode 4 (EXPERIMENT, MX_VIDEO_MFMA_MATRIX=1; DESIGN.md "Colour matrix on the matrix cores"): the Q12 3 x 4 matrix as v_mfma_i32_4x4x4_16b_i8 -- sixteen independent
+// 4 x 4 x 4 i8 products per instruction, a block = four neighbouring lanes.  Lane (block, j) supplies column j of B -- ITS OWN pixel as the signed bytes
+// (R - 128, G - 128, B - 128, 0) -- and row j of A -- row j of the coefficient matrix -- and receives D[0..3][j]: the three output channels of its own pixel
+// (layout probed on the chip, tools/mfma_probe.hip).  Integer, hence exact: m = 256 mh + ml with ml in [-128, 127] and mh an i8 (the launcher takes this mode only
+// when every coefficient is below 2^15 - 128 in magnitude): sum m v = 256 sum mh x + sum ml x + 128 sum m with x = v - 128; the constant (m3 + 2048 + 128 sum m) enters
+// through the accumulator.  Per pixel: 2 MFMA + 3 shift-adds + the same clip-and-pack as the integer modes.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct MfmaMatrix { int a_hi, a_lo, c0, c1, c2; };   // this lane's rows of mh / ml (bytes k = 0 .. 2, byte 3 zero) and the three constants
+__device__ __forceinline__ uint32_t mx_px_mfma(const MfmaMatrix& q, uint32_t rgb_s /* (R, G, B, 0) - 128 as bytes */) {
+    const i32x4 z = {0, 0, 0, 0};
+    const i32x4 h = __builtin_amdgcn_mfma_i32_4x4x4i8(q.a_hi, (int)rgb_s, z, 0, 0, 0);
+    const i32x4 c = {(h.x << 8) + q.c0, (h.y << 8) + q.c1, (h.z << 8) + q.c2, 0};
+    const i32x4 d = __builtin_amdgcn_mfma_i32_4x4x4i8(q.a_lo, (int)rgb_s, c, 0, 0, 0);
+    return pack_rgba(d.x, d.y, d.z, 12);
+}
+__device__ __forceinline__ void yuv_px_pair_mfma(const MfmaMatrix& q, int Y0, int Y1, int U, int V, uint32_t& p0, uint32_t& p1) {
+    const int D = U - 128, E = V - 128;
+    const int cr = 459 * E + 128, cg = -55 * D - 136 * E + 128, cb = 541 * D + 128;
+    const int y0 = 298 * (Y0 - 16), y1 = 298 * (Y1 - 16);
+    const uint32_t rg0 = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(y0 + cr, y0 + cg, 8);
+    const uint32_t rg1 = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(y1 + cr, y1 + cg, 8);
+    const uint32_t bb = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(y0 + cb, y1 + cb, 8);
+    p0 = mx_px_mfma(q, __builtin_amdgcn_perm(bb, rg0, 0x0c040100u) ^ 0x00808080u);    // (R0, G0, B0, 0)
+    p1 = mx_px_mfma(q, __builtin_amdgcn_perm(bb, rg1, 0x0c050100u) ^ 0x00808080u);    // (R1, G1, B1, 0)
+}
+template <int MM>   // matrix mode: 0 none, 1 full 32-bit products, 2 24-bit products (3: yuv_px_pair_f32, 4: yuv_px_pair_mfma)
 __device__ __forceinline__ uint32_t yuv_px(const int* m, int Y, int U, int V) {
     const int C = Y - 16, D = U - 128, E = V - 128;
     const int rs = 298 * C + 459 * E + 128, gs = 298 * C - 55 * D - 136 * E + 128, bs = 298 * C + 541 * D + 128;
@@ -406,22 +432,29 @@ __device__ __forceinline__ void sc_stage(const uint8_t* src, uint32_t src_stride
 }
 // H pass of tile column i over window rows: T2[p][i] = (t'[p], t'[p+1]) for p in [p0, p1) -- a thread walks its rows in order, so every
 // H-filtered value costs one dot-product group and one LDS store of the pair it closes.
-__device__ __forceinline__ int sc_hdot(const uint8_t* Srow, int hb, uint32_t sh8, const uint2 hpk) {   // (t - 16384) << 7, low bits kept
+// One H-filtered value t' = t - 16384 from the four staged bytes w (low 16 bits are what the callers keep): (256 hi + lo + 64) >> 7 == 2 hi + ((lo + 64) >> 7) exactly
+// -- 256 hi is a multiple of 128 -- so the two dot products do not wait for each other, and there is no shift-and-or between them.  `clamp` is never reached
+// (|hi|, |lo| < 2^17): it is there because only the three-operand v_dot4_i32_i8 has it -- the compiler otherwise selects the accumulating v_dot4c with a
+// v_mov of the addend in front (one more VALU instruction per value; the tile is issue-bound).
+__device__ __forceinline__ uint32_t sc_h_value(const uint32_t w, const uint2 hpk) {
+    const int hi = __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, true);                        // sum ch s'
+    const int lo = __builtin_amdgcn_sdot4((int)w, (int)hpk.y, 64, true);                       // sum cl s' + 64
+    return (uint32_t)(2 * hi + (lo >> 7));
+}
+__device__ __forceinline__ uint32_t sc_hdot(const uint8_t* Srow, int hb, uint32_t sh8, const uint2 hpk) {   // t - 16384, low 16 bits valid
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(Srow + hb);
-    const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], sh8);                         // s' of taps hf .. hf + 3
-    const int hi = __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, false);                       // sum ch s'
-    return __builtin_amdgcn_sdot4((int)w, (int)hpk.y, hi * 256 + 64, false);                  // 256 sum ch s' + sum cl s' + 64
+    return sc_h_value(__builtin_amdgcn_alignbyte(sp[1], sp[0], sh8), hpk);                     // s' of taps hf .. hf + 3
 }
 __device__ __forceinline__ void sc_hcol(const uint8_t* S, int s_stride, int hf /* first tap - cxa */, const uint2 hpk, uint32_t* T2, int t_cols, int i, int p0, int p1) {
     if (p0 >= p1) return;
     const int hb = hf & ~3; const uint32_t sh8 = (uint32_t)(hf & 3);
     const uint8_t* Srow = S + (size_t)p0 * s_stride;
     uint32_t* out = T2 + p0 * t_cols + i;
-    uint32_t prev = (uint32_t)sc_hdot(Srow, hb, sh8, hpk) >> 7;
+    uint32_t prev = sc_hdot(Srow, hb, sh8, hpk);
 #pragma unroll 2
     for (int p = p0; p < p1; ++p) {
         Srow += s_stride;
-        const uint32_t cur = (uint32_t)sc_hdot(Srow, hb, sh8, hpk) >> 7;
+        const uint32_t cur = sc_hdot(Srow, hb, sh8, hpk);
         *out = __builtin_amdgcn_perm(cur, prev, 0x05040100u);                                  // (t'[p] & 0xffff) | (t'[p+1] << 16)
         out += t_cols; prev = cur;
     }
@@ -433,7 +466,8 @@ __device__ __forceinline__ uint32_t sc_vquad(const uint32_t* T2, int t_cols, int
     const uint4 p0 = *reinterpret_cast<const uint4*>(P), p1 = *reinterpret_cast<const uint4*>(P + 2 * t_cols);
     const sc_s2 c01 = __builtin_bit_cast(sc_s2, vpk.x), c23 = __builtin_bit_cast(sc_s2, vpk.y);
     const int K = 16384 * 16384 + (1 << 20);
-    auto px = [&](uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(sc_s2, b), c23, __builtin_amdgcn_sdot2(__builtin_bit_cast(sc_s2, a), c01, K, false), false); };
+    // (clamp: never reached -- the host bounds the sum below 2^31 -- and only the three-operand v_dot2_i32_i16 has it: no v_mov of K per pixel, see sc_h_value)
+    auto px = [&](uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(sc_s2, b), c23, __builtin_amdgcn_sdot2(__builtin_bit_cast(sc_s2, a), c01, K, true), true); };
     // clip8(sum >> 21) x 4 -> one dword: two v_ashr_pk_u8_i32 (explicit builtin, see pack_rgba)
     const uint32_t lo = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(px(p0.x, p1.x), px(p0.y, p1.y), 21);
     const uint32_t hi = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(px(p0.z, p1.z), px(p0.w, p1.w), 21);
@@ -492,6 +526,26 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
         yb = q; xb = idx - q * upr;
     }
     const bool valid = xb * 8 < a.width && yb * 2 < a.height;
+    // Coverage planes FIRST (AL): which layers carry one is only known at run time, so these loads sit in (wave-uniform) branches -- issued before the layers'
+    // unconditional burst they cost their issue slots and nothing else: memory returns in order, so by the time the first layer dword is waited for (the
+    // counted waits below count only what was issued AFTER it) every coverage dword is there.  Raw row dwords here; the chroma selection happens at the use.
+    uint32_t A[AL ? MX_CHAIN_MAX_SRC : 1][6];
+    if constexpr (AL) {
+        const uint32_t mask = a.alpha_mask;
+        const uint32_t xc = min(xb, (a.width - 1u) >> 3), yc = min(yb, (a.height - 1u) >> 1);
+#pragma unroll
+        for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
+#pragma unroll
+            for (int w = 0; w < 6; ++w) A[k][w] = 0xffffffffu;
+            if ((mask >> k) & 1u) {
+                const auto& al = a.al[k];
+                const uint32_t o0 = __umul24(2u * yc, al.stride) + xc * 8u;
+                const uint2 r0 = *reinterpret_cast<const uint2*>(al.p + (size_t)o0);
+                const uint2 r1 = *reinterpret_cast<const uint2*>(al.p + (size_t)(o0 + al.stride));
+                A[k][0] = r0.x; A[k][1] = r0.y; A[k][2] = r1.x; A[k][3] = r1.y;
+            }
+        }
+    }
     // per source: 2 dwords of Y for each of the two rows, one dword of U, one of V  (6 dwords)
     uint32_t L[MX_CHAIN_MAX_SRC][6];
     if constexpr (!SC) {
@@ -622,37 +676,34 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
     for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) { fa[k] = a.fa_pk[k]; fb[k] = a.fb_pk[k]; }
 #pragma unroll
     for (int k = 0; k < 12; ++k) { if (MM == 3) mtf[k] = a.mf[k]; else mtx[k] = a.m[k]; }
+    MfmaMatrix mq{};
+    if constexpr (MM == 4) {   // the launcher left the packed rows in mf[]: [0..3] rows of mh, [4..7] rows of ml, [8..10] the constants; this lane's row is lane & 3
+        const int j = tid & 3;
+        const int h0 = __builtin_bit_cast(int, a.mf[0]), h1 = __builtin_bit_cast(int, a.mf[1]), h2 = __builtin_bit_cast(int, a.mf[2]);
+        const int l0 = __builtin_bit_cast(int, a.mf[4]), l1 = __builtin_bit_cast(int, a.mf[5]), l2 = __builtin_bit_cast(int, a.mf[6]);
+        mq.a_hi = j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : 0));
+        mq.a_lo = j == 0 ? l0 : (j == 1 ? l1 : (j == 2 ? l2 : 0));
+        mq.c0 = __builtin_bit_cast(int, a.mf[8]); mq.c1 = __builtin_bit_cast(int, a.mf[9]); mq.c2 = __builtin_bit_cast(int, a.mf[10]);
+    }
     if constexpr (AL) {
         // coverage of the unit's 8 x 2 luma samples (the layout of L[k][0..3]) and of its 4 chroma samples -- the co-sited luma samples (2x, 2y): the even
         // bytes of the upper row -- for U and V alike.  Only layers that carry a plane are read (the mask is wave-uniform).
         const uint32_t mask = a.alpha_mask;
-        const uint32_t xc = min(xb, (a.width - 1u) >> 3), yc = min(yb, (a.height - 1u) >> 1);
-        uint32_t A[MX_CHAIN_MAX_SRC][6];
-#pragma unroll
-        for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) {
-#pragma unroll
-            for (int w = 0; w < 6; ++w) A[k][w] = 0xffffffffu;
-            if ((mask >> k) & 1u) {
-                const auto& al = a.al[k];
-                const uint32_t o0 = __umul24(2u * yc, al.stride) + xc * 8u;
-                const uint2 r0 = *reinterpret_cast<const uint2*>(al.p + (size_t)o0);
-                const uint2 r1 = *reinterpret_cast<const uint2*>(al.p + (size_t)(o0 + al.stride));
-                A[k][0] = r0.x; A[k][1] = r0.y; A[k][2] = r1.x; A[k][3] = r1.y;
-                A[k][4] = A[k][5] = __builtin_amdgcn_perm(r0.y, r0.x, 0x06040200u);
-            }
-        }
         uint32_t fd[MX_CHAIN_MAX_SRC - 1], via[MX_CHAIN_MAX_SRC - 1];
 #pragma unroll
         for (int k = 0; k < MX_CHAIN_MAX_SRC - 1; ++k) { fd[k] = a.fade[k]; via[k] = a.v_is_a[k]; }
+        // the coverage of the 4 chroma samples -- the co-sited luma samples (2x, 2y): the even bytes of the upper row -- for U and V alike
+#pragma unroll
+        for (int k = 0; k < MX_CHAIN_MAX_SRC; ++k) A[k][4] = A[k][5] = __builtin_amdgcn_perm(A[k][1], A[k][0], 0x06040200u);
         chain_eval_alpha<6>(v, L, A, a.n_src, fd, via, mask);
     } else {
         chain_eval_pk<6>(v, L, a.n_src, fa, fb);
     }
-    if (!valid) return;
+    if constexpr (MM != 4) { if (!valid) return; }   // (mode 4: an MFMA is executed by the whole wave -- lanes outside the picture compute their clamped unit and store nothing)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t yrow = 2 * yb + r;
-        if (yrow >= a.height) break;
+        if constexpr (MM != 4) { if (yrow >= a.height) break; }
         uint8_t* o = a.rgba + (size_t)yrow * a.rgba_stride + (size_t)xb * 32;
 #pragma unroll
         for (int g4 = 0; g4 < 2; ++g4) {       // 2 groups of 4 pixels
@@ -663,12 +714,17 @@ __device__ __forceinline__ void chain_rgba_tile(ArgsRef& a, const int bx, const 
 #pragma unroll
                 for (int k = 0; k < 4; k += 2)
                     yuv_px_pair_f32(mtf, (int)((yw >> (8 * k)) & 0xff), (int)((yw >> (8 * k + 8)) & 0xff), (int)((cu >> (4 * k)) & 0xff), (int)((cv >> (4 * k)) & 0xff), px[k], px[k + 1]);
+            } else if constexpr (MM == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k += 2)
+                    yuv_px_pair_mfma(mq, (int)((yw >> (8 * k)) & 0xff), (int)((yw >> (8 * k + 8)) & 0xff), (int)((cu >> (4 * k)) & 0xff), (int)((cv >> (4 * k)) & 0xff), px[k], px[k + 1]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     px[k] = yuv_px<MM>(mtx, (int)((yw >> (8 * k)) & 0xff), (int)((cu >> (8 * (k >> 1))) & 0xff), (int)((cv >> (8 * (k >> 1))) & 0xff));
             }
             const uint32_t x = xb * 8 + g4 * 4;
+            if constexpr (MM == 4) { if (!valid || yrow >= a.height) continue; }
             if (x + 4 <= a.width) *reinterpret_cast<uint4*>(o + g4 * 16) = make_uint4(px[0], px[1], px[2], px[3]);
             else for (uint32_t k = 0; x + k < a.width; ++k) reinterpret_cast<uint32_t*>(o + g4 * 16)[k] = px[k];
         }
@@ -759,6 +815,28 @@ static int chain_matrix_mode(ChainRgbaArgs& a) {
         }
         a.use_matrix = 3;
     }
+    // the experiment: the matrix on the matrix cores (yuv_px_pair_mfma); read per call so one process can run both forms
+    const char* const mf_env = getenv("MX_VIDEO_MFMA_MATRIX");
+    if (mf_env && atoi(mf_env) != 0 && !a.alpha_mask && !a.n_scaled) {
+        bool ok = true;
+        for (int k = 0; k < 12; ++k) if ((k & 3) != 3 && (a.m[k] <= -(32768 - 128) || a.m[k] >= 32768 - 128)) ok = false;
+        for (int i = 0; i < 3 && ok; ++i) {   // the accumulator stays in i32: |sum| <= 255 * 3 * 2^15 + |constant|
+            const long long c = (long long)a.m[4 * i + 3] + 2048 + 128ll * ((long long)a.m[4 * i] + a.m[4 * i + 1] + a.m[4 * i + 2]);
+            if (c > 0x3fffffffll || c < -0x3fffffffll) ok = false;
+        }
+        if (ok) {
+            uint32_t hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0}; int32_t c0[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 3; ++i) {
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t mm = a.m[4 * i + k], mh = (mm + 128) >> 8, ml = mm - 256 * mh;
+                    hi[i] |= (uint32_t)(mh & 0xff) << (8 * k); lo[i] |= (uint32_t)(ml & 0xff) << (8 * k);
+                }
+                c0[i] = (int32_t)((long long)a.m[4 * i + 3] + 2048 + 128ll * ((long long)a.m[4 * i] + a.m[4 * i + 1] + a.m[4 * i + 2]));
+            }
+            for (int i = 0; i < 4; ++i) { std::memcpy(&a.mf[i], &hi[i], 4); std::memcpy(&a.mf[4 + i], &lo[i], 4); std::memcpy(&a.mf[8 + i], &c0[i], 4); }
+            a.use_matrix = 4;
+        }
+    }
     return a.use_matrix;
 }
 void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
@@ -786,7 +864,8 @@ void launch_fade_chain_rgba(const ChainRgbaArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((k_fade_chain_rgba<0, false, true>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
         return;
     }
-    if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+    if (a.use_matrix == 4) hipLaunchKernelGGL((k_fade_chain_rgba<4, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
+    else if (a.use_matrix == 3) hipLaunchKernelGGL((k_fade_chain_rgba<3, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
     else if (a.use_matrix == 2) hipLaunchKernelGGL((k_fade_chain_rgba<2, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
     else if (a.use_matrix) hipLaunchKernelGGL((k_fade_chain_rgba<1, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
     else hipLaunchKernelGGL((k_fade_chain_rgba<0, false>), dim3(nb), dim3(256), 0, s, a, 0u, nb);
@@ -861,7 +940,7 @@ __device__ __forceinline__ void sc_hcol_fixed(const uint8_t* S, int hf /* first 
     uint32_t prev;
     { const uint32_t* sp = reinterpret_cast<const uint32_t*>(Srow);
       const uint32_t w = __builtin_amdgcn_alignbyte(sp[1], sp[0], sh8);
-      prev = (uint32_t)__builtin_amdgcn_sdot4((int)w, (int)hpk.y, __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, false) * 256 + 64, false) >> 7; }
+      prev = sc_h_value(w, hpk); }
 #pragma unroll
     for (int g = 0; g < HR / 8; ++g) {
         uint32_t lo[8], hi[8];
@@ -878,8 +957,7 @@ __device__ __forceinline__ void sc_hcol_fixed(const uint8_t* S, int hf /* first 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t w = __builtin_amdgcn_alignbyte(hi[j], lo[j], sh8);                      // s' of taps hf .. hf + 3
-            const int a = __builtin_amdgcn_sdot4((int)w, (int)hpk.x, 0, false);                    // sum ch s'
-            const uint32_t cur = (uint32_t)__builtin_amdgcn_sdot4((int)w, (int)hpk.y, a * 256 + 64, false) >> 7;   // 256 sum ch s' + sum cl s' + 64
+            const uint32_t cur = sc_h_value(w, hpk);                                               // t' of this row
             out[(8 * g + j) * SC_TW] = __builtin_amdgcn_perm(cur, prev, 0x05040100u);             // (t'[p] & 0xffff) | (t'[p+1] << 16)
             prev = cur;
         }
@@ -1280,7 +1358,8 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
         else if (mm == 1) hipLaunchKernelGGL((k_video_batch<1, true>), grid, dim3(256), lds, s, dd, rows);
         else hipLaunchKernelGGL((k_video_batch<0, true>), grid, dim3(256), lds, s, dd, rows);
     } else
-    if (mm == 3) hipLaunchKernelGGL(k_video_batch<3>, grid, dim3(256), lds, s, dd, rows);
+    if (mm == 4) hipLaunchKernelGGL(k_video_batch<4>, grid, dim3(256), lds, s, dd, rows);
+    else if (mm == 3) hipLaunchKernelGGL(k_video_batch<3>, grid, dim3(256), lds, s, dd, rows);
     else if (mm == 2) hipLaunchKernelGGL(k_video_batch<2>, grid, dim3(256), lds, s, dd, rows);
     else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd, rows);
     else hipLaunchKernelGGL(k_video_batch<0>, grid, dim3(256), lds, s, dd, rows);

@@ -106,7 +106,7 @@ struct ChainRgbaArgs {   // the same chain feeding the build-specified YUV420P -
 };
 // Several ticks' video work as ONE launch (mx_k_video.hip k_video_batch): up to MX_VB_MAX_CHAINS RGBA chains and MX_VB_MAX_JOBS scale jobs
 // (a job = the three planes of one scaled frame).  The descriptor is uploaded to device memory per launch.
-enum { MX_VB_MAX_CHAINS = 16, MX_VB_MAX_JOBS = 32 };
+enum { MX_VB_MAX_CHAINS = 16, MX_VB_MAX_JOBS = 48 };   // jobs: two scaled layers per tick of 16 ticks, and room for the coverage-plane companions of layers that carry one
 struct ScaleJob { ScalePlane p[3]; uint32_t tile_start[4]; uint32_t tiles_x[3]; uint32_t variant, s_rows; };
 struct VideoBatchDesc {   // header | c[n_chains] | ScaleJob[n_jobs] at byte jobs_off: only the used part is uploaded
     uint32_t n_chains, n_jobs, jobs_off, _pad;

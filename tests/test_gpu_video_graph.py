@@ -405,3 +405,28 @@ def test_random_cascade_scenarios_in_random_batches(seed, inline, monkeypatch):
             for p, (a, b) in enumerate(zip(prog.download(), want.visible())):
                 assert np.array_equal(a, b), f"batch ending at tick {t + batch - 1}: plane {p}"
         t += batch
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (322, 182), (66, 38)], ids=["1080p", "322x182", "66x38"])
+@pytest.mark.parametrize("matrix", [MATRIX, [4096, 0, 0, 0, 0, 4096, 0, 0, 0, 0, 4096, 0], [-3000, 7000, 300, -90000, 32639, -32639, 127, 4096, -128, 129, -129, 250000]],
+                         ids=["bench", "identity", "extremes"])
+def test_colour_matrix_on_the_matrix_cores_is_bit_exact(size, matrix, monkeypatch):
+    """MX_VIDEO_MFMA_MATRIX=1 (an experiment kept as an opt-in, DESIGN.md "Colour matrix on the matrix cores"): the Q12 3 x 4 matrix of the RGBA sink evaluated with
+    v_mfma_i32_4x4x4_16b_i8 -- each lane's own pixel as the B column of its four-lane block, the coefficient rows (split into high and low bytes) as A, the constant in
+    the accumulator.  Integer arithmetic: the picture must be the oracle's, bit for bit, also with negative coefficients, coefficients at the i8 x 256 limit, large
+    constants, and widths that leave lanes outside the picture."""
+    monkeypatch.setenv("MX_VIDEO_MFMA_MATRIX", "1")
+    sizes = [size] * 4
+    ws, srcs, mixers, rgba = cascade(sizes, matrix)
+    g = ws.build(max_ticks_per_run=3)
+    layers = [ov.HostFrame(*size).fill(k, seed=11) for k in range(4)]
+    keep = [upload(l) for l in layers]
+    for s, d in zip(srcs, keep):
+        video.graph_set_video_source(g, s, d, dur=(1, 60), off=(0, 1), repeat=True)
+    g.run_ticks(0, 3)
+    oms = [ov.OracleVideoMixer(a=0, b=1, fader=FADERS[k]) for k in range(3)]
+    for tick in range(3):
+        prev = (layers[0], (1, 60), (0, 1))
+        for k in range(3):
+            prev = (oms[k].run_tick(tick * 735, [prev, (layers[k + 1], (1, 60), (0, 1)), None, None]), (1, 60), (0, 1))
+    assert np.array_equal(video.graph_rgba_output(g, rgba), ov.to_rgba(prev[0], matrix))

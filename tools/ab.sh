@@ -1,7 +1,7 @@
-# A/B of two builds on one box: mixlab_amd/build/ab_old.so against the in-tree library.  gpurun -- 'bash tools/ab.sh <script> [rounds]'
+# A/B of two builds on one box: tools/ab_old.so against the in-tree library.  gpurun -- 'bash tools/ab.sh <script> [rounds]'
 S=$1; N=${2:-2}
 cp mixlab_amd/libmixlab_gpu.so /tmp/ab_new.so
 for i in $(seq $N); do
-  cp mixlab_amd/build/ab_old.so mixlab_amd/libmixlab_gpu.so; echo "== old"; bash $S
+  cp tools/ab_old.so mixlab_amd/libmixlab_gpu.so; echo "== old"; bash $S
   cp /tmp/ab_new.so mixlab_amd/libmixlab_gpu.so; echo "== new"; bash $S
 done
