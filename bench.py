@@ -1141,64 +1141,59 @@ def main():
         realtime = {"ticks_per_submission": 1, "tick_us": round(tick_us, 1), "tick_budget_us": round(1e6 / 60.0, 1),
                     "headroom": round(1e6 / 60.0 / tick_us, 1), "note": "submit + wait per tick (host-paired), same 1024-strip graph, exact EqThree"}
 
-    # shorter submissions of the same graph (T in {1, 64, 1024}; T = 1 is the real-time leg above), gates toggling as in the headline
+    # shorter submissions of the same strips (T in {1, 64, 1024}; T = 1 is the real-time leg above), gates toggling as in the headline.  Each length runs on a graph
+    # BUILT for it (max_ticks_per_run = T, as a host that submits T ticks at a time builds it), over the headline graph's resident sources: what the library decides from the
+    # submission length -- the chunk plan, and for submissions of at most one EqThree wave per SIMD the Mixer bank beside the next submission's EqThree group (automatic since
+    # round 5, MX_OVERLAP_AUTO) -- is then what is measured.
     t_sweep = None
     if not use_dist and not args.no_t_sweep:
         t_sweep = {}
         with torch.cuda.stream(stream):
             tick0 = (nxt + 64) * T
-            for Ts in (64, 1024):
-                if Ts >= T:
-                    continue
-                n_sub = 12 if Ts >= 512 else 60
+
+            def sweep(Ts, n_sub, auto):
+                nonlocal tick0
+                if auto:
+                    os.environ.pop("MX_OVERLAP_AUTO", None)
+                else:
+                    os.environ["MX_OVERLAP_AUTO"] = "0"
+                try:
+                    gs = ws.build(max_ticks_per_run=Ts, flags=flags & ~abi.FLAG_OVERLAP_TAIL, device=local_rank, stream=stream.cuda_stream)
+                finally:
+                    os.environ.pop("MX_OVERLAP_AUTO", None)
+                for sn in srcs:
+                    gs.bind_source_device(sn, g.output_device_ptr(sn, 0)[0])
                 evs = [gate_events(abi, trigs, first, tick0 + i * Ts, Ts) if toggling else None for i in range(n_sub + 3)]
 
                 def sub(i):
                     if evs[i] is not None:
-                        g.schedule_params_batch(evs[i][0], evs[i][1])
-                    g.run_ticks(tick0 + i * Ts, Ts)
+                        gs.schedule_params_batch(evs[i][0], evs[i][1])
+                    gs.run_ticks(tick0 + i * Ts, Ts)
                 sub(0)
-                torch.cuda.synchronize()
+                gs.sync()
                 th = time.perf_counter()
                 for i in range(1, 3):
                     sub(i)
                 host_free_s = (time.perf_counter() - th) / 2     # two submissions into an idle queue: what the host needs when nothing makes it wait
-                torch.cuda.synchronize()
+                gs.sync()
                 t0 = time.perf_counter()
                 for i in range(3, n_sub + 3):
                     sub(i)
                 host_s = time.perf_counter() - t0        # the host's share: scheduling + enqueueing, before the device is waited for
-                torch.cuda.synchronize()
+                gs.sync()
                 dts = time.perf_counter() - t0
-                t_sweep[str(Ts)] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub,
-                                    "host_ms_per_step": round(host_s / n_sub * 1e3, 4), "host_ms_per_step_idle_queue": round(host_free_s * 1e3, 4)}
+                rec = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub,
+                       "host_ms_per_step": round(host_s / n_sub * 1e3, 4), "host_ms_per_step_idle_queue": round(host_free_s * 1e3, 4),
+                       "mixer_beside_next_eq_three": gs.tail_stream() is not None}
                 tick0 += (n_sub + 3) * Ts
-            # T = 64 again on a graph built with MX_FLAG_OVERLAP_TAIL: the Mixer bank of submission k on a second stream beside submission
-            # k + 1's EqThree group.  At T = 2048 that loses (the EqThree launch is exactly one round of three waves per SIMD and Mixer waves
-            # push part of it into a second round); a 64-tick submission is ONE EqThree wave per SIMD running a dependent f64 chain, with
-            # issue slots and the whole memory system idle beside it -- there the Mixer rides along.
-            if 64 < T and not overlap:
-                Ts, n_sub = 64, 60
-                g2 = ws.build(max_ticks_per_run=Ts, flags=flags | abi.FLAG_OVERLAP_TAIL, device=local_rank, stream=stream.cuda_stream)
-                for j, sn in enumerate(srcs):
-                    g2.write_source(sn, synth.noise(first + j, Ts * spt), Ts)
-                evs = [gate_events(abi, trigs, first, tick0 + i * Ts, Ts) if toggling else None for i in range(n_sub + 3)]
-
-                def sub2(i):
-                    if evs[i] is not None:
-                        g2.schedule_params_batch(evs[i][0], evs[i][1])
-                    g2.run_ticks(tick0 + i * Ts, Ts)
-                for i in range(3):
-                    sub2(i)
-                g2.sync()
-                t0 = time.perf_counter()
-                for i in range(3, n_sub + 3):
-                    sub2(i)
-                g2.sync()
-                dts = time.perf_counter() - t0
-                t_sweep["64_overlap_tail"] = {"ms_per_step": round(dts / n_sub * 1e3, 4), "value": args.strips * Ts * n_sub / dts, "unit": "channel-ticks/s", "submissions": n_sub,
-                                              "flag": "MX_FLAG_OVERLAP_TAIL (the last Mixer bank on a second stream beside the next submission's EqThree group; bit-identical results)"}
-                g2.close()
+                gs.close()
+                return rec
+            for Ts in (64, 256, 1024):
+                if Ts >= T:
+                    continue
+                t_sweep[str(Ts)] = sweep(Ts, 12 if Ts >= 512 else 60, True)
+            if "64" in t_sweep and t_sweep["64"]["mixer_beside_next_eq_three"]:
+                t_sweep["64_one_stream"] = dict(sweep(64, 60, False), note="MX_OVERLAP_AUTO=0: the same submissions with every launch group on one stream (round 4's default)")
 
     # the same job at the reference's own sample rate (config 2 is written for 48 kHz; the reference runs at 44.1 kHz)
     rate_leg = None

@@ -125,7 +125,11 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
                                   reads are double-buffered and alternate per run.  Results are unchanged bit for bit; mx_graph_sync, every
                                   read-back and mx_graph_run_ticks' own ordering cover both streams.  mx_graph_output_device_ptr of a port
                                   the tail READS names the buffer of the last run only (it alternates); the tail's own outputs do not move.
-                                  A consumer on another stream of the tail's outputs orders itself after mx_graph_tail_stream(). */
+                                  A consumer on another stream of the tail's outputs orders itself after mx_graph_tail_stream().
+                                  WITHOUT the flag the library takes this mode on its own where it was measured to pay -- graphs whose longest submission is
+                                  at most one EqThree wave per SIMD (e.g. 1024 strips x 64 ticks: +14 %) -- and only while nobody holds a raw pointer to the
+                                  tail's outputs: mx_graph_output_device_ptr of such a port (and an mx_exchange over it) ends the automatism for that graph,
+                                  so stream-ordered consumers of the buses see one-stream ordering as before.  MX_OVERLAP_AUTO=0 (environment) turns it off. */
 #define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
                                 [-> Amplifier [<- Envelope <- Trigger]] into the EQ kernel, a single-consumer Trigger into
                                 its Envelope, and stores an L == R stereo result that only Mixers read as one float per
@@ -537,7 +541,7 @@ int mx_loopback_group_create(uint32_t world, mx_loopback_group** out);
 void mx_loopback_group_destroy(mx_loopback_group* grp);
 
 /* Exchange of Mixer `mixer_node`'s two output buses of `g` over steps of `n_ticks` ticks (<= max_ticks_per_run).  Exactly one of
- * nccl_unique_id / loopback is given.  `g` must outlive the exchange; not with MX_FLAG_OVERLAP_TAIL. */
+ * nccl_unique_id / loopback is given.  `g` must outlive the exchange.  (With MX_FLAG_OVERLAP_TAIL the submit waits for the Mixer bank on the tail stream first.) */
 int mx_exchange_create(mx_graph* g, uint32_t mixer_node, uint32_t n_ticks, uint32_t rank, uint32_t world,
                        const void* nccl_unique_id, mx_loopback_group* loopback, uint32_t mode, mx_exchange** out);
 void mx_exchange_destroy(mx_exchange* x);

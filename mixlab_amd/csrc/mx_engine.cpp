@@ -313,7 +313,19 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     }
     // MX_FLAG_OVERLAP_TAIL: the last launch group, if it is a Mixer bank alone on the highest level of an audio-only graph, may run beside
     // the next run's earlier groups; every port it reads gets a second buffer (the next run must not overwrite what it is still reading)
-    if ((flags_ & MX_FLAG_OVERLAP_TAIL) && !has_video_ && groups_.size() >= 2 && groups_.back().kind == MX_KIND_MIXER &&
+    // AUTOMATIC where it was measured to pay (round 5): short submissions whose EqThree group is at most ONE wave per SIMD -- a dependent f64 chain with issue slots and the
+    // whole memory system idle beside it (1024 strips x 64 ticks: 176 -> 201 M channel-ticks/s; at four waves per SIMD the Mixer's waves push EqThree waves into a second
+    // round and the same mode loses) -- and the second buffers are small there.  MX_OVERLAP_AUTO=0 turns the automatism off; results are bit-identical either way.
+    bool overlap_auto = false;
+    {
+        const char* const ae = getenv("MX_OVERLAP_AUTO");   // read per graph: tests build both kinds in one process
+        const bool auto_on = !(ae && atoi(ae) == 0);
+        const size_t max_ticks = spt_ ? cap_frames_ / spt_ : 0;
+        size_t n_eq = 0;
+        for (const Group& g : groups_) if (g.kind == MX_KIND_EQ_THREE) n_eq = std::max(n_eq, g.nodes.size());
+        overlap_auto = auto_on && eq_exact() && n_eq >= 64 && max_ticks >= 16 && n_eq * ((max_ticks + 63) / 64) <= 1024;
+    }
+    if (((flags_ & MX_FLAG_OVERLAP_TAIL) || overlap_auto) && !has_video_ && groups_.size() >= 2 && groups_.back().kind == MX_KIND_MIXER &&
         groups_[groups_.size() - 2].level < groups_.back().level && plotter_nodes_.empty()) {
         bool ok = true;
         std::vector<std::pair<uint32_t, uint32_t>> ports;
@@ -326,6 +338,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
             }
         if (ok) {
             tail_gi_ = (int)groups_.size() - 1;
+            tail_auto_ = !(flags_ & MX_FLAG_OVERLAP_TAIL);
             for (auto& pp : ports) nodes_[pp.first].out_off2[pp.second] = 0;   // marked; layout_slab gives it its offset
             hip_check(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking), "hipStreamCreate(tail)");
             hip_check(hipEventCreateWithFlags(&ev_head_done_, hipEventDisableTiming), "hipEventCreate");
@@ -1325,6 +1338,9 @@ float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
     if (nodes_[node].out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
     if (nodes_[node].out_dup[port]) throw Error(MX_ERR_INVALID, "port is stored as one float per frame (L == R fused result): use mx_graph_read_output, or build with MX_FLAG_NO_FUSE");
     if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]) * (spt_ * nodes_[node].dom_num / nodes_[node].dom_den);   // floats per TICK in the port's own rate domain
+    // A consumer that takes the raw pointer of a bus reads it in stream order on stream(): a Mixer bank the library moved to the second stream ON ITS OWN (short submissions,
+    // MX_OVERLAP_AUTO) would not be ordered before it -- so the automatism ends here, for good.  (A host that asked for MX_FLAG_OVERLAP_TAIL knows about mx_graph_tail_stream.)
+    if (tail_gi_ >= 0 && tail_auto_ && nodes_[node].group == tail_gi_) { wait_tail(-1); tail_gi_ = -1; }
     return out_ptr(nodes_[node], port);
 }
 

@@ -115,6 +115,7 @@ public:
     int device() const { return device_; }
     uint32_t ticks_per_second() const { return tps_; }
     hipStream_t tail_stream() const { return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL
+    void join_tail() { if (tail_gi_ >= 0) wait_tail(-1); }   // the graph's stream waits for a Mixer bank still running on the tail stream (consumers that read the buses on stream())
     size_t n_nodes() const { return nodes_.size(); }
     bool eq_exact() const { return (flags_ & MX_FLAG_EQ_EXACT) || !(flags_ & MX_FLAG_EQ_FAST); }   // the default is the reference's order
     bool fp_contract() const { return (flags_ & MX_FLAG_FP_CONTRACT) != 0; }                       // the contracted order (mixlab_gpu.h)
@@ -200,6 +201,7 @@ private:
     DevBuf slab_;
     // MX_FLAG_OVERLAP_TAIL (see mixlab_gpu.h): the last launch group on a second stream, beside the next run's earlier groups
     int tail_gi_ = -1;                    // index of that group in groups_, -1 = mode off
+    bool tail_auto_ = false;              // the mode was chosen by the library (short submissions), not asked for with MX_FLAG_OVERLAP_TAIL
     uint32_t parity_ = 0;                 // which buffer of the double-buffered ports the current / last run uses
     bool building_alt_ = false;           // upload_group is filling desc_alt / extra_alt
     bool building_main_ = false;          // ... desc / extra (first buffers whatever the current parity is)

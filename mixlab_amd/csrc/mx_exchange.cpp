@@ -84,7 +84,7 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
     if (lb && uid) throw Error(MX_ERR_INVALID, "give either an ncclUniqueId or a loopback group, not both");
     if (lb && lb->world != world) throw Error(MX_ERR_INVALID, "the loopback group was made for another world size");
     if (lb && lb->members[rank]) throw Error(MX_ERR_INVALID, "this rank of the loopback group is taken");
-    if (g.tail_stream()) throw Error(MX_ERR_INVALID, "the exchange packs the buses on the graph's stream: MX_FLAG_OVERLAP_TAIL graphs are not supported");
+    graph_ = &g;   // (a graph whose Mixer bank runs on a second stream -- MX_FLAG_OVERLAP_TAIL, or automatically for short submissions -- is waited for before the buses are packed)
     if (mix >= g.n_nodes() || g.node(mix).kind != MX_KIND_MIXER) throw Error(MX_ERR_INVALID, "node is not a Mixer");
     device_ = g.device();
     tps_ = g.ticks_per_second();
@@ -220,6 +220,7 @@ void Exchange::submit(uint64_t step) {
     // release (an event on ITS stream) has to order the pack, not only the next exchange (the other modes' results are written on cs_)
     if (mode_ == MX_EXCHANGE_ALLREDUCE && sl.consumed_pending) hip_check(hipStreamWaitEvent(compute_, sl.consumed, 0), "hipStreamWaitEvent");
     float* part = (float*)sl.part.p;
+    graph_->join_tail();   // the buses are packed on the graph's stream: a Mixer bank still running on the tail stream finishes first
     if (c_ptr_ == m_ptr_ + n_fl_ && n_flp_ == n_fl_) {   // Master and Cue are neighbours in the graph's slab: one copy packs both
         hip_check(hipMemcpyAsync(part, m_ptr_, 2 * n_fl_ * sizeof(float), hipMemcpyDeviceToDevice, compute_), "hipMemcpyAsync(pack)");
     } else {

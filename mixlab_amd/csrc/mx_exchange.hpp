@@ -82,6 +82,7 @@ private:
     size_t L_ = 0, Lp_ = 0; // slices: floats per time slice (and padded)
     float *m_ptr_ = nullptr, *c_ptr_ = nullptr;
     hipStream_t compute_ = nullptr, cs_ = nullptr;
+    Graph* graph_ = nullptr;   // the graph whose buses this exchange packs (outlives the exchange: it owns the buffers)
     Slot slots_[2];
 };
 

@@ -1372,14 +1372,30 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
         // 5.83 ms, 256 chunks (4 waves) 4.55 ms.  Waves beyond one round of 4 per SIMD wait for a second round.  Few instances => more,
         // shorter chunks, down to one warm-up (the rank of an 8-GPU job).  Below one wave per SIMD a wave runs at its own pace whether 1
         // or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
+        // MEASURED table (round 5, tools/q_grid.sh on MI355X: 1024 strips x 64 .. 2048 ticks and 128 .. 1024 strips x 2048 ticks, every whole-tick chunk length): the time of
+        // a launch is what the busiest SIMD needs -- w waves, each walking its chunk and its warm-up -- and a wave's pace depends on how many share the SIMD:
+        //   per chunk sample    0.26 (0.325 with several waves per strip) / 0.235 / 0.19 / 0.155 us per wave at w = 1 / 2 / 3 / 4 (one wave alone is latency-bound, four are issue-bound: 0.62 us per sample and SIMD)
+        //   per warm-up         24 / 45 / 75 / 103 us per wave (1 280 samples at 48 kHz; at w <= 2 the launcher's second tile keeps the next super-block in flight, at w = 4 every
+        //                       wave of the SIMD is in its warm-up at the same time and there is nothing to hide a round trip behind)
+        // The model this replaces charged occupancy linearly (half the waves = twice the time): it took one-tick chunks at four waves per SIMD for 1024 strips x 256 ticks
+        // (0.95 ms; two-tick chunks at two waves: 0.80 ms) and x 128 ticks (0.50 against 0.47), and 2 048 chunks for the 128-strip rank of an 8-GPU job.
         auto cost = [&](size_t nc) {
             const double waves = (double)n * (double)((nc + 63) / 64);
-            const double resident = two_tiles ? 2560.0 : 4096.0;      // 16 KiB of LDS per wave (input + control tile): ten waves per CU instead of sixteen
-            const double rounds = std::ceil(waves / resident);
-            const double occ = waves / (rounds * resident);
-            // (a second round does not start until slots of the first free up wave by wave, and its tail runs on a half-empty chip: measured with the control tile,
-            // 293 chunks in two rounds 6.75 ms against 128 in one 5.96 ms where this model without the factor called them equal)
-            return ((double)nc * (double)(chunk_of(nc) + W)) / occ * (two_tiles ? 1.0 + 0.15 * (rounds - 1.0) : 1.0);     // ~ frames + nc * W, with the chunk rounding
+            const double Cn = (double)chunk_of(nc), wscale = (double)W / 1280.0;
+            if (two_tiles) {   // a control tile beside the input's (16 KiB of LDS per wave: ten waves per CU): the round-4 model, measured on that shape
+                const double resident = 2560.0, rounds = std::ceil(waves / resident), occ = waves / (rounds * resident);
+                return ((double)nc * (Cn + (double)W)) / occ * (1.0 + 0.15 * (rounds - 1.0));
+            }
+            static const double m_us[5] = {0.0, 0.26, 0.235, 0.19, 0.1554}, warm_us[5] = {0.0, 24.0, 45.0, 75.0, 103.0};
+            const double per_simd = waves / 1024.0;
+            if (per_simd <= 4.0) {
+                const int w = std::max(1, (int)std::ceil(per_simd - 1e-9));
+                // (one wave per SIMD made of SEVERAL waves per strip is slower than one wave per strip at the same chunk length -- 0.325 against 0.26 us per sample, same
+                // instruction count, same grid: measured on 128 x 2048, 256 x 1024 and 512 x 512 against 1024 x 256; not understood)
+                const double m = (w == 1 && nc > 64) ? 0.325 : m_us[w];
+                return (double)w * (Cn * m + warm_us[w] * wscale);
+            }
+            return per_simd * (Cn * m_us[4] + warm_us[4] * wscale) * 0.94;   // further rounds of four start as slots free up: a little better than whole rounds (measured 0.94)
         };
         best = std::min<size_t>(64, nc_max);
         double best_cost = cost(best);

@@ -96,3 +96,30 @@ def test_mode_is_refused_silently_where_it_does_not_apply():
     x = synth.noise(3, 4 * 2 * SPT)
     g.write_source(s, x, 4); g.run_ticks(0, 4)
     assert_bit_exact(g.read_output(m, 0, 4, True), x, "unity mixer")
+
+
+def test_mode_is_automatic_for_short_submissions_of_many_strips_and_can_be_turned_off(monkeypatch):
+    """Round 5: a graph whose EqThree group is at most one wave per SIMD for its longest submission (here 64 strips x 16 ticks) gets the Mixer bank on the second stream
+    WITHOUT the flag -- where the mode was measured to pay -- unless MX_OVERLAP_AUTO=0; long submissions and small graphs stay on one stream.  The
+    results are the oracle's either way."""
+    n_strips, batch, n_runs = 64, 16, 4
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch)
+    g = ws.build(max_ticks_per_run=batch)
+    assert g.tail_stream() is not None
+    assert ws.build(max_ticks_per_run=2048).tail_stream() is None            # 64 strips x 32 waves: more than one wave per SIMD
+    assert ws.build(max_ticks_per_run=4).tail_stream() is None               # a tick or a few at a time: the real-time regime is left alone
+    monkeypatch.setenv("MX_OVERLAP_AUTO", "0")
+    off = ws.build(max_ticks_per_run=batch)
+    assert off.tail_stream() is None
+    monkeypatch.delenv("MX_OVERLAP_AUTO")
+    for gg in (g, off):
+        for r in range(n_runs):
+            schedule_gates(gg, trigs, r * batch, batch)
+            for k, s in enumerate(srcs):
+                gg.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+            gg.run_ticks(r * batch, batch)
+            if r in (0, 2, 3):
+                assert_bit_exact(gg.read_output(mix, 0, batch, True), want[r][0], f"master of run {r}")
+                assert_bit_exact(gg.read_output(mix, 1, batch, True), want[r][1], f"cue of run {r}")
