@@ -4,7 +4,7 @@
 # FETCH_SIZE and WRITE_SIZE in separate runs (MI355X_MICROARCH.md).  profiles/rNN/README.md is generated from these outputs
 # (tools/profile_readme.py), not written by hand.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
@@ -57,6 +57,8 @@ rm -rf /tmp/fk; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv
 cp $(find /tmp/fk -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_fir_leg.csv
 pmc fir_sq $SQ1 -- python $REPO/tools/fleg.py 128 6 > /dev/null
 pmc fir_sq2 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY -- python $REPO/tools/fleg.py 128 6 > /dev/null
+# 7b. the resampler's limiter as counters (VERDICT r4 task 5): LDS conflicts / LDS array cycles / LDS issue stalls / LDS instructions, beside wave and busy cycles
+pmc fir_sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python $REPO/tools/fleg.py 128 6 > /dev/null
 FF=$(pmc fir_fetch FETCH_SIZE -- python $REPO/tools/fleg.py 128 6)
 FW=$(pmc fir_write WRITE_SIZE -- python $REPO/tools/fleg.py 128 6)
 python $REPO/tools/pmc_traffic.py $FF $FW $OUT/fir_pmc_traffic.json $OUT/fir_pmc_hbm_traffic.md '{"leg": "fir_resample", "ticks_per_step": 128}' fir
