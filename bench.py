@@ -405,7 +405,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
             os.environ.pop("MX_VIDEO_MFMA_MATRIX", None)
         out["mfma_matrix"] = {"env": "MX_VIDEO_MFMA_MATRIX=1", "value": st4 * T / dt4, "unit": "frames/s", "device_us_per_frame": round(ms4 * 1e3, 2),
                               "vs_headline_us": round((ms4 - dev_ms) * 1e3, 2), "parity": "bit-exact (integer; tests/test_gpu_video_graph.py)",
-                              "counters": "profiles/r05/video_sq_mfma.txt beside video_sq.txt (SQ_INSTS_VALU per launch of 16 frames)"}
+                              "counters": "profiles/r05/video_sq_mfma_{0,1}.txt (SQ_INSTS_VALU per launch of 16 frames)"}
     return out
 
 
@@ -536,7 +536,7 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup, flags=0, with_contract=
            "ticks_per_step": T, "ms_per_step": dt / steps * 1e3, "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
            "realtime_stereo_channels_equiv": n_ch * T * steps / dt / 60.0}
     # per-kernel roofs: the f64 operations the spec prescribes against the f64 VALU rate, the bytes a kernel has to move against HBM, and the
-    # HBM traffic of the committed PMC passes (profiles/r04/fir_pmc_traffic.json) while the kernel sources are the ones it was collected on
+    # HBM traffic of the committed PMC passes (profiles/rNN/fir_pmc_traffic.json) while the kernel sources are the ones it was collected on
     traffic = {}
     try:
         rec = json.load(open(PROFILE_DIR / "fir_pmc_traffic.json"))
@@ -554,7 +554,7 @@ def fir_leg(torch, stream, local_rank, T, steps, warmup, flags=0, with_contract=
                        "moved_bytes_per_launch": moved[k], "hbm_frac": round(moved[k] / sec / 1e9 / HBM_PEAK_GBS, 4),
                        "traffic": traffic.get(k), "bound": "f64 VALU (prescribed mul + add, no FMA by spec)" if k == "fir" else "on-chip: LDS issue (three 8-byte reads per tap step and lane against four f64 operations) and the latency between a group's barriers; neither the f64 rate nor HBM"}
     out["roofline"] = {"per_kernel": roof, "f64_peak_tops": F64_VALU_PEAK_TOPS, "hbm_peak_gbs": HBM_PEAK_GBS,
-                       "traffic_source": "profiles/r04/fir_pmc_traffic.json" if traffic else None}
+                       "traffic_source": f"{PROFILE_TAG}/fir_pmc_traffic.json" if traffic else None}
     if "fir" in k_ms:
         out["fir_f64_valu"] = {"ops_per_launch": fir_ops, "achieved_tops": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12, 2), "peak_tops": 39.3,
                                "frac": round(fir_ops / (k_ms["fir"] * 1e-3) / 1e12 / 39.3, 3), "note": "prescribed f64 mul + add only (no FMA by spec)"}
@@ -635,7 +635,14 @@ def fir_cpu_baseline(T_ref_ticks=8, n_ch=8):
             "sample": f"{n_ch} of the 256 stereo channels x {n_ticks} ticks, single thread, {dt:.1f} s"}
 
 
-PROFILE_DIR = ROOT / "profiles" / "r04"
+def _profile_dir():
+    """the newest profiles/rNN that holds counter summaries (tools/profile_round.sh copies them there before it runs the default command)"""
+    ds = sorted(d for d in (ROOT / "profiles").glob("r[0-9][0-9]") if (d / "pmc_traffic.json").exists())
+    return ds[-1] if ds else ROOT / "profiles" / "r05"
+
+
+PROFILE_DIR = _profile_dir()
+PROFILE_TAG = f"profiles/{PROFILE_DIR.name}"
 
 
 def _kernel_hash(family):
@@ -645,7 +652,7 @@ def _kernel_hash(family):
 
 
 def pmc_traffic(kernel, args, world, toggling, fc=None):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r04/pmc_traffic.json, collected
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/rNN/pmc_traffic.json of the newest round, collected
     with this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide streaming reads); None when the run's configuration differs from the profiled one
     OR the kernel sources have changed since the profile was collected (their hash is recorded in the JSON) -- counters cannot be
@@ -657,18 +664,18 @@ def pmc_traffic(kernel, args, world, toggling, fc=None):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_sources_sha16") != _kernel_hash("audio"):
-        return None, f"profiles/r04/{name} is STALE (kernel sources changed since it was collected): not copied"
+        return None, f"{PROFILE_TAG}/{name} is STALE (kernel sources changed since it was collected): not copied"
     c = rec.get("config", {})
     same = (c.get("strips") == args.strips and c.get("ticks_per_step") == args.ticks_per_step and c.get("sample_rate") == args.sample_rate
             and c.get("fused") == (not args.no_fuse) and c.get("eq_fast") == bool(args.eq_fast) and c.get("n_gpus") == world
             and c.get("gates_toggle") == bool(toggling) and bool(c.get("fp_contract", False)) == fc)
     if not same or kernel not in rec.get("bytes_per_launch", {}):
         return None, None
-    return rec["bytes_per_launch"][kernel], f"profiles/r04/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; the x2 confirmed on this kernel's whole-line reads by tools/fetch_probe.hip; kernel sources unchanged since)"
+    return rec["bytes_per_launch"][kernel], f"{PROFILE_TAG}/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; the x2 confirmed on this kernel's whole-line reads by tools/fetch_probe.hip; kernel sources unchanged since)"
 
 
 def sq_profile(kernel_substr, fc, samples):
-    """What the committed SQ counter pass (profiles/r04/pmc_sq_toggle.json / pmc_sq_fc.json: means per dispatch) says about the dominant kernel, per
+    """What the committed SQ counter pass (profiles/rNN/pmc_sq_toggle.json / pmc_sq_fc.json: means per dispatch) says about the dominant kernel, per
     OUTPUT sample of the launch: VALU wave-instructions x 64 lanes / samples.  None when the profile was collected on other kernel sources."""
     try:
         rec = json.load(open(PROFILE_DIR / ("pmc_sq_fc.json" if fc else "pmc_sq_toggle.json")))
@@ -686,7 +693,7 @@ def sq_profile(kernel_substr, fc, samples):
 
 
 def sustained_clock_ghz(kernel_substr, fc=False):
-    """The clock the chip held under a kernel in the committed counter pass (profiles/r04/clock.json, clock_fc.json), or None when that profile was
+    """The clock the chip held under a kernel in the committed counter pass (profiles/rNN/clock.json, clock_fc.json), or None when that profile was
     collected on other kernel sources."""
     try:
         rec = json.load(open(PROFILE_DIR / ("clock_fc.json" if fc else "clock.json")))
@@ -1318,7 +1325,7 @@ def main():
             if dom == "eq_three":
                 sq = sq_profile("k_eq_three_spec_tiled", bool(args.fp_contract), local_strips * frames)
                 mand = (26.0 + 5.0 + 12.0 * 0.7) if args.fp_contract else (36.0 + 8.0 + 15.0)
-                roof["limiter"] = ("f64 VALU issue, not HBM: " + (f"{sq['valu_instructions_per_output_sample']} VALU instructions per output sample (PMC SQ_INSTS_VALU, profiles/r04), " if sq else "") +
+                roof["limiter"] = ("f64 VALU issue, not HBM: " + (f"{sq['valu_instructions_per_output_sample']} VALU instructions per output sample (PMC SQ_INSTS_VALU, {PROFILE_TAG}), " if sq else "") +
                                    f"{mand:.0f} of them the reference's own operations" + (" with each multiply fused into its add" if args.fp_contract else " in the reference's order") +
                                    "; every chunk re-runs a warm-up of 1 280 samples per 6 400; " +
                                    (f"HBM traffic {traffic / alg:.2f}x the algorithmic bytes (PMC; the warm-up re-read is 1.10x of that by construction)" if traffic else "HBM traffic: no current PMC pass") +
@@ -1341,7 +1348,7 @@ def main():
                 if ghz:
                     roof["f64_valu"]["sustained_clock"] = {"ghz": ghz, "peak_tops_at_that_clock": round(F64_VALU_PEAK_TOPS * ghz / 2.4, 1),
                                                            "frac_at_that_clock": round(f64_ops / (avg_ms * 1e-3) / 1e12 / (F64_VALU_PEAK_TOPS * ghz / 2.4), 3),
-                                                           "source": "profiles/r04/clock.json: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled; a committed measurement of these kernel sources, not read live"}
+                                                           "source": f"{PROFILE_TAG}/clock.json: GRBM_GUI_ACTIVE / XCDs / kernel duration under k_eq_three_spec_tiled; a committed measurement of these kernel sources, not read live"}
         if contract is not None:
             ck_ms = contract["kernel_ms_per_step"]
             if "eq_three" in ck_ms:

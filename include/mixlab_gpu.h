@@ -372,6 +372,11 @@ int mx_video_scaler_taps(uint32_t src, uint32_t dst, int32_t* first, int32_t* co
 /* BUILD-SPECIFIED (no reference counterpart): BT.709 limited-range YUV420P -> RGBA8 (+ optional Q12 3x4 matrix). */
 int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride, const int32_t* matrix_q12 /* 12 or NULL */, void* stream);
 int mx_video_sync(void* stream);
+/* A caller-owned hipStream_t that graphs / scalers / mixers launched pictures on is about to be destroyed: release what the library keeps per (device, stream) for its
+ * batched video launches (page-locked descriptor staging, device copies, events, an upload stream).  The library frees this itself for streams it created; for a caller's
+ * stream it cannot know when the stream dies -- and a later stream may be given the same handle value.  Call it after the last launch on the stream has finished
+ * (it synchronises the upload stream, not `stream`). */
+int mx_stream_retired(void* stream);
 
 /* VideoMixer (src/module/video_mixer.rs): 4 video inputs, program + A + B outputs. */
 typedef struct { mx_dframe* frame; /* NULL = no frame this tick */ int64_t dur_num, dur_den, off_num, off_den; } mx_video_input;

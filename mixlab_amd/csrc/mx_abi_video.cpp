@@ -265,6 +265,14 @@ void mx_video_scaler_destroy(mx_video_scaler* sc) {
     (void)guard([&] { if (sc) { (void)hipStreamSynchronize(sc->stream); delete sc; } });
 }
 
+int mx_stream_retired(void* stream) {
+    return guard([&] {
+        REQUIRE(stream, "stream is NULL (the library's own default video stream is never retired)");
+        mx::flush_scales((hipStream_t)stream);
+        mx::video_stream_retired((hipStream_t)stream);
+    });
+}
+
 int mx_video_to_rgba(const mx_dframe* in, void* device_rgba, int32_t rgba_stride, const int32_t* matrix_q12, void* stream) {
     return guard([&] {
         REQUIRE(in && device_rgba, "NULL argument");

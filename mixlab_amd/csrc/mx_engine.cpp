@@ -3,6 +3,8 @@
 
 #include "mx_engine.hpp"
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -564,6 +566,13 @@ void Graph::upload_group_one(Group& g) {
             d[i] = e;
             const int em = eq_epilogue_mode(e.epi, e.flags, e.ctl != nullptr);
             g.eq_mode = i == 0 ? em : (g.eq_mode == em ? em : -1);
+            // the groups were cut by eq_key()'s idea of this mode (from the fusion plan); the descriptor's is the one the kernels see.  If they ever disagree a group
+            // silently falls to the general direct-load kernel (29 ms against 5): refuse loudly instead
+            if (nd.sub_key != 0 && nd.sub_key != 1 + em && !eq_mode_warned_) {   // (results are right either way: say it, once per graph, and go on)
+                eq_mode_warned_ = true;
+                fprintf(stderr, "mixlab_gpu: EqThree node %u was grouped for epilogue mode %d but its descriptor says %d: the group runs the general (slower) kernel\n",
+                        (unsigned)g.nodes[i], nd.sub_key - 1, em);
+            }
         }
         up(desc_buf(g), d.data(), n * sizeof(EqDesc));
         if (any_env) up(g.tick_desc, td.data(), n * sizeof(EnvTickDesc));

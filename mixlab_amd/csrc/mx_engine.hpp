@@ -201,6 +201,7 @@ private:
     DevBuf slab_;
     // MX_FLAG_OVERLAP_TAIL (see mixlab_gpu.h): the last launch group on a second stream, beside the next run's earlier groups
     int tail_gi_ = -1;                    // index of that group in groups_, -1 = mode off
+    bool eq_mode_warned_ = false;         // the grouping / descriptor mode mismatch was reported (build_descriptors)
     bool tail_auto_ = false;              // the mode was chosen by the library (short submissions), not asked for with MX_FLAG_OVERLAP_TAIL
     uint32_t parity_ = 0;                 // which buffer of the double-buffered ports the current / last run uses
     bool building_alt_ = false;           // upload_group is filling desc_alt / extra_alt

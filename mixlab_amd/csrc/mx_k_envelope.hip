@@ -239,8 +239,12 @@ void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, 
     if (!n || !frames) return;
     const double rsr = 1.0 / sample_rate;
     if (!fpc) fpc = frames;
-    uint32_t S = env_segments(n, frames);
-    if (S > 1 && (!scratch || scratch_bytes < envelope_scratch_bytes(n, frames))) S = 1;
+    const uint32_t S_plan = env_segments(n, frames);                // (MX_ENV_SEGMENTS is read per launch on purpose -- the tests switch it inside one process -- but once per launch)
+    uint32_t S = S_plan;
+    if (S > 1) {
+        const size_t words0 = ((frames + 63) / 64 + 63) / 64;
+        if (!scratch || scratch_bytes < (size_t)n * S * sizeof(EnvState) + 2 * (size_t)n * words0 * sizeof(uint64_t)) S = 1;
+    }
     size_t seg_len = frames;
     const EnvState* seg_state = nullptr;
     if (S > 1) {
@@ -250,7 +254,7 @@ void launch_envelope(const EnvDesc* d, EnvState* st, uint32_t n, size_t frames, 
     if (S > 1) {
         const uint32_t words = (uint32_t)(((frames + 63) / 64 + 63) / 64);
         EnvState* ss = (EnvState*)scratch;
-        uint64_t* has1 = (uint64_t*)(ss + (size_t)n * env_segments(n, frames));
+        uint64_t* has1 = (uint64_t*)(ss + (size_t)n * S_plan);
         uint64_t* has0 = has1 + (size_t)n * words;
         hipLaunchKernelGGL(k_env_flags, dim3((words + 3) / 4, n), dim3(256), 0, s, d, n, frames, fpc, gates, words, has1, has0);
         if (fc) hipLaunchKernelGGL(k_env_resolve<true>, dim3((n + 3) / 4), dim3(256), 0, s, d, st, n, frames, fpc, gates, t0, sample_rate, rsr, S, seg_len, words, has1, has0, ss);

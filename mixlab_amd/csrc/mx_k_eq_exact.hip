@@ -1456,7 +1456,9 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     const int sb_auto = (size_t)n * wpi <= 2048 ? (r.fc ? 16 : 32) : 321;
     const int sb = sb_env == 0 ? sb_auto : (!r.fc && sb_env == 32) ? 32 : (sb_env == 16 ? 16 : 321);   // samples per lane per super-block
     // ragged ticks (RT instantiations): an inline Envelope at a rate whose tick is not whole super-blocks (44.1 kHz: 735) -- chunks of whole ticks, multiples of 4 samples
-    const bool rt = !no_tiles && (um == 6 || um == 7) && r.fpc >= 32 && r.fpc % 32 != 0 && plan.chunk % r.fpc == 0 && plan.chunk % 4 == 0 && r.frames % 4 == 0 &&
+    // (ticks of at least 64 samples: the RT kernel's boundary walk looks at the current and the next tick only -- with a super-block of 32 samples and row shifts up to 28
+    // a shorter tick could end twice inside one block; shorter ragged ticks take the direct form)
+    const bool rt = !no_tiles && (um == 6 || um == 7) && r.fpc >= 64 && r.fpc % 32 != 0 && plan.chunk % r.fpc == 0 && plan.chunk % 4 == 0 && r.frames % 4 == 0 &&
                     plan.warm % 32 == 0 && r.frames < (1ull << 30) && r.frames >= 4;
     // a control BUFFER (um 4 / 5: an Amplifier modulated by another module's output -- an LFO, an Envelope that is not folded in): the control of a super-block travels
     // through a second tile beside the input's (one tile each, 16 KiB per wave: ten waves per CU); the direct form it had until round 4: 33 ms per step where this takes 6

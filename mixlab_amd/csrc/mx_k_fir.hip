@@ -293,78 +293,6 @@ __global__ __launch_bounds__(256) void k_resample_ps(const ResampleDesc* __restr
         }
     }
 }
-// k_resample_pw ("per-wave windows", round 5; an experiment kept as an opt-in: it lost) -- k_resample_ps with the workgroup barrier taken out.  Counters of k_resample_ps (profiles/r05/fir_sq3.txt): no LDS bank
-// conflict at all, the LDS array 38 % busy, the VALUs 44 % -- and the waves parked in s_waitcnt / s_barrier for 55 % of their cycles: four waves meet at a barrier once per
-// group of 256 outputs, each with ~360 cycles of f64 issue between two meetings.  Here a WAVE is a workgroup: it stages the window its own 64 outputs read (74 frames for
-// 160 / 147 with 16 taps: one load per lane and a second one for the first lanes), in LDS that no other wave touches -- a wave's LDS operations execute in order, so the only
-// synchronisation is its own lgkmcnt.  Everything else is k_resample_ps: the lane's phase, its coefficients in registers and its window offset are launch-invariant (the
-// launcher makes the waves per channel a multiple of UP / gcd(UP, 64)), the frames of the next two groups are in flight while this group's taps run.
-template <int UP, int P, bool FC>
-__global__ __launch_bounds__(64) void k_resample_pw(const ResampleDesc* __restrict__ descs, size_t out_frames, uint64_t out_base, uint64_t in_base) {
-    const ResampleDesc d = descs[blockIdx.y];
-    constexpr int H = P - 1;
-    constexpr uint32_t CAP = 96;                                          // window frames per group: 63 * down / UP + 2 + P <= 96 (launcher)
-    const uint32_t down = d.down;
-    __shared__ double win[2][CAP];                                        // [left, right][frame], widened once while staging
-    const int l = threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 64;                         // a multiple of UP outputs: phases and offsets repeat
-    size_t blk = (size_t)blockIdx.x * 64;
-    if (blk >= out_frames) return;
-    const uint64_t num0 = (out_base + blk) * down;
-    const uint64_t n0_abs = num0 / UP;
-    const uint32_t r0 = (uint32_t)(num0 - n0_abs * UP);
-    const uint32_t q = r0 + (uint32_t)l * down;
-    const uint32_t dn = q / UP, phase = q - dn * UP;                      // my input frame relative to the group's first, my phase: loop-invariant
-    double c[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) c[k] = d.taps[(size_t)phase * P + k];
-    const uint64_t in_step = (uint64_t)(stride / UP) * down;              // input frames between two groups of this wave (exact: stride % UP == 0)
-    long long f0 = (long long)(n0_abs - in_base) - H;                    // input index of window frame 0 of the current group
-    const uint32_t cnt_full = min((uint32_t)((r0 + 63ull * down) / UP) + 1u + (uint32_t)H, CAP);
-    const float2* __restrict__ in2 = reinterpret_cast<const float2*>(d.in);
-    auto fetch = [&](long long base_f, size_t g_blk, uint32_t idx) {
-        if (base_f >= 0 && out_frames - g_blk >= 64 && in2) return idx < cnt_full ? (in2 + base_f)[idx] : make_float2(0.f, 0.f);   // an interior group (wave-uniform test)
-        uint32_t cnt = cnt_full;
-        if (out_frames - g_blk < 64) cnt = min((uint32_t)((r0 + (uint64_t)(out_frames - 1 - g_blk) * down) / UP) + 1u + (uint32_t)H, CAP);   // the stream's last, partial group
-        const long long f = base_f + (long long)idx;
-        float2 v = make_float2(0.f, 0.f);
-        if (idx < cnt) {
-            if (f >= 0) { if (in2) v = in2[f]; }
-            else { const long long hh = (long long)H + f; if (hh >= 0) v = d.hist[hh]; }
-        }
-        return v;
-    };
-    const bool second = (uint32_t)l + 64u < CAP;                          // lanes 0 .. 31 also bring window frame 64 + l
-    float2 pa = fetch(f0, blk, (uint32_t)l), pb = second ? fetch(f0, blk, (uint32_t)l + 64u) : make_float2(0.f, 0.f);
-    float2 qa = make_float2(0.f, 0.f), qb = qa;
-    if (blk + stride < out_frames) { qa = fetch(f0 + (long long)in_step, blk + stride, (uint32_t)l); if (second) qb = fetch(f0 + (long long)in_step, blk + stride, (uint32_t)l + 64u); }
-    f0 += 2 * (long long)in_step;
-    typedef volatile __attribute__((address_space(3))) double* LdsW;
-    typedef const volatile __attribute__((address_space(3))) double* LdsD;
-    const LdsW wl = (LdsW)&win[0][0], wr = (LdsW)&win[1][0];
-    for (; blk < out_frames; blk += stride) {
-        // (the taps of the group before have all been read: LDS operations of one wave execute in the order they were issued)
-        wl[l] = (double)pa.x; wr[l] = (double)pa.y;
-        if (second) { wl[64 + l] = (double)pb.x; wr[64 + l] = (double)pb.y; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the window is written before any lane of the wave reads it
-        pa = qa; pb = qb;
-        const size_t nxt2 = blk + 2 * stride;
-        if (nxt2 < out_frames) { qa = fetch(f0, nxt2, (uint32_t)l); if (second) qb = fetch(f0, nxt2, (uint32_t)l + 64u); }
-        f0 += (long long)in_step;
-        if (blk + l < out_frames) {
-            const LdsD lp = (LdsD)(&win[0][H + dn]);                      // lp[0] = frame n of this output
-            const LdsD rp = (LdsD)(&win[1][H + dn]);
-            double al = 0.0, ar = 0.0;
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const double vl = lp[-k], vr = rp[-k];
-                al = mul_add<FC>(c[k], vl, al);
-                ar = mul_add<FC>(c[k], vr, ar);
-            }
-            reinterpret_cast<float2*>(d.out)[blk + l] = make_float2((float)al, (float)ar);
-        }
-    }
-}
 template <bool FC>
 __global__ __launch_bounds__(256) void k_resample_gather(const ResampleDesc* __restrict__ descs, size_t out_frames,
                                                          uint64_t out_base, uint64_t in_base) {
@@ -417,19 +345,8 @@ void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint3
         uint32_t per_ch = std::max<uint32_t>(1u, resident / n) / m * m;
         if (per_ch == 0) per_ch = m;
         per_ch = (uint32_t)std::min<size_t>(per_ch, (groups + m - 1) / m * m);
-        // per-wave windows (k_resample_pw, round 5): workgroups of ONE wave, no barrier.  Measured SLOWER (0.173-0.192 ms against 0.151 at 4-8 waves per SIMD): the barrier is
-        // not what the waves wait for.  Opt-in (MX_RESAMPLE_PW=1, read per launch) for A/B; bit-exact like the other forms.
-        const int pw = env_int("MX_RESAMPLE_PW", 0);
-        if (pw && (uint64_t)63 * common_down / 160u + 2u + 16u <= 96u) {
-            const size_t groups64 = (out_frames + 63) / 64;
-            static const int wps = env_int("MX_RESAMPLE_PW_WAVES", 0);   // waves per SIMD (0: as many as the chip holds -- 8)
-            const uint32_t resident_w = cus * 4u * (uint32_t)(wps > 0 ? wps : 8);
-            uint32_t wpc = std::max<uint32_t>(1u, resident_w / n) / m * m;   // 160 / gcd(160, 64) = 5 again
-            if (wpc == 0) wpc = m;
-            wpc = (uint32_t)std::min<size_t>(wpc, (groups64 + m - 1) / m * m);
-            if (fc) hipLaunchKernelGGL((k_resample_pw<160, 16, true>), dim3(wpc, n), dim3(64), 0, s, d, out_frames, out_base, in_base);
-            else hipLaunchKernelGGL((k_resample_pw<160, 16, false>), dim3(wpc, n), dim3(64), 0, s, d, out_frames, out_base, in_base);
-        } else
+        // (the barrier-free form -- every wave staging the window of its own 64 outputs, workgroups of one wave -- was built twice, rounds 4 and 5, bit-exact, and lost
+        // both times: 0.21 / 0.17-0.19 ms against 0.15.  The waves' 55 % of parked cycles are not the barrier's: profiles/r05/fir_sq3.txt)
         if (fc) hipLaunchKernelGGL((k_resample_ps<160, 16, true>), dim3(per_ch, n), dim3(256), 0, s, d, out_frames, out_base, in_base);
         else hipLaunchKernelGGL((k_resample_ps<160, 16, false>), dim3(per_ch, n), dim3(256), 0, s, d, out_frames, out_base, in_base);
         hipLaunchKernelGGL(k_resample_history, dim3(n), dim3(256), (max_taps + 1) * sizeof(float2), s, d, in_frames);

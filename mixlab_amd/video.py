@@ -45,6 +45,7 @@ _proto("mx_video_scale_geometry", C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C
        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _proto("mx_video_to_rgba", C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p)
 _proto("mx_video_sync", C.c_int, C.c_void_p)
+_proto("mx_stream_retired", C.c_int, C.c_void_p)
 _proto("mx_video_mixer_create", C.c_int, C.POINTER(VideoMixerParams), C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p))
 _proto("mx_video_mixer_update", C.c_int, C.c_void_p, C.POINTER(VideoMixerParams))
 _proto("mx_video_mixer_run_tick", C.c_int, C.c_void_p, C.c_uint64, C.POINTER(VideoInput),
@@ -237,6 +238,11 @@ class DFrame:
 
     def device_planes(self):
         return [self._data[p] for p in range(3)], [self._stride[p] for p in range(3)]
+
+
+def stream_retired(stream):
+    """a caller-owned stream is going away: the library drops what it keeps for it (mx_stream_retired)"""
+    check(lib.mx_stream_retired(stream))
 
 
 def blank(f: DFrame, stream=None):

@@ -59,10 +59,8 @@ def test_fir_short_calls_shorter_than_the_filter():
         assert_bit_exact(got, want, f"call {k}")
 
 
-@pytest.mark.parametrize("form", ["blocks", "per-wave-windows"])   # k_resample_ps (default) / k_resample_pw (MX_RESAMPLE_PW=1: the barrier-free experiment of round 5, kept as an opt-in)
 @pytest.mark.parametrize("batch", [1, 4])
-def test_config3_fir_reverb_then_resampler_graph(batch, form, monkeypatch):
-    monkeypatch.setenv("MX_RESAMPLE_PW", "1" if form == "per-wave-windows" else "0")
+def test_config3_fir_reverb_then_resampler_graph(batch):
     n_ch, n_ticks = 12, 8
     table = polyphase_table()
     ws = Workspace(44100, 60)

@@ -430,3 +430,31 @@ def test_colour_matrix_on_the_matrix_cores_is_bit_exact(size, matrix, monkeypatc
         for k in range(3):
             prev = (oms[k].run_tick(tick * 735, [prev, (layers[k + 1], (1, 60), (0, 1)), None, None]), (1, 60), (0, 1))
     assert np.array_equal(video.graph_rgba_output(g, rgba), ov.to_rgba(prev[0], matrix))
+
+
+def test_a_callers_stream_can_be_retired_and_its_handle_reused():
+    """mx_stream_retired: what the batched video launches keep per (device, stream) -- descriptor slots whose content is compared with the next launch's --
+    is dropped when the host says its stream is gone; a graph that later runs on a stream with the same handle starts from an empty ring and composes the right picture."""
+    import torch
+    with pytest.raises(abi.MxError):
+        video.stream_retired(None)
+    st = torch.cuda.Stream()
+    sizes = [(320, 180)] * 3 + [(212, 120)]
+    for rnd in range(2):
+        ws, srcs, mixers, rgba = cascade(sizes, MATRIX)
+        g = ws.build(max_ticks_per_run=4, stream=st.cuda_stream)
+        layers = [ov.HostFrame(w, h).fill(k, seed=20 + rnd) for k, (w, h) in enumerate(sizes)]
+        keep = [upload(l) for l in layers]
+        for s, d in zip(srcs, keep):
+            video.graph_set_video_source(g, s, d, dur=(1, 60), off=(0, 1), repeat=True)
+        g.run_ticks(0, 4)
+        oms = [ov.OracleVideoMixer(a=0, b=1, fader=FADERS[k]) for k in range(3)]
+        for tick in range(4):
+            prev = (layers[0], (1, 60), (0, 1))
+            for k in range(3):
+                prev = (oms[k].run_tick(tick * 735, [prev, (layers[k + 1], (1, 60), (0, 1)), None, None]), (1, 60), (0, 1))
+        assert np.array_equal(video.graph_rgba_output(g, rgba), ov.to_rgba(prev[0], MATRIX)), f"round {rnd}"
+        g.close(); del keep
+        st.synchronize()
+        video.stream_retired(st.cuda_stream)       # twice in the second round is harmless too
+    video.stream_retired(st.cuda_stream)
