@@ -435,10 +435,20 @@ def test_colour_matrix_on_the_matrix_cores_is_bit_exact(size, matrix, monkeypatc
 def test_a_callers_stream_can_be_retired_and_its_handle_reused():
     """mx_stream_retired: what the batched video launches keep per (device, stream) -- descriptor slots whose content is compared with the next launch's --
     is dropped when the host says its stream is gone; a graph that later runs on a stream with the same handle starts from an empty ring and composes the right picture."""
-    import torch
+    import ctypes as C
     with pytest.raises(abi.MxError):
         video.stream_retired(None)
-    st = torch.cuda.Stream()
+    hip = C.CDLL("libamdhip64.so")                 # the runtime the library itself is linked against (importing torch here would bring a second one)
+    handle = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(handle)) == 0 and handle.value
+
+    class _St:                                     # a caller-owned stream
+        cuda_stream = handle.value
+
+        @staticmethod
+        def synchronize():
+            assert hip.hipStreamSynchronize(handle) == 0
+    st = _St()
     sizes = [(320, 180)] * 3 + [(212, 120)]
     for rnd in range(2):
         ws, srcs, mixers, rgba = cascade(sizes, MATRIX)
@@ -458,3 +468,4 @@ def test_a_callers_stream_can_be_retired_and_its_handle_reused():
         st.synchronize()
         video.stream_retired(st.cuda_stream)       # twice in the second round is harmless too
     video.stream_retired(st.cuda_stream)
+    assert hip.hipStreamDestroy(handle) == 0
