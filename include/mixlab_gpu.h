@@ -192,6 +192,10 @@ int mx_graph_eq_spec_stats(mx_graph* g, uint64_t* chunks_run, uint64_t* chunks_r
  * side by side, outputs rewritten), [4] fill steps of 16 samples (constant input, standing state, outputs differ), [5] rounds of islands
  * walked side by side, [6] in-order walks after an island that ended apart from the speculative run, [7] streams finished by the NaN fill. */
 int mx_graph_eq_repair_stats(mx_graph* g, uint64_t out[8]);
+/* DEBUG / profiling aid: the chunk records of the first EqThree launch group's last speculative launch (device memory owned by the graph, valid until the next run;
+ * synchronises).  144 bytes per chunk: start[8], end[8] (f64 poles), min / max input bits, and in the padding -- written by the tiled kernel -- lane 0 of a wave: the
+ * shader clock (low 32 bits) when the wave entered, lane 1: HW_ID, lane 2: XCC_ID, every lane: the clock when it left.  tools/wave_times.py reads it. */
+int mx_graph_debug_eq_records(mx_graph* g, void** device_records, size_t* bytes);
 
 /* Feed a SOURCE_* node: n_ticks consecutive tick buffers (SPT mono / 2*SPT interleaved stereo f32). */
 int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks);

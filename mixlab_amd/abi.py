@@ -113,6 +113,7 @@ class ParamEvent(C.Structure):
 _proto("mx_graph_schedule_params", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_schedule_params_batch", C.c_int, C.c_void_p, C.POINTER(ParamEvent), C.c_size_t)
 _proto("mx_graph_eq_spec_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+_proto("mx_graph_debug_eq_records", C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 _proto("mx_graph_eq_repair_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64))
 _proto("mx_graph_write_source", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_bind_source_device", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p)
@@ -233,6 +234,12 @@ class Graph:
         check(lib.mx_graph_eq_repair_stats(self._h, v))
         keys = ("chunks_run", "chunks_repaired", "settled_by_comparison", "walk_steps_16", "fill_steps_16", "island_rounds", "in_order_walks", "nan_fills")
         return {k: int(x) for k, x in zip(keys, v)}
+
+    def debug_eq_records(self):
+        """-> (device pointer, bytes) of the first EqThree group's chunk records of the last speculative launch (mx_graph_debug_eq_records)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib.mx_graph_debug_eq_records(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def eq_spec_stats(self):
         """-> (chunks run, chunks repaired) of the speculative exact EqThree path since the graph was built."""

@@ -124,6 +124,14 @@ int mx_graph_eq_spec_stats(mx_graph* g, uint64_t* chunks_run, uint64_t* chunks_r
     });
 }
 
+int mx_graph_debug_eq_records(mx_graph* g, void** device_records, size_t* bytes) {
+    return guard([&] {
+        REQUIRE(g && device_records, "NULL argument");
+        g->g->sync();
+        *device_records = g->g->debug_eq_records(bytes);
+    });
+}
+
 int mx_graph_eq_repair_stats(mx_graph* g, uint64_t out[8]) {
     return guard([&] {
         REQUIRE(g, "graph is NULL");

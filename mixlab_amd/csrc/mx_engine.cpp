@@ -325,7 +325,10 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         const size_t max_ticks = spt_ ? cap_frames_ / spt_ : 0;
         size_t n_eq = 0;
         for (const Group& g : groups_) if (g.kind == MX_KIND_EQ_THREE) n_eq = std::max(n_eq, g.nodes.size());
-        overlap_auto = auto_on && eq_exact() && n_eq >= 64 && max_ticks >= 16 && n_eq * ((max_ticks + 63) / 64) <= 1024;
+        // ... and the Mixer bank of a submission is at most one workgroup per CU (a frame per thread: 65 536 frames).  A larger bank still holds slots on every CU when the next
+        // submission's EqThree groups arrive, the dispatcher places them unevenly around it, and the launch lasts as long as its most crowded SIMD: 1024 strips x 256 ticks
+        // 0.99 -> 1.50 ms, 128 x 2048 1.03 -> 1.57 with the bank beside them (tools/q_ov.sh); x 64 ticks 0.372 -> 0.326, x 128 ticks 0.583 -> 0.577.
+        overlap_auto = auto_on && eq_exact() && n_eq >= 64 && max_ticks >= 16 && n_eq * ((max_ticks + 63) / 64) <= 1024 && cap_frames_ <= 65536;
     }
     if (((flags_ & MX_FLAG_OVERLAP_TAIL) || overlap_auto) && !has_video_ && groups_.size() >= 2 && groups_.back().kind == MX_KIND_MIXER &&
         groups_[groups_.size() - 2].level < groups_.back().level && plotter_nodes_.empty()) {
@@ -1340,6 +1343,13 @@ void Graph::write_source_i16(uint32_t node, const int16_t* host, size_t frames) 
     hip_check(hipMemcpyAsync(conv_stage_.p, host, cnt * sizeof(int16_t), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D i16)");
     launch_i16_to_f32((const int16_t*)conv_stage_.p, out_ptr(n, 0), cnt, stream_);
     sync();   // host buffer is the caller's again on return
+}
+
+void* Graph::debug_eq_records(size_t* bytes) const {
+    for (const Group& g : groups_)
+        if (g.kind == MX_KIND_EQ_THREE && g.spec.p) { if (bytes) *bytes = g.spec.bytes; return g.spec.p; }
+    if (bytes) *bytes = 0;
+    return nullptr;
 }
 
 float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {

@@ -115,6 +115,8 @@ public:
     int device() const { return device_; }
     uint32_t ticks_per_second() const { return tps_; }
     hipStream_t tail_stream() const { return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL
+    // debug: the chunk records of the first EqThree group's last speculative launch (device pointer, bytes; nullptr when there is none)
+    void* debug_eq_records(size_t* bytes) const;
     void join_tail() { if (tail_gi_ >= 0) wait_tail(-1); }   // the graph's stream waits for a Mixer bank still running on the tail stream (consumers that read the buses on stream())
     size_t n_nodes() const { return nodes_.size(); }
     bool eq_exact() const { return (flags_ & MX_FLAG_EQ_EXACT) || !(flags_ & MX_FLAG_EQ_FAST); }   // the default is the reference's order

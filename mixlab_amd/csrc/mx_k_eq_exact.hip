@@ -705,20 +705,31 @@ __device__ __forceinline__ void eq_tile_store(const EqTileCtx& c, const float* b
 
 // RT ("ragged ticks", inline Envelope only): ticks that are not whole super-blocks -- 735 samples at 44.1 kHz, the reference's own rate -- in chunks of whole ticks that
 // are multiples of 4 samples (2 940 = 4 ticks).  An instantiation of its own: the 48 kHz kernels keep their code and their registers.
+// A WORKGROUP IS FOUR WAVES (round 5) that never meet: no barrier, each wave has its own tiles in the group's LDS.  The four waves of a 256-thread group go to the four
+// SIMDs of one CU by construction.  As 64-thread groups the dispatcher placed the waves one by one, and launches of one or two waves per SIMD came out uneven -- 128 strips x
+// 2048 ticks in 1 024 waves: 60 SIMDs with two waves and 60 with none (tools/wave_times.py reads every wave's HW_ID and its time in the launch out of the chunk records);
+// the launch lasts as long as its most crowded SIMD: 0.99 ms where the same work spread evenly takes 0.71.
+enum { EQ_WPB = 4 };
 template <int SB, int KMODE, int KSTEREO, bool FC, int NBUF = 2, bool RT = false>
-__global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
-                                                                uint32_t waves_per_inst, EqChunkRec* __restrict__ recs) {
-    extern __shared__ __attribute__((aligned(16))) float eq_tiles[];   // [2][TILE]
+__global__ __launch_bounds__(64 * EQ_WPB, 4) void k_eq_three_spec_tiled(const EqDesc* __restrict__ descs, const EqState* __restrict__ states, EqRun r, EqSpecPlan plan,
+                                                                         uint32_t waves_per_inst, EqChunkRec* __restrict__ recs, uint32_t n_waves) {
+    extern __shared__ __attribute__((aligned(16))) float eq_tiles_all[];   // [EQ_WPB][tiles per wave][TILE]
     constexpr int EQ_SB = SB, EQ_TILE = EqTileGeo<SB>::TILE;
-    const uint32_t inst = blockIdx.x / waves_per_inst;
+    constexpr int EQ_TILES_PER_WAVE = (NBUF == 2 || KMODE == EQM_AMP_CTL) ? 2 : 1;
+    const uint32_t t_enter = (uint32_t)__builtin_amdgcn_s_memtime();   // (a wave's life inside the launch, kept in its records' padding: mx_graph_debug_eq_records, tools/wave_times.py)
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave in the group: wave-uniform, so that everything derived from it stays in SGPRs
+    const uint32_t wave_id = blockIdx.x * EQ_WPB + wib;
+    if (wave_id >= n_waves) return;
+    float* const eq_tiles = eq_tiles_all + wib * (EQ_TILES_PER_WAVE * EQ_TILE);
+    const uint32_t inst = wave_id / waves_per_inst;
     const EqDesc& d = descs[inst];
     const EqK K = eq_constants(d, r);
     EqTileCtx c;
     c.in = d.in; c.out = d.out;
-    c.chunk0 = (blockIdx.x % waves_per_inst) * 64u; c.n_chunks = plan.n_chunks; c.C = plan.chunk; c.F = (uint32_t)r.frames;
-    c.lane = threadIdx.x;
+    c.chunk0 = (wave_id % waves_per_inst) * 64u; c.n_chunks = plan.n_chunks; c.C = plan.chunk; c.F = (uint32_t)r.frames;
+    c.lane = (int)(threadIdx.x & 63u);
     eq_tile_bases<SB, RT>(c);
-    const uint32_t j = c.chunk0 + threadIdx.x;
+    const uint32_t j = c.chunk0 + (uint32_t)c.lane;
     const bool active = j < plan.n_chunks;
     const long long begin = (long long)j * c.C;
     const int len = active ? (int)((long long)c.F - begin < (long long)c.C ? (long long)c.F - begin : (long long)c.C) : 0;
@@ -886,6 +897,12 @@ __global__ __launch_bounds__(64, 4) void k_eq_three_spec_tiled(const EqDesc* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) { rec->end[k] = s.lo[k]; rec->end[4 + k] = s.hi[k]; }
         rec->xmin = xmin; rec->xmax = xmax;
+        // lane 0: when the wave entered; lane 1: where it ran (HW_ID: wave slot, SIMD, CU, SE); lane 2: its XCD; every lane: when it left
+        uint32_t hw = 0, xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        rec->pad[0] = c.lane == 0 ? t_enter : (c.lane == 1 ? hw : (c.lane == 2 ? xcc : 0u));
+        rec->pad[1] = (uint32_t)__builtin_amdgcn_s_memtime();
     }
 }
 
@@ -1372,13 +1389,14 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
         // 5.83 ms, 256 chunks (4 waves) 4.55 ms.  Waves beyond one round of 4 per SIMD wait for a second round.  Few instances => more,
         // shorter chunks, down to one warm-up (the rank of an 8-GPU job).  Below one wave per SIMD a wave runs at its own pace whether 1
         // or 64 of its lanes work, so the chunk count only shortens it: as many lanes of the one wave as fit.
-        // MEASURED table (round 5, tools/q_grid.sh on MI355X: 1024 strips x 64 .. 2048 ticks and 128 .. 1024 strips x 2048 ticks, every whole-tick chunk length): the time of
-        // a launch is what the busiest SIMD needs -- w waves, each walking its chunk and its warm-up -- and a wave's pace depends on how many share the SIMD:
-        //   per chunk sample    0.26 (0.325 with several waves per strip) / 0.235 / 0.19 / 0.155 us per wave at w = 1 / 2 / 3 / 4 (one wave alone is latency-bound, four are issue-bound: 0.62 us per sample and SIMD)
-        //   per warm-up         24 / 45 / 75 / 103 us per wave (1 280 samples at 48 kHz; at w <= 2 the launcher's second tile keeps the next super-block in flight, at w = 4 every
-        //                       wave of the SIMD is in its warm-up at the same time and there is nothing to hide a round trip behind)
-        // The model this replaces charged occupancy linearly (half the waves = twice the time): it took one-tick chunks at four waves per SIMD for 1024 strips x 256 ticks
-        // (0.95 ms; two-tick chunks at two waves: 0.80 ms) and x 128 ticks (0.50 against 0.47), and 2 048 chunks for the 128-strip rank of an 8-GPU job.
+        // MEASURED table (round 5, tools/q_grid3.sh on MI355X after the workgroups became four waves: 1024 strips x 64 .. 2048 ticks and 128 .. 1024 strips x 2048 ticks,
+        // every whole-tick chunk length): the time of a launch is what a SIMD needs for its w waves, each walking its chunk and its warm-up, and a wave's pace depends on
+        // how many share the SIMD:
+        //   per chunk sample    0.20 / 0.16 / 0.153 / 0.154 us per wave at w = 1 / 2 / 3 / 4 (a SIMD turns out 5.0 / 6.25 / 6.5 / 6.5 samples per us: one wave alone is
+        //                       latency-bound at 77 % of what four reach, two are at 96 %)
+        //   per warm-up         120 / 140 / 120 / 95 us per wave (1 280 samples at 48 kHz)
+        // The model this replaces charged occupancy linearly (half the waves = twice the time) and took one-tick chunks at four waves per SIMD wherever it could:
+        // 1024 strips x 256 ticks 0.95 ms (two-tick chunks: 0.80), x 512 ticks 1.41 (1.33), 256 strips x 2048 ticks 1.48 (1.40), 128 x 2048 0.99 (0.83-0.85).
         auto cost = [&](size_t nc) {
             const double waves = (double)n * (double)((nc + 63) / 64);
             const double Cn = (double)chunk_of(nc), wscale = (double)W / 1280.0;
@@ -1386,14 +1404,11 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
                 const double resident = 2560.0, rounds = std::ceil(waves / resident), occ = waves / (rounds * resident);
                 return ((double)nc * (Cn + (double)W)) / occ * (1.0 + 0.15 * (rounds - 1.0));
             }
-            static const double m_us[5] = {0.0, 0.26, 0.235, 0.19, 0.1554}, warm_us[5] = {0.0, 24.0, 45.0, 75.0, 103.0};
+            static const double m_us[5] = {0.0, 0.20, 0.16, 0.153, 0.1542}, warm_us[5] = {0.0, 120.0, 140.0, 120.0, 95.0};
             const double per_simd = waves / 1024.0;
             if (per_simd <= 4.0) {
                 const int w = std::max(1, (int)std::ceil(per_simd - 1e-9));
-                // (one wave per SIMD made of SEVERAL waves per strip is slower than one wave per strip at the same chunk length -- 0.325 against 0.26 us per sample, same
-                // instruction count, same grid: measured on 128 x 2048, 256 x 1024 and 512 x 512 against 1024 x 256; not understood)
-                const double m = (w == 1 && nc > 64) ? 0.325 : m_us[w];
-                return (double)w * (Cn * m + warm_us[w] * wscale);
+                return (double)w * (Cn * m_us[w] + warm_us[w] * wscale);
             }
             return per_simd * (Cn * m_us[4] + warm_us[4] * wscale) * 0.94;   // further rounds of four start as slots free up: a little better than whole rounds (measured 0.94)
         };
@@ -1468,22 +1483,23 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     if (!tiled && tail) { r = r_in; plan = plan_in; tail = 0; wpi = (plan.n_chunks + 63) / 64; }   // the direct form takes any length itself
     if (tiled) {
         static const int lds_pad = env_int("MX_EQ_SPEC_LDS", 0);   // A/B: bytes of LDS requested per wave (occupancy shaping)
+        const uint32_t nwv = n * wpi, nwg = (nwv + EQ_WPB - 1) / EQ_WPB;   // waves, and workgroups of EQ_WPB waves
         const size_t lds = std::max<size_t>((sb == 321 ? 1 : 2) * 64 * (size_t)(sb == 321 ? 32 : sb) * sizeof(float), (size_t)lds_pad);
         // the contracted order (MX_FLAG_FP_CONTRACT) is compiled for the 16-sample super-block only (the faster of the two)
-#define MX_GT(M, S) { if (sb == 321 && r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, true, 1>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
-                      else if (sb == 321) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false, 1>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
-                      else if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
-                      else if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); \
-                      else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, false>), dim3(n * wpi), dim3(64), lds, s, d, (const EqState*)st, r, plan, wpi, recs); }
+#define MX_GT(M, S) { if (sb == 321 && r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, true, 1>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds, s, d, (const EqState*)st, r, plan, wpi, recs, nwv); \
+                      else if (sb == 321) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false, 1>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds, s, d, (const EqState*)st, r, plan, wpi, recs, nwv); \
+                      else if (r.fc) hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, true>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds, s, d, (const EqState*)st, r, plan, wpi, recs, nwv); \
+                      else if (sb == 32) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, M, S, false>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds, s, d, (const EqState*)st, r, plan, wpi, recs, nwv); \
+                      else hipLaunchKernelGGL((k_eq_three_spec_tiled<16, M, S, false>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds, s, d, (const EqState*)st, r, plan, wpi, recs, nwv); }
         if (um == 4 || um == 5) {
             const size_t lds2 = (size_t)2 * 64 * 32 * sizeof(float);
-#define MX_GCT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_CTL, S, F, 1>), dim3(n * wpi), dim3(64), lds2, s, d, (const EqState*)st, r, plan, wpi, recs)
+#define MX_GCT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_CTL, S, F, 1>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds2, s, d, (const EqState*)st, r, plan, wpi, recs, nwv)
             if (um == 4) { if (r.fc) MX_GCT(0, true); else MX_GCT(0, false); } else { if (r.fc) MX_GCT(1, true); else MX_GCT(1, false); }
 #undef MX_GCT
         } else
         if (rt) {   // one tile of whole 16-byte rows (the rows of such chunks are not line-aligned either way)
             const size_t lds1 = (size_t)64 * 32 * sizeof(float);
-#define MX_GRT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_ENV, S, F, 1, true>), dim3(n * wpi), dim3(64), lds1, s, d, (const EqState*)st, r, plan, wpi, recs)
+#define MX_GRT(S, F) hipLaunchKernelGGL((k_eq_three_spec_tiled<32, EQM_AMP_ENV, S, F, 1, true>), dim3(nwg), dim3(64 * EQ_WPB), EQ_WPB * lds1, s, d, (const EqState*)st, r, plan, wpi, recs, nwv)
             if (um == 6) { if (r.fc) MX_GRT(0, true); else MX_GRT(0, false); } else { if (r.fc) MX_GRT(1, true); else MX_GRT(1, false); }
 #undef MX_GRT
         } else
