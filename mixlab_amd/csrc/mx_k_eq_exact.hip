@@ -1468,7 +1468,10 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     // Unset: ONE tile while three or four waves share a SIMD (they hide each other's tile round trips and a second tile would cost a wave), TWO where at most two do
     // (short submissions: a wave alone on its SIMD waits out every round trip itself; 1024 strips x 64 ticks 0.294 -> 0.276 ms, x 128 ticks 0.470 -> 0.458 ms).
     const int sb_env = env_int("MX_EQ_SPEC_SB", 0);
-    const int sb_auto = (size_t)n * wpi <= 2048 ? (r.fc ? 16 : 32) : 321;
+    // (round 5, four-wave workgroups, tools/q_fc2.sh: two tiles pay only while a wave has its SIMD to itself -- 1024 strips x 64 / 128 ticks exact 0.294 / 0.458 ms against
+    // 0.311 / 0.476 with one tile; from two waves per SIMD on one whole-line tile is the faster form: 1024 x 2048 in 128 chunks 4.28 against 4.36 ms exact, 3.85 against 4.14
+    // contracted -- the contracted order's two-tile form is the half-line one and pays its 1.44x source bytes there)
+    const int sb_auto = (size_t)n * wpi <= 1024 ? (r.fc ? 16 : 32) : 321;
     const int sb = sb_env == 0 ? sb_auto : (!r.fc && sb_env == 32) ? 32 : (sb_env == 16 ? 16 : 321);   // samples per lane per super-block
     // ragged ticks (RT instantiations): an inline Envelope at a rate whose tick is not whole super-blocks (44.1 kHz: 735) -- chunks of whole ticks, multiples of 4 samples
     // (ticks of at least 64 samples: the RT kernel's boundary walk looks at the current and the next tick only -- with a super-block of 32 samples and row shifts up to 28

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--toggle", action="store_true")
     ap.add_argument("--fast", action="store_true")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--fp-contract", action="store_true", help="MX_FLAG_FP_CONTRACT")
     ap.add_argument("--overlap-tail", action="store_true", help="MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k beside step k + 1's EqThree group")
     args = ap.parse_args()
     import synth
@@ -38,7 +39,7 @@ def main():
         else:
             os.environ.pop("MX_EQ_SPEC_CHUNKS", None)
         ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, args.strips, 0, SR, want_trigs=True)
-        g = ws.build(max_ticks_per_run=T, flags=(abi.FLAG_EQ_FAST if args.fast else 0) | (abi.FLAG_OVERLAP_TAIL if args.overlap_tail else 0))
+        g = ws.build(max_ticks_per_run=T, flags=(abi.FLAG_EQ_FAST if args.fast else 0) | (abi.FLAG_FP_CONTRACT if args.fp_contract else 0) | (abi.FLAG_OVERLAP_TAIL if args.overlap_tail else 0))
         base = min(T, 256)
         for j, s in enumerate(srcs):
             blk = synth.noise(j, base * spt)
@@ -57,7 +58,7 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         by_kind, tot, n = g.profile_collect()
         ran, rep = g.eq_spec_stats()
-        print(f"strips={args.strips} T={T} overlap={args.overlap_tail} chunks={ch or 'auto'} toggle={args.toggle} fast={args.fast}: step {dt * 1e3:.3f} ms  " +
+        print(f"strips={args.strips} T={T} overlap={args.overlap_tail} chunks={ch or 'auto'} toggle={args.toggle} fast={args.fast} fc={args.fp_contract} sb={os.environ.get('MX_EQ_SPEC_SB', 'auto')}: step {dt * 1e3:.3f} ms  " +
               "  ".join(f"{k} {v / n:.3f}" for k, v in sorted(by_kind.items())) + f"  | spec chunks {ran} repaired {rep}"
               f"  => {args.strips * T / dt / 1e6:.1f} M channel-ticks/s", flush=True)
         g.close()
