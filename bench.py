@@ -796,12 +796,12 @@ def other_rate_leg(torch, np, synth, abi, Workspace, args, local_rank, stream, s
                 g.schedule_params_batch(evs[i][0], evs[i][1])
             g.run_ticks(i * T, T)
         step(0)
-        torch.cuda.synchronize()
+        g.sync(); torch.cuda.synchronize()
         g.profile_enable(not args.no_profile)
         t0 = time.perf_counter()
         for i in range(1, steps + 1):
             step(i)
-        torch.cuda.synchronize()
+        g.sync(); torch.cuda.synchronize()      # (mx_graph_sync: a held-back Mixer bank of the last step included)
         dt = time.perf_counter() - t0
         g.profile_enable(False)
         by_kind, _tot, n_prof = g.profile_collect()
@@ -885,6 +885,7 @@ def main():
     ap.add_argument("--ticks-per-step", type=int, default=2048, help="ticks batched per submission (SURVEY 8d: throughput mode; 1 = real-time mode)")
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-fast", action="store_true", help="MX_FLAG_EQ_FAST: the time-parallel EqThree scan (<= 1 ULP, NOT bit-exact) instead of the exact default")
+    ap.add_argument("--no-one-stream-leg", action="store_true", help="skip the MX_OVERLAP_AUTO=0 leg (each kernel alone on the chip) that the roofline block quotes")
     ap.add_argument("--overlap-tail", action="store_true",
                     help="MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k on a second stream beside step k + 1's EqThree group (measured SLOWER: 6.53 vs 6.00 ms per step, DESIGN.md 5.2)")
     ap.add_argument("--no-held-leg", action="store_true", help="skip the held-gates comparison leg (counter passes: keep the dispatches of one kind)")
@@ -989,11 +990,16 @@ def main():
             dist.barrier()
 
     def timed_region(i0, k, scheduled=True):
+        # g.sync() = mx_graph_sync: every launch of the graph, on both of its streams, INCLUDING a Mixer bank the library holds back for the next run's EqThree launch
+        # (automatic overlap): the region starts with nothing of this graph outstanding and ends when all K steps' launches -- K EqThree groups and K Mixer
+        # banks, the last bank alone -- have completed
+        g.sync()
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
         for i in range(k):
             step(i0 + i, scheduled)
+        g.sync()
         torch.cuda.synchronize()
         barrier()
         return time.perf_counter() - t0
@@ -1063,12 +1069,12 @@ def main():
                 g_fc.run_ticks(i * T, T)
             for i in range(2):
                 step_fc(i)
-            torch.cuda.synchronize()
+            g_fc.sync(); torch.cuda.synchronize()
             g_fc.profile_enable(not args.no_profile)
             t0 = time.perf_counter()
             for i in range(n_c):
                 step_fc(2 + i)
-            torch.cuda.synchronize()
+            g_fc.sync(); torch.cuda.synchronize()
             dt_c = time.perf_counter() - t0
             g_fc.profile_enable(False)
             ck, _ct, cn = g_fc.profile_collect()
@@ -1084,6 +1090,41 @@ def main():
                         "what": "the reference's f64 expressions with each multiply fused into the add that consumes it: EqThree 26 instead of 36 f64 instructions per sample "
                                 "(eq_three.rs:76-88,117-124), Envelope decay and Amplifier depth() one fma each"}
             g_fc.close()
+
+    # The same job with every launch group on ONE stream (MX_OVERLAP_AUTO=0): what each kernel takes when it has the chip to itself -- the figures the roofline block
+    # quotes beside those of the timed region, where the Mixer bank of step k runs beside step k + 1's EqThree group.  Own graph over the same resident sources; not `value`.
+    one_stream = None
+    overlap_active = (not use_dist) and g.tail_stream() is not None
+    if overlap_active and not args.no_profile and not args.no_one_stream_leg:
+        with torch.cuda.stream(stream):
+            os.environ["MX_OVERLAP_AUTO"] = "0"
+            try:
+                g1 = ws.build(max_ticks_per_run=T, flags=flags & ~abi.FLAG_OVERLAP_TAIL, device=local_rank, stream=stream.cuda_stream)
+            finally:
+                os.environ.pop("MX_OVERLAP_AUTO", None)
+            for sn in srcs:
+                g1.bind_source_device(sn, g.output_device_ptr(sn, 0)[0])
+            n_1 = min(args.steps, 8)
+            evs1 = [gate_events(abi, trigs, first, i * T, T) if toggling else None for i in range(2 + n_1)]
+
+            def step_1(i):
+                if evs1[i] is not None:
+                    g1.schedule_params_batch(evs1[i][0], evs1[i][1])
+                g1.run_ticks(i * T, T)
+            for i in range(2):
+                step_1(i)
+            g1.sync(); torch.cuda.synchronize()
+            g1.profile_enable(True)
+            t0 = time.perf_counter()
+            for i in range(n_1):
+                step_1(2 + i)
+            g1.sync(); torch.cuda.synchronize()
+            dt_1 = time.perf_counter() - t0
+            g1.profile_enable(False)
+            k1, _t1, nn1 = g1.profile_collect()
+            one_stream = {"env": "MX_OVERLAP_AUTO=0", "ms_per_step": round(dt_1 / n_1 * 1e3, 4), "value": args.strips * T * n_1 / dt_1, "unit": "channel-ticks/s", "steps": n_1,
+                          "kernel_ms_per_step": {k: round(v / max(1, nn1), 5) for k, v in sorted(k1.items()) if v > 0}}
+            g1.close()
 
     exch = None
     if ex is not None:
@@ -1314,7 +1355,17 @@ def main():
                 if b:
                     per_kernel[k] = {"moved_bytes_per_launch": b, "ms": round(ms, 5), "tb_per_s": round(b / (ms * 1e-3) / 1e12, 3),
                                      "hbm_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            roof = {"kernel": dom + ("" if args.no_fuse or dom == "mixer" else " launch group (fused Trigger + Envelope + EqThree + StereoPanner + Amplifier: k_env_ticks + k_eq_three_spec_tiled + k_eq_three_repair)"),
+            shared = overlap_active and dom == "eq_three" and "mixer" in k_ms
+            if shared:
+                # The dominant launch does not have the chip to itself: the Mixer bank of the step before runs beside it from its first workgroup to (nearly) its last.
+                # The roofline of that WINDOW is what the chip moves in it -- the EqThree group's algorithmic bytes and the bank's -- over the EqThree group's duration.
+                alg_eq, alg_mix = alg, moved_bytes("mixer")
+                alg = alg_eq + alg_mix
+                ach = alg / (avg_ms * 1e-3) / 1e9
+                t_mix, _src_mix = pmc_traffic("mixer", args, world, toggling)
+                traffic = (traffic + t_mix) if (traffic and t_mix) else None
+            roof = {"kernel": dom + ("" if args.no_fuse or dom == "mixer" else " launch group (fused Trigger + Envelope + EqThree + StereoPanner + Amplifier: k_env_ticks + k_eq_three_spec_tiled + k_eq_three_repair)") +
+                              (" WITH the Mixer bank of the previous step beside it on the graph's second stream (k_mixer, held back until this launch's workgroups are placed: DESIGN.md 5.2)" if shared else ""),
                     "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": alg,
@@ -1322,6 +1373,17 @@ def main():
                     "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(k_ms.items())},
                     "kernel_timing": "hipEvents inside the timed region" if not use_dist else "hipEvents on 3 extra steps after the timed region",
                     "per_kernel": per_kernel}
+            if shared:
+                roof["window"] = {"what": "achieved / frac / algorithmic_bytes_per_launch / traffic above are those of the WINDOW: both kernels' bytes over the EqThree group's duration (avg_launch_ms); "
+                                          "per_kernel lists each kernel's own bytes over its own duration in the timed region (they overlap: the durations do not add up to a step)",
+                                  "eq_three_bytes": alg_eq, "mixer_bytes": alg_mix,
+                                  "eq_three_alone_frac_in_this_window": round(alg_eq / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                if one_stream is not None:
+                    o = one_stream["kernel_ms_per_step"]
+                    roof["one_stream"] = {"env": "MX_OVERLAP_AUTO=0 (each launch alone on the chip; same job, own graph, measured after the timed region)", "ms_per_step": one_stream["ms_per_step"],
+                                          "value": one_stream["value"],
+                                          "per_kernel": {k: {"ms": o[k], "moved_bytes_per_launch": moved_bytes(k), "hbm_frac": round(moved_bytes(k) / (o[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                                         for k in sorted(o) if moved_bytes(k)}}
             if dom == "eq_three":
                 sq = sq_profile("k_eq_three_spec_tiled", bool(args.fp_contract), local_strips * frames)
                 mand = (26.0 + 5.0 + 12.0 * 0.7) if args.fp_contract else (36.0 + 8.0 + 15.0)
@@ -1379,7 +1441,8 @@ def main():
                        "eq_mode": "time-parallel scan (<= 1 ULP, MX_FLAG_EQ_FAST)" if args.eq_fast else ("CONTRACTED order (MX_FLAG_FP_CONTRACT): <= 1 ULP of the reference, NOT its bits" if args.fp_contract
                                    else "exact order (default): speculative time-parallel kernel, verified bit-exact"),
                        "fusion": "off (every port materialised)" if args.no_fuse else "Trigger+Envelope+EqThree+StereoPanner+Amplifier in one kernel, L==R strips stored mono",
-                       "overlap": "MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k runs on a second stream beside step k + 1's EqThree group (strip ports double-buffered)" if overlap else "off",
+                       "overlap": ("MX_FLAG_OVERLAP_TAIL: " if overlap else "automatic (MX_OVERLAP_AUTO): ") + "the Mixer bank of step k runs on a second stream beside step k + 1's EqThree group (strip ports double-buffered)"
+                                  if (overlap or overlap_active) else "off",
                        "parallelism": f"strips sharded x{world}" + (f", {ex.mode}" if ex is not None else "") + (", ticks per step scaled with N (--scale-ticks)" if args.scale_ticks else ""),
                        "rccl_ranks": ex.world if ex is not None else 0},
             "realtime_channels_equiv": value / 60.0,
@@ -1391,6 +1454,7 @@ def main():
                         "median": round(rep_sorted[len(rep_sorted) // 2], 4), "min": round(rep_sorted[0], 4), "max": round(rep_sorted[-1], 4),
                         "spread_pct": round((rep_sorted[-1] - rep_sorted[0]) / rep_sorted[len(rep_sorted) // 2] * 100.0, 2)},
             "held_gates": held,
+            "one_stream": one_stream,
             "fp_contract": contract,
             "exchange": exch,
             "scaled_ticks": other_policy,

@@ -125,11 +125,16 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
                                   reads are double-buffered and alternate per run.  Results are unchanged bit for bit; mx_graph_sync, every
                                   read-back and mx_graph_run_ticks' own ordering cover both streams.  mx_graph_output_device_ptr of a port
                                   the tail READS names the buffer of the last run only (it alternates); the tail's own outputs do not move.
-                                  A consumer on another stream of the tail's outputs orders itself after mx_graph_tail_stream().
-                                  WITHOUT the flag the library takes this mode on its own where it was measured to pay -- graphs whose longest submission is
-                                  at most one EqThree wave per SIMD (e.g. 1024 strips x 64 ticks: +14 %) -- and only while nobody holds a raw pointer to the
-                                  tail's outputs: mx_graph_output_device_ptr of such a port (and an mx_exchange over it) ends the automatism for that graph,
-                                  so stream-ordered consumers of the buses see one-stream ordering as before.  MX_OVERLAP_AUTO=0 (environment) turns it off. */
+                                  The bank's launch of run k is HELD BACK until run k + 1 has queued its EqThree launch (it then starts once that launch's
+                                  workgroups are placed) or until something joins the two streams: mx_graph_sync, any read-back, an exchange's submit, a run cut
+                                  by a scheduled update, and mx_graph_tail_stream() itself.  A consumer on another stream of the tail's outputs therefore calls
+                                  mx_graph_tail_stream() AFTER the run it wants and orders itself after the stream it returns.
+                                  WITHOUT the flag the library takes this mode on its own for graphs with at least 64 EqThree instances built for submissions of
+                                  at least 16 ticks (runs of fewer ticks stay on one stream), while the second buffers fit (MX_OVERLAP_AUTO_MAX_GB, default 32, and
+                                  a quarter of the free device memory) and only while nobody holds a raw pointer to the tail's outputs:
+                                  mx_graph_output_device_ptr of such a port (and an mx_exchange over it) ends the automatism for that graph, so stream-ordered
+                                  consumers of the buses see one-stream ordering as before.  1024 strips x 2048 ticks: 5.3 -> 4.8 ms per run.
+                                  MX_OVERLAP_AUTO=0 (environment) turns it off. */
 #define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
                                 [-> Amplifier [<- Envelope <- Trigger]] into the EQ kernel, a single-consumer Trigger into
                                 its Envelope, and stores an L == R stereo result that only Mixers read as one float per
@@ -166,7 +171,8 @@ int mx_graph_run_order(const mx_graph* g, uint32_t* order, size_t cap, size_t* n
 
 /* The hipStream_t the graph launches on (the one given in mx_graph_opts, or its own): for ordering other device work against a run. */
 int mx_graph_stream(mx_graph* g, void** stream);
-/* MX_FLAG_OVERLAP_TAIL: the stream the last launch group runs on (NULL when the mode is off or the graph has no such group). */
+/* MX_FLAG_OVERLAP_TAIL (or the automatic mode): the stream the last launch group runs on (NULL when the mode is off or the graph has no such group).
+ * Releases a launch of that group the library was holding back for the next run (see the flag): call it after the run whose result is wanted. */
 int mx_graph_tail_stream(mx_graph* g, void** stream);
 
 /* ModuleT::update (src/module/mod.rs:16): replace one node's params between ticks. */

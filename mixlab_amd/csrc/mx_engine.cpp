@@ -315,9 +315,11 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     }
     // MX_FLAG_OVERLAP_TAIL: the last launch group, if it is a Mixer bank alone on the highest level of an audio-only graph, may run beside
     // the next run's earlier groups; every port it reads gets a second buffer (the next run must not overwrite what it is still reading)
-    // AUTOMATIC where it was measured to pay (round 5): short submissions whose EqThree group is at most ONE wave per SIMD -- a dependent f64 chain with issue slots and the
-    // whole memory system idle beside it (1024 strips x 64 ticks: 176 -> 201 M channel-ticks/s; at four waves per SIMD the Mixer's waves push EqThree waves into a second
-    // round and the same mode loses) -- and the second buffers are small there.  MX_OVERLAP_AUTO=0 turns the automatism off; results are bit-identical either way.
+    // AUTOMATIC (round 5) for graphs with at least 64 EqThree instances and submissions of at least 16 ticks, while the second buffers stay below MX_OVERLAP_AUTO_MAX_GB
+    // (default 32) and a quarter of the free device memory: the bank's launch is held back until the next run's EqThree launch has been placed (flush_deferred_tail,
+    // k_tail_gate) and then shares the SIMDs with it -- 1024 strips x 2048 ticks 5.42 -> 4.84 ms, x 256 ticks 0.915 -> 0.860, 128 strips x 2048 ticks 0.934 -> 0.875
+    // (tools/q_gate.sh).  Launched at once instead (round 4, MX_TAIL_GATE=0) the same mode LOST from 256 ticks up: the next run's k_env_ticks ran beside the bank (140 us
+    // instead of 9) with the EqThree launch waiting behind it.  MX_OVERLAP_AUTO=0 turns the automatism off; results are bit-identical either way.
     bool overlap_auto = false;
     {
         const char* const ae = getenv("MX_OVERLAP_AUTO");   // read per graph: tests build both kinds in one process
@@ -325,10 +327,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         const size_t max_ticks = spt_ ? cap_frames_ / spt_ : 0;
         size_t n_eq = 0;
         for (const Group& g : groups_) if (g.kind == MX_KIND_EQ_THREE) n_eq = std::max(n_eq, g.nodes.size());
-        // ... and the Mixer bank of a submission is at most one workgroup per CU (a frame per thread: 65 536 frames).  A larger bank still holds slots on every CU when the next
-        // submission's EqThree groups arrive, the dispatcher places them unevenly around it, and the launch lasts as long as its most crowded SIMD: 1024 strips x 256 ticks
-        // 0.99 -> 1.50 ms, 128 x 2048 1.03 -> 1.57 with the bank beside them (tools/q_ov.sh); x 64 ticks 0.372 -> 0.326, x 128 ticks 0.583 -> 0.577.
-        overlap_auto = auto_on && eq_exact() && n_eq >= 64 && max_ticks >= 16 && n_eq * ((max_ticks + 63) / 64) <= 1024 && cap_frames_ <= 65536;
+        overlap_auto = auto_on && eq_exact() && n_eq >= 64 && max_ticks >= 16;
     }
     if (((flags_ & MX_FLAG_OVERLAP_TAIL) || overlap_auto) && !has_video_ && groups_.size() >= 2 && groups_.back().kind == MX_KIND_MIXER &&
         groups_[groups_.size() - 2].level < groups_.back().level && plotter_nodes_.empty()) {
@@ -341,6 +340,14 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
                 if (sn.kind == MX_KIND_SOURCE_MONO || sn.kind == MX_KIND_SOURCE_STEREO || sn.group == (int)groups_.size() - 1) { ok = false; break; }   // a source is rewritten by the caller while the tail may still read it
                 ports.push_back({(uint32_t)pr.node, pr.port});
             }
+        if (ok && overlap_auto && !(flags_ & MX_FLAG_OVERLAP_TAIL)) {   // the second buffers must be affordable (an upper bound: every port as interleaved stereo)
+            const char* const ge = getenv("MX_OVERLAP_AUTO_MAX_GB");
+            const double max_gb = ge ? atof(ge) : 32.0;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+            const double extra = (double)ports.size() * (double)cap_frames_ * 8.0;
+            if (extra > max_gb * 1073741824.0 || extra > (double)free_b / 4.0) ok = false;
+        }
         if (ok) {
             tail_gi_ = (int)groups_.size() - 1;
             tail_auto_ = !(flags_ & MX_FLAG_OVERLAP_TAIL);
@@ -354,7 +361,20 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     build_descriptors();
 }
 
+void Graph::flush_deferred_tail(bool gated) {
+    if (!deferred_.pending) return;
+    deferred_.pending = false;
+    hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
+    if (gated && gate_armed_) launch_tail_gate((const uint32_t*)gate_flag_.p, gate_seq_, 300u, tail_stream_);
+    if (deferred_.prof_begin) hip_check(hipEventRecord(deferred_.prof_begin, tail_stream_), "hipEventRecord");
+    launch_mixer((const MixDesc*)deferred_.desc, deferred_.n, deferred_.max_ch, deferred_.frames, deferred_.dup_mode, tail_stream_);
+    hip_check(hipEventRecord(ev_tail_done_[deferred_.parity], tail_stream_), "hipEventRecord");
+    tail_pending_[deferred_.parity] = true;
+    if (deferred_.prof_ev) hip_check(hipEventRecord(deferred_.prof_ev, tail_stream_), "hipEventRecord");
+}
+
 void Graph::wait_tail(int parity_or_all) {
+    if (deferred_.pending && (parity_or_all < 0 || parity_or_all == (int)deferred_.parity)) flush_deferred_tail(false);
     for (int p = 0; p < 2; ++p)
         if ((parity_or_all < 0 || parity_or_all == p) && tail_pending_[p]) {
             hip_check(hipStreamWaitEvent(stream_, ev_tail_done_[p], 0), "hipStreamWaitEvent");
@@ -364,6 +384,7 @@ void Graph::wait_tail(int parity_or_all) {
 
 Graph::~Graph() {
     flush_scales(stream_);
+    try { flush_deferred_tail(false); } catch (...) {}
     if (tail_stream_) (void)hipStreamSynchronize(tail_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (tail_stream_) { (void)hipStreamDestroy(tail_stream_); (void)hipEventDestroy(ev_head_done_); for (auto& e : ev_tail_done_) (void)hipEventDestroy(e); }
@@ -788,7 +809,10 @@ void Graph::stage_upload(void* dst, const void* src, size_t bytes) {
     }
     if (!st.done) hip_check(hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "hipEventCreate");
     std::memcpy(st.host, src, bytes);
-    hip_check(hipMemcpyAsync(dst, st.host, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D staged)");
+    // a graph with a second stream: by a kernel, not an SDMA copy -- a copy queued behind a cross-stream wait makes the HOST wait for that event (k_upload); everybody else
+    // keeps the copy engine (a tick at a time it is the shorter path: 74 against 84 us per tick of 1024 strips)
+    if (tail_gi_ >= 0) launch_upload(dst, st.host, bytes, stream_);
+    else hip_check(hipMemcpyAsync(dst, st.host, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(H2D staged)");
     hip_check(hipEventRecord(st.done, stream_), "hipEventRecord");
     st.pending = true;
 }
@@ -885,6 +909,7 @@ void Graph::set_input_enabled(uint32_t node, uint32_t port, bool enabled) {
 void Graph::sync() {
     hip_check(hipSetDevice(device_), "hipSetDevice");   // the current device is per thread: a graph may be driven from another thread than its creator's
     flush_scales(stream_);
+    flush_deferred_tail(false);
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     if (tail_stream_) { hip_check(hipStreamSynchronize(tail_stream_), "hipStreamSynchronize"); tail_pending_[0] = tail_pending_[1] = false; }
 }
@@ -964,7 +989,8 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     prof_this_run_ = prof;
     // MX_FLAG_OVERLAP_TAIL: an uncut run alternates the double-buffered ports and leaves its tail on the second stream; before its
     // earlier groups overwrite a buffer, the tail that last read THAT buffer (two runs ago) must be done -- not the previous run's
-    overlap_this_run_ = tail_gi_ >= 0 && cuts.empty();
+    // (automatic mode: a run of a tick or a few on a graph built for long submissions stays on one stream -- two cross-stream events cost 13 us of an 75 us tick)
+    overlap_this_run_ = tail_gi_ >= 0 && cuts.empty() && (!tail_auto_ || n_calls >= 16);
     if (overlap_this_run_) { parity_ ^= 1u; wait_tail((int)parity_); }
     else if (tail_gi_ >= 0) wait_tail(-1);
     if (cuts.empty()) {
@@ -1015,7 +1041,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
     if (prof) {
         if (!prof_pool_.empty()) { ev = std::move(prof_pool_.back()); prof_pool_.pop_back(); }
         else {
-            ev.resize(groups_.size() + 2);   // one slot per launch group + the per-tick video section
+            ev.resize(groups_.size() + 3);   // one slot per launch group + the per-tick video section + the begin of a tail launch that was held back (its own stream)
             for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
         }
         hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
@@ -1049,7 +1075,13 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                     const size_t need = eq_spec_scratch_bytes(n, plan);
                     if (g.spec.bytes < need || !g.spec.p) { sync(); g.spec.alloc(need); }
                     if (!eq_stats_.p) { eq_stats_.alloc(8 * sizeof(uint64_t)); hip_check(hipMemset(eq_stats_.p, 0, 8 * sizeof(uint64_t)), "hipMemset"); }
+                    gate_armed_ = false;
+                    if (deferred_.pending) {
+                        if (!gate_flag_.p) { gate_flag_.alloc(64); hip_check(hipMemset(gate_flag_.p, 0, 64), "hipMemset"); }
+                        r.started = (uint32_t*)gate_flag_.p; r.started_seq = ++gate_seq_; gate_armed_ = true;
+                    }
                     launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
+                    if (deferred_.pending) flush_deferred_tail(true);     // run k's Mixer bank: behind the gate this launch opens
                 } else {
                     void* scratch = nullptr;
                     if (eq_use_poles_split(n, gf)) {     // short streams, few instances: two lanes per instance + a sample-parallel epilogue kernel
@@ -1078,7 +1110,16 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_MIXER:
             if (overlap_this_run_ && (int)gi == tail_gi_) {   // beside the next run's earlier groups (HBM-bound beside VALU-bound)
+                if (deferred_.pending) flush_deferred_tail(false);   // (a run whose earlier groups had no speculative EqThree launch: nothing opened a gate)
                 hip_check(hipEventRecord(ev_head_done_, stream_), "hipEventRecord");
+                if (tail_gate_ < 0) { const char* e = getenv("MX_TAIL_GATE"); tail_gate_ = e && atoi(e) == 0 ? 0 : 1; }   // A/B: 0 = launched at once (round 4's form)
+                if (tail_gate_) {
+                    deferred_.pending = true; deferred_.desc = desc_of(g); deferred_.n = n; deferred_.max_ch = g.max_taps; deferred_.frames = gf; deferred_.dup_mode = g.dup_mode; deferred_.parity = parity_;
+                    deferred_.prof_ev = prof ? ev[gi + 1] : nullptr; deferred_.prof_begin = prof ? ev[groups_.size() + 2] : nullptr;
+                    tail_held_this_span_ = true;
+                    ++gi;
+                    continue;
+                }
                 hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
                 launch_mixer((const MixDesc*)desc_of(g), n, g.max_taps, gf, g.dup_mode, tail_stream_);
                 hip_check(hipEventRecord(ev_tail_done_[parity_], tail_stream_), "hipEventRecord");
@@ -1130,7 +1171,8 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         for (uint32_t id : video_order_) { Node& vn = nodes_[id]; if (!vn.rgba_pending.empty()) launch_pending_rgba(vn, vn.rgba_pending.size(), false); vn.rgba_calls = 0; }   // the last ticks' sinks
     }
     if (prof && has_video_) hip_check(hipEventRecord(ev[groups_.size() + 1], stream_), "hipEventRecord");
-    if (prof) prof_runs_.push_back(std::move(ev));
+    if (prof) { prof_runs_.push_back(std::move(ev)); prof_runs_held_.push_back(tail_held_this_span_); }
+    tail_held_this_span_ = false;
 }
 
 static bool group_launches(const Group& g) {
@@ -1149,13 +1191,22 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
     if (ms_total) *ms_total = 0.f;
     const uint32_t n = prof_runs_count_;   // run() calls; a run cut into spans recorded one event list per span
     prof_runs_count_ = 0;
+    size_t run_i = 0;
     for (auto& ev : prof_runs_) {
+        const bool held = run_i < prof_runs_held_.size() && prof_runs_held_[run_i]; ++run_i;
         perf_group_ms_.assign(groups_.size() + 1, 0.f);
         size_t last = 0;   // index of the latest event that was recorded in this run
         for (size_t i = 0; i + 1 < ev.size() && i <= groups_.size(); ++i) {
             const bool recorded = i < groups_.size() ? group_launches(groups_[i]) : has_video_;
             if (!recorded) continue;
             float ms = 0.f;
+            if (held && (int)i == tail_gi_) {
+                // a tail launch that was held back ran on its own stream, inside the NEXT run's window: its own begin and end; the run's total ends where its stream's work did
+                hip_check(hipEventElapsedTime(&ms, ev[groups_.size() + 2], ev[i + 1]), "hipEventElapsedTime");
+                if (ms_by_kind) ms_by_kind[groups_[i].kind] += ms;
+                perf_group_ms_[i] = ms;
+                continue;
+            }
             hip_check(hipEventElapsedTime(&ms, ev[last], ev[i + 1]), "hipEventElapsedTime");
             if (ms_by_kind) ms_by_kind[i < groups_.size() ? groups_[i].kind : (uint32_t)MX_KIND_VIDEO_MIXER] += ms;
             perf_group_ms_[i] = ms;
@@ -1167,7 +1218,7 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
             perf_last_lag_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         prof_pool_.push_back(std::move(ev));
     }
-    prof_runs_.clear();
+    prof_runs_.clear(); prof_runs_held_.clear();
     return n;
 }
 

@@ -114,7 +114,7 @@ public:
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
     uint32_t ticks_per_second() const { return tps_; }
-    hipStream_t tail_stream() const { return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL
+    hipStream_t tail_stream() { if (tail_gi_ >= 0) flush_deferred_tail(false); return tail_gi_ >= 0 ? tail_stream_ : nullptr; }   // MX_FLAG_OVERLAP_TAIL; asking for it releases a held tail launch: what the caller orders after the stream then includes the last run's
     // debug: the chunk records of the first EqThree group's last speculative launch (device pointer, bytes; nullptr when there is none)
     void* debug_eq_records(size_t* bytes) const;
     void join_tail() { if (tail_gi_ >= 0) wait_tail(-1); }   // the graph's stream waits for a Mixer bank still running on the tail stream (consumers that read the buses on stream())
@@ -213,6 +213,14 @@ private:
     hipEvent_t ev_tail_done_[2] = {nullptr, nullptr};   // recorded on tail_stream_ after the tail of a run (by parity)
     bool tail_pending_[2] = {false, false};
     bool overlap_this_run_ = false;
+    // The tail launch of run k is HELD BACK until run k + 1 has queued its speculative EqThree launch, and goes behind a gate (k_tail_gate, one wave) that opens when that
+    // launch's last workgroup has started: the next run's k_env_ticks runs alone (beside a Mixer bank it took 140 us instead of 9 and the EqThree launch behind it started
+    // when the bank was nearly done: no overlap at all), the EqThree workgroups are placed on an empty chip, and the Mixer's waves fill what is left.  Every join
+    // (mx_graph_sync, read-backs, mx_graph_tail_stream, an exchange's submit, a cut run) releases a held launch at once.  MX_TAIL_GATE=0: launched at once as in round 4.
+    struct DeferredTail { bool pending = false; const void* desc = nullptr; uint32_t n = 0, max_ch = 0; size_t frames = 0; int dup_mode = 0; uint32_t parity = 0; hipEvent_t prof_ev = nullptr, prof_begin = nullptr; } deferred_;
+    bool tail_held_this_span_ = false; std::vector<bool> prof_runs_held_;   // parallel to prof_runs_: that run's tail launch was held back (its events sit on the tail stream)
+    DevBuf gate_flag_; uint32_t gate_seq_ = 0; bool gate_armed_ = false; int tail_gate_ = -1;
+    void flush_deferred_tail(bool gated);
     void wait_tail(int parity_or_all);    // stream_ waits for the tail launches that have not been waited for (-1: both)
     DevBuf& desc_buf(Group& g) { return building_alt_ ? g.desc_alt : g.desc; }
     DevBuf& extra_buf(Group& g) { return (building_alt_ && g.kind == MX_KIND_MIXER) ? g.extra_alt : g.extra; }

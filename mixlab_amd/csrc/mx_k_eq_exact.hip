@@ -717,6 +717,8 @@ __global__ __launch_bounds__(64 * EQ_WPB, 4) void k_eq_three_spec_tiled(const Eq
     constexpr int EQ_SB = SB, EQ_TILE = EqTileGeo<SB>::TILE;
     constexpr int EQ_TILES_PER_WAVE = (NBUF == 2 || KMODE == EQM_AMP_CTL) ? 2 : 1;
     const uint32_t t_enter = (uint32_t)__builtin_amdgcn_s_memtime();   // (a wave's life inside the launch, kept in its records' padding: mx_graph_debug_eq_records, tools/wave_times.py)
+    // (Graph's tail gate: workgroups are placed in order, so when the last one runs every other one of this launch has its place)
+    if (r.started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_store(r.started, r.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave in the group: wave-uniform, so that everything derived from it stays in SGPRs
     const uint32_t wave_id = blockIdx.x * EQ_WPB + wib;
     if (wave_id >= n_waves) return;
@@ -1432,6 +1434,20 @@ bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_
     plan.chunk = (uint32_t)C; plan.warm = (uint32_t)W; plan.warm_hi = (uint32_t)std::min(W, W_hi);
     plan.n_chunks = (uint32_t)((frames + C - 1) / C);
     return plan.n_chunks >= 2;
+}
+
+__global__ __launch_bounds__(64) void k_tail_gate(const uint32_t* flag, uint32_t seq, uint32_t limit_ticks) {
+    if (threadIdx.x) return;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();                            // the constant 100 MHz counter (s_memtime runs with the shader clock)
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(v - seq) >= 0) break;
+        if ((uint64_t)__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) break;  // an ordering hint, never a dependency: bounded
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+void launch_tail_gate(const uint32_t* flag, uint32_t seq, uint32_t limit_us, hipStream_t s) {
+    hipLaunchKernelGGL(k_tail_gate, dim3(1), dim3(64), 0, s, flag, seq, limit_us * 100u);   // s_memtime: 100 MHz
 }
 
 size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan) { return (size_t)n * plan.n_chunks * sizeof(EqChunkRec); }

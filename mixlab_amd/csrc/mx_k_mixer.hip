@@ -311,6 +311,9 @@ void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch, size_t frames, 
         return;
     }
     const size_t items = ns / w;
+    // (round 5: a ring of 64 loads per lane for launches of fewer waves than SIMDs -- 1024 strips x 64 ticks is 800 waves, 6.5 MB in flight, 1.9 - 2.5 TB/s -- was built
+    // and measured: 0.084 -> 0.449 ms.  Every refill then comes from the NEXT descriptor block, whose descriptor loads are a step old at best: the first refill waits for
+    // them with vmcnt(0) and the ring drains.  With 32 the first half of a block refills from descriptors already in registers.)
     dim3 grid(grid_x(items, 64, 16384), n);
 #define MX_MIX_LAUNCH(W, R, D) hipLaunchKernelGGL((k_mixer<W, R, D>), grid, dim3(64), 0, s, d, ns)
     if (w == 4) { if (dup_mode == 0) MX_MIX_LAUNCH(4, 16, 0); else if (dup_mode == 1) MX_MIX_LAUNCH(4, 16, 1); else MX_MIX_LAUNCH(4, 16, 2); }

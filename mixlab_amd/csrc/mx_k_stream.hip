@@ -230,6 +230,26 @@ void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s) {
 
 // a list of small device-to-device copies as ONE launch (a topology edit carries thousands of modules' states over, mx_graph_adopt_state):
 // block b copies job b; 4-byte words when both ends and the length allow, bytes otherwise
+// Staged host -> device uploads of a run (gate bits, descriptors, parameter events: a few KB to a few MB) as a KERNEL that reads the page-locked staging buffer.
+// hipMemcpyAsync puts them on an SDMA engine, and an SDMA copy cannot wait for a barrier packet of a compute queue: when the stream has a pending hipStreamWaitEvent on
+// another stream's event (the tail stream of an overlapped graph), the RUNTIME waits for that event ON THE HOST before it queues the copy -- measured (round 5, rocprofv3
+// --hip-runtime-trace): hipMemcpyAsync calls of 8 - 10 ms every few runs, the queue drained each time, 1024 strips x 256 ticks 0.90 -> 1.40 ms per run.  A launch is
+// ordered on the device.
+__global__ __launch_bounds__(256) void k_upload(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t bytes, int aligned) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    if (!aligned) { for (size_t i = t; i < bytes; i += step) dst[i] = src[i]; return; }     // (a destination inside a buffer: plot jobs)
+    const size_t n16 = bytes / 16;
+    for (size_t i = t; i < n16; i += step) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) dst[n16 * 16 + threadIdx.x] = src[n16 * 16 + threadIdx.x];
+}
+void launch_upload(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    const int aligned = ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) ? 1 : 0;
+    const size_t items = aligned ? bytes / 16 + 1 : bytes;
+    const size_t blocks = std::min<size_t>(1024, (items + 255) / 256);
+    hipLaunchKernelGGL(k_upload, dim3((unsigned)blocks), dim3(256), 0, s, (uint8_t*)dst, (const uint8_t*)src, bytes, aligned);
+}
+
 __global__ __launch_bounds__(64) void k_copy_jobs(const CopyJob* __restrict__ jobs) {
     const CopyJob j = jobs[blockIdx.x];
     const bool words = ((((uintptr_t)j.dst) | ((uintptr_t)j.src) | j.bytes) & 3u) == 0;

@@ -105,7 +105,8 @@ size_t envelope_scratch_bytes(uint32_t n, size_t frames);
 // per-tick Envelope states of the folded Envelopes of an EqThree group: ticks[inst][call], `n_calls` ticks of `fpc` samples from t0
 void launch_env_ticks(const EnvTickDesc* d, uint32_t n, const GateBits& gates, uint32_t n_calls, size_t fpc, uint64_t t0, double sample_rate, EnvTick* ticks, hipStream_t s, bool fc = false);
 // what every EqThree launch needs beyond the descriptors: the per-tick Envelope table (null when no instance folds one)
-struct EqRun { size_t frames; size_t fpc /* samples per tick (call) */; uint32_t n_calls; uint32_t fc /* MX_FLAG_FP_CONTRACT: the contracted order */; uint64_t t0; double sr, rsr /* RN(1 / sr), host */, lo_f, hi_f; const EnvTick* ticks /* [n][n_calls] */; };
+struct EqRun { size_t frames; size_t fpc /* samples per tick (call) */; uint32_t n_calls; uint32_t fc /* MX_FLAG_FP_CONTRACT: the contracted order */; uint64_t t0; double sr, rsr /* RN(1 / sr), host */, lo_f, hi_f; const EnvTick* ticks /* [n][n_calls] */;
+               uint32_t* started = nullptr; uint32_t started_seq = 0; /* tiled speculative kernel: its last workgroup stores started_seq there when it starts (every earlier one has been placed by then): Graph's tail gate */ };
 // scratch != nullptr: the split-cascade form for few instances (eq_use_poles_split; eq_poles_scratch_bytes of scratch); else one lane per instance
 void launch_eq_three_exact(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, void* scratch, hipStream_t s);
 bool eq_use_poles_split(uint32_t n, size_t frames);
@@ -118,6 +119,8 @@ struct EqSpecPlan { uint32_t n_chunks; uint32_t chunk; uint32_t warm; uint32_t p
 bool eq_plan_spec(uint32_t n, size_t frames, size_t fpc, double lo_f, double hi_f, EqSpecPlan& plan, bool whole_ticks = false /* an inline Envelope: chunks of whole ticks at any rate */,
                   bool two_tiles = false /* a control buffer: input and control tile per wave, ten waves per CU */);   // false: one lane per instance (launch_eq_three_exact)
 size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan);
+// one wave that leaves when *flag has reached seq (or after limit_us): a launch queued behind it on its stream starts once the kernel that stores the flag has been placed
+void launch_tail_gate(const uint32_t* flag, uint32_t seq, uint32_t limit_us, hipStream_t s);
 int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl);   // 0..7: (epilogue kind) * 2 + (stereo store); the specialisation key
 void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode /* 0..7, or -1: mixed */,
                           void* scratch, uint64_t* stats /* [2]: chunks run, chunks repaired */, hipStream_t s);
@@ -134,6 +137,8 @@ void launch_f32_to_i16(const float* in, int16_t* out, size_t n, int dup, hipStre
 void launch_i16_to_f32(const int16_t* in, float* out, size_t n, hipStream_t s);
 struct CopyJob { void* dst; const void* src; size_t bytes; };
 void launch_copy_jobs(const CopyJob* device_jobs, uint32_t n, hipStream_t s);   // one block per job
+// bytes out of page-locked host memory into device memory BY A KERNEL (the device reads the host buffer): ordered by the queue's own barrier packets like any launch
+void launch_upload(void* dst_device, const void* src_pinned_host, size_t bytes, hipStream_t s);
 void launch_fir(const FirDesc* d, uint32_t n, uint32_t max_taps, size_t frames, hipStream_t s, bool fc = false);
 void launch_resample(const ResampleDesc* d, uint32_t n, uint32_t max_taps, uint32_t tab_doubles /* max up * taps_per_phase */,
                      uint32_t win_frames /* max 255 * down / up + 2 + taps_per_phase */, size_t in_frames, size_t out_frames,

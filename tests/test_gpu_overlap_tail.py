@@ -99,17 +99,20 @@ def test_mode_is_refused_silently_where_it_does_not_apply():
 
 
 def test_mode_is_automatic_for_short_submissions_of_many_strips_and_can_be_turned_off(monkeypatch):
-    """Round 5: a graph whose EqThree group is at most one wave per SIMD for its longest submission (here 64 strips x 16 ticks) gets the Mixer bank on the second stream
-    WITHOUT the flag -- where the mode was measured to pay -- unless MX_OVERLAP_AUTO=0; long submissions and small graphs stay on one stream.  The
-    results are the oracle's either way."""
+    """Round 5: a graph with at least 64 EqThree strips and submissions of at least 16 ticks gets the Mixer bank on the second stream WITHOUT the flag (held back until the
+    next run's EqThree launch has been placed: DESIGN.md 5.2) unless MX_OVERLAP_AUTO=0 or the second buffers would not be affordable; a tick or a few at a time and small
+    graphs stay on one stream.  The results are the oracle's either way."""
     n_strips, batch, n_runs = 64, 16, 4
     ws, mix, srcs, trigs = strips(n_strips, SR)
     noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
     want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch)
     g = ws.build(max_ticks_per_run=batch)
     assert g.tail_stream() is not None
-    assert ws.build(max_ticks_per_run=2048).tail_stream() is None            # 64 strips x 32 waves: more than one wave per SIMD
+    assert ws.build(max_ticks_per_run=2048).tail_stream() is not None        # long submissions too, since the bank's launch is held behind the next EqThree launch
     assert ws.build(max_ticks_per_run=4).tail_stream() is None               # a tick or a few at a time: the real-time regime is left alone
+    monkeypatch.setenv("MX_OVERLAP_AUTO_MAX_GB", "0.001")
+    assert ws.build(max_ticks_per_run=2048).tail_stream() is None            # second buffers over the budget: 64 ports x 1.6 M frames
+    monkeypatch.delenv("MX_OVERLAP_AUTO_MAX_GB")
     monkeypatch.setenv("MX_OVERLAP_AUTO", "0")
     off = ws.build(max_ticks_per_run=batch)
     assert off.tail_stream() is None

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--fast", action="store_true")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--fp-contract", action="store_true", help="MX_FLAG_FP_CONTRACT")
+    ap.add_argument("--no-profile", action="store_true", help="no per-group events: the wall clock of the steps only")
+    ap.add_argument("--host-times", action="store_true", help="print how long every run_ticks call kept the host (us)")
     ap.add_argument("--overlap-tail", action="store_true", help="MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k beside step k + 1's EqThree group")
     args = ap.parse_args()
     import synth
@@ -49,14 +51,18 @@ def main():
             if ev[i]: g.schedule_params_batch(ev[i][0], ev[i][1])
             g.run_ticks(i * T, T)
         g.sync()
-        g.profile_enable(True)
+        g.profile_enable(not args.no_profile)
         t0 = time.perf_counter()
+        host = []
         for i in range(args.steps):
+            th = time.perf_counter()
             if ev[2 + i]: g.schedule_params_batch(ev[2 + i][0], ev[2 + i][1])
             g.run_ticks((2 + i) * T, T)
+            host.append((time.perf_counter() - th) * 1e6)
         g.sync()
+        if args.host_times: print("host us per call:", " ".join(f"{h:.0f}" for h in host))
         dt = (time.perf_counter() - t0) / args.steps
-        by_kind, tot, n = g.profile_collect()
+        by_kind, tot, n = g.profile_collect() if not args.no_profile else ({}, 0, 1)
         ran, rep = g.eq_spec_stats()
         print(f"strips={args.strips} T={T} overlap={args.overlap_tail} chunks={ch or 'auto'} toggle={args.toggle} fast={args.fast} fc={args.fp_contract} sb={os.environ.get('MX_EQ_SPEC_SB', 'auto')}: step {dt * 1e3:.3f} ms  " +
               "  ".join(f"{k} {v / n:.3f}" for k, v in sorted(by_kind.items())) + f"  | spec chunks {ran} repaired {rep}"

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--strips", type=int, default=128)
     ap.add_argument("--ticks", type=int, default=2048)
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--overlap-tail", action="store_true")
+    ap.add_argument("--steps", type=int, default=4)
     args = ap.parse_args()
     if args.chunks:
         os.environ["MX_EQ_SPEC_CHUNKS"] = str(args.chunks)
@@ -26,16 +28,18 @@ def main():
     from mixlab_amd.workspace import Workspace
     T, SR, spt = args.ticks, 48000, 800
     ws, mix, srcs, trigs = build_strips(abi, Workspace, synth, args.strips, 0, SR, want_trigs=True)
-    g = ws.build(max_ticks_per_run=T)
+    g = ws.build(max_ticks_per_run=T, flags=abi.FLAG_OVERLAP_TAIL if args.overlap_tail else 0)
     base = min(T, 256)
     for j, s in enumerate(srcs):
         g.write_source(s, np.tile(synth.noise(j, base * spt), (T + base - 1) // base)[: T * spt], T)
-    for i in range(4):
+    for i in range(args.steps):
         ev = gate_events(abi, trigs, 0, i * T, T)
         if ev: g.schedule_params_batch(ev[0], ev[1])
         g.run_ticks(i * T, T)
     ran, _ = g.eq_spec_stats()
-    n_chunks = ran // 4 // args.strips
+    g.sync()
+    ran, _ = g.eq_spec_stats()
+    n_chunks = ran // args.steps // args.strips
     p, nbytes = g.debug_eq_records()
     rec = np.empty(args.strips * n_chunks * 144, np.uint8)
     abi.check(abi.lib.mx_device_download(rec.ctypes.data_as(C.c_void_p), C.c_void_p(p), rec.size, None))
