@@ -126,3 +126,56 @@ def test_mode_is_automatic_for_short_submissions_of_many_strips_and_can_be_turne
             if r in (0, 2, 3):
                 assert_bit_exact(gg.read_output(mix, 0, batch, True), want[r][0], f"master of run {r}")
                 assert_bit_exact(gg.read_output(mix, 1, batch, True), want[r][1], f"cue of run {r}")
+
+
+def test_a_bank_released_by_the_next_runs_eq_three_launch_is_the_oracles():
+    """Round 5: the bank's launch of run k is held back and goes out behind run k + 1's speculative EqThree launch (k_tail_gate).  Every read-back joins the streams and would
+    release a held launch itself, so THIS launch's result is read where only it can be seen: by a copy queued on the tail stream after run k + 1 was queued (the bank of
+    run k is then on that stream, the bank of run k + 1 is still held).  mx_graph_tail_stream() releases what is held: the handle is taken before anything is."""
+    n_strips, batch, n_runs = 64, 16, 5                      # 16 ticks: long enough for the speculative EqThree path whose last workgroup opens the gate
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch)
+    g = ws.build(max_ticks_per_run=batch, flags=abi.FLAG_OVERLAP_TAIL)   # (the flag, not the automatism: taking the buses' device pointers would end that)
+    tail = g.tail_stream()
+    assert tail is not None
+    hip = C.CDLL("libamdhip64.so")
+    pm, nm = g.output_device_ptr(mix, 0)
+    pc, _ = g.output_device_ptr(mix, 1)
+    assert nm == 2 * SPT                                   # floats per tick; the buffer holds the run's ticks back to back
+    nm *= batch
+    got_m, got_c = np.empty(nm, np.float32), np.empty(nm, np.float32)
+    ran0, _ = g.eq_spec_stats()
+    for r in range(n_runs):
+        schedule_gates(g, trigs, r * batch, batch)
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+        g.run_ticks(r * batch, batch)                        # queues run r's EqThree launch and, behind its gate, the bank of run r - 1
+        if r >= 1:
+            for dst, src in ((got_m, pm), (got_c, pc)):
+                assert hip.hipMemcpyAsync(dst.ctypes.data_as(C.c_void_p), C.c_void_p(src), C.c_size_t(nm * 4), 2, C.c_void_p(tail)) == 0   # 2 = hipMemcpyDeviceToHost
+            assert hip.hipStreamSynchronize(C.c_void_p(tail)) == 0
+            assert_bit_exact(got_m, want[r - 1][0], f"master of run {r - 1}, released by run {r}")
+            assert_bit_exact(got_c, want[r - 1][1], f"cue of run {r - 1}, released by run {r}")
+    assert_bit_exact(g.read_output(mix, 0, batch, True), want[-1][0], "master of the last run (released by the read-back)")
+    ran1, _ = g.eq_spec_stats()
+    assert ran1 > ran0                                       # the speculative kernel (the one that opens the gate) is what ran
+
+
+def test_per_group_times_with_a_held_back_bank():
+    """mx_graph_profile_*: a bank that was held back is timed by its own pair of events on the tail stream; every kind that launched reports a positive time."""
+    n_strips, batch = 64, 16
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    g = ws.build(max_ticks_per_run=batch)                    # automatic mode
+    assert g.tail_stream() is not None
+    for k, s in enumerate(srcs):
+        g.write_source(s, synth.noise(k, batch * SPT), batch)
+    g.run_ticks(0, batch)
+    g.sync()
+    g.profile_enable(True)
+    for r in range(1, 5):
+        g.run_ticks(r * batch, batch)
+    by_kind, total, n = g.profile_collect()
+    assert n == 4 and total > 0
+    assert by_kind["eq_three"] > 0 and by_kind["mixer"] > 0
+    assert by_kind["mixer"] < 50.0 and by_kind["eq_three"] < 50.0   # ms over four runs of 16 ticks: event pairs of one stream each, no garbage from unrecorded events
