@@ -1094,8 +1094,8 @@ def main():
     # The same job with every launch group on ONE stream (MX_OVERLAP_AUTO=0): what each kernel takes when it has the chip to itself -- the figures the roofline block
     # quotes beside those of the timed region, where the Mixer bank of step k runs beside step k + 1's EqThree group.  Own graph over the same resident sources; not `value`.
     one_stream = None
-    overlap_active = (not use_dist) and g.tail_stream() is not None
-    if overlap_active and not args.no_profile and not args.no_one_stream_leg:
+    overlap_active = g.tail_stream() is not None
+    if overlap_active and not use_dist and not args.no_profile and not args.no_one_stream_leg:
         with torch.cuda.stream(stream):
             os.environ["MX_OVERLAP_AUTO"] = "0"
             try:

@@ -556,7 +556,9 @@ int mx_loopback_group_create(uint32_t world, mx_loopback_group** out);
 void mx_loopback_group_destroy(mx_loopback_group* grp);
 
 /* Exchange of Mixer `mixer_node`'s two output buses of `g` over steps of `n_ticks` ticks (<= max_ticks_per_run).  Exactly one of
- * nccl_unique_id / loopback is given.  `g` must outlive the exchange.  (With MX_FLAG_OVERLAP_TAIL the submit waits for the Mixer bank on the tail stream first.) */
+ * nccl_unique_id / loopback is given.  `g` must outlive the exchange.  Over a graph whose Mixer bank runs on the second stream (MX_FLAG_OVERLAP_TAIL or the automatic mode,
+ * which an exchange does NOT end) an RCCL exchange's pack and collectives of step k go out behind the bank when the graph releases it -- with run k + 1, or when the step's
+ * result is asked for (wait / result / read_result / elapsed_ms / sync) -- and run k + 2 starts after them; the loopback transport joins the streams at the submit. */
 int mx_exchange_create(mx_graph* g, uint32_t mixer_node, uint32_t n_ticks, uint32_t rank, uint32_t world,
                        const void* nccl_unique_id, mx_loopback_group* loopback, uint32_t mode, mx_exchange** out);
 void mx_exchange_destroy(mx_exchange* x);

@@ -371,6 +371,7 @@ void Graph::flush_deferred_tail(bool gated) {
     hip_check(hipEventRecord(ev_tail_done_[deferred_.parity], tail_stream_), "hipEventRecord");
     tail_pending_[deferred_.parity] = true;
     if (deferred_.prof_ev) hip_check(hipEventRecord(deferred_.prof_ev, tail_stream_), "hipEventRecord");
+    if (tail_hook_) { auto hook = std::move(tail_hook_); tail_hook_ = nullptr; hook(tail_stream_); }   // (mx_exchange: pack + exchange of that run's buses, behind the bank)
 }
 
 void Graph::wait_tail(int parity_or_all) {
@@ -990,6 +991,8 @@ void Graph::run(uint64_t t0, size_t fpc, uint32_t n_calls, float* ms_by_kind, fl
     // MX_FLAG_OVERLAP_TAIL: an uncut run alternates the double-buffered ports and leaves its tail on the second stream; before its
     // earlier groups overwrite a buffer, the tail that last read THAT buffer (two runs ago) must be done -- not the previous run's
     // (automatic mode: a run of a tick or a few on a graph built for long submissions stays on one stream -- two cross-stream events cost 13 us of an 75 us tick)
+    for (hipEvent_t e : head_waits_) hip_check(hipStreamWaitEvent(stream_, e, 0), "hipStreamWaitEvent");
+    head_waits_.clear();
     overlap_this_run_ = tail_gi_ >= 0 && cuts.empty() && (!tail_auto_ || n_calls >= 16);
     if (overlap_this_run_) { parity_ ^= 1u; wait_tail((int)parity_); }
     else if (tail_gi_ >= 0) wait_tail(-1);
@@ -1403,14 +1406,14 @@ void* Graph::debug_eq_records(size_t* bytes) const {
     return nullptr;
 }
 
-float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf) {
+float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf, bool stream_ordered_consumer) {
     if (node >= nodes_.size() || port >= nodes_[node].out_type.size()) throw Error(MX_ERR_INVALID, "output terminal out of range");
     if (nodes_[node].out_elided[port]) throw Error(MX_ERR_INVALID, "port is not materialised: it only feeds a fused consumer (build with MX_FLAG_NO_FUSE to observe it)");
     if (nodes_[node].out_dup[port]) throw Error(MX_ERR_INVALID, "port is stored as one float per frame (L == R fused result): use mx_graph_read_output, or build with MX_FLAG_NO_FUSE");
     if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]) * (spt_ * nodes_[node].dom_num / nodes_[node].dom_den);   // floats per TICK in the port's own rate domain
     // A consumer that takes the raw pointer of a bus reads it in stream order on stream(): a Mixer bank the library moved to the second stream ON ITS OWN (short submissions,
     // MX_OVERLAP_AUTO) would not be ordered before it -- so the automatism ends here, for good.  (A host that asked for MX_FLAG_OVERLAP_TAIL knows about mx_graph_tail_stream.)
-    if (tail_gi_ >= 0 && tail_auto_ && nodes_[node].group == tail_gi_) { wait_tail(-1); tail_gi_ = -1; }
+    if (stream_ordered_consumer && tail_gi_ >= 0 && tail_auto_ && nodes_[node].group == tail_gi_) { wait_tail(-1); tail_gi_ = -1; }
     return out_ptr(nodes_[node], port);
 }
 

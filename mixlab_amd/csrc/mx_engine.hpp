@@ -5,6 +5,7 @@
 // keeps every port buffer resident in one HBM slab, batches all instances of a module kind at one
 // dependency level into one launch, and runs n_ticks ticks per submission.
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -141,7 +142,16 @@ public:
     void read_output(uint32_t node, uint32_t port, float* host, size_t frames, size_t first_frame = 0);   // frames [first_frame, first_frame + frames) of the last run
     void read_output_i16(uint32_t node, uint32_t port, int16_t* host, size_t frames);   // sink hand-off format
     void write_source_i16(uint32_t node, const int16_t* host, size_t frames);            // ingest format
-    float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_tick);
+    float* output_ptr(uint32_t node, uint32_t port, size_t* floats_per_tick, bool stream_ordered_consumer = true /* false: a caller inside the library that orders itself
+                      after the tail stream (mx_exchange): the automatic second-stream mode stays on */);
+    // A Mixer bank of the last run that is being held back for the next run's EqThree launch (flush_deferred_tail)?  `hook` then runs ONCE, right after that launch has been
+    // queued, with the stream it was queued on -- what mx_exchange uses to pack the buses behind the bank instead of joining the streams.
+    bool tail_held() const { return deferred_.pending; }
+    void set_tail_hook(std::function<void(hipStream_t)> hook) { tail_hook_ = std::move(hook); }
+    // The NEXT run's first launch waits for `ev` (once).  What mx_exchange asks for its collectives and its combine of step k, which went out behind the bank that run k + 1
+    // released: they normally end inside run k + 1's EqThree launch; when the bank outlasts that launch they would run into run k + 2's EqThree workgroups being placed --
+    // thousands of small workgroups around which the dispatcher places those unevenly (every other launch 6.1 instead of 4.7 ms, rocprofv3 --kernel-trace).
+    void wait_before_next_run(hipEvent_t ev) { head_waits_.push_back(ev); }
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
     // topology edit (client_update, src/engine.rs:277-398): modules persist while the connection set changes.
@@ -218,6 +228,8 @@ private:
     // when the bank was nearly done: no overlap at all), the EqThree workgroups are placed on an empty chip, and the Mixer's waves fill what is left.  Every join
     // (mx_graph_sync, read-backs, mx_graph_tail_stream, an exchange's submit, a cut run) releases a held launch at once.  MX_TAIL_GATE=0: launched at once as in round 4.
     struct DeferredTail { bool pending = false; const void* desc = nullptr; uint32_t n = 0, max_ch = 0; size_t frames = 0; int dup_mode = 0; uint32_t parity = 0; hipEvent_t prof_ev = nullptr, prof_begin = nullptr; } deferred_;
+    std::function<void(hipStream_t)> tail_hook_;
+    std::vector<hipEvent_t> head_waits_;
     bool tail_held_this_span_ = false; std::vector<bool> prof_runs_held_;   // parallel to prof_runs_: that run's tail launch was held back (its events sit on the tail stream)
     DevBuf gate_flag_; uint32_t gate_seq_ = 0; bool gate_armed_ = false; int tail_gate_ = -1;
     void flush_deferred_tail(bool gated);

@@ -11,6 +11,7 @@
 //   allreduce   ncclAllReduce(sum), what the north-star names.  NOT the sum order of any graph the reference can express (the
 //               ring's order differs per chunk): explicitly non-parity, RCCL only.
 #include "mx_exchange.hpp"
+#include "mx_kernels.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on first use (below)
@@ -90,8 +91,8 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
     tps_ = g.ticks_per_second();
     hip_check(hipSetDevice(device_), "hipSetDevice");
     size_t fpt = 0, fpt_c = 0;
-    m_ptr_ = g.output_ptr(mix, 0, &fpt);
-    c_ptr_ = g.output_ptr(mix, 1, &fpt_c);
+    m_ptr_ = g.output_ptr(mix, 0, &fpt, false);   // (this consumer orders itself after the Mixer bank wherever it runs: the graph keeps its automatic second-stream mode)
+    c_ptr_ = g.output_ptr(mix, 1, &fpt_c, false);
     fpt_ = fpt;
     if ((size_t)n_ticks * g.spt() > g.cap_frames())
         throw Error(MX_ERR_INVALID, "n_ticks exceeds the graph's max_ticks_per_run");
@@ -138,6 +139,8 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
 
 void Exchange::destroy() noexcept {
     (void)hipSetDevice(device_);
+    if (held_) { try { ensure_submitted(); } catch (...) {} }
+    if (graph_) graph_->set_tail_hook(nullptr);
     if (cs_) (void)hipStreamSynchronize(cs_);
     if (lb_ && joined_ && rank_ < lb_->members.size() && lb_->members[rank_] == this) {
         // peers may still be reading this member's buffers
@@ -211,23 +214,47 @@ void Exchange::submit(uint64_t step) {
             if (r != rank_ && lb_->arrived[r] != lb_->completed && lb_->arrived[r] != (int64_t)step)
                 throw Error(MX_ERR_INVALID, "loopback: the ranks of a group submit the same step numbers in the same order");
     }
+    // RCCL transport over a graph that holds its Mixer bank back for the next run's EqThree launch (the second-stream mode): the pack and the exchange go out when the
+    // graph releases that launch -- behind it, on its stream -- instead of joining the streams now (which would put the bank in front of the next run again).  Whoever asks
+    // for this step's result first (wait / result / read_result / elapsed_ms / sync) releases it.  (The loopback transport keeps the join: its members' submits are counted
+    // when they are made.)
+    if (!lb_) {
+        ensure_submitted();
+        if (graph_->tail_held()) {
+            held_ = true; held_step_ = step;
+            graph_->set_tail_hook([this](hipStream_t ts) { if (held_) { held_ = false; do_submit(held_step_, ts); } });
+            return;
+        }
+    }
+    graph_->join_tail();   // the buses are packed on the graph's stream: a Mixer bank still running on the tail stream finishes first
+    do_submit(step, compute_);
+}
+
+void Exchange::ensure_submitted() {
+    if (held_) graph_->join_tail();      // releases the bank; the hook runs do_submit
+    if (held_) { held_ = false; graph_->set_tail_hook(nullptr); do_submit(held_step_, compute_); }   // (the graph had nothing held after all)
+}
+
+void Exchange::do_submit(uint64_t step, hipStream_t ps) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    Slot& sl = slots_[step & 1];
     // the exchange that last used this slot has finished with the packed partials (loopback: every peer that read them, too)
     if (sl.used) {
-        if (lb_) { for (Exchange* q : lb_->members) hip_check(hipStreamWaitEvent(compute_, q->slots_[step & 1].done, 0), "hipStreamWaitEvent"); }
-        else hip_check(hipStreamWaitEvent(compute_, sl.done, 0), "hipStreamWaitEvent");
+        if (lb_) { for (Exchange* q : lb_->members) hip_check(hipStreamWaitEvent(ps, q->slots_[step & 1].done, 0), "hipStreamWaitEvent"); }
+        else hip_check(hipStreamWaitEvent(ps, sl.done, 0), "hipStreamWaitEvent");
     }
     // all-reduce runs in place: its RESULT is `part`, which the pack below overwrites -- on the compute stream, so the consumer's
     // release (an event on ITS stream) has to order the pack, not only the next exchange (the other modes' results are written on cs_)
-    if (mode_ == MX_EXCHANGE_ALLREDUCE && sl.consumed_pending) hip_check(hipStreamWaitEvent(compute_, sl.consumed, 0), "hipStreamWaitEvent");
+    if (mode_ == MX_EXCHANGE_ALLREDUCE && sl.consumed_pending) hip_check(hipStreamWaitEvent(ps, sl.consumed, 0), "hipStreamWaitEvent");
     float* part = (float*)sl.part.p;
-    graph_->join_tail();   // the buses are packed on the graph's stream: a Mixer bank still running on the tail stream finishes first
+    // (by a kernel: a copy-engine copy queued behind a cross-stream wait makes the host wait for that event -- k_upload, mx_k_stream.hip)
     if (c_ptr_ == m_ptr_ + n_fl_ && n_flp_ == n_fl_) {   // Master and Cue are neighbours in the graph's slab: one copy packs both
-        hip_check(hipMemcpyAsync(part, m_ptr_, 2 * n_fl_ * sizeof(float), hipMemcpyDeviceToDevice, compute_), "hipMemcpyAsync(pack)");
+        launch_upload(part, m_ptr_, 2 * n_fl_ * sizeof(float), ps);
     } else {
-        hip_check(hipMemcpyAsync(part, m_ptr_, n_fl_ * sizeof(float), hipMemcpyDeviceToDevice, compute_), "hipMemcpyAsync(pack)");
-        hip_check(hipMemcpyAsync(part + n_flp_, c_ptr_, n_fl_ * sizeof(float), hipMemcpyDeviceToDevice, compute_), "hipMemcpyAsync(pack)");
+        launch_upload(part, m_ptr_, n_fl_ * sizeof(float), ps);
+        launch_upload(part + n_flp_, c_ptr_, n_fl_ * sizeof(float), ps);
     }
-    hip_check(hipEventRecord(sl.packed, compute_), "hipEventRecord");
+    hip_check(hipEventRecord(sl.packed, ps), "hipEventRecord");
     sl.step = (int64_t)step;
     sl.queued = false;
     if (!lb_) {
@@ -237,6 +264,7 @@ void Exchange::submit(uint64_t step) {
         collective_rccl(sl);
         hip_check(hipEventRecord(sl.done, cs_), "hipEventRecord");
         sl.used = true; sl.queued = true;
+        if (ps != compute_) graph_->wait_before_next_run(sl.done);   // packed behind a released Mixer bank: see Graph::wait_before_next_run
         return;
     }
     lb_->arrived[rank_] = (int64_t)step;
@@ -330,12 +358,14 @@ void Exchange::loopback_round(LoopbackGroup& grp, uint64_t step) {
 }
 
 void Exchange::wait(uint64_t step, hipStream_t consumer) {
+    ensure_submitted();
     Slot& sl = slot_of(step, "mx_exchange_wait");
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipStreamWaitEvent(consumer ? consumer : compute_, sl.done, 0), "hipStreamWaitEvent");
 }
 
 void Exchange::release(uint64_t step, hipStream_t consumer) {
+    ensure_submitted();
     Slot& sl = slot_of(step, "mx_exchange_release");
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipEventRecord(sl.consumed, consumer ? consumer : compute_), "hipEventRecord");
@@ -343,6 +373,7 @@ void Exchange::release(uint64_t step, hipStream_t consumer) {
 }
 
 void Exchange::result(uint64_t step, float** master, float** cue, size_t* floats) {
+    ensure_submitted();
     Slot& sl = slot_of(step, "mx_exchange_result");
     float *m, *c;
     if (mode_ == MX_EXCHANGE_ALLGATHER) { m = sl.fm_out; c = sl.fc_out; }
@@ -354,6 +385,7 @@ void Exchange::result(uint64_t step, float** master, float** cue, size_t* floats
 }
 
 void Exchange::read_result(uint64_t step, float* master, float* cue) {
+    ensure_submitted();
     Slot& sl = slot_of(step, "mx_exchange_read_result");
     float *m, *c; size_t n;
     result(step, &m, &c, &n);
@@ -364,6 +396,7 @@ void Exchange::read_result(uint64_t step, float* master, float* cue) {
 }
 
 float Exchange::elapsed_ms(uint64_t step) {
+    ensure_submitted();
     Slot& sl = slot_of(step, "mx_exchange_elapsed_ms");
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipEventSynchronize(sl.done), "hipEventSynchronize");
@@ -373,6 +406,7 @@ float Exchange::elapsed_ms(uint64_t step) {
 }
 
 void Exchange::sync() {
+    ensure_submitted();
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipStreamSynchronize(cs_), "hipStreamSynchronize");
 }

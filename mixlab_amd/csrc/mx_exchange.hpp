@@ -69,6 +69,9 @@ private:
     void build_combine(Slot& sl, uint32_t ticks, const float* base, size_t peer_stride, size_t cue_off);
     void collective_rccl(Slot& sl);
     static void loopback_round(LoopbackGroup& grp, uint64_t step);
+    void do_submit(uint64_t step, hipStream_t pack_stream);   // pack the buses on pack_stream (the graph's stream, or its tail stream behind a released Mixer bank) + the exchange behind them
+    void ensure_submitted();           // a submit that waits for the graph to release its held-back Mixer bank: release it now
+    bool held_ = false; uint64_t held_step_ = 0;
     void destroy() noexcept;           // what the destructor does; also the constructor's exit by exception
     bool joined_ = true;
 

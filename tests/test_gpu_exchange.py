@@ -44,10 +44,13 @@ unique_id()
 assert rccl_mapped(), "mx_exchange_unique_id did not bind librccl"
 print("ok lazy-rccl", flush=True)
 
-for sr, T, n in ((48000, 8, 6), (44100, 3, 5)):          # 44.1 kHz x an odd tick count: bus lengths that are not multiples of a cache line
+# (third shape: MX_FLAG_OVERLAP_TAIL and runs long enough for the speculative EqThree launch -- the Mixer bank of a run is held back for the next run's launch, and the
+#  exchange's pack and collectives go out behind it when it is released: by the next run, or by whoever asks for the step's result first)
+for sr, T, n, fl in ((48000, 8, 6, 0), (44100, 3, 5, 0), (48000, 16, 6, abi.FLAG_OVERLAP_TAIL)):          # 44.1 kHz x an odd tick count: bus lengths that are not multiples of a cache line
     for mode in ("allgather", "slices", "allreduce"):
         ws, mix = strips(n, sr)
-        g = ws.build(max_ticks_per_run=T, device=0)
+        g = ws.build(max_ticks_per_run=T, device=0, flags=fl)
+        assert (g.tail_stream() is not None) == bool(fl)
         ref = ws.build(max_ticks_per_run=T)                    # the same shard, run on its own: what the bus must be
         ex = BusExchange(g, mix, T, 0, 1, mode=mode, nccl_id=unique_id())
         assert ex.world == 1 and ex.mode == mode
@@ -75,7 +78,7 @@ for sr, T, n in ((48000, 8, 6), (44100, 3, 5)):          # 44.1 kHz x an odd tic
         assert ex.bytes_received_per_step() == 0                           # a single rank receives nothing
         assert ex.elapsed_ms(3) > 0.0
         ex.close()
-        print("ok", sr, mode, flush=True)
+        print("ok", sr, mode, "overlap" if fl else "", flush=True)
 
 ws, mix = strips(2)
 g = ws.build(max_ticks_per_run=4, device=0)
@@ -95,6 +98,8 @@ def test_single_rank_rccl_exchange_through_the_c_abi_returns_the_local_bus_over_
     for sr in (48000, 44100):
         for mode in ("allgather", "slices", "allreduce"):
             assert f"ok {sr} {mode}" in res.stdout, res.stdout[-2000:]
+    for mode in ("allgather", "slices", "allreduce"):
+        assert f"ok 48000 {mode} overlap" in res.stdout, res.stdout[-2000:]
     assert "ok bogus-mode" in res.stdout and "ok lazy-rccl" in res.stdout
 
 
