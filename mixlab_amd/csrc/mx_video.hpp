@@ -124,6 +124,7 @@ struct VbRow {
     uint32_t ts1, ts2;                // jobs: first tile of planes 1 and 2 (plane 0 starts at 0)
     uint32_t tx0, tx1, tx2;           // jobs: tiles per tile row of each plane
     uint32_t variant, s_rows;         // jobs: tile body variant and window rows
+    uint32_t prio;                    // s_setprio per tile kind: bits 0..1 chain rows, bits 2..3 job rows (launch_video_batch)
 };
 struct VbRows { VbRow r[MX_VB_MAX_CHAINS + MX_VB_MAX_JOBS]; };
 void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
