@@ -1305,8 +1305,8 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     }
     // row order (MX_VIDEO_ORDER): 0 the chains' rows first, the jobs' behind them; 1 interleaved in proportion; 2 the jobs' first.
     // Round 5: interleaved rows WITH the scaler tiles' waves one priority level above the chain tiles' -- the VALU-bound waves issue whenever they can, the memory-bound
-    // ones fill the gaps: 9.54 -> 9.28 us per frame (8 layers read: 10.09 -> 9.60); interleaved without the priority it is 9.94, with the chains' waves on top 10.1
-    // (tools/q_vprio.sh).  A launch with coverage planes (their scale jobs double the job rows) keeps the chains first: 13.2 against 13.5.
+    // ones fill the gaps: 9.54 -> 9.28 us per frame (8 layers read: 10.09 -> 9.60); interleaved without the priority it is 9.94, with the chains' waves on top 10.1,
+    // with only the chain tiles' load requests on top (priority dropped before their arithmetic) 9.37 against 8.95 on that box (tools/q_vprio.sh).  A launch with coverage planes (their scale jobs double the job rows) keeps the chains first: 13.2 against 13.5.
     {
         static const int order_env = env_int("MX_VIDEO_ORDER", -1);
         const int order = order_env >= 0 ? order_env : (any_alpha ? 0 : 1);
