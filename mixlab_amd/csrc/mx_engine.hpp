@@ -152,6 +152,7 @@ public:
     // released: they normally end inside run k + 1's EqThree launch; when the bank outlasts that launch they would run into run k + 2's EqThree workgroups being placed --
     // thousands of small workgroups around which the dispatcher places those unevenly (every other launch 6.1 instead of 4.7 ms, rocprofv3 --kernel-trace).
     void wait_before_next_run(hipEvent_t ev) { head_waits_.push_back(ev); }
+    void forget_waits_before_next_run() { head_waits_.clear(); }   // (their owner is going away: its events with it)
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
     // topology edit (client_update, src/engine.rs:277-398): modules persist while the connection set changes.

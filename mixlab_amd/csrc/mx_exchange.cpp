@@ -140,7 +140,7 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
 void Exchange::destroy() noexcept {
     (void)hipSetDevice(device_);
     if (held_) { try { ensure_submitted(); } catch (...) {} }
-    if (graph_) graph_->set_tail_hook(nullptr);
+    if (graph_) { graph_->set_tail_hook(nullptr); graph_->forget_waits_before_next_run(); }
     if (cs_) (void)hipStreamSynchronize(cs_);
     if (lb_ && joined_ && rank_ < lb_->members.size() && lb_->members[rank_] == this) {
         // peers may still be reading this member's buffers
