@@ -202,6 +202,9 @@ int mx_graph_eq_repair_stats(mx_graph* g, uint64_t out[8]);
  * synchronises).  144 bytes per chunk: start[8], end[8] (f64 poles), min / max input bits, and in the padding -- written by the tiled kernel -- lane 0 of a wave: the
  * shader clock (low 32 bits) when the wave entered, lane 1: HW_ID, lane 2: XCC_ID, every lane: the clock when it left.  tools/wave_times.py reads it. */
 int mx_graph_debug_eq_records(mx_graph* g, void** device_records, size_t* bytes);
+/* DEBUG: how the Mixer banks of the second-stream mode (MX_FLAG_OVERLAP_TAIL / automatic) went out since the graph was built: behind the gate that the next run's EqThree
+ * launch opens, or at once (a join released them, or the next run had no such launch).  Tests use it to know which path they exercised. */
+int mx_graph_debug_tail_releases(mx_graph* g, uint64_t* gated, uint64_t* at_once);
 
 /* Feed a SOURCE_* node: n_ticks consecutive tick buffers (SPT mono / 2*SPT interleaved stereo f32). */
 int mx_graph_write_source(mx_graph* g, uint32_t node, const float* host_samples, size_t n_ticks);

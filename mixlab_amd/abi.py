@@ -114,6 +114,7 @@ _proto("mx_graph_schedule_params", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, 
 _proto("mx_graph_schedule_params_batch", C.c_int, C.c_void_p, C.POINTER(ParamEvent), C.c_size_t)
 _proto("mx_graph_eq_spec_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _proto("mx_graph_debug_eq_records", C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+_proto("mx_graph_debug_tail_releases", C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _proto("mx_graph_eq_repair_stats", C.c_int, C.c_void_p, C.POINTER(C.c_uint64))
 _proto("mx_graph_write_source", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
 _proto("mx_graph_bind_source_device", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p)
@@ -234,6 +235,12 @@ class Graph:
         check(lib.mx_graph_eq_repair_stats(self._h, v))
         keys = ("chunks_run", "chunks_repaired", "settled_by_comparison", "walk_steps_16", "fill_steps_16", "island_rounds", "in_order_walks", "nan_fills")
         return {k: int(x) for k, x in zip(keys, v)}
+
+    def debug_tail_releases(self):
+        """-> (gated, at_once): how the held-back Mixer banks of the second-stream mode went out (mx_graph_debug_tail_releases)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib.mx_graph_debug_tail_releases(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def debug_eq_records(self):
         """-> (device pointer, bytes) of the first EqThree group's chunk records of the last speculative launch (mx_graph_debug_eq_records)"""

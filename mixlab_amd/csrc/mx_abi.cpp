@@ -131,6 +131,9 @@ int mx_graph_debug_eq_records(mx_graph* g, void** device_records, size_t* bytes)
         *device_records = g->g->debug_eq_records(bytes);
     });
 }
+int mx_graph_debug_tail_releases(mx_graph* g, uint64_t* gated, uint64_t* at_once) {
+    return guard([&] { REQUIRE(g, "NULL argument"); g->g->tail_releases(gated, at_once); });
+}
 
 int mx_graph_eq_repair_stats(mx_graph* g, uint64_t out[8]) {
     return guard([&] {

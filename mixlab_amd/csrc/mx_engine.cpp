@@ -365,7 +365,7 @@ void Graph::flush_deferred_tail(bool gated) {
     if (!deferred_.pending) return;
     deferred_.pending = false;
     hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
-    if (gated && gate_armed_) launch_tail_gate((const uint32_t*)gate_flag_.p, gate_seq_, 300u, tail_stream_);
+    if (gated && gate_armed_) { launch_tail_gate((const uint32_t*)gate_flag_.p, gate_seq_, 300u, tail_stream_); ++n_gated_; } else ++n_at_once_;
     if (deferred_.prof_begin) hip_check(hipEventRecord(deferred_.prof_begin, tail_stream_), "hipEventRecord");
     launch_mixer((const MixDesc*)deferred_.desc, deferred_.n, deferred_.max_ch, deferred_.frames, deferred_.dup_mode, tail_stream_);
     hip_check(hipEventRecord(ev_tail_done_[deferred_.parity], tail_stream_), "hipEventRecord");
@@ -748,7 +748,9 @@ void Graph::update_params(uint32_t node, const void* params, size_t len) {
     if (node >= nodes_.size()) throw Error(MX_ERR_INVALID, "node out of range");
     if (len != nodes_[node].params.size()) throw Error(MX_ERR_INVALID, "params_len differs from the node's params (terminal count is frozen with the topology)");
     if (len && !params) throw Error(MX_ERR_INVALID, "params is NULL");
-    sync();
+    // a Trigger's params live in the GateBits rows the next run uploads: nothing on the device reads them, nothing has to be waited for (and a Mixer bank that is being
+    // held back for the next run stays held)
+    if (nodes_[node].kind != MX_KIND_TRIGGER) sync();
     apply_params(node, params, len);
 }
 

@@ -147,6 +147,7 @@ public:
     // A Mixer bank of the last run that is being held back for the next run's EqThree launch (flush_deferred_tail)?  `hook` then runs ONCE, right after that launch has been
     // queued, with the stream it was queued on -- what mx_exchange uses to pack the buses behind the bank instead of joining the streams.
     bool tail_held() const { return deferred_.pending; }
+    void tail_releases(uint64_t* gated, uint64_t* at_once) const { if (gated) *gated = n_gated_; if (at_once) *at_once = n_at_once_; }
     void set_tail_hook(std::function<void(hipStream_t)> hook) { tail_hook_ = std::move(hook); }
     // The NEXT run's first launch waits for `ev` (once).  What mx_exchange asks for its collectives and its combine of step k, which went out behind the bank that run k + 1
     // released: they normally end inside run k + 1's EqThree launch; when the bank outlasts that launch they would run into run k + 2's EqThree workgroups being placed --
@@ -231,6 +232,7 @@ private:
     struct DeferredTail { bool pending = false; const void* desc = nullptr; uint32_t n = 0, max_ch = 0; size_t frames = 0; int dup_mode = 0; uint32_t parity = 0; hipEvent_t prof_ev = nullptr, prof_begin = nullptr; } deferred_;
     std::function<void(hipStream_t)> tail_hook_;
     std::vector<hipEvent_t> head_waits_;
+    uint64_t n_gated_ = 0, n_at_once_ = 0;
     bool tail_held_this_span_ = false; std::vector<bool> prof_runs_held_;   // parallel to prof_runs_: that run's tail launch was held back (its events sit on the tail stream)
     DevBuf gate_flag_; uint32_t gate_seq_ = 0; bool gate_armed_ = false; int tail_gate_ = -1;
     void flush_deferred_tail(bool gated);

@@ -160,6 +160,8 @@ def test_a_bank_released_by_the_next_runs_eq_three_launch_is_the_oracles():
     assert_bit_exact(g.read_output(mix, 0, batch, True), want[-1][0], "master of the last run (released by the read-back)")
     ran1, _ = g.eq_spec_stats()
     assert ran1 > ran0                                       # the speculative kernel (the one that opens the gate) is what ran
+    gated, at_once = g.debug_tail_releases()
+    assert gated == n_runs - 1 and at_once == 1, (gated, at_once)   # every bank but the last went out behind the next run's gate
 
 
 def test_per_group_times_with_a_held_back_bank():
