@@ -707,7 +707,7 @@ def sustained_clock_ghz(kernel_substr, fc=False):
     return None
 
 
-def scaling_probe(torch, stream, local_rank, abi, Workspace, synth, strips, T, SR, toggling, flags, t1_ms):
+def scaling_probe(torch, stream, local_rank, abi, Workspace, synth, strips, T, SR, toggling, flags, t1_ms, with_exchange=True):
     """What ONE rank of an N-GPU job computes per step, measured on this GPU: its strip share (strips / N) for T ticks (strong scaling as the
     driver runs it) and for T x N ticks (--scale-ticks: the chunk length per lane of the speculative EqThree stays what it is at N = 1).  The
     exchange is not run here (one GPU): its time is modelled as bytes received per rank and step / 300 GB/s of xGMI and assumed hidden behind
@@ -735,12 +735,31 @@ def scaling_probe(torch, stream, local_rank, abi, Workspace, synth, strips, T, S
                 g.run_ticks(i * Tn, Tn)
             g.sync()
             ms = (time.perf_counter() - t0) / k * 1e3
+            # the same rank with an exchange in the loop (fixed T only): a ONE-rank RCCL communicator -- the pack, the library's RCCL call and the combine graph really run
+            # (behind the held-back Mixer bank); what no single GPU can show is the wire
+            ms_x = None
+            if policy == "fixed_ticks" and with_exchange:
+                from mixlab_amd.exchange import BusExchange, unique_id
+                ex1 = BusExchange(g, mix, Tn, 0, 1, mode="allgather", nccl_id=unique_id())
+                kx = 4
+                evx = [gate_events(abi, trigs, 0, (2 + k + i) * Tn, Tn) if toggling else None for i in range(2 + kx)]
+                for i in range(2 + kx):
+                    if i == 2:
+                        g.sync(); ex1.sync(); tx0 = time.perf_counter()
+                    if evx[i] is not None:
+                        g.schedule_params_batch(evx[i][0], evx[i][1])
+                    g.run_ticks((2 + k + i) * Tn, Tn)
+                    ex1.submit(i)
+                g.sync(); ex1.sync()
+                ms_x = (time.perf_counter() - tx0) / kx * 1e3
+                ex1.close()
             g.close(); del noise
             bus = 2 * 2 * spt * Tn * 4                                   # Master + Cue, interleaved stereo f32, per step
             recv = 2 * (n - 1) * bus // n if (n >= 4 and Tn % n == 0) else (n - 1) * bus
             ex_ms = recv / 300e9 * 1e3
             step_ms = max(ms, ex_ms)
             out[policy][str(n)] = {"strips_per_rank": sn, "ticks_per_step": Tn, "rank_compute_ms_per_step": round(ms, 4),
+                                   **({"rank_step_ms_with_a_1_rank_rccl_exchange_in_the_loop": round(ms_x, 4)} if ms_x is not None else {}),
                                    "exchange_bytes_received_per_rank": recv, "exchange_ms_at_300GBps": round(ex_ms, 4),
                                    "predicted_job_value": strips * Tn / (step_ms * 1e-3),
                                    "predicted_speedup_vs_1_gpu": round((strips * Tn / step_ms) / (strips * T / t1_ms), 2)}
