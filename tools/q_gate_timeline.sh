@@ -3,7 +3,7 @@ cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export MX_TAIL_GATE=1
 rm -rf /tmp/kt_y
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_y -- python $R/tools/eq_sweep.py --toggle --steps 12 --no-profile --ticks 256 --overlap-tail 2>&1 | grep strips
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_y -- python $R/tools/eq_sweep.py --toggle --steps 12 --no-profile --ticks ${TICKS:-256} ${OVERLAP---overlap-tail} 2>&1 | grep strips
 python - $(find /tmp/kt_y -name "*kernel_trace.csv" | head -1) <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
