@@ -181,3 +181,44 @@ def test_per_group_times_with_a_held_back_bank():
     assert n == 4 and total > 0
     assert by_kind["eq_three"] > 0 and by_kind["mixer"] > 0
     assert by_kind["mixer"] < 50.0 and by_kind["eq_three"] < 50.0   # ms over four runs of 16 ticks: event pairs of one stream each, no garbage from unrecorded events
+
+
+def test_a_gate_that_nobody_opens_times_out_and_the_results_stand():
+    """The gate is an ordering hint, never a dependency: with the speculative EqThree launch in its direct form (MX_EQ_SPEC_DIRECT: a kernel that does not store the
+    flag) every held-back bank goes behind a gate that only its bounded spin (300 us) opens.  Same buses, bit for bit.  In a process of its own: the launcher reads
+    that override once."""
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    code = f"""
+import sys
+sys.path.insert(0, {str(root)!r}); sys.path.insert(0, {str(root / 'tests')!r})
+import numpy as np
+import synth
+from mixlab_amd import abi
+from test_gpu_audio_parity import assert_bit_exact, strips
+from test_gpu_schedule import schedule_gates
+from test_gpu_overlap_tail import oracle_runs, SR, SPT
+n_strips, batch, n_runs = 64, 16, 4
+ws, mix, srcs, trigs = strips(n_strips, SR)
+noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch)
+g = ws.build(max_ticks_per_run=batch, flags=abi.FLAG_OVERLAP_TAIL)
+for r in range(n_runs):
+    schedule_gates(g, trigs, r * batch, batch)
+    for k, s in enumerate(srcs):
+        g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+    g.run_ticks(r * batch, batch)
+assert_bit_exact(g.read_output(mix, 0, batch, True), want[-1][0], "master of the last run")
+assert_bit_exact(g.read_output(mix, 1, batch, True), want[-1][1], "cue of the last run")
+gated, at_once = g.debug_tail_releases()
+assert gated == n_runs - 1, (gated, at_once)
+ran, _ = g.eq_spec_stats()
+assert ran > 0
+print("ok gate-timeout")
+"""
+    env = dict(os.environ, MX_EQ_SPEC_DIRECT="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "ok gate-timeout" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
