@@ -250,3 +250,50 @@ def test_headline_shape_1024_strips_x_2048_ticks_with_the_planners_own_plan_agai
     assert rec["verdict"] == "bit-exact", rec
     assert rec["strips_checked"] == 16 and rec["samples_compared"] == 16 * T * 2 * SPT48
     assert rec["buses"]["verdict"] == "bit-exact", rec
+
+
+def test_headline_shape_bank_released_behind_the_gate_equals_the_one_stream_bank(monkeypatch):
+    """Round 5: at the headline's own shape the Mixer bank of run k goes out behind the gate that run k + 1's EqThree launch opens and shares the chip with it.  Only the
+    schedule differs from the one-stream form -- which the test above pins to the oracle -- so the buses must be the same bits: the bank of run 1, read by a copy queued
+    on the tail stream once run 2 is queued (the only place a gated bank can be seen: every read-back releases a held bank itself), against the same run's buses of a
+    graph built with MX_OVERLAP_AUTO=0."""
+    import ctypes as C
+
+    import bench
+    from mixlab_amd.workspace import Workspace
+
+    T, n_runs = 2048, 3
+    ws, mix, srcs, trigs = bench.build_strips(abi, Workspace, synth, N, 0, SR48, want_trigs=True)
+    g = ws.build(max_ticks_per_run=T, flags=abi.FLAG_OVERLAP_TAIL)
+    tail = g.tail_stream()
+    assert tail is not None
+    monkeypatch.setenv("MX_OVERLAP_AUTO", "0")
+    one = ws.build(max_ticks_per_run=T)
+    monkeypatch.delenv("MX_OVERLAP_AUTO")
+    assert one.tail_stream() is None
+    for j, s in enumerate(srcs):
+        buf = np.tile(synth.noise(j, 256 * SPT48), T // 256)
+        g.write_source(s, buf, T)
+        one.bind_source_device(s, g.output_device_ptr(s, 0)[0])
+    hip = C.CDLL("libamdhip64.so")
+    pm, fpt = g.output_device_ptr(mix, 0)
+    pc, _ = g.output_device_ptr(mix, 1)
+    n = fpt * T
+    got_m, got_c = np.empty(n, np.float32), np.empty(n, np.float32)
+    want = None
+    for r in range(n_runs):
+        ev = bench.gate_events(abi, trigs, 0, r * T, T)
+        g.schedule_params_batch(ev[0], ev[1]); one.schedule_params_batch(ev[0], ev[1])
+        g.run_ticks(r * T, T)
+        if r == 2:      # run 2 is queued: the bank of run 1 is behind its gate on the tail stream, the bank of run 2 is held
+            for dst, src in ((got_m, pm), (got_c, pc)):
+                assert hip.hipMemcpyAsync(dst.ctypes.data_as(C.c_void_p), C.c_void_p(src), C.c_size_t(n * 4), 2, C.c_void_p(tail)) == 0
+            assert hip.hipStreamSynchronize(C.c_void_p(tail)) == 0
+        one.run_ticks(r * T, T)
+        if r == 1:
+            want = (one.read_output(mix, 0, T, True).copy(), one.read_output(mix, 1, T, True).copy())
+    assert np.array_equal(got_m.view(np.uint32), want[0].view(np.uint32)), "master of run 1"
+    assert np.array_equal(got_c.view(np.uint32), want[1].view(np.uint32)), "cue of run 1"
+    gated, at_once = g.debug_tail_releases()
+    assert gated == 2 and at_once == 0, (gated, at_once)
+    assert np.array_equal(g.read_output(mix, 0, T, True).view(np.uint32), one.read_output(mix, 0, T, True).view(np.uint32))   # and the last run's, released by the read-back
