@@ -120,8 +120,8 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
  * arithmetic): mx_graph_build fails with MX_ERR_INVALID. */
 #define MX_FLAG_FP_CONTRACT 16u
 
-#define MX_FLAG_OVERLAP_TAIL 8u /* throughput mode for batched runs: the LAST launch group, when it is a Mixer bank, runs on a second
-                                  stream beside the NEXT run's earlier groups (an HBM-bound kernel beside a VALU-bound one); the ports it
+#define MX_FLAG_OVERLAP_TAIL 8u /* throughput mode for batched runs: the Mixer groups at the END of the launch order (a bank, or a bank and the
+                                  group / master buses above it) run on a second stream beside the NEXT run's earlier groups (an HBM-bound kernel beside a VALU-bound one); the ports it
                                   reads are double-buffered and alternate per run.  Results are unchanged bit for bit; mx_graph_sync, every
                                   read-back and mx_graph_run_ticks' own ordering cover both streams.  mx_graph_output_device_ptr of a port
                                   the tail READS names the buffer of the last run only (it alternates); the tail's own outputs do not move.

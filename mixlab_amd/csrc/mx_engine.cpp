@@ -329,16 +329,24 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
         for (const Group& g : groups_) if (g.kind == MX_KIND_EQ_THREE) n_eq = std::max(n_eq, g.nodes.size());
         overlap_auto = auto_on && eq_exact() && n_eq >= 64 && max_ticks >= 16;
     }
-    if (((flags_ & MX_FLAG_OVERLAP_TAIL) || overlap_auto) && !has_video_ && groups_.size() >= 2 && groups_.back().kind == MX_KIND_MIXER &&
-        groups_[groups_.size() - 2].level < groups_.back().level && plotter_nodes_.empty()) {
+    // The tail is every Mixer group at the END of the launch order: a bank, or a bank and the buses above it (group buses -> master).  What its groups read from the
+    // groups before them is double-buffered; what they read from each other is not (they run in order on the one tail stream).
+    size_t t_first = groups_.size();
+    while (t_first > 0 && groups_[t_first - 1].kind == MX_KIND_MIXER) --t_first;
+    if (((flags_ & MX_FLAG_OVERLAP_TAIL) || overlap_auto) && !has_video_ && groups_.size() >= 2 && t_first >= 1 && t_first < groups_.size() &&
+        groups_[t_first - 1].level < groups_[t_first].level && plotter_nodes_.empty()) {
         bool ok = true;
         std::vector<std::pair<uint32_t, uint32_t>> ports;
-        for (uint32_t id : groups_.back().nodes)
-            for (const PortRef& pr : nodes_[id].in_src) {
-                if (pr.node < 0) continue;
-                const Node& sn = nodes_[pr.node];
-                if (sn.kind == MX_KIND_SOURCE_MONO || sn.kind == MX_KIND_SOURCE_STEREO || sn.group == (int)groups_.size() - 1) { ok = false; break; }   // a source is rewritten by the caller while the tail may still read it
-                ports.push_back({(uint32_t)pr.node, pr.port});
+        for (size_t tg = t_first; tg < groups_.size() && ok; ++tg)
+            for (uint32_t id : groups_[tg].nodes) {
+                for (const PortRef& pr : nodes_[id].in_src) {
+                    if (pr.node < 0) continue;
+                    const Node& sn = nodes_[pr.node];
+                    if (sn.group >= (int)t_first && sn.group < (int)tg) continue;   // another tail group's output: same stream, in order
+                    if (sn.kind == MX_KIND_SOURCE_MONO || sn.kind == MX_KIND_SOURCE_STEREO || sn.group >= (int)tg) { ok = false; break; }   // a source is rewritten by the caller while the tail may still read it
+                    if (std::find(ports.begin(), ports.end(), std::make_pair((uint32_t)pr.node, (uint32_t)pr.port)) == ports.end()) ports.push_back({(uint32_t)pr.node, pr.port});
+                }
+                if (!ok) break;
             }
         if (ok && overlap_auto && !(flags_ & MX_FLAG_OVERLAP_TAIL)) {   // the second buffers must be affordable (an upper bound: every port as interleaved stereo)
             const char* const ge = getenv("MX_OVERLAP_AUTO_MAX_GB");
@@ -349,7 +357,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
             if (extra > max_gb * 1073741824.0 || extra > (double)free_b / 4.0) ok = false;
         }
         if (ok) {
-            tail_gi_ = (int)groups_.size() - 1;
+            tail_gi_ = (int)t_first;
             tail_auto_ = !(flags_ & MX_FLAG_OVERLAP_TAIL);
             for (auto& pp : ports) nodes_[pp.first].out_off2[pp.second] = 0;   // marked; layout_slab gives it its offset
             hip_check(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking), "hipStreamCreate(tail)");
@@ -367,10 +375,13 @@ void Graph::flush_deferred_tail(bool gated) {
     hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
     if (gated && gate_armed_) { launch_tail_gate((const uint32_t*)gate_flag_.p, gate_seq_, 300u, tail_stream_); ++n_gated_; } else ++n_at_once_;
     if (deferred_.prof_begin) hip_check(hipEventRecord(deferred_.prof_begin, tail_stream_), "hipEventRecord");
-    launch_mixer((const MixDesc*)deferred_.desc, deferred_.n, deferred_.max_ch, deferred_.frames, deferred_.dup_mode, tail_stream_);
+    for (const TailLaunch& t : deferred_.items) {
+        launch_mixer((const MixDesc*)t.desc, t.n, t.max_ch, t.frames, t.dup_mode, tail_stream_);
+        if (t.prof_ev) hip_check(hipEventRecord(t.prof_ev, tail_stream_), "hipEventRecord");
+    }
+    deferred_.items.clear();
     hip_check(hipEventRecord(ev_tail_done_[deferred_.parity], tail_stream_), "hipEventRecord");
     tail_pending_[deferred_.parity] = true;
-    if (deferred_.prof_ev) hip_check(hipEventRecord(deferred_.prof_ev, tail_stream_), "hipEventRecord");
     if (tail_hook_) { auto hook = std::move(tail_hook_); tail_hook_ = nullptr; hook(tail_stream_); }   // (mx_exchange: pack + exchange of that run's buses, behind the bank)
 }
 
@@ -1114,22 +1125,23 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
         }
         case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_); break;
         case MX_KIND_MIXER:
-            if (overlap_this_run_ && (int)gi == tail_gi_) {   // beside the next run's earlier groups (HBM-bound beside VALU-bound)
-                if (deferred_.pending) flush_deferred_tail(false);   // (a run whose earlier groups had no speculative EqThree launch: nothing opened a gate)
-                hip_check(hipEventRecord(ev_head_done_, stream_), "hipEventRecord");
-                if (tail_gate_ < 0) { const char* e = getenv("MX_TAIL_GATE"); tail_gate_ = e && atoi(e) == 0 ? 0 : 1; }   // A/B: 0 = launched at once (round 4's form)
-                if (tail_gate_) {
-                    deferred_.pending = true; deferred_.desc = desc_of(g); deferred_.n = n; deferred_.max_ch = g.max_taps; deferred_.frames = gf; deferred_.dup_mode = g.dup_mode; deferred_.parity = parity_;
-                    deferred_.prof_ev = prof ? ev[gi + 1] : nullptr; deferred_.prof_begin = prof ? ev[groups_.size() + 2] : nullptr;
-                    tail_held_this_span_ = true;
-                    ++gi;
-                    continue;
+            if (overlap_this_run_ && (int)gi >= tail_gi_) {   // beside the next run's earlier groups (HBM-bound beside VALU-bound)
+                const bool first = (int)gi == tail_gi_, last = gi + 1 == groups_.size();
+                if (first) {
+                    if (deferred_.pending) flush_deferred_tail(false);   // (a run whose earlier groups had no speculative EqThree launch: nothing opened a gate)
+                    hip_check(hipEventRecord(ev_head_done_, stream_), "hipEventRecord");
+                    if (tail_gate_ < 0) { const char* e = getenv("MX_TAIL_GATE"); tail_gate_ = e && atoi(e) == 0 ? 0 : 1; }   // A/B: 0 = launched at once (round 4's form)
+                    if (tail_gate_) { deferred_.items.clear(); deferred_.parity = parity_; deferred_.prof_begin = prof ? ev[groups_.size() + 2] : nullptr; tail_held_this_span_ = true; }
+                    else hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
                 }
-                hip_check(hipStreamWaitEvent(tail_stream_, ev_head_done_, 0), "hipStreamWaitEvent");
-                launch_mixer((const MixDesc*)desc_of(g), n, g.max_taps, gf, g.dup_mode, tail_stream_);
-                hip_check(hipEventRecord(ev_tail_done_[parity_], tail_stream_), "hipEventRecord");
-                tail_pending_[parity_] = true;
-                if (prof) hip_check(hipEventRecord(ev[gi + 1], tail_stream_), "hipEventRecord");
+                if (tail_gate_) {
+                    deferred_.items.push_back(TailLaunch{desc_of(g), n, g.max_taps, gf, g.dup_mode, prof ? ev[gi + 1] : nullptr});
+                    if (last) deferred_.pending = true;
+                } else {
+                    launch_mixer((const MixDesc*)desc_of(g), n, g.max_taps, gf, g.dup_mode, tail_stream_);
+                    if (prof) hip_check(hipEventRecord(ev[gi + 1], tail_stream_), "hipEventRecord");
+                    if (last) { hip_check(hipEventRecord(ev_tail_done_[parity_], tail_stream_), "hipEventRecord"); tail_pending_[parity_] = true; }
+                }
                 ++gi;
                 continue;
             }
@@ -1205,9 +1217,10 @@ uint32_t Graph::profile_collect(float* ms_by_kind, float* ms_total) {
             const bool recorded = i < groups_.size() ? group_launches(groups_[i]) : has_video_;
             if (!recorded) continue;
             float ms = 0.f;
-            if (held && (int)i == tail_gi_) {
-                // a tail launch that was held back ran on its own stream, inside the NEXT run's window: its own begin and end; the run's total ends where its stream's work did
-                hip_check(hipEventElapsedTime(&ms, ev[groups_.size() + 2], ev[i + 1]), "hipEventElapsedTime");
+            if (held && i < groups_.size() && (int)i >= tail_gi_) {
+                // a tail launch that was held back ran on its own stream, inside the NEXT run's window: its own begin (the tail's, or the tail group's before it) and end;
+                // the run's total ends where its stream's work did
+                hip_check(hipEventElapsedTime(&ms, (int)i == tail_gi_ ? ev[groups_.size() + 2] : ev[i], ev[i + 1]), "hipEventElapsedTime");
                 if (ms_by_kind) ms_by_kind[groups_[i].kind] += ms;
                 perf_group_ms_[i] = ms;
                 continue;
@@ -1415,7 +1428,7 @@ float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf, bool stream_
     if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]) * (spt_ * nodes_[node].dom_num / nodes_[node].dom_den);   // floats per TICK in the port's own rate domain
     // A consumer that takes the raw pointer of a bus reads it in stream order on stream(): a Mixer bank the library moved to the second stream ON ITS OWN (short submissions,
     // MX_OVERLAP_AUTO) would not be ordered before it -- so the automatism ends here, for good.  (A host that asked for MX_FLAG_OVERLAP_TAIL knows about mx_graph_tail_stream.)
-    if (stream_ordered_consumer && tail_gi_ >= 0 && tail_auto_ && nodes_[node].group == tail_gi_) { wait_tail(-1); tail_gi_ = -1; }
+    if (stream_ordered_consumer && tail_gi_ >= 0 && tail_auto_ && nodes_[node].group >= tail_gi_) { wait_tail(-1); tail_gi_ = -1; }
     return out_ptr(nodes_[node], port);
 }
 

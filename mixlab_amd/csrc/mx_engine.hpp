@@ -214,7 +214,7 @@ private:
     bool own_stream_ = false;
     DevBuf slab_;
     // MX_FLAG_OVERLAP_TAIL (see mixlab_gpu.h): the last launch group on a second stream, beside the next run's earlier groups
-    int tail_gi_ = -1;                    // index of that group in groups_, -1 = mode off
+    int tail_gi_ = -1;                    // index of the FIRST tail group in groups_ (every group from it on is a Mixer group), -1 = mode off
     bool eq_mode_warned_ = false;         // the grouping / descriptor mode mismatch was reported (build_descriptors)
     bool tail_auto_ = false;              // the mode was chosen by the library (short submissions), not asked for with MX_FLAG_OVERLAP_TAIL
     uint32_t parity_ = 0;                 // which buffer of the double-buffered ports the current / last run uses
@@ -229,7 +229,8 @@ private:
     // launch's last workgroup has started: the next run's k_env_ticks runs alone (beside a Mixer bank it took 140 us instead of 9 and the EqThree launch behind it started
     // when the bank was nearly done: no overlap at all), the EqThree workgroups are placed on an empty chip, and the Mixer's waves fill what is left.  Every join
     // (mx_graph_sync, read-backs, mx_graph_tail_stream, an exchange's submit, a cut run) releases a held launch at once.  MX_TAIL_GATE=0: launched at once as in round 4.
-    struct DeferredTail { bool pending = false; const void* desc = nullptr; uint32_t n = 0, max_ch = 0; size_t frames = 0; int dup_mode = 0; uint32_t parity = 0; hipEvent_t prof_ev = nullptr, prof_begin = nullptr; } deferred_;
+    struct TailLaunch { const void* desc = nullptr; uint32_t n = 0, max_ch = 0; size_t frames = 0; int dup_mode = 0; hipEvent_t prof_ev = nullptr; };
+    struct DeferredTail { bool pending = false; std::vector<TailLaunch> items; uint32_t parity = 0; hipEvent_t prof_begin = nullptr; } deferred_;   // the tail: every Mixer group from tail_gi_ on (a bank, or a bank and the buses above it), in order
     std::function<void(hipStream_t)> tail_hook_;
     std::vector<hipEvent_t> head_waits_;
     uint64_t n_gated_ = 0, n_at_once_ = 0;

@@ -222,3 +222,71 @@ print("ok gate-timeout")
     env = dict(os.environ, MX_EQ_SPEC_DIRECT="1")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and "ok gate-timeout" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_group_buses_the_tail_is_the_bank_and_the_master_above_it():
+    """Hierarchical mix (64 strips -> four group Mixers of 16 -> a master Mixer of 4): the tail is BOTH Mixer groups, held back together and released in order behind the
+    next run's EqThree launch.  Master, cue and the four group buses of every run against the oracle ticked, read back one run later on the tail stream where only
+    gated banks can be seen (flag mode), and directly (automatic mode)."""
+    import ctypes as C
+    from mixlab_amd.workspace import Workspace
+    n_groups, per, batch, n_runs = 4, 16, 16, 5
+    n_strips = n_groups * per
+    ws = Workspace(SR, 60)
+    gains = synth.uniform(10, 3 * n_strips, -24.0, 6.0)
+    master = ws.mixer([(-1.0 * j, 0.9, j % 2 == 0) for j in range(n_groups)])
+    gms = [ws.mixer([(-0.5 * k, 1.0 - 0.02 * k, k % 5 == 0) for k in range(per)]) for _ in range(n_groups)]
+    srcs, trigs = [], []
+    for k in range(n_strips):
+        trig = ws.trigger(False); env = ws.envelope(); src = ws.source_mono()
+        eq = ws.eq_three(float(gains[3 * k]), float(gains[3 * k + 1]), float(gains[3 * k + 2])); pan = ws.stereo_panner(); amp = ws.amplifier(1.0, 0.5)
+        ws.connect(trig, 0, env, 0); ws.connect(src, 0, eq, 0); ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1)
+        ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1); ws.connect(amp, 0, gms[k // per], k % per)
+        srcs.append(src); trigs.append(trig)
+    for j, gm in enumerate(gms):
+        ws.connect(gm, 0, master, j)
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    og = oracle.OracleGraph(ws)
+    want = []
+    for r in range(n_runs):
+        acc = {"m": [], "c": [], "g": [[] for _ in gms]}
+        for kk in range(batch):
+            tick = r * batch + kk
+            for k, tr in enumerate(trigs):
+                og.update_params(tr, abi.TriggerParams(1 if gate_open(tick, k) else 0))
+            for k, s in enumerate(srcs):
+                og.set_source(s, noise[k][tick * SPT:(tick + 1) * SPT])
+            og.run_tick(tick)
+            acc["m"].append(og.output(master, 0).copy()); acc["c"].append(og.output(master, 1).copy())
+            for j, gm in enumerate(gms):
+                acc["g"][j].append(og.output(gm, 0).copy())
+        want.append((np.concatenate(acc["m"]), np.concatenate(acc["c"]), [np.concatenate(x) for x in acc["g"]]))
+    hip = C.CDLL("libamdhip64.so")
+    for flags in (abi.FLAG_OVERLAP_TAIL, 0):
+        g = ws.build(max_ticks_per_run=batch, flags=flags)
+        tail = g.tail_stream()
+        assert tail is not None
+        if flags:
+            pm, fpt = g.output_device_ptr(master, 0)
+            pg = [g.output_device_ptr(gm, 0)[0] for gm in gms]
+            nfl = fpt * batch
+            got = np.empty(nfl, np.float32)
+        for r in range(n_runs):
+            schedule_gates(g, trigs, r * batch, batch)
+            for k, s in enumerate(srcs):
+                g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+            g.run_ticks(r * batch, batch)
+            if flags and r >= 1:                      # the banks of run r - 1, released by run r, on the tail stream
+                for ptr, w, what in [(pm, want[r - 1][0], "master")] + [(pg[j], want[r - 1][2][j], f"group bus {j}") for j in range(n_groups)]:
+                    assert hip.hipMemcpyAsync(got.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nfl * 4), 2, C.c_void_p(tail)) == 0
+                    assert hip.hipStreamSynchronize(C.c_void_p(tail)) == 0
+                    assert_bit_exact(got, w, f"{what} of run {r - 1}, released by run {r}")
+            if not flags and r in (1, 3):
+                assert_bit_exact(g.read_output(master, 0, batch, True), want[r][0], f"master of run {r}")
+                assert_bit_exact(g.read_output(gms[2], 0, batch, True), want[r][2][2], f"group bus 2 of run {r}")
+        assert_bit_exact(g.read_output(master, 0, batch, True), want[-1][0], "master of the last run")
+        assert_bit_exact(g.read_output(master, 1, batch, True), want[-1][1], "cue of the last run")
+        for j, gm in enumerate(gms):
+            assert_bit_exact(g.read_output(gm, 0, batch, True), want[-1][2][j], f"group bus {j} of the last run")
+        gated, at_once = g.debug_tail_releases()
+        assert gated >= 2, (gated, at_once)
