@@ -19,6 +19,27 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+def bus_strips(n_strips, n_groups):
+    """config-2 strips into n_groups group Mixers, those into a master Mixer(n_groups); -> ws, master, sources, triggers, first EqThree node"""
+    from mixlab_amd.workspace import Workspace
+    per = n_strips // n_groups
+    ws = Workspace(SR, 60)
+    gains = synth.uniform(10, 3 * n_strips, -24.0, 6.0)
+    master = ws.mixer([(-1.0 * j, 1.0 - 0.1 * j, j % 2 == 0) for j in range(n_groups)])
+    gms = [ws.mixer([(-0.5 * k, 1.0 - 0.01 * k, k % 5 == 0) for k in range(per)]) for _ in range(n_groups)]
+    srcs, trigs, eq0 = [], [], None
+    for k in range(per * n_groups):
+        trig = ws.trigger(False); env = ws.envelope(); src = ws.source_mono()
+        eq = ws.eq_three(float(gains[3 * k]), float(gains[3 * k + 1]), float(gains[3 * k + 2])); pan = ws.stereo_panner(); amp = ws.amplifier(1.0, 0.5)
+        eq0 = eq if eq0 is None else eq0
+        ws.connect(trig, 0, env, 0); ws.connect(src, 0, eq, 0); ws.connect(eq, 0, pan, 0); ws.connect(eq, 0, pan, 1)
+        ws.connect(pan, 0, amp, 0); ws.connect(env, 0, amp, 1); ws.connect(amp, 0, gms[k // per], k % per)
+        srcs.append(src); trigs.append(trig)
+    for j, gm in enumerate(gms):
+        ws.connect(gm, 0, master, j)
+    return ws, master, srcs, trigs, eq0
+
+
 def scenario(seed):
     rng = np.random.default_rng(seed)
     n_strips = int(rng.choice([64, 72, 96]))
@@ -28,8 +49,12 @@ def scenario(seed):
     use_flag = bool(rng.integers(0, 2))
     lens = [int(rng.choice([1, 3, 16, max_ticks, max_ticks, int(rng.integers(16, max_ticks + 1))])) for _ in range(n_runs)]
     total = sum(lens)
-    ws, mix, srcs, trigs = strips(n_strips, SR)
-    eq0 = mix + 4
+    if rng.random() < 0.4:            # group buses: the tail is the bank of group Mixers AND the master above it
+        ws, mix, srcs, trigs, eq0 = bus_strips(n_strips, int(rng.choice([2, 4, 8])))
+    else:
+        ws, mix, srcs, trigs = strips(n_strips, SR)
+        eq0 = mix + 4
+    n_strips = len(srcs)
     noise = [synth.noise(1000 * (seed % 97) + k, total * SPT) for k in range(n_strips)]
     cuts = {}                                           # run -> (tick in run, params)
     for r in range(n_runs):
