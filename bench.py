@@ -904,6 +904,7 @@ def main():
     ap.add_argument("--ticks-per-step", type=int, default=2048, help="ticks batched per submission (SURVEY 8d: throughput mode; 1 = real-time mode)")
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--eq-fast", action="store_true", help="MX_FLAG_EQ_FAST: the time-parallel EqThree scan (<= 1 ULP, NOT bit-exact) instead of the exact default")
+    ap.add_argument("--no-buses-leg", action="store_true", help="skip the group-bus topology leg (8 x Mixer(strips / 8) -> Mixer(8))")
     ap.add_argument("--no-one-stream-leg", action="store_true", help="skip the MX_OVERLAP_AUTO=0 leg (each kernel alone on the chip) that the roofline block quotes")
     ap.add_argument("--overlap-tail", action="store_true",
                     help="MX_FLAG_OVERLAP_TAIL: the Mixer bank of step k on a second stream beside step k + 1's EqThree group (measured SLOWER: 6.53 vs 6.00 ms per step, DESIGN.md 5.2)")
@@ -1190,6 +1191,45 @@ def main():
                 dist.broadcast_object_list(box, src=0)
             return box[0]
         other_policy = scaled_ticks_leg(torch, dist, np, synth, abi, shard, Workspace, args, rank, world, local_rank, stream, fresh_id, toggling)
+
+    # The same strips mixed through GROUP BUSES (8 x Mixer(strips / 8) -> Mixer(8)): a topology the reference expresses with its own Mixer module, and the shape a console
+    # has.  The second-stream mode takes the bank AND the master above it as its tail.  Own graphs over the headline graph's resident sources; not `value`.
+    buses_leg = None
+    if not use_dist and not args.no_buses_leg and not args.no_fuse and args.strips % 8 == 0:
+        with torch.cuda.stream(stream):
+            buses_leg = {}
+            for label, auto in (("second_stream", True), ("one_stream", False)):
+                if auto:
+                    os.environ.pop("MX_OVERLAP_AUTO", None)
+                else:
+                    os.environ["MX_OVERLAP_AUTO"] = "0"
+                try:
+                    wsb = Workspace(SR, 60); gm, sb, tb = [], [], []
+                    for j in range(8):
+                        wsb, m_, s_, t_ = build_strips(abi, Workspace, synth, args.strips // 8, j * (args.strips // 8), SR, ws=wsb, total=args.strips, want_trigs=True)
+                        gm.append(m_); sb += s_; tb += t_
+                    master = wsb.mixer([(0.0, 1.0, False)] * 8)
+                    for j, m_ in enumerate(gm):
+                        wsb.connect(m_, 0, master, j)
+                    gb = wsb.build(max_ticks_per_run=T, flags=flags & ~abi.FLAG_OVERLAP_TAIL, device=local_rank, stream=stream.cuda_stream)
+                finally:
+                    os.environ.pop("MX_OVERLAP_AUTO", None)
+                for sn_b, sn in zip(sb, srcs):
+                    gb.bind_source_device(sn_b, g.output_device_ptr(sn, 0)[0])
+                kb = min(args.steps, 8)
+                evb = [gate_events(abi, tb, 0, i * T, T) if toggling else None for i in range(2 + kb)]
+                for i in range(2 + kb):
+                    if i == 2:
+                        gb.sync(); tb0 = time.perf_counter()
+                    if evb[i] is not None:
+                        gb.schedule_params_batch(evb[i][0], evb[i][1])
+                    gb.run_ticks(i * T, T)
+                gb.sync()
+                dtb = (time.perf_counter() - tb0) / kb
+                buses_leg[label] = {"ms_per_step": round(dtb * 1e3, 4), "value": args.strips * T / dtb, "unit": "channel-ticks/s", "steps": kb,
+                                    "mixer_groups_beside_next_eq_three": gb.tail_stream() is not None}
+                gb.close()
+            buses_leg["topology"] = f"8 x Mixer({args.strips // 8}) -> Mixer(8, unity), {T} ticks per step, gates as in the headline"
 
     # real-time regime: one 60 Hz tick per submission, synchronised every tick like a live engine
     realtime = None
@@ -1479,6 +1519,7 @@ def main():
             "scaled_ticks": other_policy,
             "realtime": realtime,
             "t_sweep": t_sweep,
+            "group_buses": buses_leg,
             "rate_44100": rate_leg,
             "material": material,
             "scaling_model": scaling,

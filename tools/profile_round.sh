@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-realtime --no-t-sweep --no-north-star --no-held-leg --no-material-leg --no-rate-leg --no-contract-leg --no-scaling-probe --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 0"
+COMMON="--no-cpu-baseline --no-realtime --no-buses-leg --no-one-stream-leg --no-t-sweep --no-north-star --no-held-leg --no-material-leg --no-rate-leg --no-contract-leg --no-scaling-probe --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 0"
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
 pmc() {   # pmc <tag> <counters...> -- <command...>: one counter pass, summary into $OUT/<tag>.txt, raw csv path echoed
   local tag=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
