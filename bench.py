@@ -895,7 +895,17 @@ def _cpu_model():
     return "unknown"
 
 
+_RESULT_FD = None
+
+
 def main():
+    # stdout carries the result line and nothing else: file descriptor 1 is pointed at stderr for the whole run (libraries print banners from C code, past sys.stdout)
+    # and the line is written to the original descriptor at the end
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -1545,7 +1555,9 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(json.dumps(out), flush=True)
+        # the ONE line of this program's stdout (everything else any library prints while it runs -- RCCL's version banner, for one -- went to stderr: see main())
+        sys.stdout.flush()
+        os.write(_RESULT_FD if _RESULT_FD is not None else 1, (json.dumps(out) + "\n").encode())
 
     if use_dist:
         dist.destroy_process_group()

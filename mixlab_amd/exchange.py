@@ -41,10 +41,32 @@ _proto("mx_exchange_sync", C.c_int, C.c_void_p)
 _proto("mx_exchange_get_info", C.c_int, C.c_void_p, C.POINTER(ExchangeInfo))
 
 
+class _rccl_banner_to_stderr:
+    """RCCL prints a version banner ("RCCL version : ...", five lines) on the PROCESS's stdout when its first communicator comes up.  A program whose stdout is its
+    result -- bench.py prints one JSON line -- must not carry it: while RCCL initialises, file descriptor 1 points at stderr (C stdio flushed on both sides)."""
+
+    def __enter__(self):
+        import os, sys
+        self._os = os
+        sys.stdout.flush()
+        self._libc = C.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        self._os.dup2(self._saved, 1)
+        self._os.close(self._saved)
+        return False
+
+
 def unique_id() -> bytes:
     """ncclGetUniqueId: made on rank 0, handed to every rank's BusExchange."""
     buf = C.create_string_buffer(ID_BYTES)
-    check(lib.mx_exchange_unique_id(buf))
+    with _rccl_banner_to_stderr():
+        check(lib.mx_exchange_unique_id(buf))
     return buf.raw
 
 
@@ -79,8 +101,9 @@ class BusExchange:
         self._h = C.c_void_p()
         self._graph, self._grp = graph, loopback            # the library requires both to outlive the exchange
         idbuf = C.create_string_buffer(nccl_id, ID_BYTES) if nccl_id is not None else None
-        check(lib.mx_exchange_create(graph._h, mix, n_ticks, rank, world, idbuf, loopback._h if loopback is not None else None,
-                                     MODES.index(mode), C.byref(self._h)))
+        with _rccl_banner_to_stderr():
+            check(lib.mx_exchange_create(graph._h, mix, n_ticks, rank, world, idbuf, loopback._h if loopback is not None else None,
+                                         MODES.index(mode), C.byref(self._h)))
         info = ExchangeInfo()
         check(lib.mx_exchange_get_info(self._h, C.byref(info)))
         self.mode, self.rank, self.world = MODES[info.mode], info.rank, info.world
