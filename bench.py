@@ -1308,9 +1308,10 @@ def main():
             for Ts in (64, 256, 1024):
                 if Ts >= T:
                     continue
-                t_sweep[str(Ts)] = sweep(Ts, 12 if Ts >= 512 else 60, True)
+                # (enough submissions for the steady state: the first few dozen of a new graph are slower -- first-use allocations, the clock settling)
+                t_sweep[str(Ts)] = sweep(Ts, {64: 480, 256: 160}.get(Ts, 40), True)
             if "64" in t_sweep and t_sweep["64"]["mixer_beside_next_eq_three"]:
-                t_sweep["64_one_stream"] = dict(sweep(64, 60, False), note="MX_OVERLAP_AUTO=0: the same submissions with every launch group on one stream (round 4's default)")
+                t_sweep["64_one_stream"] = dict(sweep(64, 480, False), note="MX_OVERLAP_AUTO=0: the same submissions with every launch group on one stream (round 4's default)")
 
     # the same job at the reference's own sample rate (config 2 is written for 48 kHz; the reference runs at 44.1 kHz)
     rate_leg = None
