@@ -131,9 +131,11 @@ typedef struct { uint32_t src_node, src_port, dst_node, dst_port; } mx_edge;  /*
                                   mx_graph_tail_stream() AFTER the run it wants and orders itself after the stream it returns.
                                   WITHOUT the flag the library takes this mode on its own for graphs with at least 64 EqThree instances built for submissions of
                                   at least 16 ticks (runs of fewer ticks stay on one stream), while the second buffers fit (MX_OVERLAP_AUTO_MAX_GB, default 32, and
-                                  a quarter of the free device memory) and only while nobody holds a raw pointer to the tail's outputs:
-                                  mx_graph_output_device_ptr of such a port (and an mx_exchange over it) ends the automatism for that graph, so stream-ordered
-                                  consumers of the buses see one-stream ordering as before.  1024 strips x 2048 ticks: 5.3 -> 4.8 ms per run.
+                                  a quarter of the free device memory) and only while no HOST holds a raw pointer the mode would not keep fresh:
+                                  mx_graph_output_device_ptr of one of the tail's outputs, or of a port the tail reads (double-buffered in this mode), ends the
+                                  automatism for that graph for good -- everything outstanding completes, the last run's data is where the pointer says, and from
+                                  then on the graph is a one-stream graph (stream-ordered consumers see one-stream ordering as before).  An mx_exchange over a bus
+                                  does NOT end it: the exchange orders itself behind the bank on whichever stream it runs.  1024 strips x 2048 ticks: 5.3 -> 4.8 ms per run.
                                   MX_OVERLAP_AUTO=0 (environment) turns it off. */
 #define MX_FLAG_NO_FUSE 2u   /* materialise every port.  By default the graph compiler folds EqThree -> StereoPanner(L = R)
                                 [-> Amplifier [<- Envelope <- Trigger]] into the EQ kernel, a single-consumer Trigger into

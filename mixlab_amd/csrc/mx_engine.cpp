@@ -380,9 +380,11 @@ void Graph::flush_deferred_tail(bool gated) {
         if (t.prof_ev) hip_check(hipEventRecord(t.prof_ev, tail_stream_), "hipEventRecord");
     }
     deferred_.items.clear();
+    if (tail_hook_) { auto hook = std::move(tail_hook_); tail_hook_ = nullptr; hook(tail_stream_); }   // (mx_exchange: pack + exchange of that run's buses, behind the bank)
+    // recorded AFTER the hook: whoever waits for this tail (wait_tail) is then also ordered behind the hook's reads of the buses on the tail stream -- a later run's Mixer on
+    // stream_ must not overwrite them under a pack that is still copying
     hip_check(hipEventRecord(ev_tail_done_[deferred_.parity], tail_stream_), "hipEventRecord");
     tail_pending_[deferred_.parity] = true;
-    if (tail_hook_) { auto hook = std::move(tail_hook_); tail_hook_ = nullptr; hook(tail_stream_); }   // (mx_exchange: pack + exchange of that run's buses, behind the bank)
 }
 
 void Graph::wait_tail(int parity_or_all) {
@@ -392,6 +394,29 @@ void Graph::wait_tail(int parity_or_all) {
             hip_check(hipStreamWaitEvent(stream_, ev_tail_done_[p], 0), "hipStreamWaitEvent");
             tail_pending_[p] = false;
         }
+}
+
+// The automatic second-stream mode ends, for good.  Everything outstanding completes; the double-buffered ports go back to their FIRST buffer (the last run's data moves
+// there when it sits in the second), the second set of descriptors is dropped and the first rebuilt -- from here on the graph is a one-stream graph in every respect
+// (update_params, cut runs and ensure_capacity touch the only descriptors there are).
+void Graph::end_auto_tail() {
+    if (tail_gi_ < 0) return;
+    sync();
+    for (Node& n : nodes_)
+        for (size_t k = 0; k < n.out_type.size(); ++k) {
+            if (n.out_off2[k] == SIZE_MAX) continue;
+            if (parity_ && n.out_off[k] != SIZE_MAX) {
+                const size_t fl = (n.out_dup[k] ? 1 : floats_per_frame(n.out_type[k])) * (cap_frames_ * n.dom_num / n.dom_den + 1);
+                hip_check(hipMemcpyAsync((float*)slab_.p + n.out_off[k], (const float*)slab_.p + n.out_off2[k], fl * sizeof(float), hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(D2D)");
+            }
+            n.out_off2[k] = SIZE_MAX;
+        }
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    tail_gi_ = -1;
+    parity_ = 0;
+    overlap_this_run_ = false;
+    for (Group& g : groups_) { g.desc_alt.free_(); g.extra_alt.free_(); }
+    build_descriptors();
 }
 
 Graph::~Graph() {
@@ -1096,7 +1121,8 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                         if (!gate_flag_.p) { gate_flag_.alloc(64); hip_check(hipMemset(gate_flag_.p, 0, 64), "hipMemset"); }
                         r.started = (uint32_t*)gate_flag_.p; r.started_seq = ++gate_seq_; gate_armed_ = true;
                     }
-                    launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
+                    const bool opens_gate = launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
+                    if (!opens_gate) gate_armed_ = false;                 // the direct form never stores the flag: a gate would spin to its time limit before the bank starts
                     if (deferred_.pending) flush_deferred_tail(true);     // run k's Mixer bank: behind the gate this launch opens
                 } else {
                     void* scratch = nullptr;
@@ -1428,7 +1454,8 @@ float* Graph::output_ptr(uint32_t node, uint32_t port, size_t* fpf, bool stream_
     if (fpf) *fpf = floats_per_frame(nodes_[node].out_type[port]) * (spt_ * nodes_[node].dom_num / nodes_[node].dom_den);   // floats per TICK in the port's own rate domain
     // A consumer that takes the raw pointer of a bus reads it in stream order on stream(): a Mixer bank the library moved to the second stream ON ITS OWN (short submissions,
     // MX_OVERLAP_AUTO) would not be ordered before it -- so the automatism ends here, for good.  (A host that asked for MX_FLAG_OVERLAP_TAIL knows about mx_graph_tail_stream.)
-    if (stream_ordered_consumer && tail_gi_ >= 0 && tail_auto_ && nodes_[node].group >= tail_gi_) { wait_tail(-1); tail_gi_ = -1; }
+    // The same holds for a port the tail READS: it is double-buffered while the mode is on, and a raw pointer would see fresh data only every other run.
+    if (stream_ordered_consumer && tail_gi_ >= 0 && tail_auto_ && (nodes_[node].group >= tail_gi_ || nodes_[node].out_off2[port] != SIZE_MAX)) end_auto_tail();
     return out_ptr(nodes_[node], port);
 }
 

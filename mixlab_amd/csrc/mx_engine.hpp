@@ -5,6 +5,7 @@
 // keeps every port buffer resident in one HBM slab, batches all instances of a module kind at one
 // dependency level into one launch, and runs n_ticks ticks per submission.
 #pragma once
+#include <algorithm>
 #include <functional>
 #include <hip/hip_runtime.h>
 
@@ -153,7 +154,7 @@ public:
     // released: they normally end inside run k + 1's EqThree launch; when the bank outlasts that launch they would run into run k + 2's EqThree workgroups being placed --
     // thousands of small workgroups around which the dispatcher places those unevenly (every other launch 6.1 instead of 4.7 ms, rocprofv3 --kernel-trace).
     void wait_before_next_run(hipEvent_t ev) { head_waits_.push_back(ev); }
-    void forget_waits_before_next_run() { head_waits_.clear(); }   // (their owner is going away: its events with it)
+    void forget_wait_before_next_run(hipEvent_t ev) { head_waits_.erase(std::remove(head_waits_.begin(), head_waits_.end(), ev), head_waits_.end()); }   // (its owner is going away; other owners' waits stay)
     int read_plotter(uint32_t node, uint32_t call, float* left, float* right);
     void ensure_capacity(size_t frames);   // module compat path: grow the slab (state is kept)
     // topology edit (client_update, src/engine.rs:277-398): modules persist while the connection set changes.
@@ -237,6 +238,7 @@ private:
     bool tail_held_this_span_ = false; std::vector<bool> prof_runs_held_;   // parallel to prof_runs_: that run's tail launch was held back (its events sit on the tail stream)
     DevBuf gate_flag_; uint32_t gate_seq_ = 0; bool gate_armed_ = false; int tail_gate_ = -1;
     void flush_deferred_tail(bool gated);
+    void end_auto_tail();                 // the library-chosen second-stream mode ends for good (a host took a raw pointer that mode would not keep fresh)
     void wait_tail(int parity_or_all);    // stream_ waits for the tail launches that have not been waited for (-1: both)
     DevBuf& desc_buf(Group& g) { return building_alt_ ? g.desc_alt : g.desc; }
     DevBuf& extra_buf(Group& g) { return (building_alt_ && g.kind == MX_KIND_MIXER) ? g.extra_alt : g.extra; }

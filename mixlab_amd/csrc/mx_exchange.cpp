@@ -140,7 +140,7 @@ Exchange::Exchange(Graph& g, uint32_t mix, uint32_t n_ticks, uint32_t rank, uint
 void Exchange::destroy() noexcept {
     (void)hipSetDevice(device_);
     if (held_) { try { ensure_submitted(); } catch (...) {} }
-    if (graph_) { graph_->set_tail_hook(nullptr); graph_->forget_waits_before_next_run(); }
+    if (graph_) { graph_->set_tail_hook(nullptr); for (Slot& sl : slots_) if (sl.done) graph_->forget_wait_before_next_run(sl.done); }
     if (cs_) (void)hipStreamSynchronize(cs_);
     if (lb_ && joined_ && rank_ < lb_->members.size() && lb_->members[rank_] == this) {
         // peers may still be reading this member's buffers
@@ -206,7 +206,6 @@ Exchange::Slot& Exchange::slot_of(uint64_t step, const char* what) {
 
 void Exchange::submit(uint64_t step) {
     hip_check(hipSetDevice(device_), "hipSetDevice");
-    Slot& sl = slots_[step & 1];
     if (lb_) {   // everything that can be refused is refused BEFORE the slot or the group's bookkeeping is touched: a refused submit leaves the group usable
         if (lb_->arrived[rank_] != lb_->completed) throw Error(MX_ERR_INVALID, "loopback: this rank already submitted a step the other ranks have not submitted yet");
         for (Exchange* q : lb_->members) if (!q) throw Error(MX_ERR_INVALID, "loopback: not every rank of the group has been created");

@@ -1458,8 +1458,8 @@ int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl) {
     return mode * 2 + stereo;
 }
 
-void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r_in, const EqSpecPlan& plan_in, int uniform_mode, void* scratch, uint64_t* stats, hipStream_t s) {
-    if (!n || !r_in.frames) return;
+bool launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r_in, const EqSpecPlan& plan_in, int uniform_mode, void* scratch, uint64_t* stats, hipStream_t s) {
+    if (!n || !r_in.frames) return false;
     // A stream that is not whole pieces of four samples (735 t frames at 44.1 kHz with t not a multiple of 4): the tiled kernel runs the frames up to the last
     // multiple of four, and the proof / repair kernel -- which ends up holding the exact state there -- walks the one to three samples left (`tail`).
     EqRun r = r_in; EqSpecPlan plan = plan_in;
@@ -1476,7 +1476,7 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     // treated as having ended apart from the speculative run (the in-order fallback that rewrites everything behind it).  Both paths are otherwise reached
     // only by inputs whose f32 outputs differ between two states a few f64 ulps apart.
     EqSpecPlan plan_t = plan; plan_t.pad = (uint32_t)env_int("MX_EQ_REPAIR_TEST", 0);
-    static const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere
+    const int no_tiles = env_int("MX_EQ_SPEC_DIRECT", 0);   // A/B: the direct (16 bytes per lane) form everywhere (read per launch: tests switch it inside one process)
     const int um = uniform_mode;
     // 321: whole 128-byte lines, ONE tile of 32 samples per row (8 KiB of LDS per wave); 16: half lines, two tiles (round 3's default:
     // 1.44x the source bytes on the fabric, tools/fetch_probe.hip); 32: whole lines, two tiles (16 KiB: ten waves per CU).  Measured, 1024 strips x
@@ -1544,6 +1544,7 @@ void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun&
     plan_t.n_chunks = plan.n_chunks;
     if (r.fc) hipLaunchKernelGGL(k_eq_three_repair<true>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats, tail);
     else hipLaunchKernelGGL(k_eq_three_repair<false>, dim3(n), dim3(64), 0, s, d, st, r, plan_t, (const EqChunkRec*)recs, (unsigned long long*)stats, tail);
+    return tiled;   // only the tiled kernel stores r.started (the flag k_tail_gate waits for)
 }
 
 }  // namespace mx

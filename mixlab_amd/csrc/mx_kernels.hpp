@@ -122,7 +122,7 @@ size_t eq_spec_scratch_bytes(uint32_t n, const EqSpecPlan& plan);
 // one wave that leaves when *flag has reached seq (or after limit_us): a launch queued behind it on its stream starts once the kernel that stores the flag has been placed
 void launch_tail_gate(const uint32_t* flag, uint32_t seq, uint32_t limit_us, hipStream_t s);
 int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl);   // 0..7: (epilogue kind) * 2 + (stereo store); the specialisation key
-void launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode /* 0..7, or -1: mixed */,
+bool launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode /* 0..7, or -1: mixed */,
                           void* scratch, uint64_t* stats /* [2]: chunks run, chunks repaired */, hipStream_t s);
 void eq_plan_split(uint32_t n, size_t frames, double lo_f, double hi_f, EqSplit& sp);
 void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);

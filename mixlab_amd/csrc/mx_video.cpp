@@ -626,8 +626,9 @@ FrameRef Scaler::scale_keep(const FrameRef& in0) {
     if (in.f != in0.f && in->width == out_w_ && in->height == out_h_ && in->fmt == MX_PIXFMT_YUV420P) return in;
     if (!frame_ || in_w_ != in->width || in_h_ != in->height || in_fmt_ != in->fmt || in_alpha_ != in->with_alpha) retarget(in->width, in->height, in->fmt, in->with_alpha);
     FrameRef out;
-    for (auto& f : keep_pool_) if (f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }   // only the pool holds it
-    if (!out) { keep_pool_.push_back(FrameRef(DFrame::create(out_w_, out_h_, stream_), false)); out = keep_pool_.back(); }
+    // (a layer that carries coverage keeps it through this path too: pool frames are made like retarget()'s ring frames, with a coverage plane when the input has one)
+    for (auto& f : keep_pool_) if (f->with_alpha == in_alpha_ && f->rc.load(std::memory_order_acquire) == 1) { out = f; break; }   // only the pool holds it
+    if (!out) { keep_pool_.push_back(FrameRef(DFrame::create(out_w_, out_h_, stream_, MX_PIXFMT_YUV420P, in_alpha_), false)); out = keep_pool_.back(); }
     if (t_->geo.scaled_w == 0 || t_->geo.scaled_h == 0) return out;
     scale_into(in, t_, out, tmp_plane_, stream_);
     return out;

@@ -290,3 +290,86 @@ def test_group_buses_the_tail_is_the_bank_and_the_master_above_it():
             assert_bit_exact(g.read_output(gm, 0, batch, True), want[-1][2][j], f"group bus {j} of the last run")
         gated, at_once = g.debug_tail_releases()
         assert gated >= 2, (gated, at_once)
+
+
+@pytest.mark.parametrize("runs_before", [1, 2], ids=["odd-parity", "even-parity"])
+@pytest.mark.parametrize("what", ["bus", "strip-port"])
+def test_taking_a_raw_pointer_ends_the_automatism_and_leaves_a_one_stream_graph(runs_before, what):
+    """The automatic mode ends when a host takes mx_graph_output_device_ptr of a bus (the tail's output) or of a port the tail reads (double-buffered while the mode is on).
+    From then on the graph is a one-stream graph in EVERY respect: after an odd number of overlapped runs (the ports at their second buffer) a parameter update, a run cut
+    by a scheduled update and later runs still land in the descriptors the kernels read, the pointer names the buffer that holds the last run, and it stays fresh."""
+    n_strips, batch, n_runs = 64, 16, runs_before + 3
+    flags = abi.FLAG_NO_FUSE if what == "strip-port" else 0       # (fused, a strip port is stored one float per frame and has no public pointer)
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    eq0, amp0 = mix + 4, mix + 6
+    assert ws.nodes[eq0][0] == abi.KIND_EQ_THREE and ws.nodes[amp0][0] == abi.KIND_AMPLIFIER
+    new_eq = abi.EqThreeParams(-6.0, 3.0, 1.5)
+    upd_tick = runs_before * batch                                # update_params between two runs, right after the pointer was taken
+    cut_eq, cut_tick = abi.EqThreeParams(2.0, -4.0, 0.5), (runs_before + 1) * batch + 5     # and a run cut by a scheduled update after that
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    og = oracle.OracleGraph(ws)
+    want, want_amp = [], []
+    for r in range(n_runs):
+        m, c, a = [], [], []
+        for kk in range(batch):
+            tick = r * batch + kk
+            if tick == upd_tick:
+                og.update_params(eq0, new_eq)
+            if tick == cut_tick:
+                og.update_params(eq0, cut_eq)
+            for k, tr in enumerate(trigs):
+                og.update_params(tr, abi.TriggerParams(1 if gate_open(tick, k) else 0))
+            for k, s in enumerate(srcs):
+                og.set_source(s, noise[k][tick * SPT:(tick + 1) * SPT])
+            og.run_tick(tick)
+            m.append(og.output(mix, 0).copy()); c.append(og.output(mix, 1).copy()); a.append(og.output(amp0, 0).copy())
+        want.append((np.concatenate(m), np.concatenate(c))); want_amp.append(np.concatenate(a))
+    g = ws.build(max_ticks_per_run=batch, flags=flags)
+    assert g.tail_stream() is not None                            # automatic mode
+    hip = C.CDLL("libamdhip64.so")
+    ptr = n_fl = None
+
+    def peek():                                                   # what a stream-ordered consumer on the graph's stream sees behind the raw pointer
+        g.sync()
+        buf = np.empty(n_fl, np.float32)
+        assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(n_fl * 4), 2) == 0
+        return buf
+
+    for r in range(n_runs):
+        schedule_gates(g, trigs, r * batch, batch)
+        if r == runs_before + 1:
+            g.schedule_params(eq0, cut_tick - r * batch, cut_eq)
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+        g.run_ticks(r * batch, batch)
+        if r == runs_before - 1:
+            ptr, fpt = g.output_device_ptr(mix if what == "bus" else amp0, 0)
+            n_fl = fpt * batch
+            assert g.tail_stream() is None                        # the automatism ended, for good
+            assert_bit_exact(peek(), want[r][0] if what == "bus" else want_amp[r], f"behind the pointer right after it was taken (run {r})")
+            g.update_params(eq0, new_eq)
+        elif ptr is not None:
+            assert g.output_device_ptr(mix if what == "bus" else amp0, 0)[0] == ptr     # it does not move any more
+            assert_bit_exact(peek(), want[r][0] if what == "bus" else want_amp[r], f"behind the pointer after run {r}")
+        assert_bit_exact(g.read_output(mix, 0, batch, True), want[r][0], f"master of run {r}")
+        assert_bit_exact(g.read_output(mix, 1, batch, True), want[r][1], f"cue of run {r}")
+
+
+def test_a_direct_form_eq_three_launch_does_not_arm_a_gate(monkeypatch):
+    """Only the tiled speculative kernel stores the flag k_tail_gate waits for.  Where the planner takes the direct form (MX_EQ_SPEC_DIRECT here; mixed-mode groups and short
+    ragged ticks in the field) the held-back bank is released at once instead of spinning to the gate's 300 us limit -- and the results stand."""
+    n_strips, batch, n_runs = 64, 16, 4
+    ws, mix, srcs, trigs = strips(n_strips, SR)
+    noise = [synth.noise(k, n_runs * batch * SPT) for k in range(n_strips)]
+    want = oracle_runs(ws, mix, srcs, trigs, noise, n_runs, batch)
+    monkeypatch.setenv("MX_EQ_SPEC_DIRECT", "1")
+    g = ws.build(max_ticks_per_run=batch)
+    assert g.tail_stream() is not None
+    for r in range(n_runs):
+        schedule_gates(g, trigs, r * batch, batch)
+        for k, s in enumerate(srcs):
+            g.write_source(s, noise[k][r * batch * SPT:(r + 1) * batch * SPT], batch)
+        g.run_ticks(r * batch, batch)
+    assert_bit_exact(g.read_output(mix, 0, batch, True), want[-1][0], "master of the last run")
+    gated, at_once = g.debug_tail_releases()
+    assert gated == 0 and at_once >= n_runs - 1, (gated, at_once)
