@@ -1122,7 +1122,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
                         r.started = (uint32_t*)gate_flag_.p; r.started_seq = ++gate_seq_; gate_armed_ = true;
                     }
                     const bool opens_gate = launch_eq_three_spec((const EqDesc*)desc_of(g), (EqState*)g.state.p, n, r, plan, g.eq_mode, g.spec.p, (uint64_t*)eq_stats_.p, stream_);
-                    if (!opens_gate) gate_armed_ = false;                 // the direct form never stores the flag: a gate would spin to its time limit before the bank starts
+                    if (!opens_gate && !(getenv("MX_TAIL_GATE_TEST") && atoi(getenv("MX_TAIL_GATE_TEST")))) gate_armed_ = false;   // the direct form never stores the flag: a gate would spin to its time limit before the bank starts (MX_TAIL_GATE_TEST: tests of that bounded spin)
                     if (deferred_.pending) flush_deferred_tail(true);     // run k's Mixer bank: behind the gate this launch opens
                 } else {
                     void* scratch = nullptr;

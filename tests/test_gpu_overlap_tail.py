@@ -185,8 +185,8 @@ def test_per_group_times_with_a_held_back_bank():
 
 def test_a_gate_that_nobody_opens_times_out_and_the_results_stand():
     """The gate is an ordering hint, never a dependency: with the speculative EqThree launch in its direct form (MX_EQ_SPEC_DIRECT: a kernel that does not store the
-    flag) every held-back bank goes behind a gate that only its bounded spin (300 us) opens.  Same buses, bit for bit.  In a process of its own: the launcher reads
-    that override once."""
+    flag) and the gate armed all the same (MX_TAIL_GATE_TEST -- since round 6 the library arms a gate only for the tiled launch that opens it) every held-back bank
+    goes behind a gate that only its bounded spin (300 us) opens.  Same buses, bit for bit.  In a process of its own."""
     import os
     import pathlib
     import subprocess
@@ -219,7 +219,7 @@ ran, _ = g.eq_spec_stats()
 assert ran > 0
 print("ok gate-timeout")
 """
-    env = dict(os.environ, MX_EQ_SPEC_DIRECT="1")
+    env = dict(os.environ, MX_EQ_SPEC_DIRECT="1", MX_TAIL_GATE_TEST="1")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and "ok gate-timeout" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
