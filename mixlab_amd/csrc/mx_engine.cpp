@@ -320,6 +320,7 @@ Graph::Graph(const mx_node* nodes, size_t n_nodes, const mx_edge* edges, size_t 
     // k_tail_gate) and then shares the SIMDs with it -- 1024 strips x 2048 ticks 5.42 -> 4.84 ms, x 256 ticks 0.915 -> 0.860, 128 strips x 2048 ticks 0.934 -> 0.875
     // (tools/q_gate.sh).  Launched at once instead (round 4, MX_TAIL_GATE=0) the same mode LOST from 256 ticks up: the next run's k_env_ticks ran beside the bank (140 us
     // instead of 9) with the EqThree launch waiting behind it.  MX_OVERLAP_AUTO=0 turns the automatism off; results are bit-identical either way.
+    { const char* const sm = getenv("MX_SIN_MODE"); sin_mode_ = sm ? atoi(sm) : 0; }   // (A/B and tests: mx_k_stream.hip SIN_MODE)
     bool overlap_auto = false;
     {
         const char* const ae = getenv("MX_OVERLAP_AUTO");   // read per graph: tests build both kinds in one process
@@ -1149,7 +1150,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
             }
             break;
         }
-        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_); break;
+        case MX_KIND_FM_SINE: launch_fm_sine((const FmDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_, sin_mode_); break;
         case MX_KIND_MIXER:
             if (overlap_this_run_ && (int)gi >= tail_gi_) {   // beside the next run's earlier groups (HBM-bound beside VALU-bound)
                 const bool first = (int)gi == tail_gi_, last = gi + 1 == groups_.size();
@@ -1173,7 +1174,7 @@ void Graph::run_span(uint64_t t0, size_t fpc, uint32_t call_off, uint32_t n_call
             }
             launch_mixer((const MixDesc*)desc_of(g), n, g.max_taps /* = most channels */, gf, g.dup_mode, stream_);
             break;
-        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_); break;
+        case MX_KIND_OSCILLATOR: launch_oscillator((const OscDesc*)desc_of(g), n, gf, t0, sample_rate_, stream_, sin_mode_); break;
         case MX_KIND_STEREO_PANNER: launch_panner((const PanDesc*)desc_of(g), n, gf, stream_); break;
         case MX_KIND_STEREO_SPLITTER: launch_splitter((const SplitDesc*)desc_of(g), n, gf, stream_); break;
         case MX_KIND_TRIGGER: launch_trigger((const TrigDesc*)desc_of(g), n, gf, gfpc, &gates, stream_); break;

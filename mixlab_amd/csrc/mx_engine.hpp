@@ -218,6 +218,7 @@ private:
     int tail_gi_ = -1;                    // index of the FIRST tail group in groups_ (every group from it on is a Mixer group), -1 = mode off
     bool eq_mode_warned_ = false;         // the grouping / descriptor mode mismatch was reported (build_descriptors)
     bool tail_auto_ = false;              // the mode was chosen by the library (short submissions), not asked for with MX_FLAG_OVERLAP_TAIL
+    int sin_mode_ = 0;                    // MX_SIN_MODE at build time (0: the reference's float through Ziv's strategy)
     uint32_t parity_ = 0;                 // which buffer of the double-buffered ports the current / last run uses
     bool building_alt_ = false;           // upload_group is filling desc_alt / extra_alt
     bool building_main_ = false;          // ... desc / extra (first buffers whatever the current parity is)

@@ -8,6 +8,7 @@
 // Instances of one module kind are batched into one launch.
 #include "mx_dev.hpp"
 #include "mx_env_math.hpp"
+#include "mx_sin_f32.hpp"
 
 namespace mx {
 
@@ -49,9 +50,18 @@ void launch_amplifier(const AmpDesc* d, uint32_t n, size_t frames, hipStream_t s
 
 // ---------------------------------------------------------------------------------------------
 // Oscillator (src/module/oscillator.rs:15-37,65-92) and FmSine (src/module/fm_sine.rs:37-56).
-// f64 sin = ocml's; the reference's is the host libm.  Both are sub-ULP f64 routines; after the
-// f32 cast the Sine / FmSine results differ in at most 1 f32 ULP, rarely (measured in tests).  Square is bit-exact.
+// The reference's f64 sin is the host libm's, the device's is ocml's: both good f64 routines whose f32 casts differ only where the real sine lies within their
+// last-bit errors of an f32 rounding boundary (counted: DESIGN.md "Sine").  module_sin_f32 (mx_sin_f32.hpp) takes the device's sine unless that is the case and
+// otherwise rounds the real sine, computed in double-double arithmetic: the float (float)glibc_sin(x) gives, save ~2 samples in 10^9.  Square is exact (below).
 // ---------------------------------------------------------------------------------------------
+// SIN_MODE (MX_SIN_MODE, read once per graph): 0 the default above; 1 the plain cast of the device's sine (the A/B of that count); 2 the double-double path for
+// every sample (tests)
+#define MX_SIN_DEVICE_ULPS 8.6   // ocml's f64 sin error bound (2 ulp) taken four times over + glibc's 0.55: the slow path then runs on ~3 samples in 10^8
+__device__ __forceinline__ float module_sin_f32(double x, int mode) {
+    if (mode == 2) return (x == x && fabs(x) < 1099511627776.0) ? dd_to_f32(sin_dd(x)) : (float)sin(x);
+    const double y = sin(x);
+    return mode == 1 ? (float)y : sin_f32_from(x, y, MX_SIN_DEVICE_ULPS);
+}
 #define MX_PI 3.14159265358979323846264338327950288
 
 __device__ __forceinline__ double osc_saw(double n) { return 2.0 * (n - floor(0.5 + n)); }
@@ -79,14 +89,19 @@ __device__ __forceinline__ bool sin_is_negative(double x) {
     return (r < 0.0) != m_odd;
 }
 
-__global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
+__global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr, int sin_mode) {
     const OscDesc d = descs[blockIdx.y];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256) {
         const double tt = (double)(t0 + (uint64_t)i) / sr;
         const double n = tt * d.freq;
         double v;
+        if (d.waveform == 2) {                                                        // Sine: `(n * 2.0 * PI).sin() as f32` (oscillator.rs:25-27,87)
+            const float sm = module_sin_f32(n * 2.0 * MX_PI, sin_mode);
+            d.mono[i] = sm;
+            reinterpret_cast<float2*>(d.stereo)[i] = make_float2(sm, sm);
+            continue;
+        }
         switch (d.waveform) {
-        case 2: v = sin(n * 2.0 * MX_PI); break;                                      // Sine
         case 3: v = sin_is_negative(n * 2.0 * MX_PI) ? -1.0 : 1.0; break;                // Square: exact sign of sin (see sin_is_negative)
         case 5: v = osc_saw(n); break;                                                // Saw
         case 4: v = 2.0 * fabs(osc_saw(n)) - 1.0; break;                              // Triangle
@@ -98,26 +113,26 @@ __global__ __launch_bounds__(256) void k_oscillator(const OscDesc* __restrict__ 
         reinterpret_cast<float2*>(d.stereo)[i] = make_float2(sm, sm);
     }
 }
-void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s, int sin_mode) {
     if (!n || !frames) return;
     dim3 grid(grid_x(frames, 256, 4096), n);
-    hipLaunchKernelGGL(k_oscillator, grid, dim3(256), 0, s, d, frames, t0, sample_rate);
+    hipLaunchKernelGGL(k_oscillator, grid, dim3(256), 0, s, d, frames, t0, sample_rate, sin_mode);
 }
 
-__global__ __launch_bounds__(256) void k_fm_sine(const FmDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr) {
+__global__ __launch_bounds__(256) void k_fm_sine(const FmDesc* __restrict__ descs, size_t frames, uint64_t t0, double sr, int sin_mode) {
     const FmDesc d = descs[blockIdx.y];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += (size_t)gridDim.x * 256) {
         const double tt = (double)(t0 + (uint64_t)i) / sr;
         const double xin = d.in ? (double)d.in[i] : 0.0;
         const double co = (d.freq_mid + d.freq_amp * xin) * 2.0 * MX_PI;
-        const float x = (float)sin(co * tt);
+        const float x = module_sin_f32(co * tt, sin_mode);                              // `(co * t).sin() as f32` (fm_sine.rs:50-52)
         reinterpret_cast<float2*>(d.out)[i] = make_float2(x, x);
     }
 }
-void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s) {
+void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s, int sin_mode) {
     if (!n || !frames) return;
     dim3 grid(grid_x(frames, 256, 4096), n);
-    hipLaunchKernelGGL(k_fm_sine, grid, dim3(256), 0, s, d, frames, t0, sample_rate);
+    hipLaunchKernelGGL(k_fm_sine, grid, dim3(256), 0, s, d, frames, t0, sample_rate, sin_mode);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -125,10 +125,10 @@ int eq_epilogue_mode(uint32_t epi, uint32_t flags, bool has_ctl);   // 0..7: (ep
 bool launch_eq_three_spec(const EqDesc* d, EqState* st, uint32_t n, const EqRun& r, const EqSpecPlan& plan, int uniform_mode /* 0..7, or -1: mixed */,
                           void* scratch, uint64_t* stats /* [2]: chunks run, chunks repaired */, hipStream_t s);
 void eq_plan_split(uint32_t n, size_t frames, double lo_f, double hi_f, EqSplit& sp);
-void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
+void launch_fm_sine(const FmDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s, int sin_mode /* mx_k_stream.hip SIN_MODE */);
 void launch_mixer(const MixDesc* d, uint32_t n, uint32_t max_ch /* most channels of any mixer in the group */, size_t frames,
                   int dup_mode /* 0 none, 1 all, 2 mixed */, hipStream_t s);
-void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s);
+void launch_oscillator(const OscDesc* d, uint32_t n, size_t frames, uint64_t t0, double sample_rate, hipStream_t s, int sin_mode);
 void launch_panner(const PanDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_splitter(const SplitDesc* d, uint32_t n, size_t frames, hipStream_t s);
 void launch_trigger(const TrigDesc* d, uint32_t n, size_t frames, size_t fpc, const GateBits* gates /* null: constant per instance */, hipStream_t s);

@@ -1,8 +1,8 @@
 """GPU parity: hand-written HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
 
 Bars: bit-exact for every module whose arithmetic order is preserved (Mixer, EqThree exact mode,
-Envelope, Amplifier, shuffles, Saw/Triangle oscillators); <= 1 f32 ULP where the device's f64 sin
-(ocml) stands in for the host libm (Sine/Square oscillators, FmSine).
+Envelope, Amplifier, shuffles, every oscillator waveform, FmSine -- the f32 of a sine is made independent of whose libm computed
+the f64 sine: mixlab_amd/csrc/mx_sin_f32.hpp); <= 1 ULP only for the opt-in modes that change the order of operations.
 
 Everything except EqThree is unpinned by reference tests: the oracle restates the
 reference source and these tests are only as good as that restatement.
@@ -189,7 +189,7 @@ def test_amplifier_bit_exact(ctl_connected, amp, depth):
 
 
 @pytest.mark.parametrize("wave,exact", [(abi.WAVE_SAW, True), (abi.WAVE_TRIANGLE, True), (abi.WAVE_ON, True), (abi.WAVE_OFF, True),
-                                        (abi.WAVE_SINE, False), (abi.WAVE_SQUARE, True)])   # Square: exact sign of sin on the device
+                                        (abi.WAVE_SINE, True), (abi.WAVE_SQUARE, True)])   # Sine: Ziv's strategy (mx_sin_f32.hpp); Square: exact sign of sin on the device
 @pytest.mark.parametrize("freq,tick", [(100.0, 0), (440.0, 1000), (880.5, 216000)])
 @pytest.mark.parametrize("rate", RATES)
 def test_oscillator(wave, exact, freq, tick, rate):
@@ -210,7 +210,7 @@ def test_oscillator(wave, exact, freq, tick, rate):
 
 @pytest.mark.parametrize("tick", [0, 5000])
 @pytest.mark.parametrize("rate", RATES)
-def test_fm_sine_within_one_ulp(tick, rate):
+def test_fm_sine(tick, rate):
     SR, SPT = rate
     t = tick * SPT
     x = synth.noise(31, SPT)
@@ -218,7 +218,36 @@ def test_fm_sine_within_one_ulp(tick, rate):
     m = abi.Module(abi.KIND_FM_SINE, abi.FmSineParams(220.0, 880.0), sample_rate=SR)
     got = np.empty(2 * SPT, np.float32)
     m.run_tick(t, [(abi.MX_MONO, x)], [(abi.MX_STEREO, got)])
-    assert_ulp(got, want, 1, "FmSine")
+    assert_bit_exact(got, want, "FmSine")
+
+
+@pytest.mark.parametrize("mode", ["0", "2"], ids=["ziv", "double-double-everywhere"])
+def test_sine_and_fm_sine_over_a_long_stretch_are_the_oracles_bits(mode, monkeypatch):
+    """1.5 M sines per module kind: 16 Sine oscillators (27.5 Hz .. 19 kHz) and 16 FmSines over 60 ticks starting five hours into the clock (arguments up to 2e9 rad) in
+    one batched graph, bit for bit against the oracle's (float)glibc_sin.  MX_SIN_MODE=2 runs the double-double path on EVERY sample: the rare path of the default
+    is then the one under test.  (The residual the design admits -- the real sine within glibc's own error of a rounding boundary -- is ~2 in 10^9.)"""
+    monkeypatch.setenv("MX_SIN_MODE", mode)
+    n_ticks, tick0 = 60, 5 * 3600 * 60
+    ws = Workspace(SR, 60)
+    freqs = [27.5 * (19000.0 / 27.5) ** (k / 15.0) for k in range(16)]
+    oscs = [ws.oscillator(f, abi.WAVE_SINE) for f in freqs]
+    fms = []
+    for k in range(16):
+        lfo = ws.oscillator(0.5 + k, abi.WAVE_TRIANGLE)
+        fm = ws.fm_sine(110.0 * (k + 1), 110.0 * (k + 1) + 80.0 * k)      # (freq_lo, freq_hi): mid + amp * in, fm_sine.rs:41-45
+        ws.connect(lfo, 0, fm, 0)
+        fms.append(fm)
+    g = ws.build(max_ticks_per_run=n_ticks)
+    og = oracle.OracleGraph(ws)
+    g.run_ticks(tick0, n_ticks)
+    got_o = [g.read_output(o, 0, n_ticks, False) for o in oscs]
+    got_f = [g.read_output(f, 0, n_ticks, True) for f in fms]
+    for k in range(n_ticks):
+        og.run_tick(tick0 + k)
+        for j, o in enumerate(oscs):
+            assert_bit_exact(got_o[j][k * SPT:(k + 1) * SPT], og.output(o, 0), f"Sine {freqs[j]:.1f} Hz tick {k}")
+        for j, f in enumerate(fms):
+            assert_bit_exact(got_f[j][k * 2 * SPT:(k + 1) * 2 * SPT], og.output(f, 0), f"FmSine {j} tick {k}")
 
 
 def test_trigger_panner_splitter_exact():
@@ -280,17 +309,14 @@ def config1():
 
 @pytest.mark.parametrize("batch", [1, 12])
 def test_config1_four_osc_mixer_plotter(batch):
-    """SURVEY 8d config 1, all 600 ticks.  Saw, Triangle and (exact sign of sin) Square are bit-exact, so the Cue bus
-    (channels 1 and 3: Saw, Triangle) is bit-exact; the Master carries the one Sine oscillator, whose device sin may differ
-    from libm's by 1 f32 ULP on rare samples, so it is compared within 2 ULP of the bus and the differing samples are
-    counted.  The Plotter indication is compared with the ORACLE's indication (same bound) and must be the device's own
-    Master bit for bit."""
+    """SURVEY 8d config 1 (BASELINE.json configs[0]), all 600 ticks, BIT-EXACT: Saw, Triangle, Square (exact sign of sin) and -- since round 6 -- Sine (Ziv's
+    strategy, mx_sin_f32.hpp) are the oracle's bits, so both buses and the Plotter indication are."""
     ws, oscs, mix, plot = config1()
     n_ticks = 600
     og = oracle.OracleGraph(ws)
     g = ws.build(max_ticks_per_run=batch)
     assert g.run_order() == og.run_order()
-    n_diff = n_fired = 0
+    n_fired = 0
     for t0 in range(0, n_ticks, batch):
         g.run_ticks(t0, batch)
         got_m = g.read_output(mix, 0, batch, True)
@@ -300,18 +326,16 @@ def test_config1_four_osc_mixer_plotter(batch):
             sl = slice(k * 2 * SPT, (k + 1) * 2 * SPT)
             wm, wc = og.output(mix, 0), og.output(mix, 1)
             assert_bit_exact(got_c[sl], wc, f"Cue tick {t0 + k}")
-            assert_ulp(got_m[sl], wm, 2, f"Master tick {t0 + k}")
-            n_diff += int(np.count_nonzero(bits(got_m[sl]) != bits(wm)))
+            assert_bit_exact(got_m[sl], wm, f"Master tick {t0 + k}")
             want_p = og.plotter(plot)
             got_p = g.read_plotter(plot, k)
             assert (want_p is None) == (got_p is None)
             if want_p is not None:
                 n_fired += 1
                 assert (t0 + k + 1) % 6 == 0
-                assert_ulp(got_p[0], want_p[0], 2, "Plotter left vs oracle"); assert_ulp(got_p[1], want_p[1], 2, "Plotter right vs oracle")
+                assert_bit_exact(got_p[0], want_p[0], "Plotter left vs oracle"); assert_bit_exact(got_p[1], want_p[1], "Plotter right vs oracle")
                 assert_bit_exact(got_p[0], got_m[sl][0::2]); assert_bit_exact(got_p[1], got_m[sl][1::2])
     assert n_fired == n_ticks // 6
-    assert n_diff <= n_ticks * 2 * SPT // 50, f"{n_diff} Master samples differ from the oracle"
 
 
 def strips(n_strips, sr=SR):
