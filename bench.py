@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=4, help="further repetitions of the K timed steps after the headline region (spread of the clock)")
     ap.add_argument("--parity-strips", type=int, default=16, help="strips replayed through the CPU oracle from tick 0 for headline_parity")
     ap.add_argument("--fir-ticks", type=int, default=128, help="ticks per step of the FIR + resampler leg (BASELINE configs[2]; 0 = skip)")
-    ap.add_argument("--video-frames", type=int, default=1920, help="composited frames in the video leg (0 = skip)")
+    ap.add_argument("--video-frames", type=int, default=4096, help="composited frames in the video leg (0 = skip)")
     ap.add_argument("--video-band-as", default=None, metavar="R/W", help="single GPU: run the video leg as rank R of a W-rank row-band job")
     ap.add_argument("--video-shard", choices=["replicas", "bands"], default="replicas",
                     help="N > 1: independent 8-layer streams per rank (weak scaling), or ONE stream cut into row bands over the ranks (strong scaling)")

@@ -17,15 +17,17 @@ F = 1920 * 1080 * 3 // 2
 F720 = 1280 * 720 * 3 // 2
 RGBA = 1920 * 1080 * 4
 ALPHA_LAYERS = (2, 5, 7)     # two 1080p layers and a scaled 720p one carry coverage in the `alpha` variant
-T = 256                      # ticks per submission (a throughput knob like the audio leg's: the video pipeline fills and drains once per run)
+T_DEFAULT = 1024             # ticks per submission (a throughput knob like the audio leg's 2048: the video pipeline fills -- one scale-only launch -- and drains once per run;
+                             # 256 until round 5: 0.28 us per frame of that fill, profiles/r06/video_experiments.md)
 
 
-def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16, shard_mode="replicas", rank=0, band_as=None, only=None):
+def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16, shard_mode="replicas", rank=0, band_as=None, only=None, ticks_per_submission=None):
     import alpha_patterns   # seeded coverage planes (numpy only)
     import synth            # seeded synthetic patterns (numpy only)
     from mixlab_amd import shard, video
     from mixlab_amd.workspace import Workspace
 
+    T = int(os.environ.get("VLEG_T", "0")) or ticks_per_submission or min(T_DEFAULT, max(16, frames))
     bands = shard_mode == "bands"
     row0, rows = shard.row_bands(1080, world)[rank] if bands else (0, 1080)
     if band_as:                                                        # one GPU plays rank R of W (what a rank of the sharded job costs)
@@ -120,7 +122,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
            "hbm_frac_moved_bytes_wall": round((moved_scaler + moved_chain) * n_frames / world / dt / 1e9 / HBM_PEAK_GBS, 4),
            "per_kernel_moved_bytes": {"scaler tiles (2 layers)": moved_scaler, "chain tiles": moved_chain, "layers_read_by_the_chain": layers_read, "ticks_per_submission": T}}
     if variants and only is None:
-        nf = min(frames, 1024)
+        nf = min(frames, 2048)
         dt2, st2, ms2 = run(no_rest, (), nf, 1)    # every fader inside its travel: nothing is pruned, the chain reads all eight layers
         lr2, mc2 = moved_chain_of(no_rest)
         out["no_rest_fader"] = {"faders": no_rest, "value": st2 * T / dt2, "unit": "frames/s", "device_us_per_frame": round(ms2 * 1e3, 2), "layers_read_by_the_chain": lr2,
