@@ -44,8 +44,11 @@ const Rccl& rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
-        if (!h) { const char* e = dlerror(); r.error = std::string("librccl.so could not be loaded (") + (e ? e : "?") + "): the RCCL transport is not available on this host"; return; }
+        // MX_RCCL_LIB: the library to bind instead (tests: tests/helpers/fake_rccl.c, a test double that runs these collectives between processes sharing one GPU)
+        const char* const over = getenv("MX_RCCL_LIB");
+        if (over && *over) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        else for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { const char* e = dlerror(); r.error = std::string(over && *over ? over : "librccl.so") + std::string(" could not be loaded (") + (e ? e : "?") + "): the RCCL transport is not available on this host"; return; }
         auto sym = [&](auto& fp, const char* n) { fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(h, n)); if (!fp && r.error.empty()) r.error = std::string("librccl.so has no ") + n; };
         sym(r.GetErrorString, "ncclGetErrorString"); sym(r.GetUniqueId, "ncclGetUniqueId"); sym(r.CommInitRank, "ncclCommInitRank");
         sym(r.CommDestroy, "ncclCommDestroy"); sym(r.AllGather, "ncclAllGather"); sym(r.AllReduce, "ncclAllReduce");
