@@ -25,7 +25,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 from benchlegs import cpu, headline, line as bench_line, realtime, scaling, variants  # noqa: E402
-from benchlegs.common import HBM_PEAK_GBS, Job, build_strips, gate_events, gate_open  # noqa: E402,F401  (re-exported: tests and tools import them from here)
+from benchlegs.common import HBM_PEAK_GBS, Job, build_strips, dist_backend, dist_device, gate_events, gate_open  # noqa: E402,F401  (re-exported: tests and tools import them from here)
 from benchlegs.fir import fir_leg  # noqa: E402
 from benchlegs.video import video_leg  # noqa: E402
 
@@ -97,7 +97,7 @@ def main(argv=None):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("MX_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))   # (tests: every rank on GPU 0, with MX_BENCH_DIST_BACKEND=gloo and MX_RCCL_LIB)
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
@@ -107,7 +107,10 @@ def main(argv=None):
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist_backend() == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(dist_backend(), rank=rank, world_size=world)
 
     # N > 1 tick policy, decided here and named in config.ticks_policy: the headline runs T x N ticks per step unless --fixed-ticks
     scaled = world > 1 and not args.fixed_ticks
@@ -199,7 +202,7 @@ def main(argv=None):
             full["held_gates"] = {"ms_per_step": dt_h / nh * 1e3, "value": args.strips * T * nh / dt_h, "unit": "channel-ticks/s",
                                   "kernel_ms_per_step": {k: round(v / max(1, hn), 5) for k, v in sorted(hk.items()) if v > 0}}
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device=dist_device())
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         job.nxt, job.dt = nxt, dt

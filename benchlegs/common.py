@@ -30,6 +30,16 @@ VIDEO_MATRIX = [3900, 150, 46, 4096, 60, 3980, 56, -2048, 20, 120, 3956, 0]
 VIDEO_SIZES = [(1920, 1080)] * 6 + [(1280, 720)] * 2
 
 
+def dist_backend():
+    """torch.distributed backend of an N > 1 run: RCCL ("nccl").  MX_BENCH_DIST_BACKEND=gloo (tests: N processes sharing ONE GPU, the library's exchange on the RCCL test
+    double) carries the same barriers / maxima / gathers on the host."""
+    return os.environ.get("MX_BENCH_DIST_BACKEND", "nccl")
+
+
+def dist_device():
+    return "cuda" if dist_backend() == "nccl" else "cpu"
+
+
 def gate_open(tick, k):
     """the Trigger of strip k toggles every 30 ticks with phase k mod 60."""
     return ((tick + k) // 30) % 2 == 1

@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from .common import (BYTES_PER_FRAME, BYTES_PER_FRAME_FUSED, F64_VALU_PEAK_TOPS, HBM_PEAK_GBS, PROFILE_TAG, build_strips, pmc_traffic, sq_profile,
+from .common import (dist_device, BYTES_PER_FRAME, BYTES_PER_FRAME_FUSED, F64_VALU_PEAK_TOPS, HBM_PEAK_GBS, PROFILE_TAG, build_strips, pmc_traffic, sq_profile,
                      sustained_clock_ghz, tiled_noise)
 from .scaling import exchange_parity
 
@@ -153,7 +153,7 @@ def exchange_section(job, ex, step_after):
         # parity evidence that needs none of the exchange's own code (collective: every rank takes part; rank 0 reports)
         exch["parity_check"] = exchange_parity(torch, dist, g, ex, job.mix, T, step_after + 3, world)
         if world > 1:
-            ok = torch.tensor([1 if exch["parity_check"]["verdict"] == "bit-exact" else 0], device="cuda")
+            ok = torch.tensor([1 if exch["parity_check"]["verdict"] == "bit-exact" else 0], device=dist_device())
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             exch["parity_check"]["all_ranks"] = "bit-exact" if int(ok.item()) == 1 else "MISMATCH on some rank"
     elif world > 1:

@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-from .common import build_strips, gate_events, tiled_noise
+from .common import build_strips, dist_device, gate_events, tiled_noise
 
 
 def exchange_parity(torch, dist, g, ex, mix, T, step, world):
@@ -17,7 +17,7 @@ def exchange_parity(torch, dist, g, ex, mix, T, step, world):
     sum is made on the host in rank order with numpy f32 adds, and compared bit for bit with mx_exchange_read_result.  Collective: every
     rank calls it; returns this rank's verdict."""
     part = np.concatenate([g.read_output(mix, 0, T, True), g.read_output(mix, 1, T, True)])
-    mine = torch.from_numpy(part).cuda()
+    mine = torch.from_numpy(part).to(dist_device())
     if world > 1:
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
@@ -67,7 +67,7 @@ def other_policy_leg(job, T, label, nccl_id_fn):
     dt = time.perf_counter() - t0
     parity = exchange_parity(torch, dist, g, ex, mix, T, warm + steps - 1, job.world) if ex.mode != "allreduce" else None
     if job.world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=dist_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     out = {"policy": label, "ticks_per_step": T, "steps": steps, "ms_per_step": dt / steps * 1e3,

@@ -11,7 +11,7 @@ from __future__ import annotations
 import os
 import time
 
-from .common import HBM_PEAK_GBS, VIDEO_FADERS, VIDEO_SIZES, video_cascade
+from .common import HBM_PEAK_GBS, VIDEO_FADERS, VIDEO_SIZES, dist_device, video_cascade
 
 F = 1920 * 1080 * 3 // 2
 F720 = 1280 * 720 * 3 // 2
@@ -87,7 +87,7 @@ def video_leg(torch, dist, world, stream, local_rank, frames, warmup, n_sets=16,
     else:
         dt, steps, dev_ms = run(VIDEO_FADERS, (), frames, warmup)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=dist_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # bytes per composited frame.  Module-boundary accounting (every VideoMixer output materialised): 7 cross-fades x 3F + 2 scales

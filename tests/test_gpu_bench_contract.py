@@ -111,3 +111,34 @@ def test_two_rank_rccl_job_is_bit_exact_when_two_gpus_are_visible(tmp_path):
         assert pc["verdict"] == "bit-exact" and pc["all_ranks"] == "bit-exact", pc
         assert line["config"]["ticks_per_step"] == 128 and "T x N" in line["config"]["ticks_policy"]
         assert full["other_policy"]["ticks_per_step"] == 64 and full["other_policy"]["parity"]["verdict"] == "bit-exact"
+
+
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (4, "slices")])
+def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(world, mode, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` with N REAL ranks on a one-GPU box: every rank on GPU 0 (MX_BENCH_SHARE_GPU), torch.distributed on
+    gloo (barriers, the max of the clock, the plain all_gather of the parity check), the library's exchange on the RCCL test double (MX_RCCL_LIB, tests/helpers/fake_rccl.c).
+    Times mean nothing here; what is checked is the N > 1 code of bench.py and of mx_exchange.cpp as the driver will run it: the T x N tick policy as the headline, the
+    fixed-T policy beside it, both exchanges bit-exact on every rank against the host sum in rank order."""
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", str(so), str(ROOT / "tests" / "helpers" / "fake_rccl.c"),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lrt"], check=True)
+    import os
+    full = tmp_path / "full.json"
+    env = dict(os.environ, MX_BENCH_SHARE_GPU="1", MX_BENCH_DIST_BACKEND="gloo", MX_RCCL_LIB=str(so))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29581 + world),
+           str(ROOT / "bench.py"), "--gpus", str(world), "--exchange", mode, *SMALL, "--full-out", str(full)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 8192
+    line, rec = _strict(lines[0]), _strict(full.read_text())
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["cpu_baseline"] is None
+    assert line["config"]["ticks_per_step"] == 64 * world and "T x N" in line["config"]["ticks_policy"]
+    assert line["value"] == pytest.approx(64 * 64 * world * 1000.0 / line["ms_per_step"], rel=1e-6)
+    ex = rec["exchange"]
+    assert ex["mode"] == mode and ex["rccl_ranks"] == world
+    assert ex["parity_check"]["verdict"] == "bit-exact" and ex["parity_check"]["all_ranks"] == "bit-exact", ex
+    assert ex["parity_check"]["samples_compared"] == 2 * 64 * world * 1600
+    op = rec["other_policy"]
+    assert op["ticks_per_step"] == 64 and op["parity"]["verdict"] == "bit-exact" and op["exchange_mode"] == mode
+    assert rec["roofline"]["kernel_timing"].startswith("hipEvents on 3 extra steps")
