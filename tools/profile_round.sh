@@ -4,13 +4,13 @@
 # FETCH_SIZE and WRITE_SIZE in separate runs (MI355X_MICROARCH.md).  profiles/rNN/README.md is generated from these outputs
 # (tools/profile_readme.py), not written by hand.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-realtime --no-buses-leg --no-one-stream-leg --no-t-sweep --no-north-star --no-held-leg --no-material-leg --no-rate-leg --no-contract-leg --no-scaling-probe --fir-ticks 0 --repeats 0 --steps 4 --warmup 1 --video-frames 0"
+COMMON="--headline-only --steps 4 --warmup 1 --full-out /tmp/bench_full_pmc.json"
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
 pmc() {   # pmc <tag> <counters...> -- <command...>: one counter pass, summary into $OUT/<tag>.txt, raw csv path echoed
   local tag=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
@@ -21,8 +21,14 @@ pmc() {   # pmc <tag> <counters...> -- <command...>: one counter pass, summary i
   echo $f
 }
 # 2. the same command under the kernel trace
-rm -rf /tmp/kt; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py > $OUT/bench_line_under_rocprof.json 2>/dev/null
+rm -rf /tmp/kt; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py --full-out /tmp/bench_full_kt.json > $OUT/bench_line_under_rocprof.json 2>/dev/null
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_default_bench.csv
+# 2b. the headline's window as the kernel trace sees it (no counters): per-dispatch start / end in the default schedule and on one stream -> window_timeline.md
+HL="--headline-only --no-headline-parity --steps 10 --warmup 2 --full-out /tmp/bench_full_hl.json"
+rm -rf /tmp/kw_a /tmp/kw_1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kw_a -- python $REPO/bench.py $HL > /dev/null 2>&1
+MX_OVERLAP_AUTO=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kw_1 -- python $REPO/bench.py $HL > /dev/null 2>&1
+python $REPO/tools/window_timeline.py $(find /tmp/kw_a -name "*kernel_trace.csv" | head -1) $(find /tmp/kw_1 -name "*kernel_trace.csv" | head -1) 1024 2048 > $OUT/window_timeline.md
 # 3. HBM traffic of the headline configuration
 FCSV=$(pmc pmc_fetch FETCH_SIZE -- python $REPO/bench.py $COMMON)
 WCSV=$(pmc pmc_write WRITE_SIZE -- python $REPO/bench.py $COMMON)
@@ -46,7 +52,7 @@ python $REPO/tools/pmc_clock.py $CCSV $OUT/pmc_clock_kernel_trace.csv $OUT/clock
 CCSV=$(pmc pmc_clock_fc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -- python $REPO/bench.py $COMMON --fp-contract)
 python $REPO/tools/pmc_clock.py $CCSV $(find /tmp/p_pmc_clock_fc -name "*kernel_trace.csv" | head -1) $OUT/clock_fc.json
 # 6. config 4 (video leg alone): kernel times, SQ counters, traffic
-rm -rf /tmp/vk; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vk -- python $REPO/tools/vleg.py 3840 > $OUT/video_leg_line.json 2>/dev/null
+rm -rf /tmp/vk; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vk -- python $REPO/tools/vleg.py 4096 > $OUT/video_leg_line.json 2>/dev/null
 cp $(find /tmp/vk -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_video_leg.csv
 pmc video_sq $SQ1 -- python $REPO/tools/vleg.py 1280 > /dev/null
 VF=$(pmc video_fetch FETCH_SIZE -- python $REPO/tools/vleg.py 1280)
@@ -70,6 +76,7 @@ cd /tmp
 # 8. LAST: the default command, as the driver runs it -- with this round's counter summaries in place, so that the line's roofline.traffic / limiter /
 #    sustained clock are the ones just collected on these kernel sources (bench.py copies them only while the recorded source hash matches)
 mkdir -p $REPO/profiles/$R && cp $OUT/*.json $REPO/profiles/$R/ 2>/dev/null
-timeout 900 python $REPO/bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
+timeout 900 python $REPO/bench.py --full-out $OUT/bench_full.json > $OUT/bench_default_line.json 2> $OUT/bench_default.err
+wc -c $OUT/bench_default_line.json
 python $REPO/tools/profile_readme.py $OUT $R > $OUT/README.md
 ls -la $OUT
