@@ -114,6 +114,8 @@ def main(argv=None):
 
     # N > 1 tick policy, decided here and named in config.ticks_policy: the headline runs T x N ticks per step unless --fixed-ticks
     scaled = world > 1 and not args.fixed_ticks
+    if scaled:
+        args.parity_strips = max(2, args.parity_strips // world)    # the oracle replays a strip from tick 0: N x the audio per step, so 1 / N of the strips (seconds, on rank 0, outside every clock)
     T, SR = args.ticks_per_step * (world if scaled else 1), args.sample_rate
     first, local_strips = shard.strip_range(rank, world, args.strips)
     flags = (abi.FLAG_EQ_FAST if args.eq_fast else 0) | (abi.FLAG_NO_FUSE if args.no_fuse else 0) | (abi.FLAG_FP_CONTRACT if args.fp_contract else 0)

@@ -20,7 +20,7 @@ for r in csv.DictReader(open(kt)):
     dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); name[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0]
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for d, b in busy.items():
-    if d in dur and dur[d] > 100000:         # the GRBM method is not usable below ~100 us (it reported 2.84-3.06 GHz, above the 2.4 GHz maximum, for the short kernels)
+    if d in dur and dur[d] > 100000 and "mx::" in name[d] and "k_tail_gate" not in name[d]:   # (this library's kernels; not the runtime's copies, not the one-wave gate)         # the GRBM method is not usable below ~100 us (it reported 2.84-3.06 GHz, above the 2.4 GHz maximum, for the short kernels)
         a = agg[name[d]]; a[0] += b / 8.0; a[1] += dur[d]; a[2] += 1
 res = {k: {"ghz": round(v[0] / v[1], 3), "dispatches": v[2]} for k, v in agg.items()}
 json.dump({"kernel_sources_sha16": kernel_hash("audio"), "ghz_by_kernel": res,
