@@ -552,7 +552,10 @@ typedef struct mx_exchange mx_exchange;
 typedef struct mx_loopback_group mx_loopback_group;
 
 /* ncclGetUniqueId: rank 0 makes the job's id and hands the 128 bytes to the other ranks by any means it has (the reference's
- * hosts already talk over sockets); every rank passes them to mx_exchange_create, which is collective (ncclCommInitRank). */
+ * hosts already talk over sockets); every rank passes them to mx_exchange_create, which is collective (ncclCommInitRank).
+ * librccl is bound on first use (dlopen of librccl.so.1): a host without it still loads this library and gets MX_ERR_DEVICE here.
+ * MX_RCCL_LIB (environment) names another library to bind in its place -- the test suite's stand-in for RCCL between processes that
+ * share one GPU (tests/helpers/fake_rccl.c), through which the RCCL transport's own code runs with 2 and 4 real peers on a one-GPU box. */
 int mx_exchange_unique_id(void* id_out /* MX_EXCHANGE_ID_BYTES */);
 /* In-process transport for `world` exchanges of ONE process (virtual ranks on one GPU, or one thread driving several GPUs):
  * device-to-device copies stand in for the collectives; buffers, combine and pipelining are the RCCL path's.  Every member
