@@ -113,8 +113,8 @@ def test_two_rank_rccl_job_is_bit_exact_when_two_gpus_are_visible(tmp_path):
         assert full["other_policy"]["ticks_per_step"] == 64 and full["other_policy"]["parity"]["verdict"] == "bit-exact"
 
 
-@pytest.mark.parametrize("world,mode", [(2, "allgather"), (4, "slices")])
-def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(world, mode, tmp_path):
+@pytest.mark.parametrize("world,mode,vshard", [(2, "allgather", "replicas"), (4, "slices", "bands")])
+def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(world, mode, vshard, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` with N REAL ranks on a one-GPU box: every rank on GPU 0 (MX_BENCH_SHARE_GPU), torch.distributed on
     gloo (barriers, the max of the clock, the plain all_gather of the parity check), the library's exchange on the RCCL test double (MX_RCCL_LIB, tests/helpers/fake_rccl.c).
     Times mean nothing here; what is checked is the N > 1 code of bench.py and of mx_exchange.cpp as the driver will run it: the T x N tick policy as the headline, the
@@ -125,8 +125,10 @@ def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(w
     import os
     full = tmp_path / "full.json"
     env = dict(os.environ, MX_BENCH_SHARE_GPU="1", MX_BENCH_DIST_BACKEND="gloo", MX_RCCL_LIB=str(so))
+    small = list(SMALL)
+    small[small.index("--video-frames") + 1] = "64"        # the video leg runs here too: replicas per rank, or ONE stream in row bands
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29581 + world),
-           str(ROOT / "bench.py"), "--gpus", str(world), "--exchange", mode, *SMALL, "--full-out", str(full)]
+           str(ROOT / "bench.py"), "--gpus", str(world), "--exchange", mode, *small, "--video-shard", vshard, "--full-out", str(full)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -142,3 +144,5 @@ def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(w
     op = rec["other_policy"]
     assert op["ticks_per_step"] == 64 and op["parity"]["verdict"] == "bit-exact" and op["exchange_mode"] == mode
     assert rec["roofline"]["kernel_timing"].startswith("hipEvents on 3 extra steps")
+    v = rec["video"]
+    assert v["value"] > 0 and v["scaling"] == ("weak" if vshard == "replicas" else "strong") and v["frames"] == (64 * world if vshard == "replicas" else 64)
