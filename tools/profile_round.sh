@@ -26,7 +26,8 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_default
 # 2b. the headline's window as the kernel trace sees it (no counters): per-dispatch start / end in the default schedule and on one stream -> window_timeline.md
 HL="--headline-only --no-headline-parity --steps 10 --warmup 2 --full-out /tmp/bench_full_hl.json"
 rm -rf /tmp/kw_a /tmp/kw_1
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kw_a -- python $REPO/bench.py $HL > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kw_a -- python $REPO/bench.py $HL > /dev/null 2>&1
+cp $(find /tmp/kw_a -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_headline_only.csv   # the headline's shape alone: the average the line's roofline.avg_launch_ms must agree with
 MX_OVERLAP_AUTO=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kw_1 -- python $REPO/bench.py $HL > /dev/null 2>&1
 python $REPO/tools/window_timeline.py $(find /tmp/kw_a -name "*kernel_trace.csv" | head -1) $(find /tmp/kw_1 -name "*kernel_trace.csv" | head -1) 1024 2048 > $OUT/window_timeline.md
 # 3. HBM traffic of the headline configuration
