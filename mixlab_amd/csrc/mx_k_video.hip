@@ -12,7 +12,6 @@
 
 #include "mx_dev.hpp"
 #include "mx_video.hpp"
-#include "mx_kernels.hpp"
 
 namespace mx {
 
@@ -1087,8 +1086,6 @@ __global__ __launch_bounds__(256) void k_video_batch(const VideoBatchDesc* desc,
     VbRow r = rows.r[blockIdx.y];                        // kernel arguments: the whole record requested at once, waited for once
     asm volatile("" : "+s"(r.is_job), "+s"(r.n_tiles), "+s"(r.off), "+s"(r.ts1), "+s"(r.ts2), "+s"(r.tx0), "+s"(r.tx1), "+s"(r.tx2), "+s"(r.variant), "+s"(r.s_rows), "+s"(r.prio));
     const uint32_t n = r.n_tiles;
-    if (rows.started && threadIdx.x == 0 && (rows._pad ? (blockIdx.x == 0 && blockIdx.y == 0) : (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1)))   // (_pad: the FIRST workgroup opens the gate)
-        __hip_atomic_store(rows.started, rows.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every workgroup of this launch has been placed (k_tail_gate)
     if (x >= n) return;
     // wave priority per tile kind (launcher; MX_VIDEO_PRIO): bits 0..1 the chain tiles', bits 2..3 the scaler tiles'
     { const uint32_t pr = r.is_job ? (r.prio >> 2) & 3u : r.prio & 3u;
@@ -1224,9 +1221,7 @@ static bool plan_scale_job(const ScaleArgs& a, ScaleJob& j) {
 // takes the least recently used slot: it is rewritten only after the last launch that read it has finished.
 namespace {
 struct DescSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t bytes = 0; uint64_t hash = 0, used_at = 0; hipEvent_t done = nullptr, copied = nullptr; bool used = false; };
-struct DescRing { DescSlot slot[16]; uint64_t clock = 0; hipStream_t copy = nullptr; std::vector<uint8_t> build; std::mutex mu;
-                  // MX_VIDEO_SPLIT (experiment, profiles/r06/video_experiments.md): the scale jobs of a batch as a launch of their own on `side`, the chains on the caller's stream behind a gate
-                  hipStream_t side = nullptr; hipEvent_t ev_chain = nullptr, ev_jobs = nullptr; uint32_t* flag = nullptr; uint32_t seq = 0; bool side_pending = false, chain_recorded = false; };   // `copy`: the uploads' own stream -- they run beside the previous launch
+struct DescRing { DescSlot slot[16]; uint64_t clock = 0; hipStream_t copy = nullptr; std::vector<uint8_t> build; std::mutex mu; };   // `copy`: the uploads' own stream -- they run beside the previous launch
 std::mutex g_desc_mu;
 std::map<std::pair<int, hipStream_t>, DescRing> g_desc;
 constexpr size_t VB_HEADER = offsetof(VideoBatchDesc, c);
@@ -1254,10 +1249,6 @@ void video_stream_retired(hipStream_t s) {
             if (c.copied) (void)hipEventDestroy(c.copied);
         }
         if (ring.copy) { (void)hipStreamSynchronize(ring.copy); (void)hipStreamDestroy(ring.copy); }
-        if (ring.side) { (void)hipStreamSynchronize(ring.side); (void)hipStreamDestroy(ring.side); }
-        if (ring.ev_chain) (void)hipEventDestroy(ring.ev_chain);
-        if (ring.ev_jobs) (void)hipEventDestroy(ring.ev_jobs);
-        if (ring.flag) (void)hipFree(ring.flag);
         it = g_desc.erase(it);
     }
 }
@@ -1371,44 +1362,6 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
             r.variant = jb.variant; r.s_rows = jb.s_rows;
         }
     }
-    rows.started = nullptr; rows.started_seq = 0;
-    if (ring.side_pending) { hip_check(hipStreamWaitEvent(s, ring.ev_jobs, 0), "hipStreamWaitEvent"); ring.side_pending = false; }   // the scale jobs a split launch put on the side stream: this launch's chains read them
-    static const int split_env = env_int("MX_VIDEO_SPLIT", 0);
-    if (split_env && n_jobs > 0 && n_chains > 0 && !any_alpha && mm == 3) {
-        // EXPERIMENT: the scaler tiles of batch k + 1 as their own launch on a second stream, the chain launch of batch k held back on the caller's stream
-        // behind a gate until the scaler launch's workgroups are placed -- the mechanism of the audio pair (Graph::flush_deferred_tail).  Order kept: the jobs wait for the
-        // chains of the batch BEFORE this one (the last readers of the ring frames they overwrite), the chains of the next batch for these jobs.
-        if (!ring.side) {
-            hip_check(hipStreamCreateWithFlags(&ring.side, hipStreamNonBlocking), "hipStreamCreate(video side)");
-            hip_check(hipEventCreateWithFlags(&ring.ev_chain, hipEventDisableTiming), "hipEventCreate");
-            hip_check(hipEventCreateWithFlags(&ring.ev_jobs, hipEventDisableTiming), "hipEventCreate");
-            hip_check(hipMalloc((void**)&ring.flag, 64), "hipMalloc(video gate flag)");
-            hip_check(hipMemset(ring.flag, 0, 64), "hipMemset");
-        }
-        VbRows rj, rc;
-        std::memset(&rj, 0, sizeof rj); std::memset(&rc, 0, sizeof rc);
-        int nj = 0, nc = 0;
-        uint32_t gxj = 0, gxc = 0;
-        for (int y = 0; y < n_chains + n_jobs; ++y) {
-            const bool keep_prio = split_env >= 3;    // 3: gate opened by the jobs launch's FIRST workgroup, wave priorities kept; 4: no gate, priorities kept
-            if (rows.r[y].is_job) { rj.r[nj] = rows.r[y]; if (!keep_prio) rj.r[nj].prio = 0; gxj = std::max(gxj, rows.r[y].n_tiles); ++nj; }
-            else { rc.r[nc] = rows.r[y]; if (!keep_prio) rc.r[nc].prio = 0; gxc = std::max(gxc, rows.r[y].n_tiles); ++nc; }
-        }
-        if (!hit) hip_check(hipStreamWaitEvent(ring.side, sl->copied, 0), "hipStreamWaitEvent");
-        if (ring.chain_recorded) hip_check(hipStreamWaitEvent(ring.side, ring.ev_chain, 0), "hipStreamWaitEvent");
-        else { hipEvent_t& e0 = ring.ev_chain; hip_check(hipEventRecord(e0, s), "hipEventRecord"); hip_check(hipStreamWaitEvent(ring.side, e0, 0), "hipStreamWaitEvent"); }   // first split launch: everything queued on s so far
-        rj.started = ring.flag; rj.started_seq = ++ring.seq; rj._pad = split_env == 3 ? 1u : 0u;
-        hipLaunchKernelGGL(k_video_batch<3>, dim3((gxj + 7u) & ~7u, (uint32_t)nj), dim3(256), lds, ring.side, dd, rj);
-        hip_check(hipEventRecord(ring.ev_jobs, ring.side), "hipEventRecord");
-        ring.side_pending = true;
-        if (split_env == 1 || split_env == 3) launch_tail_gate(ring.flag, ring.seq, 300u, s);   // (2, 4: two streams without the gate)
-        hipLaunchKernelGGL(k_video_batch<3>, dim3((gxc + 7u) & ~7u, (uint32_t)nc), dim3(256), 0, s, dd, rc);
-        hip_check(hipEventRecord(ring.ev_chain, s), "hipEventRecord");
-        ring.chain_recorded = true;
-        hip_check(hipEventRecord(sl->done, s), "hipEventRecord");
-        sl->used = true;
-        return;
-    }
     if (any_alpha) {
         if (mm == 3) hipLaunchKernelGGL((k_video_batch<3, true>), grid, dim3(256), lds, s, dd, rows);
         else if (mm == 2) hipLaunchKernelGGL((k_video_batch<2, true>), grid, dim3(256), lds, s, dd, rows);
@@ -1421,7 +1374,6 @@ void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* 
     else if (mm == 1) hipLaunchKernelGGL(k_video_batch<1>, grid, dim3(256), lds, s, dd, rows);
     else hipLaunchKernelGGL(k_video_batch<0>, grid, dim3(256), lds, s, dd, rows);
     hip_check(hipEventRecord(sl->done, s), "hipEventRecord");
-    if (ring.ev_chain) { hip_check(hipEventRecord(ring.ev_chain, s), "hipEventRecord"); ring.chain_recorded = true; }   // (MX_VIDEO_SPLIT: later side-stream jobs are ordered behind this launch too)
     sl->used = true;
 }
 // Downscaling: the kernel widens with the scale factor (hn / vn taps, DESIGN.md "Scaler").  Two plain passes through

@@ -12,8 +12,6 @@
 // Plain C++ (fma, rint): compiled by hipcc for the device and by g++ for the CPU check of the slow path (tests/helpers/sin_f32_check.cpp).
 #pragma once
 #include <cmath>
-#include <cstdint>
-#include <cstring>
 
 #if defined(__HIPCC__)
 #define MX_SIN_HD __host__ __device__

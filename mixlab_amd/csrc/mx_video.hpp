@@ -126,7 +126,7 @@ struct VbRow {
     uint32_t variant, s_rows;         // jobs: tile body variant and window rows
     uint32_t prio;                    // s_setprio per tile kind: bits 0..1 chain rows, bits 2..3 job rows (launch_video_batch)
 };
-struct VbRows { VbRow r[MX_VB_MAX_CHAINS + MX_VB_MAX_JOBS]; uint32_t* started; uint32_t started_seq, _pad; };   // started: the launch's last workgroup stores started_seq there when it is placed (MX_VIDEO_SPLIT: opens the gate in front of the chain launch)
+struct VbRows { VbRow r[MX_VB_MAX_CHAINS + MX_VB_MAX_JOBS]; };
 void launch_video_batch(const ScaleArgs* jobs, int n_jobs, const ChainRgbaArgs* chains, int n_chains, hipStream_t s);
 void video_stream_retired(hipStream_t s);   // the stream is going away: free what launch_video_batch keeps for it
 // K: how many ticks' RGBA chains (and the scale jobs of the K ticks after them) share one launch inside a batched run (MX_VIDEO_BATCH, default 16, 1..16)
