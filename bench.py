@@ -9,7 +9,7 @@ whose per-rank chunk length equals the one-GPU job's (T x N ticks per step), the
 
 stdout carries ONE compact JSON line (benchlegs/line.py: the contract's keys, `roofline` of the dominant launch group -- its own bytes over its own
 hipEvent duration inside the timed region --, `cpu_baseline` = the CPU oracle on a bounded sample, one number per secondary leg); everything the
-legs measured is written to bench_full.json beside this file and echoed to stderr.  The legs: benchlegs/*.py.
+legs measured is written to bench_full.json beside this file (stderr only says where).  The legs: benchlegs/*.py.
 """
 from __future__ import annotations
 
@@ -288,7 +288,7 @@ def main(argv=None):
             full_ref = os.path.relpath(args.full_out, ROOT) if str(args.full_out).startswith(str(ROOT)) else str(args.full_out)
         except OSError as e:
             full_ref = f"(not written: {e})"
-        print(full_text, file=sys.stderr)
+        print(f"[bench.py] everything the legs measured: {full_ref} ({len(full_text)} bytes)", file=sys.stderr)   # (a pointer, not the record: a reader that keeps a tail of the merged streams must still find the line)
         text = bench_line.dumps_checked(bench_line.compact(out, full_ref))
         # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe): drain it first so the JSON line is the LAST thing on stdout
         import ctypes

@@ -1,5 +1,5 @@
 """The ONE line of stdout: the contract's keys, `roofline` and `cpu_baseline`, and one number per secondary leg -- small enough for any reader's buffer
-(asserted: <= 8 KiB, target <= 4 KiB).  Everything the legs measured goes to bench_full.json beside bench.py (and to stderr)."""
+(asserted: <= 8 KiB, target <= 4 KiB).  Everything the legs measured goes to bench_full.json beside bench.py."""
 from __future__ import annotations
 
 import json
