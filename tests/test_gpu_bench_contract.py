@@ -24,6 +24,7 @@ def _run(cmd, tmp_path, timeout=900):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert res.stdout.endswith("\n") and res.stdout.count("\n") == 1, "stdout carries ONE line and nothing else"
     assert len(res.stdout.encode()) <= 8192, f"the line is {len(res.stdout.encode())} bytes"
+    assert len(res.stderr.encode()) <= 8192, f"stderr carries {len(res.stderr.encode())} bytes: a reader that keeps a tail of the merged streams must still find the line\n" + res.stderr[-1500:]
     return _strict(res.stdout), _strict(full.read_text())
 
 
