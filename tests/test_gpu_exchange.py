@@ -80,6 +80,31 @@ for sr, T, n, fl in ((48000, 8, 6, 0), (44100, 3, 5, 0), (48000, 16, 6, abi.FLAG
         ex.close()
         print("ok", sr, mode, "overlap" if fl else "", flush=True)
 
+# The AUTOMATIC second-stream mode (64 strips, 16 ticks per run) under an RCCL exchange, ended mid-way by a host that takes a raw pointer to the bus: a held submit is
+# released by the sync inside, the later submits pack on the graph's stream, every step's bus stays the local Mixer's (round 6: Graph::end_auto_tail)
+ws, mix = strips(64)
+T = 16
+g = ws.build(max_ticks_per_run=T, device=0)
+assert g.tail_stream() is not None
+ref = ws.build(max_ticks_per_run=T, flags=abi.FLAG_NO_FUSE)
+ex = BusExchange(g, mix, T, 0, 1, mode="allgather", nccl_id=unique_id())
+want = []
+for i in range(5):
+    ref.run_ticks(i * T, T)
+    want.append((ref.read_output(mix, 0, T, True), ref.read_output(mix, 1, T, True)))
+for i in range(5):
+    g.run_ticks(i * T, T); ex.submit(i)
+    if i == 2:
+        g.output_device_ptr(mix, 0)                      # step 2's submit is being held for the next run: this releases it and ends the mode
+        assert g.tail_stream() is None
+    if i >= 1:
+        m, c = ex.result(i - 1)
+        assert np.array_equal(bits(m), bits(want[i - 1][0])) and np.array_equal(bits(c), bits(want[i - 1][1])), f"auto mode ended mid-way: step {{i - 1}}"
+m, c = ex.result(4)
+assert np.array_equal(bits(m), bits(want[4][0])) and np.array_equal(bits(c), bits(want[4][1]))
+ex.close()
+print("ok auto-mode-ended-under-an-exchange", flush=True)
+
 ws, mix = strips(2)
 g = ws.build(max_ticks_per_run=4, device=0)
 try:
@@ -100,7 +125,7 @@ def test_single_rank_rccl_exchange_through_the_c_abi_returns_the_local_bus_over_
             assert f"ok {sr} {mode}" in res.stdout, res.stdout[-2000:]
     for mode in ("allgather", "slices", "allreduce"):
         assert f"ok 48000 {mode} overlap" in res.stdout, res.stdout[-2000:]
-    assert "ok bogus-mode" in res.stdout and "ok lazy-rccl" in res.stdout
+    assert "ok bogus-mode" in res.stdout and "ok lazy-rccl" in res.stdout and "ok auto-mode-ended-under-an-exchange" in res.stdout, res.stdout[-2000:]
 
 
 def test_a_refused_loopback_submit_leaves_the_group_usable():
