@@ -93,6 +93,7 @@ def test_bench_exchange_path_checks_its_own_parity_single_rank_rccl(mode, tmp_pa
     st = full["other_policy"]
     assert st["ticks_per_step"] == 64 and st["parity"]["verdict"] == "bit-exact" and st["value"] > 0
     assert line["legs"]["exchange_parity"] == "bit-exact" and line["legs"]["other_ticks_policy_ticks"] == 64
+    assert line["headline_parity"]["verdict"] == "bit-exact" and line["headline_parity"]["buses"] == "bit-exact"      # (replayed up to the last submission the graph ran: the 3 profiled extra steps of the N > 1 path included)
 
 
 def test_two_rank_rccl_job_is_bit_exact_when_two_gpus_are_visible(tmp_path):
@@ -112,9 +113,10 @@ def test_two_rank_rccl_job_is_bit_exact_when_two_gpus_are_visible(tmp_path):
         assert pc["verdict"] == "bit-exact" and pc["all_ranks"] == "bit-exact", pc
         assert line["config"]["ticks_per_step"] == 128 and "T x N" in line["config"]["ticks_policy"]
         assert full["other_policy"]["ticks_per_step"] == 64 and full["other_policy"]["parity"]["verdict"] == "bit-exact"
+        assert line["headline_parity"]["verdict"] == "bit-exact"
 
 
-@pytest.mark.parametrize("world,mode,vshard", [(2, "allgather", "replicas"), (4, "slices", "bands")])
+@pytest.mark.parametrize("world,mode,vshard", [(2, "allgather", "replicas"), (4, "slices", "bands"), (8, "auto", "replicas")])
 def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(world, mode, vshard, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` with N REAL ranks on a one-GPU box: every rank on GPU 0 (MX_BENCH_SHARE_GPU), torch.distributed on
     gloo (barriers, the max of the clock, the plain all_gather of the parity check), the library's exchange on the RCCL test double (MX_RCCL_LIB, tests/helpers/fake_rccl.c).
@@ -139,11 +141,12 @@ def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(w
     assert line["config"]["ticks_per_step"] == 64 * world and "T x N" in line["config"]["ticks_policy"]
     assert line["value"] == pytest.approx(64 * 64 * world * 1000.0 / line["ms_per_step"], rel=1e-6)
     ex = rec["exchange"]
-    assert ex["mode"] == mode and ex["rccl_ranks"] == world
+    assert ex["mode"] == (mode if mode != "auto" else "slices") and ex["rccl_ranks"] == world
     assert ex["parity_check"]["verdict"] == "bit-exact" and ex["parity_check"]["all_ranks"] == "bit-exact", ex
     assert ex["parity_check"]["samples_compared"] == 2 * 64 * world * 1600
     op = rec["other_policy"]
-    assert op["ticks_per_step"] == 64 and op["parity"]["verdict"] == "bit-exact" and op["exchange_mode"] == mode
+    assert op["ticks_per_step"] == 64 and op["parity"]["verdict"] == "bit-exact" and op["exchange_mode"] == ex["mode"]
     assert rec["roofline"]["kernel_timing"].startswith("hipEvents on 3 extra steps")
+    assert line["headline_parity"]["verdict"] == "bit-exact" and line["headline_parity"]["buses"] == "bit-exact", rec["headline_parity"]
     v = rec["video"]
     assert v["value"] > 0 and v["scaling"] == ("weak" if vshard == "replicas" else "strong") and v["frames"] == (64 * world if vshard == "replicas" else 64)
