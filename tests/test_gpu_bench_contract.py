@@ -116,27 +116,31 @@ def test_two_rank_rccl_job_is_bit_exact_when_two_gpus_are_visible(tmp_path):
         assert line["headline_parity"]["verdict"] == "bit-exact"
 
 
-@pytest.mark.parametrize("world,mode,vshard", [(2, "allgather", "replicas"), (4, "slices", "bands"), (8, "auto", "replicas")])
-def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(world, mode, vshard, tmp_path):
-    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` with N REAL ranks on a one-GPU box: every rank on GPU 0 (MX_BENCH_SHARE_GPU), torch.distributed on
-    gloo (barriers, the max of the clock, the plain all_gather of the parity check), the library's exchange on the RCCL test double (MX_RCCL_LIB, tests/helpers/fake_rccl.c).
-    Times mean nothing here; what is checked is the N > 1 code of bench.py and of mx_exchange.cpp as the driver will run it: the T x N tick policy as the headline, the
-    fixed-T policy beside it, both exchanges bit-exact on every rank against the host sum in rank order."""
+def _multi_rank_on_one_gpu(world, extra, tmp_path, small=None):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` with N REAL ranks on a one-GPU box: every rank on GPU 0 (MX_BENCH_SHARE_GPU), torch.distributed
+    on gloo (barriers, the max of the clock, the plain all_gather of the parity check), the library's exchange on the RCCL test double (MX_RCCL_LIB, tests/helpers/fake_rccl.c)."""
+    import os
     so = tmp_path / "libfake_rccl.so"
     subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", str(so), str(ROOT / "tests" / "helpers" / "fake_rccl.c"),
                     "-L/opt/rocm/lib", "-lamdhip64", "-lrt"], check=True)
-    import os
     full = tmp_path / "full.json"
     env = dict(os.environ, MX_BENCH_SHARE_GPU="1", MX_BENCH_DIST_BACKEND="gloo", MX_RCCL_LIB=str(so))
-    small = list(SMALL)
-    small[small.index("--video-frames") + 1] = "64"        # the video leg runs here too: replicas per rank, or ONE stream in row bands
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29581 + world),
-           str(ROOT / "bench.py"), "--gpus", str(world), "--exchange", mode, *small, "--video-shard", vshard, "--full-out", str(full)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29581 + world + 16 * len(extra)),
+           str(ROOT / "bench.py"), "--gpus", str(world), *(small or SMALL), *extra, "--full-out", str(full)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) <= 8192
-    line, rec = _strict(lines[0]), _strict(full.read_text())
+    return _strict(lines[0]), _strict(full.read_text())
+
+
+@pytest.mark.parametrize("world,mode,vshard", [(2, "allgather", "replicas"), (4, "slices", "bands"), (8, "auto", "replicas")])
+def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(world, mode, vshard, tmp_path):
+    """Times mean nothing here; what is checked is the N > 1 code of bench.py and of mx_exchange.cpp as the driver will run it: the T x N tick policy as the headline, the
+    fixed-T policy beside it, both exchanges bit-exact on every rank against the host sum in rank order, the oracle replay of the last submission, the video leg."""
+    small = list(SMALL)
+    small[small.index("--video-frames") + 1] = "64"        # the video leg runs here too: replicas per rank, or ONE stream in row bands
+    line, rec = _multi_rank_on_one_gpu(world, ["--exchange", mode, "--video-shard", vshard], tmp_path, small)
     assert line["n_gpus"] == world and line["scaling"] == "strong" and line["cpu_baseline"] is None
     assert line["config"]["ticks_per_step"] == 64 * world and "T x N" in line["config"]["ticks_policy"]
     assert line["value"] == pytest.approx(64 * 64 * world * 1000.0 / line["ms_per_step"], rel=1e-6)
@@ -150,3 +154,20 @@ def test_the_drivers_multi_rank_launch_line_on_one_gpu_through_the_rccl_double(w
     assert line["headline_parity"]["verdict"] == "bit-exact" and line["headline_parity"]["buses"] == "bit-exact", rec["headline_parity"]
     v = rec["video"]
     assert v["value"] > 0 and v["scaling"] == ("weak" if vshard == "replicas" else "strong") and v["frames"] == (64 * world if vshard == "replicas" else 64)
+
+
+@pytest.mark.parametrize("world,extra", [(2, ["--exchange", "allreduce"]), (2, ["--fixed-ticks"]), (4, ["--fp-contract"]), (3, ["--strips", "96"]), (2, ["--hold-gates"])],
+                         ids=["allreduce", "fixed-ticks", "fp-contract", "three-ranks", "hold-gates"])
+def test_flags_of_the_multi_rank_path_that_no_other_test_drives(world, extra, tmp_path):
+    """--exchange allreduce (the non-parity collective: its distance from the ordered sum is measured against a second, ordered exchange made on the fly), --fixed-ticks (the
+    policies swap places), the contracted order, a rank count that is not a power of two, held gates."""
+    line, rec = _multi_rank_on_one_gpu(world, extra, tmp_path)
+    assert line["n_gpus"] == world and line["headline_parity"]["verdict"] == "bit-exact" and line["headline_parity"]["buses"] == "bit-exact"
+    ex = rec["exchange"]
+    if "allreduce" in extra:
+        assert ex["mode"] == "allreduce" and "parity_check" not in ex and ex["max_ulp_vs_ordered_sum"] == 0     # (the double's all-reduce IS the rank-ordered sum; real RCCL's is not)
+        assert rec["other_policy"]["parity"] is None
+    else:
+        assert ex["parity_check"]["all_ranks"] == "bit-exact" and rec["other_policy"]["parity"]["verdict"] == "bit-exact"
+    fixed = "--fixed-ticks" in extra
+    assert line["config"]["ticks_per_step"] == (64 if fixed else 64 * world) and rec["other_policy"]["ticks_per_step"] == (64 * world if fixed else 64)
