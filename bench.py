@@ -291,7 +291,7 @@ def main(argv=None):
         except OSError as e:
             full_ref = f"(not written: {e})"
         print(f"[bench.py] everything the legs measured: {full_ref} ({len(full_text)} bytes)", file=sys.stderr)   # (a pointer, not the record: a reader that keeps a tail of the merged streams must still find the line)
-        text = bench_line.dumps_checked(bench_line.compact(out, full_ref))
+        text = bench_line.dumps_within_cap(bench_line.compact(out, full_ref))
         # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe): drain it first so the JSON line is the LAST thing on stdout
         import ctypes
         try:

@@ -64,3 +64,17 @@ def dumps_checked(line):
     if "\n" in s or len(s) > LINE_HARD_CAP:
         raise AssertionError(f"bench line is {len(s)} bytes (cap {LINE_HARD_CAP}): move detail to bench_full.json")
     return s
+
+
+def dumps_within_cap(line):
+    """dumps_checked, but a run never ends without its line: should the compact line ever outgrow the cap, the optional parts go (the legs' numbers, then the free-text
+    config entries) before the contract's keys do -- they are all in bench_full.json."""
+    try:
+        return dumps_checked(line)
+    except AssertionError:
+        slim = dict(line, legs={"dropped": "line over the cap: see `full`"})
+        try:
+            return dumps_checked(slim)
+        except AssertionError:
+            slim["config"] = {"workload": str(line["config"].get("workload", ""))[:200]}
+            return dumps_checked(slim)

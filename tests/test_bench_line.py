@@ -43,6 +43,9 @@ def test_a_nan_or_an_oversized_line_is_refused():
     c["config"]["workload"] = "x" * 9000
     with pytest.raises(AssertionError):
         line.dumps_checked(c)
+    text = line.dumps_within_cap(c)                           # what bench.py calls: a run never ends without its line -- the optional parts go first
+    got = json.loads(text)
+    assert len(text) <= line.LINE_HARD_CAP and all(k in got for k in line.CONTRACT + ("roofline", "cpu_baseline", "config")) and got["roofline"] == c["roofline"]
 
 
 def test_bench_py_stays_a_thin_assembler():
