@@ -54,6 +54,8 @@ def compact(full, full_path):
         "other_ticks_policy_value": _r(_get(full, "other_policy", "value"), 1), "other_ticks_policy_ticks": _get(full, "other_policy", "ticks_per_step"),
     }
     line["legs"] = {k: v for k, v in legs.items() if v is not None}
+    if full.get("leg_errors"):
+        line["leg_errors"] = sorted(full["leg_errors"])         # (names only: the messages are in the full record and on stderr)
     line["full"] = full_path
     return line
 

@@ -75,6 +75,18 @@ def test_default_command_line_with_every_leg_on_prints_one_compact_strict_line(t
     for leg in ("video", "fir_resample", "fp_contract", "realtime", "t_sweep", "group_buses", "rate_44100", "material", "scaling_model", "north_star_realtime", "held_gates"):
         assert full.get(leg), leg
     assert full["video"]["cpu_baseline"]["value"] > 0 and full["fir_resample"]["cpu_baseline"]["value"] > 0
+    assert "leg_errors" not in full and "leg_errors" not in line
+
+
+def test_a_failing_secondary_leg_does_not_cost_the_run_its_line(tmp_path, monkeypatch):
+    """A secondary leg that raises (injected here) is reported -- `leg_errors` in the line and the record, the traceback on stderr -- and the headline line still goes out."""
+    monkeypatch.setenv("MX_BENCH_FAIL_LEG", "fir_resample")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--strips", "64", "--ticks-per-step", "64", "--no-realtime", "--no-t-sweep",
+           "--no-north-star", "--no-held-leg", "--no-material-leg", "--no-scaling-probe", "--no-contract-leg", "--no-buses-leg", "--no-rate-leg", "--fir-ticks", "16", "--repeats", "0",
+           "--video-frames", "0", "--no-cpu-baseline"]
+    line, full = _run(cmd, tmp_path)
+    assert line["leg_errors"] == ["fir_resample"] and "injected" in full["leg_errors"]["fir_resample"] and full["fir_resample"] is None
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["headline_parity"]["verdict"] == "bit-exact"
 
 
 SMALL = ["--steps", "3", "--warmup", "1", "--strips", "64", "--ticks-per-step", "64", "--no-realtime", "--no-t-sweep", "--no-north-star", "--no-held-leg",
